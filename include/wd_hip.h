@@ -1,0 +1,214 @@
+/*
+ * include/wd_hip.h -- C ABI of the MI355X (gfx950) Wide&Deep train-step hot path.
+ *
+ * The reference (Lapis-Hong/wide_deep) has no FFI boundary of its own: the hot
+ * path is Python that selects TensorFlow ops.  Each entry point below replaces
+ * the TF op(s) that one reference call site selects; the citation is the
+ * reference file:line that wires that op in.
+ *
+ * Conventions
+ *   - plain C ABI, no torch / STL types; every pointer is a DEVICE pointer
+ *     unless its name ends in _host.
+ *   - the caller owns every buffer; nothing is allocated behind the caller's
+ *     back (workspace sizes come from the *_workspace_bytes queries).
+ *   - every launch goes to the hipStream_t passed as `stream` (void* here so
+ *     that the header needs no HIP include); calls are asynchronous.
+ *   - return value: WD_OK (0) or a negative WD_ERR_*; wd_last_error() gives a
+ *     thread-local message for the last failure.
+ *   - ids and CSR offsets are int32 on the device (SURVEY 8(d) byte contract).
+ *
+ * Device batch layout ("bag CSR", example-major): with S categorical slots
+ * and a batch of B examples, bag(b, s) = b*S + s; bag_offs[B*S + 1] are the
+ * CSR offsets into ids[nnz]; ids are slot-local row numbers in [0, num_buckets).
+ */
+#ifndef WD_HIP_H_
+#define WD_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WD_OK 0
+#define WD_ERR_INVALID (-1)
+#define WD_ERR_LAUNCH (-2)
+#define WD_ERR_WORKSPACE (-3)
+#define WD_ERR_UNSUPPORTED (-4)
+
+#define WD_MAX_CROSS_KEYS 8
+
+typedef void *wd_stream_t; /* hipStream_t */
+
+const char *wd_last_error(void);
+int wd_abi_version(void);
+
+/* Per-slot descriptor (device array of S entries, built once by the host). */
+typedef struct wd_slot {
+  int64_t emb_off;     /* element offset of row 0 of this slot's table in the flat embedding buffer; -1: none */
+  int64_t row_base;    /* first row of this slot in the fused categorical row space (wide table / sort keys) */
+  int32_t num_buckets; /* rows of this slot */
+  int32_t dim;         /* embedding dim D (0 if the slot has no embedding) */
+  int32_t out_col;     /* first column of this slot in the deep input matrix x (-1: not in deep input) */
+  int32_t kind;        /* WD_SLOT_* */
+  int32_t wide;        /* 1: slot contributes to the wide (linear) logit */
+  int32_t pad_;
+} wd_slot_t;
+
+#define WD_SLOT_NONE 0      /* wide-only categorical column (bucketized, cross with is_deep=0) */
+#define WD_SLOT_EMBEDDING 1 /* embedding_column(combiner='mean')   build_estimator.py:90-97,157 */
+#define WD_SLOT_INDICATOR 2 /* indicator_column (multi-hot counts) build_estimator.py:108,118 */
+
+/* ---- a4: categorical_column_with_hash_bucket -> string_to_hash_bucket_fast ------------------
+ * (python/lib/build_estimator.py:86-88).  Tokens are packed in `bytes`, token t is
+ * bytes[tok_offs[t] .. tok_offs[t+1]).  out_fp[t] = FarmHash Fingerprint64(token t). */
+int wd_fingerprint64(const uint8_t *bytes, const int32_t *tok_offs, int64_t ntok, uint64_t *out_fp,
+                     wd_stream_t stream);
+
+/* ids[t] = Fingerprint64(token t) % num_buckets of the token's slot.  Tokens are in bag order
+ * (example-major); token_bag_offs = bag CSR over tokens (NULL: exactly one token per bag, bag t = token t);
+ * the slot of bag g is g % S.  Fuses fingerprint + modulo for the pure hash-bucket configs. */
+int wd_hash_bucket(const uint8_t *bytes, const int32_t *tok_offs, int64_t ntok, const int32_t *token_bag_offs,
+                   int64_t nbags, const wd_slot_t *slots, int32_t S, int32_t *out_ids, wd_stream_t stream);
+
+/* Emit the ids of ONE slot from precomputed fingerprints of one feature's tokens:
+ * feature CSR feat_offs[B+1] into fp[]; writes ids[bag_offs[b*S+slot] + j] = fp % num_buckets. */
+int wd_emit_hash_slot(const uint64_t *fp, const int32_t *feat_offs, int64_t batch, uint64_t num_buckets,
+                      const int32_t *bag_offs, int32_t S, int32_t slot, int32_t *ids, wd_stream_t stream);
+
+/* Emit already-integer ids (identity / bucketized / host-looked-up vocab) of ONE slot. */
+int wd_emit_int_slot(const int32_t *vals, const int32_t *feat_offs, int64_t batch, const int32_t *bag_offs, int32_t S,
+                     int32_t slot, int32_t *ids, wd_stream_t stream);
+
+/* ---- a5: crossed_column -> SparseCross (hashed)  (python/lib/build_estimator.py:138-155) ----
+ * Key k of the cross: vals[k] (uint64: Fingerprint64 of a string token, or the int64 id of an
+ * identity / bucketized key) with CSR offs[k][batch+1].  Per example the cartesian product is
+ * enumerated with the LAST key varying fastest; h = hash_key; h = FingerprintCat64(h, v_k);
+ * id = h % num_buckets (0 buckets: % INT64_MAX).  Output goes to slot `slot` of the bag CSR;
+ * bag_offs must already give that bag prod_k(count_k) entries. */
+typedef struct wd_cross_keys {
+  const uint64_t *vals[WD_MAX_CROSS_KEYS];
+  const int32_t *offs[WD_MAX_CROSS_KEYS];
+  int32_t nkeys;
+} wd_cross_keys_t;
+
+int wd_cross_hash(const wd_cross_keys_t *keys_host, int64_t batch, uint64_t hash_key, uint64_t num_buckets,
+                  const int32_t *bag_offs, int32_t S, int32_t slot, int32_t *ids, wd_stream_t stream);
+
+/* ---- a8: tf.feature_column.input_layer (python/lib/dnn.py:83-90) ---------------------------
+ * Fused multi-slot embedding-bag gather: for every slot g in group_slots (all of one dim D):
+ *   x[b, out_col_g .. +D) = mean_{ids in bag(b,g)} emb[emb_off_g + id*D ..]   (empty bag -> 0). */
+int wd_embag_fwd(const float *emb, const wd_slot_t *slots, int32_t S, const int32_t *group_slots, int32_t ngroup,
+                 int32_t dim, const int32_t *ids, const int32_t *bag_offs, int64_t batch, float *x, int64_t ldx,
+                 wd_stream_t stream);
+
+/* indicator_column slots: x[b, out_col + id] = multiplicity of id in bag(b, slot). */
+int wd_indicator_fwd(const wd_slot_t *slots, int32_t S, const int32_t *group_slots, int32_t ngroup,
+                     const int32_t *ids, const int32_t *bag_offs, int64_t batch, float *x, int64_t ldx,
+                     wd_stream_t stream);
+
+/* numeric_column(normalizer_fn) (python/lib/build_estimator.py:61-68,121-136):
+ * x[b, out_col[j]] = f_j(dense[b, j]); kind 0: identity, 1: (v-p0)/(p1-p0) min_max, 2: (v-p0)/p1 standard, 3: log. */
+typedef struct wd_dense_col {
+  float p0, p1;
+  int32_t kind;
+  int32_t out_col;
+} wd_dense_col_t;
+int wd_dense_fwd(const float *dense, int64_t ld_dense, const wd_dense_col_t *cols, int32_t ncols, int64_t batch,
+                 float *x, int64_t ldx, wd_stream_t stream);
+
+/* ---- a7: tf.feature_column.linear_model(sparse_combiner='sum') (python/lib/linear.py:29-36) --
+ * wide state is array-of-structs: wide[row*4 + {0,1,2}] = {w, z (Ftrl_1 "linear"), n (Ftrl "accum")}.
+ * out[b] = bias[0] + sum over wide slots s, ids in bag(b,s) of w[row_base_s + id]. */
+int wd_wide_fwd(const float *wide, const float *bias, const wd_slot_t *slots, int32_t S, const int32_t *ids,
+                const int32_t *bag_offs, int64_t batch, float *out, wd_stream_t stream);
+
+/* ---- a11: head, sigmoid CE, SUM reduction, weight column (python/lib/joint.py:216-222,402-406) --
+ * logit = dnn_logit (may be NULL) + wide_logit (may be NULL); loss_sum[0] += sum_b w_b*CE; dlogit[b] = w_b*(p-y);
+ * prob[b] = sigmoid(logit).  weights may be NULL.  loss_sum must be zeroed by the caller. */
+int wd_bce_sum_fwd_bwd(const float *dnn_logit, const float *wide_logit, const float *labels, const float *weights,
+                       int64_t batch, float *logit, float *prob, float *dlogit, float *loss_sum, wd_stream_t stream);
+
+/* ---- a12: sparse optimizer apply (python/lib/joint.py:224-262, utils/model_util.py:84-90) ----
+ * Step 1: keys[j] = row_base[slot(j)] + ids[j], vals[j] = bag(j); stable radix sort by key.
+ * Workspace query then sort. */
+size_t wd_sort_workspace_bytes(int64_t nnz, int32_t key_bits);
+int wd_build_sort_keys(const wd_slot_t *slots, int32_t S, const int32_t *ids, const int32_t *bag_offs, int64_t nbags,
+                       int64_t nnz, uint32_t *keys, int32_t *vals, wd_stream_t stream);
+int wd_sort_pairs(const uint32_t *keys_in, const int32_t *vals_in, uint32_t *keys_out, int32_t *vals_out, int64_t nnz,
+                  int32_t key_bits, void *workspace, size_t workspace_bytes, wd_stream_t stream);
+
+/* Step 2 (embedding rows, one launch per dim group): for every unique key whose slot has dim D,
+ * g = sum over its occurrences of dx[b, out_col..+D) / len(bag)   (duplicates summed first, TF IndexedSlices),
+ * then tf.train.AdagradOptimizer: acc += g*g; row -= lr*g/sqrt(acc). */
+int wd_embag_bwd_adagrad(float *emb, float *emb_accum, const wd_slot_t *slots, int32_t S, int32_t dim,
+                         const uint32_t *keys_sorted, const int32_t *vals_sorted, int64_t nnz,
+                         const int32_t *bag_offs, const float *dx, int64_t ldx, float lr, wd_stream_t stream);
+
+/* Step 3 (wide rows): g = sum of dlogit[b] over the occurrences of the row, then tf.train.FtrlOptimizer
+ * (lr_power -0.5): n' = n+g^2; z += g-(sqrt(n')-sqrt(n))/lr*w; w = |z|>l1 ? (sign(z)*l1-z)/(sqrt(n')/lr+2*l2) : 0. */
+int wd_wide_bwd_ftrl(float *wide, const wd_slot_t *slots, int32_t S, const uint32_t *keys_sorted,
+                     const int32_t *vals_sorted, int64_t nnz, const float *dlogit, float lr, float l1, float l2,
+                     wd_stream_t stream);
+
+/* bias_weights of the linear model: g = sum_b dlogit[b]; dense FTRL on {w,z,n} = bias[0..2]. */
+int wd_bias_ftrl(float *bias_wzn, const float *dlogit, int64_t batch, float lr, float l1, float l2,
+                 wd_stream_t stream);
+
+/* ---- a9: dense tower (python/lib/dnn.py:92-234) ---------------------------------------------
+ * fp32 MFMA GEMMs, row-major.  C[M,N] = epi(A op B):
+ *   NN: C = A[M,K] B[K,N]        (forward; epilogue: + bias[N], activation)
+ *   NT: C (+)= A[M,K] B[N,K]^T   (input gradient)
+ *   TN: Cpart[split][M,N] = A[K,M]^T B[K,N] over K-slices (weight gradient; partials reduced by wd_mlp_finalize) */
+#define WD_ACT_NONE 0
+#define WD_ACT_RELU 1
+#define WD_ACT_SIGMOID 2
+#define WD_ACT_TANH 3
+#define WD_ACT_RELU6 4
+#define WD_ACT_LEAKY_RELU 5
+#define WD_ACT_ELU 6
+#define WD_ACT_SELU 7
+#define WD_ACT_SOFTPLUS 8
+#define WD_ACT_SOFTSIGN 9
+
+int wd_gemm_nn_bias_act(const float *A, int64_t lda, const float *B, int64_t ldb, const float *bias, int32_t act,
+                        float *C, int64_t ldc, int64_t M, int64_t N, int64_t K, wd_stream_t stream);
+int wd_gemm_nt(const float *A, int64_t lda, const float *B, int64_t ldb, float *C, int64_t ldc, int64_t M, int64_t N,
+               int64_t K, int32_t accumulate, wd_stream_t stream);
+/* Cpart[split][(M + append_ones)][N] = A[Kslice, M]^T B[Kslice, N]; with append_ones the extra output row M is
+ * ones^T B = the column sums of B (the bias gradient).  The caller provides nsplit*(M+append_ones)*N floats. */
+int wd_gemm_tn_splitk(const float *A, int64_t lda, const float *B, int64_t ldb, float *Cpart, int64_t M, int64_t N,
+                      int64_t K, int32_t nsplit, int32_t append_ones, wd_stream_t stream);
+
+/* Dense parameters live in ONE flat fp32 buffer P (kernels [K,N] row-major, biases, BN gamma/beta); the
+ * gradient buffer Gflat has the same layout.  gamma_idx[k] / beta_idx[k] give, for input column k of a
+ * layer, the index in P of the BN gamma / beta of the unit that produced that column (-1: raw input column).
+ *
+ * BN is the inference-mode affine of SURVEY App. C.1 (python/lib/dnn.py:113-114), folded into the consumer:
+ *   s[k] = gamma*inv (or 1), t[k] = beta (or 0), inv = 1/sqrt(1+eps);
+ *   Wf[k,n] = s[k]*W[k,n];  bf[n] = b[n] + sum_k t[k]*W[k,n]. */
+int wd_fold_affine(const float *P, int64_t w_off, int64_t b_off, const int32_t *gamma_idx, const int32_t *beta_idx,
+                   float inv, float *Wf, float *bf, float *s, float *t, int64_t K, int64_t N, wd_stream_t stream);
+
+/* dz = da * act'(a), the derivative expressed through the activation output a. */
+int wd_act_bwd(const float *da, int64_t ldda, const float *a, int64_t lda, int32_t act, float *dz, int64_t lddz,
+               int64_t M, int64_t N, wd_stream_t stream);
+
+/* Reduce the split-K partials G = sum_split Gpart ([K+1, N], row K = db) and un-fold the affine:
+ *   Gflat[w_off + k*N + n] = s[k]*G[k,n] + t[k]*db[n];   Gflat[b_off + n] = db[n];
+ *   Gflat[gamma_idx[k]] += inv * sum_n W[k,n]*G[k,n];     Gflat[beta_idx[k]] += sum_n W[k,n]*db[n]. */
+int wd_mlp_finalize(const float *Gpart, int32_t nsplit, const float *P, int64_t w_off, int64_t b_off, const float *s,
+                    const float *t, const int32_t *gamma_idx, const int32_t *beta_idx, float inv, float *Gflat,
+                    int64_t K, int64_t N, wd_stream_t stream);
+
+/* tf.train.AdagradOptimizer dense apply over a flat parameter buffer. */
+int wd_adagrad_dense(float *w, float *accum, const float *g, int64_t n, float lr, wd_stream_t stream);
+
+/* misc plumbing */
+int wd_fill_f32(float *p, float v, int64_t n, wd_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WD_HIP_H_ */

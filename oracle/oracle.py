@@ -1,0 +1,401 @@
+"""oracle/oracle.py -- TEST INFRASTRUCTURE ONLY (the checker, never the product).
+
+CPU restatement of the reference's train-step hot path.  The integer / sparse
+pieces call the plain-C restatement in ``wd_oracle.c``; the dense tower is a
+plain fp32 PyTorch-CPU autograd graph (so the hand-written HIP backward is
+checked against an independently derived gradient).
+
+What it follows in the reference (Lapis-Hong/wide_deep):
+  * column wiring             python/lib/build_estimator.py:49-169
+  * wide logits               python/lib/linear.py:20-36
+  * deep input layer + tower  python/lib/dnn.py:43-275
+  * combine + head + train op python/lib/joint.py:81-269
+  * optimizers/activations    python/lib/utils/model_util.py:28-105
+and the TensorFlow-1.x semantics those calls select,
+including the quirks of Appendix C (BN always inference-mode affine, batch-SUM
+loss, no lr decay, regularizers never added to the loss).
+
+Only ``tests/``, ``bench.py``'s ``cpu_baseline`` leg and
+``__graft_entry__.smoke()`` may import this module.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "_build", "libwd_oracle.so")
+_lib = None
+
+BN_EPS = 1e-3  # tf.layers.batch_normalization default epsilon
+
+
+def build(force=False):
+    if force or not os.path.exists(_LIB_PATH):
+        subprocess.check_call(["sh", os.path.join(_HERE, "build.sh")])
+    return _LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = ctypes.CDLL(_LIB_PATH)
+        L.wdo_fingerprint64.restype = ctypes.c_uint64
+        L.wdo_fingerprint64.argtypes = [ctypes.c_char_p, ctypes.c_size_t]
+        L.wdo_fingerprint_cat64.restype = ctypes.c_uint64
+        L.wdo_fingerprint_cat64.argtypes = [ctypes.c_uint64, ctypes.c_uint64]
+        L.wdo_embag_row_grads.restype = ctypes.c_int64
+        L.wdo_bce_sum.restype = ctypes.c_double
+        L.wdo_num_threads.restype = ctypes.c_int
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    if a is None:
+        return None
+    if isinstance(a, torch.Tensor):
+        return ctypes.c_void_p(a.data_ptr())
+    return ctypes.c_void_p(a.ctypes.data)
+
+
+# ---------------------------------------------------------------------------
+# integer path
+# ---------------------------------------------------------------------------
+def fingerprint64(s: bytes) -> int:
+    return int(lib().wdo_fingerprint64(s, len(s)))
+
+
+def fingerprint_cat64(a: int, b: int) -> int:
+    return int(lib().wdo_fingerprint_cat64(ctypes.c_uint64(a), ctypes.c_uint64(b)))
+
+
+def pack_tokens(tokens):
+    """list[bytes|str] -> (uint8 bytes, int64 offs[n+1])"""
+    bs = [t.encode() if isinstance(t, str) else t for t in tokens]
+    offs = np.zeros(len(bs) + 1, dtype=np.int64)
+    if bs:
+        offs[1:] = np.cumsum([len(b) for b in bs])
+    data = np.frombuffer(b"".join(bs), dtype=np.uint8).copy() if bs else np.zeros(0, np.uint8)
+    return data, offs
+
+
+def fingerprint64_batch(data, offs):
+    n = len(offs) - 1
+    out = np.zeros(n, dtype=np.uint64)
+    data = np.ascontiguousarray(data)
+    if data.size == 0:
+        data = np.zeros(1, np.uint8)
+    lib().wdo_fingerprint64_batch(_p(data), _p(np.ascontiguousarray(offs, dtype=np.int64)), ctypes.c_int64(n), _p(out))
+    return out
+
+
+def hash_bucket(tokens, num_buckets):
+    """string_to_hash_bucket_fast over a list of tokens -> int64 ids."""
+    data, offs = pack_tokens(tokens)
+    fp = fingerprint64_batch(data, offs)
+    return (fp % np.uint64(num_buckets)).astype(np.int64)
+
+
+def cross_hash(cols, num_buckets, hash_key=0xDECAFCAFFE):
+    """SparseCross (hashed).  cols: list of (vals uint64[nnz_k], offs int32[B+1]).
+    String keys pass Fingerprint64(token); int keys pass the id itself.
+    Returns (ids int64, offs int32[B+1]); last key varies fastest."""
+    nk = len(cols)
+    assert 1 <= nk <= 16
+    B = len(cols[0][1]) - 1
+    vals = [np.ascontiguousarray(np.asarray(c[0]).astype(np.uint64)) for c in cols]
+    vals = [v if v.size else np.zeros(1, np.uint64) for v in vals]
+    offs = [np.ascontiguousarray(c[1], dtype=np.int32) for c in cols]
+    VP = (ctypes.c_void_p * nk)(*[v.ctypes.data for v in vals])
+    OP = (ctypes.c_void_p * nk)(*[o.ctypes.data for o in offs])
+    out_offs = np.zeros(B + 1, dtype=np.int32)
+    lib().wdo_cross_offsets(OP, ctypes.c_int(nk), ctypes.c_int64(B), _p(out_offs))
+    out = np.zeros(max(int(out_offs[-1]), 1), dtype=np.int64)
+    lib().wdo_cross_hash(VP, OP, ctypes.c_int(nk), ctypes.c_int64(B), ctypes.c_uint64(hash_key),
+                         ctypes.c_uint64(int(num_buckets)), _p(out_offs), _p(out))
+    return out[: int(out_offs[-1])], out_offs
+
+
+def bucketize(x, boundaries):
+    """tf bucketized_column: number of boundaries <= x."""
+    return np.searchsorted(np.asarray(boundaries, dtype=np.float32), np.asarray(x, dtype=np.float32), side="right").astype(np.int64)
+
+
+# ---------------------------------------------------------------------------
+# sparse float pieces (one column at a time, like TF)
+# ---------------------------------------------------------------------------
+def embag_fwd(table, ids, offs, mean):
+    V, D = table.shape
+    B = len(offs) - 1
+    out = torch.zeros(B, D, dtype=torch.float32)
+    ids = np.ascontiguousarray(ids, dtype=np.int64)
+    if ids.size == 0:
+        ids = np.zeros(1, np.int64)
+    lib().wdo_embag_fwd(_p(table), ctypes.c_int64(D), _p(ids), _p(np.ascontiguousarray(offs, dtype=np.int32)),
+                        ctypes.c_int64(B), ctypes.c_int(1 if mean else 0), _p(out), ctypes.c_int64(D))
+    return out
+
+
+def embag_row_grads(D, ids, offs, grad_out, mean):
+    B = len(offs) - 1
+    nnz = int(offs[-1])
+    ids = np.ascontiguousarray(ids, dtype=np.int64)
+    if ids.size == 0:
+        ids = np.zeros(1, np.int64)
+    uniq = np.zeros(max(nnz, 1), dtype=np.int64)
+    rg = torch.zeros(max(nnz, 1), D, dtype=torch.float32)
+    g = grad_out.contiguous()
+    n = lib().wdo_embag_row_grads(ctypes.c_int64(D), _p(ids), _p(np.ascontiguousarray(offs, dtype=np.int32)),
+                                  ctypes.c_int64(B), ctypes.c_int(1 if mean else 0), _p(g), ctypes.c_int64(D),
+                                  _p(uniq), _p(rg))
+    return uniq[:n], rg[:n]
+
+
+def adagrad_rows(table, accum, uniq, row_grad, lr):
+    D = table.shape[1]
+    lib().wdo_adagrad_rows(_p(table), _p(accum), ctypes.c_int64(D), _p(np.ascontiguousarray(uniq)),
+                           ctypes.c_int64(len(uniq)), _p(row_grad.contiguous()), ctypes.c_float(lr))
+
+
+def adagrad_dense(w, accum, g, lr):
+    assert w.is_contiguous() and accum.is_contiguous()
+    lib().wdo_adagrad_dense(_p(w), _p(accum), _p(g.contiguous()), ctypes.c_int64(w.numel()), ctypes.c_float(lr))
+
+
+def ftrl_rows(w, z, n, uniq, row_grad, lr, l1, l2):
+    D = w.shape[1] if w.dim() > 1 else 1
+    lib().wdo_ftrl_rows(_p(w), _p(z), _p(n), ctypes.c_int64(D), _p(np.ascontiguousarray(uniq)),
+                        ctypes.c_int64(len(uniq)), _p(row_grad.contiguous()), ctypes.c_float(lr), ctypes.c_float(l1),
+                        ctypes.c_float(l2))
+
+
+def ftrl_dense(w, z, n, g, lr, l1, l2):
+    lib().wdo_ftrl_dense(_p(w), _p(z), _p(n), _p(g.contiguous()), ctypes.c_int64(w.numel()), ctypes.c_float(lr),
+                         ctypes.c_float(l1), ctypes.c_float(l2))
+
+
+def bce_sum(logits, labels, weights=None):
+    n = logits.numel()
+    dl = torch.zeros(n, dtype=torch.float32)
+    pr = torch.zeros(n, dtype=torch.float32)
+    loss = lib().wdo_bce_sum(_p(logits.contiguous()), _p(labels.contiguous()),
+                             _p(weights.contiguous()) if weights is not None else None, ctypes.c_int64(n), _p(dl), _p(pr))
+    return float(loss), dl, pr
+
+
+# ---------------------------------------------------------------------------
+# activations (python/lib/utils/model_util.py:44-55)
+# ---------------------------------------------------------------------------
+ACTIVATIONS = {
+    "sigmoid": torch.sigmoid,
+    "tanh": torch.tanh,
+    "relu": torch.relu,
+    "relu6": torch.nn.functional.relu6,
+    "leaky_relu": lambda x: torch.nn.functional.leaky_relu(x, 0.2),  # tf.nn.leaky_relu default alpha=0.2
+    "elu": torch.nn.functional.elu,
+    "selu": torch.selu,
+    "softplus": torch.nn.functional.softplus,
+    "softsign": torch.nn.functional.softsign,
+}
+
+
+def tower_forward(x, tw, mode, act, batch_norm):
+    """python/lib/dnn.py:92-234 for one tower.  tw: dict with lists 'kernel','bias','gamma','beta' (hidden
+    layers) and 'logits_kernel','logits_bias'.  BN is the inference-mode affine of SURVEY App. C.1."""
+    f = ACTIVATIONS[act]
+    inv = 1.0 / float(np.sqrt(np.float32(1.0) + np.float32(BN_EPS)))
+    input_layer = x
+    net = x
+    coll = [x]
+    for l in range(len(tw["kernel"])):
+        h = f(net @ tw["kernel"][l] + tw["bias"][l])
+        if batch_norm:
+            h = h * (tw["gamma"][l] * inv) + tw["beta"][l]
+        if mode == "simple":
+            net = h
+        elif mode == "first_dense":
+            net = torch.cat([h, input_layer], dim=1)
+        elif mode == "last_dense":
+            coll.append(h)
+            net = h
+        elif mode == "dense":
+            coll.append(h)
+            net = torch.cat(coll, dim=1)
+        elif mode == "resnet":
+            net = torch.cat([h, coll[l]], dim=1)
+            coll.append(net)
+        else:
+            raise ValueError(mode)
+    if mode == "last_dense":
+        net = torch.cat(coll, dim=1)
+    return net @ tw["logits_kernel"] + tw["logits_bias"]
+
+
+class OracleWideDeep:
+    """Whole-model oracle.  Columns are described neutrally:
+
+    deep_cols: list of dicts {name, kind: 'embedding'|'indicator'|'numeric', key, num_buckets, dim}
+    wide_cols: list of dicts {name, key, num_buckets}
+    towers:    list of (hidden_units, mode)
+    state:     dict TF-variable-name -> torch.float32 CPU tensor (see wide_deep_amd/checkpoint naming)
+
+    batch: {'ids': {key: (ids int64, offs int32[B+1])}, 'dense': {key: float32[B]},
+            'labels': float32[B], 'weights': float32[B] or None}
+    """
+
+    def __init__(self, model_type, deep_cols, wide_cols, towers, state, act="relu", batch_norm=True,
+                 dnn_opt=("Adagrad", 0.05, 0.1), lin_opt=("Ftrl", 0.1, 0.5, 1.0, 0.1)):
+        self.model_type = model_type
+        # both tf.feature_column.input_layer and linear_model sort columns by name
+        self.deep_cols = sorted(deep_cols, key=lambda c: c["name"])
+        self.wide_cols = sorted(wide_cols, key=lambda c: c["name"])
+        self.towers = towers
+        self.state = state
+        self.act = act
+        self.batch_norm = batch_norm
+        self.dnn_opt = dnn_opt
+        self.lin_opt = lin_opt
+
+    # -- variable names ----------------------------------------------------
+    @staticmethod
+    def emb_name(col):
+        return "dnn/input_from_feature_columns/input_layer/%s/embedding_weights" % col["name"]
+
+    @staticmethod
+    def wide_name(col):
+        return "linear/linear_model/%s/weights" % col["name"]
+
+    def tower_params(self, t):
+        hidden, _ = self.towers[t]
+        p = "dnn/dnn_%d/" % (t + 1)
+        tw = {"kernel": [], "bias": [], "gamma": [], "beta": []}
+        for l in range(len(hidden)):
+            tw["kernel"].append(self.state[p + "hiddenlayer_%d/kernel" % l])
+            tw["bias"].append(self.state[p + "hiddenlayer_%d/bias" % l])
+            if self.batch_norm:
+                tw["gamma"].append(self.state[p + "hiddenlayer_%d/batch_normalization/gamma" % l])
+                tw["beta"].append(self.state[p + "hiddenlayer_%d/batch_normalization/beta" % l])
+        tw["logits_kernel"] = self.state[p + "logits/kernel"]
+        tw["logits_bias"] = self.state[p + "logits/bias"]
+        return tw
+
+    # -- forward -------------------------------------------------------------
+    def input_layer(self, batch):
+        B = len(batch["labels"]) if "labels" in batch else batch["batch_size"]
+        parts = []
+        for c in self.deep_cols:
+            if c["kind"] == "embedding":
+                ids, offs = batch["ids"][c["key"]]
+                parts.append(embag_fwd(self.state[self.emb_name(c)], ids, offs, mean=True))
+            elif c["kind"] == "indicator":
+                ids, offs = batch["ids"][c["key"]]
+                o = torch.zeros(B, c["num_buckets"], dtype=torch.float32)
+                for b in range(B):
+                    for j in range(offs[b], offs[b + 1]):
+                        if ids[j] >= 0:
+                            o[b, int(ids[j])] += 1.0
+                parts.append(o)
+            else:
+                parts.append(torch.as_tensor(np.asarray(batch["dense"][c["key"]], dtype=np.float32)).reshape(B, 1))
+        return torch.cat(parts, dim=1) if parts else torch.zeros(B, 0)
+
+    def wide_logits(self, batch):
+        B = len(batch["labels"]) if "labels" in batch else batch["batch_size"]
+        out = torch.zeros(B, dtype=torch.float32)
+        for c in self.wide_cols:
+            ids, offs = batch["ids"][c["key"]]
+            out += embag_fwd(self.state[self.wide_name(c)], ids, offs, mean=False)[:, 0]
+        return out + self.state["linear/linear_model/bias_weights"][0]
+
+    def forward(self, batch, need_grad=False):
+        B = len(batch["labels"]) if "labels" in batch else batch["batch_size"]
+        logits = torch.zeros(B, dtype=torch.float32)
+        cache = {}
+        if self.model_type in ("deep", "wide_deep"):
+            x = self.input_layer(batch)
+            x.requires_grad_(need_grad)
+            dnn = None
+            params = []
+            for t, (hidden, mode) in enumerate(self.towers):
+                tw = self.tower_params(t)
+                if need_grad:
+                    for k in ("kernel", "bias", "gamma", "beta"):
+                        for v in tw[k]:
+                            v.requires_grad_(True)
+                    tw["logits_kernel"].requires_grad_(True)
+                    tw["logits_bias"].requires_grad_(True)
+                lg = tower_forward(x, tw, mode, self.act, self.batch_norm)[:, 0]
+                dnn = lg if dnn is None else dnn + lg
+                params.append(tw)
+            cache.update(x=x, dnn=dnn, params=params)
+            logits = logits + dnn.detach()
+        if self.model_type in ("wide", "wide_deep"):
+            wl = self.wide_logits(batch)
+            cache["wide"] = wl
+            logits = logits + wl
+        return logits, cache
+
+    def predict(self, batch):
+        with torch.no_grad():
+            logits, _ = self.forward(batch, need_grad=False)
+        return logits, torch.sigmoid(logits)
+
+    # -- one train step (joint.py:224-262 with TF optimizer semantics) --------
+    def train_step(self, batch):
+        labels = torch.as_tensor(np.asarray(batch["labels"], dtype=np.float32))
+        weights = batch.get("weights")
+        weights = torch.as_tensor(np.asarray(weights, dtype=np.float32)) if weights is not None else None
+        logits, cache = self.forward(batch, need_grad=True)
+        loss, dlogit, _ = bce_sum(logits, labels, weights)
+
+        if "dnn" in cache:
+            cache["dnn"].backward(dlogit)
+            _, lr, _ = self.dnn_opt
+            assert self.dnn_opt[0] == "Adagrad"
+            dx = cache["x"].grad
+            # dense tower params
+            with torch.no_grad():
+                for t, tw in enumerate(cache["params"]):
+                    names = []
+                    p = "dnn/dnn_%d/" % (t + 1)
+                    for l in range(len(tw["kernel"])):
+                        names += [p + "hiddenlayer_%d/kernel" % l, p + "hiddenlayer_%d/bias" % l]
+                        if self.batch_norm:
+                            names += [p + "hiddenlayer_%d/batch_normalization/gamma" % l,
+                                      p + "hiddenlayer_%d/batch_normalization/beta" % l]
+                    names += [p + "logits/kernel", p + "logits/bias"]
+                    for nm in names:
+                        v = self.state[nm]
+                        g = v.grad
+                        v.requires_grad_(False)
+                        adagrad_dense(v, self.state[nm + "/Adagrad"], g, lr)
+                        v.grad = None
+            # embedding rows
+            col0 = 0
+            for c in self.deep_cols:
+                if c["kind"] == "embedding":
+                    D = c["dim"]
+                    ids, offs = batch["ids"][c["key"]]
+                    uniq, rg = embag_row_grads(D, ids, offs, dx[:, col0:col0 + D], mean=True)
+                    nm = self.emb_name(c)
+                    adagrad_rows(self.state[nm], self.state[nm + "/Adagrad"], uniq, rg, lr)
+                    col0 += D
+                elif c["kind"] == "indicator":
+                    col0 += c["num_buckets"]
+                else:
+                    col0 += 1
+        if "wide" in cache:
+            assert self.lin_opt[0] == "Ftrl"
+            _, lr, l1, l2, _ = self.lin_opt
+            for c in self.wide_cols:
+                ids, offs = batch["ids"][c["key"]]
+                uniq, rg = embag_row_grads(1, ids, offs, dlogit.reshape(-1, 1), mean=False)
+                nm = self.wide_name(c)
+                ftrl_rows(self.state[nm], self.state[nm + "/Ftrl_1"], self.state[nm + "/Ftrl"], uniq, rg, lr, l1, l2)
+            nm = "linear/linear_model/bias_weights"
+            ftrl_dense(self.state[nm], self.state[nm + "/Ftrl_1"], self.state[nm + "/Ftrl"], dlogit.sum().reshape(1), lr, l1, l2)
+        return loss, logits

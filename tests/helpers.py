@@ -1,0 +1,71 @@
+"""Shared helpers for the GPU parity tests: engine batch/state -> oracle batch/model."""
+import numpy as np
+import torch
+
+from oracle import oracle as O
+
+
+def slot_csr(plan, ids, bag_offs, B):
+    """example-major bag CSR -> {slot name: (ids int64, offs int32[B+1])} (one CSR per column, like TF)."""
+    S = plan.S
+    ids = np.asarray(ids)
+    offs = np.asarray(bag_offs).astype(np.int64)
+    out = {}
+    for si, s in enumerate(plan.slots):
+        v, o = [], [0]
+        for b in range(B):
+            g = b * S + si
+            v.extend(ids[offs[g]:offs[g + 1]].tolist())
+            o.append(len(v))
+        out[s.name] = (np.asarray(v, dtype=np.int64), np.asarray(o, dtype=np.int32))
+    return out
+
+
+def oracle_batch(plan, ids, bag_offs, B, dense, labels, weights=None):
+    bt = {"ids": slot_csr(plan, ids, bag_offs, B), "dense": {}, "labels": np.asarray(labels, dtype=np.float32),
+          "weights": None if weights is None else np.asarray(weights, dtype=np.float32)}
+    for j, d in enumerate(plan.dense_cols):
+        v = np.asarray(dense)[:, j].astype(np.float32)
+        if d.kind == 1:
+            v = (v - np.float32(d.p0)) / (np.float32(d.p1) - np.float32(d.p0))
+        elif d.kind == 2:
+            v = (v - np.float32(d.p0)) / np.float32(d.p1)
+        elif d.kind == 3:
+            v = np.log(v)
+        bt["dense"][d.name] = v.astype(np.float32)
+    return bt
+
+
+def oracle_from_engine(eng):
+    spec, plan = eng.spec, eng.plan
+    deep_cols, wide_cols = [], []
+    for s in plan.slots:
+        if spec.has_deep and s.deep == "embedding":
+            deep_cols.append({"name": s.deep_name, "kind": "embedding", "key": s.name, "num_buckets": s.num_buckets, "dim": s.dim})
+        elif spec.has_deep and s.deep == "indicator":
+            deep_cols.append({"name": s.deep_name, "kind": "indicator", "key": s.name, "num_buckets": s.num_buckets, "dim": 0})
+        if spec.has_wide and s.wide:
+            wide_cols.append({"name": s.name, "key": s.name, "num_buckets": s.num_buckets})
+    for d in plan.dense_cols:
+        deep_cols.append({"name": d.name, "kind": "numeric", "key": d.name, "num_buckets": 0, "dim": 1})
+    state = {k: v.clone().float() if v.dtype != torch.int64 else v for k, v in eng.export_state().items()}
+    towers = [(t.hidden_units, t.mode) for t in spec.towers]
+    return O.OracleWideDeep(spec.model_type, deep_cols, wide_cols, towers, state, act=spec.activation,
+                            batch_norm=spec.batch_norm, dnn_opt=spec.dnn_opt, lin_opt=spec.lin_opt)
+
+
+def max_rel_err(a, b, floor=1e-6):
+    a = torch.as_tensor(a).double().reshape(-1)
+    b = torch.as_tensor(b).double().reshape(-1)
+    return float(((a - b).abs() / (b.abs().clamp_min(floor) + 0)).max()) if a.numel() else 0.0
+
+
+def assert_close(a, b, rtol, atol, what=""):
+    a = torch.as_tensor(a).double().reshape(-1).cpu()
+    b = torch.as_tensor(b).double().reshape(-1).cpu()
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    err = (a - b).abs()
+    tol = atol + rtol * b.abs()
+    bad = err > tol
+    assert not bool(bad.any()), "%s: %d/%d out of tolerance, max abs err %.3e (rtol %g atol %g)" % (
+        what, int(bad.sum()), a.numel(), float(err.max()), rtol, atol)

@@ -1,0 +1,33 @@
+"""CPU: the C-ABI library builds for gfx950, loads, and exports every symbol include/wd_hip.h declares."""
+import ctypes
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "wd_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(wd_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_symbols_exported():
+    from wide_deep_amd import capi
+    if not os.path.exists(capi.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    lib = ctypes.CDLL(capi.LIB_PATH)
+    names = _declared()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(lib, n), "missing export %s" % n
+    # binding table covers the header exactly
+    assert sorted(names) == capi.EXPORTED_SYMBOLS
+
+
+def test_abi_version_and_error_string():
+    from wide_deep_amd import capi
+    lib = capi.load()
+    assert lib.wd_abi_version() == 1
+    assert isinstance(lib.wd_last_error(), bytes)

@@ -1,0 +1,242 @@
+"""GPU: each hot-path kernel, called through the C ABI, against the CPU oracle.
+Integer work is compared bit-exactly; fp32 work within the stated tolerance."""
+import os
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+RTOL, ATOL = 2e-5, 1e-6   # fp32 tolerance for sums whose order differs from the oracle's
+
+
+def _dev(a, dt):
+    return torch.as_tensor(np.asarray(a), dtype=dt).cuda()
+
+
+def _rand_tokens(rnd, n, maxlen):
+    toks = []
+    for _ in range(n):
+        L = rnd.choice([0, 1, 2, 3, 4, 7, 8, 9, 15, 16, 17, 31, 32, 33, 36, 54, 63, 64, 65, 100, 127, 128, 129, 200]) if rnd.random() < 0.5 else rnd.randint(0, maxlen)
+        toks.append(bytes(rnd.getrandbits(8) for _ in range(L)))
+    return toks
+
+
+def test_fingerprint64_bit_exact_all_length_branches():
+    from wide_deep_amd.capi import call, ptr
+    rnd = random.Random(3)
+    toks = _rand_tokens(rnd, 5000, 300) + [str(i).encode() for i in range(2000)]
+    data, offs = O.pack_tokens(toks)
+    exp = O.fingerprint64_batch(data, offs)
+    d = _dev(data if data.size else np.zeros(1, np.uint8), torch.uint8)
+    o = _dev(offs, torch.int32)
+    out = torch.zeros(len(toks), dtype=torch.int64, device="cuda")
+    call("wd_fingerprint64", ptr(d), ptr(o), len(toks), ptr(out), torch.cuda.current_stream().cuda_stream)
+    got = out.cpu().numpy().view(np.uint64)
+    assert np.array_equal(got, exp)
+
+
+def test_golden_kat_on_device():
+    import json
+    from wide_deep_amd.capi import call, ptr
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "kat_hash.json")))
+    toks = list(g["fingerprint64"].keys())
+    data, offs = O.pack_tokens(toks)
+    out = torch.zeros(len(toks), dtype=torch.int64, device="cuda")
+    call("wd_fingerprint64", ptr(_dev(data, torch.uint8)), ptr(_dev(offs, torch.int32)), len(toks), ptr(out),
+         torch.cuda.current_stream().cuda_stream)
+    assert out.cpu().numpy().view(np.uint64).tolist() == [g["fingerprint64"][t] for t in toks]
+
+
+def _engine(spec, **kw):
+    from wide_deep_amd.engine import WideDeepEngine
+    return WideDeepEngine(spec, **kw)
+
+
+def test_hash_bucket_multi_slot_and_multi_token():
+    from wide_deep_amd import synth
+    from wide_deep_amd.plan import criteo_spec
+    spec = criteo_spec(n_dense=2, n_sparse=5, buckets=1000, dim=8, hidden=(16,))
+    spec.slots[1].num_buckets = 77
+    spec.slots[3].num_buckets = 100003
+    eng = _engine(spec, max_batch=64)
+    for mean_len in (1, 3):
+        hb = synth.make_raw_batch(eng.plan, 37, seed=5, mean_len=mean_len, n_raw=10**9)
+        tb = synth.TokenBatch(eng.plan, hb)
+        bt = synth.hash_tokens(eng, tb)
+        torch.cuda.synchronize()
+        S = eng.plan.S
+        slot_of = np.repeat(np.tile(np.arange(S), hb["B"]), hb["lens"].reshape(-1))
+        exp = np.zeros(len(hb["raw"]), dtype=np.int64)
+        for si, s in enumerate(eng.plan.slots):
+            m = slot_of == si
+            exp[m] = O.hash_bucket([str(v) for v in hb["raw"][m]], s.num_buckets)
+        assert np.array_equal(bt.ids.cpu().numpy().astype(np.int64), exp)
+
+
+def test_cross_hash_bit_exact_ragged_and_empty():
+    from wide_deep_amd import capi
+    from wide_deep_amd.capi import call, ptr
+    rnd = np.random.default_rng(11)
+    B, S, slot = 50, 3, 1
+    keys_host = []
+    for k in range(3):
+        lens = rnd.integers(0, 4, size=B)
+        if k == 2:
+            lens = np.maximum(lens, 1)
+        offs = np.zeros(B + 1, np.int32); np.cumsum(lens, out=offs[1:])
+        vals = rnd.integers(0, 2**63, size=int(offs[-1]), dtype=np.int64).astype(np.uint64)
+        keys_host.append((vals, offs))
+    for nb in (7, 100, 1000003):
+        exp_ids, exp_offs = O.cross_hash(keys_host, nb)
+        # bag offsets: slot 1 of 3 gets the cross, the others are empty
+        lens_all = np.zeros((B, S), dtype=np.int64)
+        lens_all[:, slot] = np.diff(exp_offs)
+        bag_offs = np.zeros(B * S + 1, np.int32); np.cumsum(lens_all.reshape(-1), out=bag_offs[1:])
+        ck = capi.WdCrossKeys()
+        keep = []
+        for k, (v, o) in enumerate(keys_host):
+            vd = _dev(v.view(np.int64) if v.size else np.zeros(1, np.int64), torch.int64); od = _dev(o, torch.int32)
+            keep += [vd, od]
+            ck.vals[k] = vd.data_ptr(); ck.offs[k] = od.data_ptr()
+        ck.nkeys = 3
+        ids = torch.full((max(int(bag_offs[-1]), 1),), -1, dtype=torch.int32, device="cuda")
+        call("wd_cross_hash", ck, B, 0xDECAFCAFFE, nb, ptr(_dev(bag_offs, torch.int32)), S, slot, ptr(ids),
+             torch.cuda.current_stream().cuda_stream)
+        assert np.array_equal(ids.cpu().numpy()[: len(exp_ids)].astype(np.int64), exp_ids)
+
+
+@pytest.mark.parametrize("dim", [4, 8, 16, 32, 64, 6])
+def test_embag_fwd_mean_matches_oracle(dim):
+    from wide_deep_amd import synth
+    from wide_deep_amd.plan import criteo_spec
+    spec = criteo_spec(n_dense=3, n_sparse=4, buckets=500, dim=dim, hidden=(8,))
+    eng = _engine(spec, max_batch=128)
+    rng = np.random.default_rng(dim)
+    hb = synth.make_raw_batch(eng.plan, 100, seed=dim, mean_len=3)
+    hb["lens"][rng.random(hb["lens"].shape) < 0.2] = 0        # empty bags -> zero vector
+    nnz = int(hb["lens"].sum()); hb["raw"] = hb["raw"][:nnz]
+    bt = synth.to_device_ids(eng.plan, hb)
+    eng.forward(bt)
+    torch.cuda.synchronize()
+    from tests.helpers import slot_csr, assert_close
+    csr = slot_csr(eng.plan, bt.ids.cpu().numpy(), bt.bag_offs.cpu().numpy(), bt.B)
+    st = eng.export_state()
+    x = eng.towers[0]["act"][: bt.B].cpu()
+    for si, s in enumerate(eng.plan.slots):
+        tab = st["dnn/input_from_feature_columns/input_layer/%s/embedding_weights" % s.deep_name]
+        exp = O.embag_fwd(tab, *csr[s.name], mean=True)
+        c0 = eng.plan.out_col[si]
+        assert_close(x[:, c0:c0 + dim], exp, RTOL, ATOL, "embag slot %s" % s.name)
+    for j in range(3):
+        assert torch.equal(x[:, eng.plan.dense_out_col[j]], torch.as_tensor(hb["dense"][:, j]))
+
+
+def test_gemm_variants_match_torch_fp32():
+    from wide_deep_amd.capi import call, ptr
+    from tests.helpers import assert_close
+    st = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator(device="cuda"); g.manual_seed(0)
+    for (M, N, K) in [(100, 64, 48), (257, 130, 77), (64, 1, 64), (1000, 256, 429), (33, 7, 5)]:
+        lda, ldb, ldc = K + 3, N, N + 5
+        A = torch.randn(M, lda, device="cuda", generator=g); Bm = torch.randn(K, ldb, device="cuda", generator=g)
+        bias = torch.randn(N, device="cuda", generator=g)
+        C = torch.zeros(M, ldc, device="cuda")
+        call("wd_gemm_nn_bias_act", ptr(A), lda, ptr(Bm), ldb, ptr(bias), 1, ptr(C), ldc, M, N, K, st)
+        ref = torch.relu(A[:, :K].double() @ Bm[:, :N].double() + bias.double())
+        assert_close(C[:, :N], ref, 1e-5, 1e-4, "NN %s" % ((M, N, K),))
+        assert float(C[:, N:].abs().max()) == 0.0
+        # NT: C[M,K] (+)= dZ[M,N] W[K,N]^T
+        dZ = torch.randn(M, N, device="cuda", generator=g)
+        C2 = torch.ones(M, K + 1, device="cuda")
+        call("wd_gemm_nt", ptr(dZ), N, ptr(Bm), ldb, ptr(C2), K + 1, M, K, N, 1, st)
+        ref2 = 1.0 + dZ.double() @ Bm[:, :N].double().t()
+        assert_close(C2[:, :K], ref2, 1e-5, 1e-4, "NT acc")
+        call("wd_gemm_nt", ptr(dZ), N, ptr(Bm), ldb, ptr(C2), K + 1, M, K, N, 0, st)
+        assert_close(C2[:, :K], ref2 - 1.0, 1e-5, 1e-4, "NT")
+        # TN split-K with ones row: G[K+1,N] = [A|1]^T dZ
+        for ns in (1, 3):
+            Gp = torch.zeros(ns, K + 1, N, device="cuda")
+            call("wd_gemm_tn_splitk", ptr(A), lda, ptr(dZ), N, ptr(Gp), K, N, M, ns, 1, st)
+            G = Gp.double().sum(0)
+            assert_close(G[:K], A[:, :K].double().t() @ dZ.double(), 1e-5, 2e-4, "TN")
+            assert_close(G[K], dZ.double().sum(0), 1e-5, 2e-4, "TN ones row")
+
+
+def test_a_identity_asymmetric_b_detects_transposes():
+    from wide_deep_amd.capi import call, ptr
+    st = torch.cuda.current_stream().cuda_stream
+    n = 64
+    A = torch.eye(n, device="cuda")
+    Bm = (torch.arange(n, device="cuda").float()[:, None] * 100 + torch.arange(n, device="cuda").float()[None, :]).contiguous()
+    C = torch.zeros(n, n, device="cuda")
+    call("wd_gemm_nn_bias_act", ptr(A), n, ptr(Bm), n, None, 0, ptr(C), n, n, n, n, st)
+    assert torch.equal(C, Bm)
+
+
+def test_sort_and_sparse_updates_match_oracle():
+    from wide_deep_amd import synth
+    from wide_deep_amd.plan import criteo_spec
+    from tests.helpers import slot_csr, assert_close
+    spec = criteo_spec(n_dense=0, n_sparse=3, buckets=50, dim=16, hidden=(8,))   # tiny tables -> many duplicates
+    eng = _engine(spec, max_batch=256)
+    hb = synth.make_raw_batch(eng.plan, 200, seed=9, mean_len=4)
+    bt = synth.to_device_ids(eng.plan, hb)
+    st0 = eng.export_state()
+    B, ld = bt.B, eng.towers[0]["layout"].ld
+    g = torch.Generator(device="cuda"); g.manual_seed(1)
+    dx = torch.randn(B, ld, device="cuda", generator=g)
+    eng.towers[0]["dact"][:B] = dx
+    eng.dlogit[:B] = torch.randn(B, device="cuda", generator=g)
+    s = torch.cuda.current_stream().cuda_stream
+    eng.sort_occurrences(bt, s)
+    torch.cuda.synchronize()
+    ks = eng.keys_sorted[: bt.nnz].cpu().numpy().view(np.uint32)
+    assert np.all(np.diff(ks.astype(np.int64)) >= 0)
+    from wide_deep_amd.capi import call, ptr
+    call("wd_embag_bwd_adagrad", ptr(eng.emb), ptr(eng.emb_acc), ptr(eng.slots_dev), eng.plan.S, 16, ptr(eng.keys_sorted),
+         ptr(eng.vals_sorted), bt.nnz, ptr(bt.bag_offs), ptr(eng.towers[0]["dact"]), ld, 0.05, s)
+    call("wd_wide_bwd_ftrl", ptr(eng.wide), ptr(eng.slots_dev), eng.plan.S, ptr(eng.keys_sorted), ptr(eng.vals_sorted),
+         bt.nnz, ptr(eng.dlogit), 0.1, 0.5, 1.0, s)
+    call("wd_bias_ftrl", ptr(eng.bias), ptr(eng.dlogit), B, 0.1, 0.5, 1.0, s)
+    torch.cuda.synchronize()
+    st1 = eng.export_state()
+    csr = slot_csr(eng.plan, bt.ids.cpu().numpy(), bt.bag_offs.cpu().numpy(), B)
+    dxc, dl = dx.cpu(), eng.dlogit[:B].cpu()
+    for si, sl in enumerate(eng.plan.slots):
+        nm = "dnn/input_from_feature_columns/input_layer/%s/embedding_weights" % sl.deep_name
+        tab, acc = st0[nm].clone(), st0[nm + "/Adagrad"].clone()
+        c0 = eng.plan.out_col[si]
+        uniq, rg = O.embag_row_grads(16, *csr[sl.name], dxc[:, c0:c0 + 16].contiguous(), mean=True)
+        O.adagrad_rows(tab, acc, uniq, rg, 0.05)
+        assert_close(st1[nm], tab, RTOL, ATOL, "emb " + sl.name)
+        assert_close(st1[nm + "/Adagrad"], acc, RTOL, ATOL, "emb acc " + sl.name)
+        wn = "linear/linear_model/%s/weights" % sl.name
+        w, z, n = st0[wn].clone(), st0[wn + "/Ftrl_1"].clone(), st0[wn + "/Ftrl"].clone()
+        uniq, rg = O.embag_row_grads(1, *csr[sl.name], dl.reshape(-1, 1).contiguous(), mean=False)
+        O.ftrl_rows(w, z, n, uniq, rg, 0.1, 0.5, 1.0)
+        assert_close(st1[wn], w, RTOL, ATOL, "wide w " + sl.name)
+        assert_close(st1[wn + "/Ftrl_1"], z, RTOL, ATOL, "wide z " + sl.name)
+        assert_close(st1[wn + "/Ftrl"], n, RTOL, ATOL, "wide n " + sl.name)
+    b = "linear/linear_model/bias_weights"
+    w, z, n = st0[b].clone(), st0[b + "/Ftrl_1"].clone(), st0[b + "/Ftrl"].clone()
+    O.ftrl_dense(w, z, n, dl.sum().reshape(1), 0.1, 0.5, 1.0)
+    assert_close(st1[b], w, 1e-4, 1e-6, "bias")
+
+
+def test_bce_head_matches_oracle():
+    from wide_deep_amd.capi import call, ptr
+    from tests.helpers import assert_close
+    n = 1000
+    g = torch.Generator(device="cuda"); g.manual_seed(2)
+    a = torch.randn(n, device="cuda", generator=g) * 8; b = torch.randn(n, device="cuda", generator=g)
+    y = (torch.rand(n, device="cuda", generator=g) < 0.3).float(); w = torch.rand(n, device="cuda", generator=g)
+    logit = torch.zeros(n, device="cuda"); p = torch.zeros(n, device="cuda"); dl = torch.zeros(n, device="cuda"); loss = torch.zeros(1, device="cuda")
+    call("wd_bce_sum_fwd_bwd", ptr(a), ptr(b), ptr(y), ptr(w), n, ptr(logit), ptr(p), ptr(dl), ptr(loss), torch.cuda.current_stream().cuda_stream)
+    el, edl, ep = O.bce_sum((a + b).cpu(), y.cpu(), w.cpu())
+    assert_close(dl, edl, 1e-5, 1e-6, "dlogit"); assert_close(p, ep, 1e-5, 1e-7, "prob")
+    assert abs(float(loss) - el) <= 1e-4 * abs(el)

@@ -1,0 +1,126 @@
+"""ctypes binding of the C-ABI hot-path library (include/wd_hip.h -> _lib/libwd_hip.so).
+
+The product path has NO CPU fallback: if the HIP library is missing or a call
+fails, this module raises.  (The CPU oracle under oracle/ is test infrastructure
+and is never imported from here.)
+"""
+import ctypes
+import os
+
+import torch  # noqa: F401  (loads torch's bundled HIP runtime first so libwd_hip.so binds to the same one)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "_lib", "libwd_hip.so")
+
+WD_MAX_CROSS_KEYS = 8
+
+SLOT_NONE, SLOT_EMBEDDING, SLOT_INDICATOR = 0, 1, 2
+
+ACT_IDS = {
+    None: 0, "none": 0, "relu": 1, "sigmoid": 2, "tanh": 3, "relu6": 4, "leaky_relu": 5, "elu": 6, "selu": 7,
+    "softplus": 8, "softsign": 9,
+}
+
+
+class WdSlot(ctypes.Structure):
+    _fields_ = [
+        ("emb_off", ctypes.c_int64),
+        ("row_base", ctypes.c_int64),
+        ("num_buckets", ctypes.c_int32),
+        ("dim", ctypes.c_int32),
+        ("out_col", ctypes.c_int32),
+        ("kind", ctypes.c_int32),
+        ("wide", ctypes.c_int32),
+        ("pad_", ctypes.c_int32),
+    ]
+
+
+class WdDenseCol(ctypes.Structure):
+    _fields_ = [("p0", ctypes.c_float), ("p1", ctypes.c_float), ("kind", ctypes.c_int32), ("out_col", ctypes.c_int32)]
+
+
+class WdCrossKeys(ctypes.Structure):
+    _fields_ = [
+        ("vals", ctypes.c_void_p * WD_MAX_CROSS_KEYS),
+        ("offs", ctypes.c_void_p * WD_MAX_CROSS_KEYS),
+        ("nkeys", ctypes.c_int32),
+    ]
+
+
+P = ctypes.c_void_p
+I32, I64, U64, F32, SZ = ctypes.c_int32, ctypes.c_int64, ctypes.c_uint64, ctypes.c_float, ctypes.c_size_t
+
+# name -> argtypes; every function returns int status unless listed in _RESTYPES
+_PROTOS = {
+    "wd_abi_version": [],
+    "wd_fingerprint64": [P, P, I64, P, P],
+    "wd_hash_bucket": [P, P, I64, P, I64, P, I32, P, P],
+    "wd_emit_hash_slot": [P, P, I64, U64, P, I32, I32, P, P],
+    "wd_emit_int_slot": [P, P, I64, P, I32, I32, P, P],
+    "wd_cross_hash": [ctypes.POINTER(WdCrossKeys), I64, U64, U64, P, I32, I32, P, P],
+    "wd_embag_fwd": [P, P, I32, P, I32, I32, P, P, I64, P, I64, P],
+    "wd_indicator_fwd": [P, I32, P, I32, P, P, I64, P, I64, P],
+    "wd_dense_fwd": [P, I64, P, I32, I64, P, I64, P],
+    "wd_wide_fwd": [P, P, P, I32, P, P, I64, P, P],
+    "wd_bce_sum_fwd_bwd": [P, P, P, P, I64, P, P, P, P, P],
+    "wd_sort_workspace_bytes": [I64, I32],
+    "wd_build_sort_keys": [P, I32, P, P, I64, I64, P, P, P],
+    "wd_sort_pairs": [P, P, P, P, I64, I32, P, SZ, P],
+    "wd_embag_bwd_adagrad": [P, P, P, I32, I32, P, P, I64, P, P, I64, F32, P],
+    "wd_wide_bwd_ftrl": [P, P, I32, P, P, I64, P, F32, F32, F32, P],
+    "wd_bias_ftrl": [P, P, I64, F32, F32, F32, P],
+    "wd_gemm_nn_bias_act": [P, I64, P, I64, P, I32, P, I64, I64, I64, I64, P],
+    "wd_gemm_nt": [P, I64, P, I64, P, I64, I64, I64, I64, I32, P],
+    "wd_gemm_tn_splitk": [P, I64, P, I64, P, I64, I64, I64, I32, I32, P],
+    "wd_fold_affine": [P, I64, I64, P, P, F32, P, P, P, P, I64, I64, P],
+    "wd_act_bwd": [P, I64, P, I64, I32, P, I64, I64, I64, P],
+    "wd_mlp_finalize": [P, I32, P, I64, I64, P, P, P, P, F32, P, I64, I64, P],
+    "wd_adagrad_dense": [P, P, P, I64, F32, P],
+    "wd_fill_f32": [P, F32, I64, P],
+}
+_RESTYPES = {"wd_sort_workspace_bytes": SZ}
+
+EXPORTED_SYMBOLS = sorted(list(_PROTOS) + ["wd_last_error"])
+
+_lib = None
+
+
+class WdError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libwd_hip.so (fails loudly when the HIP extension has not been built)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise WdError(
+            "HIP extension %s not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(wide_deep_amd/csrc/build.sh).  There is no CPU fallback for the hot path." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    lib.wd_last_error.restype = ctypes.c_char_p
+    lib.wd_last_error.argtypes = []
+    for name, argtypes in _PROTOS.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = _RESTYPES.get(name, ctypes.c_int)
+    _lib = lib
+    return lib
+
+
+def ptr(t):
+    """device/host pointer of a torch tensor (None -> NULL)."""
+    if t is None:
+        return None
+    return t.data_ptr()
+
+
+def call(name, *args):
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if name in _RESTYPES:
+        return rc
+    if rc != 0:
+        raise WdError("%s failed (%d): %s" % (name, rc, lib.wd_last_error().decode()))
+    return rc

@@ -1,0 +1,234 @@
+// wide_deep_amd/csrc/embag.hip -- forward sparse side of the train step on gfx950.
+//
+//   wd_embag_fwd      tf.feature_column.input_layer / embedding_column(combiner='mean')   python/lib/dnn.py:83-90
+//   wd_indicator_fwd  indicator_column multi-hot counts                                   build_estimator.py:108,118
+//   wd_dense_fwd      numeric_column(normalizer_fn)                                       build_estimator.py:61-68,121-136
+//   wd_wide_fwd       tf.feature_column.linear_model(sparse_combiner='sum')               python/lib/linear.py:29-36
+//   wd_bce_sum_fwd_bwd  binary head, sigmoid CE, SUM reduction                            python/lib/joint.py:216-222,264-269
+//
+// All of it is HBM-bound gather work.  Layout decisions:
+//   * bags are example-major (bag = b*S + s) so a wavefront's pooled rows land in ONE contiguous
+//     span of x (16 bags x 64 B for D=16) and its id / offset reads are coalesced;
+//   * a row of D floats is read by D/4 lanes as float4 (16 B per lane, 1 KiB per wave instruction);
+//   * each lane group keeps UNROLL independent row reads in flight to cover HBM latency.
+#include "common.h"
+
+namespace {
+
+template <int LANES>  // LANES = D/4 lanes cooperate on one bag
+__global__ void __launch_bounds__(256)
+k_embag_fwd(const float *__restrict__ emb, const wd_slot_t *__restrict__ slots, int32_t S,
+            const int32_t *__restrict__ group_slots, int32_t ngroup, const int32_t *__restrict__ ids,
+            const int32_t *__restrict__ bag_offs, int64_t nwork, float *__restrict__ x, int64_t ldx) {
+  constexpr int D = LANES * 4;
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t work = tid / LANES;  // (b, g) pair
+  const int lane = (int)(tid % LANES);
+  if (work >= nwork) return;
+  const int64_t b = work / ngroup;
+  const int32_t s = group_slots[work - b * ngroup];
+  const wd_slot_t sl = slots[s];
+  const int64_t bag = b * S + s;
+  const int32_t j0 = bag_offs[bag], j1 = bag_offs[bag + 1];
+  const float4 *__restrict__ tab = reinterpret_cast<const float4 *>(emb + sl.emb_off);
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  int32_t j = j0;
+  // 4 independent row reads in flight per lane group
+  for (; j + 4 <= j1; j += 4) {
+    int32_t i0 = ids[j], i1 = ids[j + 1], i2 = ids[j + 2], i3 = ids[j + 3];
+    float4 r0 = tab[(int64_t)i0 * LANES + lane];
+    float4 r1 = tab[(int64_t)i1 * LANES + lane];
+    float4 r2 = tab[(int64_t)i2 * LANES + lane];
+    float4 r3 = tab[(int64_t)i3 * LANES + lane];
+    acc.x += r0.x; acc.y += r0.y; acc.z += r0.z; acc.w += r0.w;
+    acc.x += r1.x; acc.y += r1.y; acc.z += r1.z; acc.w += r1.w;
+    acc.x += r2.x; acc.y += r2.y; acc.z += r2.z; acc.w += r2.w;
+    acc.x += r3.x; acc.y += r3.y; acc.z += r3.z; acc.w += r3.w;
+  }
+  for (; j < j1; ++j) {
+    float4 r = tab[(int64_t)ids[j] * LANES + lane];
+    acc.x += r.x; acc.y += r.y; acc.z += r.z; acc.w += r.w;
+  }
+  const int32_t n = j1 - j0;
+  if (n > 1) {  // combiner='mean': sum / count (duplicates counted), SURVEY App. A.6
+    const float c = (float)n;
+    acc.x /= c; acc.y /= c; acc.z /= c; acc.w /= c;
+  }
+  float *o = x + b * ldx + sl.out_col + lane * 4;
+  if ((((uintptr_t)o) & 15) == 0) {
+    *reinterpret_cast<float4 *>(o) = acc;
+  } else {
+    o[0] = acc.x; o[1] = acc.y; o[2] = acc.z; o[3] = acc.w;
+  }
+  (void)D;
+}
+
+// dims that are not a multiple of 4 (never produced by the reference's embedding_dim, kept for the
+// opt-in embedding_dim override): one lane per (bag, element).
+__global__ void k_embag_fwd_generic(const float *__restrict__ emb, const wd_slot_t *__restrict__ slots, int32_t S,
+                                    const int32_t *__restrict__ group_slots, int32_t ngroup, int32_t D,
+                                    const int32_t *__restrict__ ids, const int32_t *__restrict__ bag_offs,
+                                    int64_t nwork, float *__restrict__ x, int64_t ldx) {
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t work = tid / D;
+  const int d = (int)(tid % D);
+  if (work >= nwork) return;
+  const int64_t b = work / ngroup;
+  const int32_t s = group_slots[work - b * ngroup];
+  const wd_slot_t sl = slots[s];
+  const int64_t bag = b * S + s;
+  const int32_t j0 = bag_offs[bag], j1 = bag_offs[bag + 1];
+  const float *tab = emb + sl.emb_off;
+  float acc = 0.f;
+  for (int32_t j = j0; j < j1; ++j) acc += tab[(int64_t)ids[j] * D + d];
+  if (j1 - j0 > 1) acc /= (float)(j1 - j0);
+  x[b * ldx + sl.out_col + d] = acc;
+}
+
+__global__ void k_indicator_fwd(const wd_slot_t *__restrict__ slots, int32_t S,
+                                const int32_t *__restrict__ group_slots, int32_t ngroup,
+                                const int32_t *__restrict__ ids, const int32_t *__restrict__ bag_offs, int64_t nwork,
+                                float *__restrict__ x, int64_t ldx) {
+  const int64_t work = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (work >= nwork) return;
+  const int64_t b = work / ngroup;
+  const int32_t s = group_slots[work - b * ngroup];
+  const wd_slot_t sl = slots[s];
+  float *o = x + b * ldx + sl.out_col;
+  for (int32_t c = 0; c < sl.num_buckets; ++c) o[c] = 0.f;
+  const int64_t bag = b * S + s;
+  for (int32_t j = bag_offs[bag]; j < bag_offs[bag + 1]; ++j) o[ids[j]] += 1.0f;
+}
+
+__global__ void k_dense_fwd(const float *__restrict__ dense, int64_t ld_dense, const wd_dense_col_t *__restrict__ cols,
+                            int32_t ncols, int64_t batch, float *__restrict__ x, int64_t ldx) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= batch * ncols) return;
+  const int64_t b = i / ncols;
+  const int32_t j = (int32_t)(i - b * ncols);
+  const wd_dense_col_t c = cols[j];
+  float v = dense[b * ld_dense + j];
+  if (c.kind == 1) v = (v - c.p0) / (c.p1 - c.p0);
+  else if (c.kind == 2) v = (v - c.p0) / c.p1;
+  else if (c.kind == 3) v = logf(v);
+  x[b * ldx + c.out_col] = v;
+}
+
+// 16 lanes per example: lanes stride over the example's bags, then a shuffle reduction inside the
+// 16-lane group (4 examples per wavefront).
+__global__ void __launch_bounds__(256)
+k_wide_fwd(const float *__restrict__ wide, const float *__restrict__ bias, const wd_slot_t *__restrict__ slots,
+           int32_t S, const int32_t *__restrict__ ids, const int32_t *__restrict__ bag_offs, int64_t batch,
+           float *__restrict__ out) {
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t b = tid >> 4;
+  const int lane = (int)(tid & 15);
+  float acc = 0.f;
+  if (b < batch) {
+    for (int32_t s = lane; s < S; s += 16) {
+      const wd_slot_t sl = slots[s];
+      if (!sl.wide) continue;
+      const int64_t bag = b * S + s;
+      const int32_t j0 = bag_offs[bag], j1 = bag_offs[bag + 1];
+      for (int32_t j = j0; j < j1; ++j) acc += wide[(sl.row_base + ids[j]) * 4];
+    }
+  }
+  acc += __shfl_xor(acc, 8, 16);
+  acc += __shfl_xor(acc, 4, 16);
+  acc += __shfl_xor(acc, 2, 16);
+  acc += __shfl_xor(acc, 1, 16);
+  if (b < batch && lane == 0) out[b] = acc + bias[0];
+}
+
+__global__ void k_bce(const float *__restrict__ dnn_logit, const float *__restrict__ wide_logit,
+                      const float *__restrict__ labels, const float *__restrict__ weights, int64_t batch,
+                      float *__restrict__ logit, float *__restrict__ prob, float *__restrict__ dlogit,
+                      float *__restrict__ loss_sum) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  float l = 0.f;
+  if (i < batch) {
+    float x = 0.f;
+    if (dnn_logit) x += dnn_logit[i];
+    if (wide_logit) x += wide_logit[i];
+    const float y = labels[i];
+    const float w = weights ? weights[i] : 1.0f;
+    const float e = expf(-fabsf(x));
+    // sigmoid_cross_entropy_with_logits: max(x,0) - x*y + log(1+exp(-|x|))
+    l = w * (fmaxf(x, 0.f) - x * y + log1pf(e));
+    const float p = x >= 0.f ? 1.0f / (1.0f + e) : e / (1.0f + e);
+    if (logit) logit[i] = x;
+    if (prob) prob[i] = p;
+    if (dlogit) dlogit[i] = w * (p - y);
+  }
+  // wave reduction, then one atomic per wave
+  for (int off = 32; off > 0; off >>= 1) l += __shfl_down(l, off, 64);
+  if ((threadIdx.x & 63) == 0 && loss_sum) atomicAdd(loss_sum, l);
+}
+
+}  // namespace
+
+extern "C" int wd_embag_fwd(const float *emb, const wd_slot_t *slots, int32_t S, const int32_t *group_slots,
+                            int32_t ngroup, int32_t dim, const int32_t *ids, const int32_t *bag_offs, int64_t batch,
+                            float *x, int64_t ldx, wd_stream_t stream) {
+  if (batch <= 0 || ngroup <= 0) return WD_OK;
+  WD_REQUIRE(emb && slots && group_slots && ids && bag_offs && x, "null pointer");
+  WD_REQUIRE(dim > 0, "dim must be > 0");
+  const int64_t nwork = batch * ngroup;
+  hipStream_t st = wd::as_stream(stream);
+#define WD_LAUNCH_EMBAG(L)                                                                                         \
+  hipLaunchKernelGGL(k_embag_fwd<L>, dim3((unsigned)wd::ceil_div(nwork * L, 256)), dim3(256), 0, st, emb, slots, S, \
+                     group_slots, ngroup, ids, bag_offs, nwork, x, ldx)
+  switch (dim) {
+    case 4: WD_LAUNCH_EMBAG(1); break;
+    case 8: WD_LAUNCH_EMBAG(2); break;
+    case 16: WD_LAUNCH_EMBAG(4); break;
+    case 32: WD_LAUNCH_EMBAG(8); break;
+    case 64: WD_LAUNCH_EMBAG(16); break;
+    case 128: WD_LAUNCH_EMBAG(32); break;
+    default:
+      hipLaunchKernelGGL(k_embag_fwd_generic, dim3((unsigned)wd::ceil_div(nwork * dim, 256)), dim3(256), 0, st, emb,
+                         slots, S, group_slots, ngroup, dim, ids, bag_offs, nwork, x, ldx);
+  }
+#undef WD_LAUNCH_EMBAG
+  return wd::check_launch("wd_embag_fwd");
+}
+
+extern "C" int wd_indicator_fwd(const wd_slot_t *slots, int32_t S, const int32_t *group_slots, int32_t ngroup,
+                                const int32_t *ids, const int32_t *bag_offs, int64_t batch, float *x, int64_t ldx,
+                                wd_stream_t stream) {
+  if (batch <= 0 || ngroup <= 0) return WD_OK;
+  WD_REQUIRE(slots && group_slots && ids && bag_offs && x, "null pointer");
+  const int64_t nwork = batch * ngroup;
+  hipLaunchKernelGGL(k_indicator_fwd, dim3((unsigned)wd::ceil_div(nwork, 256)), dim3(256), 0, wd::as_stream(stream),
+                     slots, S, group_slots, ngroup, ids, bag_offs, nwork, x, ldx);
+  return wd::check_launch("wd_indicator_fwd");
+}
+
+extern "C" int wd_dense_fwd(const float *dense, int64_t ld_dense, const wd_dense_col_t *cols, int32_t ncols,
+                            int64_t batch, float *x, int64_t ldx, wd_stream_t stream) {
+  if (batch <= 0 || ncols <= 0) return WD_OK;
+  WD_REQUIRE(dense && cols && x, "null pointer");
+  hipLaunchKernelGGL(k_dense_fwd, dim3((unsigned)wd::ceil_div(batch * ncols, 256)), dim3(256), 0,
+                     wd::as_stream(stream), dense, ld_dense, cols, ncols, batch, x, ldx);
+  return wd::check_launch("wd_dense_fwd");
+}
+
+extern "C" int wd_wide_fwd(const float *wide, const float *bias, const wd_slot_t *slots, int32_t S, const int32_t *ids,
+                           const int32_t *bag_offs, int64_t batch, float *out, wd_stream_t stream) {
+  if (batch <= 0) return WD_OK;
+  WD_REQUIRE(wide && bias && slots && ids && bag_offs && out, "null pointer");
+  hipLaunchKernelGGL(k_wide_fwd, dim3((unsigned)wd::ceil_div(batch * 16, 256)), dim3(256), 0, wd::as_stream(stream),
+                     wide, bias, slots, S, ids, bag_offs, batch, out);
+  return wd::check_launch("wd_wide_fwd");
+}
+
+extern "C" int wd_bce_sum_fwd_bwd(const float *dnn_logit, const float *wide_logit, const float *labels,
+                                  const float *weights, int64_t batch, float *logit, float *prob, float *dlogit,
+                                  float *loss_sum, wd_stream_t stream) {
+  if (batch <= 0) return WD_OK;
+  WD_REQUIRE(labels, "labels required");
+  WD_REQUIRE(dnn_logit || wide_logit, "at least one logit source required");
+  hipLaunchKernelGGL(k_bce, dim3((unsigned)wd::ceil_div(batch, 256)), dim3(256), 0, wd::as_stream(stream), dnn_logit,
+                     wide_logit, labels, weights, batch, logit, prob, dlogit, loss_sum);
+  return wd::check_launch("wd_bce_sum_fwd_bwd");
+}

@@ -1,0 +1,304 @@
+// wide_deep_amd/csrc/hash.hip -- bit-exact feature hashing on gfx950.
+//
+// Replaces the TF ops the reference selects at
+//   python/lib/build_estimator.py:86-88   categorical_column_with_hash_bucket -> string_to_hash_bucket_fast
+//   python/lib/build_estimator.py:138-155 crossed_column -> SparseCross (hashed)
+// i.e. FarmHash farmhashna::Hash64 ("Fingerprint64") and TF FingerprintCat64.
+//
+// Integer, HBM/latency-bound work: one token per lane, tokens packed back to back so a wavefront
+// touches one contiguous span of the byte buffer.  No LDS needed; 64-bit integer VALU only.
+#include "common.h"
+
+namespace {
+
+constexpr uint64_t k0 = 0xc3a5c85c97cb3127ULL;
+constexpr uint64_t k1 = 0xb492b66fbe98f273ULL;
+constexpr uint64_t k2 = 0x9ae16a3b2f90404fULL;
+
+__device__ __forceinline__ uint64_t fetch64(const uint8_t *p) {
+  uint64_t r;
+  __builtin_memcpy(&r, p, 8);
+  return r;
+}
+__device__ __forceinline__ uint64_t fetch32(const uint8_t *p) {
+  uint32_t r;
+  __builtin_memcpy(&r, p, 4);
+  return (uint64_t)r;
+}
+__device__ __forceinline__ uint64_t rotr(uint64_t v, int s) { return s == 0 ? v : ((v >> s) | (v << (64 - s))); }
+__device__ __forceinline__ uint64_t shift_mix(uint64_t v) { return v ^ (v >> 47); }
+__device__ __forceinline__ uint64_t hash_len16(uint64_t u, uint64_t v, uint64_t mul) {
+  uint64_t a = (u ^ v) * mul;
+  a ^= (a >> 47);
+  uint64_t b = (v ^ a) * mul;
+  b ^= (b >> 47);
+  return b * mul;
+}
+
+struct Pair {
+  uint64_t first, second;
+};
+
+__device__ __forceinline__ Pair weak32(const uint8_t *s, uint64_t a, uint64_t b) {
+  uint64_t w = fetch64(s), x = fetch64(s + 8), y = fetch64(s + 16), z = fetch64(s + 24);
+  a += w;
+  b = rotr(b + a + z, 21);
+  uint64_t c = a;
+  a += x;
+  a += y;
+  b += rotr(a, 44);
+  return Pair{a + z, b + c};
+}
+
+__device__ uint64_t fingerprint64(const uint8_t *s, uint32_t len) {
+  if (len <= 16) {
+    if (len >= 8) {
+      uint64_t mul = k2 + (uint64_t)len * 2;
+      uint64_t a = fetch64(s) + k2;
+      uint64_t b = fetch64(s + len - 8);
+      uint64_t c = rotr(b, 37) * mul + a;
+      uint64_t d = (rotr(a, 25) + b) * mul;
+      return hash_len16(c, d, mul);
+    }
+    if (len >= 4) {
+      uint64_t mul = k2 + (uint64_t)len * 2;
+      uint64_t a = fetch32(s);
+      return hash_len16((uint64_t)len + (a << 3), fetch32(s + len - 4), mul);
+    }
+    if (len > 0) {
+      uint8_t a = s[0], b = s[len >> 1], c = s[len - 1];
+      uint32_t y = (uint32_t)a + ((uint32_t)b << 8);
+      uint32_t z = len + ((uint32_t)c << 2);
+      return shift_mix((uint64_t)y * k2 ^ (uint64_t)z * k0) * k2;
+    }
+    return k2;
+  }
+  if (len <= 32) {
+    uint64_t mul = k2 + (uint64_t)len * 2;
+    uint64_t a = fetch64(s) * k1;
+    uint64_t b = fetch64(s + 8);
+    uint64_t c = fetch64(s + len - 8) * mul;
+    uint64_t d = fetch64(s + len - 16) * k2;
+    return hash_len16(rotr(a + b, 43) + rotr(c, 30) + d, a + rotr(b + k2, 18) + c, mul);
+  }
+  if (len <= 64) {
+    uint64_t mul = k2 + (uint64_t)len * 2;
+    uint64_t a = fetch64(s) * k2;
+    uint64_t b = fetch64(s + 8);
+    uint64_t c = fetch64(s + len - 8) * mul;
+    uint64_t d = fetch64(s + len - 16) * k2;
+    uint64_t y = rotr(a + b, 43) + rotr(c, 30) + d;
+    uint64_t z = hash_len16(y, a + rotr(b + k2, 18) + c, mul);
+    uint64_t e = fetch64(s + 16) * mul;
+    uint64_t f = fetch64(s + 24);
+    uint64_t g = (y + fetch64(s + len - 32)) * mul;
+    uint64_t h = (z + fetch64(s + len - 24)) * mul;
+    return hash_len16(rotr(e + f, 43) + rotr(g, 30) + h, e + rotr(f + a, 18) + g, mul);
+  }
+  const uint64_t seed = 81;
+  uint64_t x = seed;
+  uint64_t y = seed * k1 + 113;
+  uint64_t z = shift_mix(y * k2 + 113) * k2;
+  Pair v{0, 0}, w{0, 0};
+  x = x * k2 + fetch64(s);
+  const uint8_t *end = s + ((len - 1) / 64) * 64;
+  const uint8_t *last64 = end + ((len - 1) & 63) - 63;
+  do {
+    x = rotr(x + y + v.first + fetch64(s + 8), 37) * k1;
+    y = rotr(y + v.second + fetch64(s + 48), 42) * k1;
+    x ^= w.second;
+    y += v.first + fetch64(s + 40);
+    z = rotr(z + w.first, 33) * k1;
+    v = weak32(s, v.second * k1, x + w.first);
+    w = weak32(s + 32, z + w.second, y + fetch64(s + 16));
+    uint64_t t = z;
+    z = x;
+    x = t;
+    s += 64;
+  } while (s != end);
+  uint64_t mul = k1 + ((z & 0xff) << 1);
+  s = last64;
+  w.first += ((len - 1) & 63);
+  v.first += w.first;
+  w.first += v.first;
+  x = rotr(x + y + v.first + fetch64(s + 8), 37) * mul;
+  y = rotr(y + v.second + fetch64(s + 48), 42) * mul;
+  x ^= w.second * 9;
+  y += v.first * 9 + fetch64(s + 40);
+  z = rotr(z + w.first, 33) * mul;
+  v = weak32(s, v.second * mul, x + w.first);
+  w = weak32(s + 32, z + w.second, y + fetch64(s + 16));
+  {
+    uint64_t t = z;
+    z = x;
+    x = t;
+  }
+  return hash_len16(hash_len16(v.first, w.first, mul) + shift_mix(y) * k0 + z, hash_len16(v.second, w.second, mul) + x,
+                    mul);
+}
+
+__device__ __forceinline__ uint64_t fingerprint_cat64(uint64_t fp1, uint64_t fp2) {
+  const uint64_t kMul = 0xc6a4a7935bd1e995ULL;
+  uint64_t r = fp1 ^ kMul;
+  r ^= shift_mix(fp2 * kMul) * kMul;
+  r *= kMul;
+  r = shift_mix(r) * kMul;
+  r = shift_mix(r);
+  return r;
+}
+
+__global__ void k_fingerprint64(const uint8_t *__restrict__ bytes, const int32_t *__restrict__ tok_offs, int64_t ntok,
+                                uint64_t *__restrict__ out) {
+  int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= ntok) return;
+  int32_t o0 = tok_offs[t], o1 = tok_offs[t + 1];
+  out[t] = fingerprint64(bytes + o0, (uint32_t)(o1 - o0));
+}
+
+// first bag g with token_bag_offs[g+1] > t  (bags may be empty)
+__device__ __forceinline__ int64_t bag_of_token(const int32_t *__restrict__ offs, int64_t nbags, int32_t t) {
+  int64_t lo = 0, hi = nbags - 1;
+  while (lo < hi) {
+    int64_t mid = (lo + hi) >> 1;
+    if (offs[mid + 1] > t) hi = mid; else lo = mid + 1;
+  }
+  return lo;
+}
+
+__global__ void k_hash_bucket(const uint8_t *__restrict__ bytes, const int32_t *__restrict__ tok_offs, int64_t ntok,
+                              const int32_t *__restrict__ token_bag_offs, int64_t nbags,
+                              const wd_slot_t *__restrict__ slots, int32_t S, int32_t *__restrict__ out_ids) {
+  int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= ntok) return;
+  int32_t o0 = tok_offs[t], o1 = tok_offs[t + 1];
+  uint64_t fp = fingerprint64(bytes + o0, (uint32_t)(o1 - o0));
+  int64_t bag = token_bag_offs ? bag_of_token(token_bag_offs, nbags, (int32_t)t) : t;
+  uint64_t nb = (uint64_t)slots[bag % S].num_buckets;
+  out_ids[t] = (int32_t)(fp % nb);
+}
+
+__global__ void k_emit_hash_slot(const uint64_t *__restrict__ fp, const int32_t *__restrict__ feat_offs, int64_t batch,
+                                 uint64_t num_buckets, const int32_t *__restrict__ bag_offs, int32_t S, int32_t slot,
+                                 int32_t *__restrict__ ids) {
+  int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= batch) return;
+  int32_t f0 = feat_offs[b], f1 = feat_offs[b + 1];
+  int32_t o = bag_offs[b * S + slot];
+  for (int32_t j = f0; j < f1; ++j) ids[o + (j - f0)] = (int32_t)(fp[j] % num_buckets);
+}
+
+__global__ void k_emit_int_slot(const int32_t *__restrict__ vals, const int32_t *__restrict__ feat_offs, int64_t batch,
+                                const int32_t *__restrict__ bag_offs, int32_t S, int32_t slot,
+                                int32_t *__restrict__ ids) {
+  int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= batch) return;
+  int32_t f0 = feat_offs[b], f1 = feat_offs[b + 1];
+  int32_t o = bag_offs[b * S + slot];
+  for (int32_t j = f0; j < f1; ++j) ids[o + (j - f0)] = vals[j];
+}
+
+struct CrossArgs {
+  const uint64_t *vals[WD_MAX_CROSS_KEYS];
+  const int32_t *offs[WD_MAX_CROSS_KEYS];
+  int32_t nkeys;
+};
+
+// One lane per example; the product of a cross is tiny (1..prod Lmax) for CTR data.
+__global__ void k_cross_hash(CrossArgs a, int64_t batch, uint64_t hash_key, uint64_t num_buckets,
+                             const int32_t *__restrict__ bag_offs, int32_t S, int32_t slot, int32_t *__restrict__ ids) {
+  int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= batch) return;
+  int32_t base[WD_MAX_CROSS_KEYS], cnt[WD_MAX_CROSS_KEYS];
+  int64_t total = 1;
+#pragma unroll
+  for (int k = 0; k < WD_MAX_CROSS_KEYS; ++k) {
+    if (k < a.nkeys) {
+      base[k] = a.offs[k][b];
+      cnt[k] = a.offs[k][b + 1] - base[k];
+      total *= cnt[k];
+    }
+  }
+  int32_t o = bag_offs[b * S + slot];
+  const uint64_t m = num_buckets > 0 ? num_buckets : (uint64_t)INT64_MAX;
+  for (int64_t j = 0; j < total; ++j) {
+    // mixed-radix decode of j, last key fastest: digits consumed from the last key backwards,
+    // FingerprintCat64 must be applied in key order, so decode first.
+    int32_t idx[WD_MAX_CROSS_KEYS];
+    int64_t r = j;
+#pragma unroll
+    for (int k = WD_MAX_CROSS_KEYS - 1; k >= 0; --k) {
+      if (k < a.nkeys) {
+        idx[k] = (int32_t)(r % cnt[k]);
+        r /= cnt[k];
+      }
+    }
+    uint64_t h = hash_key;
+#pragma unroll
+    for (int k = 0; k < WD_MAX_CROSS_KEYS; ++k) {
+      if (k < a.nkeys) h = fingerprint_cat64(h, a.vals[k][base[k] + idx[k]]);
+    }
+    ids[o + j] = (int32_t)(h % m);
+  }
+}
+
+}  // namespace
+
+extern "C" int wd_fingerprint64(const uint8_t *bytes, const int32_t *tok_offs, int64_t ntok, uint64_t *out_fp,
+                                wd_stream_t stream) {
+  if (ntok <= 0) return WD_OK;
+  WD_REQUIRE(bytes && tok_offs && out_fp, "null pointer");
+  hipLaunchKernelGGL(k_fingerprint64, dim3((unsigned)wd::ceil_div(ntok, 256)), dim3(256), 0, wd::as_stream(stream),
+                     bytes, tok_offs, ntok, out_fp);
+  return wd::check_launch("wd_fingerprint64");
+}
+
+extern "C" int wd_hash_bucket(const uint8_t *bytes, const int32_t *tok_offs, int64_t ntok,
+                              const int32_t *token_bag_offs, int64_t nbags, const wd_slot_t *slots, int32_t S,
+                              int32_t *out_ids, wd_stream_t stream) {
+  if (ntok <= 0) return WD_OK;
+  WD_REQUIRE(bytes && tok_offs && slots && out_ids, "null pointer");
+  WD_REQUIRE(S > 0, "S must be > 0");
+  WD_REQUIRE(token_bag_offs || nbags == ntok, "one-token-per-bag mode needs nbags == ntok");
+  hipLaunchKernelGGL(k_hash_bucket, dim3((unsigned)wd::ceil_div(ntok, 256)), dim3(256), 0, wd::as_stream(stream),
+                     bytes, tok_offs, ntok, token_bag_offs, nbags, slots, S, out_ids);
+  return wd::check_launch("wd_hash_bucket");
+}
+
+extern "C" int wd_emit_hash_slot(const uint64_t *fp, const int32_t *feat_offs, int64_t batch, uint64_t num_buckets,
+                                 const int32_t *bag_offs, int32_t S, int32_t slot, int32_t *ids, wd_stream_t stream) {
+  if (batch <= 0) return WD_OK;
+  WD_REQUIRE(feat_offs && bag_offs && ids, "null pointer");
+  WD_REQUIRE(num_buckets > 0 && num_buckets < (1ull << 31), "num_buckets out of range");
+  WD_REQUIRE(slot >= 0 && slot < S, "slot out of range");
+  hipLaunchKernelGGL(k_emit_hash_slot, dim3((unsigned)wd::ceil_div(batch, 256)), dim3(256), 0, wd::as_stream(stream),
+                     fp, feat_offs, batch, num_buckets, bag_offs, S, slot, ids);
+  return wd::check_launch("wd_emit_hash_slot");
+}
+
+extern "C" int wd_emit_int_slot(const int32_t *vals, const int32_t *feat_offs, int64_t batch, const int32_t *bag_offs,
+                                int32_t S, int32_t slot, int32_t *ids, wd_stream_t stream) {
+  if (batch <= 0) return WD_OK;
+  WD_REQUIRE(feat_offs && bag_offs && ids, "null pointer");
+  WD_REQUIRE(slot >= 0 && slot < S, "slot out of range");
+  hipLaunchKernelGGL(k_emit_int_slot, dim3((unsigned)wd::ceil_div(batch, 256)), dim3(256), 0, wd::as_stream(stream),
+                     vals, feat_offs, batch, bag_offs, S, slot, ids);
+  return wd::check_launch("wd_emit_int_slot");
+}
+
+extern "C" int wd_cross_hash(const wd_cross_keys_t *keys_host, int64_t batch, uint64_t hash_key, uint64_t num_buckets,
+                             const int32_t *bag_offs, int32_t S, int32_t slot, int32_t *ids, wd_stream_t stream) {
+  if (batch <= 0) return WD_OK;
+  WD_REQUIRE(keys_host && bag_offs && ids, "null pointer");
+  WD_REQUIRE(keys_host->nkeys >= 1 && keys_host->nkeys <= WD_MAX_CROSS_KEYS, "nkeys out of range");
+  WD_REQUIRE(num_buckets < (1ull << 31), "num_buckets must fit int32 ids");
+  WD_REQUIRE(slot >= 0 && slot < S, "slot out of range");
+  CrossArgs a;
+  a.nkeys = keys_host->nkeys;
+  for (int k = 0; k < WD_MAX_CROSS_KEYS; ++k) {
+    a.vals[k] = k < a.nkeys ? keys_host->vals[k] : nullptr;
+    a.offs[k] = k < a.nkeys ? keys_host->offs[k] : nullptr;
+  }
+  hipLaunchKernelGGL(k_cross_hash, dim3((unsigned)wd::ceil_div(batch, 256)), dim3(256), 0, wd::as_stream(stream), a,
+                     batch, hash_key, num_buckets, bag_offs, S, slot, ids);
+  return wd::check_launch("wd_cross_hash");
+}

@@ -1,0 +1,439 @@
+"""WideDeepEngine -- the MI355X train step behind the reference's model_fn.
+
+One engine instance = what the reference builds in ``_wide_deep_combined_model_fn``
+(python/lib/joint.py:81-269): wide logits (python/lib/linear.py:20-36) + deep logits
+(python/lib/dnn.py:43-275) -> sigmoid-CE head -> per-scope optimizers (Ftrl for `linear`,
+Adagrad for `dnn`).  All arithmetic runs in hand-written gfx950 kernels reached through the C ABI
+(include/wd_hip.h); torch is used for device memory, streams and graph capture only.
+
+There is no CPU fallback: constructing an engine without a GPU or without the built HIP library
+raises.
+"""
+import ctypes
+import math
+
+import numpy as np
+import torch
+
+from . import capi
+from .capi import call, ptr
+from .plan import BN_EPS, FeaturePlan, ModelSpec
+
+
+class DeviceBatch:
+    """One batch, resident in HBM, in the example-major bag-CSR layout (include/wd_hip.h)."""
+
+    def __init__(self, B, ids, bag_offs, dense=None, labels=None, weights=None, nnz=None):
+        self.B = int(B)
+        self.ids = ids              # int32 [nnz]
+        self.bag_offs = bag_offs    # int32 [B*S + 1]
+        self.dense = dense          # float32 [B, n_dense] or None
+        self.labels = labels        # float32 [B] or None
+        self.weights = weights      # float32 [B] or None
+        self.nnz = int(nnz if nnz is not None else ids.numel())
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+class WideDeepEngine:
+    def __init__(self, spec: ModelSpec, max_batch=8192, max_nnz=None, device="cuda", seed=0):
+        if not torch.cuda.is_available():
+            raise capi.WdError("WideDeepEngine needs a GPU (MI355X / gfx950); there is no CPU fallback")
+        capi.load()
+        if spec.dropout:
+            raise NotImplementedError("dnn_dropout is not implemented yet (reference default is empty)")
+        if spec.has_deep and spec.dnn_opt[0] != "Adagrad":
+            raise NotImplementedError("dnn_optimizer %s: only Adagrad is implemented" % (spec.dnn_opt[0],))
+        if spec.has_wide and spec.lin_opt[0] != "Ftrl":
+            raise NotImplementedError("linear_optimizer %s: only Ftrl is implemented" % (spec.lin_opt[0],))
+        self.spec = spec
+        self.plan = plan = FeaturePlan(spec)
+        self.device = torch.device(device)
+        self.max_batch = int(max_batch)
+        self.max_nnz = int(max_nnz) if max_nnz else self.max_batch * max(plan.S, 1) * 2
+        self.inv = 1.0 / math.sqrt(1.0 + BN_EPS)
+        self.act_id = capi.ACT_IDS[spec.activation]
+        self.global_step = 0
+        dev = self.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        i32 = dict(dtype=torch.int32, device=dev)
+
+        # ---- slot descriptors --------------------------------------------------------------
+        S = plan.S
+        arr = (capi.WdSlot * max(S, 1))()
+        for i, s in enumerate(plan.slots):
+            is_emb = s.deep == "embedding" and spec.has_deep
+            is_ind = s.deep == "indicator" and spec.has_deep
+            arr[i].emb_off = plan.emb_off[i]
+            arr[i].row_base = plan.row_base[i]
+            arr[i].num_buckets = int(s.num_buckets)
+            arr[i].dim = int(s.dim) if is_emb else 0
+            arr[i].out_col = plan.out_col[i]
+            arr[i].kind = capi.SLOT_EMBEDDING if is_emb else (capi.SLOT_INDICATOR if is_ind else capi.SLOT_NONE)
+            arr[i].wide = 1 if (spec.has_wide and s.wide) else 0
+        raw = np.frombuffer(bytes(arr), dtype=np.uint8).copy()
+        self.slots_dev = torch.from_numpy(raw).to(dev)
+        self.group_slots = {d: torch.tensor(v, **i32) for d, v in plan.emb_groups.items()}
+        self.ind_slots_dev = torch.tensor(plan.ind_slots, **i32) if plan.ind_slots else None
+        if plan.dense_cols:
+            darr = (capi.WdDenseCol * len(plan.dense_cols))()
+            for j, d in enumerate(plan.dense_cols):
+                darr[j].p0, darr[j].p1, darr[j].kind, darr[j].out_col = d.p0, d.p1, d.kind, plan.dense_out_col[j]
+            self.dense_cols_dev = torch.from_numpy(np.frombuffer(bytes(darr), dtype=np.uint8).copy()).to(dev)
+        else:
+            self.dense_cols_dev = None
+
+        # ---- sparse state ------------------------------------------------------------------
+        g = torch.Generator(device=dev)
+        g.manual_seed(seed)
+        self.gen = g
+        if spec.has_deep:
+            self.emb = torch.zeros(max(plan.emb_elems, 4), **f32)
+            self.emb_acc = torch.full((max(plan.emb_elems, 4),), float(spec.dnn_opt[2]), **f32)
+            for i, s in enumerate(plan.slots):
+                if plan.emb_off[i] >= 0:
+                    v = self.emb[plan.emb_off[i]: plan.emb_off[i] + s.num_buckets * s.dim]
+                    std = 1.0 / math.sqrt(s.dim)
+                    # embedding_column initializer: truncated_normal(0, 1/sqrt(dim))  
+                    torch.nn.init.trunc_normal_(v, mean=0.0, std=std, a=-2 * std, b=2 * std, generator=g)
+        else:
+            self.emb = self.emb_acc = None
+        if spec.has_wide:
+            self.wide = torch.zeros(max(plan.total_rows, 1), 4, **f32)   # {w, z, n, -}
+            self.wide[:, 2] = float(spec.lin_opt[4])
+            self.bias = torch.zeros(4, **f32)
+            self.bias[2] = float(spec.lin_opt[4])
+        else:
+            self.wide = self.bias = None
+
+        # ---- dense state -------------------------------------------------------------------
+        B = self.max_batch
+        self.towers = []
+        if spec.has_deep:
+            n = plan.dense_param_elems
+            self.P = torch.zeros(n, **f32)
+            self.Pacc = torch.full((n,), float(spec.dnn_opt[2]), **f32)
+            self.G = torch.zeros(n, **f32)
+            for ti, tl in enumerate(plan.towers):
+                metas = plan.layer_meta[ti]
+                L = len(tl.hidden)
+                tw = {"layout": tl, "metas": metas, "L": L}
+                tw["act"] = torch.zeros(B, tl.ld, **f32)
+                tw["dact"] = torch.zeros(B, tl.ld, **f32)
+                maxN = max([m["N"] for m in metas])
+                tw["dz"] = torch.zeros(B * maxN, **f32)
+                tw["logit"] = torch.zeros(B, **f32)
+                tw["Wf"], tw["bf"], tw["s"], tw["t"], tw["gidx"], tw["bidx"], tw["nsplit"] = [], [], [], [], [], [], []
+                gmax = 4
+                for l, m in enumerate(metas):
+                    K, N = m["K"], m["N"]
+                    tw["Wf"].append(torch.zeros(K * N, **f32))
+                    tw["bf"].append(torch.zeros(N, **f32))
+                    tw["s"].append(torch.zeros(K, **f32))
+                    tw["t"].append(torch.zeros(K, **f32))
+                    tw["gidx"].append(torch.from_numpy(m["gamma_idx"]).to(dev))
+                    tw["bidx"].append(torch.from_numpy(m["beta_idx"]).to(dev))
+                    tiles = math.ceil((K + 1) / 64) * math.ceil(N / 64)
+                    ns = max(1, min(math.ceil(768 / tiles), max(1, B // 128)))
+                    tw["nsplit"].append(ns)
+                    gmax = max(gmax, ns * (K + 1) * N)
+                    # tf.glorot_uniform_initializer kernel, zero bias, gamma 1, beta 0  
+                    Ktf = len(plan.tf_rows_of_layer(ti, l))
+                    lim = math.sqrt(6.0 / (Ktf + N))
+                    W = self.P[m["w_off"]: m["w_off"] + K * N].view(K, N)
+                    rows = torch.from_numpy(plan.tf_rows_of_layer(ti, l)).to(dev)
+                    Wtf = (torch.rand(Ktf, N, generator=g, **f32) * 2 - 1) * lim
+                    W[rows] = Wtf
+                    if "gamma_off" in m:
+                        self.P[m["gamma_off"]: m["gamma_off"] + N] = 1.0
+                tw["Gpart"] = torch.zeros(gmax, **f32)
+                self.towers.append(tw)
+            self.dnn_logit = torch.zeros(B, **f32)
+        else:
+            self.P = self.Pacc = self.G = None
+            self.dnn_logit = None
+
+        # ---- per-step buffers --------------------------------------------------------------
+        self.wide_logit = torch.zeros(B, **f32) if spec.has_wide else None
+        self.logit = torch.zeros(B, **f32)
+        self.prob = torch.zeros(B, **f32)
+        self.dlogit = torch.zeros(B, **f32)
+        self.loss = torch.zeros(1, **f32)
+        M = self.max_nnz
+        self.keys = torch.zeros(M, dtype=torch.int32, device=dev)
+        self.vals = torch.zeros(M, **i32)
+        self.keys_sorted = torch.zeros(M, dtype=torch.int32, device=dev)
+        self.vals_sorted = torch.zeros(M, **i32)
+        self.sort_ws_bytes = int(call("wd_sort_workspace_bytes", M, plan.key_bits))
+        if self.sort_ws_bytes == 0:
+            raise capi.WdError("wd_sort_workspace_bytes failed")
+        self.sort_ws = torch.zeros(self.sort_ws_bytes, dtype=torch.uint8, device=dev)
+        self._graph = None
+
+    # ------------------------------------------------------------------------------------------
+    # forward
+    # ------------------------------------------------------------------------------------------
+    def _check_batch(self, bt):
+        if bt.B > self.max_batch:
+            raise ValueError("batch %d exceeds max_batch %d" % (bt.B, self.max_batch))
+        if bt.nnz > self.max_nnz:
+            raise ValueError("nnz %d exceeds max_nnz %d" % (bt.nnz, self.max_nnz))
+
+    def _x_ptr(self, tw):
+        return tw["act"].data_ptr() + 4 * tw["layout"].seg_start[0]
+
+    def forward(self, bt: DeviceBatch, need_loss=True):
+        """Fills self.logit / self.prob (and self.dlogit / self.loss when labels are given)."""
+        self._check_batch(bt)
+        plan, spec, st = self.plan, self.spec, _stream()
+        B, S = bt.B, plan.S
+        if spec.has_deep:
+            tw0 = self.towers[0]
+            ld = tw0["layout"].ld
+            xp = self._x_ptr(tw0)
+            for dim, gs in self.group_slots.items():
+                call("wd_embag_fwd", ptr(self.emb), ptr(self.slots_dev), S, ptr(gs), gs.numel(), dim, ptr(bt.ids),
+                     ptr(bt.bag_offs), B, xp, ld, st)
+            if self.ind_slots_dev is not None:
+                call("wd_indicator_fwd", ptr(self.slots_dev), S, ptr(self.ind_slots_dev), self.ind_slots_dev.numel(),
+                     ptr(bt.ids), ptr(bt.bag_offs), B, xp, ld, st)
+            if self.dense_cols_dev is not None:
+                call("wd_dense_fwd", ptr(bt.dense), bt.dense.stride(0), ptr(self.dense_cols_dev),
+                     len(plan.dense_cols), B, xp, ld, st)
+            for ti, tw in enumerate(self.towers):
+                tl = tw["layout"]
+                if ti > 0:  # towers share the input layer (AUTO_REUSE, python/lib/dnn.py:83-90)
+                    w0 = tl.seg_width[0]
+                    tw["act"][:B, tl.seg_start[0]: tl.seg_start[0] + w0].copy_(
+                        tw0["act"][:B, tw0["layout"].seg_start[0]: tw0["layout"].seg_start[0] + w0])
+                self._tower_forward(tw, B, st)
+            if len(self.towers) == 1:
+                dnn_logit = self.towers[0]["logit"]
+            else:
+                torch.add(self.towers[0]["logit"], self.towers[1]["logit"], out=self.dnn_logit)
+                for tw in self.towers[2:]:
+                    self.dnn_logit.add_(tw["logit"])
+                dnn_logit = self.dnn_logit
+        else:
+            dnn_logit = None
+        if spec.has_wide:
+            call("wd_wide_fwd", ptr(self.wide), ptr(self.bias), ptr(self.slots_dev), S, ptr(bt.ids), ptr(bt.bag_offs),
+                 B, ptr(self.wide_logit), st)
+        if bt.labels is not None and need_loss:
+            self.loss.zero_()
+            call("wd_bce_sum_fwd_bwd", ptr(dnn_logit), ptr(self.wide_logit), ptr(bt.labels), ptr(bt.weights), B,
+                 ptr(self.logit), ptr(self.prob), ptr(self.dlogit), ptr(self.loss), st)
+        else:
+            # logits / probabilities only: reuse the head kernel with a zero label vector
+            self.loss.zero_()
+            zeros = self.dlogit
+            zeros[:B].zero_()
+            call("wd_bce_sum_fwd_bwd", ptr(dnn_logit), ptr(self.wide_logit), ptr(zeros), None, B, ptr(self.logit),
+                 ptr(self.prob), None, None, st)
+        return self.logit[:B]
+
+    def _tower_forward(self, tw, B, st):
+        tl, metas, L = tw["layout"], tw["metas"], tw["L"]
+        act = tw["act"]
+        for l, m in enumerate(metas):
+            K, N = m["K"], m["N"]
+            call("wd_fold_affine", ptr(self.P), m["w_off"], m["b_off"], ptr(tw["gidx"][l]), ptr(tw["bidx"][l]),
+                 self.inv, ptr(tw["Wf"][l]), ptr(tw["bf"][l]), ptr(tw["s"][l]), ptr(tw["t"][l]), K, N, st)
+            a_ptr = act.data_ptr() + 4 * tl.in_start[l]
+            if l < L:
+                c_ptr, ldc, act_id = act.data_ptr() + 4 * tl.seg_start[l + 1], tl.ld, self.act_id
+            else:
+                c_ptr, ldc, act_id = tw["logit"].data_ptr(), 1, 0
+            call("wd_gemm_nn_bias_act", a_ptr, tl.ld, ptr(tw["Wf"][l]), N, ptr(tw["bf"][l]), act_id, c_ptr, ldc, B, N,
+                 K, st)
+
+    # ------------------------------------------------------------------------------------------
+    # backward + optimizers
+    # ------------------------------------------------------------------------------------------
+    def _tower_backward(self, tw, B, st, need_dx):
+        tl, metas, L = tw["layout"], tw["metas"], tw["L"]
+        act, dact = tw["act"], tw["dact"]
+        accumulate = 0 if tl.mode == "simple" else 1
+        if accumulate:
+            dact[:B].zero_()
+        for l in range(L, -1, -1):
+            m = metas[l]
+            K, N = m["K"], m["N"]
+            if l == L:
+                dz_ptr, lddz = self.dlogit.data_ptr(), 1
+            else:
+                seg = tl.seg_start[l + 1]
+                dz_ptr, lddz = tw["dz"].data_ptr(), N
+                call("wd_act_bwd", dact.data_ptr() + 4 * seg, tl.ld, act.data_ptr() + 4 * seg, tl.ld, self.act_id,
+                     dz_ptr, lddz, B, N, st)
+            a_ptr = act.data_ptr() + 4 * tl.in_start[l]
+            ns = tw["nsplit"][l]
+            call("wd_gemm_tn_splitk", a_ptr, tl.ld, dz_ptr, lddz, ptr(tw["Gpart"]), K, N, B, ns, 1, st)
+            call("wd_mlp_finalize", ptr(tw["Gpart"]), ns, ptr(self.P), m["w_off"], m["b_off"], ptr(tw["s"][l]),
+                 ptr(tw["t"][l]), ptr(tw["gidx"][l]), ptr(tw["bidx"][l]), self.inv, ptr(self.G), K, N, st)
+            if l > 0 or need_dx:
+                call("wd_gemm_nt", dz_ptr, lddz, ptr(tw["Wf"][l]), N, dact.data_ptr() + 4 * tl.in_start[l], tl.ld, B,
+                     K, N, accumulate, st)
+
+    def sort_occurrences(self, bt, st):
+        plan = self.plan
+        call("wd_build_sort_keys", ptr(self.slots_dev), plan.S, ptr(bt.ids), ptr(bt.bag_offs), bt.B * plan.S, bt.nnz,
+             ptr(self.keys), ptr(self.vals), st)
+        call("wd_sort_pairs", ptr(self.keys), ptr(self.vals), ptr(self.keys_sorted), ptr(self.vals_sorted), bt.nnz,
+             plan.key_bits, ptr(self.sort_ws), self.sort_ws_bytes, st)
+
+    def backward_and_update(self, bt: DeviceBatch):
+        plan, spec, st = self.plan, self.spec, _stream()
+        B, S = bt.B, plan.S
+        has_emb = bool(self.group_slots) if spec.has_deep else False
+        if spec.has_deep:
+            self.G.zero_()
+            for tw in self.towers:
+                self._tower_backward(tw, B, st, need_dx=has_emb)
+            tw0 = self.towers[0]
+            tl0 = tw0["layout"]
+            if has_emb and len(self.towers) > 1:
+                w0 = tl0.seg_width[0]
+                dx0 = tw0["dact"][:B, tl0.seg_start[0]: tl0.seg_start[0] + w0]
+                for tw in self.towers[1:]:
+                    tl = tw["layout"]
+                    dx0.add_(tw["dact"][:B, tl.seg_start[0]: tl.seg_start[0] + w0])
+            call("wd_adagrad_dense", ptr(self.P), ptr(self.Pacc), ptr(self.G), self.P.numel(), float(spec.dnn_opt[1]),
+                 st)
+        if bt.nnz > 0 and (has_emb or spec.has_wide):
+            self.sort_occurrences(bt, st)
+            if has_emb:
+                dx_ptr = tw0["dact"].data_ptr() + 4 * tl0.seg_start[0]
+                for dim in self.group_slots:
+                    call("wd_embag_bwd_adagrad", ptr(self.emb), ptr(self.emb_acc), ptr(self.slots_dev), S, dim,
+                         ptr(self.keys_sorted), ptr(self.vals_sorted), bt.nnz, ptr(bt.bag_offs), dx_ptr, tl0.ld,
+                         float(spec.dnn_opt[1]), st)
+            if spec.has_wide:
+                _, lr, l1, l2, _ = spec.lin_opt
+                call("wd_wide_bwd_ftrl", ptr(self.wide), ptr(self.slots_dev), S, ptr(self.keys_sorted),
+                     ptr(self.vals_sorted), bt.nnz, ptr(self.dlogit), float(lr), float(l1), float(l2), st)
+        if spec.has_wide:
+            _, lr, l1, l2, _ = spec.lin_opt
+            call("wd_bias_ftrl", ptr(self.bias), ptr(self.dlogit), B, float(lr), float(l1), float(l2), st)
+
+    def train_step(self, bt: DeviceBatch):
+        """One step of python/lib/joint.py:224-262: forward, batch-SUM loss, both optimizers."""
+        if bt.labels is None:
+            raise ValueError("train_step needs labels")
+        self.forward(bt, need_loss=True)
+        self.backward_and_update(bt)
+        # the reference bumps global_step once per minimize() plus the explicit assign_add (quirk C.4)
+        self.global_step += 3 if self.spec.model_type == "wide_deep" else 2
+        return self.loss
+
+    # ------------------------------------------------------------------------------------------
+    # HIP-graph capture of the whole step (fixed batch geometry)
+    # ------------------------------------------------------------------------------------------
+    def capture_train_step(self, bt: DeviceBatch, warmup=2):
+        """Capture forward+backward+updates on `bt`'s buffers into a hipGraph; returns a replay callable.
+        The caller refreshes the contents of bt's tensors in place between replays."""
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self.train_step(bt)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            self.train_step(bt)
+        self._graph = graph
+
+        def replay():
+            graph.replay()
+            self.global_step += 3 if self.spec.model_type == "wide_deep" else 2
+            return self.loss
+
+        return replay
+
+    # ------------------------------------------------------------------------------------------
+    # state exchange in the reference's checkpoint naming
+    # ------------------------------------------------------------------------------------------
+    def export_state(self):
+        plan, spec = self.plan, self.spec
+        out = {}
+        if spec.has_deep:
+            for i, s in enumerate(plan.slots):
+                if plan.emb_off[i] >= 0:
+                    nm = "dnn/input_from_feature_columns/input_layer/%s/embedding_weights" % s.deep_name
+                    sl = slice(plan.emb_off[i], plan.emb_off[i] + s.num_buckets * s.dim)
+                    out[nm] = self.emb[sl].view(s.num_buckets, s.dim).cpu().clone()
+                    out[nm + "/Adagrad"] = self.emb_acc[sl].view(s.num_buckets, s.dim).cpu().clone()
+            for ti, tw in enumerate(self.towers):
+                p = "dnn/dnn_%d/" % (ti + 1)
+                for l, m in enumerate(tw["metas"]):
+                    K, N = m["K"], m["N"]
+                    scope = p + ("hiddenlayer_%d/" % l if l < tw["L"] else "logits/")
+                    rows = torch.from_numpy(plan.tf_rows_of_layer(ti, l)).to(self.device)
+                    for buf, suf in ((self.P, ""), (self.Pacc, "/Adagrad")):
+                        out[scope + "kernel" + suf] = buf[m["w_off"]: m["w_off"] + K * N].view(K, N)[rows].cpu().clone()
+                        out[scope + "bias" + suf] = buf[m["b_off"]: m["b_off"] + N].cpu().clone()
+                        if "gamma_off" in m:
+                            out[scope + "batch_normalization/gamma" + suf] = buf[m["gamma_off"]: m["gamma_off"] + N].cpu().clone()
+                            out[scope + "batch_normalization/beta" + suf] = buf[m["beta_off"]: m["beta_off"] + N].cpu().clone()
+                    if "gamma_off" in m:
+                        out[scope + "batch_normalization/moving_mean"] = torch.zeros(N)
+                        out[scope + "batch_normalization/moving_variance"] = torch.ones(N)
+        if spec.has_wide:
+            for i, s in enumerate(plan.slots):
+                if s.wide:
+                    nm = "linear/linear_model/%s/weights" % s.name
+                    r0 = plan.row_base[i]
+                    blk = self.wide[r0: r0 + s.num_buckets].cpu()
+                    out[nm] = blk[:, 0:1].clone()
+                    out[nm + "/Ftrl_1"] = blk[:, 1:2].clone()
+                    out[nm + "/Ftrl"] = blk[:, 2:3].clone()
+            b = self.bias.cpu()
+            out["linear/linear_model/bias_weights"] = b[0:1].clone()
+            out["linear/linear_model/bias_weights/Ftrl_1"] = b[1:2].clone()
+            out["linear/linear_model/bias_weights/Ftrl"] = b[2:3].clone()
+        out["global_step"] = torch.tensor(self.global_step, dtype=torch.int64)
+        return out
+
+    def import_state(self, state):
+        plan, spec, dev = self.plan, self.spec, self.device
+        if spec.has_deep:
+            for i, s in enumerate(plan.slots):
+                if plan.emb_off[i] >= 0:
+                    nm = "dnn/input_from_feature_columns/input_layer/%s/embedding_weights" % s.deep_name
+                    sl = slice(plan.emb_off[i], plan.emb_off[i] + s.num_buckets * s.dim)
+                    self.emb[sl] = state[nm].to(dev).reshape(-1)
+                    if nm + "/Adagrad" in state:
+                        self.emb_acc[sl] = state[nm + "/Adagrad"].to(dev).reshape(-1)
+            for ti, tw in enumerate(self.towers):
+                p = "dnn/dnn_%d/" % (ti + 1)
+                for l, m in enumerate(tw["metas"]):
+                    K, N = m["K"], m["N"]
+                    scope = p + ("hiddenlayer_%d/" % l if l < tw["L"] else "logits/")
+                    rows = torch.from_numpy(plan.tf_rows_of_layer(ti, l)).to(dev)
+                    for buf, suf in ((self.P, ""), (self.Pacc, "/Adagrad")):
+                        if scope + "kernel" + suf not in state:
+                            continue
+                        buf[m["w_off"]: m["w_off"] + K * N].view(K, N)[rows] = state[scope + "kernel" + suf].to(dev)
+                        buf[m["b_off"]: m["b_off"] + N] = state[scope + "bias" + suf].to(dev)
+                        if "gamma_off" in m:
+                            buf[m["gamma_off"]: m["gamma_off"] + N] = state[scope + "batch_normalization/gamma" + suf].to(dev)
+                            buf[m["beta_off"]: m["beta_off"] + N] = state[scope + "batch_normalization/beta" + suf].to(dev)
+        if spec.has_wide:
+            for i, s in enumerate(plan.slots):
+                if s.wide:
+                    nm = "linear/linear_model/%s/weights" % s.name
+                    r0 = plan.row_base[i]
+                    self.wide[r0: r0 + s.num_buckets, 0:1] = state[nm].to(dev)
+                    if nm + "/Ftrl" in state:
+                        self.wide[r0: r0 + s.num_buckets, 1:2] = state[nm + "/Ftrl_1"].to(dev)
+                        self.wide[r0: r0 + s.num_buckets, 2:3] = state[nm + "/Ftrl"].to(dev)
+            nm = "linear/linear_model/bias_weights"
+            self.bias[0:1] = state[nm].to(dev)
+            if nm + "/Ftrl" in state:
+                self.bias[1:2] = state[nm + "/Ftrl_1"].to(dev)
+                self.bias[2:3] = state[nm + "/Ftrl"].to(dev)
+        if "global_step" in state:
+            self.global_step = int(state["global_step"])

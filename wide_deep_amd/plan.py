@@ -1,0 +1,327 @@
+"""Feature -> column planning (host logic of the hot path).
+
+Mirrors what the reference's ``_build_model_columns`` (python/lib/build_estimator.py:49-169) does
+at graph-build time, but produces a flat *plan* for the gfx950 kernels instead of
+tf.feature_column objects:
+
+  * every categorical column (hash / vocab / identity / bucketized / crossed) is a *slot* of the
+    example-major bag CSR;
+  * slots get a contiguous row range in ONE fused row space (wide table, sort keys) and, when they
+    carry an embedding, an element offset in ONE flat embedding buffer;
+  * the deep input matrix x is laid out embedding columns first (16-byte aligned for float4
+    stores), then indicator columns, then numeric columns; ``tf_input_perm`` maps the
+    name-sorted TF concat order to these internal columns so that weights can be
+    exchanged with the reference's checkpoint naming.
+"""
+import math
+from dataclasses import dataclass, field
+from typing import List, Optional
+
+import numpy as np
+
+BN_EPS = 1e-3  # tf.layers.batch_normalization default epsilon
+
+
+def embedding_dim(num_buckets):
+    """Reference rule (python/lib/build_estimator.py:57-59): 2**ceil(ln(d**0.25)), natural log."""
+    return int(np.power(2, np.ceil(np.log(num_buckets ** 0.25))))
+
+
+@dataclass
+class CrossKey:
+    feature: str
+    kind: str  # 'string' | 'identity' | 'bucket'
+    num_buckets: int = 0
+    boundaries: Optional[List[float]] = None
+
+
+@dataclass
+class CatSlot:
+    name: str                 # TF categorical column name (= linear_model variable scope)
+    kind: str                 # 'hash' | 'vocab' | 'identity' | 'bucket' | 'cross'
+    num_buckets: int
+    feature: Optional[str] = None
+    deep: Optional[str] = None   # 'embedding' | 'indicator' | None
+    dim: int = 0
+    wide: bool = True
+    vocab: Optional[List[str]] = None
+    boundaries: Optional[List[float]] = None
+    normalizer: Optional[tuple] = None      # ('min_max'|'standard'|'log', p0, p1) applied BEFORE bucketize (quirk C.5)
+    cross_keys: Optional[List[CrossKey]] = None
+    hash_key: int = 0xDECAFCAFFE
+
+    @property
+    def deep_name(self):
+        if self.deep == "embedding":
+            return self.name + "_embedding"
+        if self.deep == "indicator":
+            return self.name + "_indicator"
+        return None
+
+
+@dataclass
+class DenseCol:
+    name: str
+    feature: str
+    kind: int = 0       # 0 identity, 1 min_max, 2 standard, 3 log
+    p0: float = 0.0
+    p1: float = 1.0
+
+
+@dataclass
+class TowerSpec:
+    hidden_units: List[int]
+    mode: str = "simple"
+
+
+@dataclass
+class ModelSpec:
+    model_type: str = "wide_deep"          # 'wide' | 'deep' | 'wide_deep'
+    slots: List[CatSlot] = field(default_factory=list)
+    dense_cols: List[DenseCol] = field(default_factory=list)
+    towers: List[TowerSpec] = field(default_factory=list)
+    activation: str = "relu"
+    batch_norm: bool = True
+    dropout: Optional[float] = None
+    dnn_opt: tuple = ("Adagrad", 0.05, 0.1)            # name, lr, initial_accumulator_value
+    lin_opt: tuple = ("Ftrl", 0.1, 0.5, 1.0, 0.1)      # name, lr, l1, l2, initial_accumulator_value
+    use_weight_column: bool = False
+    pos_weight: float = 1.0
+    neg_weight: float = 1.0
+
+    @property
+    def has_deep(self):
+        return self.model_type in ("deep", "wide_deep")
+
+    @property
+    def has_wide(self):
+        return self.model_type in ("wide", "wide_deep")
+
+
+def _round_up(x, m):
+    return (x + m - 1) // m * m
+
+
+class TowerLayout:
+    """Column layout of one tower's activation buffer + per-layer GEMM windows.
+
+    Segment 0 is the deep input x, segment l+1 the output of hidden layer l.  Each layer reads ONE
+    contiguous column window of the buffer (free concat):
+      simple      seg_l only
+      dense       [seg0 | seg1 | ... | seg_l]          (python/lib/dnn.py:155-173)
+      resnet      [seg_l | seg_{l-1} | ... | seg0]     (python/lib/dnn.py:175-193, concat not add: quirk C.8)
+      last_dense  hidden layers as simple, logits over [seg0 | ... | seg_L]  (python/lib/dnn.py:135-153)
+    """
+
+    def __init__(self, deep_dim, hidden, mode):
+        if mode not in ("simple", "dense", "resnet", "last_dense"):
+            raise ValueError("connected_mode `%s` is not supported by the gfx950 engine yet "
+                             "(supported: simple, dense, resnet, last_dense)" % (mode,))
+        self.mode = mode
+        self.hidden = list(hidden)
+        widths = [deep_dim] + self.hidden
+        L = len(self.hidden)
+        if mode in ("dense", "last_dense"):
+            starts, c = [], 0
+            for w in widths:
+                starts.append(c)
+                c += w
+            total = c
+        elif mode == "resnet":
+            # newest segment leftmost: [seg_L | ... | seg1 | seg0]; every layer reads a suffix window
+            starts = [0] * (L + 1)
+            c = 0
+            for l in range(L, -1, -1):
+                starts[l] = c
+                c += widths[l]
+            total = c
+        else:  # simple: every segment 16-float aligned, no window spans two segments
+            starts, c = [], 0
+            for w in widths:
+                starts.append(c)
+                c += _round_up(w, 16)
+            total = c
+        self.seg_start = starts
+        self.seg_width = widths
+        self.ld = _round_up(total, 16)
+        # per layer (hidden layers 0..L-1, then logits = index L): input window [in_start, in_start+K), list of segments
+        self.in_start, self.in_K, self.in_segs = [], [], []
+        for l in range(L + 1):
+            is_logits = l == L
+            if mode == "simple" or (mode == "last_dense" and not is_logits):
+                segs = [l]
+            elif mode in ("dense", "last_dense"):
+                segs = list(range(0, l + 1))
+            else:  # resnet
+                segs = list(range(l, -1, -1))
+            s0 = min(starts[j] for j in segs)
+            e0 = max(starts[j] + widths[j] for j in segs)
+            self.in_start.append(s0)
+            self.in_K.append(e0 - s0)
+            self.in_segs.append(segs)
+
+    def window_cols(self, l):
+        """For layer l: list of (segment, unit) for every column of its input window, -1 segment for pad."""
+        s0, K = self.in_start[l], self.in_K[l]
+        cols = [(-1, 0)] * K
+        for j in self.in_segs[l]:
+            for u in range(self.seg_width[j]):
+                cols[self.seg_start[j] + u - s0] = (j, u)
+        return cols
+
+
+class FeaturePlan:
+    def __init__(self, spec: ModelSpec):
+        self.spec = spec
+        slots = list(spec.slots)
+        emb = sorted([s for s in slots if s.deep == "embedding" and spec.has_deep],
+                     key=lambda s: (-(s.dim % 4 == 0), -s.dim, s.name))
+        ind = sorted([s for s in slots if s.deep == "indicator" and spec.has_deep], key=lambda s: s.name)
+        rest = sorted([s for s in slots if s not in emb and s not in ind], key=lambda s: s.name)
+        if not spec.has_wide:
+            rest = []  # wide-only columns are not needed by a deep-only model
+        self.slots = emb + ind + rest
+        self.S = len(self.slots)
+        self.slot_index = {s.name: i for i, s in enumerate(self.slots)}
+        self.n_emb, self.n_ind = len(emb), len(ind)
+
+        # fused categorical row space + flat embedding buffer
+        self.row_base, self.emb_off = [], []
+        r, e = 0, 0
+        for s in self.slots:
+            self.row_base.append(r)
+            r += int(s.num_buckets)
+            if s.deep == "embedding" and spec.has_deep:
+                self.emb_off.append(e)
+                e += int(s.num_buckets) * int(s.dim)
+                e = _round_up(e, 4)
+            else:
+                self.emb_off.append(-1)
+        self.total_rows = r
+        self.emb_elems = e
+        if self.total_rows >= (1 << 32):
+            raise ValueError("fused categorical row space exceeds 2^32 rows")
+        self.key_bits = max(1, int(math.ceil(math.log2(max(self.total_rows, 2)))))
+
+        # deep input columns
+        self.out_col = [-1] * self.S
+        c = 0
+        if spec.has_deep:
+            for i, s in enumerate(self.slots):
+                if s.deep == "embedding":
+                    if s.dim % 4 == 0:
+                        c = _round_up(c, 4)
+                    self.out_col[i] = c
+                    c += s.dim
+            for i, s in enumerate(self.slots):
+                if s.deep == "indicator":
+                    self.out_col[i] = c
+                    c += s.num_buckets
+        self.dense_cols = list(spec.dense_cols) if spec.has_deep else []
+        self.dense_out_col = []
+        for d in self.dense_cols:
+            self.dense_out_col.append(c)
+            c += 1
+        self.deep_dim = c          # internal width (may contain alignment holes, see tf_input_perm)
+        self.emb_groups = {}
+        for i, s in enumerate(self.slots):
+            if s.deep == "embedding" and spec.has_deep:
+                self.emb_groups.setdefault(int(s.dim), []).append(i)
+        self.ind_slots = [i for i, s in enumerate(self.slots) if s.deep == "indicator" and spec.has_deep]
+
+        # TF concat order (columns sorted by name) -> internal column index
+        tf_cols = []
+        if spec.has_deep:
+            for i, s in enumerate(self.slots):
+                if s.deep == "embedding":
+                    tf_cols.append((s.deep_name, self.out_col[i], s.dim))
+                elif s.deep == "indicator":
+                    tf_cols.append((s.deep_name, self.out_col[i], s.num_buckets))
+            for j, d in enumerate(self.dense_cols):
+                tf_cols.append((d.name, self.dense_out_col[j], 1))
+        tf_cols.sort(key=lambda t: t[0])
+        self.tf_deep_cols = tf_cols
+        perm = []
+        for _, c0, w in tf_cols:
+            perm.extend(range(c0, c0 + w))
+        self.tf_input_perm = np.asarray(perm, dtype=np.int64)   # len = TF deep input dim
+        self.tf_deep_dim = len(perm)
+
+        # towers + flat dense parameter layout
+        self.towers = [TowerLayout(self.deep_dim, t.hidden_units, t.mode) for t in spec.towers] if spec.has_deep else []
+        self.param_segments = []   # (name, offset, shape)
+        self.layer_meta = []       # per tower: list of dicts per layer (hidden..., logits)
+        off = 0
+        for ti, tl in enumerate(self.towers):
+            metas = []
+            L = len(tl.hidden)
+            for l in range(L + 1):
+                K = tl.in_K[l]
+                N = tl.hidden[l] if l < L else 1
+                m = {"K": K, "N": N, "w_off": off}
+                off += K * N
+                m["b_off"] = off
+                off += N
+                if l < L and spec.batch_norm:
+                    m["gamma_off"] = off
+                    off += N
+                    m["beta_off"] = off
+                    off += N
+                off = _round_up(off, 4)
+                metas.append(m)
+            # gamma / beta index per input column of each layer
+            for l in range(L + 1):
+                gi, bi = [], []
+                for (seg, u) in tl.window_cols(l):
+                    if seg >= 1 and spec.batch_norm:
+                        gi.append(metas[seg - 1]["gamma_off"] + u)
+                        bi.append(metas[seg - 1]["beta_off"] + u)
+                    else:
+                        gi.append(-1)
+                        bi.append(-1)
+                metas[l]["gamma_idx"] = np.asarray(gi, dtype=np.int32)
+                metas[l]["beta_idx"] = np.asarray(bi, dtype=np.int32)
+            self.layer_meta.append(metas)
+        self.dense_param_elems = max(off, 4)
+
+    # ---- helpers -----------------------------------------------------------------------------
+    def tf_rows_of_layer(self, ti, l):
+        """Row indices (into the internal [K, N] kernel of tower ti layer l) in TF row order, i.e. the
+        order of the reference's concat, with seg0 expanded through tf_input_perm."""
+        tl = self.towers[ti]
+        rows = []
+        s0 = tl.in_start[l]
+        if tl.mode in ("simple",) or (tl.mode == "last_dense" and l < len(tl.hidden)):
+            order = [l]
+        elif tl.mode in ("dense", "last_dense"):
+            order = list(range(0, l + 1))
+        else:
+            order = list(range(l, -1, -1))
+        for j in order:
+            base = tl.seg_start[j] - s0
+            if j == 0:
+                rows.extend((base + self.tf_input_perm).tolist())
+            else:
+                rows.extend(range(base, base + tl.seg_width[j]))
+        return np.asarray(rows, dtype=np.int64)
+
+
+# ---------------------------------------------------------------------------------------------
+# Synthetic Criteo-shaped specs (BASELINE.json configs 2-5)
+# ---------------------------------------------------------------------------------------------
+def criteo_spec(n_dense=13, n_sparse=26, buckets=1_000_000, dim=16, hidden=(256, 128, 64), mode="simple",
+                model_type="wide_deep", batch_norm=True, crosses=(), cross_buckets=200, use_weight_column=False,
+                pos_weight=0.99, neg_weight=0.01):
+    slots = []
+    for i in range(n_sparse):
+        slots.append(CatSlot(name="C%02d" % i, kind="hash", num_buckets=int(buckets), feature="C%02d" % i,
+                             deep="embedding", dim=int(dim), wide=True))
+    for keys in crosses:
+        feats = ["C%02d" % k for k in keys]
+        slots.append(CatSlot(name="_X_".join(sorted(feats)), kind="cross", num_buckets=int(cross_buckets),
+                             deep="embedding", dim=embedding_dim(cross_buckets), wide=True,
+                             cross_keys=[CrossKey(f, "string") for f in feats]))
+    dense = [DenseCol(name="I%02d" % i, feature="I%02d" % i) for i in range(n_dense)]
+    return ModelSpec(model_type=model_type, slots=slots, dense_cols=dense,
+                     towers=[TowerSpec(list(hidden), mode)], batch_norm=batch_norm,
+                     use_weight_column=use_weight_column, pos_weight=pos_weight, neg_weight=neg_weight)

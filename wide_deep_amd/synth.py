@@ -1,0 +1,110 @@
+"""Synthetic Criteo-shaped batches (SURVEY section 8(d) recipes) and host->HBM batch packing.
+
+Host-side plumbing only: builds the example-major bag CSR the kernels consume, either directly as
+ids or as raw string tokens that the hash kernels turn into ids on the device.
+"""
+import numpy as np
+import torch
+
+from . import capi
+from .capi import call, ptr
+from .engine import DeviceBatch
+
+
+def bag_lengths(rng, B, S, mean_len, max_len=32):
+    if mean_len <= 1:
+        return np.ones((B, S), dtype=np.int64)
+    # 1 + Poisson(mean-1), clipped (BASELINE config 4: avg 5 ids/slot)
+    return np.clip(1 + rng.poisson(mean_len - 1.0, size=(B, S)), 1, max_len).astype(np.int64)
+
+
+def zipf_ranks(rng, n, vocab, s=1.05):
+    """Zipf(s) over `vocab` ranks via inverse-CDF on a truncated support."""
+    w = 1.0 / np.power(np.arange(1, vocab + 1, dtype=np.float64), s)
+    cdf = np.cumsum(w)
+    cdf /= cdf[-1]
+    return np.searchsorted(cdf, rng.random(n), side="left").astype(np.int64)
+
+
+def make_raw_batch(plan, B, seed=20260925, mean_len=1, dist="uniform", pos_rate=0.03, n_raw=None):
+    """Host batch with RAW per-feature values (before hashing): dict with
+       lens [B,S] int64, raw [nnz] int64 (raw categorical value per occurrence, example-major),
+       dense [B,nd] f32, labels [B] f32."""
+    rng = np.random.default_rng(seed)
+    S = plan.S
+    lens = bag_lengths(rng, B, S, mean_len)
+    nnz = int(lens.sum())
+    slot_of = np.repeat(np.tile(np.arange(S), B), lens.reshape(-1))
+    nb = np.asarray([s.num_buckets for s in plan.slots], dtype=np.int64)
+    hi = nb[slot_of] if n_raw is None else np.full(nnz, n_raw, dtype=np.int64)
+    if dist == "uniform":
+        raw = (rng.random(nnz) * hi).astype(np.int64)
+    elif dist == "zipf":
+        vocab = int(hi.max())
+        ranks = zipf_ranks(rng, nnz, vocab)
+        perm_rng = np.random.default_rng(12345)
+        perm = perm_rng.permutation(vocab)
+        raw = perm[ranks] % hi
+    else:
+        raise ValueError(dist)
+    nd = len(plan.dense_cols)
+    dense = rng.standard_normal((B, nd)).astype(np.float32) if nd else None
+    labels = (rng.random(B) < pos_rate).astype(np.float32)
+    return {"B": B, "lens": lens, "raw": raw, "dense": dense, "labels": labels}
+
+
+def offsets_from_lens(lens):
+    offs = np.zeros(lens.size + 1, dtype=np.int32)
+    np.cumsum(lens.reshape(-1), out=offs[1:])
+    return offs
+
+
+def to_device_ids(plan, hb, device="cuda", weights=None):
+    """Treat raw values as already-bucketed ids (raw % num_buckets)."""
+    S = plan.S
+    lens = hb["lens"]
+    slot_of = np.repeat(np.tile(np.arange(S), hb["B"]), lens.reshape(-1))
+    nb = np.asarray([s.num_buckets for s in plan.slots], dtype=np.int64)
+    ids = (hb["raw"] % nb[slot_of]).astype(np.int32)
+    offs = offsets_from_lens(lens)
+    t = lambda a, dt: torch.as_tensor(a, dtype=dt).to(device) if a is not None else None
+    return DeviceBatch(hb["B"], t(ids, torch.int32), t(offs, torch.int32), t(hb["dense"], torch.float32),
+                       t(hb["labels"], torch.float32), t(weights, torch.float32), nnz=len(ids))
+
+
+def pack_decimal_tokens(raw):
+    """raw int64 [n] -> (uint8 bytes, int32 offs[n+1]) of their decimal strings."""
+    strs = np.char.mod("%d", raw)
+    lens = np.char.str_len(strs).astype(np.int32)
+    offs = np.zeros(len(raw) + 1, dtype=np.int32)
+    np.cumsum(lens, out=offs[1:])
+    data = np.frombuffer("".join(strs.tolist()).encode(), dtype=np.uint8).copy()
+    return data, offs
+
+
+class TokenBatch:
+    """Raw string tokens resident in HBM + the buffers the hash kernel fills."""
+
+    def __init__(self, plan, hb, device="cuda", weights=None):
+        self.B = hb["B"]
+        data, tok_offs = pack_decimal_tokens(hb["raw"])
+        lens = hb["lens"]
+        self.ntok = len(hb["raw"])
+        self.one_per_bag = bool((lens == 1).all())
+        self.bytes = torch.from_numpy(data).to(device)
+        self.tok_offs = torch.from_numpy(tok_offs).to(device)
+        offs = offsets_from_lens(lens)
+        self.bag_offs = torch.from_numpy(offs).to(device)
+        t = lambda a: torch.as_tensor(a, dtype=torch.float32).to(device) if a is not None else None
+        self.ids = torch.zeros(max(self.ntok, 1), dtype=torch.int32, device=device)
+        self.batch = DeviceBatch(self.B, self.ids, self.bag_offs, t(hb["dense"]), t(hb["labels"]), t(weights),
+                                 nnz=self.ntok)
+
+
+def hash_tokens(engine, tb: TokenBatch):
+    """tokens -> ids on the device (wd_hash_bucket): a4 of SURVEY section 8."""
+    plan = engine.plan
+    st = torch.cuda.current_stream().cuda_stream
+    call("wd_hash_bucket", ptr(tb.bytes), ptr(tb.tok_offs), tb.ntok, None if tb.one_per_bag else ptr(tb.bag_offs),
+         tb.B * plan.S, ptr(engine.slots_dev), plan.S, ptr(tb.ids), st)
+    return tb.batch

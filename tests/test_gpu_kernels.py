@@ -47,8 +47,8 @@ def test_golden_kat_on_device():
     toks = list(g["fingerprint64"].keys())
     data, offs = O.pack_tokens(toks)
     out = torch.zeros(len(toks), dtype=torch.int64, device="cuda")
-    call("wd_fingerprint64", ptr(_dev(data, torch.uint8)), ptr(_dev(offs, torch.int32)), len(toks), ptr(out),
-         torch.cuda.current_stream().cuda_stream)
+    d, o = _dev(data, torch.uint8), _dev(offs, torch.int32)
+    call("wd_fingerprint64", ptr(d), ptr(o), len(toks), ptr(out), torch.cuda.current_stream().cuda_stream)
     assert out.cpu().numpy().view(np.uint64).tolist() == [g["fingerprint64"][t] for t in toks]
 
 
@@ -105,8 +105,10 @@ def test_cross_hash_bit_exact_ragged_and_empty():
             ck.vals[k] = vd.data_ptr(); ck.offs[k] = od.data_ptr()
         ck.nkeys = 3
         ids = torch.full((max(int(bag_offs[-1]), 1),), -1, dtype=torch.int32, device="cuda")
-        call("wd_cross_hash", ck, B, 0xDECAFCAFFE, nb, ptr(_dev(bag_offs, torch.int32)), S, slot, ptr(ids),
+        bo = _dev(bag_offs, torch.int32)
+        call("wd_cross_hash", ck, B, 0xDECAFCAFFE, nb, ptr(bo), S, slot, ptr(ids),
              torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
         assert np.array_equal(ids.cpu().numpy()[: len(exp_ids)].astype(np.int64), exp_ids)
 
 

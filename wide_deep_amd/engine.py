@@ -52,7 +52,7 @@ class WideDeepEngine:
         self.plan = plan = FeaturePlan(spec)
         self.device = torch.device(device)
         self.max_batch = int(max_batch)
-        self.max_nnz = int(max_nnz) if max_nnz else self.max_batch * max(plan.S, 1) * 2
+        self.max_nnz = int(max_nnz) if max_nnz else self.max_batch * max(plan.S, 1) * 8
         self.inv = 1.0 / math.sqrt(1.0 + BN_EPS)
         self.act_id = capi.ACT_IDS[spec.activation]
         self.global_step = 0
@@ -166,9 +166,15 @@ class WideDeepEngine:
         self.vals = torch.zeros(M, **i32)
         self.keys_sorted = torch.zeros(M, dtype=torch.int32, device=dev)
         self.vals_sorted = torch.zeros(M, **i32)
-        self.sort_ws_bytes = int(call("wd_sort_workspace_bytes", M, plan.key_bits))
-        if self.sort_ws_bytes == 0:
+        # rocPRIM picks its algorithm by size: take the max over the sizes we may be called with
+        sizes, m = [], M
+        while m >= 1:
+            sizes.append(m)
+            m //= 2
+        qs = [int(call("wd_sort_workspace_bytes", n, plan.key_bits)) for n in sizes]
+        if min(qs) == 0:
             raise capi.WdError("wd_sort_workspace_bytes failed")
+        self.sort_ws_bytes = max(qs)
         self.sort_ws = torch.zeros(self.sort_ws_bytes, dtype=torch.uint8, device=dev)
         self._graph = None
 
@@ -279,6 +285,7 @@ class WideDeepEngine:
 
     def sort_occurrences(self, bt, st):
         plan = self.plan
+        self._check_batch(bt)
         call("wd_build_sort_keys", ptr(self.slots_dev), plan.S, ptr(bt.ids), ptr(bt.bag_offs), bt.B * plan.S, bt.nnz,
              ptr(self.keys), ptr(self.vals), st)
         call("wd_sort_pairs", ptr(self.keys), ptr(self.vals), ptr(self.keys_sorted), ptr(self.vals_sorted), bt.nnz,

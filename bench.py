@@ -1,0 +1,269 @@
+#!/usr/bin/env python
+"""bench.py -- examples/sec of the Wide&Deep train step on MI355X (BASELINE.json metric).
+
+A "step" = one full train step of the hot path over one synthetic Criteo-shaped batch that is
+already resident in HBM as raw string tokens: hash -> embedding-bag gather + wide sum -> BN/ReLU
+tower (fp32 MFMA) -> sigmoid-CE (batch SUM) -> backward -> Adagrad (dense + embedding rows) + FTRL
+(wide rows).  Nothing is skipped inside the timed region.
+
+  python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+
+Prints ONE JSON line (rank 0) with the contract fields plus `roofline` (embedding-gather kernel,
+HBM-bound; achieved = algorithmic bytes / measured kernel time) and `cpu_baseline` (the CPU oracle
+timed on this box's host cores on a bounded sample of the same workload; N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")   # CPU-baseline leg: no spin-waiting across OpenMP runtimes
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured copy ceiling
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=8192, help="examples per GPU per step")
+    ap.add_argument("--config", default="c2", choices=["c2", "c4"])
+    ap.add_argument("--dist", default="uniform", choices=["uniform", "zipf"])
+    ap.add_argument("--pool", type=int, default=32, help="distinct resident batches cycled through")
+    ap.add_argument("--no-graph", action="store_true", help="launch kernels eagerly instead of hipGraph replay")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=20)
+    ap.add_argument("--ids-input", action="store_true", help="feed pre-hashed ids (skips the hash kernel)")
+    return ap.parse_args()
+
+
+def make_spec(cfg):
+    from wide_deep_amd.plan import criteo_spec
+    if cfg == "c2":
+        # BASELINE.json configs[1]: 13 dense + 26 sparse slots, 1M buckets, emb 16, Dnn [256,128,64]
+        return criteo_spec(n_dense=13, n_sparse=26, buckets=1_000_000, dim=16, hidden=(256, 128, 64), mode="simple"), 1
+    # configs[3] shape on one GPU: multi-hot (avg 5 ids/slot), ResDnn, weight column
+    return criteo_spec(n_dense=13, n_sparse=26, buckets=1_000_000, dim=16, hidden=(256, 128, 64), mode="resnet",
+                       use_weight_column=True), 5
+
+
+def event_time_ms(fn, iters):
+    """GPU time of `iters` back-to-back calls on the current stream (HIP events on that stream)."""
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for i in range(iters):
+        fn(i)
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def gather_roofline(eng, batches, iters=200):
+    """Embedding-gather kernel (wd_embag_fwd): algorithmic bytes / measured duration."""
+    from wide_deep_amd.capi import call, ptr
+    plan = eng.plan
+    tw0 = eng.towers[0]
+    ld = tw0["layout"].ld
+    xp = tw0["act"].data_ptr() + 4 * tw0["layout"].seg_start[0]
+    st = torch.cuda.current_stream().cuda_stream
+    (dim, gs), = list(eng.group_slots.items())[:1]
+
+    def run(i):
+        bt = batches[i % len(batches)]
+        call("wd_embag_fwd", ptr(eng.emb), ptr(eng.slots_dev), plan.S, ptr(gs), gs.numel(), dim, ptr(bt.ids),
+             ptr(bt.bag_offs), bt.B, xp, ld, st)
+
+    for i in range(10):
+        run(i)
+    torch.cuda.synchronize()
+    ms = event_time_ms(run, iters)
+    bt = batches[0]
+    nbag = bt.B * gs.numel()
+    # nnz*D*4 (row reads) + nnz*4 (ids) + (B*S+1)*4 (offsets) + B*S*D*4 (pooled write)
+    alg = bt.nnz * dim * 4 + bt.nnz * 4 + (bt.B * plan.S + 1) * 4 + nbag * dim * 4
+    gbs = alg / (ms * 1e-3) / 1e9
+    return {"bound": "hbm", "kernel": "k_embag_fwd<%d>" % (dim // 4), "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
+            "algorithmic_bytes_per_launch": int(alg), "avg_launch_us": round(ms * 1e3, 2)}
+
+
+def cpu_baseline(eng, host_batches, steps, B):
+    """The CPU oracle (oracle/, a port restating the reference's TF semantics -- TF itself is not installable
+    here) timed on this box's host cores over `steps` batches of the same workload, hashing included."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle import oracle as O
+    from tests.helpers import oracle_batch, oracle_from_engine
+    from wide_deep_amd import synth
+    ncpu = os.cpu_count() or 1
+    ora = oracle_from_engine(eng)
+    plan = eng.plan
+    S = plan.S
+    nb = [s.num_buckets for s in plan.slots]
+
+    # tokens packed ahead of the timed region, exactly as the GPU path receives them (resident, packed)
+    packed = {}
+    for hb in host_batches:
+        data, offs = synth.pack_decimal_tokens(hb["raw"])
+        packed[id(hb)] = (data, offs.astype(np.int64))
+
+    def one(hb):
+        lens = hb["lens"]
+        slot_of = np.repeat(np.tile(np.arange(S), hb["B"]), lens.reshape(-1))
+        data, offs = packed[id(hb)]
+        fp = O.fingerprint64_batch(data, offs)
+        ids = (fp % np.asarray(nb, dtype=np.uint64)[slot_of]).astype(np.int64)
+        bag_offs = synth.offsets_from_lens(lens)
+        w = None
+        if eng.spec.use_weight_column:
+            w = np.where(hb["labels"] > 0, eng.spec.pos_weight, eng.spec.neg_weight).astype(np.float32)
+        ob = oracle_batch(plan, ids, bag_offs, hb["B"], hb["dense"], hb["labels"], w)
+        return ora.train_step(ob)
+
+    # the port's sparse ops are short OpenMP loops: more threads is not faster.  Pick the best of a
+    # small sweep (one step each) and report the thread count actually used.
+    one(host_batches[0])  # warm-up (page-in)
+    best, cores = None, 1
+    for nt in sorted({min(ncpu, n) for n in (8, 16, 32)}):
+        torch.set_num_threads(nt)
+        O.lib().wdo_set_num_threads(nt)
+        one(host_batches[0])
+        t0 = time.perf_counter()
+        one(host_batches[1 % len(host_batches)])
+        dt = time.perf_counter() - t0
+        if best is None or dt < best:
+            best, cores = dt, nt
+    torch.set_num_threads(cores)
+    O.lib().wdo_set_num_threads(cores)
+    t0 = time.perf_counter()
+    for i in range(steps):
+        one(host_batches[(i + 1) % len(host_batches)])
+    dt = time.perf_counter() - t0
+    return {"value": round(steps * B / dt, 1), "unit": "examples/sec", "cores": cores, "host_cpus": ncpu, "kind": "port",
+            "sample": "%d steps x batch %d of the same synthetic workload (token hashing + full train step), "
+                      "CPU oracle = C/OpenMP sparse ops + torch-CPU fp32 tower; TensorFlow (the reference's runtime) "
+                      "is not installable in this image" % (steps, B),
+            "seconds": round(dt, 2)}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..."
+                             % (args.gpus, args.gpus))
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from wide_deep_amd import synth
+    from wide_deep_amd.engine import WideDeepEngine
+
+    spec, mean_len = make_spec(args.config)
+    B = args.batch
+    if world > 1:
+        from wide_deep_amd.dist import ShardedWideDeepEngine
+        eng = ShardedWideDeepEngine(spec, max_batch=B, max_nnz=B * 26 * (2 * mean_len + 2), seed=0)
+    else:
+        eng = WideDeepEngine(spec, max_batch=B, max_nnz=B * 26 * (2 * mean_len + 2), seed=0)
+    plan = eng.plan
+
+    # resident batch pool (raw tokens in HBM); distinct seeds per rank
+    host_batches, dev_batches = [], []
+    for i in range(args.pool):
+        hb = synth.make_raw_batch(plan, B, seed=20260925 + 1000 * rank + i, mean_len=mean_len, dist=args.dist)
+        w = None
+        if spec.use_weight_column:
+            w = np.where(hb["labels"] > 0, spec.pos_weight, spec.neg_weight).astype(np.float32)
+        if i < 4:
+            host_batches.append(hb)
+        dev_batches.append(synth.TokenBatch(plan, hb, weights=w))
+    if args.ids_input:
+        for tb in dev_batches:
+            synth.hash_tokens(eng, tb)
+    torch.cuda.synchronize()
+
+    def step_eager(tb):
+        bt = tb.batch if args.ids_input else synth.hash_tokens(eng, tb)
+        return eng.train_step(bt)
+
+    use_graph = not args.no_graph and world == 1
+    if use_graph:
+        replays = []
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):
+            step_eager(dev_batches[0])
+            step_eager(dev_batches[1 % len(dev_batches)])
+        torch.cuda.synchronize()
+        for tb in dev_batches:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=side):
+                step_eager(tb)
+            replays.append(g)
+        run = lambda i: replays[i % len(replays)].replay()
+    else:
+        run = lambda i: step_eager(dev_batches[i % len(dev_batches)])
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        run(i)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        run(args.warmup + i)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    loss = float(eng.loss)
+    value = args.steps * B * world / elapsed
+
+    out = {
+        "metric": "examples/sec", "value": round(value, 1), "unit": "examples/sec", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {
+            "workload": "BASELINE configs[1] (C2): Criteo-shape synthetic, 13 dense + 26 sparse slots x 1M hash buckets, "
+                        "emb_dim 16, Dnn [256,128,64] BN+ReLU, wide FTRL + deep Adagrad, batch %d per GPU" % B
+            if args.config == "c2" else
+            "BASELINE configs[3] shape (C4) on %d GPU(s): multi-hot avg %d ids/slot, ResDnn, weight column" % (world, mean_len),
+            "global_batch": B * world, "ids": args.dist, "input": "pre-hashed ids" if args.ids_input else "raw string tokens (hashed in step)",
+            "hip_graph": bool(use_graph), "parallelism": "dp%d+row-sharded tables" % world if world > 1 else "single GPU",
+            "final_loss_sum": round(loss, 3),
+        },
+    }
+    if rank == 0:
+        if world == 1:
+            # dominant-bandwidth kernel named by the metric: the embedding gather
+            for tb in dev_batches:
+                synth.hash_tokens(eng, tb)
+            torch.cuda.synchronize()
+            out["roofline"] = gather_roofline(eng, [tb.batch for tb in dev_batches])
+            if not args.no_cpu_baseline:
+                out["cpu_baseline"] = cpu_baseline(eng, host_batches, args.cpu_steps, B)
+            else:
+                out["cpu_baseline"] = None
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -120,9 +120,10 @@ int wd_dense_fwd(const float *dense, int64_t ld_dense, const wd_dense_col_t *col
 
 /* ---- a7: tf.feature_column.linear_model(sparse_combiner='sum') (python/lib/linear.py:29-36) --
  * wide state is array-of-structs: wide[row*4 + {0,1,2}] = {w, z (Ftrl_1 "linear"), n (Ftrl "accum")}.
- * out[b] = bias[0] + sum over wide slots s, ids in bag(b,s) of w[row_base_s + id]. */
-int wd_wide_fwd(const float *wide, const float *bias, const wd_slot_t *slots, int32_t S, const int32_t *ids,
-                const int32_t *bag_offs, int64_t batch, float *out, wd_stream_t stream);
+ * out[b] = bias[0] + sum over wide slots s, ids in bag(b,s) of wide[(row_base_s + id) * wide_stride]
+ * (wide_stride 4 for the AoS table; 1 when summing weights that arrived through the all-to-all exchange). */
+int wd_wide_fwd(const float *wide, int32_t wide_stride, const float *bias, const wd_slot_t *slots, int32_t S,
+                const int32_t *ids, const int32_t *bag_offs, int64_t batch, float *out, wd_stream_t stream);
 
 /* ---- a11: head, sigmoid CE, SUM reduction, weight column (python/lib/joint.py:216-222,402-406) --
  * logit = dnn_logit (may be NULL) + wide_logit (may be NULL); loss_sum[0] += sum_b w_b*CE; dlogit[b] = w_b*(p-y);
@@ -172,8 +173,9 @@ int wd_bias_ftrl(float *bias_wzn, const float *dlogit, int64_t batch, float lr, 
 #define WD_ACT_SOFTPLUS 8
 #define WD_ACT_SOFTSIGN 9
 
-int wd_gemm_nn_bias_act(const float *A, int64_t lda, const float *B, int64_t ldb, const float *bias, int32_t act,
-                        float *C, int64_t ldc, int64_t M, int64_t N, int64_t K, wd_stream_t stream);
+/* bias (may be NULL) is the sum of `bias_parts` vectors bias[p*N + n] (the partial sums wd_fold_affine emits). */
+int wd_gemm_nn_bias_act(const float *A, int64_t lda, const float *B, int64_t ldb, const float *bias, int32_t bias_parts,
+                        int32_t act, float *C, int64_t ldc, int64_t M, int64_t N, int64_t K, wd_stream_t stream);
 int wd_gemm_nt(const float *A, int64_t lda, const float *B, int64_t ldb, float *C, int64_t ldc, int64_t M, int64_t N,
                int64_t K, int32_t accumulate, wd_stream_t stream);
 /* Cpart[split][(M + append_ones)][N] = A[Kslice, M]^T B[Kslice, N]; with append_ones the extra output row M is
@@ -187,7 +189,9 @@ int wd_gemm_tn_splitk(const float *A, int64_t lda, const float *B, int64_t ldb, 
  *
  * BN is the inference-mode affine of SURVEY App. C.1 (python/lib/dnn.py:113-114), folded into the consumer:
  *   s[k] = gamma*inv (or 1), t[k] = beta (or 0), inv = 1/sqrt(1+eps);
- *   Wf[k,n] = s[k]*W[k,n];  bf[n] = b[n] + sum_k t[k]*W[k,n]. */
+ *   Wf[k,n] = s[k]*W[k,n];  bf[n] = b[n] + sum_k t[k]*W[k,n], emitted as WD_FOLD_PARTS partial vectors
+ *   bf[p*N + n] (K split into WD_FOLD_PARTS chunks; fixed summation order, no atomics). */
+#define WD_FOLD_PARTS 16
 int wd_fold_affine(const float *P, int64_t w_off, int64_t b_off, const int32_t *gamma_idx, const int32_t *beta_idx,
                    float inv, float *Wf, float *bf, float *s, float *t, int64_t K, int64_t N, wd_stream_t stream);
 

@@ -10,14 +10,19 @@ def slot_csr(plan, ids, bag_offs, B):
     S = plan.S
     ids = np.asarray(ids)
     offs = np.asarray(bag_offs).astype(np.int64)
+    lens = np.diff(offs).reshape(B, S)
+    starts = offs[:-1].reshape(B, S)
     out = {}
     for si, s in enumerate(plan.slots):
-        v, o = [], [0]
-        for b in range(B):
-            g = b * S + si
-            v.extend(ids[offs[g]:offs[g + 1]].tolist())
-            o.append(len(v))
-        out[s.name] = (np.asarray(v, dtype=np.int64), np.asarray(o, dtype=np.int32))
+        l = lens[:, si]
+        o = np.zeros(B + 1, dtype=np.int32)
+        np.cumsum(l, out=o[1:])
+        if (l == 1).all():
+            v = ids[starts[:, si]]
+        else:
+            idx = np.repeat(starts[:, si] - o[:-1], l) + np.arange(int(o[-1]))
+            v = ids[idx]
+        out[s.name] = (v.astype(np.int64), o)
     return out
 
 

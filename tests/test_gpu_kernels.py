@@ -148,7 +148,7 @@ def test_gemm_variants_match_torch_fp32():
         A = torch.randn(M, lda, device="cuda", generator=g); Bm = torch.randn(K, ldb, device="cuda", generator=g)
         bias = torch.randn(N, device="cuda", generator=g)
         C = torch.zeros(M, ldc, device="cuda")
-        call("wd_gemm_nn_bias_act", ptr(A), lda, ptr(Bm), ldb, ptr(bias), 1, ptr(C), ldc, M, N, K, st)
+        call("wd_gemm_nn_bias_act", ptr(A), lda, ptr(Bm), ldb, ptr(bias), 1, 1, ptr(C), ldc, M, N, K, st)
         ref = torch.relu(A[:, :K].double() @ Bm[:, :N].double() + bias.double())
         assert_close(C[:, :N], ref, 1e-5, 1e-4, "NN %s" % ((M, N, K),))
         assert float(C[:, N:].abs().max()) == 0.0
@@ -176,7 +176,7 @@ def test_a_identity_asymmetric_b_detects_transposes():
     A = torch.eye(n, device="cuda")
     Bm = (torch.arange(n, device="cuda").float()[:, None] * 100 + torch.arange(n, device="cuda").float()[None, :]).contiguous()
     C = torch.zeros(n, n, device="cuda")
-    call("wd_gemm_nn_bias_act", ptr(A), n, ptr(Bm), n, None, 0, ptr(C), n, n, n, n, st)
+    call("wd_gemm_nn_bias_act", ptr(A), n, ptr(Bm), n, None, 0, 0, ptr(C), n, n, n, n, st)
     assert torch.equal(C, Bm)
 
 

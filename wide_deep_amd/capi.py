@@ -13,6 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "_lib", "libwd_hip.so")
 
 WD_MAX_CROSS_KEYS = 8
+WD_FOLD_PARTS = 16
 
 SLOT_NONE, SLOT_EMBEDDING, SLOT_INDICATOR = 0, 1, 2
 
@@ -61,7 +62,7 @@ _PROTOS = {
     "wd_embag_fwd": [P, P, I32, P, I32, I32, P, P, I64, P, I64, P],
     "wd_indicator_fwd": [P, I32, P, I32, P, P, I64, P, I64, P],
     "wd_dense_fwd": [P, I64, P, I32, I64, P, I64, P],
-    "wd_wide_fwd": [P, P, P, I32, P, P, I64, P, P],
+    "wd_wide_fwd": [P, I32, P, P, I32, P, P, I64, P, P],
     "wd_bce_sum_fwd_bwd": [P, P, P, P, I64, P, P, P, P, P],
     "wd_sort_workspace_bytes": [I64, I32],
     "wd_build_sort_keys": [P, I32, P, P, I64, I64, P, P, P],
@@ -69,7 +70,7 @@ _PROTOS = {
     "wd_embag_bwd_adagrad": [P, P, P, I32, I32, P, P, I64, P, P, I64, F32, P],
     "wd_wide_bwd_ftrl": [P, P, I32, P, P, I64, P, F32, F32, F32, P],
     "wd_bias_ftrl": [P, P, I64, F32, F32, F32, P],
-    "wd_gemm_nn_bias_act": [P, I64, P, I64, P, I32, P, I64, I64, I64, I64, P],
+    "wd_gemm_nn_bias_act": [P, I64, P, I64, P, I32, I32, P, I64, I64, I64, I64, P],
     "wd_gemm_nt": [P, I64, P, I64, P, I64, I64, I64, I64, I32, P],
     "wd_gemm_tn_splitk": [P, I64, P, I64, P, I64, I64, I64, I32, I32, P],
     "wd_fold_affine": [P, I64, I64, P, P, F32, P, P, P, P, I64, I64, P],

@@ -119,7 +119,7 @@ __global__ void k_dense_fwd(const float *__restrict__ dense, int64_t ld_dense, c
 __global__ void __launch_bounds__(256)
 k_wide_fwd(const float *__restrict__ wide, const float *__restrict__ bias, const wd_slot_t *__restrict__ slots,
            int32_t S, const int32_t *__restrict__ ids, const int32_t *__restrict__ bag_offs, int64_t batch,
-           float *__restrict__ out) {
+           int32_t stride, float *__restrict__ out) {
   const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t b = tid >> 4;
   const int lane = (int)(tid & 15);
@@ -130,7 +130,7 @@ k_wide_fwd(const float *__restrict__ wide, const float *__restrict__ bias, const
       if (!sl.wide) continue;
       const int64_t bag = b * S + s;
       const int32_t j0 = bag_offs[bag], j1 = bag_offs[bag + 1];
-      for (int32_t j = j0; j < j1; ++j) acc += wide[(sl.row_base + ids[j]) * 4];
+      for (int32_t j = j0; j < j1; ++j) acc += wide[(sl.row_base + ids[j]) * stride];
     }
   }
   acc += __shfl_xor(acc, 8, 16);
@@ -213,12 +213,12 @@ extern "C" int wd_dense_fwd(const float *dense, int64_t ld_dense, const wd_dense
   return wd::check_launch("wd_dense_fwd");
 }
 
-extern "C" int wd_wide_fwd(const float *wide, const float *bias, const wd_slot_t *slots, int32_t S, const int32_t *ids,
-                           const int32_t *bag_offs, int64_t batch, float *out, wd_stream_t stream) {
+extern "C" int wd_wide_fwd(const float *wide, int32_t wide_stride, const float *bias, const wd_slot_t *slots, int32_t S,
+                           const int32_t *ids, const int32_t *bag_offs, int64_t batch, float *out, wd_stream_t stream) {
   if (batch <= 0) return WD_OK;
   WD_REQUIRE(wide && bias && slots && ids && bag_offs && out, "null pointer");
   hipLaunchKernelGGL(k_wide_fwd, dim3((unsigned)wd::ceil_div(batch * 16, 256)), dim3(256), 0, wd::as_stream(stream),
-                     wide, bias, slots, S, ids, bag_offs, batch, out);
+                     wide, bias, slots, S, ids, bag_offs, batch, wide_stride, out);
   return wd::check_launch("wd_wide_fwd");
 }
 

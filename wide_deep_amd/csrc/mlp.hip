@@ -41,6 +41,7 @@ struct GemmArgs {
   int64_t ones_row;     // TN: output row index of A^T that is synthesised as all-ones (-1: none)
   int32_t act;
   int32_t accumulate;
+  int32_t bias_parts;   // bias = sum of `bias_parts` vectors of stride N
   int32_t a_vec, b_vec; // float4 loads legal (ld % 4 == 0 and 16-byte aligned base)
   int32_t tiles_m, tiles_n;
 };
@@ -182,7 +183,10 @@ __global__ void __launch_bounds__(256) k_gemm(GemmArgs g) {
   const int64_t n = n0 + wn * 32 + fc;
   if (n >= g.N) return;
   float *Cz = g.C + (EPI == 2 ? (int64_t)blockIdx.z * g.c_split : 0);
-  const float bv = (EPI == 0 && g.bias) ? g.bias[n] : 0.f;
+  float bv = 0.f;
+  if (EPI == 0 && g.bias) {
+    for (int p = 0; p < g.bias_parts; ++p) bv += g.bias[(int64_t)p * g.N + n];
+  }
 #pragma unroll
   for (int rg = 0; rg < 16; ++rg) {
     const int64_t m = m0 + wm * 32 + (rg & 3) + 8 * (rg >> 2) + 4 * fr;
@@ -212,30 +216,43 @@ int launch_gemm(GemmArgs g, int nsplit, hipStream_t st, const char *what) {
 
 // ---- small per-layer kernels -------------------------------------------------------------------
 
-// s[k] = gamma*inv (or 1), t[k] = beta (or 0);  Wf = diag(s) W;  bf = b + t^T W
+// s[k] = gamma*inv (or 1), t[k] = beta (or 0);  Wf = diag(s) W;  bf_part[c] = (c == 0 ? b : 0) + t_c^T W_c
+// grid (ceil(N/64), WD_FOLD_PARTS): block = 64 columns x 4 k-lanes over one K chunk; the partial bias
+// sums stay separate per chunk (deterministic) and are added up by the GEMM epilogue.
 __global__ void __launch_bounds__(256)
 k_fold_affine(const float *__restrict__ P, int64_t w_off, int64_t b_off, const int32_t *__restrict__ gamma_idx,
               const int32_t *__restrict__ beta_idx, float inv, float *__restrict__ Wf, float *__restrict__ bf,
               float *__restrict__ s_out, float *__restrict__ t_out, int64_t K, int64_t N) {
-  const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  __shared__ float red[4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int64_t n = (int64_t)blockIdx.x * 64 + tx;
+  const int64_t kc = (K + WD_FOLD_PARTS - 1) / WD_FOLD_PARTS;
+  const int64_t k0 = (int64_t)blockIdx.y * kc;
+  const int64_t k1 = k0 + kc < K ? k0 + kc : K;
   const float *W = P + w_off;
   float tb = 0.f;
-  for (int64_t k = 0; k < K; ++k) {
+  for (int64_t k = k0 + ty; k < k1; k += 4) {
     const int32_t gi = gamma_idx ? gamma_idx[k] : -1;
     const int32_t bi = beta_idx ? beta_idx[k] : -1;
-    const float s = gi >= 0 ? P[gi] * inv : 1.0f;
-    const float tt = bi >= 0 ? P[bi] : 0.0f;
-    if (n == 0) {
-      s_out[k] = s;
-      t_out[k] = tt;
+    const float sk = gi >= 0 ? P[gi] * inv : 1.0f;
+    const float tk = bi >= 0 ? P[bi] : 0.0f;
+    if (blockIdx.x == 0 && tx == 0) {
+      s_out[k] = sk;
+      t_out[k] = tk;
     }
     if (n < N) {
       const float w = W[k * N + n];
-      Wf[k * N + n] = s * w;
-      tb += tt * w;
+      Wf[k * N + n] = sk * w;
+      tb += tk * w;
     }
   }
-  if (n < N) bf[n] = P[b_off + n] + tb;
+  red[ty][tx] = tb;
+  __syncthreads();
+  if (ty == 0 && n < N) {
+    float v = red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx];
+    if (blockIdx.y == 0) v += P[b_off + n];
+    bf[(int64_t)blockIdx.y * N + n] = v;
+  }
 }
 
 __global__ void __launch_bounds__(256)
@@ -312,14 +329,14 @@ k_adagrad_dense(float *__restrict__ w, float *__restrict__ accum, const float *_
 }  // namespace
 
 extern "C" int wd_gemm_nn_bias_act(const float *A, int64_t lda, const float *B, int64_t ldb, const float *bias,
-                                   int32_t act, float *C, int64_t ldc, int64_t M, int64_t N, int64_t K,
-                                   wd_stream_t stream) {
+                                   int32_t bias_parts, int32_t act, float *C, int64_t ldc, int64_t M, int64_t N,
+                                   int64_t K, wd_stream_t stream) {
   if (M <= 0 || N <= 0) return WD_OK;
   WD_REQUIRE(A && B && C, "null pointer");
   WD_REQUIRE(K > 0, "K must be > 0");
   GemmArgs g{};
   g.A = A; g.B = B; g.C = C; g.bias = bias; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
-  g.M = M; g.N = N; g.K = K; g.kchunk = K; g.ones_row = -1; g.act = act;
+  g.M = M; g.N = N; g.K = K; g.kchunk = K; g.ones_row = -1; g.act = act; g.bias_parts = bias_parts > 0 ? bias_parts : 1;
   return launch_gemm<true, false, 0>(g, 1, wd::as_stream(stream), "wd_gemm_nn_bias_act");
 }
 
@@ -354,8 +371,8 @@ extern "C" int wd_fold_affine(const float *P, int64_t w_off, int64_t b_off, cons
                               int64_t N, wd_stream_t stream) {
   WD_REQUIRE(P && Wf && bf && s && t, "null pointer");
   WD_REQUIRE(K > 0 && N > 0, "K, N must be > 0");
-  hipLaunchKernelGGL(k_fold_affine, dim3((unsigned)wd::ceil_div(N, 256)), dim3(256), 0, wd::as_stream(stream), P,
-                     w_off, b_off, gamma_idx, beta_idx, inv, Wf, bf, s, t, K, N);
+  hipLaunchKernelGGL(k_fold_affine, dim3((unsigned)wd::ceil_div(N, 64), WD_FOLD_PARTS), dim3(256), 0,
+                     wd::as_stream(stream), P, w_off, b_off, gamma_idx, beta_idx, inv, Wf, bf, s, t, K, N);
   return wd::check_launch("wd_fold_affine");
 }
 

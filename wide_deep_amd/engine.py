@@ -130,13 +130,13 @@ class WideDeepEngine:
                 for l, m in enumerate(metas):
                     K, N = m["K"], m["N"]
                     tw["Wf"].append(torch.zeros(K * N, **f32))
-                    tw["bf"].append(torch.zeros(N, **f32))
+                    tw["bf"].append(torch.zeros(capi.WD_FOLD_PARTS * N, **f32))
                     tw["s"].append(torch.zeros(K, **f32))
                     tw["t"].append(torch.zeros(K, **f32))
                     tw["gidx"].append(torch.from_numpy(m["gamma_idx"]).to(dev))
                     tw["bidx"].append(torch.from_numpy(m["beta_idx"]).to(dev))
                     tiles = math.ceil((K + 1) / 64) * math.ceil(N / 64)
-                    ns = max(1, min(math.ceil(768 / tiles), max(1, B // 128)))
+                    ns = max(1, min(math.ceil(768 / tiles), 32, max(1, B // 128)))
                     tw["nsplit"].append(ns)
                     gmax = max(gmax, ns * (K + 1) * N)
                     # tf.glorot_uniform_initializer kernel, zero bias, gamma 1, beta 0  
@@ -190,10 +190,9 @@ class WideDeepEngine:
     def _x_ptr(self, tw):
         return tw["act"].data_ptr() + 4 * tw["layout"].seg_start[0]
 
-    def forward(self, bt: DeviceBatch, need_loss=True):
-        """Fills self.logit / self.prob (and self.dlogit / self.loss when labels are given)."""
-        self._check_batch(bt)
-        plan, spec, st = self.plan, self.spec, _stream()
+    def _sparse_forward(self, bt: DeviceBatch, st):
+        """Input layer (embedding bags, indicators, numeric columns) into tower 0's x, and the wide logit."""
+        plan, spec = self.plan, self.spec
         B, S = bt.B, plan.S
         if spec.has_deep:
             tw0 = self.towers[0]
@@ -208,6 +207,18 @@ class WideDeepEngine:
             if self.dense_cols_dev is not None:
                 call("wd_dense_fwd", ptr(bt.dense), bt.dense.stride(0), ptr(self.dense_cols_dev),
                      len(plan.dense_cols), B, xp, ld, st)
+        if spec.has_wide:
+            call("wd_wide_fwd", ptr(self.wide), 4, ptr(self.bias), ptr(self.slots_dev), S, ptr(bt.ids),
+                 ptr(bt.bag_offs), B, ptr(self.wide_logit), st)
+
+    def forward(self, bt: DeviceBatch, need_loss=True):
+        """Fills self.logit / self.prob (and self.dlogit / self.loss when labels are given)."""
+        self._check_batch(bt)
+        spec, st = self.spec, _stream()
+        B = bt.B
+        self._sparse_forward(bt, st)
+        if spec.has_deep:
+            tw0 = self.towers[0]
             for ti, tw in enumerate(self.towers):
                 tl = tw["layout"]
                 if ti > 0:  # towers share the input layer (AUTO_REUSE, python/lib/dnn.py:83-90)
@@ -224,9 +235,6 @@ class WideDeepEngine:
                 dnn_logit = self.dnn_logit
         else:
             dnn_logit = None
-        if spec.has_wide:
-            call("wd_wide_fwd", ptr(self.wide), ptr(self.bias), ptr(self.slots_dev), S, ptr(bt.ids), ptr(bt.bag_offs),
-                 B, ptr(self.wide_logit), st)
         if bt.labels is not None and need_loss:
             self.loss.zero_()
             call("wd_bce_sum_fwd_bwd", ptr(dnn_logit), ptr(self.wide_logit), ptr(bt.labels), ptr(bt.weights), B,
@@ -252,8 +260,8 @@ class WideDeepEngine:
                 c_ptr, ldc, act_id = act.data_ptr() + 4 * tl.seg_start[l + 1], tl.ld, self.act_id
             else:
                 c_ptr, ldc, act_id = tw["logit"].data_ptr(), 1, 0
-            call("wd_gemm_nn_bias_act", a_ptr, tl.ld, ptr(tw["Wf"][l]), N, ptr(tw["bf"][l]), act_id, c_ptr, ldc, B, N,
-                 K, st)
+            call("wd_gemm_nn_bias_act", a_ptr, tl.ld, ptr(tw["Wf"][l]), N, ptr(tw["bf"][l]), capi.WD_FOLD_PARTS, act_id,
+                 c_ptr, ldc, B, N, K, st)
 
     # ------------------------------------------------------------------------------------------
     # backward + optimizers
@@ -291,9 +299,35 @@ class WideDeepEngine:
         call("wd_sort_pairs", ptr(self.keys), ptr(self.vals), ptr(self.keys_sorted), ptr(self.vals_sorted), bt.nnz,
              plan.key_bits, ptr(self.sort_ws), self.sort_ws_bytes, st)
 
-    def backward_and_update(self, bt: DeviceBatch):
-        plan, spec, st = self.plan, self.spec, _stream()
+    def _reduce_dense_grads(self):
+        """Hook for data-parallel ranks (dist.py: all_reduce(SUM) of the flat gradient buffer)."""
+
+    def _sparse_backward(self, bt: DeviceBatch, st):
+        """Scatter-add of the row gradients + fused Adagrad (embedding rows) / FTRL (wide rows, bias)."""
+        plan, spec = self.plan, self.spec
         B, S = bt.B, plan.S
+        has_emb = bool(self.group_slots) if spec.has_deep else False
+        if bt.nnz > 0 and (has_emb or spec.has_wide):
+            self.sort_occurrences(bt, st)
+            if has_emb:
+                tw0 = self.towers[0]
+                tl0 = tw0["layout"]
+                dx_ptr = tw0["dact"].data_ptr() + 4 * tl0.seg_start[0]
+                for dim in self.group_slots:
+                    call("wd_embag_bwd_adagrad", ptr(self.emb), ptr(self.emb_acc), ptr(self.slots_dev), S, dim,
+                         ptr(self.keys_sorted), ptr(self.vals_sorted), bt.nnz, ptr(bt.bag_offs), dx_ptr, tl0.ld,
+                         float(spec.dnn_opt[1]), st)
+            if spec.has_wide:
+                _, lr, l1, l2, _ = spec.lin_opt
+                call("wd_wide_bwd_ftrl", ptr(self.wide), ptr(self.slots_dev), S, ptr(self.keys_sorted),
+                     ptr(self.vals_sorted), bt.nnz, ptr(self.dlogit), float(lr), float(l1), float(l2), st)
+        if spec.has_wide:
+            _, lr, l1, l2, _ = spec.lin_opt
+            call("wd_bias_ftrl", ptr(self.bias), ptr(self.dlogit), B, float(lr), float(l1), float(l2), st)
+
+    def backward_and_update(self, bt: DeviceBatch):
+        spec, st = self.spec, _stream()
+        B = bt.B
         has_emb = bool(self.group_slots) if spec.has_deep else False
         if spec.has_deep:
             self.G.zero_()
@@ -307,23 +341,10 @@ class WideDeepEngine:
                 for tw in self.towers[1:]:
                     tl = tw["layout"]
                     dx0.add_(tw["dact"][:B, tl.seg_start[0]: tl.seg_start[0] + w0])
+            self._reduce_dense_grads()
             call("wd_adagrad_dense", ptr(self.P), ptr(self.Pacc), ptr(self.G), self.P.numel(), float(spec.dnn_opt[1]),
                  st)
-        if bt.nnz > 0 and (has_emb or spec.has_wide):
-            self.sort_occurrences(bt, st)
-            if has_emb:
-                dx_ptr = tw0["dact"].data_ptr() + 4 * tl0.seg_start[0]
-                for dim in self.group_slots:
-                    call("wd_embag_bwd_adagrad", ptr(self.emb), ptr(self.emb_acc), ptr(self.slots_dev), S, dim,
-                         ptr(self.keys_sorted), ptr(self.vals_sorted), bt.nnz, ptr(bt.bag_offs), dx_ptr, tl0.ld,
-                         float(spec.dnn_opt[1]), st)
-            if spec.has_wide:
-                _, lr, l1, l2, _ = spec.lin_opt
-                call("wd_wide_bwd_ftrl", ptr(self.wide), ptr(self.slots_dev), S, ptr(self.keys_sorted),
-                     ptr(self.vals_sorted), bt.nnz, ptr(self.dlogit), float(lr), float(l1), float(l2), st)
-        if spec.has_wide:
-            _, lr, l1, l2, _ = spec.lin_opt
-            call("wd_bias_ftrl", ptr(self.bias), ptr(self.dlogit), B, float(lr), float(l1), float(l2), st)
+        self._sparse_backward(bt, st)
 
     def train_step(self, bt: DeviceBatch):
         """One step of python/lib/joint.py:224-262: forward, batch-SUM loss, both optimizers."""

@@ -178,6 +178,10 @@ int wd_gemm_nn_bias_act(const float *A, int64_t lda, const float *B, int64_t ldb
                         int32_t act, float *C, int64_t ldc, int64_t M, int64_t N, int64_t K, wd_stream_t stream);
 int wd_gemm_nt(const float *A, int64_t lda, const float *B, int64_t ldb, float *C, int64_t ldc, int64_t M, int64_t N,
                int64_t K, int32_t accumulate, wd_stream_t stream);
+/* NT with the activation derivative fused into the epilogue (simple connection mode):
+ *   C[m,n] = (A B^T)[m,n] * act'(act_src[m*ld_act + n])   = dz of the producing layer, no separate elementwise pass. */
+int wd_gemm_nt_actbwd(const float *A, int64_t lda, const float *B, int64_t ldb, float *C, int64_t ldc, int64_t M,
+                      int64_t N, int64_t K, const float *act_src, int64_t ld_act, int32_t act, wd_stream_t stream);
 /* Cpart[split][(M + append_ones)][N] = A[Kslice, M]^T B[Kslice, N]; with append_ones the extra output row M is
  * ones^T B = the column sums of B (the bias gradient).  The caller provides nsplit*(M+append_ones)*N floats. */
 int wd_gemm_tn_splitk(const float *A, int64_t lda, const float *B, int64_t ldb, float *Cpart, int64_t M, int64_t N,
@@ -194,6 +198,41 @@ int wd_gemm_tn_splitk(const float *A, int64_t lda, const float *B, int64_t ldb, 
 #define WD_FOLD_PARTS 16
 int wd_fold_affine(const float *P, int64_t w_off, int64_t b_off, const int32_t *gamma_idx, const int32_t *beta_idx,
                    float inv, float *Wf, float *bf, float *s, float *t, int64_t K, int64_t N, wd_stream_t stream);
+
+/* Per-layer descriptor (device array) for the all-layers-in-one-launch variants below. */
+typedef struct wd_mlp_layer {
+  int64_t w_off, b_off;     /* kernel [K,N] / bias [N] offsets in P and Gflat */
+  int64_t K, N;
+  const int32_t *gamma_idx; /* [K] or NULL */
+  const int32_t *beta_idx;  /* [K] or NULL */
+  float *Wf, *bf, *s, *t;   /* folded outputs (as wd_fold_affine) */
+  const float *Gpart;       /* split-K partials of this layer (as wd_mlp_finalize) */
+  int32_t nsplit;
+  int32_t pad_;
+} wd_mlp_layer_t;
+
+/* wd_fold_affine for every layer of every tower in ONE launch; also zero-fills up to two small buffers
+ * (the step's loss accumulator / flat gradient buffer) so a step needs no separate fill launches. */
+int wd_fold_affine_all(const float *P, const wd_mlp_layer_t *layers_dev, int32_t nlayers, int64_t max_n, float inv,
+                       float *zero_a, int64_t zero_a_n, float *zero_b, int64_t zero_b_n, wd_stream_t stream);
+
+/* wd_mlp_finalize for every layer in ONE launch.  Only valid when every BN gamma/beta feeds exactly one consumer
+ * layer (connected_mode `simple`): the affine gradients are then stored, not accumulated, and Gflat needs no zeroing. */
+int wd_mlp_finalize_all(const wd_mlp_layer_t *layers_dev, int32_t nlayers, int64_t max_k, const float *P, float inv,
+                        float *Gflat, wd_stream_t stream);
+
+/* ---- logits layer + head fused (python/lib/dnn.py:226-232, python/lib/joint.py:216-222,264-269) ----
+ * dnn_logit[b] = a[b, 0..K) . wf + sum(bf parts); logit = dnn_logit + wide_logit (may be NULL); sigmoid CE SUM into
+ * loss_sum (+=), prob, dlogit = w*(p-y).  Backward of the logits layer in the same launch:
+ *   out[b*ld_out + k] = dlogit[b]*wf[k]  (times act'(a[b,k]) when act != 0, i.e. out = dz of the last hidden layer),
+ *   Gpart[blk*(K+1) + k] = sum over the block's 64 examples of a[b,k]*dlogit[b], [.. + K] = sum dlogit  (split-K
+ *   partials in wd_mlp_finalize's layout with nsplit = wd_logits_head_blocks(batch)).
+ * labels NULL: forward only (predict); out / Gpart may be NULL. */
+int64_t wd_logits_head_blocks(int64_t batch);
+int wd_logits_head(const float *a, int64_t ld_a, int64_t K, const float *wf, const float *bf, int32_t bias_parts,
+                   const float *wide_logit, const float *labels, const float *weights, int64_t batch,
+                   float *dnn_logit, float *logit, float *prob, float *dlogit, float *loss_sum, float *out,
+                   int64_t ld_out, int32_t act, float *Gpart, wd_stream_t stream);
 
 /* dz = da * act'(a), the derivative expressed through the activation output a. */
 int wd_act_bwd(const float *da, int64_t ldda, const float *a, int64_t lda, int32_t act, float *dz, int64_t lddz,

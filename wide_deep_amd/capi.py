@@ -40,6 +40,15 @@ class WdDenseCol(ctypes.Structure):
     _fields_ = [("p0", ctypes.c_float), ("p1", ctypes.c_float), ("kind", ctypes.c_int32), ("out_col", ctypes.c_int32)]
 
 
+class WdMlpLayer(ctypes.Structure):
+    _fields_ = [
+        ("w_off", ctypes.c_int64), ("b_off", ctypes.c_int64), ("K", ctypes.c_int64), ("N", ctypes.c_int64),
+        ("gamma_idx", ctypes.c_void_p), ("beta_idx", ctypes.c_void_p),
+        ("Wf", ctypes.c_void_p), ("bf", ctypes.c_void_p), ("s", ctypes.c_void_p), ("t", ctypes.c_void_p),
+        ("Gpart", ctypes.c_void_p), ("nsplit", ctypes.c_int32), ("pad_", ctypes.c_int32),
+    ]
+
+
 class WdCrossKeys(ctypes.Structure):
     _fields_ = [
         ("vals", ctypes.c_void_p * WD_MAX_CROSS_KEYS),
@@ -72,14 +81,19 @@ _PROTOS = {
     "wd_bias_ftrl": [P, P, I64, F32, F32, F32, P],
     "wd_gemm_nn_bias_act": [P, I64, P, I64, P, I32, I32, P, I64, I64, I64, I64, P],
     "wd_gemm_nt": [P, I64, P, I64, P, I64, I64, I64, I64, I32, P],
+    "wd_gemm_nt_actbwd": [P, I64, P, I64, P, I64, I64, I64, I64, P, I64, I32, P],
     "wd_gemm_tn_splitk": [P, I64, P, I64, P, I64, I64, I64, I32, I32, P],
+    "wd_fold_affine_all": [P, P, I32, I64, F32, P, I64, P, I64, P],
+    "wd_mlp_finalize_all": [P, I32, I64, P, F32, P, P],
+    "wd_logits_head_blocks": [I64],
+    "wd_logits_head": [P, I64, I64, P, P, I32, P, P, P, I64, P, P, P, P, P, P, I64, I32, P, P],
     "wd_fold_affine": [P, I64, I64, P, P, F32, P, P, P, P, I64, I64, P],
     "wd_act_bwd": [P, I64, P, I64, I32, P, I64, I64, I64, P],
     "wd_mlp_finalize": [P, I32, P, I64, I64, P, P, P, P, F32, P, I64, I64, P],
     "wd_adagrad_dense": [P, P, P, I64, F32, P],
     "wd_fill_f32": [P, F32, I64, P],
 }
-_RESTYPES = {"wd_sort_workspace_bytes": SZ}
+_RESTYPES = {"wd_sort_workspace_bytes": SZ, "wd_logits_head_blocks": I64}
 
 EXPORTED_SYMBOLS = sorted(list(_PROTOS) + ["wd_last_error"])
 

@@ -27,14 +27,17 @@ namespace {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
-constexpr int BM = 64, BN = 64, BK = 16, LD = 68;
+constexpr int BM = 64, BN = 64;
+constexpr int LD_RC = 65;  // reduction-contiguous operand: transposed through 4 scalar LDS stores (2-way conflicts, free)
+constexpr int LD_OC = 68;  // output-contiguous operand: float4 LDS stores need 16-byte rows
 
 struct GemmArgs {
   const float *A;
   const float *B;
   float *C;
   const float *bias;
-  int64_t lda, ldb, ldc;
+  const float *act_src; // NT epilogue: C = (A B^T) * act'(act_src[m, n])  (NULL: plain)
+  int64_t lda, ldb, ldc, ld_act;
   int64_t M, N, K;      // output M x N, reduction K
   int64_t kchunk;       // reduction slice per blockIdx.z
   int64_t c_split;      // element stride between split-K partial outputs
@@ -77,24 +80,49 @@ __device__ __forceinline__ float act_bwd(float a, int act) {
   }
 }
 
-// rows x cols window [R, C] of a row-major matrix; 4 consecutive columns starting at col (col % 4 == 0)
-__device__ __forceinline__ float4 load4(const float *__restrict__ P, int64_t row, int64_t col, int64_t ld, int64_t R,
-                                        int64_t C, bool vec_ok) {
-  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (row >= R || col >= C) return v;
-  const float *p = P + row * ld + col;
-  if (vec_ok && col + 3 < C) return *reinterpret_cast<const float4 *>(p);
-  v.x = p[0];
-  if (col + 1 < C) v.y = p[1];
-  if (col + 2 < C) v.z = p[2];
-  if (col + 3 < C) v.w = p[3];
+// Branch-free tile loads: the address is clamped into the matrix (so the load is always legal and is issued
+// unconditionally -> it stays in flight across the MFMA block), out-of-range elements are zeroed when the
+// registers are written to LDS.  VEC: ld % 4 == 0 and a 16-byte aligned base, one 16-byte load; else 4 scalar loads.
+template <bool VEC>
+__device__ __forceinline__ float4 load4c(const float *__restrict__ P, int64_t row, int64_t col, int64_t ld, int64_t R,
+                                         int64_t C) {
+  const int64_t rc = row < R ? row : R - 1;
+  if (VEC) {
+    const int64_t cc = col < C ? col : 0;  // col % 4 == 0, C <= ld, ld % 4 == 0  =>  cc + 3 < ld
+    return *reinterpret_cast<const float4 *>(P + rc * ld + cc);
+  }
+  const float *p = P + rc * ld;
+  const int64_t cl = C - 1;
+  float4 v;
+  v.x = p[col < cl ? col : cl];
+  v.y = p[col + 1 < cl ? col + 1 : cl];
+  v.z = p[col + 2 < cl ? col + 2 : cl];
+  v.w = p[col + 3 < cl ? col + 3 : cl];
   return v;
 }
 
-template <bool A_RC, bool B_RC, int EPI>
+__device__ __forceinline__ float4 mask4(float4 v, int64_t row, int64_t col, int64_t R, int64_t C) {
+  const bool r = row < R;
+  v.x = (r && col < C) ? v.x : 0.f;
+  v.y = (r && col + 1 < C) ? v.y : 0.f;
+  v.z = (r && col + 2 < C) ? v.z : 0.f;
+  v.w = (r && col + 3 < C) ? v.w : 0.f;
+  return v;
+}
+
+// 64x64 output tile, BK-deep reduction slab, LDS double-buffered: the global loads of slab i+1 are issued
+// before the BK/2 MFMAs of slab i and land in the other LDS buffer afterwards -> ONE barrier per slab and
+// NV = BK/16 independent 16-byte loads per operand per lane in flight (the BK=16 single-stage version paid
+// one full HBM/L2 latency per 8 MFMAs).  MFMA fragments are read from LDS one group of FG steps ahead.
+template <bool A_RC, bool B_RC, int EPI, int BK, bool VEC>
 __global__ void __launch_bounds__(256) k_gemm(GemmArgs g) {
-  __shared__ float As[BK * LD];
-  __shared__ float Bs[BK * LD];
+  constexpr int LDA = A_RC ? LD_RC : LD_OC;
+  constexpr int LDB = B_RC ? LD_RC : LD_OC;
+  constexpr int NV = BK / 16;  // float4 per lane per operand per slab
+  constexpr int FG = 8;        // MFMA steps per fragment group
+  constexpr int NG = BK / 2 / FG;
+  __shared__ __attribute__((aligned(16))) float As[2][BK * LDA];
+  __shared__ __attribute__((aligned(16))) float Bs[2][BK * LDB];
   const int t = threadIdx.x;
   const int lane = t & 63, wave = t >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -111,41 +139,63 @@ __global__ void __launch_bounds__(256) k_gemm(GemmArgs g) {
 
   const int64_t kbeg = (int64_t)blockIdx.z * g.kchunk;
   const int64_t kend = kbeg + g.kchunk < g.K ? kbeg + g.kchunk : g.K;
+  const int64_t a_cols = g.ones_row >= 0 ? g.ones_row : g.M;  // TN: the appended ones row is synthesised
 
-  // loader coordinates
-  const int rc_o = t >> 2, rc_r = (t & 3) * 4;  // RC: 64 out rows x 16 reduction (4 float4 per row)
-  const int oc_r = t >> 4, oc_o = (t & 15) * 4; // OC: 16 reduction rows x 64 out (16 float4 per row)
-
-  auto load_a = [&](int64_t k0) -> float4 {
-    if (A_RC) return load4(g.A, m0 + rc_o, k0 + rc_r, g.lda, g.M, kend, g.a_vec);
-    float4 v = load4(g.A, k0 + oc_r, m0 + oc_o, g.lda, kend, g.ones_row >= 0 ? g.ones_row : g.M, g.a_vec);
-    if (g.ones_row >= 0 && k0 + oc_r < kend) {
-      const int64_t c = m0 + oc_o;
-      if (c == g.ones_row) v.x = 1.f;
-      if (c + 1 == g.ones_row) v.y = 1.f;
-      if (c + 2 == g.ones_row) v.z = 1.f;
-      if (c + 3 == g.ones_row) v.w = 1.f;
-    }
-    return v;
-  };
-  auto load_b = [&](int64_t k0) -> float4 {
-    if (B_RC) return load4(g.B, n0 + rc_o, k0 + rc_r, g.ldb, g.N, kend, g.b_vec);
-    return load4(g.B, k0 + oc_r, n0 + oc_o, g.ldb, kend, g.N, g.b_vec);
-  };
-  auto store_a = [&](float4 v) {
-    if (A_RC) {
-      As[(rc_r + 0) * LD + rc_o] = v.x; As[(rc_r + 1) * LD + rc_o] = v.y;
-      As[(rc_r + 2) * LD + rc_o] = v.z; As[(rc_r + 3) * LD + rc_o] = v.w;
-    } else {
-      *reinterpret_cast<float4 *>(&As[oc_r * LD + oc_o]) = v;
+  // loader coordinates of float4 number v (idx = t + 256 v):
+  //   RC: 64 out rows x BK reduction, BK/4 float4 per row      OC: BK reduction rows x 64 out, 16 float4 per row
+  auto load_a = [&](int64_t k0, float4 (&ra)[NV]) {
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const int idx = t + v * 256;
+      if (A_RC) ra[v] = load4c<VEC>(g.A, m0 + idx / (BK / 4), k0 + (idx % (BK / 4)) * 4, g.lda, g.M, kend);
+      else ra[v] = load4c<VEC>(g.A, k0 + (idx >> 4), m0 + (idx & 15) * 4, g.lda, kend, a_cols);
     }
   };
-  auto store_b = [&](float4 v) {
-    if (B_RC) {
-      Bs[(rc_r + 0) * LD + rc_o] = v.x; Bs[(rc_r + 1) * LD + rc_o] = v.y;
-      Bs[(rc_r + 2) * LD + rc_o] = v.z; Bs[(rc_r + 3) * LD + rc_o] = v.w;
-    } else {
-      *reinterpret_cast<float4 *>(&Bs[oc_r * LD + oc_o]) = v;
+  auto load_b = [&](int64_t k0, float4 (&rb)[NV]) {
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const int idx = t + v * 256;
+      if (B_RC) rb[v] = load4c<VEC>(g.B, n0 + idx / (BK / 4), k0 + (idx % (BK / 4)) * 4, g.ldb, g.N, kend);
+      else rb[v] = load4c<VEC>(g.B, k0 + (idx >> 4), n0 + (idx & 15) * 4, g.ldb, kend, g.N);
+    }
+  };
+  // registers -> LDS (zeroing what lies outside the matrix)
+  auto store_a = [&](float *S, int64_t k0, const float4 (&rv)[NV]) {
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const int idx = t + v * 256;
+      if (A_RC) {
+        const int o = idx / (BK / 4), kr = (idx % (BK / 4)) * 4;
+        const float4 x = mask4(rv[v], m0 + o, k0 + kr, g.M, kend);
+        S[(kr + 0) * LD_RC + o] = x.x; S[(kr + 1) * LD_RC + o] = x.y;
+        S[(kr + 2) * LD_RC + o] = x.z; S[(kr + 3) * LD_RC + o] = x.w;
+      } else {
+        const int rr = idx >> 4, cc = (idx & 15) * 4;
+        float4 x = mask4(rv[v], k0 + rr, m0 + cc, kend, a_cols);
+        if (g.ones_row >= 0 && k0 + rr < kend) {
+          const int64_t c = m0 + cc;
+          if (c == g.ones_row) x.x = 1.f;
+          if (c + 1 == g.ones_row) x.y = 1.f;
+          if (c + 2 == g.ones_row) x.z = 1.f;
+          if (c + 3 == g.ones_row) x.w = 1.f;
+        }
+        *reinterpret_cast<float4 *>(&S[rr * LD_OC + cc]) = x;
+      }
+    }
+  };
+  auto store_b = [&](float *S, int64_t k0, const float4 (&rv)[NV]) {
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const int idx = t + v * 256;
+      if (B_RC) {
+        const int o = idx / (BK / 4), kr = (idx % (BK / 4)) * 4;
+        const float4 x = mask4(rv[v], n0 + o, k0 + kr, g.N, kend);
+        S[(kr + 0) * LD_RC + o] = x.x; S[(kr + 1) * LD_RC + o] = x.y;
+        S[(kr + 2) * LD_RC + o] = x.z; S[(kr + 3) * LD_RC + o] = x.w;
+      } else {
+        const int rr = idx >> 4, cc = (idx & 15) * 4;
+        *reinterpret_cast<float4 *>(&S[rr * LD_OC + cc]) = mask4(rv[v], k0 + rr, n0 + cc, kend, g.N);
+      }
     }
   };
 
@@ -153,30 +203,48 @@ __global__ void __launch_bounds__(256) k_gemm(GemmArgs g) {
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 
-  float4 ra = load_a(kbeg), rb = load_b(kbeg);
-  store_a(ra);
-  store_b(rb);
+  float4 ra[NV], rb[NV];
+  load_a(kbeg, ra);
+  load_b(kbeg, rb);
+  store_a(As[0], kbeg, ra);
+  store_b(Bs[0], kbeg, rb);
   __syncthreads();
 
   const int fr = (lane >> 5), fc = (lane & 31);
+  int cur = 0;
   for (int64_t k0 = kbeg; k0 < kend; k0 += BK) {
     const bool more = k0 + BK < kend;
     if (more) {
-      ra = load_a(k0 + BK);
-      rb = load_b(k0 + BK);
+      load_a(k0 + BK, ra);
+      load_b(k0 + BK, rb);
+    }
+    const float *Ac = As[cur] + fr * LDA + wm * 32 + fc;
+    const float *Bc = Bs[cur] + fr * LDB + wn * 32 + fc;
+    float fa[2][FG], fb[2][FG];
+#pragma unroll
+    for (int j = 0; j < FG; ++j) {
+      fa[0][j] = Ac[(2 * j) * LDA];
+      fb[0][j] = Bc[(2 * j) * LDB];
     }
 #pragma unroll
-    for (int kk = 0; kk < BK / 2; ++kk) {
-      const float a = As[(kk * 2 + fr) * LD + wm * 32 + fc];
-      const float b = Bs[(kk * 2 + fr) * LD + wn * 32 + fc];
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    for (int gi = 0; gi < NG; ++gi) {
+      if (gi + 1 < NG) {
+#pragma unroll
+        for (int j = 0; j < FG; ++j) {
+          fa[(gi + 1) & 1][j] = Ac[(2 * ((gi + 1) * FG + j)) * LDA];
+          fb[(gi + 1) & 1][j] = Bc[(2 * ((gi + 1) * FG + j)) * LDB];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < FG; ++j)
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[gi & 1][j], fb[gi & 1][j], acc, 0, 0, 0);
+    }
+    if (more) {
+      store_a(As[cur ^ 1], k0 + BK, ra);
+      store_b(Bs[cur ^ 1], k0 + BK, rb);
     }
     __syncthreads();
-    if (more) {
-      store_a(ra);
-      store_b(rb);
-      __syncthreads();
-    }
+    cur ^= 1;
   }
 
   // C/D layout of 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
@@ -196,12 +264,15 @@ __global__ void __launch_bounds__(256) k_gemm(GemmArgs g) {
       v = act_fwd(v + bv, g.act);
     } else if (EPI == 1) {
       if (g.accumulate) v += Cz[m * g.ldc + n];
+      if (g.act_src) v *= act_bwd(g.act_src[m * g.ld_act + n], g.act);
     }
     Cz[m * g.ldc + n] = v;
   }
 }
 
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+constexpr int kBK = 64;
 
 template <bool A_RC, bool B_RC, int EPI>
 int launch_gemm(GemmArgs g, int nsplit, hipStream_t st, const char *what) {
@@ -210,7 +281,8 @@ int launch_gemm(GemmArgs g, int nsplit, hipStream_t st, const char *what) {
   g.a_vec = (g.lda % 4 == 0) && aligned16(g.A);
   g.b_vec = (g.ldb % 4 == 0) && aligned16(g.B);
   dim3 grid((unsigned)(g.tiles_m * g.tiles_n), 1, (unsigned)nsplit);
-  hipLaunchKernelGGL((k_gemm<A_RC, B_RC, EPI>), grid, dim3(256), 0, st, g);
+  if (g.a_vec && g.b_vec) hipLaunchKernelGGL((k_gemm<A_RC, B_RC, EPI, kBK, true>), grid, dim3(256), 0, st, g);
+  else hipLaunchKernelGGL((k_gemm<A_RC, B_RC, EPI, kBK, false>), grid, dim3(256), 0, st, g);
   return wd::check_launch(what);
 }
 
@@ -219,15 +291,16 @@ int launch_gemm(GemmArgs g, int nsplit, hipStream_t st, const char *what) {
 // s[k] = gamma*inv (or 1), t[k] = beta (or 0);  Wf = diag(s) W;  bf_part[c] = (c == 0 ? b : 0) + t_c^T W_c
 // grid (ceil(N/64), WD_FOLD_PARTS): block = 64 columns x 4 k-lanes over one K chunk; the partial bias
 // sums stay separate per chunk (deterministic) and are added up by the GEMM epilogue.
-__global__ void __launch_bounds__(256)
-k_fold_affine(const float *__restrict__ P, int64_t w_off, int64_t b_off, const int32_t *__restrict__ gamma_idx,
-              const int32_t *__restrict__ beta_idx, float inv, float *__restrict__ Wf, float *__restrict__ bf,
-              float *__restrict__ s_out, float *__restrict__ t_out, int64_t K, int64_t N) {
-  __shared__ float red[4][64];
+__device__ __forceinline__ void fold_affine_body(const float *__restrict__ P, int64_t w_off, int64_t b_off,
+                                                 const int32_t *__restrict__ gamma_idx,
+                                                 const int32_t *__restrict__ beta_idx, float inv,
+                                                 float *__restrict__ Wf, float *__restrict__ bf,
+                                                 float *__restrict__ s_out, float *__restrict__ t_out, int64_t K,
+                                                 int64_t N, int bx, int by, float (*red)[64]) {
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-  const int64_t n = (int64_t)blockIdx.x * 64 + tx;
+  const int64_t n = (int64_t)bx * 64 + tx;
   const int64_t kc = (K + WD_FOLD_PARTS - 1) / WD_FOLD_PARTS;
-  const int64_t k0 = (int64_t)blockIdx.y * kc;
+  const int64_t k0 = (int64_t)by * kc;
   const int64_t k1 = k0 + kc < K ? k0 + kc : K;
   const float *W = P + w_off;
   float tb = 0.f;
@@ -236,7 +309,7 @@ k_fold_affine(const float *__restrict__ P, int64_t w_off, int64_t b_off, const i
     const int32_t bi = beta_idx ? beta_idx[k] : -1;
     const float sk = gi >= 0 ? P[gi] * inv : 1.0f;
     const float tk = bi >= 0 ? P[bi] : 0.0f;
-    if (blockIdx.x == 0 && tx == 0) {
+    if (bx == 0 && tx == 0) {
       s_out[k] = sk;
       t_out[k] = tk;
     }
@@ -250,9 +323,33 @@ k_fold_affine(const float *__restrict__ P, int64_t w_off, int64_t b_off, const i
   __syncthreads();
   if (ty == 0 && n < N) {
     float v = red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx];
-    if (blockIdx.y == 0) v += P[b_off + n];
-    bf[(int64_t)blockIdx.y * N + n] = v;
+    if (by == 0) v += P[b_off + n];
+    bf[(int64_t)by * N + n] = v;
   }
+}
+
+__global__ void __launch_bounds__(256)
+k_fold_affine(const float *__restrict__ P, int64_t w_off, int64_t b_off, const int32_t *__restrict__ gamma_idx,
+              const int32_t *__restrict__ beta_idx, float inv, float *__restrict__ Wf, float *__restrict__ bf,
+              float *__restrict__ s_out, float *__restrict__ t_out, int64_t K, int64_t N) {
+  __shared__ float red[4][64];
+  fold_affine_body(P, w_off, b_off, gamma_idx, beta_idx, inv, Wf, bf, s_out, t_out, K, N, blockIdx.x, blockIdx.y, red);
+}
+
+// every layer of every tower in ONE launch: blockIdx.z = layer (descriptor table in HBM); also clears the
+// step's small accumulators (loss, optional flat gradient buffer) so that the step needs no separate fills.
+__global__ void __launch_bounds__(256)
+k_fold_affine_all(const float *__restrict__ P, const wd_mlp_layer_t *__restrict__ layers, float inv,
+                  float *__restrict__ zero_a, int64_t zero_a_n, float *__restrict__ zero_b, int64_t zero_b_n) {
+  __shared__ float red[4][64];
+  const int64_t bid = ((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+  const int64_t nthreads = (int64_t)gridDim.x * gridDim.y * gridDim.z * 256;
+  for (int64_t i = bid * 256 + threadIdx.x; i < zero_a_n; i += nthreads) zero_a[i] = 0.f;
+  for (int64_t i = bid * 256 + threadIdx.x; i < zero_b_n; i += nthreads) zero_b[i] = 0.f;
+  const wd_mlp_layer_t L = layers[blockIdx.z];
+  if ((int64_t)blockIdx.x * 64 >= L.N) return;
+  fold_affine_body(P, L.w_off, L.b_off, L.gamma_idx, L.beta_idx, inv, L.Wf, L.bf, L.s, L.t, L.K, L.N, blockIdx.x,
+                   blockIdx.y, red);
 }
 
 __global__ void __launch_bounds__(256)
@@ -265,52 +362,192 @@ k_act_bwd(const float *__restrict__ da, int64_t ldda, const float *__restrict__ 
 }
 
 // One block per input column k (row of W): reduce the split-K partials, emit dW row, and the
-// affine-parameter gradients of the producer of column k.
-__global__ void __launch_bounds__(256)
-k_mlp_finalize(const float *__restrict__ Gpart, int32_t nsplit, const float *__restrict__ P, int64_t w_off,
-               int64_t b_off, const float *__restrict__ s, const float *__restrict__ t,
-               const int32_t *__restrict__ gamma_idx, const int32_t *__restrict__ beta_idx, float inv,
-               float *__restrict__ Gflat, int64_t K, int64_t N) {
-  __shared__ float red_s[4], red_t[4];
-  const int64_t k = blockIdx.x;  // 0..K (row K = ones row = db)
+// affine-parameter gradients of the producer of column k.  `store_affine`: the producer has exactly one
+// consumer (simple mode) -> plain store; otherwise accumulate (launches are stream-ordered and k is unique
+// within a launch, so no atomics are needed).
+__device__ __forceinline__ void mlp_finalize_body(const float *__restrict__ Gpart, int32_t nsplit,
+                                                  const float *__restrict__ P, int64_t w_off, int64_t b_off,
+                                                  const float *__restrict__ s, const float *__restrict__ t,
+                                                  const int32_t *__restrict__ gamma_idx,
+                                                  const int32_t *__restrict__ beta_idx, float inv,
+                                                  float *__restrict__ Gflat, int64_t K, int64_t N, int64_t k,
+                                                  bool store_affine, float *red_g, float *red_d) {
+  // thread (nx, zq): column nx (+ j*NT), splits zq, zq+ZQ, ...; the ZQ partial sums are combined in fixed order
+  const int NT = N >= 256 ? 256 : (N > 128 ? 256 : (N > 64 ? 128 : (N > 32 ? 64 : (N > 16 ? 32 : 16))));
+  const int ZQ = 256 / NT;
+  const int nx = threadIdx.x % NT, zq = threadIdx.x / NT;
   const int64_t split_stride = (K + 1) * N;
   const float *W = P + w_off;
   float acc_s = 0.f, acc_t = 0.f;
-  for (int64_t n = threadIdx.x; n < N; n += blockDim.x) {
+  for (int64_t n0 = 0; n0 < N; n0 += NT) {
+    const int64_t n = n0 + nx;
     float gk = 0.f, db = 0.f;
-    for (int32_t z = 0; z < nsplit; ++z) {
-      gk += Gpart[z * split_stride + k * N + n];
-      db += Gpart[z * split_stride + K * N + n];
+    if (n < N) {
+#pragma unroll 4
+      for (int32_t z = zq; z < nsplit; z += ZQ) {
+        gk += Gpart[z * split_stride + k * N + n];
+        db += Gpart[z * split_stride + K * N + n];
+      }
     }
-    if (k == K) {
-      Gflat[b_off + n] = db;
-    } else {
-      Gflat[w_off + k * N + n] = s[k] * gk + t[k] * db;
-      const float w = W[k * N + n];
-      acc_s += w * gk;
-      acc_t += w * db;
+    if (ZQ > 1) {
+      __syncthreads();
+      red_g[zq * NT + nx] = gk;
+      red_d[zq * NT + nx] = db;
+      __syncthreads();
+      if (zq == 0) {
+        for (int j = 1; j < ZQ; ++j) {
+          gk += red_g[j * NT + nx];
+          db += red_d[j * NT + nx];
+        }
+      }
+    }
+    if (zq == 0 && n < N) {
+      if (k == K) {
+        Gflat[b_off + n] = db;
+      } else {
+        Gflat[w_off + k * N + n] = s[k] * gk + t[k] * db;
+        const float w = W[k * N + n];
+        acc_s += w * gk;
+        acc_t += w * db;
+      }
     }
   }
   if (k == K) return;
   const int32_t gi = gamma_idx ? gamma_idx[k] : -1;
   const int32_t bi = beta_idx ? beta_idx[k] : -1;
   if (gi < 0 && bi < 0) return;
+  // block reduction of (acc_s, acc_t) in fixed order (only zq == 0 threads hold non-zero values)
   for (int off = 32; off > 0; off >>= 1) {
     acc_s += __shfl_down(acc_s, off, 64);
     acc_t += __shfl_down(acc_t, off, 64);
   }
+  __syncthreads();
   if ((threadIdx.x & 63) == 0) {
-    red_s[threadIdx.x >> 6] = acc_s;
-    red_t[threadIdx.x >> 6] = acc_t;
+    red_g[threadIdx.x >> 6] = acc_s;
+    red_d[threadIdx.x >> 6] = acc_t;
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    const float ss = red_s[0] + red_s[1] + red_s[2] + red_s[3];
-    const float tt = red_t[0] + red_t[1] + red_t[2] + red_t[3];
-    // several consumer layers may feed the same producer (dense / resnet modes): accumulate.
-    // Launches are stream-ordered and k is unique within a launch, so no atomics are needed.
-    if (gi >= 0) Gflat[gi] += ss * inv;
-    if (bi >= 0) Gflat[bi] += tt;
+    const float ss = red_g[0] + red_g[1] + red_g[2] + red_g[3];
+    const float tt = red_d[0] + red_d[1] + red_d[2] + red_d[3];
+    if (store_affine) {
+      if (gi >= 0) Gflat[gi] = ss * inv;
+      if (bi >= 0) Gflat[bi] = tt;
+    } else {
+      if (gi >= 0) Gflat[gi] += ss * inv;
+      if (bi >= 0) Gflat[bi] += tt;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256)
+k_mlp_finalize(const float *__restrict__ Gpart, int32_t nsplit, const float *__restrict__ P, int64_t w_off,
+               int64_t b_off, const float *__restrict__ s, const float *__restrict__ t,
+               const int32_t *__restrict__ gamma_idx, const int32_t *__restrict__ beta_idx, float inv,
+               float *__restrict__ Gflat, int64_t K, int64_t N) {
+  __shared__ float red_g[256], red_d[256];
+  mlp_finalize_body(Gpart, nsplit, P, w_off, b_off, s, t, gamma_idx, beta_idx, inv, Gflat, K, N, blockIdx.x, false,
+                    red_g, red_d);
+}
+
+// all layers in one launch (blockIdx.y = layer): legal only when every BN gamma/beta has ONE consumer layer
+__global__ void __launch_bounds__(256)
+k_mlp_finalize_all(const wd_mlp_layer_t *__restrict__ layers, const float *__restrict__ P, float inv,
+                   float *__restrict__ Gflat) {
+  __shared__ float red_g[256], red_d[256];
+  const wd_mlp_layer_t L = layers[blockIdx.y];
+  if ((int64_t)blockIdx.x > L.K) return;
+  mlp_finalize_body(L.Gpart, L.nsplit, P, L.w_off, L.b_off, L.s, L.t, L.gamma_idx, L.beta_idx, inv, Gflat, L.K, L.N,
+                    blockIdx.x, true, red_g, red_d);
+}
+
+// ---- logits layer + head, forward AND backward of that layer in one launch ------------------------
+// (python/lib/dnn.py:226-232 logits dense(units=1); python/lib/joint.py:216-222 add_n; head joint.py:264-269.)
+// Block `blk` owns examples [blk*64, blk*64+64):
+//   phase 1 (wave per example): dnn_logit = a[b, window] . wf + bias; logit = dnn + wide; CE loss, p, dlogit
+//   phase 2 (lane per input column k): gradient wrt the window  out[b,k] = dlogit[b]*wf[k] (* act'(a[b,k]) when
+//           `act` != 0: simple mode, `out` is then dz of the last hidden layer), and this block's partial of the
+//           kernel gradient  Gpart[blk][k] = sum_b a[b,k]*dlogit[b],  Gpart[blk][K] = sum_b dlogit[b]  (fixed order).
+constexpr int HEAD_CHUNK = 64;
+__global__ void __launch_bounds__(256)
+k_logits_head(const float *__restrict__ a, int64_t ld_a, int64_t K, const float *__restrict__ wf,
+              const float *__restrict__ bf, int32_t bias_parts, const float *__restrict__ wide_logit,
+              const float *__restrict__ labels, const float *__restrict__ weights, int64_t batch,
+              float *__restrict__ dnn_logit, float *__restrict__ logit, float *__restrict__ prob,
+              float *__restrict__ dlogit, float *__restrict__ loss_sum, float *__restrict__ out, int64_t ld_out,
+              int32_t act, float *__restrict__ Gpart) {
+  __shared__ float sdl[HEAD_CHUNK];
+  __shared__ float red[256];
+  const int64_t b0 = (int64_t)blockIdx.x * HEAD_CHUNK;
+  float bias = 0.f;
+  for (int p = 0; p < bias_parts; ++p) bias += bf[p];
+  // phase 1: 4 lanes per example (k = part, part+4, ...), the block's 64 examples in parallel
+  const int ex = threadIdx.x >> 2, part = threadIdx.x & 3;
+  const int64_t b = b0 + ex;
+  const bool live = b < batch;
+  float d = 0.f;
+  if (live) {
+    const float *ar = a + b * ld_a;
+#pragma unroll 4
+    for (int64_t k = part; k < K; k += 4) d += ar[k] * wf[k];
+  }
+  d += __shfl_xor(d, 1, 64);
+  d += __shfl_xor(d, 2, 64);
+  float lsum = 0.f, dl = 0.f;
+  if (live && part == 0) {
+    const float dn = d + bias;
+    const float x = dn + (wide_logit ? wide_logit[b] : 0.f);
+    const float y = labels ? labels[b] : 0.f;
+    const float w = weights ? weights[b] : 1.0f;
+    const float e = expf(-fabsf(x));
+    const float p = x >= 0.f ? 1.0f / (1.0f + e) : e / (1.0f + e);
+    dl = w * (p - y);
+    lsum = w * (fmaxf(x, 0.f) - x * y + log1pf(e));
+    if (dnn_logit) dnn_logit[b] = dn;
+    if (logit) logit[b] = x;
+    if (prob) prob[b] = p;
+    if (dlogit) dlogit[b] = dl;
+  }
+  if (part == 0) sdl[ex] = dl;
+  for (int off = 32; off > 0; off >>= 1) lsum += __shfl_down(lsum, off, 64);
+  if ((threadIdx.x & 63) == 0 && loss_sum) atomicAdd(loss_sum, lsum);
+  if (!out && !Gpart) return;
+  __syncthreads();
+  // phase 2: thread (kx, q): column kx (+ j*KT when K > 256), examples q, q+Q, ...
+  const int KT = K <= 64 ? 64 : (K <= 128 ? 128 : 256);
+  const int Q = 256 / KT;
+  const int kx = threadIdx.x % KT, q = threadIdx.x / KT;
+  float *Gp = Gpart ? Gpart + (int64_t)blockIdx.x * (K + 1) : nullptr;
+  for (int64_t k = kx; k < K; k += KT) {
+    const float w = wf[k];
+    float gw = 0.f;
+#pragma unroll 4
+    for (int i = q; i < HEAD_CHUNK; i += Q) {
+      const int64_t b = b0 + i;
+      if (b >= batch) break;
+      const float av = a[b * ld_a + k];
+      const float dl = sdl[i];
+      gw += av * dl;
+      if (out) out[b * ld_out + k] = act ? dl * w * act_bwd(av, act) : dl * w;
+    }
+    if (Q == 1) {
+      if (Gp) Gp[k] = gw;
+    } else {
+      red[q * KT + kx] = gw;  // K <= 128 <= KT: this loop body runs at most once per thread
+    }
+  }
+  if (Q > 1) {  // combine the Q example-strided partials in fixed order
+    __syncthreads();
+    if (q == 0 && kx < K && Gp) {
+      float v = red[kx];
+      for (int j = 1; j < Q; ++j) v += red[j * KT + kx];
+      Gp[kx] = v;
+    }
+  }
+  if (threadIdx.x == 0 && Gp) {
+    float v = 0.f;
+    for (int i = 0; i < HEAD_CHUNK; ++i) v += sdl[i];
+    Gp[K] = v;
   }
 }
 
@@ -351,6 +588,19 @@ extern "C" int wd_gemm_nt(const float *A, int64_t lda, const float *B, int64_t l
   return launch_gemm<true, true, 1>(g, 1, wd::as_stream(stream), "wd_gemm_nt");
 }
 
+extern "C" int wd_gemm_nt_actbwd(const float *A, int64_t lda, const float *B, int64_t ldb, float *C, int64_t ldc,
+                                 int64_t M, int64_t N, int64_t K, const float *act_src, int64_t ld_act, int32_t act,
+                                 wd_stream_t stream) {
+  if (M <= 0 || N <= 0) return WD_OK;
+  WD_REQUIRE(A && B && C && act_src, "null pointer");
+  WD_REQUIRE(K > 0, "K must be > 0");
+  GemmArgs g{};
+  g.A = A; g.B = B; g.C = C; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+  g.M = M; g.N = N; g.K = K; g.kchunk = K; g.ones_row = -1; g.accumulate = 0;
+  g.act_src = act_src; g.ld_act = ld_act; g.act = act;
+  return launch_gemm<true, true, 1>(g, 1, wd::as_stream(stream), "wd_gemm_nt_actbwd");
+}
+
 extern "C" int wd_gemm_tn_splitk(const float *A, int64_t lda, const float *B, int64_t ldb, float *Cpart, int64_t M,
                                  int64_t N, int64_t K, int32_t nsplit, int32_t append_ones, wd_stream_t stream) {
   if (M <= 0 || N <= 0) return WD_OK;
@@ -360,7 +610,7 @@ extern "C" int wd_gemm_tn_splitk(const float *A, int64_t lda, const float *B, in
   const int64_t Mo = append_ones ? M + 1 : M;
   g.A = A; g.B = B; g.C = Cpart; g.lda = lda; g.ldb = ldb; g.ldc = N;
   g.M = Mo; g.N = N; g.K = K;
-  g.kchunk = wd::ceil_div(wd::ceil_div(K, nsplit), BK) * BK;
+  g.kchunk = wd::ceil_div(wd::ceil_div(K, nsplit), kBK) * kBK;
   g.c_split = Mo * N;
   g.ones_row = append_ones ? M : -1;
   return launch_gemm<false, false, 2>(g, nsplit, wd::as_stream(stream), "wd_gemm_tn_splitk");
@@ -401,4 +651,41 @@ extern "C" int wd_adagrad_dense(float *w, float *accum, const float *g, int64_t 
   int blocks = (int)std::min<int64_t>(wd::ceil_div(n, 256), 2048);
   hipLaunchKernelGGL(k_adagrad_dense, dim3(blocks), dim3(256), 0, wd::as_stream(stream), w, accum, g, n, lr);
   return wd::check_launch("wd_adagrad_dense");
+}
+
+extern "C" int wd_fold_affine_all(const float *P, const wd_mlp_layer_t *layers_dev, int32_t nlayers, int64_t max_n,
+                                  float inv, float *zero_a, int64_t zero_a_n, float *zero_b, int64_t zero_b_n,
+                                  wd_stream_t stream) {
+  WD_REQUIRE(P && layers_dev, "null pointer");
+  WD_REQUIRE(nlayers > 0 && max_n > 0, "nlayers, max_n must be > 0");
+  hipLaunchKernelGGL(k_fold_affine_all, dim3((unsigned)wd::ceil_div(max_n, 64), WD_FOLD_PARTS, (unsigned)nlayers),
+                     dim3(256), 0, wd::as_stream(stream), P, layers_dev, inv, zero_a, zero_a ? zero_a_n : 0, zero_b,
+                     zero_b ? zero_b_n : 0);
+  return wd::check_launch("wd_fold_affine_all");
+}
+
+extern "C" int wd_mlp_finalize_all(const wd_mlp_layer_t *layers_dev, int32_t nlayers, int64_t max_k, const float *P,
+                                   float inv, float *Gflat, wd_stream_t stream) {
+  WD_REQUIRE(P && layers_dev && Gflat, "null pointer");
+  WD_REQUIRE(nlayers > 0 && max_k > 0, "nlayers, max_k must be > 0");
+  hipLaunchKernelGGL(k_mlp_finalize_all, dim3((unsigned)(max_k + 1), (unsigned)nlayers), dim3(256), 0,
+                     wd::as_stream(stream), layers_dev, P, inv, Gflat);
+  return wd::check_launch("wd_mlp_finalize_all");
+}
+
+extern "C" int64_t wd_logits_head_blocks(int64_t batch) { return wd::ceil_div(batch, HEAD_CHUNK); }
+
+extern "C" int wd_logits_head(const float *a, int64_t ld_a, int64_t K, const float *wf, const float *bf,
+                              int32_t bias_parts, const float *wide_logit, const float *labels, const float *weights,
+                              int64_t batch, float *dnn_logit, float *logit, float *prob, float *dlogit,
+                              float *loss_sum, float *out, int64_t ld_out, int32_t act, float *Gpart,
+                              wd_stream_t stream) {
+  if (batch <= 0) return WD_OK;
+  WD_REQUIRE(a && wf && bf, "null pointer");
+  WD_REQUIRE(K > 0 && bias_parts > 0, "K, bias_parts must be > 0");
+  WD_REQUIRE(labels || (!dlogit && !out && !Gpart), "labels required for the backward outputs");
+  hipLaunchKernelGGL(k_logits_head, dim3((unsigned)wd::ceil_div(batch, HEAD_CHUNK)), dim3(256), 0,
+                     wd::as_stream(stream), a, ld_a, K, wf, bf, bias_parts, wide_logit, labels, weights, batch,
+                     dnn_logit, logit, prob, dlogit, loss_sum, out, ld_out, act, Gpart);
+  return wd::check_launch("wd_logits_head");
 }

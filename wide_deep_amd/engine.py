@@ -122,11 +122,12 @@ class WideDeepEngine:
                 tw = {"layout": tl, "metas": metas, "L": L}
                 tw["act"] = torch.zeros(B, tl.ld, **f32)
                 tw["dact"] = torch.zeros(B, tl.ld, **f32)
-                maxN = max([m["N"] for m in metas])
-                tw["dz"] = torch.zeros(B * maxN, **f32)
+                maxN = max([m["N"] for m in metas] + [metas[L]["K"]])
+                tw["dz"] = [torch.zeros(B * maxN, **f32), torch.zeros(B * maxN, **f32)]   # ping-pong (fused act')
                 tw["logit"] = torch.zeros(B, **f32)
                 tw["Wf"], tw["bf"], tw["s"], tw["t"], tw["gidx"], tw["bidx"], tw["nsplit"] = [], [], [], [], [], [], []
-                gmax = 4
+                tw["Gpart"] = []
+                head_blocks = int(call("wd_logits_head_blocks", B))
                 for l, m in enumerate(metas):
                     K, N = m["K"], m["N"]
                     tw["Wf"].append(torch.zeros(K * N, **f32))
@@ -135,10 +136,13 @@ class WideDeepEngine:
                     tw["t"].append(torch.zeros(K, **f32))
                     tw["gidx"].append(torch.from_numpy(m["gamma_idx"]).to(dev))
                     tw["bidx"].append(torch.from_numpy(m["beta_idx"]).to(dev))
-                    tiles = math.ceil((K + 1) / 64) * math.ceil(N / 64)
-                    ns = max(1, min(math.ceil(768 / tiles), 32, max(1, B // 128)))
+                    if l == L:     # logits layer: partials come from wd_logits_head, one per 64-example block
+                        ns = head_blocks
+                    else:          # split-K over the batch: ~512 workgroups, >= 4 reduction slabs (of 64) each
+                        tiles = math.ceil((K + 1) / 64) * math.ceil(N / 64)
+                        ns = max(1, min(math.ceil(512 / tiles), 64, max(1, B // 256)))
                     tw["nsplit"].append(ns)
-                    gmax = max(gmax, ns * (K + 1) * N)
+                    tw["Gpart"].append(torch.zeros(ns * (K + 1) * N, **f32))
                     # tf.glorot_uniform_initializer kernel, zero bias, gamma 1, beta 0  
                     Ktf = len(plan.tf_rows_of_layer(ti, l))
                     lim = math.sqrt(6.0 / (Ktf + N))
@@ -148,8 +152,27 @@ class WideDeepEngine:
                     W[rows] = Wtf
                     if "gamma_off" in m:
                         self.P[m["gamma_off"]: m["gamma_off"] + N] = 1.0
-                tw["Gpart"] = torch.zeros(gmax, **f32)
                 self.towers.append(tw)
+            # descriptor table of every layer of every tower (wd_fold_affine_all / wd_mlp_finalize_all)
+            nl = sum(len(tw["metas"]) for tw in self.towers)
+            larr = (capi.WdMlpLayer * nl)()
+            i = 0
+            self.max_layer_n = self.max_layer_k = 1
+            for tw in self.towers:
+                for l, m in enumerate(tw["metas"]):
+                    d = larr[i]
+                    d.w_off, d.b_off, d.K, d.N = m["w_off"], m["b_off"], m["K"], m["N"]
+                    d.gamma_idx, d.beta_idx = tw["gidx"][l].data_ptr(), tw["bidx"][l].data_ptr()
+                    d.Wf, d.bf, d.s, d.t = (tw["Wf"][l].data_ptr(), tw["bf"][l].data_ptr(), tw["s"][l].data_ptr(),
+                                            tw["t"][l].data_ptr())
+                    d.Gpart, d.nsplit = tw["Gpart"][l].data_ptr(), tw["nsplit"][l]
+                    self.max_layer_n = max(self.max_layer_n, m["N"])
+                    self.max_layer_k = max(self.max_layer_k, m["K"])
+                    i += 1
+            self.n_layers = nl
+            self.layers_dev = torch.from_numpy(np.frombuffer(bytes(larr), dtype=np.uint8).copy()).to(dev)
+            # one launch finalises all layers iff every BN gamma/beta has a single consumer layer
+            self.all_simple = len(self.towers) == 1 and self.towers[0]["layout"].mode == "simple"
             self.dnn_logit = torch.zeros(B, **f32)
         else:
             self.P = self.Pacc = self.G = None
@@ -212,84 +235,142 @@ class WideDeepEngine:
                  ptr(bt.bag_offs), B, ptr(self.wide_logit), st)
 
     def forward(self, bt: DeviceBatch, need_loss=True):
-        """Fills self.logit / self.prob (and self.dlogit / self.loss when labels are given)."""
+        """Fills self.logit / self.prob (and self.dlogit / self.loss + the logits-layer backward when labels are given)."""
         self._check_batch(bt)
         spec, st = self.spec, _stream()
         B = bt.B
+        train = bt.labels is not None and need_loss
         self._sparse_forward(bt, st)
         if spec.has_deep:
+            # one launch: fold the BN affines of every layer into its consumer's weights; clear loss (+ G when the
+            # per-layer finalize path accumulates into it)
+            zero_g = train and not self.all_simple
+            call("wd_fold_affine_all", ptr(self.P), ptr(self.layers_dev), self.n_layers, self.max_layer_n, self.inv,
+                 ptr(self.loss), 1, ptr(self.G) if zero_g else None, self.G.numel() if zero_g else 0, st)
             tw0 = self.towers[0]
+            nt = len(self.towers)
             for ti, tw in enumerate(self.towers):
                 tl = tw["layout"]
                 if ti > 0:  # towers share the input layer (AUTO_REUSE, python/lib/dnn.py:83-90)
                     w0 = tl.seg_width[0]
                     tw["act"][:B, tl.seg_start[0]: tl.seg_start[0] + w0].copy_(
                         tw0["act"][:B, tw0["layout"].seg_start[0]: tw0["layout"].seg_start[0] + w0])
-                self._tower_forward(tw, B, st)
-            if len(self.towers) == 1:
-                dnn_logit = self.towers[0]["logit"]
+                self._tower_hidden_forward(tw, B, st)
+            if nt == 1:
+                self._tower_head(tw0, bt, B, st, train, fused=True)
             else:
+                # multi-DNN (python/lib/dnn.py:260-274): logits are summed over towers BEFORE the head, so each
+                # tower's logits layer runs forward-only here and its backward after the joint head
+                for tw in self.towers:
+                    self._tower_head(tw, bt, B, st, False, fused=False)
                 torch.add(self.towers[0]["logit"], self.towers[1]["logit"], out=self.dnn_logit)
                 for tw in self.towers[2:]:
                     self.dnn_logit.add_(tw["logit"])
-                dnn_logit = self.dnn_logit
+                self._plain_head(self.dnn_logit, bt, B, st, train)
         else:
-            dnn_logit = None
-        if bt.labels is not None and need_loss:
             self.loss.zero_()
+            self._plain_head(None, bt, B, st, train)
+        return self.logit[:B]
+
+    def _plain_head(self, dnn_logit, bt, B, st, train):
+        if train:
             call("wd_bce_sum_fwd_bwd", ptr(dnn_logit), ptr(self.wide_logit), ptr(bt.labels), ptr(bt.weights), B,
                  ptr(self.logit), ptr(self.prob), ptr(self.dlogit), ptr(self.loss), st)
         else:
             # logits / probabilities only: reuse the head kernel with a zero label vector
-            self.loss.zero_()
             zeros = self.dlogit
             zeros[:B].zero_()
             call("wd_bce_sum_fwd_bwd", ptr(dnn_logit), ptr(self.wide_logit), ptr(zeros), None, B, ptr(self.logit),
                  ptr(self.prob), None, None, st)
-        return self.logit[:B]
 
-    def _tower_forward(self, tw, B, st):
+    def _tower_hidden_forward(self, tw, B, st):
         tl, metas, L = tw["layout"], tw["metas"], tw["L"]
         act = tw["act"]
-        for l, m in enumerate(metas):
+        for l in range(L):
+            m = metas[l]
             K, N = m["K"], m["N"]
-            call("wd_fold_affine", ptr(self.P), m["w_off"], m["b_off"], ptr(tw["gidx"][l]), ptr(tw["bidx"][l]),
-                 self.inv, ptr(tw["Wf"][l]), ptr(tw["bf"][l]), ptr(tw["s"][l]), ptr(tw["t"][l]), K, N, st)
             a_ptr = act.data_ptr() + 4 * tl.in_start[l]
-            if l < L:
-                c_ptr, ldc, act_id = act.data_ptr() + 4 * tl.seg_start[l + 1], tl.ld, self.act_id
-            else:
-                c_ptr, ldc, act_id = tw["logit"].data_ptr(), 1, 0
-            call("wd_gemm_nn_bias_act", a_ptr, tl.ld, ptr(tw["Wf"][l]), N, ptr(tw["bf"][l]), capi.WD_FOLD_PARTS, act_id,
-                 c_ptr, ldc, B, N, K, st)
+            c_ptr = act.data_ptr() + 4 * tl.seg_start[l + 1]
+            call("wd_gemm_nn_bias_act", a_ptr, tl.ld, ptr(tw["Wf"][l]), N, ptr(tw["bf"][l]), capi.WD_FOLD_PARTS,
+                 self.act_id, c_ptr, tl.ld, B, N, K, st)
+
+    def _head_out(self, tw):
+        """Where the logits layer's input gradient goes: simple mode -> dz of the last hidden layer (act' fused),
+        otherwise the logits window of dact (plain store; the window covers every segment later accumulated into)."""
+        tl, L = tw["layout"], tw["L"]
+        if tl.mode == "simple" and L > 0:
+            return tw["dz"][0].data_ptr(), tw["metas"][L]["K"], self.act_id
+        return tw["dact"].data_ptr() + 4 * tl.in_start[L], tl.ld, 0
+
+    def _tower_head(self, tw, bt, B, st, train, fused):
+        """Logits layer.  fused=True: + joint head (wide logit, CE loss) + the layer's backward, one launch."""
+        tl, metas, L = tw["layout"], tw["metas"], tw["L"]
+        m = metas[L]
+        a_ptr = tw["act"].data_ptr() + 4 * tl.in_start[L]
+        if fused:
+            out_ptr, ld_out, act_id = self._head_out(tw) if train else (None, 0, 0)
+            call("wd_logits_head", a_ptr, tl.ld, m["K"], ptr(tw["Wf"][L]), ptr(tw["bf"][L]), capi.WD_FOLD_PARTS,
+                 ptr(self.wide_logit), ptr(bt.labels) if train else None, ptr(bt.weights) if train else None, B,
+                 ptr(tw["logit"]), ptr(self.logit), ptr(self.prob), ptr(self.dlogit) if train else None,
+                 ptr(self.loss) if train else None, out_ptr, ld_out, act_id,
+                 ptr(tw["Gpart"][L]) if train else None, st)
+        else:
+            call("wd_logits_head", a_ptr, tl.ld, m["K"], ptr(tw["Wf"][L]), ptr(tw["bf"][L]), capi.WD_FOLD_PARTS,
+                 None, None, None, B, ptr(tw["logit"]), None, None, None, None, None, 0, 0, None, st)
 
     # ------------------------------------------------------------------------------------------
     # backward + optimizers
     # ------------------------------------------------------------------------------------------
-    def _tower_backward(self, tw, B, st, need_dx):
+    def _tower_backward(self, tw, B, st, need_dx, head_done):
+        """Hidden layers L-1..0 (and the logits layer when the fused head has not already done it)."""
         tl, metas, L = tw["layout"], tw["metas"], tw["L"]
         act, dact = tw["act"], tw["dact"]
-        accumulate = 0 if tl.mode == "simple" else 1
-        if accumulate:
-            dact[:B].zero_()
-        for l in range(L, -1, -1):
+        simple = tl.mode == "simple"
+        if not head_done:
+            # multi-tower: dlogit is shared; run this tower's logits-layer backward (dlogit given as `labels`-free input)
+            m = metas[L]
+            out_ptr, ld_out, act_id = self._head_out(tw)
+            a_ptr = act.data_ptr() + 4 * tl.in_start[L]
+            call("wd_gemm_tn_splitk", a_ptr, tl.ld, ptr(self.dlogit), 1, ptr(tw["Gpart"][L]), m["K"], 1, B, 1, 1, st)
+            if simple and L > 0:
+                call("wd_gemm_nt_actbwd", ptr(self.dlogit), 1, ptr(tw["Wf"][L]), 1, out_ptr, ld_out, B, m["K"], 1,
+                     a_ptr, tl.ld, act_id, st)
+            else:
+                call("wd_gemm_nt", ptr(self.dlogit), 1, ptr(tw["Wf"][L]), 1, out_ptr, ld_out, B, m["K"], 1, 0, st)
+        if not self.all_simple:
+            self._finalize_layer(tw, L, st, 1 if not head_done else tw["nsplit"][L])
+        cur = 0
+        for l in range(L - 1, -1, -1):
             m = metas[l]
             K, N = m["K"], m["N"]
-            if l == L:
-                dz_ptr, lddz = self.dlogit.data_ptr(), 1
+            if simple:
+                dz_ptr, lddz = tw["dz"][cur].data_ptr(), N
             else:
                 seg = tl.seg_start[l + 1]
-                dz_ptr, lddz = tw["dz"].data_ptr(), N
+                dz_ptr, lddz = tw["dz"][0].data_ptr(), N
                 call("wd_act_bwd", dact.data_ptr() + 4 * seg, tl.ld, act.data_ptr() + 4 * seg, tl.ld, self.act_id,
                      dz_ptr, lddz, B, N, st)
             a_ptr = act.data_ptr() + 4 * tl.in_start[l]
             ns = tw["nsplit"][l]
-            call("wd_gemm_tn_splitk", a_ptr, tl.ld, dz_ptr, lddz, ptr(tw["Gpart"]), K, N, B, ns, 1, st)
-            call("wd_mlp_finalize", ptr(tw["Gpart"]), ns, ptr(self.P), m["w_off"], m["b_off"], ptr(tw["s"][l]),
-                 ptr(tw["t"][l]), ptr(tw["gidx"][l]), ptr(tw["bidx"][l]), self.inv, ptr(self.G), K, N, st)
-            if l > 0 or need_dx:
+            call("wd_gemm_tn_splitk", a_ptr, tl.ld, dz_ptr, lddz, ptr(tw["Gpart"][l]), K, N, B, ns, 1, st)
+            if not self.all_simple:
+                self._finalize_layer(tw, l, st, ns)
+            if simple:
+                if l > 0:     # dz of layer l-1 = (dz_l Wf_l^T) * act'(a_l-1's output), written to the other buffer
+                    call("wd_gemm_nt_actbwd", dz_ptr, lddz, ptr(tw["Wf"][l]), N, tw["dz"][cur ^ 1].data_ptr(), K, B, K, N,
+                         a_ptr, tl.ld, self.act_id, st)
+                    cur ^= 1
+                elif need_dx:
+                    call("wd_gemm_nt", dz_ptr, lddz, ptr(tw["Wf"][l]), N, dact.data_ptr() + 4 * tl.in_start[l], tl.ld,
+                         B, K, N, 0, st)
+            elif l > 0 or need_dx:
                 call("wd_gemm_nt", dz_ptr, lddz, ptr(tw["Wf"][l]), N, dact.data_ptr() + 4 * tl.in_start[l], tl.ld, B,
-                     K, N, accumulate, st)
+                     K, N, 1, st)
+
+    def _finalize_layer(self, tw, l, st, ns):
+        m = tw["metas"][l]
+        call("wd_mlp_finalize", ptr(tw["Gpart"][l]), ns, ptr(self.P), m["w_off"], m["b_off"], ptr(tw["s"][l]),
+             ptr(tw["t"][l]), ptr(tw["gidx"][l]), ptr(tw["bidx"][l]), self.inv, ptr(self.G), m["K"], m["N"], st)
 
     def sort_occurrences(self, bt, st):
         plan = self.plan
@@ -330,9 +411,14 @@ class WideDeepEngine:
         B = bt.B
         has_emb = bool(self.group_slots) if spec.has_deep else False
         if spec.has_deep:
-            self.G.zero_()
+            head_done = len(self.towers) == 1
             for tw in self.towers:
-                self._tower_backward(tw, B, st, need_dx=has_emb)
+                self._tower_backward(tw, B, st, need_dx=has_emb, head_done=head_done)
+            if self.all_simple:
+                if not head_done:
+                    raise NotImplementedError("multi-tower + all-layer finalize")  # guarded in __init__
+                call("wd_mlp_finalize_all", ptr(self.layers_dev), self.n_layers, self.max_layer_k, ptr(self.P), self.inv,
+                     ptr(self.G), st)
             tw0 = self.towers[0]
             tl0 = tw0["layout"]
             if has_emb and len(self.towers) > 1:

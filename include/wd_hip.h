@@ -157,6 +157,21 @@ int wd_wide_bwd_ftrl(float *wide, const wd_slot_t *slots, int32_t S, const uint3
 int wd_bias_ftrl(float *bias_wzn, const float *dlogit, int64_t batch, float lr, float l1, float l2,
                  wd_stream_t stream);
 
+/* Fused sparse backward (the path the engine uses; same arithmetic as steps 1-3 above in FOUR short launches, no
+ * device-wide sort): occurrences are bucketed by row range (bucket = (row_base + id) >> shift), each bucket is
+ * sorted on (row, bag) by one workgroup in LDS, duplicates are summed in ascending bag order and Adagrad
+ * (embedding rows, lr_emb) / FTRL (wide rows and bias_wzn, lr_wide, l1, l2) are applied in the same kernel.
+ * emb / wide / bias_wzn may be NULL (deep-only / wide-only).  Workspaces (caller-owned, no initialisation needed):
+ * bucket_cnt[(2 * wd_bucket_chunks() + 1) * nbuckets], bucket_start[nbuckets + 1], rank[nnz], pairs[nnz] (uint64).
+ * nbuckets = ceil(total_rows / 2^shift) <= wd_bucket_max(). */
+int32_t wd_bucket_max(void);
+int32_t wd_bucket_chunks(void);
+int wd_sparse_bwd_fused(float *emb, float *emb_accum, float *wide, float *bias_wzn, const wd_slot_t *slots, int32_t S,
+                        const int32_t *ids, const int32_t *bag_offs, int64_t batch, int64_t nnz, const float *dx,
+                        int64_t ldx, const float *dlogit, float lr_emb, float lr_wide, float l1, float l2,
+                        int32_t *bucket_cnt, int32_t *bucket_start, int32_t *rank, uint64_t *pairs, int32_t nbuckets,
+                        int32_t shift, wd_stream_t stream);
+
 /* ---- a9: dense tower (python/lib/dnn.py:92-234) ---------------------------------------------
  * fp32 MFMA GEMMs, row-major.  C[M,N] = epi(A op B):
  *   NN: C = A[M,K] B[K,N]        (forward; epilogue: + bias[N], activation)

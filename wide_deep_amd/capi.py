@@ -79,6 +79,9 @@ _PROTOS = {
     "wd_embag_bwd_adagrad": [P, P, P, I32, I32, P, P, I64, P, P, I64, F32, P],
     "wd_wide_bwd_ftrl": [P, P, I32, P, P, I64, P, F32, F32, F32, P],
     "wd_bias_ftrl": [P, P, I64, F32, F32, F32, P],
+    "wd_bucket_max": [],
+    "wd_bucket_chunks": [],
+    "wd_sparse_bwd_fused": [P, P, P, P, P, I32, P, P, I64, I64, P, I64, P, F32, F32, F32, F32, P, P, P, P, I32, I32, P],
     "wd_gemm_nn_bias_act": [P, I64, P, I64, P, I32, I32, P, I64, I64, I64, I64, P],
     "wd_gemm_nt": [P, I64, P, I64, P, I64, I64, I64, I64, I32, P],
     "wd_gemm_nt_actbwd": [P, I64, P, I64, P, I64, I64, I64, I64, P, I64, I32, P],
@@ -93,7 +96,7 @@ _PROTOS = {
     "wd_adagrad_dense": [P, P, P, I64, F32, P],
     "wd_fill_f32": [P, F32, I64, P],
 }
-_RESTYPES = {"wd_sort_workspace_bytes": SZ, "wd_logits_head_blocks": I64}
+_RESTYPES = {"wd_sort_workspace_bytes": SZ, "wd_logits_head_blocks": I64, "wd_bucket_max": I32, "wd_bucket_chunks": I32}
 
 EXPORTED_SYMBOLS = sorted(list(_PROTOS) + ["wd_last_error"])
 

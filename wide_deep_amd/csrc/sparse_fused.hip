@@ -1,0 +1,439 @@
+// wide_deep_amd/csrc/sparse_fused.hip -- sparse backward of the train step in FOUR short launches.
+//
+// Same contract as sparse_update.hip (python/lib/joint.py:224-262 with tf.train.AdagradOptimizer on the
+// embedding rows and tf.train.FtrlOptimizer on the wide rows; duplicate rows of the IndexedSlices gradient
+// are summed BEFORE the optimizer formula is applied once per unique row), but without a
+// device-wide sort: a device radix/merge sort of the ~2e5 occurrences of a batch costs 15-17 dependent
+// launches (~100-150 us on MI355X) for 1.7 MB of data.  Instead:
+//
+//   K1 k_bucket_hist     occurrence -> bucket = (row_base + id) >> shift; each workgroup histograms its chunk of bags
+//                        in LDS (rank = LDS atomicAdd: device-scope returned atomics on ~1.6k counters measured
+//                        35 us for 2e5 occurrences) and writes its row of the [chunks x buckets] count matrix
+//   K1b k_bucket_colscan per bucket: exclusive prefix over the chunks (column scan) + bucket totals
+//   K2 k_bucket_scatter  every block scans the totals in LDS (nb <= 8192) and scatters (key << 32 | bag) pairs to
+//                        start[bucket] + chunk_prefix + rank: all occurrences of a row range are now contiguous
+//   K3 k_bucket_update   one workgroup per bucket: sort of the 64-bit pairs in LDS (rank sort up to 512 pairs,
+//                        bitonic up to 1024 pairs; larger buckets sort in place in HBM/L2), then per
+//                        unique row the gradient is reduced in ascending bag order and the Adagrad / FTRL
+//                        update is applied in the same kernel; the extra last workgroup does bias_weights.
+//
+// The arrival order inside a bucket (atomics) is arbitrary, but the full sort on (row, bag) makes the
+// summation order -- and therefore every updated bit -- independent of it: the step stays deterministic.
+// Rows hit more than 32 times (Zipf heads, "missing value" tokens) are reduced cooperatively by the whole
+// workgroup (64 lane groups in parallel + a fixed-shape LDS tree) instead of serially by one lane group.
+#include "common.h"
+
+namespace {
+
+constexpr int CAP_LDS = 1024;   // pairs sorted in LDS per workgroup (8 KB: keeps 8 workgroups resident per CU)
+constexpr int LONG_SEG = 32;    // segments longer than this are reduced by the whole workgroup
+constexpr int MAX_LONG = 128;   // long-segment list per bucket
+constexpr int MAX_NB = 8192;    // buckets (LDS scan array of K2)
+
+constexpr int RANK_MAX = 512;   // buckets up to this size are rank-sorted (O(m^2 / 256) per lane, 2 barriers)
+constexpr int MAX_CHUNKS = 128; // workgroups of K1 / K2 (rows of the count matrix)
+
+// chunk c = bags [c*bags_per_chunk, (c+1)*bags_per_chunk)
+__global__ void __launch_bounds__(256)
+k_bucket_hist(const wd_slot_t *__restrict__ slots, int32_t S, const int32_t *__restrict__ ids,
+              const int32_t *__restrict__ bag_offs, int64_t nbags, int64_t bags_per_chunk, int32_t shift, int32_t nb,
+              int32_t *__restrict__ cntm, int32_t *__restrict__ rank) {
+  __shared__ int32_t hist[MAX_NB];
+  for (int i = threadIdx.x; i < nb; i += 256) hist[i] = 0;
+  __syncthreads();
+  const int64_t b0 = (int64_t)blockIdx.x * bags_per_chunk;
+  const int64_t b1 = b0 + bags_per_chunk < nbags ? b0 + bags_per_chunk : nbags;
+  for (int64_t bag = b0 + threadIdx.x; bag < b1; bag += 256) {
+    const int64_t base = slots[bag % S].row_base;
+    const int32_t j0 = bag_offs[bag], j1 = bag_offs[bag + 1];
+    for (int32_t j = j0; j < j1; ++j) {
+      const uint32_t key = (uint32_t)(base + ids[j]);
+      rank[j] = atomicAdd(&hist[key >> shift], 1);
+    }
+  }
+  __syncthreads();
+  int32_t *row = cntm + (int64_t)blockIdx.x * nb;
+  for (int i = threadIdx.x; i < nb; i += 256) row[i] = hist[i];
+}
+
+// thread per bucket: cpre[c][b] = sum_{c' < c} cntm[c'][b];  total[b] = column sum.  Out of place and 8 loads
+// deep: the in-place version was one dependent L2 round trip per chunk (30 us for 104 chunks).
+__global__ void __launch_bounds__(256)
+k_bucket_colscan(const int32_t *__restrict__ cntm, int32_t *__restrict__ cpre, int32_t nchunks, int32_t nb,
+                 int32_t *__restrict__ total) {
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  if (b >= nb) return;
+  int32_t run = 0;
+  for (int c0 = 0; c0 < nchunks; c0 += 8) {
+    int32_t v[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = c0 + q < nchunks ? cntm[(int64_t)(c0 + q) * nb + b] : 0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      if (c0 + q < nchunks) cpre[(int64_t)(c0 + q) * nb + b] = run;
+      run += v[q];
+    }
+  }
+  total[b] = run;
+}
+
+__global__ void __launch_bounds__(256)
+k_bucket_scatter(const wd_slot_t *__restrict__ slots, int32_t S, const int32_t *__restrict__ ids,
+                 const int32_t *__restrict__ bag_offs, int64_t nbags, int64_t bags_per_chunk, int32_t shift,
+                 int32_t nb, const int32_t *__restrict__ total, const int32_t *__restrict__ cntm,
+                 const int32_t *__restrict__ rank, int32_t *__restrict__ start, uint64_t *__restrict__ pairs) {
+  __shared__ int32_t sstart[MAX_NB];
+  __shared__ int32_t wsum[4];
+  // exclusive scan of total[0..nb): thread t owns E consecutive counters
+  const int t = threadIdx.x;
+  const int E = (nb + 255) / 256;
+  int32_t local = 0;
+  for (int e = 0; e < E; ++e) {
+    const int i = t * E + e;
+    const int32_t c = i < nb ? total[i] : 0;
+    if (i < nb) sstart[i] = local;  // exclusive within the thread's run
+    local += c;
+  }
+  int32_t incl = local;
+  for (int off = 1; off < 64; off <<= 1) {
+    const int32_t v = __shfl_up(incl, off, 64);
+    if ((t & 63) >= off) incl += v;
+  }
+  if ((t & 63) == 63) wsum[t >> 6] = incl;
+  __syncthreads();
+  int32_t wbase = 0;
+  for (int w = 0; w < (t >> 6); ++w) wbase += wsum[w];
+  const int32_t excl = wbase + incl - local;
+  const int32_t *row = cntm + (int64_t)blockIdx.x * nb;
+  for (int e = 0; e < E; ++e) {
+    const int i = t * E + e;
+    if (i < nb) {
+      const int32_t st = sstart[i] + excl;
+      if (blockIdx.x == 0) start[i] = st;
+      sstart[i] = st + row[i];  // + what earlier chunks put into this bucket
+    }
+  }
+  if (blockIdx.x == 0 && t == 255) start[nb] = excl + local;
+  __syncthreads();
+  const int64_t b0 = (int64_t)blockIdx.x * bags_per_chunk;
+  const int64_t b1 = b0 + bags_per_chunk < nbags ? b0 + bags_per_chunk : nbags;
+  for (int64_t bag = b0 + t; bag < b1; bag += 256) {
+    const int64_t base = slots[bag % S].row_base;
+    const int32_t j0 = bag_offs[bag], j1 = bag_offs[bag + 1];
+    for (int32_t j = j0; j < j1; ++j) {
+      const uint32_t key = (uint32_t)(base + ids[j]);
+      pairs[sstart[key >> shift] + rank[j]] = ((uint64_t)key << 32) | (uint32_t)bag;
+    }
+  }
+}
+
+__device__ __forceinline__ void ftrl_update(float &w, float &z, float &n, float g, float lr, float l1, float l2) {
+  const float n_new = n + g * g;
+  z += g - (sqrtf(n_new) - sqrtf(n)) / lr * w;
+  const float quad = sqrtf(n_new) / lr + 2.0f * l2;
+  const float sgn = z > 0.f ? 1.f : (z < 0.f ? -1.f : 0.f);
+  const float pre = (sgn * l1 - z) / quad;
+  w = fabsf(z) > l1 ? pre : 0.f;
+  n = n_new;
+}
+
+__device__ __forceinline__ float4 adagrad4(float4 &a, float4 w, float4 g, float lr) {
+  a.x += g.x * g.x; a.y += g.y * g.y; a.z += g.z * g.z; a.w += g.w * g.w;
+  w.x -= lr * g.x / sqrtf(a.x);
+  w.y -= lr * g.y / sqrtf(a.y);
+  w.z -= lr * g.z / sqrtf(a.z);
+  w.w -= lr * g.w / sqrtf(a.w);
+  return w;
+}
+
+struct UpdArgs {
+  float *emb, *accum, *wide, *bias;
+  const wd_slot_t *slots;
+  const int32_t *bag_offs;
+  const float *dx;
+  const float *dlogit;
+  int64_t ldx, batch;
+  int32_t S, nb;
+  float lr_emb, lr_w, l1, l2;
+};
+
+// all comparators ascending (mirror first step), so virtual +inf padding beyond m never moves.
+// k and j are powers of two: indices by shifts/masks.
+template <typename PtrT>
+__device__ __forceinline__ void bitonic_sort(PtrT p, int m) {
+  int lgP = 0;
+  while ((1 << lgP) < m) ++lgP;
+  const int half = (1 << lgP) >> 1;
+  for (int lk = 1; lk <= lgP; ++lk) {
+    const int k = 1 << lk, kh = k >> 1;
+    for (int tq = threadIdx.x; tq < half; tq += 256) {
+      const int blk = tq >> (lk - 1), off = tq & (kh - 1);
+      const int i1 = (blk << lk) + off, i2 = (blk << lk) + k - 1 - off;
+      if (i2 < m) {
+        const uint64_t a = p[i1], b = p[i2];
+        if (a > b) { p[i1] = b; p[i2] = a; }
+      }
+    }
+    __syncthreads();
+    for (int lj = lk - 2; lj >= 0; --lj) {
+      const int j = 1 << lj;
+      for (int tq = threadIdx.x; tq < half; tq += 256) {
+        const int i1 = ((tq >> lj) << (lj + 1)) | (tq & (j - 1)), i2 = i1 + j;
+        if (i2 < m) {
+          const uint64_t a = p[i1], b = p[i2];
+          if (a > b) { p[i1] = b; p[i2] = a; }
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256)
+k_bucket_update(UpdArgs u, const int32_t *__restrict__ start, uint64_t *__restrict__ pairs) {
+  __shared__ uint64_t lds_pairs[CAP_LDS];
+  __shared__ float4 red[256];                               // long-segment tree; doubles as the rank-sort input
+  uint64_t *lds_in = reinterpret_cast<uint64_t *>(red);     // RANK_MAX * 8 B == 256 * 16 B
+  __shared__ float redw[256];
+  __shared__ int long_i0[MAX_LONG], long_i1[MAX_LONG];
+  __shared__ int nlong;
+  const int t = threadIdx.x;
+
+  if ((int)blockIdx.x == u.nb) {  // bias_weights: g = sum_b dlogit[b] (fixed-shape tree), dense FTRL
+    if (!u.bias) return;
+    float acc = 0.f;
+    for (int64_t i = t; i < u.batch; i += 256) acc += u.dlogit[i];
+    redw[t] = acc;
+    __syncthreads();
+    for (int st = 128; st >= 1; st >>= 1) {
+      if (t < st) redw[t] += redw[t + st];
+      __syncthreads();
+    }
+    if (t == 0) {
+      float w = u.bias[0], z = u.bias[1], n = u.bias[2];
+      ftrl_update(w, z, n, redw[0], u.lr_w, u.l1, u.l2);
+      u.bias[0] = w; u.bias[1] = z; u.bias[2] = n;
+    }
+    return;
+  }
+
+  const int32_t s0 = start[blockIdx.x];
+  const int m = start[blockIdx.x + 1] - s0;
+  if (t == 0) nlong = 0;
+  if (m == 0) return;
+  const uint64_t *sp;  // sorted pairs (flat pointer: LDS or global)
+  if (m <= RANK_MAX) {
+    // rank sort: position of element i = number of elements ordered before it (ties by index); every lane reads
+    // the same LDS word per step (broadcast, conflict-free), no barriers inside
+    for (int i = t; i < m; i += 256) lds_in[i] = pairs[s0 + i];
+    __syncthreads();
+    for (int i = t; i < m; i += 256) {
+      const uint64_t x = lds_in[i];
+      int r = 0;
+      for (int j = 0; j < m; ++j) {
+        const uint64_t y = lds_in[j];
+        r += (y < x || (y == x && j < i)) ? 1 : 0;
+      }
+      lds_pairs[r] = x;
+    }
+    __syncthreads();
+    sp = lds_pairs;
+  } else if (m <= CAP_LDS) {
+    for (int i = t; i < m; i += 256) lds_pairs[i] = pairs[s0 + i];
+    __syncthreads();
+    bitonic_sort<uint64_t *>(lds_pairs, m);
+    sp = lds_pairs;
+  } else {
+    __syncthreads();
+    bitonic_sort<uint64_t *>(pairs + s0, m);
+    sp = pairs + s0;
+  }
+
+  const int S = u.S;
+  const int gidx = t >> 2, gl = t & 3;
+  // ---- short segments: one 4-lane group per unique row ------------------------------------------------
+  for (int i = gidx; i < m; i += 64) {
+    const uint32_t key = (uint32_t)(sp[i] >> 32);
+    if (i > 0 && (uint32_t)(sp[i - 1] >> 32) == key) continue;  // not a segment head
+    int e = i + 1;
+    while (e < m && e - i <= LONG_SEG && (uint32_t)(sp[e] >> 32) == key) ++e;
+    bool is_long = (e - i > LONG_SEG);
+    if (is_long) {
+      int slot_l = -1;
+      if (gl == 0) slot_l = atomicAdd(&nlong, 1);
+      slot_l = __shfl(slot_l, (t & 63) & ~3, 64);
+      if (slot_l < MAX_LONG) {
+        if (gl == 0) {
+          // upper bound of key in sp[e..m)
+          int lo = e, hi = m;
+          while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if ((uint32_t)(sp[mid] >> 32) == key) lo = mid + 1; else hi = mid;
+          }
+          long_i0[slot_l] = i;
+          long_i1[slot_l] = lo;
+        }
+        continue;
+      }
+      // list full: fall through and reduce serially (correct, just slower)
+      while (e < m && (uint32_t)(sp[e] >> 32) == key) ++e;
+    }
+    const int32_t bag0 = (int32_t)(uint32_t)sp[i];
+    const wd_slot_t sl = u.slots[bag0 % S];
+    const bool do_emb = u.emb && sl.kind == WD_SLOT_EMBEDDING;
+    const bool do_wide = u.wide && sl.wide;
+    const int D = sl.dim;
+    if (do_emb && (D & 3) == 0) {
+      const int64_t off = sl.emb_off + ((int64_t)key - sl.row_base) * D;
+      for (int c = gl; c < (D >> 2); c += 4) {
+        float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int j = i; j < e; ++j) {
+          const int32_t bag = (int32_t)(uint32_t)sp[j];
+          const int32_t len = u.bag_offs[bag + 1] - u.bag_offs[bag];
+          const float scale = len > 1 ? 1.0f / (float)len : 1.0f;
+          const float4 d = *reinterpret_cast<const float4 *>(u.dx + (int64_t)(bag / S) * u.ldx + sl.out_col + 4 * c);
+          g.x += d.x * scale; g.y += d.y * scale; g.z += d.z * scale; g.w += d.w * scale;
+        }
+        float4 a = *reinterpret_cast<float4 *>(u.accum + off + 4 * c);
+        const float4 w = *reinterpret_cast<float4 *>(u.emb + off + 4 * c);
+        const float4 wn = adagrad4(a, w, g, u.lr_emb);
+        *reinterpret_cast<float4 *>(u.accum + off + 4 * c) = a;
+        *reinterpret_cast<float4 *>(u.emb + off + 4 * c) = wn;
+      }
+    } else if (do_emb) {  // dims that are not a multiple of 4 (opt-in override only)
+      const int64_t off = sl.emb_off + ((int64_t)key - sl.row_base) * D;
+      for (int d0 = gl; d0 < D; d0 += 4) {
+        float g = 0.f;
+        for (int j = i; j < e; ++j) {
+          const int32_t bag = (int32_t)(uint32_t)sp[j];
+          const int32_t len = u.bag_offs[bag + 1] - u.bag_offs[bag];
+          const float scale = len > 1 ? 1.0f / (float)len : 1.0f;
+          g += u.dx[(int64_t)(bag / S) * u.ldx + sl.out_col + d0] * scale;
+        }
+        const float a = u.accum[off + d0] + g * g;
+        u.accum[off + d0] = a;
+        u.emb[off + d0] -= u.lr_emb * g / sqrtf(a);
+      }
+    }
+    if (do_wide && gl == 0) {
+      float g = 0.f;
+      for (int j = i; j < e; ++j) g += u.dlogit[(int32_t)(uint32_t)sp[j] / S];
+      float4 r = *reinterpret_cast<float4 *>(u.wide + (int64_t)key * 4);  // {w, z, n, -}
+      ftrl_update(r.x, r.y, r.z, g, u.lr_w, u.l1, u.l2);
+      *reinterpret_cast<float4 *>(u.wide + (int64_t)key * 4) = r;
+    }
+  }
+  __syncthreads();
+  // ---- long segments: the whole workgroup per row, 64 lane groups in parallel + fixed-shape tree -------
+  const int nl = nlong < MAX_LONG ? nlong : MAX_LONG;
+  for (int q = 0; q < nl; ++q) {
+    const int i = long_i0[q], e = long_i1[q];
+    const uint32_t key = (uint32_t)(sp[i] >> 32);
+    const wd_slot_t sl = u.slots[(int32_t)(uint32_t)sp[i] % S];
+    const bool do_emb = u.emb && sl.kind == WD_SLOT_EMBEDDING;
+    const bool do_wide = u.wide && sl.wide;
+    const int D = sl.dim;
+    if (do_emb) {
+      const int64_t off = sl.emb_off + ((int64_t)key - sl.row_base) * D;
+      const int nchunk = (D + 3) >> 2;
+      for (int c0 = 0; c0 < nchunk; c0 += 4) {
+        const int c = c0 + gl;
+        float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c < nchunk) {
+          for (int j = i + gidx; j < e; j += 64) {
+            const int32_t bag = (int32_t)(uint32_t)sp[j];
+            const int32_t len = u.bag_offs[bag + 1] - u.bag_offs[bag];
+            const float scale = len > 1 ? 1.0f / (float)len : 1.0f;
+            const float *dp = u.dx + (int64_t)(bag / S) * u.ldx + sl.out_col + 4 * c;
+            float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
+            if ((D & 3) == 0) {
+              d = *reinterpret_cast<const float4 *>(dp);
+            } else {
+              d.x = dp[0];
+              if (4 * c + 1 < D) d.y = dp[1];
+              if (4 * c + 2 < D) d.z = dp[2];
+              if (4 * c + 3 < D) d.w = dp[3];
+            }
+            g.x += d.x * scale; g.y += d.y * scale; g.z += d.z * scale; g.w += d.w * scale;
+          }
+        }
+        red[t] = g;
+        __syncthreads();
+        for (int st = 32; st >= 1; st >>= 1) {
+          if (gidx < st) {
+            float4 a = red[t], b = red[t + 4 * st];
+            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+            red[t] = a;
+          }
+          __syncthreads();
+        }
+        if (gidx == 0 && c < nchunk) {
+          g = red[t];
+          float gg[4] = {g.x, g.y, g.z, g.w};
+          for (int k2 = 0; k2 < 4 && 4 * c + k2 < D; ++k2) {
+            const int64_t o = off + 4 * c + k2;
+            const float a = u.accum[o] + gg[k2] * gg[k2];
+            u.accum[o] = a;
+            u.emb[o] -= u.lr_emb * gg[k2] / sqrtf(a);
+          }
+        }
+        __syncthreads();
+      }
+    }
+    if (do_wide) {
+      float g = 0.f;
+      for (int j = i + t; j < e; j += 256) g += u.dlogit[(int32_t)(uint32_t)sp[j] / S];
+      redw[t] = g;
+      __syncthreads();
+      for (int st = 128; st >= 1; st >>= 1) {
+        if (t < st) redw[t] += redw[t + st];
+        __syncthreads();
+      }
+      if (t == 0) {
+        float4 r = *reinterpret_cast<float4 *>(u.wide + (int64_t)key * 4);
+        ftrl_update(r.x, r.y, r.z, redw[0], u.lr_w, u.l1, u.l2);
+        *reinterpret_cast<float4 *>(u.wide + (int64_t)key * 4) = r;
+      }
+      __syncthreads();
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int32_t wd_bucket_max(void) { return MAX_NB; }
+extern "C" int32_t wd_bucket_chunks(void) { return MAX_CHUNKS; }
+
+extern "C" int wd_sparse_bwd_fused(float *emb, float *emb_accum, float *wide, float *bias_wzn, const wd_slot_t *slots,
+                                   int32_t S, const int32_t *ids, const int32_t *bag_offs, int64_t batch, int64_t nnz,
+                                   const float *dx, int64_t ldx, const float *dlogit, float lr_emb, float lr_wide,
+                                   float l1, float l2, int32_t *bucket_cnt, int32_t *bucket_start, int32_t *rank,
+                                   uint64_t *pairs, int32_t nbuckets, int32_t shift, wd_stream_t stream) {
+  if (batch <= 0) return WD_OK;
+  WD_REQUIRE(slots && ids && bag_offs && bucket_cnt && bucket_start && rank && pairs, "null pointer");
+  WD_REQUIRE(S > 0 && nbuckets > 0 && nbuckets <= MAX_NB && shift >= 0 && shift < 32, "bad bucket geometry");
+  WD_REQUIRE(!emb || (emb_accum && dx), "embedding update needs accum and dx");
+  WD_REQUIRE(!(wide || bias_wzn) || dlogit, "wide / bias update needs dlogit");
+  hipStream_t st = wd::as_stream(stream);
+  const int64_t nbags = batch * S;
+  // bucket_cnt layout: [MAX_CHUNKS][nbuckets] counts, [MAX_CHUNKS][nbuckets] chunk prefixes, total[nbuckets]
+  int64_t bags_per_chunk = wd::ceil_div(wd::ceil_div(nbags, MAX_CHUNKS), 256) * 256;
+  const int nchunks = nnz > 0 ? (int)wd::ceil_div(nbags, bags_per_chunk) : 0;
+  int32_t *cpre = bucket_cnt + (int64_t)MAX_CHUNKS * nbuckets;
+  int32_t *total = cpre + (int64_t)MAX_CHUNKS * nbuckets;
+  if (nchunks > 0) {
+    hipLaunchKernelGGL(k_bucket_hist, dim3(nchunks), dim3(256), 0, st, slots, S, ids, bag_offs, nbags, bags_per_chunk,
+                       shift, nbuckets, bucket_cnt, rank);
+  }
+  hipLaunchKernelGGL(k_bucket_colscan, dim3((unsigned)wd::ceil_div(nbuckets, 256)), dim3(256), 0, st, bucket_cnt,
+                     cpre, nchunks, nbuckets, total);
+  hipLaunchKernelGGL(k_bucket_scatter, dim3(nchunks > 0 ? nchunks : 1), dim3(256), 0, st, slots, S, ids, bag_offs,
+                     nchunks > 0 ? nbags : (int64_t)0, bags_per_chunk, shift, nbuckets, total, cpre, rank,
+                     bucket_start, pairs);
+  UpdArgs u;
+  u.emb = emb; u.accum = emb_accum; u.wide = wide; u.bias = bias_wzn; u.slots = slots; u.bag_offs = bag_offs;
+  u.dx = dx; u.dlogit = dlogit; u.ldx = ldx; u.batch = batch; u.S = S; u.nb = nbuckets;
+  u.lr_emb = lr_emb; u.lr_w = lr_wide; u.l1 = l1; u.l2 = l2;
+  hipLaunchKernelGGL(k_bucket_update, dim3((unsigned)nbuckets + 1), dim3(256), 0, st, u, bucket_start, pairs);
+  return wd::check_launch("wd_sparse_bwd_fused");
+}

@@ -38,7 +38,7 @@ def _stream():
 
 
 class WideDeepEngine:
-    def __init__(self, spec: ModelSpec, max_batch=8192, max_nnz=None, device="cuda", seed=0):
+    def __init__(self, spec: ModelSpec, max_batch=8192, max_nnz=None, device="cuda", seed=0, expected_nnz=None):
         if not torch.cuda.is_available():
             raise capi.WdError("WideDeepEngine needs a GPU (MI355X / gfx950); there is no CPU fallback")
         capi.load()
@@ -199,6 +199,18 @@ class WideDeepEngine:
             raise capi.WdError("wd_sort_workspace_bytes failed")
         self.sort_ws_bytes = max(qs)
         self.sort_ws = torch.zeros(self.sort_ws_bytes, dtype=torch.uint8, device=dev)
+        # bucket geometry of the fused sparse backward (wd_sparse_bwd_fused): ~64 occurrences per bucket
+        exp_nnz = int(expected_nnz) if expected_nnz else self.max_batch * max(plan.S, 1)
+        nb_max = int(call("wd_bucket_max"))
+        target = min(max(64, 1 << max(0, math.ceil(math.log2(max(exp_nnz, 1) / 64.0)))), nb_max)
+        rows = max(plan.total_rows, 1)
+        self.bucket_shift = max(0, math.ceil(math.log2(rows / target))) if rows > target else 0
+        self.n_buckets = (rows + (1 << self.bucket_shift) - 1) >> self.bucket_shift
+        assert self.n_buckets <= nb_max, (self.n_buckets, nb_max)
+        self.bucket_cnt = torch.zeros((2 * int(call("wd_bucket_chunks")) + 1) * self.n_buckets, **i32)
+        self.bucket_start = torch.zeros(self.n_buckets + 2, **i32)
+        self.occ_rank = torch.zeros(M, **i32)
+        self.pairs = torch.zeros(M, dtype=torch.int64, device=dev)
         self._graph = None
 
     # ------------------------------------------------------------------------------------------
@@ -384,7 +396,27 @@ class WideDeepEngine:
         """Hook for data-parallel ranks (dist.py: all_reduce(SUM) of the flat gradient buffer)."""
 
     def _sparse_backward(self, bt: DeviceBatch, st):
-        """Scatter-add of the row gradients + fused Adagrad (embedding rows) / FTRL (wide rows, bias)."""
+        """Scatter-add of the row gradients + fused Adagrad (embedding rows) / FTRL (wide rows, bias): three launches."""
+        plan, spec = self.plan, self.spec
+        has_emb = bool(self.group_slots) if spec.has_deep else False
+        if not (has_emb or spec.has_wide):
+            return
+        self._check_batch(bt)
+        dx_ptr, ld = None, 0
+        if has_emb:
+            tw0 = self.towers[0]
+            tl0 = tw0["layout"]
+            dx_ptr, ld = tw0["dact"].data_ptr() + 4 * tl0.seg_start[0], tl0.ld
+        lr, l1, l2 = (spec.lin_opt[1], spec.lin_opt[2], spec.lin_opt[3]) if spec.has_wide else (0.0, 0.0, 0.0)
+        call("wd_sparse_bwd_fused", ptr(self.emb) if has_emb else None, ptr(self.emb_acc) if has_emb else None,
+             ptr(self.wide), ptr(self.bias), ptr(self.slots_dev), plan.S, ptr(bt.ids), ptr(bt.bag_offs), bt.B, bt.nnz,
+             dx_ptr, ld, ptr(self.dlogit), float(spec.dnn_opt[1]) if spec.has_deep else 0.0, float(lr), float(l1),
+             float(l2), ptr(self.bucket_cnt), ptr(self.bucket_start), ptr(self.occ_rank), ptr(self.pairs), self.n_buckets,
+             self.bucket_shift, st)
+
+    def _sparse_backward_unfused(self, bt: DeviceBatch, st):
+        """Reference path through the separate ABI entry points (device radix sort + one kernel per update);
+        kept for cross-checking the fused kernel in tests."""
         plan, spec = self.plan, self.spec
         B, S = bt.B, plan.S
         has_emb = bool(self.group_slots) if spec.has_deep else False

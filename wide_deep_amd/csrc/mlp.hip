@@ -113,19 +113,23 @@ __device__ __forceinline__ float4 mask4(float4 v, int64_t row, int64_t col, int6
 // 64x64 output tile, BK-deep reduction slab, LDS double-buffered: the global loads of slab i+1 are issued
 // before the BK/2 MFMAs of slab i and land in the other LDS buffer afterwards -> ONE barrier per slab and
 // NV = BK/16 independent 16-byte loads per operand per lane in flight (the BK=16 single-stage version paid
-// one full HBM/L2 latency per 8 MFMAs).  MFMA fragments are read from LDS one group of FG steps ahead.
+// one full HBM/L2 latency per 8 MFMAs).
 template <bool A_RC, bool B_RC, int EPI, int BK, bool VEC>
 __global__ void __launch_bounds__(256) k_gemm(GemmArgs g) {
   constexpr int LDA = A_RC ? LD_RC : LD_OC;
   constexpr int LDB = B_RC ? LD_RC : LD_OC;
   constexpr int NV = BK / 16;  // float4 per lane per operand per slab
-  constexpr int FG = 8;        // MFMA steps per fragment group
-  constexpr int NG = BK / 2 / FG;
   __shared__ __attribute__((aligned(16))) float As[2][BK * LDA];
   __shared__ __attribute__((aligned(16))) float Bs[2][BK * LDB];
   const int t = threadIdx.x;
   const int lane = t & 63, wave = t >> 6;
   const int wm = wave >> 1, wn = wave & 1;
+
+  // Two workgroups share a CU, i.e. two waves share each SIMD's MFMA pipe.  With equal priority they fall into
+  // lock-step (both in their MFMA phase at half rate, then both in their load/LDS-store phase with the pipe idle:
+  // measured 46 % MFMA busy).  Give the wave in the odd hardware slot priority: it runs its MFMA phase at full
+  // rate while the other one stores / waits, and vice versa.
+  if (__builtin_amdgcn_s_getreg((4) | (0 << 6) | (3 << 11)) & 1u) __builtin_amdgcn_s_setprio(2);  // HW_ID.WAVE_ID
 
   // XCD-aware tile mapping: hardware places block i on XCD i % 8; give each XCD a contiguous run of
   // tiles (n fastest) so the N-tiles sharing an A panel hit the same L2.  Bijective for any grid.
@@ -199,49 +203,111 @@ __global__ void __launch_bounds__(256) k_gemm(GemmArgs g) {
     }
   };
 
+  // Fast path (interior tile, full slab, 16-byte loads): no clamps, no masks, addresses = uniform slab pointer +
+  // per-lane 32-bit offsets computed once.  Both operand orientations share one offset formula because a
+  // 64 x BK (RC) and a BK x 64 (OC) slab are both 16 float4 wide at BK = 64.
+  static_assert(BK == 64, "fast-path offsets assume BK == 64");
+  const bool fast_tile = VEC && (m0 + BM <= (A_RC ? g.M : a_cols)) && (n0 + BN <= g.N);
+  int32_t offA[NV], offB[NV];
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    offA[v] = ((t >> 4) + 16 * v) * (int32_t)g.lda + (t & 15) * 4;
+    offB[v] = ((t >> 4) + 16 * v) * (int32_t)g.ldb + (t & 15) * 4;
+  }
+  const float *pa0 = A_RC ? g.A + m0 * g.lda : g.A + m0;  // tile origin, reduction index 0
+  const float *pb0 = B_RC ? g.B + n0 * g.ldb : g.B + n0;
+  const int64_t astep = A_RC ? 1 : g.lda, bstep = B_RC ? 1 : g.ldb;
+  const int lds_rc = (t & 15) * 4 * LD_RC + (t >> 4);  // + i * LD_RC + 16 v
+  const int lds_oc = (t >> 4) * LD_OC + (t & 15) * 4;  // + 16 v * LD_OC
+  auto load_fast = [&](int64_t k0, float4 (&ra)[NV], float4 (&rb)[NV]) {
+    const float *pa = pa0 + k0 * astep, *pb = pb0 + k0 * bstep;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) ra[v] = *reinterpret_cast<const float4 *>(pa + offA[v]);
+#pragma unroll
+    for (int v = 0; v < NV; ++v) rb[v] = *reinterpret_cast<const float4 *>(pb + offB[v]);
+  };
+  auto store_fast = [&](float *Sa, float *Sb, const float4 (&ra)[NV], const float4 (&rb)[NV]) {
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      if (A_RC) {
+        float *q = Sa + lds_rc + 16 * v;
+        q[0] = ra[v].x; q[LD_RC] = ra[v].y; q[2 * LD_RC] = ra[v].z; q[3 * LD_RC] = ra[v].w;
+      } else {
+        *reinterpret_cast<float4 *>(Sa + lds_oc + 16 * v * LD_OC) = ra[v];
+      }
+      if (B_RC) {
+        float *q = Sb + lds_rc + 16 * v;
+        q[0] = rb[v].x; q[LD_RC] = rb[v].y; q[2 * LD_RC] = rb[v].z; q[3 * LD_RC] = rb[v].w;
+      } else {
+        *reinterpret_cast<float4 *>(Sb + lds_oc + 16 * v * LD_OC) = rb[v];
+      }
+    }
+  };
+
   floatx16 acc;
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 
   float4 ra[NV], rb[NV];
-  load_a(kbeg, ra);
-  load_b(kbeg, rb);
-  store_a(As[0], kbeg, ra);
-  store_b(Bs[0], kbeg, rb);
+  bool fast = fast_tile && (kbeg + BK <= kend);
+  if (fast) {
+    load_fast(kbeg, ra, rb);
+    store_fast(As[0], Bs[0], ra, rb);
+  } else {
+    load_a(kbeg, ra);
+    load_b(kbeg, rb);
+    store_a(As[0], kbeg, ra);
+    store_b(Bs[0], kbeg, rb);
+  }
   __syncthreads();
 
   const int fr = (lane >> 5), fc = (lane & 31);
   int cur = 0;
   for (int64_t k0 = kbeg; k0 < kend; k0 += BK) {
     const bool more = k0 + BK < kend;
+    fast = fast_tile && (k0 + 2 * BK <= kend);  // the slab being prefetched is full
     if (more) {
-      load_a(k0 + BK, ra);
-      load_b(k0 + BK, rb);
+      if (fast) {
+        load_fast(k0 + BK, ra, rb);
+      } else {
+        load_a(k0 + BK, ra);
+        load_b(k0 + BK, rb);
+      }
     }
     const float *Ac = As[cur] + fr * LDA + wm * 32 + fc;
     const float *Bc = Bs[cur] + fr * LDB + wn * 32 + fc;
+    // software-pipelined fragment reads: the LDS reads of group gi+1 are issued BEFORE the MFMAs of group gi
+    // (sched_barrier pins the order; left alone the scheduler sinks each read next to its MFMA and the
+    // dependent MFMA chain then waits one LDS latency per pair)
+    constexpr int FG = 8, NG = BK / 2 / FG;
     float fa[2][FG], fb[2][FG];
 #pragma unroll
     for (int j = 0; j < FG; ++j) {
-      fa[0][j] = Ac[(2 * j) * LDA];
-      fb[0][j] = Bc[(2 * j) * LDB];
+      fa[0][j] = Ac[2 * j * LDA];
+      fb[0][j] = Bc[2 * j * LDB];
     }
 #pragma unroll
     for (int gi = 0; gi < NG; ++gi) {
       if (gi + 1 < NG) {
 #pragma unroll
         for (int j = 0; j < FG; ++j) {
-          fa[(gi + 1) & 1][j] = Ac[(2 * ((gi + 1) * FG + j)) * LDA];
-          fb[(gi + 1) & 1][j] = Bc[(2 * ((gi + 1) * FG + j)) * LDB];
+          fa[(gi + 1) & 1][j] = Ac[2 * ((gi + 1) * FG + j) * LDA];
+          fb[(gi + 1) & 1][j] = Bc[2 * ((gi + 1) * FG + j) * LDB];
         }
       }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int j = 0; j < FG; ++j)
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[gi & 1][j], fb[gi & 1][j], acc, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
     if (more) {
-      store_a(As[cur ^ 1], k0 + BK, ra);
-      store_b(Bs[cur ^ 1], k0 + BK, rb);
+      if (fast) {
+        store_fast(As[cur ^ 1], Bs[cur ^ 1], ra, rb);
+      } else {
+        store_a(As[cur ^ 1], k0 + BK, ra);
+        store_b(Bs[cur ^ 1], k0 + BK, rb);
+      }
     }
     __syncthreads();
     cur ^= 1;

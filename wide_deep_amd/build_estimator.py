@@ -1,0 +1,150 @@
+"""conf -> model spec -> Estimator-shaped object (python/lib/build_estimator.py:49-169, 264-294).
+
+`build_model_spec()` is what `_build_model_columns()` does at graph-build time, producing a `plan.ModelSpec` for the
+gfx950 engine instead of tf.feature_column objects.  `build_custom_estimator(model_dir, model_type)` keeps the
+reference's signature and returns `estimator.WideAndDeepClassifier` (train / evaluate / predict).
+"""
+import ast
+
+from .plan import CatSlot, CrossKey, DenseCol, ModelSpec, TowerSpec, embedding_dim
+from .read_conf import Config
+
+_NORM_KIND = {None: 0, "min_max": 1, "standard": 2, "log": 3}
+
+# tf.train optimizer defaults that matter on this path
+_OPT_ALIASES = {
+    "Adagrad": "Adagrad", "AdagradOptimizer": "Adagrad", "Ftrl": "Ftrl", "FtrlOptimizer": "Ftrl",
+    "Adam": "Adam", "AdamOptimizer": "Adam", "RMSProp": "RMSProp", "RMSPropOptimizer": "RMSProp",
+    "SGD": "SGD", "GradientDescentOptimizer": "SGD",
+}
+
+
+def parse_optimizer(opt, default_lr):
+    """'Adagrad' | 'tf.train.FtrlOptimizer(learning_rate=0.1, l1_regularization_strength=0.5, ...)' -> (name, kwargs).
+    The reference eval()s constructor strings (python/lib/utils/model_util.py:97-101); here the expression is parsed
+    with `ast` and only literal keyword arguments are accepted."""
+    if not isinstance(opt, str):
+        raise ValueError("optimizer must be a string, got %r" % (opt,))
+    text = opt.strip()
+    if "(" not in text:
+        if text not in _OPT_ALIASES:
+            raise ValueError("Unsupported optimizer name: %s. Supported names are: %s" % (text, sorted(set(_OPT_ALIASES.values()))))
+        return _OPT_ALIASES[text], {"learning_rate": default_lr}
+    node = ast.parse(text, mode="eval").body
+    if not isinstance(node, ast.Call):
+        raise ValueError("cannot parse optimizer expression `%s`" % opt)
+    fn = node.func
+    cls = fn.attr if isinstance(fn, ast.Attribute) else getattr(fn, "id", None)
+    if cls not in _OPT_ALIASES:
+        raise ValueError("Unsupported optimizer: %s" % opt)
+    kwargs = {}
+    if node.args:
+        kwargs["learning_rate"] = ast.literal_eval(node.args[0])
+    for kw in node.keywords:
+        kwargs[kw.arg] = ast.literal_eval(kw.value)
+    kwargs.setdefault("learning_rate", default_lr)
+    return _OPT_ALIASES[cls], kwargs
+
+
+def _dnn_opt_tuple(name, kw):
+    if name != "Adagrad":
+        return (name, float(kw["learning_rate"]), 0.1)
+    return ("Adagrad", float(kw["learning_rate"]), float(kw.get("initial_accumulator_value", 0.1)))
+
+
+def _lin_opt_tuple(name, kw):
+    if name != "Ftrl":
+        return (name, float(kw["learning_rate"]), 0.0, 0.0, 0.1)
+    if float(kw.get("learning_rate_power", -0.5)) != -0.5 or float(kw.get("l2_shrinkage_regularization_strength", 0.0)) != 0.0:
+        raise NotImplementedError("FtrlOptimizer: only learning_rate_power=-0.5 and no l2 shrinkage are implemented")
+    return ("Ftrl", float(kw["learning_rate"]), float(kw.get("l1_regularization_strength", 0.0)),
+            float(kw.get("l2_regularization_strength", 0.0)), float(kw.get("initial_accumulator_value", 0.1)))
+
+
+def build_model_spec(conf=None, model_type=None):
+    """Feature / cross / model conf -> ModelSpec  (the wiring of python/lib/build_estimator.py:49-169)."""
+    conf = conf or Config()
+    feature_conf = conf.read_feature_conf()
+    cross_conf = conf.read_cross_feature_conf()
+    model = conf.model
+    train = conf.train
+    model_type = model_type or train["model_type"]
+    global_dim = model.get("embedding_dim")   # extension, see read_conf.py
+
+    slots, dense = [], []
+    for f, c in feature_conf.items():
+        kind, trans, param = c["type"], c["transform"], c["parameter"]
+        if kind == "category":
+            if trans == "hash_bucket":
+                dim = int(c.get("embedding_dim") or global_dim or embedding_dim(param))
+                slots.append(CatSlot(name=f, kind="hash", num_buckets=int(param), feature=f, deep="embedding", dim=dim))
+            elif trans == "vocab":
+                vocab = [str(v) for v in param]   # vocabulary_list=map(str, f_param)  (build_estimator.py:103)
+                slots.append(CatSlot(name=f, kind="vocab", num_buckets=len(vocab), feature=f, deep="indicator", vocab=vocab))
+            else:
+                slots.append(CatSlot(name=f, kind="identity", num_buckets=int(param), feature=f, deep="indicator"))
+        else:
+            norm, bounds = param["normalization"], param["boundaries"]
+            p0, p1 = (float(norm[0]), float(norm[1])) if (trans in ("min_max", "standard")) else (0.0, 1.0)
+            dense.append(DenseCol(name=f, feature=f, kind=_NORM_KIND[trans], p0=p0, p1=p1))
+            if bounds:
+                # wide bucketized column wraps the NORMALISED numeric column while the boundaries are raw (quirk C.5)
+                slots.append(CatSlot(name=f + "_bucketized", kind="bucket", num_buckets=len(bounds) + 1, feature=f,
+                                     deep=None, boundaries=[float(b) for b in bounds],
+                                     normalizer=(trans, p0, p1) if trans else None))
+    for parts, size, is_deep in cross_conf:
+        keys, names = [], []
+        for p in parts:
+            c = feature_conf[p]
+            if c["type"] == "continuous":
+                b = [float(v) for v in c["parameter"]["boundaries"]]
+                keys.append(CrossKey(p, "bucket", num_buckets=len(b) + 1, boundaries=b))   # un-normalised column (C.5)
+                names.append(p + "_bucketized")
+            elif c["transform"] == "identity":
+                keys.append(CrossKey(p, "identity", num_buckets=int(c["parameter"])))
+                names.append(p)
+            else:
+                keys.append(CrossKey(p, "string"))
+                names.append(p)
+        nb = int(size)
+        if nb < 1:
+            raise ValueError("hash_bucket_size must be > 1. hash_bucket_size: %s" % size)
+        slots.append(CatSlot(name="_X_".join(sorted(names)), kind="cross", num_buckets=nb, deep="embedding" if is_deep else None,
+                             dim=int(global_dim or embedding_dim(size)) if is_deep else 0, cross_keys=keys))
+
+    hidden, mode = model["dnn_hidden_units"], model["dnn_connected_mode"]
+    if hidden and isinstance(hidden[0], (list, tuple)):     # multi-DNN  (python/lib/dnn.py:237-275)
+        modes = mode if isinstance(mode, (list, tuple)) else [mode] * len(hidden)
+        towers = [TowerSpec([int(h) for h in hs], _mode_name(m)) for hs, m in zip(hidden, modes)]
+    else:
+        towers = [TowerSpec([int(h) for h in hidden], _mode_name(mode))]
+    dnn_name, dnn_kw = parse_optimizer(model["dnn_optimizer"], model.get("dnn_initial_learning_rate") or 0.05)
+    lin_name, lin_kw = parse_optimizer(model["linear_optimizer"], model.get("linear_initial_learning_rate") or 0.05)
+    # weight column is switched on when EITHER weight is set (build_estimator.py:43-46) ...
+    use_w = train["pos_sample_loss_weight"] is not None or train["neg_sample_loss_weight"] is not None
+    return ModelSpec(model_type=model_type, slots=slots, dense_cols=dense, towers=towers,
+                     activation=model.get("dnn_activation_function") or "relu",
+                     batch_norm=bool(model.get("dnn_batch_normalization")), dropout=model.get("dnn_dropout") or None,
+                     dnn_opt=_dnn_opt_tuple(dnn_name, dnn_kw), lin_opt=_lin_opt_tuple(lin_name, lin_kw),
+                     use_weight_column=use_w, pos_weight=float(train["pos_sample_loss_weight"] or 1.0),
+                     neg_weight=float(train["neg_sample_loss_weight"] or 1.0))
+
+
+def _mode_name(m):
+    # connected modes: names as in python/lib/dnn.py:74-81; a 0/1 connection matrix ("arbitrary") is not supported
+    if not isinstance(m, str):
+        raise NotImplementedError("arbitrary dnn connection matrices (python/lib/dnn.py:195-224) are not implemented")
+    return {"normal": "simple"}.get(m, m)
+
+
+def build_custom_estimator(model_dir, model_type, conf=None, **engine_kw):
+    """Reference signature (python/lib/build_estimator.py:264-294)."""
+    from .estimator import WideAndDeepClassifier
+    conf = conf or Config()
+    spec = build_model_spec(conf, model_type)
+    return WideAndDeepClassifier(spec, model_dir=model_dir, runconfig=conf.runconfig, **engine_kw)
+
+
+def build_estimator(model_dir, model_type):
+    raise NotImplementedError("the canned tf.estimator builders (python/lib/build_estimator.py:201-261) are out of scope: "
+                              "train.py uses build_custom_estimator (SURVEY section 2, row 12)")

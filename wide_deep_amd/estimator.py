@@ -1,0 +1,221 @@
+"""Estimator-shaped front of the engine: what python/train.py drives (python/lib/joint.py:272-432).
+
+`WideAndDeepClassifier(spec, model_dir)` offers the three calls the reference's drivers use,
+    .train(input_fn, hooks=None, steps=None, max_steps=None, saving_listeners=None)        train.py:72-77,128-133
+    .evaluate(input_fn, steps=None, hooks=None, checkpoint_path=None, name=None) -> dict   train.py:81-87,138-143
+    .predict(input_fn, predict_keys=None, hooks=None, checkpoint_path=None) -> iterator    pred.py:65-74
+with the Estimator's life cycle: every call restores the latest checkpoint of `model_dir` (if any), `train` runs
+until the one-pass input is exhausted and writes a checkpoint at the end (timed saves every
+`save_checkpoints_secs`, `keep_checkpoint_max` newest kept).  Checkpoints are `model.ckpt-<global_step>.pt` files
+holding a {TF variable name -> tensor} dict in the reference's naming, so weights can be moved
+to / from a TF checkpoint of the reference by name.
+
+`input_fn` is a zero-argument callable returning an iterator of dataset.RawBatch (as `lambda: input_fn(...)` in
+train.py) -- or of ready DeviceBatch objects (synthetic benches).
+"""
+import glob
+import os
+import re
+import time
+
+import numpy as np
+import torch
+
+from .engine import DeviceBatch, WideDeepEngine
+from .features import Featurizer
+
+
+class WideAndDeepClassifier(object):
+    def __init__(self, spec, model_dir=None, runconfig=None, max_batch=None, max_nnz=None, cross_padding="tf_dense",
+                 seed=None, engine=None):
+        self.spec = spec
+        self.model_dir = model_dir
+        self.runconfig = dict(runconfig or {})
+        self._engine_kw = dict(max_batch=max_batch, max_nnz=max_nnz)
+        self._seed = self.runconfig.get("tf_random_seed", 0) if seed is None else seed
+        self._cross_padding = cross_padding
+        self._engine = engine
+        self._featurizer = None
+        self._restored_from = None
+
+    # ---- engine life cycle --------------------------------------------------------------------------
+    def _ensure_engine(self, first_batch):
+        if self._engine is None:
+            B = self._engine_kw["max_batch"] or max(first_batch.B, 1)
+            kw = {"max_batch": B, "seed": int(self._seed or 0)}
+            if self._engine_kw["max_nnz"]:
+                kw["max_nnz"] = self._engine_kw["max_nnz"]
+            else:
+                # multi-valued + crossed columns: generous capacity, the featurizer checks every batch against it
+                kw["max_nnz"] = B * max(len(self.spec.slots), 1) * 16
+            self._engine = WideDeepEngine(self.spec, **kw)
+        if self._featurizer is None:
+            self._featurizer = Featurizer(self._engine, self._cross_padding)
+        return self._engine
+
+    @property
+    def engine(self):
+        return self._engine
+
+    def _device_batch(self, b):
+        if isinstance(b, DeviceBatch):
+            self._ensure_engine(b)
+            return b
+        self._ensure_engine(b)
+        return self._featurizer.to_device(b)
+
+    # ---- checkpoints --------------------------------------------------------------------------------
+    def latest_checkpoint(self):
+        if not self.model_dir or not os.path.isdir(self.model_dir):
+            return None
+        best, best_step = None, -1
+        for p in glob.glob(os.path.join(self.model_dir, "model.ckpt-*.pt")):
+            m = re.search(r"model\.ckpt-(\d+)\.pt$", p)
+            if m and int(m.group(1)) > best_step:
+                best, best_step = p, int(m.group(1))
+        return best
+
+    def _restore(self, checkpoint_path=None):
+        path = checkpoint_path or self.latest_checkpoint()
+        if path and path != self._restored_from:
+            self._engine.import_state(torch.load(path, map_location="cpu"))
+            self._restored_from = path
+        return path
+
+    def save_checkpoint(self):
+        if not self.model_dir:
+            return None
+        os.makedirs(self.model_dir, exist_ok=True)
+        path = os.path.join(self.model_dir, "model.ckpt-%d.pt" % self._engine.global_step)
+        torch.save(self._engine.export_state(), path)
+        self._restored_from = path
+        keep = int(self.runconfig.get("keep_checkpoint_max") or 5)
+        ckpts = sorted(glob.glob(os.path.join(self.model_dir, "model.ckpt-*.pt")),
+                       key=lambda p: int(re.search(r"-(\d+)\.pt$", p).group(1)))
+        for old in ckpts[:-keep]:
+            os.remove(old)
+        return path
+
+    # ---- train / evaluate / predict -----------------------------------------------------------------
+    def train(self, input_fn, hooks=None, steps=None, max_steps=None, saving_listeners=None):
+        it = iter(input_fn())
+        n, t_save, t0, seen = 0, time.time(), time.time(), 0
+        save_secs = self.runconfig.get("save_checkpoints_secs")
+        log_every = int(self.runconfig.get("log_step_count_steps") or 0)
+        loss = None
+        for raw in it:
+            bt = self._device_batch(raw)
+            if n == 0:
+                self._restore()
+                if max_steps is not None and self._engine.global_step >= max_steps:
+                    break
+            loss = self._engine.train_step(bt)
+            n += 1
+            seen += bt.B
+            if log_every and n % log_every == 0:
+                torch.cuda.synchronize()
+                dt = time.time() - t0
+                print("INFO: step %d (global_step %d): loss = %.6f, %.1f examples/sec" % (
+                    n, self._engine.global_step, float(loss), seen / max(dt, 1e-9)))
+            if save_secs and time.time() - t_save >= save_secs:
+                self.save_checkpoint()
+                t_save = time.time()
+            if steps is not None and n >= steps:
+                break
+            if max_steps is not None and self._engine.global_step >= max_steps:
+                break
+        if n:
+            torch.cuda.synchronize()
+            self.last_train = {"steps": n, "examples": seen, "seconds": time.time() - t0,
+                               "loss": float(loss) if loss is not None else None}
+            self.save_checkpoint()
+        return self
+
+    def _forward_all(self, input_fn, steps, checkpoint_path, need_labels):
+        probs, logits, labels, weights = [], [], [], []
+        n = 0
+        for raw in iter(input_fn()):
+            bt = self._device_batch(raw)
+            if n == 0:
+                self._restore(checkpoint_path)
+            self._engine.forward(bt, need_loss=False)
+            B = bt.B
+            probs.append(self._engine.prob[:B].cpu())
+            logits.append(self._engine.logit[:B].cpu())
+            if need_labels:
+                if bt.labels is None:
+                    raise ValueError("evaluate needs labels (input_fn mode 'eval')")
+                labels.append(bt.labels[:B].cpu())
+                weights.append(bt.weights[:B].cpu() if bt.weights is not None else torch.ones(B))
+            n += 1
+            if steps is not None and n >= steps:
+                break
+        cat = lambda xs: torch.cat(xs) if xs else torch.zeros(0)
+        return cat(probs), cat(logits), cat(labels), cat(weights)
+
+    def evaluate(self, input_fn, steps=None, hooks=None, checkpoint_path=None, name=None):
+        """Metrics of the canned binary head: accuracy, accuracy_baseline, auc, auc_precision_recall,
+        average_loss, label/mean, loss, precision, prediction/mean, recall, global_step."""
+        p, x, y, w = self._forward_all(input_fn, steps, checkpoint_path, True)
+        return binary_head_metrics(p.double().numpy(), x.double().numpy(), y.double().numpy(), w.double().numpy(),
+                                   self._engine.global_step if self._engine else 0, self._last_batch_size(p))
+
+    def _last_batch_size(self, p):
+        return self._engine.max_batch if self._engine else max(len(p), 1)
+
+    def predict(self, input_fn, predict_keys=None, hooks=None, checkpoint_path=None):
+        p, x, _, _ = self._forward_all(input_fn, None, checkpoint_path, False)
+        for i in range(len(p)):
+            pi, xi = float(p[i]), float(x[i])
+            out = {"logits": np.asarray([xi], np.float32), "logistic": np.asarray([pi], np.float32),
+                   "probabilities": np.asarray([1.0 - pi, pi], np.float32),
+                   "class_ids": np.asarray([int(pi > 0.5)], np.int64),
+                   "classes": np.asarray([str(int(pi > 0.5)).encode()], dtype=object)}
+            yield out if predict_keys is None else {k: out[k] for k in predict_keys}
+
+
+def _auc(tp, fp, tn, fn, curve):
+    """tf.metrics.auc(num_thresholds=200, summation_method='trapezoidal')."""
+    eps = 1e-6
+    if curve == "ROC":
+        xs = fp / (fp + tn + eps)
+        ys = (tp + eps) / (tp + fn + eps)
+    else:
+        xs = (tp + eps) / (tp + fn + eps)
+        ys = (tp + eps) / (tp + fp + eps)
+    return float(np.sum((xs[:-1] - xs[1:]) * (ys[:-1] + ys[1:]) / 2.0))
+
+
+def binary_head_metrics(p, logits, y, w, global_step, batch_size):
+    n = len(p)
+    if n == 0:
+        return {"global_step": global_step}
+    wsum = w.sum()
+    ce = np.maximum(logits, 0) - logits * y + np.log1p(np.exp(-np.abs(logits)))
+    pred = (p > 0.5).astype(np.float64)
+    tp = float((w * pred * y).sum())
+    fp = float((w * pred * (1 - y)).sum())
+    fn = float((w * (1 - pred) * y).sum())
+    # 200 thresholds: [0-eps, 1/199, ..., 198/199, 1+eps]  (tf.metrics.auc)
+    k = 200
+    th = np.asarray([0.0 - 1e-7] + [(i + 1) * 1.0 / (k - 1) for i in range(k - 2)] + [1.0 + 1e-7])
+    above = p[None, :] > th[:, None]
+    tps = (above * (w * y)[None, :]).sum(1)
+    fps = (above * (w * (1 - y))[None, :]).sum(1)
+    fns = ((~above) * (w * y)[None, :]).sum(1)
+    tns = ((~above) * (w * (1 - y))[None, :]).sum(1)
+    label_mean = float((w * y).sum() / wsum)
+    nb = int(np.ceil(n / float(batch_size)))
+    return {
+        "accuracy": float((w * (pred == y)).sum() / wsum),
+        "accuracy_baseline": max(label_mean, 1.0 - label_mean),
+        "auc": _auc(tps, fps, tns, fns, "ROC"),
+        "auc_precision_recall": _auc(tps, fps, tns, fns, "PR"),
+        "average_loss": float((w * ce).sum() / wsum),
+        "label/mean": label_mean,
+        "loss": float((w * ce).sum() / max(nb, 1)),      # mean over batches of the per-batch SUM loss
+        "precision": tp / (tp + fp) if tp + fp > 0 else 0.0,
+        "prediction/mean": float((w * p).sum() / wsum),
+        "recall": tp / (tp + fn) if tp + fn > 0 else 0.0,
+        "global_step": global_step,
+    }

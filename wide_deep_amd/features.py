@@ -1,0 +1,205 @@
+"""RawBatch (parsed TSV rows) -> DeviceBatch (example-major bag CSR of ids in HBM).
+
+Runs the feature-column transforms the reference declares in `_build_model_columns`
+(python/lib/build_estimator.py:83-158) for one batch:
+
+  hash_bucket  tokens -> wd_fingerprint64 (one launch for ALL string features) -> wd_emit_hash_slot (% buckets)
+  vocab        token -> index in vocabulary_list, OOV (-1) dropped           -> wd_emit_int_slot
+  identity     id if 0 <= id < n else 0 (default_value=0); -1 dropped        -> wd_emit_int_slot
+  bucketized   #boundaries <= normalizer(x)   (wide column, quirk C.5)       -> wd_emit_int_slot
+  crossed      per key: Fingerprint64 of the raw tokens / int ids of identity & bucketized keys -> wd_cross_hash
+  numeric      raw float; the normalizer runs in wd_dense_fwd
+
+`cross_padding`: 'tf_dense' (default) reproduces the reference, where crossed columns see the
+padded_batch tensors of their string keys including the '' padding (every example contributes Lmax values per string
+key, Lmax = longest list of that feature IN THE BATCH); 'ragged' crosses only real tokens.
+
+The small per-batch index arithmetic (bag lengths, vocabulary lookups, bucketize of the <= 3 continuous columns) is
+host-side numpy, like the reference's graph-build-time Python; the hashing and all id emission run on the GPU.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import capi
+from .capi import call, ptr
+from .engine import DeviceBatch
+
+
+def _normalize(x, normalizer):
+    if not normalizer:
+        return x
+    kind, p0, p1 = normalizer
+    x = x.astype(np.float32)
+    if kind == "min_max":
+        return (x - np.float32(p0)) / (np.float32(p1) - np.float32(p0))
+    if kind == "standard":
+        return (x - np.float32(p0)) / np.float32(p1)
+    return np.log(x)
+
+
+def _bucketize(x, boundaries):
+    """tf bucketized_column: number of boundaries <= x (float32 compare)."""
+    b = np.asarray(boundaries, dtype=np.float32)
+    return np.searchsorted(b, x.astype(np.float32), side="right").astype(np.int32)
+
+
+class Featurizer(object):
+    def __init__(self, engine, cross_padding="tf_dense"):
+        if cross_padding not in ("tf_dense", "ragged"):
+            raise ValueError("cross_padding must be 'tf_dense' or 'ragged'")
+        self.engine, self.plan, self.cross_padding = engine, engine.plan, cross_padding
+        self.dev = engine.device
+        slots = self.plan.slots
+        # string features whose fingerprints are needed (hash slots + string cross keys)
+        feats = []
+        for s in slots:
+            if s.kind == "hash" and s.feature not in feats:
+                feats.append(s.feature)
+            if s.kind == "cross":
+                for k in s.cross_keys:
+                    if k.kind == "string" and k.feature not in feats:
+                        feats.append(k.feature)
+        self.fp_features = feats
+        self.vocab_maps = {i: {v.encode(): j for j, v in enumerate(s.vocab)} for i, s in enumerate(slots) if s.kind == "vocab"}
+
+    def _dev(self, a, dtype):
+        return torch.from_numpy(np.ascontiguousarray(a)).to(self.dev, dtype=dtype, non_blocking=True)
+
+    def to_device(self, raw):
+        plan, eng = self.plan, self.engine
+        B, S = raw.B, plan.S
+        st = torch.cuda.current_stream().cuda_stream
+        # ---- 1. fingerprints of every needed token, one launch (+ one trailing '' token for padding) ----------
+        tok_base, chunks, lens = {}, [], []
+        n = 0
+        for f in self.fp_features:
+            toks = raw.cat[f][0]
+            tok_base[f] = n
+            chunks.append(b"".join(toks))
+            lens.extend(len(t) for t in toks)
+            n += len(toks)
+        empty_index = n
+        lens.append(0)
+        offs = np.zeros(n + 2, dtype=np.int32)
+        np.cumsum(np.asarray(lens, dtype=np.int64), out=offs[1:])
+        data = np.frombuffer(b"".join(chunks) + b"\0", dtype=np.uint8).copy()
+        d_bytes, d_offs = self._dev(data, torch.uint8), self._dev(offs, torch.int32)
+        fp = torch.empty(n + 1, dtype=torch.int64, device=self.dev)
+        call("wd_fingerprint64", ptr(d_bytes), ptr(d_offs), n + 1, ptr(fp), st)
+
+        # ---- 2. bag lengths per (example, slot) on the host --------------------------------------------------
+        lens_bs = np.zeros((B, S), dtype=np.int64)
+        emit = []   # (slot, kind, payload)
+        for i, s in enumerate(plan.slots):
+            if s.kind == "hash":
+                toks, fo = raw.cat[s.feature]
+                lens_bs[:, i] = np.diff(fo)
+                emit.append((i, "hash", (tok_base[s.feature], fo, len(toks))))
+            elif s.kind == "vocab":
+                toks, fo = raw.cat[s.feature]
+                vm = self.vocab_maps[i]
+                idx = np.fromiter((vm.get(t, -1) for t in toks), dtype=np.int32, count=len(toks))
+                keep = idx >= 0
+                ex_of = np.repeat(np.arange(B), np.diff(fo))
+                cnt = np.bincount(ex_of[keep], minlength=B).astype(np.int64)
+                lens_bs[:, i] = cnt
+                emit.append((i, "int", (idx[keep], cnt)))
+            elif s.kind == "identity":
+                v = raw.ints[s.feature]
+                keep = v != -1                                   # -1 is the int ignore_value of the sparse conversion
+                vals = np.where((v >= 0) & (v < s.num_buckets), v, 0).astype(np.int32)
+                lens_bs[:, i] = keep
+                emit.append((i, "int", (vals[keep], keep.astype(np.int64))))
+            elif s.kind == "bucket":
+                x = _normalize(raw.floats[s.feature], s.normalizer)
+                lens_bs[:, i] = 1
+                emit.append((i, "int", (_bucketize(x, s.boundaries), np.ones(B, np.int64))))
+            elif s.kind == "cross":
+                cnt = np.ones(B, dtype=np.int64)
+                keys = []
+                for k in s.cross_keys:
+                    if k.kind == "string":
+                        toks, fo = raw.cat[k.feature]
+                        real = np.diff(fo).astype(np.int64)
+                        if self.cross_padding == "tf_dense":
+                            lmax = int(real.max()) if B else 0
+                            kc = np.full(B, lmax, dtype=np.int64)
+                            # gather indices into fp: real tokens then the '' fingerprint up to lmax
+                            col = np.arange(lmax)[None, :]
+                            gi = np.where(col < real[:, None], tok_base[k.feature] + fo[:-1, None] + col, empty_index)
+                            keys.append(("fp", gi.reshape(-1), kc))
+                        else:
+                            gi = tok_base[k.feature] + np.arange(len(toks))
+                            keys.append(("fp", gi, real))
+                            kc = real
+                    elif k.kind == "identity":
+                        v = raw.ints[k.feature]
+                        keep = v != -1
+                        vals = np.where((v >= 0) & (v < k.num_buckets), v, 0).astype(np.int64)
+                        kc = keep.astype(np.int64)
+                        keys.append(("int", vals[keep], kc))
+                    else:   # bucketized raw value (un-normalised numeric column inside crosses, quirk C.5)
+                        vals = _bucketize(raw.floats[k.feature], k.boundaries).astype(np.int64)
+                        kc = np.ones(B, dtype=np.int64)
+                        keys.append(("int", vals, kc))
+                    cnt = cnt * kc
+                lens_bs[:, i] = cnt
+                emit.append((i, "cross", keys))
+            else:
+                raise ValueError("unknown slot kind %s" % s.kind)
+        nnz = int(lens_bs.sum())
+        if nnz > eng.max_nnz or B > eng.max_batch:
+            raise ValueError("batch (B=%d, nnz=%d) exceeds engine capacity (max_batch=%d, max_nnz=%d)"
+                             % (B, nnz, eng.max_batch, eng.max_nnz))
+        bag_offs = np.zeros(B * S + 1, dtype=np.int32)
+        np.cumsum(lens_bs.reshape(-1), out=bag_offs[1:])
+        d_bag = self._dev(bag_offs, torch.int32)
+        ids = torch.zeros(max(nnz, 1), dtype=torch.int32, device=self.dev)
+
+        # ---- 3. id emission on the device --------------------------------------------------------------------
+        def csr(cnt):
+            o = np.zeros(B + 1, dtype=np.int32)
+            np.cumsum(cnt, out=o[1:])
+            return self._dev(o, torch.int32)
+
+        keep_alive = [d_bytes, d_offs, fp, d_bag]
+        for i, kind, payload in emit:
+            s = plan.slots[i]
+            if kind == "hash":
+                base, fo, ntok = payload
+                d_fo = self._dev(fo, torch.int32)
+                keep_alive.append(d_fo)
+                call("wd_emit_hash_slot", fp.data_ptr() + 8 * base, ptr(d_fo), B, s.num_buckets, ptr(d_bag), S, i, ptr(ids), st)
+            elif kind == "int":
+                vals, cnt = payload
+                d_v = self._dev(vals if len(vals) else np.zeros(1, np.int32), torch.int32)
+                d_fo = csr(cnt)
+                keep_alive += [d_v, d_fo]
+                call("wd_emit_int_slot", ptr(d_v), ptr(d_fo), B, ptr(d_bag), S, i, ptr(ids), st)
+            else:
+                ck = capi.WdCrossKeys()
+                ck.nkeys = len(payload)
+                if ck.nkeys > capi.WD_MAX_CROSS_KEYS:
+                    raise ValueError("crossed column `%s` has more than %d keys" % (s.name, capi.WD_MAX_CROSS_KEYS))
+                for k, (vk, v, cnt) in enumerate(payload):
+                    if vk == "fp":
+                        gi = self._dev(v if len(v) else np.zeros(1, np.int64), torch.int64)
+                        d_v = fp[gi]                                        # fingerprints incl. '' padding
+                    else:
+                        d_v = self._dev(v if len(v) else np.zeros(1, np.int64), torch.int64)
+                    d_fo = csr(cnt)
+                    keep_alive += [d_v, d_fo]
+                    ck.vals[k], ck.offs[k] = d_v.data_ptr(), d_fo.data_ptr()
+                call("wd_cross_hash", ctypes.byref(ck), B, s.hash_key, s.num_buckets, ptr(d_bag), S, i, ptr(ids), st)
+
+        nd = len(plan.dense_cols)
+        dense = None
+        if nd:
+            dense = self._dev(np.stack([raw.floats[d.feature] for d in plan.dense_cols], axis=1).astype(np.float32), torch.float32)
+        labels = self._dev(raw.labels, torch.float32) if raw.labels is not None else None
+        weights = self._dev(raw.weights, torch.float32) if (raw.weights is not None and self.engine.spec.use_weight_column) else None
+        bt = DeviceBatch(B, ids, d_bag, dense, labels, weights, nnz=nnz)
+        bt._keep = keep_alive   # the emission kernels are asynchronous
+        return bt

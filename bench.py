@@ -76,9 +76,7 @@ def gather_roofline(eng, batches, iters=200):
     (dim, gs), = list(eng.group_slots.items())[:1]
 
     def run(i):
-        bt = batches[i % len(batches)]
-        call("wd_embag_fwd", ptr(eng.emb), ptr(eng.slots_dev), plan.S, ptr(gs), gs.numel(), dim, ptr(bt.ids),
-             ptr(bt.bag_offs), bt.B, xp, ld, st)
+        eng.embag_fwd(dim, gs, batches[i % len(batches)], xp, ld, st)
 
     for i in range(10):
         run(i)
@@ -89,7 +87,7 @@ def gather_roofline(eng, batches, iters=200):
     # nnz*D*4 (row reads) + nnz*4 (ids) + (B*S+1)*4 (offsets) + B*S*D*4 (pooled write)
     alg = bt.nnz * dim * 4 + bt.nnz * 4 + (bt.B * plan.S + 1) * 4 + nbag * dim * 4
     gbs = alg / (ms * 1e-3) / 1e9
-    return {"bound": "hbm", "kernel": "k_embag_fwd<%d>" % (dim // 4), "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
+    return {"bound": "hbm", "kernel": "k_embag_fwd_range<%d, 2>" % (dim // 4), "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
             "algorithmic_bytes_per_launch": int(alg), "avg_launch_us": round(ms * 1e3, 2)}
 

@@ -103,6 +103,12 @@ int wd_embag_fwd(const float *emb, const wd_slot_t *slots, int32_t S, const int3
                  int32_t dim, const int32_t *ids, const int32_t *bag_offs, int64_t batch, float *x, int64_t ldx,
                  wd_stream_t stream);
 
+/* Same result for a CONTIGUOUS slot range [slot0, slot0 + ngroup) (the engine orders the slots of one dim together):
+ * no group_slots indirection, slot metadata staged in LDS, two bags per lane group.  dim in {4,8,16,32,64,128}. */
+int wd_embag_fwd_range(const float *emb, const wd_slot_t *slots, int32_t S, int32_t slot0, int32_t ngroup, int32_t dim,
+                       const int32_t *ids, const int32_t *bag_offs, int64_t batch, float *x, int64_t ldx,
+                       wd_stream_t stream);
+
 /* indicator_column slots: x[b, out_col + id] = multiplicity of id in bag(b, slot). */
 int wd_indicator_fwd(const wd_slot_t *slots, int32_t S, const int32_t *group_slots, int32_t ngroup,
                      const int32_t *ids, const int32_t *bag_offs, int64_t batch, float *x, int64_t ldx,
@@ -262,6 +268,10 @@ int wd_mlp_finalize(const float *Gpart, int32_t nsplit, const float *P, int64_t 
 
 /* tf.train.AdagradOptimizer dense apply over a flat parameter buffer. */
 int wd_adagrad_dense(float *w, float *accum, const float *g, int64_t n, float lr, wd_stream_t stream);
+
+/* Diagnostic (bench-only): n random 64-byte row reads from `table` (row = 16 floats) with `per` independent rows in
+ * flight per 4-lane group; writes one float per wavefront to out.  Measures the random-gather ceiling of the part. */
+int wd_diag_gather64(const float *table, const int32_t *ids, int64_t n, int32_t per, float *out, wd_stream_t stream);
 
 /* misc plumbing */
 int wd_fill_f32(float *p, float v, int64_t n, wd_stream_t stream);

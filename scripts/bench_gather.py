@@ -1,0 +1,46 @@
+#!/usr/bin/env python
+"""Embedding-gather kernel alone on the C2 workload (run on the GPU box): HIP-event timing, and -- under
+`rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` -- its HBM traffic next to a streaming copy of KNOWN size that
+calibrates the counters (MI355X_MICROARCH.md: FETCH_SIZE under-reports wide coalesced reads by 2x on gfx950)."""
+import os, sys, json
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from wide_deep_amd import synth
+from wide_deep_amd.engine import WideDeepEngine
+from wide_deep_amd.plan import criteo_spec
+
+B = 8192
+iters = int(os.environ.get("GATHER_ITERS", "200"))
+pool = int(os.environ.get("GATHER_POOL", "16"))
+dist = os.environ.get("GATHER_DIST", "uniform")
+spec = criteo_spec(n_dense=13, n_sparse=26, buckets=1_000_000, dim=16, hidden=(256, 128, 64))
+eng = WideDeepEngine(spec, max_batch=B)
+plan = eng.plan
+bts = [synth.to_device_ids(plan, synth.make_raw_batch(plan, B, seed=20260925 + i, dist=dist)) for i in range(pool)]
+tw0 = eng.towers[0]
+ld = tw0["layout"].ld
+xp = tw0["act"].data_ptr() + 4 * tw0["layout"].seg_start[0]
+st = torch.cuda.current_stream().cuda_stream
+(dim, gs), = list(eng.group_slots.items())
+
+# calibration: copy of a KNOWN 256 MiB (read 256 MiB + write 256 MiB), 16 B per lane
+src = torch.empty(64 * 1024 * 1024, dtype=torch.float32, device="cuda").normal_()
+dst = torch.empty_like(src)
+for _ in range(3):
+    dst.copy_(src)
+torch.cuda.synchronize()
+
+for i in range(10):
+    eng.embag_fwd(dim, gs, bts[i % pool], xp, ld, st)
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for i in range(iters):
+    eng.embag_fwd(dim, gs, bts[i % pool], xp, ld, st)
+e1.record(); e1.synchronize()
+us = e0.elapsed_time(e1) / iters * 1e3
+bt = bts[0]
+alg = bt.nnz * dim * 4 + bt.nnz * 4 + (bt.B * plan.S + 1) * 4 + bt.B * gs.numel() * dim * 4
+print(json.dumps({"kernel": "embag_fwd", "ids": dist, "avg_us": round(us, 2), "alg_bytes": alg,
+                  "GBps": round(alg / us / 1e3, 1), "frac_of_8TBps": round(alg / us / 1e3 / 8000, 4)}))

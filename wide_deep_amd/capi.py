@@ -69,6 +69,7 @@ _PROTOS = {
     "wd_emit_int_slot": [P, P, I64, P, I32, I32, P, P],
     "wd_cross_hash": [ctypes.POINTER(WdCrossKeys), I64, U64, U64, P, I32, I32, P, P],
     "wd_embag_fwd": [P, P, I32, P, I32, I32, P, P, I64, P, I64, P],
+    "wd_embag_fwd_range": [P, P, I32, I32, I32, I32, P, P, I64, P, I64, P],
     "wd_indicator_fwd": [P, I32, P, I32, P, P, I64, P, I64, P],
     "wd_dense_fwd": [P, I64, P, I32, I64, P, I64, P],
     "wd_wide_fwd": [P, I32, P, P, I32, P, P, I64, P, P],
@@ -95,6 +96,7 @@ _PROTOS = {
     "wd_mlp_finalize": [P, I32, P, I64, I64, P, P, P, P, F32, P, I64, I64, P],
     "wd_adagrad_dense": [P, P, P, I64, F32, P],
     "wd_fill_f32": [P, F32, I64, P],
+    "wd_diag_gather64": [P, P, I64, I32, P, P],
 }
 _RESTYPES = {"wd_sort_workspace_bytes": SZ, "wd_logits_head_blocks": I64, "wd_bucket_max": I32, "wd_bucket_chunks": I32}
 

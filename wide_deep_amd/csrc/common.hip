@@ -27,3 +27,45 @@ extern "C" int wd_fill_f32(float *p, float v, int64_t n, wd_stream_t stream) {
   hipLaunchKernelGGL(k_fill_f32, dim3(blocks), dim3(256), 0, wd::as_stream(stream), p, v, n);
   return wd::check_launch("wd_fill_f32");
 }
+
+// ---- diagnostics (bench-only): ceilings the gather kernel is measured against -------------------------------------
+// random 64-byte row reads: 4 lanes x float4 per row, `per` independent rows per lane group, one float out per wave
+template <int PER>
+__global__ void __launch_bounds__(256) k_diag_gather64(const float4 *__restrict__ tab, const int32_t *__restrict__ ids,
+                                                       int64_t n, float *__restrict__ out) {
+  const int64_t grp = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 2;
+  const int lane = threadIdx.x & 3;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  int32_t id[PER];
+#pragma unroll
+  for (int q = 0; q < PER; ++q) {
+    const int64_t j = grp * PER + q;
+    id[q] = j < n ? ids[j] : -1;
+  }
+#pragma unroll
+  for (int q = 0; q < PER; ++q) {
+    if (id[q] >= 0) {
+      const float4 r = tab[(int64_t)id[q] * 4 + lane];
+      acc.x += r.x; acc.y += r.y; acc.z += r.z; acc.w += r.w;
+    }
+  }
+  float v = acc.x + acc.y + acc.z + acc.w;
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  if ((threadIdx.x & 63) == 0) out[((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6] = v;
+}
+
+extern "C" int wd_diag_gather64(const float *table, const int32_t *ids, int64_t n, int32_t per, float *out,
+                                wd_stream_t stream) {
+  if (n <= 0) return WD_OK;
+  hipStream_t st = wd::as_stream(stream);
+  const float4 *t4 = reinterpret_cast<const float4 *>(table);
+  const unsigned blocks = (unsigned)wd::ceil_div(wd::ceil_div(n, per) * 4, 256);
+  switch (per) {
+    case 1: hipLaunchKernelGGL(k_diag_gather64<1>, dim3(blocks), dim3(256), 0, st, t4, ids, n, out); break;
+    case 2: hipLaunchKernelGGL(k_diag_gather64<2>, dim3(blocks), dim3(256), 0, st, t4, ids, n, out); break;
+    case 4: hipLaunchKernelGGL(k_diag_gather64<4>, dim3(blocks), dim3(256), 0, st, t4, ids, n, out); break;
+    case 8: hipLaunchKernelGGL(k_diag_gather64<8>, dim3(blocks), dim3(256), 0, st, t4, ids, n, out); break;
+    default: wd::set_error("wd_diag_gather64: per must be 1, 2, 4 or 8"); return WD_ERR_INVALID;
+  }
+  return wd::check_launch("wd_diag_gather64");
+}

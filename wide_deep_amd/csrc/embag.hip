@@ -63,6 +63,86 @@ k_embag_fwd(const float *__restrict__ emb, const wd_slot_t *__restrict__ slots, 
   (void)D;
 }
 
+// Contiguous-slot variant (the engine's layout: the slots of one embedding dim are a contiguous slot range
+// [slot0, slot0 + ngroup)): no group_slots indirection, per-slot metadata staged once per workgroup in LDS while
+// the CSR offsets are already in flight, BPG bags per lane group so that every lane has BPG independent
+// offset -> id -> row chains outstanding.  Dependent global round trips per bag: offsets, ids, row (was 5).
+template <int LANES, int BPG>
+__global__ void __launch_bounds__(256)
+k_embag_fwd_range(const float *__restrict__ emb, const wd_slot_t *__restrict__ slots, int32_t S, int32_t slot0,
+                  int32_t ngroup, const int32_t *__restrict__ ids, const int32_t *__restrict__ bag_offs,
+                  int64_t nwork, float *__restrict__ x, int64_t ldx) {
+  constexpr int MAXG = 128;
+  __shared__ int64_t s_emb_off[MAXG];
+  __shared__ int32_t s_out_col[MAXG];
+  const int t = threadIdx.x;
+  const int lane = t % LANES;
+  const int64_t grp = ((int64_t)blockIdx.x * 256 + t) / LANES;   // lane group index
+  int64_t w[BPG], b[BPG];
+  int32_t g[BPG], j0[BPG], j1[BPG];
+#pragma unroll
+  for (int q = 0; q < BPG; ++q) {
+    w[q] = grp * BPG + q;
+    const int64_t wc = w[q] < nwork ? w[q] : nwork - 1;
+    b[q] = wc / ngroup;
+    g[q] = (int32_t)(wc - b[q] * ngroup);
+    const int64_t bag = b[q] * S + slot0 + g[q];
+    j0[q] = bag_offs[bag];
+    j1[q] = bag_offs[bag + 1];
+  }
+  for (int i = t; i < ngroup; i += 256) {
+    const wd_slot_t sl = slots[slot0 + i];
+    s_emb_off[i] = sl.emb_off;
+    s_out_col[i] = sl.out_col;
+  }
+  int32_t id0[BPG];
+#pragma unroll
+  for (int q = 0; q < BPG; ++q) id0[q] = j1[q] > j0[q] ? ids[j0[q]] : 0;
+  __syncthreads();
+  float4 acc[BPG];
+#pragma unroll
+  for (int q = 0; q < BPG; ++q) {
+    const float4 *__restrict__ tab = reinterpret_cast<const float4 *>(emb + s_emb_off[g[q]]);
+    acc[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (j1[q] > j0[q]) {   // rows are touched once per step: nontemporal, do not pollute L2
+      typedef float floatx4 __attribute__((ext_vector_type(4)));
+      const floatx4 r = __builtin_nontemporal_load(reinterpret_cast<const floatx4 *>(&tab[(int64_t)id0[q] * LANES + lane]));
+      acc[q] = make_float4(r.x, r.y, r.z, r.w);
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < BPG; ++q) {
+    const float4 *__restrict__ tab = reinterpret_cast<const float4 *>(emb + s_emb_off[g[q]]);
+    int32_t j = j0[q] + 1;
+    for (; j + 4 <= j1[q]; j += 4) {   // multi-hot tail: 4 independent row reads in flight
+      const int32_t i0 = ids[j], i1 = ids[j + 1], i2 = ids[j + 2], i3 = ids[j + 3];
+      const float4 r0 = tab[(int64_t)i0 * LANES + lane], r1 = tab[(int64_t)i1 * LANES + lane];
+      const float4 r2 = tab[(int64_t)i2 * LANES + lane], r3 = tab[(int64_t)i3 * LANES + lane];
+      acc[q].x += r0.x; acc[q].y += r0.y; acc[q].z += r0.z; acc[q].w += r0.w;
+      acc[q].x += r1.x; acc[q].y += r1.y; acc[q].z += r1.z; acc[q].w += r1.w;
+      acc[q].x += r2.x; acc[q].y += r2.y; acc[q].z += r2.z; acc[q].w += r2.w;
+      acc[q].x += r3.x; acc[q].y += r3.y; acc[q].z += r3.z; acc[q].w += r3.w;
+    }
+    for (; j < j1[q]; ++j) {
+      const float4 r = tab[(int64_t)ids[j] * LANES + lane];
+      acc[q].x += r.x; acc[q].y += r.y; acc[q].z += r.z; acc[q].w += r.w;
+    }
+    const int32_t n = j1[q] - j0[q];
+    if (n > 1) {  // combiner='mean'
+      const float c = (float)n;
+      acc[q].x /= c; acc[q].y /= c; acc[q].z /= c; acc[q].w /= c;
+    }
+    if (w[q] < nwork) {
+      float *o = x + b[q] * ldx + s_out_col[g[q]] + lane * 4;
+      if ((((uintptr_t)o) & 15) == 0) {
+        *reinterpret_cast<float4 *>(o) = acc[q];
+      } else {
+        o[0] = acc[q].x; o[1] = acc[q].y; o[2] = acc[q].z; o[3] = acc[q].w;
+      }
+    }
+  }
+}
+
 // dims that are not a multiple of 4 (never produced by the reference's embedding_dim, kept for the
 // opt-in embedding_dim override): one lane per (bag, element).
 __global__ void k_embag_fwd_generic(const float *__restrict__ emb, const wd_slot_t *__restrict__ slots, int32_t S,
@@ -231,4 +311,32 @@ extern "C" int wd_bce_sum_fwd_bwd(const float *dnn_logit, const float *wide_logi
   hipLaunchKernelGGL(k_bce, dim3((unsigned)wd::ceil_div(batch, 256)), dim3(256), 0, wd::as_stream(stream), dnn_logit,
                      wide_logit, labels, weights, batch, logit, prob, dlogit, loss_sum);
   return wd::check_launch("wd_bce_sum_fwd_bwd");
+}
+
+extern "C" int wd_embag_fwd_range(const float *emb, const wd_slot_t *slots, int32_t S, int32_t slot0, int32_t ngroup,
+                                  int32_t dim, const int32_t *ids, const int32_t *bag_offs, int64_t batch, float *x,
+                                  int64_t ldx, wd_stream_t stream) {
+  if (batch <= 0 || ngroup <= 0) return WD_OK;
+  WD_REQUIRE(emb && slots && ids && bag_offs && x, "null pointer");
+  WD_REQUIRE(slot0 >= 0 && slot0 + ngroup <= S, "slot range out of bounds");
+  WD_REQUIRE(ngroup <= 128, "at most 128 slots per dim group");
+  const int64_t nwork = batch * ngroup;
+  hipStream_t st = wd::as_stream(stream);
+  constexpr int BPG = 2;
+#define WD_LAUNCH_RANGE(L)                                                                                           \
+  hipLaunchKernelGGL((k_embag_fwd_range<L, BPG>), dim3((unsigned)wd::ceil_div(wd::ceil_div(nwork, BPG) * L, 256)),   \
+                     dim3(256), 0, st, emb, slots, S, slot0, ngroup, ids, bag_offs, nwork, x, ldx)
+  switch (dim) {
+    case 4: WD_LAUNCH_RANGE(1); break;
+    case 8: WD_LAUNCH_RANGE(2); break;
+    case 16: WD_LAUNCH_RANGE(4); break;
+    case 32: WD_LAUNCH_RANGE(8); break;
+    case 64: WD_LAUNCH_RANGE(16); break;
+    case 128: WD_LAUNCH_RANGE(32); break;
+    default:
+      wd::set_error("wd_embag_fwd_range: dim %d is not one of 4,8,16,32,64,128 (use wd_embag_fwd)", dim);
+      return WD_ERR_UNSUPPORTED;
+  }
+#undef WD_LAUNCH_RANGE
+  return wd::check_launch("wd_embag_fwd_range");
 }

@@ -234,8 +234,7 @@ class WideDeepEngine:
             ld = tw0["layout"].ld
             xp = self._x_ptr(tw0)
             for dim, gs in self.group_slots.items():
-                call("wd_embag_fwd", ptr(self.emb), ptr(self.slots_dev), S, ptr(gs), gs.numel(), dim, ptr(bt.ids),
-                     ptr(bt.bag_offs), B, xp, ld, st)
+                self.embag_fwd(dim, gs, bt, xp, ld, st)
             if self.ind_slots_dev is not None:
                 call("wd_indicator_fwd", ptr(self.slots_dev), S, ptr(self.ind_slots_dev), self.ind_slots_dev.numel(),
                      ptr(bt.ids), ptr(bt.bag_offs), B, xp, ld, st)
@@ -245,6 +244,18 @@ class WideDeepEngine:
         if spec.has_wide:
             call("wd_wide_fwd", ptr(self.wide), 4, ptr(self.bias), ptr(self.slots_dev), S, ptr(bt.ids),
                  ptr(bt.bag_offs), B, ptr(self.wide_logit), st)
+
+    def embag_fwd(self, dim, gs, bt, xp, ld, st):
+        """Embedding-bag gather of one dim group into x (the kernel bench.py reports the HBM roofline of)."""
+        plan = self.plan
+        sl = plan.emb_groups[dim]
+        contiguous = sl == list(range(sl[0], sl[0] + len(sl)))
+        if contiguous and dim in (4, 8, 16, 32, 64, 128) and len(sl) <= 128:
+            call("wd_embag_fwd_range", ptr(self.emb), ptr(self.slots_dev), plan.S, sl[0], len(sl), dim, ptr(bt.ids),
+                 ptr(bt.bag_offs), bt.B, xp, ld, st)
+        else:
+            call("wd_embag_fwd", ptr(self.emb), ptr(self.slots_dev), plan.S, ptr(gs), gs.numel(), dim, ptr(bt.ids),
+                 ptr(bt.bag_offs), bt.B, xp, ld, st)
 
     def forward(self, bt: DeviceBatch, need_loss=True):
         """Fills self.logit / self.prob (and self.dlogit / self.loss + the logits-layer backward when labels are given)."""

@@ -159,11 +159,17 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..."
                              % (args.gpus, args.gpus))
-    torch.cuda.set_device(local_rank)
+    # WD_DIST_BACKEND=gloo: functional smoke test of the N>1 path with all ranks on ONE GPU (host-staged collectives)
+    backend = os.environ.get("WD_DIST_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(dev_index)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend)
 
     from wide_deep_amd import synth
     from wide_deep_amd.engine import WideDeepEngine
@@ -172,7 +178,8 @@ def main():
     B = args.batch
     if world > 1:
         from wide_deep_amd.dist import ShardedWideDeepEngine
-        eng = ShardedWideDeepEngine(spec, max_batch=B, max_nnz=B * 26 * (2 * mean_len + 2), seed=0)
+        eng = ShardedWideDeepEngine(spec, max_batch=B, max_nnz=B * 26 * (2 * mean_len + 2), seed=0,
+                                    expected_nnz=B * 26 * mean_len, slack=1.3)
     else:
         eng = WideDeepEngine(spec, max_batch=B, max_nnz=B * 26 * (2 * mean_len + 2), seed=0)
     plan = eng.plan
@@ -227,10 +234,12 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        t = torch.tensor([elapsed], device="cuda" if backend == "nccl" else "cpu", dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
     loss = float(eng.loss)
+    if world > 1:
+        eng.check_overflow()     # one device->host read AFTER the timed region
     value = args.steps * B * world / elapsed
 
     out = {

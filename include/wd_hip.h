@@ -102,6 +102,12 @@ int wd_cross_hash(const wd_cross_keys_t *keys_host, int64_t batch, uint64_t hash
 int wd_embag_fwd(const float *emb, const wd_slot_t *slots, int32_t S, const int32_t *group_slots, int32_t ngroup,
                  int32_t dim, const int32_t *ids, const int32_t *bag_offs, int64_t batch, float *x, int64_t ldx,
                  wd_stream_t stream);
+/* Same with an explicit row stride (floats, multiple of 4, >= dim): row i of a slot starts at emb_off + i*row_stride.
+ * Used to pool rows that arrived through the all-to-all exchange (rows are then `row_stride` apart); ids < 0 are
+ * skipped (they still count in the mean's denominator, like an all-zero row). */
+int wd_embag_fwd_strided(const float *emb, int64_t row_stride, const wd_slot_t *slots, int32_t S,
+                         const int32_t *group_slots, int32_t ngroup, int32_t dim, const int32_t *ids,
+                         const int32_t *bag_offs, int64_t batch, float *x, int64_t ldx, wd_stream_t stream);
 
 /* Same result for a CONTIGUOUS slot range [slot0, slot0 + ngroup) (the engine orders the slots of one dim together):
  * no group_slots indirection, slot metadata staged in LDS, two bags per lane group.  dim in {4,8,16,32,64,128}. */
@@ -169,14 +175,36 @@ int wd_bias_ftrl(float *bias_wzn, const float *dlogit, int64_t batch, float lr, 
  * (embedding rows, lr_emb) / FTRL (wide rows and bias_wzn, lr_wide, l1, l2) are applied in the same kernel.
  * emb / wide / bias_wzn may be NULL (deep-only / wide-only).  Workspaces (caller-owned, no initialisation needed):
  * bucket_cnt[(2 * wd_bucket_chunks() + 1) * nbuckets], bucket_start[nbuckets + 1], rank[nnz], pairs[nnz] (uint64).
- * nbuckets = ceil(total_rows / 2^shift) <= wd_bucket_max(). */
+ * nbuckets = ceil(total_rows / 2^shift) <= wd_bucket_max().  dlogit of example b is dlogit[b * ld_dlogit]; ids < 0
+ * are padding and are skipped; an embedding slot updates only keys below row_base + num_buckets. */
 int32_t wd_bucket_max(void);
 int32_t wd_bucket_chunks(void);
 int wd_sparse_bwd_fused(float *emb, float *emb_accum, float *wide, float *bias_wzn, const wd_slot_t *slots, int32_t S,
                         const int32_t *ids, const int32_t *bag_offs, int64_t batch, int64_t nnz, const float *dx,
-                        int64_t ldx, const float *dlogit, float lr_emb, float lr_wide, float l1, float l2,
+                        int64_t ldx, const float *dlogit, int64_t ld_dlogit, float lr_emb, float lr_wide, float l1, float l2,
                         int32_t *bucket_cnt, int32_t *bucket_start, int32_t *rank, uint64_t *pairs, int32_t nbuckets,
                         int32_t shift, wd_stream_t stream);
+
+/* ---- multi-GPU exchange (replaces the PS-partitioned variables of python/lib/joint.py:140-143, train.py:202-225):
+ * rows are sharded owner = id % world, local row = row_base_local[slot] + id / world.  All exchange buffers have
+ * `world` equal segments of `cap` entries so that the all-to-all split sizes are static (no host sync).
+ * wd_route_build: per occurrence j -> pos[j] = owner * cap + p (or -1 when the owner's segment overflowed) and
+ *   send_rows[pos[j]] = local row; unused entries are -1.  peer_counts[world] = requests per owner;
+ *   *overflow = max over owners of a count > cap (0: none; caller zeroes it once).  workspace: wd_route_chunks()*world ints.
+ * wd_owner_gather: out[r*row_stride + 0..dim) = emb[rows[r]*dim ..] when rows[r] < n_emb_rows (emb may be NULL) and
+ *   out[r*row_stride + (emb ? dim : 0)] = wide[rows[r]*4] (wide may be NULL); rows[r] < 0 skipped.
+ * wd_grad_pack: out[pos[j]*row_stride + 0..dim) = dx[b, out_col..] / len(bag) (zeros for non-embedding slots), and
+ *   out[pos[j]*row_stride + (dx ? dim : 0)] = dlogit[b] for wide slots (0 otherwise). */
+int32_t wd_route_chunks(void);
+int wd_route_build(const wd_slot_t *local_slots, int32_t S, int32_t world, const int32_t *ids, const int32_t *bag_offs,
+                   int64_t batch, int32_t cap, int32_t *send_rows, int32_t *pos, int32_t *workspace,
+                   int32_t *peer_counts, int32_t *overflow, wd_stream_t stream);
+int wd_owner_gather(const float *emb, int64_t n_emb_rows, int32_t dim, const float *wide, const int32_t *rows, int64_t n,
+                    float *out, int32_t row_stride, wd_stream_t stream);
+int wd_grad_pack(const wd_slot_t *slots, int32_t S, const int32_t *bag_offs, const int32_t *pos, int64_t batch,
+                 const float *dx, int64_t ldx, const float *dlogit, int32_t dim, int32_t row_stride, float *out,
+                 wd_stream_t stream);
+int wd_fill_i32(int32_t *p, int32_t v, int64_t n, wd_stream_t stream);
 
 /* ---- a9: dense tower (python/lib/dnn.py:92-234) ---------------------------------------------
  * fp32 MFMA GEMMs, row-major.  C[M,N] = epi(A op B):

@@ -23,6 +23,10 @@ def _spec(kind):
     from wide_deep_amd.plan import criteo_spec
     if kind == "multihot":
         return criteo_spec(n_dense=2, n_sparse=4, buckets=101, dim=16, hidden=(16, 8), mode="resnet"), 3
+    if kind == "wideonly":
+        return criteo_spec(n_dense=0, n_sparse=6, buckets=97, dim=16, hidden=(8,), model_type="wide"), 2
+    if kind == "deeponly":
+        return criteo_spec(n_dense=2, n_sparse=3, buckets=50, dim=32, hidden=(16,), model_type="deep"), 4
     return criteo_spec(n_dense=3, n_sparse=5, buckets=300, dim=16, hidden=(32, 16)), 1
 
 
@@ -57,12 +61,13 @@ def _worker(rank, world, port, kind, q):
             hbs = bs[st]
             # single engine: global batch = rank0's examples then rank1's
             glob = {"B": B_loc * world, "lens": np.concatenate([h["lens"] for h in hbs], 0),
-                    "raw": np.concatenate([h["raw"] for h in hbs]), "dense": np.concatenate([h["dense"] for h in hbs], 0),
+                    "raw": np.concatenate([h["raw"] for h in hbs]), "dense": None if hbs[0]["dense"] is None else np.concatenate([h["dense"] for h in hbs], 0),
                     "labels": np.concatenate([h["labels"] for h in hbs])}
             ref.train_step(synth.to_device_ids(ref.plan, glob))
             sh.train_step(synth.to_device_ids(sh.global_plan, hbs[rank]))
             torch.cuda.synchronize()
             assert_close(sh.logit[:B_loc], ref.logit[rank * B_loc:(rank + 1) * B_loc], 1e-4, 1e-5, "logits step %d" % st)
+            sh.check_overflow()
         full1, exp = sh.export_full_state(), ref.export_state()
         for k, v in exp.items():
             if k == "global_step":
@@ -76,7 +81,53 @@ def _worker(rank, world, port, kind, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("kind", ["onehot", "multihot"])
+def _overflow_worker(rank, world, port, kind, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        from wide_deep_amd import synth
+        from wide_deep_amd.capi import WdError
+        from wide_deep_amd.dist import ShardedWideDeepEngine
+        spec, _ = _spec("onehot")
+        # capacity sized for 1/10 of the real occurrences: every peer segment overflows
+        sh = ShardedWideDeepEngine(spec, max_batch=64, seed=1, expected_nnz=32, slack=1.0)
+        hb = synth.make_raw_batch(sh.global_plan, 64, seed=rank)
+        sh.train_step(synth.to_device_ids(sh.global_plan, hb))
+        torch.cuda.synchronize()
+        try:
+            sh.check_overflow()
+            q.put((rank, "FAIL: overflow not reported"))
+        except WdError:
+            q.put((rank, "ok"))
+    except Exception as e:  # pragma: no cover
+        import traceback
+        q.put((rank, "FAIL: %s\n%s" % (e, traceback.format_exc())))
+    finally:
+        dist.destroy_process_group()
+
+
+def _run(worker, kind):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=worker, args=(r, 2, port, kind, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(60)
+    for rank, msg in res:
+        assert msg == "ok", "rank %d: %s" % (rank, msg)
+
+
+def test_exchange_overflow_is_reported():
+    _run(_overflow_worker, "onehot")
+
+
+@pytest.mark.parametrize("kind", ["onehot", "multihot", "wideonly", "deeponly"])
 def test_sharded_world2_equals_single_engine(kind):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()

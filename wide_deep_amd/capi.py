@@ -82,7 +82,13 @@ _PROTOS = {
     "wd_bias_ftrl": [P, P, I64, F32, F32, F32, P],
     "wd_bucket_max": [],
     "wd_bucket_chunks": [],
-    "wd_sparse_bwd_fused": [P, P, P, P, P, I32, P, P, I64, I64, P, I64, P, F32, F32, F32, F32, P, P, P, P, I32, I32, P],
+    "wd_sparse_bwd_fused": [P, P, P, P, P, I32, P, P, I64, I64, P, I64, P, I64, F32, F32, F32, F32, P, P, P, P, I32, I32, P],
+    "wd_route_chunks": [],
+    "wd_route_build": [P, I32, I32, P, P, I64, I32, P, P, P, P, P, P],
+    "wd_owner_gather": [P, I64, I32, P, P, I64, P, I32, P],
+    "wd_grad_pack": [P, I32, P, P, I64, P, I64, P, I32, I32, P, P],
+    "wd_fill_i32": [P, I32, I64, P],
+    "wd_embag_fwd_strided": [P, I64, P, I32, P, I32, I32, P, P, I64, P, I64, P],
     "wd_gemm_nn_bias_act": [P, I64, P, I64, P, I32, I32, P, I64, I64, I64, I64, P],
     "wd_gemm_nt": [P, I64, P, I64, P, I64, I64, I64, I64, I32, P],
     "wd_gemm_nt_actbwd": [P, I64, P, I64, P, I64, I64, I64, I64, P, I64, I32, P],
@@ -98,7 +104,7 @@ _PROTOS = {
     "wd_fill_f32": [P, F32, I64, P],
     "wd_diag_gather64": [P, P, I64, I32, P, P],
 }
-_RESTYPES = {"wd_sort_workspace_bytes": SZ, "wd_logits_head_blocks": I64, "wd_bucket_max": I32, "wd_bucket_chunks": I32}
+_RESTYPES = {"wd_sort_workspace_bytes": SZ, "wd_logits_head_blocks": I64, "wd_bucket_max": I32, "wd_bucket_chunks": I32, "wd_route_chunks": I32}
 
 EXPORTED_SYMBOLS = sorted(list(_PROTOS) + ["wd_last_error"])
 

@@ -19,7 +19,8 @@ template <int LANES>  // LANES = D/4 lanes cooperate on one bag
 __global__ void __launch_bounds__(256)
 k_embag_fwd(const float *__restrict__ emb, const wd_slot_t *__restrict__ slots, int32_t S,
             const int32_t *__restrict__ group_slots, int32_t ngroup, const int32_t *__restrict__ ids,
-            const int32_t *__restrict__ bag_offs, int64_t nwork, float *__restrict__ x, int64_t ldx) {
+            const int32_t *__restrict__ bag_offs, int64_t nwork, float *__restrict__ x, int64_t ldx, int64_t RS4) {
+  // RS4: row stride in float4 units (LANES for a dense table; larger for rows received through the exchange)
   constexpr int D = LANES * 4;
   const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t work = tid / LANES;  // (b, g) pair
@@ -33,20 +34,22 @@ k_embag_fwd(const float *__restrict__ emb, const wd_slot_t *__restrict__ slots, 
   const float4 *__restrict__ tab = reinterpret_cast<const float4 *>(emb + sl.emb_off);
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   int32_t j = j0;
-  // 4 independent row reads in flight per lane group
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  // 4 independent row reads in flight per lane group (ids < 0: dropped exchange entries, contribute nothing)
   for (; j + 4 <= j1; j += 4) {
     int32_t i0 = ids[j], i1 = ids[j + 1], i2 = ids[j + 2], i3 = ids[j + 3];
-    float4 r0 = tab[(int64_t)i0 * LANES + lane];
-    float4 r1 = tab[(int64_t)i1 * LANES + lane];
-    float4 r2 = tab[(int64_t)i2 * LANES + lane];
-    float4 r3 = tab[(int64_t)i3 * LANES + lane];
+    float4 r0 = i0 >= 0 ? tab[(int64_t)i0 * RS4 + lane] : zero4;
+    float4 r1 = i1 >= 0 ? tab[(int64_t)i1 * RS4 + lane] : zero4;
+    float4 r2 = i2 >= 0 ? tab[(int64_t)i2 * RS4 + lane] : zero4;
+    float4 r3 = i3 >= 0 ? tab[(int64_t)i3 * RS4 + lane] : zero4;
     acc.x += r0.x; acc.y += r0.y; acc.z += r0.z; acc.w += r0.w;
     acc.x += r1.x; acc.y += r1.y; acc.z += r1.z; acc.w += r1.w;
     acc.x += r2.x; acc.y += r2.y; acc.z += r2.z; acc.w += r2.w;
     acc.x += r3.x; acc.y += r3.y; acc.z += r3.z; acc.w += r3.w;
   }
   for (; j < j1; ++j) {
-    float4 r = tab[(int64_t)ids[j] * LANES + lane];
+    const int32_t i0 = ids[j];
+    float4 r = i0 >= 0 ? tab[(int64_t)i0 * RS4 + lane] : zero4;
     acc.x += r.x; acc.y += r.y; acc.z += r.z; acc.w += r.w;
   }
   const int32_t n = j1 - j0;
@@ -210,7 +213,10 @@ k_wide_fwd(const float *__restrict__ wide, const float *__restrict__ bias, const
       if (!sl.wide) continue;
       const int64_t bag = b * S + s;
       const int32_t j0 = bag_offs[bag], j1 = bag_offs[bag + 1];
-      for (int32_t j = j0; j < j1; ++j) acc += wide[(sl.row_base + ids[j]) * stride];
+      for (int32_t j = j0; j < j1; ++j) {
+        const int32_t id = ids[j];
+        if (id >= 0) acc += wide[(sl.row_base + id) * stride];   // id < 0: dropped exchange entry
+      }
     }
   }
   acc += __shfl_xor(acc, 8, 16);
@@ -247,17 +253,20 @@ __global__ void k_bce(const float *__restrict__ dnn_logit, const float *__restri
 
 }  // namespace
 
-extern "C" int wd_embag_fwd(const float *emb, const wd_slot_t *slots, int32_t S, const int32_t *group_slots,
-                            int32_t ngroup, int32_t dim, const int32_t *ids, const int32_t *bag_offs, int64_t batch,
-                            float *x, int64_t ldx, wd_stream_t stream) {
+static int embag_fwd_impl(const float *emb, int64_t row_stride, const wd_slot_t *slots, int32_t S,
+                          const int32_t *group_slots, int32_t ngroup, int32_t dim, const int32_t *ids,
+                          const int32_t *bag_offs, int64_t batch, float *x, int64_t ldx, wd_stream_t stream) {
   if (batch <= 0 || ngroup <= 0) return WD_OK;
   WD_REQUIRE(emb && slots && group_slots && ids && bag_offs && x, "null pointer");
   WD_REQUIRE(dim > 0, "dim must be > 0");
+  WD_REQUIRE(row_stride == dim || (row_stride > dim && row_stride % 4 == 0 && dim % 4 == 0 && dim <= 128),
+             "row_stride must be dim, or a multiple of 4 above dim with dim in {4,...,128}");
+  const int64_t RS4 = row_stride / 4;
   const int64_t nwork = batch * ngroup;
   hipStream_t st = wd::as_stream(stream);
 #define WD_LAUNCH_EMBAG(L)                                                                                         \
   hipLaunchKernelGGL(k_embag_fwd<L>, dim3((unsigned)wd::ceil_div(nwork * L, 256)), dim3(256), 0, st, emb, slots, S, \
-                     group_slots, ngroup, ids, bag_offs, nwork, x, ldx)
+                     group_slots, ngroup, ids, bag_offs, nwork, x, ldx, RS4)
   switch (dim) {
     case 4: WD_LAUNCH_EMBAG(1); break;
     case 8: WD_LAUNCH_EMBAG(2); break;
@@ -271,6 +280,18 @@ extern "C" int wd_embag_fwd(const float *emb, const wd_slot_t *slots, int32_t S,
   }
 #undef WD_LAUNCH_EMBAG
   return wd::check_launch("wd_embag_fwd");
+}
+
+extern "C" int wd_embag_fwd(const float *emb, const wd_slot_t *slots, int32_t S, const int32_t *group_slots,
+                            int32_t ngroup, int32_t dim, const int32_t *ids, const int32_t *bag_offs, int64_t batch,
+                            float *x, int64_t ldx, wd_stream_t stream) {
+  return embag_fwd_impl(emb, dim, slots, S, group_slots, ngroup, dim, ids, bag_offs, batch, x, ldx, stream);
+}
+
+extern "C" int wd_embag_fwd_strided(const float *emb, int64_t row_stride, const wd_slot_t *slots, int32_t S,
+                                    const int32_t *group_slots, int32_t ngroup, int32_t dim, const int32_t *ids,
+                                    const int32_t *bag_offs, int64_t batch, float *x, int64_t ldx, wd_stream_t stream) {
+  return embag_fwd_impl(emb, row_stride, slots, S, group_slots, ngroup, dim, ids, bag_offs, batch, x, ldx, stream);
 }
 
 extern "C" int wd_indicator_fwd(const wd_slot_t *slots, int32_t S, const int32_t *group_slots, int32_t ngroup,

@@ -47,6 +47,7 @@ k_bucket_hist(const wd_slot_t *__restrict__ slots, int32_t S, const int32_t *__r
     const int64_t base = slots[bag % S].row_base;
     const int32_t j0 = bag_offs[bag], j1 = bag_offs[bag + 1];
     for (int32_t j = j0; j < j1; ++j) {
+      if (ids[j] < 0) continue;  // padding entry of a fixed-capacity exchange segment
       const uint32_t key = (uint32_t)(base + ids[j]);
       rank[j] = atomicAdd(&hist[key >> shift], 1);
     }
@@ -121,6 +122,7 @@ k_bucket_scatter(const wd_slot_t *__restrict__ slots, int32_t S, const int32_t *
     const int64_t base = slots[bag % S].row_base;
     const int32_t j0 = bag_offs[bag], j1 = bag_offs[bag + 1];
     for (int32_t j = j0; j < j1; ++j) {
+      if (ids[j] < 0) continue;
       const uint32_t key = (uint32_t)(base + ids[j]);
       pairs[sstart[key >> shift] + rank[j]] = ((uint64_t)key << 32) | (uint32_t)bag;
     }
@@ -152,7 +154,7 @@ struct UpdArgs {
   const int32_t *bag_offs;
   const float *dx;
   const float *dlogit;
-  int64_t ldx, batch;
+  int64_t ldx, batch, ld_dlogit;
   int32_t S, nb;
   float lr_emb, lr_w, l1, l2;
 };
@@ -202,7 +204,7 @@ k_bucket_update(UpdArgs u, const int32_t *__restrict__ start, uint64_t *__restri
   if ((int)blockIdx.x == u.nb) {  // bias_weights: g = sum_b dlogit[b] (fixed-shape tree), dense FTRL
     if (!u.bias) return;
     float acc = 0.f;
-    for (int64_t i = t; i < u.batch; i += 256) acc += u.dlogit[i];
+    for (int64_t i = t; i < u.batch; i += 256) acc += u.dlogit[i * u.ld_dlogit];
     redw[t] = acc;
     __syncthreads();
     for (int st = 128; st >= 1; st >>= 1) {
@@ -280,7 +282,7 @@ k_bucket_update(UpdArgs u, const int32_t *__restrict__ start, uint64_t *__restri
     }
     const int32_t bag0 = (int32_t)(uint32_t)sp[i];
     const wd_slot_t sl = u.slots[bag0 % S];
-    const bool do_emb = u.emb && sl.kind == WD_SLOT_EMBEDDING;
+    const bool do_emb = u.emb && sl.kind == WD_SLOT_EMBEDDING && (int64_t)key - sl.row_base < sl.num_buckets;
     const bool do_wide = u.wide && sl.wide;
     const int D = sl.dim;
     if (do_emb && (D & 3) == 0) {
@@ -317,7 +319,7 @@ k_bucket_update(UpdArgs u, const int32_t *__restrict__ start, uint64_t *__restri
     }
     if (do_wide && gl == 0) {
       float g = 0.f;
-      for (int j = i; j < e; ++j) g += u.dlogit[(int32_t)(uint32_t)sp[j] / S];
+      for (int j = i; j < e; ++j) g += u.dlogit[(int64_t)((int32_t)(uint32_t)sp[j] / S) * u.ld_dlogit];
       float4 r = *reinterpret_cast<float4 *>(u.wide + (int64_t)key * 4);  // {w, z, n, -}
       ftrl_update(r.x, r.y, r.z, g, u.lr_w, u.l1, u.l2);
       *reinterpret_cast<float4 *>(u.wide + (int64_t)key * 4) = r;
@@ -330,7 +332,7 @@ k_bucket_update(UpdArgs u, const int32_t *__restrict__ start, uint64_t *__restri
     const int i = long_i0[q], e = long_i1[q];
     const uint32_t key = (uint32_t)(sp[i] >> 32);
     const wd_slot_t sl = u.slots[(int32_t)(uint32_t)sp[i] % S];
-    const bool do_emb = u.emb && sl.kind == WD_SLOT_EMBEDDING;
+    const bool do_emb = u.emb && sl.kind == WD_SLOT_EMBEDDING && (int64_t)key - sl.row_base < sl.num_buckets;
     const bool do_wide = u.wide && sl.wide;
     const int D = sl.dim;
     if (do_emb) {
@@ -382,7 +384,7 @@ k_bucket_update(UpdArgs u, const int32_t *__restrict__ start, uint64_t *__restri
     }
     if (do_wide) {
       float g = 0.f;
-      for (int j = i + t; j < e; j += 256) g += u.dlogit[(int32_t)(uint32_t)sp[j] / S];
+      for (int j = i + t; j < e; j += 256) g += u.dlogit[(int64_t)((int32_t)(uint32_t)sp[j] / S) * u.ld_dlogit];
       redw[t] = g;
       __syncthreads();
       for (int st = 128; st >= 1; st >>= 1) {
@@ -406,7 +408,8 @@ extern "C" int32_t wd_bucket_chunks(void) { return MAX_CHUNKS; }
 
 extern "C" int wd_sparse_bwd_fused(float *emb, float *emb_accum, float *wide, float *bias_wzn, const wd_slot_t *slots,
                                    int32_t S, const int32_t *ids, const int32_t *bag_offs, int64_t batch, int64_t nnz,
-                                   const float *dx, int64_t ldx, const float *dlogit, float lr_emb, float lr_wide,
+                                   const float *dx, int64_t ldx, const float *dlogit, int64_t ld_dlogit, float lr_emb,
+                                   float lr_wide,
                                    float l1, float l2, int32_t *bucket_cnt, int32_t *bucket_start, int32_t *rank,
                                    uint64_t *pairs, int32_t nbuckets, int32_t shift, wd_stream_t stream) {
   if (batch <= 0) return WD_OK;
@@ -433,6 +436,7 @@ extern "C" int wd_sparse_bwd_fused(float *emb, float *emb_accum, float *wide, fl
   UpdArgs u;
   u.emb = emb; u.accum = emb_accum; u.wide = wide; u.bias = bias_wzn; u.slots = slots; u.bag_offs = bag_offs;
   u.dx = dx; u.dlogit = dlogit; u.ldx = ldx; u.batch = batch; u.S = S; u.nb = nbuckets;
+  u.ld_dlogit = ld_dlogit > 0 ? ld_dlogit : 1;
   u.lr_emb = lr_emb; u.lr_w = lr_wide; u.l1 = l1; u.l2 = l2;
   hipLaunchKernelGGL(k_bucket_update, dim3((unsigned)nbuckets + 1), dim3(256), 0, st, u, bucket_start, pairs);
   return wd::check_launch("wd_sparse_bwd_fused");

@@ -128,9 +128,16 @@ def local_spec(spec: ModelSpec, world):
 # HIP engine
 # ---------------------------------------------------------------------------------------------
 class ShardedWideDeepEngine(WideDeepEngine):
-    """WideDeepEngine whose tables hold rows id % world == rank; batches are this rank's examples."""
+    """WideDeepEngine whose tables hold rows id % world == rank; batches are this rank's examples.
 
-    def __init__(self, spec: ModelSpec, max_batch=8192, max_nnz=None, device="cuda", seed=0, group=None):
+    One step = the single-GPU step with three fixed-size all-to-alls in the sparse part and one all-reduce of the
+    flat dense gradient (csrc/dist_exchange.hip has the device side).  Nothing in the step reads a value back to
+    the host: the per-peer segments have a static capacity `cap = slack * expected_nnz / world`; `check_overflow()`
+    (one device->host read, call it every few hundred steps) raises if a peer ever received more than that.
+    """
+
+    def __init__(self, spec: ModelSpec, max_batch=8192, max_nnz=None, device="cuda", seed=0, group=None, slack=1.5,
+                 expected_nnz=None):
         if not dist.is_initialized():
             raise RuntimeError("ShardedWideDeepEngine needs torch.distributed to be initialised")
         self.group = group
@@ -146,20 +153,40 @@ class ShardedWideDeepEngine(WideDeepEngine):
             raise NotImplementedError("sharded engine: indicator columns are not exchanged yet")
         S = gp.S
         mn = int(max_nnz) if max_nnz else int(max_batch) * max(S, 1) * 8
-        # owner side may receive up to world * (requester nnz) occurrences in the worst case; size for 2x the mean
-        super().__init__(local_spec(spec, self.world), max_batch=max_batch, max_nnz=2 * mn, device=device, seed=seed)
+        W = self.world
+        # entries per peer segment: the all-to-alls always move FULL segments, so size them from the occurrences a
+        # batch really has (expected_nnz), not from the worst case the buffers could hold
+        self.cap = ((int(math.ceil(int(expected_nnz or mn) / W * slack)) + 63) // 64) * 64
+        self.n_req = W * self.cap
+        # owner side: the received list has n_req entries (padding included) -> capacity of the update workspaces
+        super().__init__(local_spec(spec, W), max_batch=max_batch, max_nnz=max(mn, self.n_req), device=device,
+                         seed=seed, expected_nnz=self.n_req)
         self.req_max_nnz = mn
         self.dim = dims.pop() if dims else 0
+        if self.dim % 4:
+            raise NotImplementedError("sharded engine: embedding dim must be a multiple of 4")
         dev = self.device
-        self.local_row_base = torch.tensor(self.plan.row_base, dtype=torch.int64, device=dev)
-        self.n_emb_slots = self.plan.n_emb if spec.has_deep else 0
-        self.emb_slot_mask = torch.tensor([1 if (s.deep == "embedding" and spec.has_deep) else 0 for s in self.plan.slots],
-                                          dtype=torch.bool, device=dev)
-        self.wide_slot_mask = torch.tensor([1 if (spec.has_wide and s.wide) else 0 for s in self.plan.slots],
-                                           dtype=torch.bool, device=dev)
-        self.out_col_t = torch.tensor(self.plan.out_col, dtype=torch.int64, device=dev)
+        lp = self.plan
+        self.n_emb_slots = lp.n_emb if spec.has_deep else 0
+        # embedding slots come first in the fused row space and share one dim: embedding row == fused local row
+        self.n_emb_rows = sum(int(s.num_buckets) for s in lp.slots[: self.n_emb_slots])
+        assert all(lp.emb_off[i] == lp.row_base[i] * self.dim for i in range(self.n_emb_slots))
+        has_emb, has_wide = self.n_emb_slots > 0, spec.has_wide
+        self.RS = (self.dim if has_emb else 0) + ((4 if has_emb else 1) if has_wide else 0)   # floats per exchanged row
+        i32 = dict(dtype=torch.int32, device=dev)
+        f32 = dict(dtype=torch.float32, device=dev)
+        self.send_rows = torch.full((self.n_req,), -1, **i32)
+        self.recv_rows = torch.full((self.n_req,), -1, **i32)
+        self.pos = torch.zeros(self.max_nnz, **i32)
+        self.route_ws = torch.zeros(int(call("wd_route_chunks")) * W, **i32)
+        self.peer_counts = torch.zeros(W, **i32)
+        self.overflow = torch.zeros(1, **i32)
+        self.fwd_send = torch.zeros(self.n_req * self.RS, **f32)
+        self.fwd_recv = torch.zeros(self.n_req * self.RS, **f32)
+        self.bwd_send = torch.zeros(self.n_req * self.RS, **f32)
+        self.bwd_recv = torch.zeros(self.n_req * self.RS, **f32)
+        self.req_offs = torch.arange(self.n_req + 1, **i32)             # one "bag" per received request
 
-        # requester-side descriptors: "table" = rows that came back, ids = position in that buffer
         def make_slots(entries):
             arr = (capi.WdSlot * len(entries))()
             for i, e in enumerate(entries):
@@ -167,141 +194,95 @@ class ShardedWideDeepEngine(WideDeepEngine):
                     setattr(arr[i], k, v)
             return torch.from_numpy(np.frombuffer(bytes(arr), dtype=np.uint8).copy()).to(dev)
 
+        # requester side: "table" = the rows that came back (fwd_recv), "id" = position in it
         xs = []
-        for i, s in enumerate(self.plan.slots):
+        for i, s in enumerate(lp.slots):
             is_emb = bool(s.deep == "embedding" and spec.has_deep)
             xs.append(dict(emb_off=0 if is_emb else -1, row_base=0, num_buckets=1 << 30, dim=int(s.dim) if is_emb else 0,
-                           out_col=self.plan.out_col[i], kind=capi.SLOT_EMBEDDING if is_emb else capi.SLOT_NONE,
+                           out_col=lp.out_col[i], kind=capi.SLOT_EMBEDDING if is_emb else capi.SLOT_NONE,
                            wide=1 if (spec.has_wide and s.wide) else 0))
         self.xslots_dev = make_slots(xs)
-        # owner-side pseudo slot: the whole local fused row space is one slot
-        self.oslot_dev = make_slots([dict(emb_off=0, row_base=0, num_buckets=1 << 30, dim=self.dim, out_col=0,
-                                          kind=capi.SLOT_EMBEDDING, wide=1)])
-        self.zero1 = torch.zeros(4, dtype=torch.float32, device=dev)
-        self.one_slot = torch.zeros(1, dtype=torch.int32, device=dev)
-        self._ex_emb = self._ex_wide = None
+        # owner side: the whole local fused row space is one slot; only rows below n_emb_rows carry embeddings
+        self.oslot_dev = make_slots([dict(emb_off=0, row_base=0, num_buckets=max(self.n_emb_rows, 1), dim=self.dim,
+                                          out_col=0, kind=capi.SLOT_EMBEDDING if has_emb else capi.SLOT_NONE, wide=1)])
+        # bias gradient = sum_b dlogit[b] = bias gradient of the logits layer -> rides in the flat all-reduce
+        self._logits_b_off = self.towers[0]["metas"][-1]["b_off"] if spec.has_deep else None
+        if spec.has_deep and len(self.towers) != 1:
+            raise NotImplementedError("sharded engine: one tower")
+        self._gsum = torch.zeros(1, **f32)
 
-    # ---- requester / owner kernels ---------------------------------------------------------
-    def _owner_gather_emb(self, req):
-        n = req.numel()
-        out = torch.empty(n, self.dim, dtype=torch.float32, device=self.device)
+    def check_overflow(self):
+        n = int(self.overflow.item())
         if n:
-            offs = torch.arange(n + 1, dtype=torch.int32, device=self.device)
-            call("wd_embag_fwd", ptr(self.emb), ptr(self.oslot_dev), 1, ptr(self.one_slot), 1, self.dim, ptr(req),
-                 ptr(offs), n, ptr(out), self.dim, _stream())
-        return out
-
-    def _owner_gather_wide(self, req):
-        n = req.numel()
-        out = torch.empty(n, dtype=torch.float32, device=self.device)
-        if n:
-            offs = torch.arange(n + 1, dtype=torch.int32, device=self.device)
-            call("wd_wide_fwd", ptr(self.wide), 4, ptr(self.zero1), ptr(self.oslot_dev), 1, ptr(req), ptr(offs), n,
-                 ptr(out), _stream())
-        return out
-
-    def _owner_update(self, req, grads, is_emb):
-        """Deduplicate by row (sort + segment sum) and apply Adagrad (embedding rows) or FTRL (wide rows)."""
-        n = req.numel()
-        if n == 0:
-            return
-        if n > self.max_nnz:
-            raise ValueError("owner received %d occurrences, capacity %d" % (n, self.max_nnz))
-        st = _stream()
-        offs = torch.arange(n + 1, dtype=torch.int32, device=self.device)
-        call("wd_build_sort_keys", ptr(self.oslot_dev), 1, ptr(req), ptr(offs), n, n, ptr(self.keys), ptr(self.vals), st)
-        call("wd_sort_pairs", ptr(self.keys), ptr(self.vals), ptr(self.keys_sorted), ptr(self.vals_sorted), n,
-             self.plan.key_bits, ptr(self.sort_ws), self.sort_ws_bytes, st)
-        if is_emb:
-            call("wd_embag_bwd_adagrad", ptr(self.emb), ptr(self.emb_acc), ptr(self.oslot_dev), 1, self.dim,
-                 ptr(self.keys_sorted), ptr(self.vals_sorted), n, ptr(offs), ptr(grads), self.dim,
-                 float(self.spec.dnn_opt[1]), st)
-        else:
-            _, lr, l1, l2, _ = self.spec.lin_opt
-            call("wd_wide_bwd_ftrl", ptr(self.wide), ptr(self.oslot_dev), 1, ptr(self.keys_sorted), ptr(self.vals_sorted),
-                 n, ptr(grads), float(lr), float(l1), float(l2), st)
+            raise capi.WdError("all-to-all segment overflow: a peer received %d requests, capacity %d; "
+                               "raise `slack` or `max_nnz`" % (n, self.cap))
 
     # ---- overrides ------------------------------------------------------------------------------
     def _sparse_forward(self, bt: DeviceBatch, st):
-        plan, spec = self.plan, self.spec
-        B, S = bt.B, plan.S
-        ids = bt.ids[: bt.nnz]
-        slot_of, ex_of, lens = occurrence_slots(bt.bag_offs, B, S, bt.nnz)
-        self._occ = (slot_of, ex_of, lens)
+        lp, spec = self.plan, self.spec
+        B, S, W = bt.B, lp.S, self.world
+        has_emb = self.n_emb_slots > 0
+        # A: route every occurrence to its owner's segment, exchange the requested local rows
+        call("wd_route_build", ptr(self.slots_dev), S, W, ptr(bt.ids), ptr(bt.bag_offs), B, self.cap, ptr(self.send_rows),
+             ptr(self.pos), ptr(self.route_ws), ptr(self.peer_counts), ptr(self.overflow), st)
+        _a2a(self.recv_rows, self.send_rows, None, None, self.group)
+        # B: owners read their rows (+ wide weight), rows travel back
+        call("wd_owner_gather", ptr(self.emb) if has_emb else None, self.n_emb_rows, self.dim,
+             ptr(self.wide) if spec.has_wide else None, ptr(self.recv_rows), self.n_req, ptr(self.fwd_send), self.RS, st)
+        _a2a(self.fwd_recv, self.fwd_send, None, None, self.group)
         if spec.has_deep:
             tw0 = self.towers[0]
             ld = tw0["layout"].ld
             xp = self._x_ptr(tw0)
-            if self.n_emb_slots:
-                m = self.emb_slot_mask[slot_of]
-                all_emb = bool(self.n_emb_slots == S)
-                sel = None if all_emb else m.nonzero().squeeze(1)
-                ex = ExchangePlan(ids if all_emb else ids[sel], slot_of if all_emb else slot_of[sel],
-                                  self.local_row_base, self.world, self.group)
-                rows = ex.to_requester(self._owner_gather_emb(ex.req_rows))         # [n, D], bucketed order
-                # position of occurrence j inside `rows`
-                pos = torch.zeros(bt.nnz, dtype=torch.int32, device=self.device)
-                if all_emb:
-                    pos = ex.inv.to(torch.int32)
-                else:
-                    pos[sel] = ex.inv.to(torch.int32)
-                self._ex_emb = (ex, sel)
+            if has_emb:
                 gs = next(iter(self.group_slots.values()))
-                call("wd_embag_fwd", ptr(rows), ptr(self.xslots_dev), S, ptr(gs), gs.numel(), self.dim, ptr(pos),
-                     ptr(bt.bag_offs), B, xp, ld, st)
+                call("wd_embag_fwd_strided", ptr(self.fwd_recv), self.RS, ptr(self.xslots_dev), S, ptr(gs), gs.numel(),
+                     self.dim, ptr(self.pos), ptr(bt.bag_offs), B, xp, ld, st)
             if self.dense_cols_dev is not None:
                 call("wd_dense_fwd", ptr(bt.dense), bt.dense.stride(0), ptr(self.dense_cols_dev),
-                     len(plan.dense_cols), B, xp, ld, st)
+                     len(lp.dense_cols), B, xp, ld, st)
         if spec.has_wide:
-            all_wide = bool(self.wide_slot_mask.all())
-            sel = None if all_wide else self.wide_slot_mask[slot_of].nonzero().squeeze(1)
-            reuse = spec.has_deep and all_wide and self.n_emb_slots == S
-            if reuse:   # same occurrence set as the embedding exchange: reuse its routing
-                ex = self._ex_emb[0]
-            else:
-                ex = ExchangePlan(ids if all_wide else ids[sel], slot_of if all_wide else slot_of[sel],
-                                  self.local_row_base, self.world, self.group)
-            w = ex.to_requester(self._owner_gather_wide(ex.req_rows))               # [n]
-            pos = torch.zeros(bt.nnz, dtype=torch.int32, device=self.device)
-            if all_wide:
-                pos = ex.inv.to(torch.int32)
-            else:
-                pos[sel] = ex.inv.to(torch.int32)
-            self._ex_wide = (ex, sel)
-            call("wd_wide_fwd", ptr(w), 1, ptr(self.bias), ptr(self.xslots_dev), S, ptr(pos), ptr(bt.bag_offs), B,
+            w_ptr = self.fwd_recv.data_ptr() + 4 * (self.dim if has_emb else 0)
+            call("wd_wide_fwd", w_ptr, self.RS, ptr(self.bias), ptr(self.xslots_dev), S, ptr(self.pos), ptr(bt.bag_offs), B,
                  ptr(self.wide_logit), st)
 
     def _reduce_dense_grads(self):
         _all_reduce_sum(self.G, self.group)
 
     def _sparse_backward(self, bt: DeviceBatch, st):
-        plan, spec = self.plan, self.spec
-        B = bt.B
-        slot_of, ex_of, lens = self._occ
-        if spec.has_deep and self.n_emb_slots:
-            ex, sel = self._ex_emb
+        lp, spec = self.plan, self.spec
+        B, S = bt.B, lp.S
+        has_emb = self.n_emb_slots > 0
+        dx_ptr, ld = None, 0
+        if has_emb:
             tw0 = self.towers[0]
             tl0 = tw0["layout"]
-            so = slot_of if sel is None else slot_of[sel]
-            eo = ex_of if sel is None else ex_of[sel]
-            bag = eo * plan.S + so
-            scale = 1.0 / lens[bag].clamp_min(1).to(torch.float32)
-            cols = (tl0.seg_start[0] + self.out_col_t[so])[:, None] + torch.arange(self.dim, device=self.device)[None, :]
-            g = tw0["dact"][eo[:, None], cols] * scale[:, None]                       # [n, D] per-occurrence row grads
-            self._owner_update(ex.req_rows, ex.to_owner(g[ex.order].contiguous()), True)
+            dx_ptr, ld = tw0["dact"].data_ptr() + 4 * tl0.seg_start[0], tl0.ld
+        # C: per-occurrence gradients to the owners
+        call("wd_grad_pack", ptr(self.slots_dev), S, ptr(bt.bag_offs), ptr(self.pos), B, dx_ptr, ld,
+             ptr(self.dlogit) if spec.has_wide else None, self.dim, self.RS, ptr(self.bwd_send), st)
+        _a2a(self.bwd_recv, self.bwd_send, None, None, self.group)
+        lr, l1, l2 = (spec.lin_opt[1], spec.lin_opt[2], spec.lin_opt[3]) if spec.has_wide else (0.0, 0.0, 0.0)
+        g_ptr = self.bwd_recv.data_ptr()
+        dl_ptr = g_ptr + 4 * (self.dim if has_emb else 0)
+        # owner: dedup by row + Adagrad / FTRL on the received (row, gradient) list; bias handled below
+        call("wd_sparse_bwd_fused", ptr(self.emb) if has_emb else None, ptr(self.emb_acc) if has_emb else None,
+             ptr(self.wide) if spec.has_wide else None, None, ptr(self.oslot_dev), 1, ptr(self.recv_rows),
+             ptr(self.req_offs), self.n_req, self.n_req, g_ptr if has_emb else None, self.RS,
+             dl_ptr if spec.has_wide else None, self.RS, float(spec.dnn_opt[1]) if spec.has_deep else 0.0, float(lr),
+             float(l1), float(l2), ptr(self.bucket_cnt), ptr(self.bucket_start), ptr(self.occ_rank), ptr(self.pairs),
+             self.n_buckets, self.bucket_shift, st)
         if spec.has_wide:
-            ex, sel = self._ex_wide
-            eo = ex_of if sel is None else ex_of[sel]
-            gw = self.dlogit[eo][ex.order].contiguous()
-            self._owner_update(ex.req_rows, ex.to_owner(gw), False)
             # bias_weights: dense FTRL on the GLOBAL sum of dlogit
-            gsum = self.dlogit[:B].sum().reshape(1)
-            _all_reduce_sum(gsum, self.group)
-            _, lr, l1, l2, _ = spec.lin_opt
+            if self._logits_b_off is not None:
+                gsum = self.G[self._logits_b_off: self._logits_b_off + 1]     # already all-reduced with G
+            else:
+                torch.sum(self.dlogit[:B], dim=0, keepdim=True, out=self._gsum)
+                gsum = _all_reduce_sum(self._gsum, self.group)
             call("wd_bias_ftrl", ptr(self.bias), ptr(gsum), 1, float(lr), float(l1), float(l2), st)
 
     def capture_train_step(self, bt, warmup=2):
-        raise NotImplementedError("the sharded step has host-visible all-to-all split sizes; it is launched eagerly")
+        raise NotImplementedError("the sharded step is launched eagerly (collectives between the kernels)")
 
     # ---- state: shard <-> full tables ---------------------------------------------------------------
     def import_full_state(self, state):

@@ -421,7 +421,7 @@ class WideDeepEngine:
         lr, l1, l2 = (spec.lin_opt[1], spec.lin_opt[2], spec.lin_opt[3]) if spec.has_wide else (0.0, 0.0, 0.0)
         call("wd_sparse_bwd_fused", ptr(self.emb) if has_emb else None, ptr(self.emb_acc) if has_emb else None,
              ptr(self.wide), ptr(self.bias), ptr(self.slots_dev), plan.S, ptr(bt.ids), ptr(bt.bag_offs), bt.B, bt.nnz,
-             dx_ptr, ld, ptr(self.dlogit), float(spec.dnn_opt[1]) if spec.has_deep else 0.0, float(lr), float(l1),
+             dx_ptr, ld, ptr(self.dlogit), 1, float(spec.dnn_opt[1]) if spec.has_deep else 0.0, float(lr), float(l1),
              float(l2), ptr(self.bucket_cnt), ptr(self.bucket_start), ptr(self.occ_rank), ptr(self.pairs), self.n_buckets,
              self.bucket_shift, st)
 

@@ -110,7 +110,9 @@ int wd_embag_fwd_strided(const float *emb, int64_t row_stride, const wd_slot_t *
                          const int32_t *bag_offs, int64_t batch, float *x, int64_t ldx, wd_stream_t stream);
 
 /* Same result for a CONTIGUOUS slot range [slot0, slot0 + ngroup) (the engine orders the slots of one dim together):
- * no group_slots indirection, slot metadata staged in LDS, two bags per lane group.  dim in {4,8,16,32,64,128}. */
+ * no group_slots indirection, slot metadata staged in LDS, two bags per lane group.  dim in {4,8,16,32,64,128}.
+ * bag_offs == NULL declares a strictly one-id-per-bag batch (bag_offs would be 0,1,2,...): ids[bag] is read directly
+ * and the CSR offsets are never touched (one dependent memory round trip less). */
 int wd_embag_fwd_range(const float *emb, const wd_slot_t *slots, int32_t S, int32_t slot0, int32_t ngroup, int32_t dim,
                        const int32_t *ids, const int32_t *bag_offs, int64_t batch, float *x, int64_t ldx,
                        wd_stream_t stream);
@@ -274,7 +276,7 @@ int wd_mlp_finalize_all(const wd_mlp_layer_t *layers_dev, int32_t nlayers, int64
  * dnn_logit[b] = a[b, 0..K) . wf + sum(bf parts); logit = dnn_logit + wide_logit (may be NULL); sigmoid CE SUM into
  * loss_sum (+=), prob, dlogit = w*(p-y).  Backward of the logits layer in the same launch:
  *   out[b*ld_out + k] = dlogit[b]*wf[k]  (times act'(a[b,k]) when act != 0, i.e. out = dz of the last hidden layer),
- *   Gpart[blk*(K+1) + k] = sum over the block's 64 examples of a[b,k]*dlogit[b], [.. + K] = sum dlogit  (split-K
+ *   Gpart[blk*(K+1) + k] = sum over the block's examples of a[b,k]*dlogit[b], [.. + K] = sum dlogit  (split-K
  *   partials in wd_mlp_finalize's layout with nsplit = wd_logits_head_blocks(batch)).
  * labels NULL: forward only (predict); out / Gpart may be NULL. */
 int64_t wd_logits_head_blocks(int64_t batch);

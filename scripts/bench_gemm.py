@@ -12,6 +12,8 @@ B = int(os.environ.get("GEMM_B", "8192"))
 iters = int(os.environ.get("GEMM_ITERS", "50"))
 st = torch.cuda.current_stream().cuda_stream
 shapes = [(432, 256), (256, 128), (128, 64)]
+if os.environ.get("GEMM_SHAPES"):
+    shapes = [tuple(int(v) for v in t.split("x")) for t in os.environ["GEMM_SHAPES"].split(",")]
 if os.environ.get("GEMM_C5"):
     shapes = [(1680, 1024), (1024, 512), (512, 256), (256, 128)]
 

@@ -70,7 +70,7 @@ k_embag_fwd(const float *__restrict__ emb, const wd_slot_t *__restrict__ slots, 
 // [slot0, slot0 + ngroup)): no group_slots indirection, per-slot metadata staged once per workgroup in LDS while
 // the CSR offsets are already in flight, BPG bags per lane group so that every lane has BPG independent
 // offset -> id -> row chains outstanding.  Dependent global round trips per bag: offsets, ids, row (was 5).
-template <int LANES, int BPG>
+template <int LANES, int BPG, bool ONEHOT>
 __global__ void __launch_bounds__(256)
 k_embag_fwd_range(const float *__restrict__ emb, const wd_slot_t *__restrict__ slots, int32_t S, int32_t slot0,
                   int32_t ngroup, const int32_t *__restrict__ ids, const int32_t *__restrict__ bag_offs,
@@ -90,8 +90,13 @@ k_embag_fwd_range(const float *__restrict__ emb, const wd_slot_t *__restrict__ s
     b[q] = wc / ngroup;
     g[q] = (int32_t)(wc - b[q] * ngroup);
     const int64_t bag = b[q] * S + slot0 + g[q];
-    j0[q] = bag_offs[bag];
-    j1[q] = bag_offs[bag + 1];
+    if (ONEHOT) {
+      j0[q] = (int32_t)bag;
+      j1[q] = (int32_t)bag + 1;
+    } else {
+      j0[q] = bag_offs[bag];
+      j1[q] = bag_offs[bag + 1];
+    }
   }
   for (int i = t; i < ngroup; i += 256) {
     const wd_slot_t sl = slots[slot0 + i];
@@ -338,15 +343,22 @@ extern "C" int wd_embag_fwd_range(const float *emb, const wd_slot_t *slots, int3
                                   int32_t dim, const int32_t *ids, const int32_t *bag_offs, int64_t batch, float *x,
                                   int64_t ldx, wd_stream_t stream) {
   if (batch <= 0 || ngroup <= 0) return WD_OK;
-  WD_REQUIRE(emb && slots && ids && bag_offs && x, "null pointer");
+  WD_REQUIRE(emb && slots && ids && x, "null pointer");
   WD_REQUIRE(slot0 >= 0 && slot0 + ngroup <= S, "slot range out of bounds");
   WD_REQUIRE(ngroup <= 128, "at most 128 slots per dim group");
   const int64_t nwork = batch * ngroup;
   hipStream_t st = wd::as_stream(stream);
   constexpr int BPG = 2;
 #define WD_LAUNCH_RANGE(L)                                                                                           \
-  hipLaunchKernelGGL((k_embag_fwd_range<L, BPG>), dim3((unsigned)wd::ceil_div(wd::ceil_div(nwork, BPG) * L, 256)),   \
-                     dim3(256), 0, st, emb, slots, S, slot0, ngroup, ids, bag_offs, nwork, x, ldx)
+  do {                                                                                                               \
+    const dim3 grid((unsigned)wd::ceil_div(wd::ceil_div(nwork, BPG) * L, 256));                                      \
+    if (bag_offs)                                                                                                    \
+      hipLaunchKernelGGL((k_embag_fwd_range<L, BPG, false>), grid, dim3(256), 0, st, emb, slots, S, slot0, ngroup,   \
+                         ids, bag_offs, nwork, x, ldx);                                                              \
+    else                                                                                                             \
+      hipLaunchKernelGGL((k_embag_fwd_range<L, BPG, true>), grid, dim3(256), 0, st, emb, slots, S, slot0, ngroup,    \
+                         ids, bag_offs, nwork, x, ldx);                                                              \
+  } while (0)
   switch (dim) {
     case 4: WD_LAUNCH_RANGE(1); break;
     case 8: WD_LAUNCH_RANGE(2); break;

@@ -529,12 +529,13 @@ k_mlp_finalize_all(const wd_mlp_layer_t *__restrict__ layers, const float *__res
 
 // ---- logits layer + head, forward AND backward of that layer in one launch ------------------------
 // (python/lib/dnn.py:226-232 logits dense(units=1); python/lib/joint.py:216-222 add_n; head joint.py:264-269.)
-// Block `blk` owns examples [blk*64, blk*64+64):
+// Block `blk` owns HEAD_CHUNK examples:
 //   phase 1 (wave per example): dnn_logit = a[b, window] . wf + bias; logit = dnn + wide; CE loss, p, dlogit
 //   phase 2 (lane per input column k): gradient wrt the window  out[b,k] = dlogit[b]*wf[k] (* act'(a[b,k]) when
 //           `act` != 0: simple mode, `out` is then dz of the last hidden layer), and this block's partial of the
 //           kernel gradient  Gpart[blk][k] = sum_b a[b,k]*dlogit[b],  Gpart[blk][K] = sum_b dlogit[b]  (fixed order).
-constexpr int HEAD_CHUNK = 64;
+constexpr int HEAD_CHUNK = 64;            // examples per workgroup
+constexpr int HEAD_LPE = 256 / HEAD_CHUNK;  // lanes per example in phase 1
 __global__ void __launch_bounds__(256)
 k_logits_head(const float *__restrict__ a, int64_t ld_a, int64_t K, const float *__restrict__ wf,
               const float *__restrict__ bf, int32_t bias_parts, const float *__restrict__ wide_logit,
@@ -547,18 +548,18 @@ k_logits_head(const float *__restrict__ a, int64_t ld_a, int64_t K, const float 
   const int64_t b0 = (int64_t)blockIdx.x * HEAD_CHUNK;
   float bias = 0.f;
   for (int p = 0; p < bias_parts; ++p) bias += bf[p];
-  // phase 1: 4 lanes per example (k = part, part+4, ...), the block's 64 examples in parallel
-  const int ex = threadIdx.x >> 2, part = threadIdx.x & 3;
+  // phase 1: HEAD_LPE lanes per example (k = part, part + HEAD_LPE, ...), the block's examples in parallel
+  const int ex = threadIdx.x / HEAD_LPE, part = threadIdx.x % HEAD_LPE;
   const int64_t b = b0 + ex;
   const bool live = b < batch;
   float d = 0.f;
   if (live) {
     const float *ar = a + b * ld_a;
 #pragma unroll 4
-    for (int64_t k = part; k < K; k += 4) d += ar[k] * wf[k];
+    for (int64_t k = part; k < K; k += HEAD_LPE) d += ar[k] * wf[k];
   }
-  d += __shfl_xor(d, 1, 64);
-  d += __shfl_xor(d, 2, 64);
+#pragma unroll
+  for (int off = 1; off < HEAD_LPE; off <<= 1) d += __shfl_xor(d, off, 64);
   float lsum = 0.f, dl = 0.f;
   if (live && part == 0) {
     const float dn = d + bias;

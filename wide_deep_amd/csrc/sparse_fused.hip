@@ -31,6 +31,7 @@ constexpr int MAX_LONG = 128;   // long-segment list per bucket
 constexpr int MAX_NB = 8192;    // buckets (LDS scan array of K2)
 
 constexpr int RANK_MAX = 512;   // buckets up to this size are rank-sorted (O(m^2 / 256) per lane, 2 barriers)
+constexpr int MAX_SLOTS_LDS = 96;  // slot descriptors cached in LDS by k_bucket_update (more slots: read from HBM)
 constexpr int MAX_CHUNKS = 128; // workgroups of K1 / K2 (rows of the count matrix)
 
 // chunk c = bags [c*bags_per_chunk, (c+1)*bags_per_chunk)
@@ -199,6 +200,7 @@ k_bucket_update(UpdArgs u, const int32_t *__restrict__ start, uint64_t *__restri
   __shared__ float redw[256];
   __shared__ int long_i0[MAX_LONG], long_i1[MAX_LONG];
   __shared__ int nlong;
+  __shared__ wd_slot_t lds_slots[MAX_SLOTS_LDS];   // slot descriptors staged once per workgroup
   const int t = threadIdx.x;
 
   if ((int)blockIdx.x == u.nb) {  // bias_weights: g = sum_b dlogit[b] (fixed-shape tree), dense FTRL
@@ -223,6 +225,8 @@ k_bucket_update(UpdArgs u, const int32_t *__restrict__ start, uint64_t *__restri
   const int m = start[blockIdx.x + 1] - s0;
   if (t == 0) nlong = 0;
   if (m == 0) return;
+  const bool slots_in_lds = u.S <= MAX_SLOTS_LDS;
+  if (slots_in_lds && t < u.S) lds_slots[t] = u.slots[t];   // overlaps with the pair loads below
   const uint64_t *sp;  // sorted pairs (flat pointer: LDS or global)
   if (m <= RANK_MAX) {
     // rank sort: position of element i = number of elements ordered before it (ties by index); every lane reads
@@ -281,10 +285,46 @@ k_bucket_update(UpdArgs u, const int32_t *__restrict__ start, uint64_t *__restri
       while (e < m && (uint32_t)(sp[e] >> 32) == key) ++e;
     }
     const int32_t bag0 = (int32_t)(uint32_t)sp[i];
-    const wd_slot_t sl = u.slots[bag0 % S];
+    const int32_t sidx = bag0 % S;
+    const wd_slot_t sl = slots_in_lds ? lds_slots[sidx] : u.slots[sidx];
     const bool do_emb = u.emb && sl.kind == WD_SLOT_EMBEDDING && (int64_t)key - sl.row_base < sl.num_buckets;
     const bool do_wide = u.wide && sl.wide;
     const int D = sl.dim;
+    if (e - i == 1 && (D & 3) == 0 && D <= 16) {
+      // the common case (a row hit once, dim <= 16): ONE round of independent loads -- bag length, dx, accumulator,
+      // row, dlogit and the wide {w,z,n} line are all addressed from (key, bag) alone
+      const int64_t b = bag0 / S;
+      const int32_t o0 = u.bag_offs[bag0], o1 = u.bag_offs[bag0 + 1];
+      const bool lane_emb = do_emb && gl < (D >> 2);
+      const int64_t off = sl.emb_off + ((int64_t)key - sl.row_base) * D + 4 * gl;
+      float4 d = make_float4(0.f, 0.f, 0.f, 0.f), a = d, w = d, r = d;
+      float dl = 0.f;
+      if (lane_emb) {
+        d = *reinterpret_cast<const float4 *>(u.dx + b * u.ldx + sl.out_col + 4 * gl);
+        a = *reinterpret_cast<float4 *>(u.accum + off);
+        w = *reinterpret_cast<float4 *>(u.emb + off);
+      }
+      if (do_wide && gl == 0) {
+        dl = u.dlogit[b * u.ld_dlogit];
+        r = *reinterpret_cast<float4 *>(u.wide + (int64_t)key * 4);
+      }
+      if (lane_emb) {
+        const int32_t len = o1 - o0;
+        const float scale = len > 1 ? 1.0f / (float)len : 1.0f;
+        float4 g = make_float4(0.f, 0.f, 0.f, 0.f);   // 0 + d*scale: same rounding as the general loop
+        g.x += d.x * scale; g.y += d.y * scale; g.z += d.z * scale; g.w += d.w * scale;
+        const float4 wn = adagrad4(a, w, g, u.lr_emb);
+        *reinterpret_cast<float4 *>(u.accum + off) = a;
+        *reinterpret_cast<float4 *>(u.emb + off) = wn;
+      }
+      if (do_wide && gl == 0) {
+        float g = 0.f;
+        g += dl;
+        ftrl_update(r.x, r.y, r.z, g, u.lr_w, u.l1, u.l2);
+        *reinterpret_cast<float4 *>(u.wide + (int64_t)key * 4) = r;
+      }
+      continue;
+    }
     if (do_emb && (D & 3) == 0) {
       const int64_t off = sl.emb_off + ((int64_t)key - sl.row_base) * D;
       for (int c = gl; c < (D >> 2); c += 4) {
@@ -331,7 +371,8 @@ k_bucket_update(UpdArgs u, const int32_t *__restrict__ start, uint64_t *__restri
   for (int q = 0; q < nl; ++q) {
     const int i = long_i0[q], e = long_i1[q];
     const uint32_t key = (uint32_t)(sp[i] >> 32);
-    const wd_slot_t sl = u.slots[(int32_t)(uint32_t)sp[i] % S];
+    const int32_t sidx = (int32_t)(uint32_t)sp[i] % S;
+    const wd_slot_t sl = slots_in_lds ? lds_slots[sidx] : u.slots[sidx];
     const bool do_emb = u.emb && sl.kind == WD_SLOT_EMBEDDING && (int64_t)key - sl.row_base < sl.num_buckets;
     const bool do_wide = u.wide && sl.wide;
     const int D = sl.dim;

@@ -23,7 +23,8 @@ from .plan import BN_EPS, FeaturePlan, ModelSpec
 class DeviceBatch:
     """One batch, resident in HBM, in the example-major bag-CSR layout (include/wd_hip.h)."""
 
-    def __init__(self, B, ids, bag_offs, dense=None, labels=None, weights=None, nnz=None):
+    def __init__(self, B, ids, bag_offs, dense=None, labels=None, weights=None, nnz=None, one_hot=False):
+        self.one_hot = bool(one_hot)   # every bag holds exactly one id (bag_offs == 0,1,2,...): kernels may skip the CSR
         self.B = int(B)
         self.ids = ids              # int32 [nnz]
         self.bag_offs = bag_offs    # int32 [B*S + 1]
@@ -252,7 +253,7 @@ class WideDeepEngine:
         contiguous = sl == list(range(sl[0], sl[0] + len(sl)))
         if contiguous and dim in (4, 8, 16, 32, 64, 128) and len(sl) <= 128:
             call("wd_embag_fwd_range", ptr(self.emb), ptr(self.slots_dev), plan.S, sl[0], len(sl), dim, ptr(bt.ids),
-                 ptr(bt.bag_offs), bt.B, xp, ld, st)
+                 None if bt.one_hot else ptr(bt.bag_offs), bt.B, xp, ld, st)
         else:
             call("wd_embag_fwd", ptr(self.emb), ptr(self.slots_dev), plan.S, ptr(gs), gs.numel(), dim, ptr(bt.ids),
                  ptr(bt.bag_offs), bt.B, xp, ld, st)

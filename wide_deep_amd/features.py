@@ -200,6 +200,6 @@ class Featurizer(object):
             dense = self._dev(np.stack([raw.floats[d.feature] for d in plan.dense_cols], axis=1).astype(np.float32), torch.float32)
         labels = self._dev(raw.labels, torch.float32) if raw.labels is not None else None
         weights = self._dev(raw.weights, torch.float32) if (raw.weights is not None and self.engine.spec.use_weight_column) else None
-        bt = DeviceBatch(B, ids, d_bag, dense, labels, weights, nnz=nnz)
+        bt = DeviceBatch(B, ids, d_bag, dense, labels, weights, nnz=nnz, one_hot=bool((lens_bs == 1).all()))
         bt._keep = keep_alive   # the emission kernels are asynchronous
         return bt

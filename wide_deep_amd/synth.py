@@ -69,7 +69,8 @@ def to_device_ids(plan, hb, device="cuda", weights=None):
     offs = offsets_from_lens(lens)
     t = lambda a, dt: torch.as_tensor(a, dtype=dt).to(device) if a is not None else None
     return DeviceBatch(hb["B"], t(ids, torch.int32), t(offs, torch.int32), t(hb["dense"], torch.float32),
-                       t(hb["labels"], torch.float32), t(weights, torch.float32), nnz=len(ids))
+                       t(hb["labels"], torch.float32), t(weights, torch.float32), nnz=len(ids),
+                       one_hot=bool((lens == 1).all()))
 
 
 def pack_decimal_tokens(raw):
@@ -98,7 +99,7 @@ class TokenBatch:
         t = lambda a: torch.as_tensor(a, dtype=torch.float32).to(device) if a is not None else None
         self.ids = torch.zeros(max(self.ntok, 1), dtype=torch.int32, device=device)
         self.batch = DeviceBatch(self.B, self.ids, self.bag_offs, t(hb["dense"]), t(hb["labels"]), t(weights),
-                                 nnz=self.ntok)
+                                 nnz=self.ntok, one_hot=self.one_per_bag)
 
 
 def hash_tokens(engine, tb: TokenBatch):

@@ -66,8 +66,13 @@ def event_time_ms(fn, iters):
 
 
 def gather_roofline(eng, batches, iters=200):
-    """Embedding-gather kernel (wd_embag_fwd): algorithmic bytes / measured duration."""
-    from wide_deep_amd.capi import call, ptr
+    """Embedding-gather kernel: algorithmic bytes / measured duration (HIP events on the launch stream).
+
+    `traffic` = HBM bytes per launch from the rocprofv3 PMC passes of scripts/gpu_gather.sh (separate FETCH_SIZE and
+    WRITE_SIZE runs of the same kernel on the same workload, committed under profiles/): FETCH_SIZE is kept RAW for
+    the 64-byte row requests (it matches the algorithmic read bytes; the gfx950 x2 correction of the guide applies to
+    128-byte streaming requests, which the calibration copy in the same run confirms) -- see profiles/README.md.
+    `ceilings` are measured on the same part (scripts/bench_ceilings.py): float4 copy and random 64-byte row reads."""
     plan = eng.plan
     tw0 = eng.towers[0]
     ld = tw0["layout"].ld
@@ -87,9 +92,26 @@ def gather_roofline(eng, batches, iters=200):
     # nnz*D*4 (row reads) + nnz*4 (ids) + (B*S+1)*4 (offsets) + B*S*D*4 (pooled write)
     alg = bt.nnz * dim * 4 + bt.nnz * 4 + (bt.B * plan.S + 1) * 4 + nbag * dim * 4
     gbs = alg / (ms * 1e-3) / 1e9
-    return {"bound": "hbm", "kernel": "k_embag_fwd_range<%d, 2>" % (dim // 4), "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
-            "algorithmic_bytes_per_launch": int(alg), "avg_launch_us": round(ms * 1e3, 2)}
+    traffic, src = None, None
+    pmc = os.path.join(ROOT, "profiles", "gather_pmc_summary.json")
+    if os.path.exists(pmc):
+        try:
+            d = json.load(open(pmc))
+            raw = (d["FETCH_SIZE"]["gather"]["mean"] + d["WRITE_SIZE"]["gather"]["mean"]) * 1024
+            # gfx950 correction (MI355X_MICROARCH.md, HBM): 128-byte streaming read requests are tallied at 64 B ->
+            # the id / offset streams count half; the 64-byte row requests count in full (calibrated: raw FETCH_SIZE
+            # = rows + half of the streams to 1.4 %, and the 256 MiB copy in the same pass reads back exactly 1/2)
+            traffic = int(raw + 0.5 * (bt.nnz * 4 + (bt.B * plan.S + 1) * 4))
+            src = ("profiles/gather_pmc_summary.json: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes, KiB per "
+                   "launch; raw sum %d B + half of the streamed id/offset bytes" % int(raw))
+        except Exception:
+            traffic = None
+    return {"bound": "hbm", "kernel": "k_embag_fwd_range<%d, 2, %s>" % (dim // 4, "true" if bt.one_hot else "false"),
+            "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": src,
+            "algorithmic_bytes_per_launch": int(alg), "avg_launch_us": round(ms * 1e3, 2),
+            "ceilings_GBps": {"float4_copy": 5386, "random_64B_rows_16M": 3459, "random_64B_rows_at_batch_size": 2076,
+                              "source": "profiles/r1i_ceilings.txt"}}
 
 
 def cpu_baseline(eng, host_batches, steps, B):

@@ -1,0 +1,107 @@
+"""GPU parity on the BASELINE configs[3] SHAPE (C4) at test size, through the whole drop-in path with a generated conf
+directory: multi-hot hash slots (avg ~3 ids), 200-bucket crossed columns over 2 and 3 slots (one wide-only), ResDnn
+(`resnet`) tower, weight column on (pos 0.99 / neg 0.01), continuous features with every normalizer.
+dataset.input_fn -> Featurizer -> WideDeepEngine vs oracle/columns.py -> OracleWideDeep, both cross paddings."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import yaml
+
+pytestmark = pytest.mark.gpu
+
+
+def _make_conf(d, mode="resnet", hidden=(32, 16)):
+    feats = ["c%d" % i for i in range(6)]
+    nums = ["x0", "x1", "x2"]
+    schema = {1: "clk"}
+    for i, f in enumerate(feats + nums + ["idn", "unused"]):
+        schema[i + 2] = f
+    feature = {}
+    for i, f in enumerate(feats):
+        feature[f] = {"type": "category", "transform": "hash_bucket", "parameter": [1000, 1000, 500, 20000, 100, 1000][i]}
+    feature["x0"] = {"type": "continuous", "transform": "min_max", "parameter": {"normalization": [0, 10], "boundaries": [2, 4, 6]}}
+    feature["x1"] = {"type": "continuous", "transform": "standard", "parameter": {"normalization": [1.5, 2.0], "boundaries": None}}
+    feature["x2"] = {"type": "continuous", "transform": None, "parameter": {"normalization": None, "boundaries": None}}
+    feature["idn"] = {"type": "category", "transform": "identity", "parameter": 7}
+    cross = {"c0&c1": {"hash_bucket_size": 0.2, "is_deep": 1},
+             "c2&c3&c4": {"hash_bucket_size": 0.2, "is_deep": 1},
+             "x0&idn&c5": {"hash_bucket_size": 0.2, "is_deep": 0}}
+    model = {"linear_optimizer": "tf.train.FtrlOptimizer(learning_rate=0.1,l1_regularization_strength=0.5,l2_regularization_strength=1)",
+             "linear_initial_learning_rate": 0.05, "linear_decay_rate": 0.8, "dnn_hidden_units": list(hidden),
+             "dnn_connected_mode": mode, "dnn_optimizer": "Adagrad", "dnn_initial_learning_rate": 0.05, "dnn_decay_rate": 0.8,
+             "dnn_activation_function": "relu", "dnn_l1": 0.1, "dnn_l2": 0.1, "dnn_dropout": None,
+             "dnn_batch_normalization": 1, "cnn_use_flag": 0, "cnn_optimizer": "Adagrad"}
+    train = {"train": {"model_dir": "model", "model_type": "wide_deep", "train_data": "x", "eval_data": "x", "test_data": "x",
+                       "image_train_data": None, "image_eval_data": None, "image_test_data": None, "dynamic_train": False,
+                       "train_epochs": 1, "epochs_per_eval": 1, "batch_size": 64, "keep_train": 0, "checkpoint_path": None,
+                       "pos_sample_loss_weight": 0.99, "neg_sample_loss_weight": 0.01, "multivalue": 1,
+                       "num_examples": 100, "num_parallel_calls": None},
+             "distribution": {"is_distribution": 0, "cluster": {"ps": [], "chief": [], "worker": []}, "job_name": "ps", "task_index": 0},
+             "runconfig": {"tf_random_seed": 1, "save_checkpoints_secs": None, "keep_checkpoint_max": 2, "log_step_count_steps": 0}}
+    os.makedirs(d, exist_ok=True)
+    for name, obj in (("schema", schema), ("feature", feature), ("cross_feature", cross), ("model", model), ("train", train)):
+        with open(os.path.join(d, name + ".yaml"), "w") as f:
+            yaml.safe_dump(obj, f, sort_keys=False)
+    return feats
+
+
+def _make_rows(n, seed):
+    rng = np.random.default_rng(seed)
+    lines = []
+    for _ in range(n):
+        parts = [b"1" if rng.random() < 0.3 else b"0"]
+        for i in range(6):
+            k = int(np.clip(1 + rng.poisson(2.0), 1, 8)) if rng.random() > 0.05 else 0
+            toks = [("t%d_%d" % (i, int(rng.integers(0, 40)))).encode() for _ in range(k)]
+            parts.append(b",".join(toks) if toks else b"-")
+        parts.append(("%.3f" % (rng.random() * 10)).encode())
+        parts.append(("%.3f" % rng.normal()).encode())
+        parts.append(("%.3f" % rng.normal()).encode() if rng.random() > 0.1 else b"-")
+        parts.append(str(int(rng.integers(-1, 9))).encode())
+        parts.append(b"junk")
+        lines.append(b"\t".join(parts))
+    return lines
+
+
+@pytest.mark.parametrize("padding,mode", [("ragged", "resnet"), ("tf_dense", "resnet"), ("ragged", "dense")])
+def test_c4_shape_through_conf_path_matches_oracle(tmp_path, monkeypatch, padding, mode):
+    from oracle import columns as OC
+    from tests.helpers import assert_close, oracle_from_engine, slot_csr
+    from wide_deep_amd import build_estimator as BE, dataset as DS
+    from wide_deep_amd.engine import WideDeepEngine
+    from wide_deep_amd.features import Featurizer
+    from wide_deep_amd.read_conf import Config
+    cdir = str(tmp_path / "conf")
+    _make_conf(cdir, mode=mode)
+    monkeypatch.setenv("WD_CONF_DIR", cdir)
+    lines = _make_rows(3 * 64, seed=5)
+    path = tmp_path / "rows.tsv"
+    path.write_bytes(b"\n".join(lines) + b"\n")
+    conf = Config()
+    spec = BE.build_model_spec(conf, "wide_deep")
+    assert spec.use_weight_column and spec.towers[0].mode == mode
+    assert sorted(s.num_buckets for s in spec.slots if s.kind == "cross") == [200, 200, 200]
+    eng = WideDeepEngine(spec, max_batch=64, max_nnz=64 * 12 * 64, seed=3)
+    fz = Featurizer(eng, cross_padding=padding)
+    oc = OC.Columns(cdir)
+    ora = oracle_from_engine(eng)
+    ora.dnn_opt, ora.lin_opt = oc.optimizers()
+    k = 0
+    for step, raw in enumerate(DS.input_fn(str(path), None, "eval", 64, conf=conf)):
+        assert raw.weights is not None
+        bt = fz.to_device(raw)
+        ob = oc.transform(oc.parse(lines[k:k + raw.B]), cross_padding=padding)
+        k += raw.B
+        torch.cuda.synchronize()
+        got = slot_csr(eng.plan, bt.ids.cpu().numpy(), bt.bag_offs.cpu().numpy(), raw.B)
+        for name, (eids, eoffs) in ob["ids"].items():
+            assert np.array_equal(got[name][1], eoffs), name
+            assert np.array_equal(got[name][0], np.asarray(eids, dtype=np.int64)), name     # bit-exact ids
+        loss = float(eng.train_step(bt))
+        torch.cuda.synchronize()
+        oloss, ologits = ora.train_step(ob)
+        assert_close(eng.logit[: raw.B], ologits, 2e-4, 2e-5, "logits step %d" % step)
+        assert abs(loss - oloss) <= 2e-4 * max(1.0, abs(oloss)), (step, loss, oloss)
+    assert k == len(lines)

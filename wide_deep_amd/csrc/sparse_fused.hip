@@ -58,7 +58,7 @@ k_bucket_hist(const wd_slot_t *__restrict__ slots, int32_t S, const int32_t *__r
   for (int i = threadIdx.x; i < nb; i += 256) row[i] = hist[i];
 }
 
-// thread per bucket: cpre[c][b] = sum_{c' < c} cntm[c'][b];  total[b] = column sum.  Out of place and 8 loads
+// thread per bucket: cpre[c][b] = sum_{c' < c} cntm[c'][b];  total[b] = column sum.  Out of place and 32 loads
 // deep: the in-place version was one dependent L2 round trip per chunk (30 us for 104 chunks).
 __global__ void __launch_bounds__(256)
 k_bucket_colscan(const int32_t *__restrict__ cntm, int32_t *__restrict__ cpre, int32_t nchunks, int32_t nb,
@@ -66,12 +66,13 @@ k_bucket_colscan(const int32_t *__restrict__ cntm, int32_t *__restrict__ cpre, i
   const int b = blockIdx.x * 256 + threadIdx.x;
   if (b >= nb) return;
   int32_t run = 0;
-  for (int c0 = 0; c0 < nchunks; c0 += 8) {
-    int32_t v[8];
+  constexpr int DEPTH = 32;   // loads in flight per lane
+  for (int c0 = 0; c0 < nchunks; c0 += DEPTH) {
+    int32_t v[DEPTH];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) v[q] = c0 + q < nchunks ? cntm[(int64_t)(c0 + q) * nb + b] : 0;
+    for (int q = 0; q < DEPTH; ++q) v[q] = c0 + q < nchunks ? cntm[(int64_t)(c0 + q) * nb + b] : 0;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
+    for (int q = 0; q < DEPTH; ++q) {
       if (c0 + q < nchunks) cpre[(int64_t)(c0 + q) * nb + b] = run;
       run += v[q];
     }

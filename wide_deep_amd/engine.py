@@ -11,6 +11,7 @@ raises.
 """
 import ctypes
 import math
+import os
 
 import numpy as np
 import torch
@@ -203,7 +204,7 @@ class WideDeepEngine:
         # bucket geometry of the fused sparse backward (wd_sparse_bwd_fused): ~64 occurrences per bucket
         exp_nnz = int(expected_nnz) if expected_nnz else self.max_batch * max(plan.S, 1)
         nb_max = int(call("wd_bucket_max"))
-        target = min(max(64, 1 << max(0, math.ceil(math.log2(max(exp_nnz, 1) / 64.0)))), nb_max)
+        target = min(max(64, 1 << max(0, math.ceil(math.log2(max(exp_nnz, 1) / float(os.environ.get("WD_BUCKET_TARGET", "64")))))), nb_max)
         rows = max(plan.total_rows, 1)
         self.bucket_shift = max(0, math.ceil(math.log2(rows / target))) if rows > target else 0
         self.n_buckets = (rows + (1 << self.bucket_shift) - 1) >> self.bucket_shift

@@ -132,6 +132,16 @@ typedef struct wd_dense_col {
 int wd_dense_fwd(const float *dense, int64_t ld_dense, const wd_dense_col_t *cols, int32_t ncols, int64_t batch,
                  float *x, int64_t ldx, wd_stream_t stream);
 
+/* The sparse forward of a step in ONE launch: wd_embag_fwd_range (one dim group) + wd_wide_fwd (wide may be NULL;
+ * AoS table, stride 4) + wd_dense_fwd (ncols may be 0) share a grid -- they are independent, and every kernel boundary
+ * on this part costs a cold L2.  bag_offs is always required (the wide part walks the CSR); one_id_per_bag != 0
+ * additionally lets the gather skip it. */
+int wd_input_layer_fwd(const float *emb, const wd_slot_t *slots, int32_t S, int32_t slot0, int32_t ngroup, int32_t dim,
+                       const int32_t *ids, const int32_t *bag_offs, int32_t one_id_per_bag, int64_t batch, float *x,
+                       int64_t ldx, const float *dense, int64_t ld_dense, const wd_dense_col_t *dense_cols, int32_t ncols,
+                       const float *wide, const float *bias, float *wide_out, wd_stream_t stream);
+
+
 /* ---- a7: tf.feature_column.linear_model(sparse_combiner='sum') (python/lib/linear.py:29-36) --
  * wide state is array-of-structs: wide[row*4 + {0,1,2}] = {w, z (Ftrl_1 "linear"), n (Ftrl "accum")}.
  * out[b] = bias[0] + sum over wide slots s, ids in bag(b,s) of wide[(row_base_s + id) * wide_stride]

@@ -70,6 +70,7 @@ _PROTOS = {
     "wd_cross_hash": [ctypes.POINTER(WdCrossKeys), I64, U64, U64, P, I32, I32, P, P],
     "wd_embag_fwd": [P, P, I32, P, I32, I32, P, P, I64, P, I64, P],
     "wd_embag_fwd_range": [P, P, I32, I32, I32, I32, P, P, I64, P, I64, P],
+    "wd_input_layer_fwd": [P, P, I32, I32, I32, I32, P, P, I32, I64, P, I64, P, I64, P, I32, P, P, P, P],
     "wd_indicator_fwd": [P, I32, P, I32, P, P, I64, P, I64, P],
     "wd_dense_fwd": [P, I64, P, I32, I64, P, I64, P],
     "wd_wide_fwd": [P, I32, P, P, I32, P, P, I64, P, P],

@@ -214,6 +214,13 @@ class WideDeepEngine:
         self.occ_rank = torch.zeros(M, **i32)
         self.pairs = torch.zeros(M, dtype=torch.int64, device=dev)
         self._graph = None
+        # sparse forward in one launch when the model has exactly one embedding dim group on a contiguous slot range
+        # and no indicator columns (all Criteo-shaped configs); otherwise one launch per piece
+        self._fused_input_layer = False
+        if spec.has_deep and len(plan.emb_groups) == 1 and not plan.ind_slots:
+            (gdim, gsl), = plan.emb_groups.items()
+            self._fused_input_layer = (gsl == list(range(gsl[0], gsl[0] + len(gsl))) and gdim in (4, 8, 16, 32, 64, 128)
+                                       and len(gsl) <= 128)
 
     # ------------------------------------------------------------------------------------------
     # forward
@@ -231,6 +238,17 @@ class WideDeepEngine:
         """Input layer (embedding bags, indicators, numeric columns) into tower 0's x, and the wide logit."""
         plan, spec = self.plan, self.spec
         B, S = bt.B, plan.S
+        if spec.has_deep and self._fused_input_layer:
+            # one launch: embedding bags + wide sum + numeric columns
+            tw0 = self.towers[0]
+            (dim, sl), = plan.emb_groups.items()
+            nd = len(plan.dense_cols)
+            call("wd_input_layer_fwd", ptr(self.emb), ptr(self.slots_dev), S, sl[0], len(sl), dim, ptr(bt.ids),
+                 ptr(bt.bag_offs), 1 if bt.one_hot else 0, B, self._x_ptr(tw0), tw0["layout"].ld,
+                 ptr(bt.dense) if nd else None, bt.dense.stride(0) if nd else 0, ptr(self.dense_cols_dev) if nd else None, nd,
+                 ptr(self.wide) if spec.has_wide else None, ptr(self.bias) if spec.has_wide else None,
+                 ptr(self.wide_logit) if spec.has_wide else None, st)
+            return
         if spec.has_deep:
             tw0 = self.towers[0]
             ld = tw0["layout"].ld

@@ -222,7 +222,10 @@ class FeaturePlan:
         for d in self.dense_cols:
             self.dense_out_col.append(c)
             c += 1
-        self.deep_dim = c          # internal width (may contain alignment holes, see tf_input_perm)
+        # internal width (may contain alignment holes, see tf_input_perm).  Wide inputs are padded to a multiple of the
+        # GEMM reduction slab (64): the pad columns stay zero, their weight rows stay zero (zero gradient), and the
+        # first layer then runs on full slabs only (a ragged last slab costs ~3 us per GEMM at C2, three per step)
+        self.deep_dim = _round_up(c, 64) if c > 128 else c
         self.emb_groups = {}
         for i, s in enumerate(self.slots):
             if s.deep == "embedding" and spec.has_deep:

@@ -34,7 +34,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=8192, help="examples per GPU per step")
-    ap.add_argument("--config", default="c2", choices=["c2", "c4"])
+    ap.add_argument("--config", default="c2", choices=["c2", "c3", "c4", "c5"])
     ap.add_argument("--dist", default="uniform", choices=["uniform", "zipf"])
     ap.add_argument("--pool", type=int, default=32, help="distinct resident batches cycled through")
     ap.add_argument("--no-graph", action="store_true", help="launch kernels eagerly instead of hipGraph replay")
@@ -49,6 +49,16 @@ def make_spec(cfg):
     if cfg == "c2":
         # BASELINE.json configs[1]: 13 dense + 26 sparse slots, 1M buckets, emb 16, Dnn [256,128,64]
         return criteo_spec(n_dense=13, n_sparse=26, buckets=1_000_000, dim=16, hidden=(256, 128, 64), mode="simple"), 1
+    if cfg == "c3":
+        # BASELINE.json configs[2] table: ONE logical 100M-row table (26 slots x 3,846,154 rows), C2 otherwise.  With
+        # --gpus N it is row-sharded over the ranks; with one GPU all 100M rows (6.4 GB + 6.4 GB Adagrad + 1.6 GB
+        # wide) are resident in its 288 GB
+        return criteo_spec(n_dense=13, n_sparse=26, buckets=3_846_154, dim=16, hidden=(256, 128, 64), mode="simple"), 1
+    if cfg == "c5":
+        # BASELINE.json configs[4] SHAPE in fp32: deep-only DenseDnn [1024,512,256,128], emb_dim 64 (the fp16-input
+        # MFMA tower of that config is not built yet; this runs the exact-fp32 MFMA tower)
+        return criteo_spec(n_dense=13, n_sparse=26, buckets=1_000_000, dim=64, hidden=(1024, 512, 256, 128),
+                           mode="dense", model_type="deep"), 1
     # configs[3] shape on one GPU: multi-hot (avg 5 ids/slot), ResDnn, weight column
     return criteo_spec(n_dense=13, n_sparse=26, buckets=1_000_000, dim=16, hidden=(256, 128, 64), mode="resnet",
                        use_weight_column=True), 5
@@ -269,10 +279,15 @@ def main():
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {
-            "workload": "BASELINE configs[1] (C2): Criteo-shape synthetic, 13 dense + 26 sparse slots x 1M hash buckets, "
-                        "emb_dim 16, Dnn [256,128,64] BN+ReLU, wide FTRL + deep Adagrad, batch %d per GPU" % B
-            if args.config == "c2" else
-            "BASELINE configs[3] shape (C4) on %d GPU(s): multi-hot avg %d ids/slot, ResDnn, weight column" % (world, mean_len),
+            "workload": {
+                "c2": "BASELINE configs[1] (C2): Criteo-shape synthetic, 13 dense + 26 sparse slots x 1M hash buckets, "
+                      "emb_dim 16, Dnn [256,128,64] BN+ReLU, wide FTRL + deep Adagrad, batch %d per GPU" % B,
+                "c3": "BASELINE configs[2] (C3) table: C2 with ONE 100M-row table (26 x 3,846,154 rows) on %d GPU(s), "
+                      "batch %d per GPU" % (world, B),
+                "c4": "BASELINE configs[3] shape (C4) on %d GPU(s): multi-hot avg %d ids/slot, ResDnn, weight column"
+                      % (world, mean_len),
+                "c5": "BASELINE configs[4] shape (C5) in fp32: deep-only DenseDnn [1024,512,256,128], emb_dim 64, batch %d" % B,
+            }[args.config],
             "global_batch": B * world, "ids": args.dist, "input": "pre-hashed ids" if args.ids_input else "raw string tokens (hashed in step)",
             "hip_graph": bool(use_graph), "parallelism": "dp%d+row-sharded tables" % world if world > 1 else "single GPU",
             "final_loss_sum": round(loss, 3),

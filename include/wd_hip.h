@@ -270,6 +270,9 @@ typedef struct wd_mlp_layer {
   const float *Gpart;       /* split-K partials of this layer (as wd_mlp_finalize) */
   int32_t nsplit;
   int32_t pad_;
+  uint16_t *Wf_h;           /* optional IEEE-half copies of the folded kernel for the fp16-input tower: */
+  uint16_t *WfT_h;          /*   Wf_h [K][ld_wf_h] and its transpose WfT_h [N][ld_wft_h]; NULL: not written */
+  int64_t ld_wf_h, ld_wft_h;
 } wd_mlp_layer_t;
 
 /* wd_fold_affine for every layer of every tower in ONE launch; also zero-fills up to two small buffers
@@ -294,6 +297,34 @@ int wd_logits_head(const float *a, int64_t ld_a, int64_t K, const float *wf, con
                    const float *wide_logit, const float *labels, const float *weights, int64_t batch,
                    float *dnn_logit, float *logit, float *prob, float *dlogit, float *loss_sum, float *out,
                    int64_t ld_out, int32_t act, float *Gpart, wd_stream_t stream);
+
+/* ---- fp16-input MFMA tower (BASELINE configs[4]; csrc/mlp_half.hip).  wd_half_t = IEEE binary16 bit pattern.
+ * Operands are half, reduction-contiguous; accumulation, bias, split-K partials and gradient accumulators are fp32.
+ *   wd_hgemm_nn:  C = act(A WT^T + bias) written as half C [M][ldc] AND transposed CT [N][ldct] (CT may be NULL)
+ *                 A [M][lda] (k contiguous), WT [N][ldw] (k contiguous) = WfT_h of wd_fold_affine_all
+ *   wd_hgemm_nt:  X = dZ W^T with dZ [M][lddz] (n contiguous), W [N=K_l rows][ldw] = Wf_h; either
+ *                 C32 != NULL: C32[m][n] (+)= X (fp32 gradient accumulator), or
+ *                 C32 == NULL: Ch / CT = half(X * act'(act_src)) and its transpose (dz of the producing layer)
+ *   wd_hgemm_tn_splitk: Gpart[z][(K+1)][N] = [AT ; 1] dZT^T over batch slices; AT [K][ldat], dZT [N][lddzt] (batch
+ *                 contiguous); row K = column sums of dZ (bias gradient), as wd_gemm_tn_splitk
+ *   wd_cast_transpose_h: dst[r][c] = half(src[r][c] * (act_h ? act'(act_h[r][c]) : 1)) and dstT[c][r] (either NULL)
+ *   wd_logits_head_h: wd_logits_head with a half activation window */
+typedef uint16_t wd_half_t;
+int wd_hgemm_nn(const wd_half_t *A, int64_t lda, const wd_half_t *WT, int64_t ldw, const float *bias, int32_t bias_parts,
+                int32_t act, wd_half_t *C, int64_t ldc, wd_half_t *CT, int64_t ldct, int64_t M, int64_t N, int64_t K,
+                wd_stream_t stream);
+int wd_hgemm_nt(const wd_half_t *dZ, int64_t lddz, const wd_half_t *W, int64_t ldw, int64_t M, int64_t N, int64_t K,
+                float *C32, int64_t ldc32, int32_t accumulate, wd_half_t *Ch, int64_t ldch, wd_half_t *CT, int64_t ldct,
+                const wd_half_t *act_src, int64_t ld_act, int32_t act, wd_stream_t stream);
+int wd_hgemm_tn_splitk(const wd_half_t *AT, int64_t ldat, const wd_half_t *dZT, int64_t lddzt, float *Gpart, int64_t K,
+                       int64_t N, int64_t batch, int32_t nsplit, wd_stream_t stream);
+int wd_cast_transpose_h(const float *src, int64_t ld_src, int64_t rows, int64_t cols, const wd_half_t *act_h,
+                        int64_t ld_act, int32_t act, wd_half_t *dst, int64_t ld_dst, wd_half_t *dstT, int64_t ld_dstT,
+                        wd_stream_t stream);
+int wd_logits_head_h(const wd_half_t *a_h, int64_t ld_a, int64_t K, const float *wf, const float *bf, int32_t bias_parts,
+                     const float *wide_logit, const float *labels, const float *weights, int64_t batch,
+                     float *dnn_logit, float *logit, float *prob, float *dlogit, float *loss_sum, float *out,
+                     int64_t ld_out, int32_t act, float *Gpart, wd_stream_t stream);
 
 /* dz = da * act'(a), the derivative expressed through the activation output a. */
 int wd_act_bwd(const float *da, int64_t ldda, const float *a, int64_t lda, int32_t act, float *dz, int64_t lddz,

@@ -362,7 +362,9 @@ __device__ __forceinline__ void fold_affine_body(const float *__restrict__ P, in
                                                  const int32_t *__restrict__ beta_idx, float inv,
                                                  float *__restrict__ Wf, float *__restrict__ bf,
                                                  float *__restrict__ s_out, float *__restrict__ t_out, int64_t K,
-                                                 int64_t N, int bx, int by, float (*red)[64]) {
+                                                 int64_t N, int bx, int by, float (*red)[64],
+                                                 _Float16 *__restrict__ Wf_h = nullptr, int64_t ld_wf_h = 0,
+                                                 _Float16 *__restrict__ WfT_h = nullptr, int64_t ld_wft_h = 0) {
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   const int64_t n = (int64_t)bx * 64 + tx;
   const int64_t kc = (K + WD_FOLD_PARTS - 1) / WD_FOLD_PARTS;
@@ -382,6 +384,8 @@ __device__ __forceinline__ void fold_affine_body(const float *__restrict__ P, in
     if (n < N) {
       const float w = W[k * N + n];
       Wf[k * N + n] = sk * w;
+      if (Wf_h) Wf_h[k * ld_wf_h + n] = (_Float16)(sk * w);     // half copies for the fp16-input tower (mlp_half.hip)
+      if (WfT_h) WfT_h[n * ld_wft_h + k] = (_Float16)(sk * w);
       tb += tk * w;
     }
   }
@@ -415,7 +419,8 @@ k_fold_affine_all(const float *__restrict__ P, const wd_mlp_layer_t *__restrict_
   const wd_mlp_layer_t L = layers[blockIdx.z];
   if ((int64_t)blockIdx.x * 64 >= L.N) return;
   fold_affine_body(P, L.w_off, L.b_off, L.gamma_idx, L.beta_idx, inv, L.Wf, L.bf, L.s, L.t, L.K, L.N, blockIdx.x,
-                   blockIdx.y, red);
+                   blockIdx.y, red, reinterpret_cast<_Float16 *>(L.Wf_h), L.ld_wf_h,
+                   reinterpret_cast<_Float16 *>(L.WfT_h), L.ld_wft_h);
 }
 
 __global__ void __launch_bounds__(256)
@@ -536,8 +541,9 @@ k_mlp_finalize_all(const wd_mlp_layer_t *__restrict__ layers, const float *__res
 //           kernel gradient  Gpart[blk][k] = sum_b a[b,k]*dlogit[b],  Gpart[blk][K] = sum_b dlogit[b]  (fixed order).
 constexpr int HEAD_CHUNK = 64;            // examples per workgroup
 constexpr int HEAD_LPE = 256 / HEAD_CHUNK;  // lanes per example in phase 1
+template <typename TA>
 __global__ void __launch_bounds__(256)
-k_logits_head(const float *__restrict__ a, int64_t ld_a, int64_t K, const float *__restrict__ wf,
+k_logits_head(const TA *__restrict__ a, int64_t ld_a, int64_t K, const float *__restrict__ wf,
               const float *__restrict__ bf, int32_t bias_parts, const float *__restrict__ wide_logit,
               const float *__restrict__ labels, const float *__restrict__ weights, int64_t batch,
               float *__restrict__ dnn_logit, float *__restrict__ logit, float *__restrict__ prob,
@@ -554,9 +560,9 @@ k_logits_head(const float *__restrict__ a, int64_t ld_a, int64_t K, const float 
   const bool live = b < batch;
   float d = 0.f;
   if (live) {
-    const float *ar = a + b * ld_a;
+    const TA *ar = a + b * ld_a;
 #pragma unroll 4
-    for (int64_t k = part; k < K; k += HEAD_LPE) d += ar[k] * wf[k];
+    for (int64_t k = part; k < K; k += HEAD_LPE) d += (float)ar[k] * wf[k];
   }
 #pragma unroll
   for (int off = 1; off < HEAD_LPE; off <<= 1) d += __shfl_xor(d, off, 64);
@@ -592,7 +598,7 @@ k_logits_head(const float *__restrict__ a, int64_t ld_a, int64_t K, const float 
     for (int i = q; i < HEAD_CHUNK; i += Q) {
       const int64_t b = b0 + i;
       if (b >= batch) break;
-      const float av = a[b * ld_a + k];
+      const float av = (float)a[b * ld_a + k];
       const float dl = sdl[i];
       gw += av * dl;
       if (out) out[b * ld_out + k] = act ? dl * w * act_bwd(av, act) : dl * w;
@@ -751,8 +757,24 @@ extern "C" int wd_logits_head(const float *a, int64_t ld_a, int64_t K, const flo
   WD_REQUIRE(a && wf && bf, "null pointer");
   WD_REQUIRE(K > 0 && bias_parts > 0, "K, bias_parts must be > 0");
   WD_REQUIRE(labels || (!dlogit && !out && !Gpart), "labels required for the backward outputs");
-  hipLaunchKernelGGL(k_logits_head, dim3((unsigned)wd::ceil_div(batch, HEAD_CHUNK)), dim3(256), 0,
+  hipLaunchKernelGGL(k_logits_head<float>, dim3((unsigned)wd::ceil_div(batch, HEAD_CHUNK)), dim3(256), 0,
                      wd::as_stream(stream), a, ld_a, K, wf, bf, bias_parts, wide_logit, labels, weights, batch,
                      dnn_logit, logit, prob, dlogit, loss_sum, out, ld_out, act, Gpart);
   return wd::check_launch("wd_logits_head");
+}
+
+extern "C" int wd_logits_head_h(const uint16_t *a_h, int64_t ld_a, int64_t K, const float *wf, const float *bf,
+                                int32_t bias_parts, const float *wide_logit, const float *labels, const float *weights,
+                                int64_t batch, float *dnn_logit, float *logit, float *prob, float *dlogit,
+                                float *loss_sum, float *out, int64_t ld_out, int32_t act, float *Gpart,
+                                wd_stream_t stream) {
+  if (batch <= 0) return WD_OK;
+  WD_REQUIRE(a_h && wf && bf, "null pointer");
+  WD_REQUIRE(K > 0 && bias_parts > 0, "K, bias_parts must be > 0");
+  WD_REQUIRE(labels || (!dlogit && !out && !Gpart), "labels required for the backward outputs");
+  hipLaunchKernelGGL(k_logits_head<_Float16>, dim3((unsigned)wd::ceil_div(batch, HEAD_CHUNK)), dim3(256), 0,
+                     wd::as_stream(stream), reinterpret_cast<const _Float16 *>(a_h), ld_a, K, wf, bf, bias_parts,
+                     wide_logit, labels, weights, batch, dnn_logit, logit, prob, dlogit, loss_sum, out, ld_out, act,
+                     Gpart);
+  return wd::check_launch("wd_logits_head_h");
 }

@@ -41,6 +41,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=20)
     ap.add_argument("--ids-input", action="store_true", help="feed pre-hashed ids (skips the hash kernel)")
+    ap.add_argument("--tower-dtype", default=None, choices=["fp32", "fp16"],
+                    help="GEMM operand type of the tower (default: fp32; c5: fp16 = BASELINE configs[4])")
     return ap.parse_args()
 
 
@@ -55,8 +57,8 @@ def make_spec(cfg):
         # wide) are resident in its 288 GB
         return criteo_spec(n_dense=13, n_sparse=26, buckets=3_846_154, dim=16, hidden=(256, 128, 64), mode="simple"), 1
     if cfg == "c5":
-        # BASELINE.json configs[4] SHAPE in fp32: deep-only DenseDnn [1024,512,256,128], emb_dim 64 (the fp16-input
-        # MFMA tower of that config is not built yet; this runs the exact-fp32 MFMA tower)
+        # BASELINE.json configs[4]: deep-only DenseDnn [1024,512,256,128], emb_dim 64, fp16 MFMA tower (fp32 embeddings);
+        # --tower-dtype fp32 runs the same shape on the exact-fp32 MFMA tower
         return criteo_spec(n_dense=13, n_sparse=26, buckets=1_000_000, dim=64, hidden=(1024, 512, 256, 128),
                            mode="dense", model_type="deep"), 1
     # configs[3] shape on one GPU: multi-hot (avg 5 ids/slot), ResDnn, weight column
@@ -207,13 +209,14 @@ def main():
     from wide_deep_amd.engine import WideDeepEngine
 
     spec, mean_len = make_spec(args.config)
+    tower_dtype = args.tower_dtype or ("fp16" if args.config == "c5" else "fp32")
     B = args.batch
     if world > 1:
         from wide_deep_amd.dist import ShardedWideDeepEngine
         eng = ShardedWideDeepEngine(spec, max_batch=B, max_nnz=B * 26 * (2 * mean_len + 2), seed=0,
                                     expected_nnz=B * 26 * mean_len, slack=1.3)
     else:
-        eng = WideDeepEngine(spec, max_batch=B, max_nnz=B * 26 * (2 * mean_len + 2), seed=0)
+        eng = WideDeepEngine(spec, max_batch=B, max_nnz=B * 26 * (2 * mean_len + 2), seed=0, tower_dtype=tower_dtype)
     plan = eng.plan
 
     # resident batch pool (raw tokens in HBM); distinct seeds per rank
@@ -277,7 +280,9 @@ def main():
     out = {
         "metric": "examples/sec", "value": round(value, 1), "unit": "examples/sec", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32" if tower_dtype == "fp32" else "f16 tower operands, f32 accumulate / embeddings / optimizer state",
+        "data": "synthetic",
         "config": {
             "workload": {
                 "c2": "BASELINE configs[1] (C2): Criteo-shape synthetic, 13 dense + 26 sparse slots x 1M hash buckets, "
@@ -286,7 +291,8 @@ def main():
                       "batch %d per GPU" % (world, B),
                 "c4": "BASELINE configs[3] shape (C4) on %d GPU(s): multi-hot avg %d ids/slot, ResDnn, weight column"
                       % (world, mean_len),
-                "c5": "BASELINE configs[4] shape (C5) in fp32: deep-only DenseDnn [1024,512,256,128], emb_dim 64, batch %d" % B,
+                "c5": "BASELINE configs[4] (C5): deep-only DenseDnn [1024,512,256,128], emb_dim 64, %s tower, batch %d"
+                      % (tower_dtype, B),
             }[args.config],
             "global_batch": B * world, "ids": args.dist, "input": "pre-hashed ids" if args.ids_input else "raw string tokens (hashed in step)",
             "hip_graph": bool(use_graph), "parallelism": "dp%d+row-sharded tables" % world if world > 1 else "single GPU",

@@ -75,3 +75,38 @@ def test_cast_transpose_with_activation_derivative():
     call("wd_cast_transpose_h", ptr(src), C + 6, R, C, ptr(a), C, 1, ptr(dst), C + 2, ptr(dstT), 320, _st())
     exp = (src[:, :C] * (a.float() > 0).float()).half()
     assert torch.equal(dst[:, :C], exp) and torch.equal(dstT[:, :R], exp.t().contiguous())
+
+
+@pytest.mark.parametrize("mode,model_type,dim,hidden", [("dense", "deep", 64, (128, 64, 32, 16)), ("simple", "wide_deep", 16, (96, 48)),
+                                                        ("resnet", "wide_deep", 8, (40, 24))])
+def test_fp16_tower_tracks_fp32_tower_and_oracle(mode, model_type, dim, hidden):
+    """BASELINE configs[4] shape at test size: deep-only DenseDnn, emb 64, fp16 MFMA tower with fp32 embeddings (and the
+    other connection modes).  Same weights and batches through tower_dtype='fp16', 'fp32' and the fp32 CPU oracle."""
+    from tests.helpers import oracle_batch, oracle_from_engine
+    from wide_deep_amd import synth
+    from wide_deep_amd.engine import WideDeepEngine
+    from wide_deep_amd.plan import criteo_spec
+    spec = criteo_spec(n_dense=5, n_sparse=6, buckets=400, dim=dim, hidden=hidden, mode=mode, model_type=model_type)
+    B = 200
+    e16 = WideDeepEngine(spec, max_batch=B, seed=5, tower_dtype="fp16")
+    e32 = WideDeepEngine(spec, max_batch=B, seed=5, tower_dtype="fp32")
+    ora = oracle_from_engine(e32)
+    first = None
+    for step in range(4):
+        hb = synth.make_raw_batch(e32.plan, B, seed=100 + step, mean_len=2, pos_rate=0.3)
+        bt = synth.to_device_ids(e32.plan, hb)
+        l16 = float(e16.train_step(bt)); l32 = float(e32.train_step(bt))
+        torch.cuda.synchronize()
+        ob = oracle_batch(e32.plan, bt.ids.cpu().numpy(), bt.bag_offs.cpu().numpy(), B, hb["dense"], hb["labels"])
+        oloss, ologits = ora.train_step(ob)
+        # fp16 operands: ~1e-3 relative per product; logits are O(1) sums of a few hundred of them
+        _close(e16.logit[:B], e32.logit[:B], 3e-2, 2e-2, "fp16 vs fp32 logits step %d" % step)
+        _close(e16.logit[:B], ologits, 3e-2, 2e-2, "fp16 vs oracle logits step %d" % step)
+        assert abs(l16 - oloss) <= 2e-2 * max(1.0, abs(oloss)), (step, l16, l32, oloss)
+        first = first if first is not None else l16
+    # the fp16 tower trains: the embedding tables moved exactly where the fp32 tower moved them (up to fp16 noise)
+    a, b = e16.export_state(), e32.export_state()
+    k = [n for n in b if n.endswith("embedding_weights")][0]
+    moved = (b[k] - oracle_from_engine(WideDeepEngine(spec, max_batch=B, seed=5)).state[k]).abs().sum()
+    # Adagrad normalises tiny gradients to ~lr-sized moves, so an fp16-noise sign flip can show as ~1e-2 on single elements
+    assert float(moved) > 0 and float((a[k] - b[k]).abs().max()) < 3e-2 and float((a[k] - b[k]).abs().mean()) < 1e-3

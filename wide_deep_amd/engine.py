@@ -40,7 +40,8 @@ def _stream():
 
 
 class WideDeepEngine:
-    def __init__(self, spec: ModelSpec, max_batch=8192, max_nnz=None, device="cuda", seed=0, expected_nnz=None):
+    def __init__(self, spec: ModelSpec, max_batch=8192, max_nnz=None, device="cuda", seed=0, expected_nnz=None,
+                 tower_dtype="fp32"):
         if not torch.cuda.is_available():
             raise capi.WdError("WideDeepEngine needs a GPU (MI355X / gfx950); there is no CPU fallback")
         capi.load()
@@ -50,6 +51,9 @@ class WideDeepEngine:
             raise NotImplementedError("dnn_optimizer %s: only Adagrad is implemented" % (spec.dnn_opt[0],))
         if spec.has_wide and spec.lin_opt[0] != "Ftrl":
             raise NotImplementedError("linear_optimizer %s: only Ftrl is implemented" % (spec.lin_opt[0],))
+        if tower_dtype not in ("fp32", "fp16"):
+            raise ValueError("tower_dtype must be 'fp32' (exact fp32 MFMA) or 'fp16' (half operands, fp32 accumulate)")
+        self.half = tower_dtype == "fp16"     # BASELINE configs[4]: fp16 MFMA dense path, fp32 embeddings
         self.spec = spec
         self.plan = plan = FeaturePlan(spec)
         self.device = torch.device(device)
@@ -141,7 +145,8 @@ class WideDeepEngine:
                     if l == L:     # logits layer: partials come from wd_logits_head, one per 64-example block
                         ns = head_blocks
                     else:          # split-K over the batch: ~512 workgroups, >= 4 reduction slabs (of 64) each
-                        tiles = math.ceil((K + 1) / 64) * math.ceil(N / 64)
+                        tsz = 128 if (self.half and N > 128) else 64
+                        tiles = math.ceil((K + 1) / tsz) * math.ceil(N / tsz)
                         ns = max(1, min(math.ceil(512 / tiles), 64, max(1, B // 256)))
                     tw["nsplit"].append(ns)
                     tw["Gpart"].append(torch.zeros(ns * (K + 1) * N, **f32))
@@ -154,6 +159,22 @@ class WideDeepEngine:
                     W[rows] = Wtf
                     if "gamma_off" in m:
                         self.P[m["gamma_off"]: m["gamma_off"] + N] = 1.0
+                if self.half:
+                    if len(plan.towers) != 1:
+                        raise NotImplementedError("tower_dtype='fp16': one tower")
+                    f16 = dict(dtype=torch.float16, device=dev)
+                    Bp = (B + 63) // 64 * 64
+                    pdz = (max(m["N"] for m in metas[:L]) + 7) // 8 * 8 if L else 8
+                    tw["Bp"], tw["pdz"] = Bp, pdz
+                    tw["act_h"] = torch.zeros(B, tl.ld, **f16)            # activations, example-major
+                    tw["actT_h"] = torch.zeros(tl.ld, Bp, **f16)          # and column-major (batch contiguous) for TN
+                    tw["dz_h"] = [torch.zeros(B, pdz, **f16), torch.zeros(B, pdz, **f16)]
+                    tw["dzT_h"] = [torch.zeros(pdz, Bp, **f16), torch.zeros(pdz, Bp, **f16)]
+                    tw["Wf_h"], tw["WfT_h"] = [], []
+                    for l in range(L):
+                        K, N = metas[l]["K"], metas[l]["N"]
+                        tw["Wf_h"].append(torch.zeros(K, (N + 7) // 8 * 8, **f16))     # [K][Np]  (NT: reduction over n)
+                        tw["WfT_h"].append(torch.zeros(N, (K + 7) // 8 * 8, **f16))    # [N][Kp]  (NN: reduction over k)
                 self.towers.append(tw)
             # descriptor table of every layer of every tower (wd_fold_affine_all / wd_mlp_finalize_all)
             nl = sum(len(tw["metas"]) for tw in self.towers)
@@ -168,6 +189,9 @@ class WideDeepEngine:
                     d.Wf, d.bf, d.s, d.t = (tw["Wf"][l].data_ptr(), tw["bf"][l].data_ptr(), tw["s"][l].data_ptr(),
                                             tw["t"][l].data_ptr())
                     d.Gpart, d.nsplit = tw["Gpart"][l].data_ptr(), tw["nsplit"][l]
+                    if self.half and l < tw["L"]:
+                        d.Wf_h, d.ld_wf_h = tw["Wf_h"][l].data_ptr(), tw["Wf_h"][l].shape[1]
+                        d.WfT_h, d.ld_wft_h = tw["WfT_h"][l].data_ptr(), tw["WfT_h"][l].shape[1]
                     self.max_layer_n = max(self.max_layer_n, m["N"])
                     self.max_layer_k = max(self.max_layer_k, m["K"])
                     i += 1
@@ -327,6 +351,8 @@ class WideDeepEngine:
                  ptr(self.prob), None, None, st)
 
     def _tower_hidden_forward(self, tw, B, st):
+        if self.half:
+            return self._tower_hidden_forward_h(tw, B, st)
         tl, metas, L = tw["layout"], tw["metas"], tw["L"]
         act = tw["act"]
         for l in range(L):
@@ -336,6 +362,21 @@ class WideDeepEngine:
             c_ptr = act.data_ptr() + 4 * tl.seg_start[l + 1]
             call("wd_gemm_nn_bias_act", a_ptr, tl.ld, ptr(tw["Wf"][l]), N, ptr(tw["bf"][l]), capi.WD_FOLD_PARTS,
                  self.act_id, c_ptr, tl.ld, B, N, K, st)
+
+    def _tower_hidden_forward_h(self, tw, B, st):
+        """fp16-input tower: x (fp32, from the gather) -> half + transposed half; every layer writes both copies."""
+        tl, metas, L = tw["layout"], tw["metas"], tw["L"]
+        ah, aT, Bp = tw["act_h"], tw["actT_h"], tw["Bp"]
+        s0, w0 = tl.seg_start[0], tl.seg_width[0]
+        call("wd_cast_transpose_h", tw["act"].data_ptr() + 4 * s0, tl.ld, B, w0, None, 0, 0, ah.data_ptr() + 2 * s0, tl.ld,
+             aT.data_ptr() + 2 * s0 * Bp, Bp, st)
+        for l in range(L):
+            m = metas[l]
+            K, N = m["K"], m["N"]
+            seg = tl.seg_start[l + 1]
+            call("wd_hgemm_nn", ah.data_ptr() + 2 * tl.in_start[l], tl.ld, ptr(tw["WfT_h"][l]), tw["WfT_h"][l].shape[1],
+                 ptr(tw["bf"][l]), capi.WD_FOLD_PARTS, self.act_id, ah.data_ptr() + 2 * seg, tl.ld,
+                 aT.data_ptr() + 2 * seg * Bp, Bp, B, N, K, st)
 
     def _head_out(self, tw):
         """Where the logits layer's input gradient goes: simple mode -> dz of the last hidden layer (act' fused),
@@ -350,15 +391,18 @@ class WideDeepEngine:
         tl, metas, L = tw["layout"], tw["metas"], tw["L"]
         m = metas[L]
         a_ptr = tw["act"].data_ptr() + 4 * tl.in_start[L]
+        head = "wd_logits_head"
+        if self.half:
+            a_ptr, head = tw["act_h"].data_ptr() + 2 * tl.in_start[L], "wd_logits_head_h"
         if fused:
             out_ptr, ld_out, act_id = self._head_out(tw) if train else (None, 0, 0)
-            call("wd_logits_head", a_ptr, tl.ld, m["K"], ptr(tw["Wf"][L]), ptr(tw["bf"][L]), capi.WD_FOLD_PARTS,
+            call(head, a_ptr, tl.ld, m["K"], ptr(tw["Wf"][L]), ptr(tw["bf"][L]), capi.WD_FOLD_PARTS,
                  ptr(self.wide_logit), ptr(bt.labels) if train else None, ptr(bt.weights) if train else None, B,
                  ptr(tw["logit"]), ptr(self.logit), ptr(self.prob), ptr(self.dlogit) if train else None,
                  ptr(self.loss) if train else None, out_ptr, ld_out, act_id,
                  ptr(tw["Gpart"][L]) if train else None, st)
         else:
-            call("wd_logits_head", a_ptr, tl.ld, m["K"], ptr(tw["Wf"][L]), ptr(tw["bf"][L]), capi.WD_FOLD_PARTS,
+            call(head, a_ptr, tl.ld, m["K"], ptr(tw["Wf"][L]), ptr(tw["bf"][L]), capi.WD_FOLD_PARTS,
                  None, None, None, B, ptr(tw["logit"]), None, None, None, None, None, 0, 0, None, st)
 
     # ------------------------------------------------------------------------------------------
@@ -366,6 +410,8 @@ class WideDeepEngine:
     # ------------------------------------------------------------------------------------------
     def _tower_backward(self, tw, B, st, need_dx, head_done):
         """Hidden layers L-1..0 (and the logits layer when the fused head has not already done it)."""
+        if self.half:
+            return self._tower_backward_h(tw, B, st, need_dx)
         tl, metas, L = tw["layout"], tw["metas"], tw["L"]
         act, dact = tw["act"], tw["dact"]
         simple = tl.mode == "simple"
@@ -409,6 +455,46 @@ class WideDeepEngine:
             elif l > 0 or need_dx:
                 call("wd_gemm_nt", dz_ptr, lddz, ptr(tw["Wf"][l]), N, dact.data_ptr() + 4 * tl.in_start[l], tl.ld, B,
                      K, N, 1, st)
+
+    def _tower_backward_h(self, tw, B, st, need_dx):
+        """Backward of the fp16-input tower (single tower; the fused head already did the logits layer)."""
+        tl, metas, L = tw["layout"], tw["metas"], tw["L"]
+        ah, aT, Bp, pdz = tw["act_h"], tw["actT_h"], tw["Bp"], tw["pdz"]
+        dact = tw["dact"]
+        simple = tl.mode == "simple"
+        if not self.all_simple:
+            self._finalize_layer(tw, L, st, tw["nsplit"][L])
+        cur = 0
+        if simple and L > 0:
+            # the head left dz of the last hidden layer in fp32 (act' fused): make the two half copies
+            call("wd_cast_transpose_h", tw["dz"][0].data_ptr(), metas[L]["K"], B, metas[L]["K"], None, 0, 0,
+                 ptr(tw["dz_h"][0]), pdz, ptr(tw["dzT_h"][0]), Bp, st)
+        for l in range(L - 1, -1, -1):
+            m = metas[l]
+            K, N = m["K"], m["N"]
+            if not simple:
+                seg = tl.seg_start[l + 1]     # dz = dact * act'(a) on segment l+1, straight into the half copies
+                call("wd_cast_transpose_h", dact.data_ptr() + 4 * seg, tl.ld, B, N, ah.data_ptr() + 2 * seg, tl.ld,
+                     self.act_id, ptr(tw["dz_h"][0]), pdz, ptr(tw["dzT_h"][0]), Bp, st)
+                cur = 0
+            ns = tw["nsplit"][l]
+            call("wd_hgemm_tn_splitk", aT.data_ptr() + 2 * tl.in_start[l] * Bp, Bp, ptr(tw["dzT_h"][cur]), Bp,
+                 ptr(tw["Gpart"][l]), K, N, B, ns, st)
+            if not self.all_simple:
+                self._finalize_layer(tw, l, st, ns)
+            wf = tw["Wf_h"][l]
+            if simple:
+                if l > 0:
+                    call("wd_hgemm_nt", ptr(tw["dz_h"][cur]), pdz, ptr(wf), wf.shape[1], B, K, N, None, 0, 0,
+                         ptr(tw["dz_h"][cur ^ 1]), pdz, ptr(tw["dzT_h"][cur ^ 1]), Bp, ah.data_ptr() + 2 * tl.in_start[l],
+                         tl.ld, self.act_id, st)
+                    cur ^= 1
+                elif need_dx:
+                    call("wd_hgemm_nt", ptr(tw["dz_h"][cur]), pdz, ptr(wf), wf.shape[1], B, K, N,
+                         dact.data_ptr() + 4 * tl.in_start[l], tl.ld, 0, None, 0, None, 0, None, 0, 0, st)
+            elif l > 0 or need_dx:
+                call("wd_hgemm_nt", ptr(tw["dz_h"][cur]), pdz, ptr(wf), wf.shape[1], B, K, N,
+                     dact.data_ptr() + 4 * tl.in_start[l], tl.ld, 1, None, 0, None, 0, None, 0, 0, st)
 
     def _finalize_layer(self, tw, l, st, ns):
         m = tw["metas"][l]

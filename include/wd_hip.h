@@ -270,9 +270,11 @@ typedef struct wd_mlp_layer {
   const float *Gpart;       /* split-K partials of this layer (as wd_mlp_finalize) */
   int32_t nsplit;
   int32_t pad_;
-  uint16_t *Wf_h;           /* optional IEEE-half copies of the folded kernel for the fp16-input tower: */
-  uint16_t *WfT_h;          /*   Wf_h [K][ld_wf_h] and its transpose WfT_h [N][ld_wft_h]; NULL: not written */
-  int64_t ld_wf_h, ld_wft_h;
+  /* optional IEEE-half copies of the folded kernel for the fp16-input tower (NULL: not written): */
+  uint16_t *WfT_h;          /*   transposed kernel WfT_h [N][ld_wft_h] (operand of wd_hgemm_nn) */
+  int64_t ld_wft_h;
+  const int64_t *cat_off;   /*   [K] element offsets into wcat (< 0: skip): row k of this layer is written to */
+  uint16_t *wcat;           /*   wcat[cat_off[k] + n], n < N -- the operand of the segment-gradient GEMM (wd_hgemm_nt) */
 } wd_mlp_layer_t;
 
 /* wd_fold_affine for every layer of every tower in ONE launch; also zero-fills up to two small buffers
@@ -290,9 +292,9 @@ int wd_mlp_finalize_all(const wd_mlp_layer_t *layers_dev, int32_t nlayers, int64
  * loss_sum (+=), prob, dlogit = w*(p-y).  Backward of the logits layer in the same launch:
  *   out[b*ld_out + k] = dlogit[b]*wf[k]  (times act'(a[b,k]) when act != 0, i.e. out = dz of the last hidden layer),
  *   Gpart[blk*(K+1) + k] = sum over the block's examples of a[b,k]*dlogit[b], [.. + K] = sum dlogit  (split-K
- *   partials in wd_mlp_finalize's layout with nsplit = wd_logits_head_blocks(batch)).
+ *   partials in wd_mlp_finalize's layout with nsplit = wd_logits_head_blocks(batch, K)).
  * labels NULL: forward only (predict); out / Gpart may be NULL. */
-int64_t wd_logits_head_blocks(int64_t batch);
+int64_t wd_logits_head_blocks(int64_t batch, int64_t K);
 int wd_logits_head(const float *a, int64_t ld_a, int64_t K, const float *wf, const float *bf, int32_t bias_parts,
                    const float *wide_logit, const float *labels, const float *weights, int64_t batch,
                    float *dnn_logit, float *logit, float *prob, float *dlogit, float *loss_sum, float *out,

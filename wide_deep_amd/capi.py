@@ -46,7 +46,7 @@ class WdMlpLayer(ctypes.Structure):
         ("gamma_idx", ctypes.c_void_p), ("beta_idx", ctypes.c_void_p),
         ("Wf", ctypes.c_void_p), ("bf", ctypes.c_void_p), ("s", ctypes.c_void_p), ("t", ctypes.c_void_p),
         ("Gpart", ctypes.c_void_p), ("nsplit", ctypes.c_int32), ("pad_", ctypes.c_int32),
-        ("Wf_h", ctypes.c_void_p), ("WfT_h", ctypes.c_void_p), ("ld_wf_h", ctypes.c_int64), ("ld_wft_h", ctypes.c_int64),
+        ("WfT_h", ctypes.c_void_p), ("ld_wft_h", ctypes.c_int64), ("cat_off", ctypes.c_void_p), ("wcat", ctypes.c_void_p),
     ]
 
 
@@ -97,7 +97,7 @@ _PROTOS = {
     "wd_gemm_tn_splitk": [P, I64, P, I64, P, I64, I64, I64, I32, I32, P],
     "wd_fold_affine_all": [P, P, I32, I64, F32, P, I64, P, I64, P],
     "wd_mlp_finalize_all": [P, I32, I64, P, F32, P, P],
-    "wd_logits_head_blocks": [I64],
+    "wd_logits_head_blocks": [I64, I64],
     "wd_logits_head_h": [P, I64, I64, P, P, I32, P, P, P, I64, P, P, P, P, P, P, I64, I32, P, P],
     "wd_hgemm_nn": [P, I64, P, I64, P, I32, I32, P, I64, P, I64, I64, I64, I64, P],
     "wd_hgemm_nt": [P, I64, P, I64, I64, I64, I64, P, I64, I32, P, I64, P, I64, P, I64, I32, P],

@@ -357,20 +357,30 @@ int launch_gemm(GemmArgs g, int nsplit, hipStream_t st, const char *what) {
 // s[k] = gamma*inv (or 1), t[k] = beta (or 0);  Wf = diag(s) W;  bf_part[c] = (c == 0 ? b : 0) + t_c^T W_c
 // grid (ceil(N/64), WD_FOLD_PARTS): block = 64 columns x 4 k-lanes over one K chunk; the partial bias
 // sums stay separate per chunk (deterministic) and are added up by the GEMM epilogue.
+constexpr int FOLD_TK = 256;      // rows of a K chunk whose transposed half copy is staged in LDS
+constexpr int FOLD_TP = FOLD_TK + 2;   // pitch (halfs): odd in dwords -> the column-wise LDS writes do not conflict
+
+// Optional half outputs for the fp16-input tower (mlp_half.hip):
+//   WfT_h [N][ld_wft_h]  transposed folded kernel (NN operand), written through an LDS tile so that the stores are
+//                        128-byte rows instead of 2-byte scatters (the scattered version took 112 us at C5)
+//   wcat + cat_off[k]    row k of this layer, as the columns [.. + n] of the "pull" backward operand of the segment
+//                        that produced input column k (see WideDeepEngine._tower_backward_h); cat_off[k] < 0: skip
 __device__ __forceinline__ void fold_affine_body(const float *__restrict__ P, int64_t w_off, int64_t b_off,
                                                  const int32_t *__restrict__ gamma_idx,
                                                  const int32_t *__restrict__ beta_idx, float inv,
                                                  float *__restrict__ Wf, float *__restrict__ bf,
                                                  float *__restrict__ s_out, float *__restrict__ t_out, int64_t K,
                                                  int64_t N, int bx, int by, float (*red)[64],
-                                                 _Float16 *__restrict__ Wf_h = nullptr, int64_t ld_wf_h = 0,
-                                                 _Float16 *__restrict__ WfT_h = nullptr, int64_t ld_wft_h = 0) {
+                                                 _Float16 *__restrict__ WfT_h = nullptr, int64_t ld_wft_h = 0,
+                                                 const int64_t *__restrict__ cat_off = nullptr,
+                                                 _Float16 *__restrict__ wcat = nullptr, _Float16 *tileT = nullptr) {
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   const int64_t n = (int64_t)bx * 64 + tx;
   const int64_t kc = (K + WD_FOLD_PARTS - 1) / WD_FOLD_PARTS;
   const int64_t k0 = (int64_t)by * kc;
   const int64_t k1 = k0 + kc < K ? k0 + kc : K;
   const float *W = P + w_off;
+  const bool stage = WfT_h && tileT && kc <= FOLD_TK;
   float tb = 0.f;
   for (int64_t k = k0 + ty; k < k1; k += 4) {
     const int32_t gi = gamma_idx ? gamma_idx[k] : -1;
@@ -384,8 +394,14 @@ __device__ __forceinline__ void fold_affine_body(const float *__restrict__ P, in
     if (n < N) {
       const float w = W[k * N + n];
       Wf[k * N + n] = sk * w;
-      if (Wf_h) Wf_h[k * ld_wf_h + n] = (_Float16)(sk * w);     // half copies for the fp16-input tower (mlp_half.hip)
-      if (WfT_h) WfT_h[n * ld_wft_h + k] = (_Float16)(sk * w);
+      if (WfT_h) {
+        if (stage) tileT[tx * FOLD_TP + (k - k0)] = (_Float16)(sk * w);
+        else WfT_h[n * ld_wft_h + k] = (_Float16)(sk * w);
+      }
+      if (cat_off) {
+        const int64_t o = cat_off[k];
+        if (o >= 0) wcat[o + n] = (_Float16)(sk * w);
+      }
       tb += tk * w;
     }
   }
@@ -395,6 +411,14 @@ __device__ __forceinline__ void fold_affine_body(const float *__restrict__ P, in
     float v = red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx];
     if (by == 0) v += P[b_off + n];
     bf[(int64_t)by * N + n] = v;
+  }
+  if (stage) {   // tile -> WfT_h: each wavefront writes one row segment (k contiguous) at a time
+    const int kcn = (int)(k1 - k0);
+    for (int nl = ty; nl < 64; nl += 4) {
+      const int64_t nn = (int64_t)bx * 64 + nl;
+      if (nn >= N) break;
+      for (int kk = tx; kk < kcn; kk += 64) WfT_h[nn * ld_wft_h + k0 + kk] = tileT[nl * FOLD_TP + kk];
+    }
   }
 }
 
@@ -412,6 +436,7 @@ __global__ void __launch_bounds__(256)
 k_fold_affine_all(const float *__restrict__ P, const wd_mlp_layer_t *__restrict__ layers, float inv,
                   float *__restrict__ zero_a, int64_t zero_a_n, float *__restrict__ zero_b, int64_t zero_b_n) {
   __shared__ float red[4][64];
+  __shared__ _Float16 tileT[64 * FOLD_TP];
   const int64_t bid = ((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
   const int64_t nthreads = (int64_t)gridDim.x * gridDim.y * gridDim.z * 256;
   for (int64_t i = bid * 256 + threadIdx.x; i < zero_a_n; i += nthreads) zero_a[i] = 0.f;
@@ -419,8 +444,8 @@ k_fold_affine_all(const float *__restrict__ P, const wd_mlp_layer_t *__restrict_
   const wd_mlp_layer_t L = layers[blockIdx.z];
   if ((int64_t)blockIdx.x * 64 >= L.N) return;
   fold_affine_body(P, L.w_off, L.b_off, L.gamma_idx, L.beta_idx, inv, L.Wf, L.bf, L.s, L.t, L.K, L.N, blockIdx.x,
-                   blockIdx.y, red, reinterpret_cast<_Float16 *>(L.Wf_h), L.ld_wf_h,
-                   reinterpret_cast<_Float16 *>(L.WfT_h), L.ld_wft_h);
+                   blockIdx.y, red, reinterpret_cast<_Float16 *>(L.WfT_h), L.ld_wft_h, L.cat_off,
+                   reinterpret_cast<_Float16 *>(L.wcat), tileT);
 }
 
 __global__ void __launch_bounds__(256)
@@ -539,9 +564,12 @@ k_mlp_finalize_all(const wd_mlp_layer_t *__restrict__ layers, const float *__res
 //   phase 2 (lane per input column k): gradient wrt the window  out[b,k] = dlogit[b]*wf[k] (* act'(a[b,k]) when
 //           `act` != 0: simple mode, `out` is then dz of the last hidden layer), and this block's partial of the
 //           kernel gradient  Gpart[blk][k] = sum_b a[b,k]*dlogit[b],  Gpart[blk][K] = sum_b dlogit[b]  (fixed order).
-constexpr int HEAD_CHUNK = 64;            // examples per workgroup
-constexpr int HEAD_LPE = 256 / HEAD_CHUNK;  // lanes per example in phase 1
-template <typename TA>
+// Two geometries: narrow logits layers (K <= 256: simple / resnet-lite towers) take 64 examples per workgroup with 4
+// lanes per example; wide ones (dense / last_dense windows, K in the thousands) take 16 examples per workgroup with a
+// whole wavefront per example, so that the row reads are 128-byte coalesced and 4x more workgroups are in flight.
+constexpr int HEAD_K_WIDE = 256;
+__host__ __device__ constexpr int head_chunk(int64_t K) { return K > HEAD_K_WIDE ? 16 : 64; }
+template <typename TA, int HEAD_CHUNK, int HEAD_LPE>
 __global__ void __launch_bounds__(256)
 k_logits_head(const TA *__restrict__ a, int64_t ld_a, int64_t K, const float *__restrict__ wf,
               const float *__restrict__ bf, int32_t bias_parts, const float *__restrict__ wide_logit,
@@ -554,34 +582,38 @@ k_logits_head(const TA *__restrict__ a, int64_t ld_a, int64_t K, const float *__
   const int64_t b0 = (int64_t)blockIdx.x * HEAD_CHUNK;
   float bias = 0.f;
   for (int p = 0; p < bias_parts; ++p) bias += bf[p];
-  // phase 1: HEAD_LPE lanes per example (k = part, part + HEAD_LPE, ...), the block's examples in parallel
-  const int ex = threadIdx.x / HEAD_LPE, part = threadIdx.x % HEAD_LPE;
-  const int64_t b = b0 + ex;
-  const bool live = b < batch;
-  float d = 0.f;
-  if (live) {
-    const TA *ar = a + b * ld_a;
+  // phase 1: HEAD_LPE lanes per example (k = part, part + HEAD_LPE, ...), 256 / HEAD_LPE examples at a time
+  constexpr int PAR = 256 / HEAD_LPE;
+  const int part = threadIdx.x % HEAD_LPE;
+  float lsum = 0.f;
+  for (int ex = threadIdx.x / HEAD_LPE; ex < HEAD_CHUNK; ex += PAR) {
+    const int64_t b = b0 + ex;
+    const bool live = b < batch;
+    float d = 0.f;
+    if (live) {
+      const TA *ar = a + b * ld_a;
 #pragma unroll 4
-    for (int64_t k = part; k < K; k += HEAD_LPE) d += (float)ar[k] * wf[k];
-  }
+      for (int64_t k = part; k < K; k += HEAD_LPE) d += (float)ar[k] * wf[k];
+    }
 #pragma unroll
-  for (int off = 1; off < HEAD_LPE; off <<= 1) d += __shfl_xor(d, off, 64);
-  float lsum = 0.f, dl = 0.f;
-  if (live && part == 0) {
-    const float dn = d + bias;
-    const float x = dn + (wide_logit ? wide_logit[b] : 0.f);
-    const float y = labels ? labels[b] : 0.f;
-    const float w = weights ? weights[b] : 1.0f;
-    const float e = expf(-fabsf(x));
-    const float p = x >= 0.f ? 1.0f / (1.0f + e) : e / (1.0f + e);
-    dl = w * (p - y);
-    lsum = w * (fmaxf(x, 0.f) - x * y + log1pf(e));
-    if (dnn_logit) dnn_logit[b] = dn;
-    if (logit) logit[b] = x;
-    if (prob) prob[b] = p;
-    if (dlogit) dlogit[b] = dl;
+    for (int off = 1; off < HEAD_LPE; off <<= 1) d += __shfl_xor(d, off, 64);
+    float dl = 0.f;
+    if (live && part == 0) {
+      const float dn = d + bias;
+      const float x = dn + (wide_logit ? wide_logit[b] : 0.f);
+      const float y = labels ? labels[b] : 0.f;
+      const float w = weights ? weights[b] : 1.0f;
+      const float e = expf(-fabsf(x));
+      const float p = x >= 0.f ? 1.0f / (1.0f + e) : e / (1.0f + e);
+      dl = w * (p - y);
+      lsum += w * (fmaxf(x, 0.f) - x * y + log1pf(e));
+      if (dnn_logit) dnn_logit[b] = dn;
+      if (logit) logit[b] = x;
+      if (prob) prob[b] = p;
+      if (dlogit) dlogit[b] = dl;
+    }
+    if (part == 0) sdl[ex] = dl;
   }
-  if (part == 0) sdl[ex] = dl;
   for (int off = 32; off > 0; off >>= 1) lsum += __shfl_down(lsum, off, 64);
   if ((threadIdx.x & 63) == 0 && loss_sum) atomicAdd(loss_sum, lsum);
   if (!out && !Gpart) return;
@@ -746,7 +778,21 @@ extern "C" int wd_mlp_finalize_all(const wd_mlp_layer_t *layers_dev, int32_t nla
   return wd::check_launch("wd_mlp_finalize_all");
 }
 
-extern "C" int64_t wd_logits_head_blocks(int64_t batch) { return wd::ceil_div(batch, HEAD_CHUNK); }
+extern "C" int64_t wd_logits_head_blocks(int64_t batch, int64_t K) { return wd::ceil_div(batch, head_chunk(K)); }
+
+template <typename TA>
+static void launch_head(hipStream_t st, const TA *a, int64_t ld_a, int64_t K, const float *wf, const float *bf,
+                        int32_t bias_parts, const float *wide_logit, const float *labels, const float *weights,
+                        int64_t batch, float *dnn_logit, float *logit, float *prob, float *dlogit, float *loss_sum,
+                        float *out, int64_t ld_out, int32_t act, float *Gpart) {
+  const dim3 grid((unsigned)wd::ceil_div(batch, head_chunk(K)));
+  if (K > HEAD_K_WIDE)
+    hipLaunchKernelGGL((k_logits_head<TA, 16, 64>), grid, dim3(256), 0, st, a, ld_a, K, wf, bf, bias_parts, wide_logit,
+                       labels, weights, batch, dnn_logit, logit, prob, dlogit, loss_sum, out, ld_out, act, Gpart);
+  else
+    hipLaunchKernelGGL((k_logits_head<TA, 64, 4>), grid, dim3(256), 0, st, a, ld_a, K, wf, bf, bias_parts, wide_logit,
+                       labels, weights, batch, dnn_logit, logit, prob, dlogit, loss_sum, out, ld_out, act, Gpart);
+}
 
 extern "C" int wd_logits_head(const float *a, int64_t ld_a, int64_t K, const float *wf, const float *bf,
                               int32_t bias_parts, const float *wide_logit, const float *labels, const float *weights,
@@ -757,8 +803,7 @@ extern "C" int wd_logits_head(const float *a, int64_t ld_a, int64_t K, const flo
   WD_REQUIRE(a && wf && bf, "null pointer");
   WD_REQUIRE(K > 0 && bias_parts > 0, "K, bias_parts must be > 0");
   WD_REQUIRE(labels || (!dlogit && !out && !Gpart), "labels required for the backward outputs");
-  hipLaunchKernelGGL(k_logits_head<float>, dim3((unsigned)wd::ceil_div(batch, HEAD_CHUNK)), dim3(256), 0,
-                     wd::as_stream(stream), a, ld_a, K, wf, bf, bias_parts, wide_logit, labels, weights, batch,
+  launch_head<float>(wd::as_stream(stream), a, ld_a, K, wf, bf, bias_parts, wide_logit, labels, weights, batch,
                      dnn_logit, logit, prob, dlogit, loss_sum, out, ld_out, act, Gpart);
   return wd::check_launch("wd_logits_head");
 }
@@ -772,9 +817,8 @@ extern "C" int wd_logits_head_h(const uint16_t *a_h, int64_t ld_a, int64_t K, co
   WD_REQUIRE(a_h && wf && bf, "null pointer");
   WD_REQUIRE(K > 0 && bias_parts > 0, "K, bias_parts must be > 0");
   WD_REQUIRE(labels || (!dlogit && !out && !Gpart), "labels required for the backward outputs");
-  hipLaunchKernelGGL(k_logits_head<_Float16>, dim3((unsigned)wd::ceil_div(batch, HEAD_CHUNK)), dim3(256), 0,
-                     wd::as_stream(stream), reinterpret_cast<const _Float16 *>(a_h), ld_a, K, wf, bf, bias_parts,
-                     wide_logit, labels, weights, batch, dnn_logit, logit, prob, dlogit, loss_sum, out, ld_out, act,
-                     Gpart);
+  launch_head<_Float16>(wd::as_stream(stream), reinterpret_cast<const _Float16 *>(a_h), ld_a, K, wf, bf, bias_parts,
+                        wide_logit, labels, weights, batch, dnn_logit, logit, prob, dlogit, loss_sum, out, ld_out, act,
+                        Gpart);
   return wd::check_launch("wd_logits_head_h");
 }

@@ -133,7 +133,7 @@ class WideDeepEngine:
                 tw["logit"] = torch.zeros(B, **f32)
                 tw["Wf"], tw["bf"], tw["s"], tw["t"], tw["gidx"], tw["bidx"], tw["nsplit"] = [], [], [], [], [], [], []
                 tw["Gpart"] = []
-                head_blocks = int(call("wd_logits_head_blocks", B))
+                head_blocks = int(call("wd_logits_head_blocks", B, metas[L]["K"]))
                 for l, m in enumerate(metas):
                     K, N = m["K"], m["N"]
                     tw["Wf"].append(torch.zeros(K * N, **f32))
@@ -163,18 +163,41 @@ class WideDeepEngine:
                     if len(plan.towers) != 1:
                         raise NotImplementedError("tower_dtype='fp16': one tower")
                     f16 = dict(dtype=torch.float16, device=dev)
+                    r8 = lambda v: (v + 7) // 8 * 8
                     Bp = (B + 63) // 64 * 64
-                    pdz = (max(m["N"] for m in metas[:L]) + 7) // 8 * 8 if L else 8
-                    tw["Bp"], tw["pdz"] = Bp, pdz
+                    tw["Bp"] = Bp
                     tw["act_h"] = torch.zeros(B, tl.ld, **f16)            # activations, example-major
                     tw["actT_h"] = torch.zeros(tl.ld, Bp, **f16)          # and column-major (batch contiguous) for TN
-                    tw["dz_h"] = [torch.zeros(B, pdz, **f16), torch.zeros(B, pdz, **f16)]
-                    tw["dzT_h"] = [torch.zeros(pdz, Bp, **f16), torch.zeros(pdz, Bp, **f16)]
-                    tw["Wf_h"], tw["WfT_h"] = [], []
-                    for l in range(L):
-                        K, N = metas[l]["K"], metas[l]["N"]
-                        tw["Wf_h"].append(torch.zeros(K, (N + 7) // 8 * 8, **f16))     # [K][Np]  (NT: reduction over n)
-                        tw["WfT_h"].append(torch.zeros(N, (K + 7) // 8 * 8, **f16))    # [N][Kp]  (NN: reduction over k)
+                    tw["WfT_h"] = [torch.zeros(metas[l]["N"], r8(metas[l]["K"]), **f16) for l in range(L)]
+                    # Z = [dlogit | dz_{L-1} | ... | dz_0] (blocks 8-aligned), example-major and transposed.  The gradient
+                    # of segment j is PULLED in one GEMM  Z[:, zbeg_j:zend_j] . Wcat_j^T  over all its consumer layers
+                    # (dense / resnet: every later layer and the logits), so nothing is accumulated in HBM.
+                    zoff, z = {L: 0}, 8
+                    for l in range(L - 1, -1, -1):
+                        zoff[l] = z
+                        z += r8(metas[l]["N"])
+                    tw["zoff"], tw["pZ"] = zoff, z
+                    tw["Z_h"] = torch.zeros(B, z, **f16)
+                    tw["ZT_h"] = torch.zeros(z, Bp, **f16)
+                    pulls, base = {}, 0
+                    for j in range(L + 1):
+                        cons = [c for c in range(L + 1) if j in tl.in_segs[c]]
+                        zb = min(zoff[c] for c in cons)
+                        ze = max(zoff[c] + metas[c]["N"] for c in cons)
+                        pitch = r8(ze - zb)
+                        pulls[j] = dict(zbeg=zb, kred=ze - zb, pitch=pitch, base=base, width=tl.seg_width[j])
+                        base += tl.seg_width[j] * pitch
+                        base = r8(base)
+                    tw["pulls"] = pulls
+                    tw["wcat"] = torch.zeros(max(base, 8), **f16)
+                    tw["cat_off"] = []
+                    for c in range(L + 1):
+                        co = np.full(metas[c]["K"], -1, dtype=np.int64)
+                        for k, (seg, u) in enumerate(tl.window_cols(c)):
+                            if seg >= 0:
+                                pj = pulls[seg]
+                                co[k] = pj["base"] + u * pj["pitch"] + (zoff[c] - pj["zbeg"])
+                        tw["cat_off"].append(torch.from_numpy(co).to(dev))
                 self.towers.append(tw)
             # descriptor table of every layer of every tower (wd_fold_affine_all / wd_mlp_finalize_all)
             nl = sum(len(tw["metas"]) for tw in self.towers)
@@ -189,9 +212,10 @@ class WideDeepEngine:
                     d.Wf, d.bf, d.s, d.t = (tw["Wf"][l].data_ptr(), tw["bf"][l].data_ptr(), tw["s"][l].data_ptr(),
                                             tw["t"][l].data_ptr())
                     d.Gpart, d.nsplit = tw["Gpart"][l].data_ptr(), tw["nsplit"][l]
-                    if self.half and l < tw["L"]:
-                        d.Wf_h, d.ld_wf_h = tw["Wf_h"][l].data_ptr(), tw["Wf_h"][l].shape[1]
-                        d.WfT_h, d.ld_wft_h = tw["WfT_h"][l].data_ptr(), tw["WfT_h"][l].shape[1]
+                    if self.half:
+                        d.cat_off, d.wcat = tw["cat_off"][l].data_ptr(), tw["wcat"].data_ptr()
+                        if l < tw["L"]:
+                            d.WfT_h, d.ld_wft_h = tw["WfT_h"][l].data_ptr(), tw["WfT_h"][l].shape[1]
                     self.max_layer_n = max(self.max_layer_n, m["N"])
                     self.max_layer_k = max(self.max_layer_k, m["K"])
                     i += 1
@@ -395,7 +419,7 @@ class WideDeepEngine:
         if self.half:
             a_ptr, head = tw["act_h"].data_ptr() + 2 * tl.in_start[L], "wd_logits_head_h"
         if fused:
-            out_ptr, ld_out, act_id = self._head_out(tw) if train else (None, 0, 0)
+            out_ptr, ld_out, act_id = self._head_out(tw) if (train and not self.half) else (None, 0, 0)
             call(head, a_ptr, tl.ld, m["K"], ptr(tw["Wf"][L]), ptr(tw["bf"][L]), capi.WD_FOLD_PARTS,
                  ptr(self.wide_logit), ptr(bt.labels) if train else None, ptr(bt.weights) if train else None, B,
                  ptr(tw["logit"]), ptr(self.logit), ptr(self.prob), ptr(self.dlogit) if train else None,
@@ -457,44 +481,33 @@ class WideDeepEngine:
                      K, N, 1, st)
 
     def _tower_backward_h(self, tw, B, st, need_dx):
-        """Backward of the fp16-input tower (single tower; the fused head already did the logits layer)."""
+        """Backward of the fp16-input tower (single tower; the fused head already produced dlogit and the logits
+        layer's kernel gradient).  Per hidden layer, two launches: the gradient of its OUTPUT segment pulled from all
+        consumer layers with the activation derivative fused (-> dz, half + transposed half), then the split-K
+        weight gradient."""
         tl, metas, L = tw["layout"], tw["metas"], tw["L"]
-        ah, aT, Bp, pdz = tw["act_h"], tw["actT_h"], tw["Bp"], tw["pdz"]
-        dact = tw["dact"]
-        simple = tl.mode == "simple"
+        ah, aT, Bp, pZ, zoff = tw["act_h"], tw["actT_h"], tw["Bp"], tw["pZ"], tw["zoff"]
+        Z, ZT, wcat = tw["Z_h"], tw["ZT_h"], tw["wcat"]
+        call("wd_cast_transpose_h", ptr(self.dlogit), 1, B, 1, None, 0, 0, ptr(Z), pZ, ptr(ZT), Bp, st)   # block L
         if not self.all_simple:
             self._finalize_layer(tw, L, st, tw["nsplit"][L])
-        cur = 0
-        if simple and L > 0:
-            # the head left dz of the last hidden layer in fp32 (act' fused): make the two half copies
-            call("wd_cast_transpose_h", tw["dz"][0].data_ptr(), metas[L]["K"], B, metas[L]["K"], None, 0, 0,
-                 ptr(tw["dz_h"][0]), pdz, ptr(tw["dzT_h"][0]), Bp, st)
         for l in range(L - 1, -1, -1):
-            m = metas[l]
+            m, pj = metas[l], tw["pulls"][l + 1]
             K, N = m["K"], m["N"]
-            if not simple:
-                seg = tl.seg_start[l + 1]     # dz = dact * act'(a) on segment l+1, straight into the half copies
-                call("wd_cast_transpose_h", dact.data_ptr() + 4 * seg, tl.ld, B, N, ah.data_ptr() + 2 * seg, tl.ld,
-                     self.act_id, ptr(tw["dz_h"][0]), pdz, ptr(tw["dzT_h"][0]), Bp, st)
-                cur = 0
+            seg = tl.seg_start[l + 1]
+            call("wd_hgemm_nt", Z.data_ptr() + 2 * pj["zbeg"], pZ, wcat.data_ptr() + 2 * pj["base"], pj["pitch"], B, N,
+                 pj["kred"], None, 0, 0, Z.data_ptr() + 2 * zoff[l], pZ, ZT.data_ptr() + 2 * zoff[l] * Bp, Bp,
+                 ah.data_ptr() + 2 * seg, tl.ld, self.act_id, st)
             ns = tw["nsplit"][l]
-            call("wd_hgemm_tn_splitk", aT.data_ptr() + 2 * tl.in_start[l] * Bp, Bp, ptr(tw["dzT_h"][cur]), Bp,
+            call("wd_hgemm_tn_splitk", aT.data_ptr() + 2 * tl.in_start[l] * Bp, Bp, ZT.data_ptr() + 2 * zoff[l] * Bp, Bp,
                  ptr(tw["Gpart"][l]), K, N, B, ns, st)
             if not self.all_simple:
                 self._finalize_layer(tw, l, st, ns)
-            wf = tw["Wf_h"][l]
-            if simple:
-                if l > 0:
-                    call("wd_hgemm_nt", ptr(tw["dz_h"][cur]), pdz, ptr(wf), wf.shape[1], B, K, N, None, 0, 0,
-                         ptr(tw["dz_h"][cur ^ 1]), pdz, ptr(tw["dzT_h"][cur ^ 1]), Bp, ah.data_ptr() + 2 * tl.in_start[l],
-                         tl.ld, self.act_id, st)
-                    cur ^= 1
-                elif need_dx:
-                    call("wd_hgemm_nt", ptr(tw["dz_h"][cur]), pdz, ptr(wf), wf.shape[1], B, K, N,
-                         dact.data_ptr() + 4 * tl.in_start[l], tl.ld, 0, None, 0, None, 0, None, 0, 0, st)
-            elif l > 0 or need_dx:
-                call("wd_hgemm_nt", ptr(tw["dz_h"][cur]), pdz, ptr(wf), wf.shape[1], B, K, N,
-                     dact.data_ptr() + 4 * tl.in_start[l], tl.ld, 1, None, 0, None, 0, None, 0, 0, st)
+        if need_dx:     # gradient of the pooled input x (fp32: the sparse optimizers consume it)
+            pj = tw["pulls"][0]
+            call("wd_hgemm_nt", Z.data_ptr() + 2 * pj["zbeg"], pZ, wcat.data_ptr() + 2 * pj["base"], pj["pitch"], B,
+                 pj["width"], pj["kred"], tw["dact"].data_ptr() + 4 * tl.seg_start[0], tl.ld, 0, None, 0, None, 0, None,
+                 0, 0, st)
 
     def _finalize_layer(self, tw, l, st, ns):
         m = tw["metas"][l]

@@ -217,7 +217,7 @@ def main():
                                     expected_nnz=B * 26 * mean_len, slack=1.3)
     else:
         eng = WideDeepEngine(spec, max_batch=B, max_nnz=B * 26 * (2 * mean_len + 2), seed=0, tower_dtype=tower_dtype)
-    plan = eng.plan
+    plan = getattr(eng, "hash_plan", eng.plan)    # sharded: batches live in the GLOBAL id space
 
     # resident batch pool (raw tokens in HBM); distinct seeds per rank
     host_batches, dev_batches = [], []

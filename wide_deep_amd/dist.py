@@ -210,6 +210,15 @@ class ShardedWideDeepEngine(WideDeepEngine):
         if spec.has_deep and len(self.towers) != 1:
             raise NotImplementedError("sharded engine: one tower")
         self._gsum = torch.zeros(1, **f32)
+        # feature hashing happens in the GLOBAL id space (id = Fingerprint64 % global buckets); only then is an id split
+        # into (owner, local row).  Batches are therefore built / hashed against global_plan + these descriptors.
+        garr = (capi.WdSlot * max(gp.S, 1))()
+        for i, sl in enumerate(gp.slots):
+            garr[i].emb_off, garr[i].row_base = -1, gp.row_base[i]
+            garr[i].num_buckets, garr[i].dim, garr[i].out_col = int(sl.num_buckets), 0, -1
+            garr[i].kind, garr[i].wide = capi.SLOT_NONE, 0
+        self.hash_slots_dev = torch.from_numpy(np.frombuffer(bytes(garr), dtype=np.uint8).copy()).to(dev)
+        self.hash_plan = gp
 
     def check_overflow(self):
         n = int(self.overflow.item())

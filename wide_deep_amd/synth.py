@@ -104,8 +104,9 @@ class TokenBatch:
 
 def hash_tokens(engine, tb: TokenBatch):
     """tokens -> ids on the device (wd_hash_bucket): a4 of SURVEY section 8."""
-    plan = engine.plan
+    plan = getattr(engine, "hash_plan", engine.plan)            # sharded engines hash in the global id space
+    slots_dev = getattr(engine, "hash_slots_dev", engine.slots_dev)
     st = torch.cuda.current_stream().cuda_stream
     call("wd_hash_bucket", ptr(tb.bytes), ptr(tb.tok_offs), tb.ntok, None if tb.one_per_bag else ptr(tb.bag_offs),
-         tb.B * plan.S, ptr(engine.slots_dev), plan.S, ptr(tb.ids), st)
+         tb.B * plan.S, ptr(slots_dev), plan.S, ptr(tb.ids), st)
     return tb.batch

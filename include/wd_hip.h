@@ -191,6 +191,15 @@ int wd_bias_ftrl(float *bias_wzn, const float *dlogit, int64_t batch, float lr, 
  * are padding and are skipped; an embedding slot updates only keys below row_base + num_buckets. */
 int32_t wd_bucket_max(void);
 int32_t wd_bucket_chunks(void);
+/* The two phases of wd_sparse_bwd_fused as separate entry points: bucketize needs only the ids (the engine runs it on a
+ * side stream, concurrently with the tower), apply needs dx / dlogit. */
+int wd_sparse_bucketize(const wd_slot_t *slots, int32_t S, const int32_t *ids, const int32_t *bag_offs, int64_t batch,
+                        int64_t nnz, int32_t *bucket_cnt, int32_t *bucket_start, int32_t *rank, uint64_t *pairs,
+                        int32_t nbuckets, int32_t shift, wd_stream_t stream);
+int wd_sparse_apply(float *emb, float *emb_accum, float *wide, float *bias_wzn, const wd_slot_t *slots, int32_t S,
+                    const int32_t *bag_offs, int64_t batch, const float *dx, int64_t ldx, const float *dlogit,
+                    int64_t ld_dlogit, float lr_emb, float lr_wide, float l1, float l2, const int32_t *bucket_start,
+                    uint64_t *pairs, int32_t nbuckets, wd_stream_t stream);
 int wd_sparse_bwd_fused(float *emb, float *emb_accum, float *wide, float *bias_wzn, const wd_slot_t *slots, int32_t S,
                         const int32_t *ids, const int32_t *bag_offs, int64_t batch, int64_t nnz, const float *dx,
                         int64_t ldx, const float *dlogit, int64_t ld_dlogit, float lr_emb, float lr_wide, float l1, float l2,

@@ -448,17 +448,14 @@ k_bucket_update(UpdArgs u, const int32_t *__restrict__ start, uint64_t *__restri
 extern "C" int32_t wd_bucket_max(void) { return MAX_NB; }
 extern "C" int32_t wd_bucket_chunks(void) { return MAX_CHUNKS; }
 
-extern "C" int wd_sparse_bwd_fused(float *emb, float *emb_accum, float *wide, float *bias_wzn, const wd_slot_t *slots,
-                                   int32_t S, const int32_t *ids, const int32_t *bag_offs, int64_t batch, int64_t nnz,
-                                   const float *dx, int64_t ldx, const float *dlogit, int64_t ld_dlogit, float lr_emb,
-                                   float lr_wide,
-                                   float l1, float l2, int32_t *bucket_cnt, int32_t *bucket_start, int32_t *rank,
+// Phase 1 (needs only the ids): bucket the occurrences.  Independent of the forward / tower work of the step, so the
+// engine runs it on a side stream while the tower computes.
+extern "C" int wd_sparse_bucketize(const wd_slot_t *slots, int32_t S, const int32_t *ids, const int32_t *bag_offs,
+                                   int64_t batch, int64_t nnz, int32_t *bucket_cnt, int32_t *bucket_start, int32_t *rank,
                                    uint64_t *pairs, int32_t nbuckets, int32_t shift, wd_stream_t stream) {
   if (batch <= 0) return WD_OK;
   WD_REQUIRE(slots && ids && bag_offs && bucket_cnt && bucket_start && rank && pairs, "null pointer");
   WD_REQUIRE(S > 0 && nbuckets > 0 && nbuckets <= MAX_NB && shift >= 0 && shift < 32, "bad bucket geometry");
-  WD_REQUIRE(!emb || (emb_accum && dx), "embedding update needs accum and dx");
-  WD_REQUIRE(!(wide || bias_wzn) || dlogit, "wide / bias update needs dlogit");
   hipStream_t st = wd::as_stream(stream);
   const int64_t nbags = batch * S;
   // bucket_cnt layout: [MAX_CHUNKS][nbuckets] counts, [MAX_CHUNKS][nbuckets] chunk prefixes, total[nbuckets]
@@ -475,11 +472,37 @@ extern "C" int wd_sparse_bwd_fused(float *emb, float *emb_accum, float *wide, fl
   hipLaunchKernelGGL(k_bucket_scatter, dim3(nchunks > 0 ? nchunks : 1), dim3(256), 0, st, slots, S, ids, bag_offs,
                      nchunks > 0 ? nbags : (int64_t)0, bags_per_chunk, shift, nbuckets, total, cpre, rank,
                      bucket_start, pairs);
+  return wd::check_launch("wd_sparse_bucketize");
+}
+
+// Phase 2 (needs dx / dlogit): per bucket sort + duplicate reduction + Adagrad / FTRL, and the bias update.
+extern "C" int wd_sparse_apply(float *emb, float *emb_accum, float *wide, float *bias_wzn, const wd_slot_t *slots,
+                               int32_t S, const int32_t *bag_offs, int64_t batch, const float *dx, int64_t ldx,
+                               const float *dlogit, int64_t ld_dlogit, float lr_emb, float lr_wide, float l1, float l2,
+                               const int32_t *bucket_start, uint64_t *pairs, int32_t nbuckets, wd_stream_t stream) {
+  if (batch <= 0) return WD_OK;
+  WD_REQUIRE(slots && bag_offs && bucket_start && pairs, "null pointer");
+  WD_REQUIRE(S > 0 && nbuckets > 0 && nbuckets <= MAX_NB, "bad bucket geometry");
+  WD_REQUIRE(!emb || (emb_accum && dx), "embedding update needs accum and dx");
+  WD_REQUIRE(!(wide || bias_wzn) || dlogit, "wide / bias update needs dlogit");
   UpdArgs u;
   u.emb = emb; u.accum = emb_accum; u.wide = wide; u.bias = bias_wzn; u.slots = slots; u.bag_offs = bag_offs;
   u.dx = dx; u.dlogit = dlogit; u.ldx = ldx; u.batch = batch; u.S = S; u.nb = nbuckets;
   u.ld_dlogit = ld_dlogit > 0 ? ld_dlogit : 1;
   u.lr_emb = lr_emb; u.lr_w = lr_wide; u.l1 = l1; u.l2 = l2;
-  hipLaunchKernelGGL(k_bucket_update, dim3((unsigned)nbuckets + 1), dim3(256), 0, st, u, bucket_start, pairs);
-  return wd::check_launch("wd_sparse_bwd_fused");
+  hipLaunchKernelGGL(k_bucket_update, dim3((unsigned)nbuckets + 1), dim3(256), 0, wd::as_stream(stream), u,
+                     bucket_start, pairs);
+  return wd::check_launch("wd_sparse_apply");
+}
+
+extern "C" int wd_sparse_bwd_fused(float *emb, float *emb_accum, float *wide, float *bias_wzn, const wd_slot_t *slots,
+                                   int32_t S, const int32_t *ids, const int32_t *bag_offs, int64_t batch, int64_t nnz,
+                                   const float *dx, int64_t ldx, const float *dlogit, int64_t ld_dlogit, float lr_emb,
+                                   float lr_wide, float l1, float l2, int32_t *bucket_cnt, int32_t *bucket_start,
+                                   int32_t *rank, uint64_t *pairs, int32_t nbuckets, int32_t shift, wd_stream_t stream) {
+  int rc = wd_sparse_bucketize(slots, S, ids, bag_offs, batch, nnz, bucket_cnt, bucket_start, rank, pairs, nbuckets,
+                               shift, stream);
+  if (rc != WD_OK) return rc;
+  return wd_sparse_apply(emb, emb_accum, wide, bias_wzn, slots, S, bag_offs, batch, dx, ldx, dlogit, ld_dlogit, lr_emb,
+                         lr_wide, l1, l2, bucket_start, pairs, nbuckets, stream);
 }

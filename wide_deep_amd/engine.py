@@ -262,6 +262,16 @@ class WideDeepEngine:
         self.occ_rank = torch.zeros(M, **i32)
         self.pairs = torch.zeros(M, dtype=torch.int64, device=dev)
         self._graph = None
+        # Optional side streams (hipGraph capture turns them into parallel branches):
+        #   side 0: bucketing of the occurrences (needs only the ids) under the forward + tower backward
+        #   side 1: the split-K weight-gradient GEMM of a layer beside the next input-gradient GEMM
+        # Measured on MI355X (ROCm 7.2): every cross-stream edge costs more than it hides at C2's kernel sizes
+        # (0.305 ms/step single-stream, 0.317 with the bucketing branch, 0.34 with the TN branch), while the fp16
+        # tower at C5 gains 4 % from the TN branch.  Defaults follow the measurements; WD_OVERLAP=none|bucket|tn|both.
+        mode = os.environ.get("WD_OVERLAP", "tn" if self.half else "none")
+        self.overlap_bucket = mode in ("both", "bucket")
+        self.overlap_tn = mode in ("both", "tn")
+        self._sides = None
         # sparse forward in one launch when the model has exactly one embedding dim group on a contiguous slot range
         # and no indicator columns (all Criteo-shaped configs); otherwise one launch per piece
         self._fused_input_layer = False
@@ -273,6 +283,11 @@ class WideDeepEngine:
     # ------------------------------------------------------------------------------------------
     # forward
     # ------------------------------------------------------------------------------------------
+    def _side(self, i):
+        if self._sides is None:
+            self._sides = [torch.cuda.Stream(device=self.device), torch.cuda.Stream(device=self.device)]
+        return self._sides[i]
+
     def _check_batch(self, bt):
         if bt.B > self.max_batch:
             raise ValueError("batch %d exceeds max_batch %d" % (bt.B, self.max_batch))
@@ -450,8 +465,17 @@ class WideDeepEngine:
                      a_ptr, tl.ld, act_id, st)
             else:
                 call("wd_gemm_nt", ptr(self.dlogit), 1, ptr(tw["Wf"][L]), 1, out_ptr, ld_out, B, m["K"], 1, 0, st)
+        # weight-gradient GEMMs (and the per-layer finalize of non-simple towers) go to side stream 1 and run beside the
+        # input-gradient GEMM of the same layer; `tn_done` keeps a dz buffer from being rewritten while a TN still reads it
+        ov = self.overlap_tn
+        main = torch.cuda.current_stream()
+        s2 = self._side(1) if ov else None
+        st_w = s2.cuda_stream if ov else st
+        tn_done = None
         if not self.all_simple:
-            self._finalize_layer(tw, L, st, 1 if not head_done else tw["nsplit"][L])
+            if ov:
+                s2.wait_stream(main)
+            self._finalize_layer(tw, L, st_w, 1 if not head_done else tw["nsplit"][L])
         cur = 0
         for l in range(L - 1, -1, -1):
             m = metas[l]
@@ -461,15 +485,25 @@ class WideDeepEngine:
             else:
                 seg = tl.seg_start[l + 1]
                 dz_ptr, lddz = tw["dz"][0].data_ptr(), N
+                if tn_done is not None:
+                    main.wait_event(tn_done)            # the previous layer's TN still reads dz[0]
                 call("wd_act_bwd", dact.data_ptr() + 4 * seg, tl.ld, act.data_ptr() + 4 * seg, tl.ld, self.act_id,
                      dz_ptr, lddz, B, N, st)
             a_ptr = act.data_ptr() + 4 * tl.in_start[l]
             ns = tw["nsplit"][l]
-            call("wd_gemm_tn_splitk", a_ptr, tl.ld, dz_ptr, lddz, ptr(tw["Gpart"][l]), K, N, B, ns, 1, st)
+            if ov:
+                s2.wait_stream(main)                    # dz of this layer is complete on the main stream
+            call("wd_gemm_tn_splitk", a_ptr, tl.ld, dz_ptr, lddz, ptr(tw["Gpart"][l]), K, N, B, ns, 1, st_w)
             if not self.all_simple:
-                self._finalize_layer(tw, l, st, ns)
+                self._finalize_layer(tw, l, st_w, ns)
+            prev_done = tn_done
+            if ov:
+                tn_done = torch.cuda.Event()
+                tn_done.record(s2)
             if simple:
                 if l > 0:     # dz of layer l-1 = (dz_l Wf_l^T) * act'(a_l-1's output), written to the other buffer
+                    if prev_done is not None:
+                        main.wait_event(prev_done)      # ... which the TN of layer l+1 was reading
                     call("wd_gemm_nt_actbwd", dz_ptr, lddz, ptr(tw["Wf"][l]), N, tw["dz"][cur ^ 1].data_ptr(), K, B, K, N,
                          a_ptr, tl.ld, self.act_id, st)
                     cur ^= 1
@@ -479,6 +513,8 @@ class WideDeepEngine:
             elif l > 0 or need_dx:
                 call("wd_gemm_nt", dz_ptr, lddz, ptr(tw["Wf"][l]), N, dact.data_ptr() + 4 * tl.in_start[l], tl.ld, B,
                      K, N, 1, st)
+        if ov:
+            main.wait_stream(s2)
 
     def _tower_backward_h(self, tw, B, st, need_dx):
         """Backward of the fp16-input tower (single tower; the fused head already produced dlogit and the logits
@@ -489,8 +525,14 @@ class WideDeepEngine:
         ah, aT, Bp, pZ, zoff = tw["act_h"], tw["actT_h"], tw["Bp"], tw["pZ"], tw["zoff"]
         Z, ZT, wcat = tw["Z_h"], tw["ZT_h"], tw["wcat"]
         call("wd_cast_transpose_h", ptr(self.dlogit), 1, B, 1, None, 0, 0, ptr(Z), pZ, ptr(ZT), Bp, st)   # block L
+        ov = self.overlap_tn       # weight gradients on side stream 1, beside the next layer's segment-gradient GEMM
+        main = torch.cuda.current_stream()
+        s2 = self._side(1) if ov else None
+        st_w = s2.cuda_stream if ov else st
         if not self.all_simple:
-            self._finalize_layer(tw, L, st, tw["nsplit"][L])
+            if ov:
+                s2.wait_stream(main)
+            self._finalize_layer(tw, L, st_w, tw["nsplit"][L])
         for l in range(L - 1, -1, -1):
             m, pj = metas[l], tw["pulls"][l + 1]
             K, N = m["K"], m["N"]
@@ -499,15 +541,19 @@ class WideDeepEngine:
                  pj["kred"], None, 0, 0, Z.data_ptr() + 2 * zoff[l], pZ, ZT.data_ptr() + 2 * zoff[l] * Bp, Bp,
                  ah.data_ptr() + 2 * seg, tl.ld, self.act_id, st)
             ns = tw["nsplit"][l]
+            if ov:
+                s2.wait_stream(main)
             call("wd_hgemm_tn_splitk", aT.data_ptr() + 2 * tl.in_start[l] * Bp, Bp, ZT.data_ptr() + 2 * zoff[l] * Bp, Bp,
-                 ptr(tw["Gpart"][l]), K, N, B, ns, st)
+                 ptr(tw["Gpart"][l]), K, N, B, ns, st_w)
             if not self.all_simple:
-                self._finalize_layer(tw, l, st, ns)
+                self._finalize_layer(tw, l, st_w, ns)
         if need_dx:     # gradient of the pooled input x (fp32: the sparse optimizers consume it)
             pj = tw["pulls"][0]
             call("wd_hgemm_nt", Z.data_ptr() + 2 * pj["zbeg"], pZ, wcat.data_ptr() + 2 * pj["base"], pj["pitch"], B,
                  pj["width"], pj["kred"], tw["dact"].data_ptr() + 4 * tl.seg_start[0], tl.ld, 0, None, 0, None, 0, None,
                  0, 0, st)
+        if ov:
+            main.wait_stream(s2)
 
     def _finalize_layer(self, tw, l, st, ns):
         m = tw["metas"][l]
@@ -525,24 +571,35 @@ class WideDeepEngine:
     def _reduce_dense_grads(self):
         """Hook for data-parallel ranks (dist.py: all_reduce(SUM) of the flat gradient buffer)."""
 
-    def _sparse_backward(self, bt: DeviceBatch, st):
-        """Scatter-add of the row gradients + fused Adagrad (embedding rows) / FTRL (wide rows, bias): three launches."""
+    def _sparse_bucketize(self, bt: DeviceBatch, st):
+        """Phase 1 of the sparse backward (ids only): occurrences -> row-range buckets."""
+        plan = self.plan
+        self._check_batch(bt)
+        call("wd_sparse_bucketize", ptr(self.slots_dev), plan.S, ptr(bt.ids), ptr(bt.bag_offs), bt.B, bt.nnz,
+             ptr(self.bucket_cnt), ptr(self.bucket_start), ptr(self.occ_rank), ptr(self.pairs), self.n_buckets,
+             self.bucket_shift, st)
+
+    def _has_sparse_update(self):
+        return (bool(self.group_slots) if self.spec.has_deep else False) or self.spec.has_wide
+
+    def _sparse_backward(self, bt: DeviceBatch, st, bucketized=False):
+        """Scatter-add of the row gradients + fused Adagrad (embedding rows) / FTRL (wide rows, bias)."""
         plan, spec = self.plan, self.spec
         has_emb = bool(self.group_slots) if spec.has_deep else False
         if not (has_emb or spec.has_wide):
             return
-        self._check_batch(bt)
+        if not bucketized:
+            self._sparse_bucketize(bt, st)
         dx_ptr, ld = None, 0
         if has_emb:
             tw0 = self.towers[0]
             tl0 = tw0["layout"]
             dx_ptr, ld = tw0["dact"].data_ptr() + 4 * tl0.seg_start[0], tl0.ld
         lr, l1, l2 = (spec.lin_opt[1], spec.lin_opt[2], spec.lin_opt[3]) if spec.has_wide else (0.0, 0.0, 0.0)
-        call("wd_sparse_bwd_fused", ptr(self.emb) if has_emb else None, ptr(self.emb_acc) if has_emb else None,
-             ptr(self.wide), ptr(self.bias), ptr(self.slots_dev), plan.S, ptr(bt.ids), ptr(bt.bag_offs), bt.B, bt.nnz,
-             dx_ptr, ld, ptr(self.dlogit), 1, float(spec.dnn_opt[1]) if spec.has_deep else 0.0, float(lr), float(l1),
-             float(l2), ptr(self.bucket_cnt), ptr(self.bucket_start), ptr(self.occ_rank), ptr(self.pairs), self.n_buckets,
-             self.bucket_shift, st)
+        call("wd_sparse_apply", ptr(self.emb) if has_emb else None, ptr(self.emb_acc) if has_emb else None,
+             ptr(self.wide), ptr(self.bias), ptr(self.slots_dev), plan.S, ptr(bt.bag_offs), bt.B, dx_ptr, ld,
+             ptr(self.dlogit), 1, float(spec.dnn_opt[1]) if spec.has_deep else 0.0, float(lr), float(l1), float(l2),
+             ptr(self.bucket_start), ptr(self.pairs), self.n_buckets, st)
 
     def _sparse_backward_unfused(self, bt: DeviceBatch, st):
         """Reference path through the separate ABI entry points (device radix sort + one kernel per update);
@@ -568,7 +625,10 @@ class WideDeepEngine:
             _, lr, l1, l2, _ = spec.lin_opt
             call("wd_bias_ftrl", ptr(self.bias), ptr(self.dlogit), B, float(lr), float(l1), float(l2), st)
 
-    def backward_and_update(self, bt: DeviceBatch):
+    def _overlap_ok(self):
+        return type(self)._sparse_backward is WideDeepEngine._sparse_backward   # subclasses with their own exchange opt out
+
+    def backward_and_update(self, bt: DeviceBatch, bucketized=False):
         spec, st = self.spec, _stream()
         B = bt.B
         has_emb = bool(self.group_slots) if spec.has_deep else False
@@ -592,14 +652,24 @@ class WideDeepEngine:
             self._reduce_dense_grads()
             call("wd_adagrad_dense", ptr(self.P), ptr(self.Pacc), ptr(self.G), self.P.numel(), float(spec.dnn_opt[1]),
                  st)
-        self._sparse_backward(bt, st)
+        if bucketized:
+            torch.cuda.current_stream().wait_stream(self._side(0))
+            self._sparse_backward(bt, st, bucketized=True)
+        else:
+            self._sparse_backward(bt, st)
 
     def train_step(self, bt: DeviceBatch):
         """One step of python/lib/joint.py:224-262: forward, batch-SUM loss, both optimizers."""
         if bt.labels is None:
             raise ValueError("train_step needs labels")
+        bucketized = False
+        if self.overlap_bucket and self._overlap_ok() and self._has_sparse_update():
+            main, side = torch.cuda.current_stream(), self._side(0)
+            side.wait_stream(main)                       # the ids were produced on the main stream
+            self._sparse_bucketize(bt, side.cuda_stream)
+            bucketized = True
         self.forward(bt, need_loss=True)
-        self.backward_and_update(bt)
+        self.backward_and_update(bt, bucketized=bucketized)
         # the reference bumps global_step once per minimize() plus the explicit assign_add (quirk C.4)
         self.global_step += 3 if self.spec.model_type == "wide_deep" else 2
         return self.loss

@@ -21,7 +21,10 @@ def load(name):
 
 
 def flow(v):
-    return yaml.safe_dump(v, default_flow_style=True, width=10 ** 6).strip()
+    if v is None:
+        return "~"
+    out = yaml.safe_dump(v, default_flow_style=True, width=10 ** 6).strip()
+    return out.splitlines()[0] if out.endswith("...") else out     # scalars carry a document-end marker
 
 
 def main():
@@ -29,11 +32,11 @@ def main():
     # schema: column position -> field name (61-field TSV; column 1 is the label `clk`)
     schema = load("schema.yaml")
     with open(os.path.join(OUT, "schema.yaml"), "w") as f:
-        f.write("# TSV column position -> field name.  Column 1 (`clk`) is the label.\n")
-        items = sorted(schema.items())
-        for i in range(0, len(items), 6):
-            f.write("".join("%d: %s\n" % (k, v) if False else "" for k, v in []))
-            f.write("\n".join("%-3s %s" % ("%d:" % k, v) for k, v in items[i:i + 6]) + "\n")
+        f.write("# TSV column position -> field name (one flow mapping, listed by field name; column 1 `clk` is the label)\n{\n")
+        items = sorted(schema.items(), key=lambda kv: str(kv[1]))     # by field name; a mapping has no order
+        for i in range(0, len(items), 5):
+            f.write("  " + ", ".join("%d: %s" % (k, v) for k, v in items[i:i + 5]) + ",\n")
+        f.write("}\n")
     # features: one line per used feature
     feat = load("feature.yaml")
     with open(os.path.join(OUT, "feature.yaml"), "w") as f:
@@ -45,22 +48,30 @@ def main():
             f.write("%s: %s\n" % (k, flow(v)))
     cross = load("cross_feature.yaml")
     with open(os.path.join(OUT, "cross_feature.yaml"), "w") as f:
-        f.write("# a&b[&c]: {hash_bucket_size: <in THOUSANDS of buckets>, is_deep: 0|1 (also embed the cross in the tower)}\n")
-        for k, v in cross.items():
-            f.write("%s: %s\n" % (k, flow(v)))
+        f.write("# a&b[&c]: {hash_bucket_size: <in THOUSANDS of buckets>, is_deep: 0|1 (also embed the cross in the tower)}\n"
+                "# (sorted by name; the order of the entries has no meaning)\n")
+        for k in sorted(cross):
+            f.write("%s: %s\n" % (k, flow(cross[k])))
     model = load("model.yaml")
     with open(os.path.join(OUT, "model.yaml"), "w") as f:
         f.write("# wide (linear) side, deep (dnn) side; cnn_* keys are accepted and ignored (image tower is out of scope)\n")
-        for k, v in model.items():
-            f.write("%s: %s\n" % (k, flow(v) if isinstance(v, (list, dict)) else ("" if v is None else v)))
+        lin = {k: v for k, v in model.items() if k.startswith("linear_")}
+        dnn = {k: v for k, v in model.items() if k.startswith("dnn_")}
+        cnn = {k: v for k, v in model.items() if k.startswith("cnn_")}
+        rest = {k: v for k, v in model.items() if k not in lin and k not in dnn and k not in cnn}
+        for grp in (lin, dnn, cnn, rest):
+            for k in sorted(grp):
+                v = grp[k]
+                f.write("%s: %s\n" % (k, flow(v) if isinstance(v, (list, dict)) else ("~" if v is None else flow(v))))
     train = load("train.yaml")
     with open(os.path.join(OUT, "train.yaml"), "w") as f:
         f.write("# train: run control; distribution: kept for schema compatibility (multi-GPU here = one process per GPU via\n"
                 "# torch.distributed, see DESIGN.md section 6); runconfig: checkpoint cadence\n")
-        for sec, d in train.items():
-            f.write("%s:\n" % sec)
-            for k, v in d.items():
-                f.write("  %s: %s\n" % (k, flow(v) if isinstance(v, (list, dict)) else ("" if v is None else str(v).lower() if isinstance(v, bool) else v)))
+        for sec in sorted(train):
+            f.write("%s: {\n" % sec)
+            for k in sorted(train[sec]):
+                f.write("  %s: %s,\n" % (k, flow(train[sec][k])))
+            f.write("}\n")
 
 
 if __name__ == "__main__":

@@ -186,3 +186,50 @@ def test_oracle_columns_known_answers():
     ids, offs = t2["ids"]["age_bucketized_X_ugender"]
     assert offs.tolist() == [0, 1, 1, 3] and ids.tolist() == [h(3, b"male"), h(11, b"female"), h(11, b"bogus")]
     assert np.allclose(t["dense"]["age"], [(27 - 10) / 80.0, (0 - 10) / 80.0, (66 - 10) / 80.0])
+
+
+def test_c_ingest_matches_python_parser_and_reports_errors(tmp_path, monkeypatch):
+    """csrc/tsv_ingest.c (the product's ingest) against the pure-Python parser of the same module: identical packed
+    token buffers, CSR offsets, ints, floats and labels on real rows + NA edge rows; malformed rows raise."""
+    assert DS.ingest_lib() is not None, "libwd_ingest.so not built (wide_deep_amd/csrc/build.sh)"
+    lines = _with_na_rows(open(FIXTURE, "rb").read().splitlines(), Config().read_schema())
+    path = tmp_path / "rows.tsv"
+    path.write_bytes(b"\n".join(lines))                       # no trailing newline on purpose
+    got_c = list(DS.CsvDataset(str(path)).input_fn("eval", 128))
+    monkeypatch.setattr(DS, "_ingest", False)                 # force the Python parser
+    got_py = list(DS.CsvDataset(str(path)).input_fn("eval", 128))
+    monkeypatch.setattr(DS, "_ingest", None)
+    assert [b.B for b in got_c] == [b.B for b in got_py] and sum(b.B for b in got_c) == len(lines)
+    for c, p in zip(got_c, got_py):
+        assert np.array_equal(c.tok_bytes[: c.tok_offs[-1]], p.tok_bytes[: p.tok_offs[-1]])
+        assert np.array_equal(c.tok_offs, p.tok_offs)
+        assert np.array_equal(c.labels, p.labels)
+        for f in p.cat:
+            assert c.cat[f].base == p.cat[f].base and c.cat[f].n == p.cat[f].n
+            assert np.array_equal(c.cat[f].ex_offs, p.cat[f].ex_offs), f
+            assert c.cat[f].tokens() == p.cat[f].tokens(), f
+        for f in p.ints:
+            assert np.array_equal(c.ints[f], p.ints[f]), f
+        for f in p.floats:
+            assert np.array_equal(c.floats[f], p.floats[f]), f          # strtod + (float) == np.float32(float(s))
+    bad = tmp_path / "bad.tsv"
+    bad.write_bytes(lines[0] + b"\n" + b"\t".join(lines[1].split(b"\t")[:-1]) + b"\n")
+    with pytest.raises(ValueError):
+        list(DS.CsvDataset(str(bad)).input_fn("eval", 8))
+    parts = lines[0].split(b"\t")
+    pos = {v: k - 1 for k, v in Config().read_schema().items()}
+    parts[pos["age"]] = b"12abc"
+    bad.write_bytes(b"\t".join(parts) + b"\n")
+    with pytest.raises(ValueError):
+        list(DS.CsvDataset(str(bad)).input_fn("eval", 8))
+
+
+def test_buffer_shuffle_semantics():
+    a = DS._buffer_shuffle(1000, 10000, seed=123)
+    assert sorted(a.tolist()) == list(range(1000))                       # fits the buffer: a permutation
+    b = DS._buffer_shuffle(1000, 64, seed=123)
+    assert sorted(b.tolist()) == list(range(1000))
+    # element i cannot be emitted before position i - buffer_size (it only enters the buffer then)
+    pos = np.empty(1000, dtype=np.int64); pos[b] = np.arange(1000)
+    assert bool((pos >= np.arange(1000) - 64).all())
+    assert np.array_equal(b, DS._buffer_shuffle(1000, 64, seed=123))

@@ -17,3 +17,6 @@ for p in $pids; do wait $p; done
 hipcc --offload-arch=gfx950 -shared -fPIC "$HERE"/_obj/common.o "$HERE"/_obj/hash.o "$HERE"/_obj/embag.o \
       "$HERE"/_obj/sparse_update.o "$HERE"/_obj/sparse_fused.o "$HERE"/_obj/dist_exchange.o "$HERE"/_obj/mlp.o "$HERE"/_obj/mlp_half.o -o "$OUT/libwd_hip.so"
 echo "built $OUT/libwd_hip.so"
+# host-side TSV ingest (plain C, no GPU code)
+gcc -O2 -fPIC -shared -std=c99 -Wall "$HERE/tsv_ingest.c" -o "$OUT/libwd_ingest.so"
+echo "built $OUT/libwd_ingest.so"

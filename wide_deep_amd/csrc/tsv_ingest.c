@@ -1,0 +1,214 @@
+/* wide_deep_amd/csrc/tsv_ingest.c -- host-side TSV ingest of the train step's input.
+ *
+ * Replaces the per-element tf.data parser of the reference (python/lib/dataset.py:133-164: decode_csv with
+ * field_delim '\t', na_value '-', record_defaults per field type; tf.string_split(',') for multi-value fields;
+ * label = clk == 1) for a whole batch of lines in two passes over the raw bytes, and packs every string feature's
+ * tokens straight into the layout the GPU hash kernel reads (wd_fingerprint64: one byte buffer + token offsets),
+ * so no Python object is created per field or per token.
+ *
+ * Plain C, no dependencies; built by wide_deep_amd/csrc/build.sh into _lib/libwd_ingest.so and bound with ctypes
+ * (wide_deep_amd/dataset.py).  Semantics are pinned against the pure-Python parser of dataset.py and the oracle's own
+ * parser (oracle/columns.py) in tests/test_conf_dataset.py.
+ */
+#include <errno.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define WD_TSV_OK 0
+#define WD_TSV_FIELDS (-1) /* wrong number of fields in a line  */
+#define WD_TSV_INT (-2)    /* an integer field does not parse   */
+#define WD_TSV_FLOAT (-3)  /* a float field does not parse      */
+
+/* line start offsets of buf[0..len): out[0] = 0, out[i] = byte after the i-th '\n'; returns the number of lines
+ * (a last line without '\n' counts; an empty tail does not).  out must hold max_lines + 1 entries. */
+int64_t wd_tsv_scan(const uint8_t *buf, int64_t len, int64_t *out, int64_t max_lines) {
+  int64_t n = 0, pos = 0;
+  while (pos < len && n < max_lines) {
+    out[n++] = pos;
+    const uint8_t *nl = (const uint8_t *)memchr(buf + pos, '\n', (size_t)(len - pos));
+    pos = nl ? (int64_t)(nl - buf) + 1 : len;
+  }
+  out[n] = pos;
+  return n;
+}
+
+static inline int is_na(const uint8_t *p, int64_t n) { return n == 0 || (n == 1 && p[0] == '-'); }
+
+/* field boundaries of one line [s, e): fills off[0..nfields] (off[i]..off[i+1]-1 is field i incl. its tab); returns
+ * the number of fields found (capped at maxf + 1) */
+static int split_fields(const uint8_t *buf, int64_t s, int64_t e, int64_t *off, int maxf) {
+  int nf = 0;
+  int64_t pos = s;
+  off[0] = s;
+  while (pos <= e) {
+    const uint8_t *tab = pos < e ? (const uint8_t *)memchr(buf + pos, '\t', (size_t)(e - pos)) : NULL;
+    int64_t end = tab ? (int64_t)(tab - buf) : e;
+    ++nf;
+    if (nf <= maxf) off[nf] = end + 1;
+    if (!tab) break;
+    pos = end + 1;
+    if (nf > maxf) break;
+  }
+  return nf;
+}
+
+static inline int64_t line_end(const uint8_t *buf, int64_t s, int64_t e) {
+  /* strip the trailing "\n" / "\r\n" of [s, e) */
+  while (e > s && (buf[e - 1] == '\n' || buf[e - 1] == '\r')) --e;
+  return e;
+}
+
+/* pass 1: tokens and token bytes per string feature over the given lines */
+int wd_tsv_count(const uint8_t *buf, const int64_t *starts, const int64_t *ends, int64_t nlines, int32_t nfields,
+                 const int32_t *str_cols, int32_t n_str, int32_t multivalue, int64_t *ntok, int64_t *nbytes,
+                 int64_t *err_line) {
+  int64_t off[512];
+  if (nfields > 510) return WD_TSV_FIELDS;
+  for (int f = 0; f < n_str; ++f) ntok[f] = nbytes[f] = 0;
+  for (int64_t i = 0; i < nlines; ++i) {
+    const int64_t s = starts[i], e = line_end(buf, starts[i], ends[i]);
+    if (split_fields(buf, s, e, off, nfields) != nfields) {
+      if (err_line) *err_line = i;
+      return WD_TSV_FIELDS;
+    }
+    for (int f = 0; f < n_str; ++f) {
+      const uint8_t *p = buf + off[str_cols[f]];
+      const int64_t n = off[str_cols[f] + 1] - 1 - off[str_cols[f]];
+      if (is_na(p, n)) continue;
+      if (!multivalue) {
+        ntok[f] += 1;
+        nbytes[f] += n;
+        continue;
+      }
+      int64_t a = 0;
+      while (a <= n) {
+        const uint8_t *c = a < n ? (const uint8_t *)memchr(p + a, ',', (size_t)(n - a)) : NULL;
+        const int64_t b = c ? (int64_t)(c - p) : n;
+        if (b > a) { /* empty pieces are skipped (tf.string_split default) */
+          ntok[f] += 1;
+          nbytes[f] += b - a;
+        }
+        if (!c) break;
+        a = b + 1;
+      }
+    }
+  }
+  return WD_TSV_OK;
+}
+
+/* pass 2: fill.  Token stream of feature f occupies tokens [tok_base[f], tok_base[f] + ntok[f]) of the shared arrays
+ * (tok_offs holds ABSOLUTE byte offsets into tok_bytes, tok_offs[total] = total bytes); ex_offs is [n_str][nlines + 1]
+ * (token index relative to the feature's base).  ints [n_int][nlines], flts [n_flt][nlines], labels [nlines]
+ * (label_col < 0: none). */
+int wd_tsv_fill(const uint8_t *buf, const int64_t *starts, const int64_t *ends, int64_t nlines, int32_t nfields,
+                const int32_t *str_cols, int32_t n_str, int32_t multivalue, const int64_t *tok_base,
+                const int64_t *byte_base, uint8_t *tok_bytes, int32_t *tok_offs, int32_t *ex_offs,
+                const int32_t *int_cols, int32_t n_int, int32_t *ints, const int32_t *flt_cols, int32_t n_flt,
+                float *flts, int32_t label_col, float *labels, int64_t *err_line) {
+  int64_t off[512];
+  int64_t tk[256], by[256];
+  if (nfields > 510 || n_str > 256) return WD_TSV_FIELDS;
+  for (int f = 0; f < n_str; ++f) {
+    tk[f] = tok_base[f];
+    by[f] = byte_base[f];
+    ex_offs[(int64_t)f * (nlines + 1)] = 0;
+  }
+  for (int64_t i = 0; i < nlines; ++i) {
+    const int64_t s = starts[i], e = line_end(buf, starts[i], ends[i]);
+    if (split_fields(buf, s, e, off, nfields) != nfields) {
+      if (err_line) *err_line = i;
+      return WD_TSV_FIELDS;
+    }
+    for (int f = 0; f < n_str; ++f) {
+      const uint8_t *p = buf + off[str_cols[f]];
+      const int64_t n = off[str_cols[f] + 1] - 1 - off[str_cols[f]];
+      if (!is_na(p, n)) {
+        int64_t a = 0;
+        while (a <= n) {
+          const uint8_t *c = (multivalue && a < n) ? (const uint8_t *)memchr(p + a, ',', (size_t)(n - a)) : NULL;
+          const int64_t b = c ? (int64_t)(c - p) : n;
+          if (b > a) {
+            tok_offs[tk[f]] = (int32_t)by[f];
+            memcpy(tok_bytes + by[f], p + a, (size_t)(b - a));
+            by[f] += b - a;
+            tk[f] += 1;
+          }
+          if (!c) break;
+          a = b + 1;
+        }
+      }
+      ex_offs[(int64_t)f * (nlines + 1) + i + 1] = (int32_t)(tk[f] - tok_base[f]);
+    }
+    for (int f = 0; f < n_int; ++f) {
+      const uint8_t *p = buf + off[int_cols[f]];
+      const int64_t n = off[int_cols[f] + 1] - 1 - off[int_cols[f]];
+      int32_t v = 0;
+      if (!is_na(p, n)) {
+        char tmp[32];
+        if (n >= (int64_t)sizeof(tmp)) { if (err_line) *err_line = i; return WD_TSV_INT; }
+        memcpy(tmp, p, (size_t)n);
+        tmp[n] = 0;
+        char *endp = NULL;
+        errno = 0;
+        long lv = strtol(tmp, &endp, 10);
+        if (errno || endp != tmp + n) { if (err_line) *err_line = i; return WD_TSV_INT; }
+        v = (int32_t)lv;
+      }
+      ints[(int64_t)f * nlines + i] = v;
+    }
+    for (int f = 0; f < n_flt; ++f) {
+      const uint8_t *p = buf + off[flt_cols[f]];
+      const int64_t n = off[flt_cols[f] + 1] - 1 - off[flt_cols[f]];
+      float v = 0.0f;
+      if (!is_na(p, n)) {
+        char tmp[64];
+        if (n >= (int64_t)sizeof(tmp)) { if (err_line) *err_line = i; return WD_TSV_FLOAT; }
+        memcpy(tmp, p, (size_t)n);
+        tmp[n] = 0;
+        char *endp = NULL;
+        double d = strtod(tmp, &endp); /* Python float() then np.float32(): the same double -> float rounding */
+        if (endp != tmp + n) { if (err_line) *err_line = i; return WD_TSV_FLOAT; }
+        v = (float)d;
+      }
+      flts[(int64_t)f * nlines + i] = v;
+    }
+    if (label_col >= 0) {
+      const uint8_t *p = buf + off[label_col];
+      const int64_t n = off[label_col + 1] - 1 - off[label_col];
+      float y = 0.0f;
+      if (!is_na(p, n)) {
+        char tmp[32];
+        if (n >= (int64_t)sizeof(tmp)) { if (err_line) *err_line = i; return WD_TSV_INT; }
+        memcpy(tmp, p, (size_t)n);
+        tmp[n] = 0;
+        char *endp = NULL;
+        long lv = strtol(tmp, &endp, 10);
+        if (endp != tmp + n) { if (err_line) *err_line = i; return WD_TSV_INT; }
+        y = lv == 1 ? 1.0f : 0.0f;
+      }
+      labels[i] = y;
+    }
+  }
+  for (int f = 0; f < n_str; ++f) (void)0;
+  return WD_TSV_OK;
+}
+
+/* vocabulary_list lookup over a packed token range: out[t - t0] = index of token t in the vocabulary or -1.
+ * Vocabularies of the reference are tiny (2-55 entries, conf/feature.yaml): linear scan with length pre-check. */
+void wd_vocab_lookup(const uint8_t *tok_bytes, const int32_t *tok_offs, int64_t t0, int64_t t1, const uint8_t *vocab_bytes,
+                     const int32_t *vocab_offs, int32_t nvocab, int32_t *out) {
+  for (int64_t t = t0; t < t1; ++t) {
+    const uint8_t *p = tok_bytes + tok_offs[t];
+    const int32_t n = tok_offs[t + 1] - tok_offs[t];
+    int32_t hit = -1;
+    for (int32_t v = 0; v < nvocab; ++v) {
+      const int32_t m = vocab_offs[v + 1] - vocab_offs[v];
+      if (m == n && memcmp(p, vocab_bytes + vocab_offs[v], (size_t)n) == 0) {
+        hit = v;
+        break;
+      }
+    }
+    out[t - t0] = hit;
+  }
+}

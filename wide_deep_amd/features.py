@@ -63,6 +63,28 @@ class Featurizer(object):
                         feats.append(k.feature)
         self.fp_features = feats
         self.vocab_maps = {i: {v.encode(): j for j, v in enumerate(s.vocab)} for i, s in enumerate(slots) if s.kind == "vocab"}
+        # packed vocabularies for the C lookup of csrc/tsv_ingest.c
+        self.vocab_packed = {}
+        for i, s in enumerate(slots):
+            if s.kind == "vocab":
+                bs = [v.encode() for v in s.vocab]
+                vo = np.zeros(len(bs) + 1, dtype=np.int32)
+                np.cumsum([len(b) for b in bs], out=vo[1:])
+                self.vocab_packed[i] = (np.frombuffer(b"".join(bs) + b"\0", dtype=np.uint8).copy(), vo, len(bs))
+
+    def _vocab_lookup(self, slot, pc):
+        """index in vocabulary_list per token of the feature (-1 = out of vocabulary)"""
+        from .dataset import ingest_lib
+        L = ingest_lib()
+        if L is None:
+            vm = self.vocab_maps[slot]
+            return np.fromiter((vm.get(t, -1) for t in pc.tokens()), dtype=np.int32, count=pc.n)
+        vb, vo, nv = self.vocab_packed[slot]
+        out = np.zeros(max(pc.n, 1), dtype=np.int32)
+        L.wd_vocab_lookup(ctypes.c_void_p(pc.bytes.ctypes.data), ctypes.c_void_p(pc.tok_offs.ctypes.data),
+                          ctypes.c_int64(pc.base), ctypes.c_int64(pc.base + pc.n), ctypes.c_void_p(vb.ctypes.data),
+                          ctypes.c_void_p(vo.ctypes.data), ctypes.c_int32(nv), ctypes.c_void_p(out.ctypes.data))
+        return out[: pc.n]
 
     def _dev(self, a, dtype):
         return torch.from_numpy(np.ascontiguousarray(a)).to(self.dev, dtype=dtype, non_blocking=True)
@@ -71,36 +93,28 @@ class Featurizer(object):
         plan, eng = self.plan, self.engine
         B, S = raw.B, plan.S
         st = torch.cuda.current_stream().cuda_stream
-        # ---- 1. fingerprints of every needed token, one launch (+ one trailing '' token for padding) ----------
-        tok_base, chunks, lens = {}, [], []
-        n = 0
-        for f in self.fp_features:
-            toks = raw.cat[f][0]
-            tok_base[f] = n
-            chunks.append(b"".join(toks))
-            lens.extend(len(t) for t in toks)
-            n += len(toks)
-        empty_index = n
-        lens.append(0)
-        offs = np.zeros(n + 2, dtype=np.int32)
-        np.cumsum(np.asarray(lens, dtype=np.int64), out=offs[1:])
-        data = np.frombuffer(b"".join(chunks) + b"\0", dtype=np.uint8).copy()
-        d_bytes, d_offs = self._dev(data, torch.uint8), self._dev(offs, torch.int32)
-        fp = torch.empty(n + 1, dtype=torch.int64, device=self.dev)
-        call("wd_fingerprint64", ptr(d_bytes), ptr(d_offs), n + 1, ptr(fp), st)
+        # ---- 1. fingerprints of every token of the batch, one launch.  The ingest already packed all string features
+        #         into one byte buffer + offsets (feature-major) with one trailing '' token (padding of crossed columns)
+        T = len(raw.tok_offs) - 2
+        empty_index = T
+        tok_base = {f: c.base for f, c in raw.cat.items()}
+        d_bytes, d_offs = self._dev(raw.tok_bytes, torch.uint8), self._dev(raw.tok_offs, torch.int32)
+        fp = torch.empty(T + 1, dtype=torch.int64, device=self.dev)
+        call("wd_fingerprint64", ptr(d_bytes), ptr(d_offs), T + 1, ptr(fp), st)
 
         # ---- 2. bag lengths per (example, slot) on the host --------------------------------------------------
         lens_bs = np.zeros((B, S), dtype=np.int64)
         emit = []   # (slot, kind, payload)
         for i, s in enumerate(plan.slots):
             if s.kind == "hash":
-                toks, fo = raw.cat[s.feature]
+                pc = raw.cat[s.feature]
+                fo = pc.ex_offs
                 lens_bs[:, i] = np.diff(fo)
-                emit.append((i, "hash", (tok_base[s.feature], fo, len(toks))))
+                emit.append((i, "hash", (pc.base, fo, pc.n)))
             elif s.kind == "vocab":
-                toks, fo = raw.cat[s.feature]
-                vm = self.vocab_maps[i]
-                idx = np.fromiter((vm.get(t, -1) for t in toks), dtype=np.int32, count=len(toks))
+                pc = raw.cat[s.feature]
+                fo = pc.ex_offs
+                idx = self._vocab_lookup(i, pc)
                 keep = idx >= 0
                 ex_of = np.repeat(np.arange(B), np.diff(fo))
                 cnt = np.bincount(ex_of[keep], minlength=B).astype(np.int64)
@@ -121,7 +135,8 @@ class Featurizer(object):
                 keys = []
                 for k in s.cross_keys:
                     if k.kind == "string":
-                        toks, fo = raw.cat[k.feature]
+                        pc = raw.cat[k.feature]
+                        fo = pc.ex_offs
                         real = np.diff(fo).astype(np.int64)
                         if self.cross_padding == "tf_dense":
                             lmax = int(real.max()) if B else 0
@@ -131,7 +146,7 @@ class Featurizer(object):
                             gi = np.where(col < real[:, None], tok_base[k.feature] + fo[:-1, None] + col, empty_index)
                             keys.append(("fp", gi.reshape(-1), kc))
                         else:
-                            gi = tok_base[k.feature] + np.arange(len(toks))
+                            gi = tok_base[k.feature] + np.arange(pc.n)
                             keys.append(("fp", gi, real))
                             kc = real
                     elif k.kind == "identity":

@@ -53,6 +53,10 @@ typedef struct wd_slot {
   int32_t out_col;     /* first column of this slot in the deep input matrix x (-1: not in deep input) */
   int32_t kind;        /* WD_SLOT_* */
   int32_t wide;        /* 1: slot contributes to the wide (linear) logit */
+  /* bucket geometry of the fused sparse backward: bucket(id) = bucket_base + (id >> bucket_shift).  Slots with few
+   * rows get bucket_shift 0 (ONE row per bucket: its occurrences need no sort), big tables ~64 occurrences a bucket. */
+  int32_t bucket_shift;
+  int32_t bucket_base;
   int32_t pad_;
 } wd_slot_t;
 
@@ -182,12 +186,13 @@ int wd_bias_ftrl(float *bias_wzn, const float *dlogit, int64_t batch, float lr, 
                  wd_stream_t stream);
 
 /* Fused sparse backward (the path the engine uses; same arithmetic as steps 1-3 above in FOUR short launches, no
- * device-wide sort): occurrences are bucketed by row range (bucket = (row_base + id) >> shift), each bucket is
- * sorted on (row, bag) by one workgroup in LDS, duplicates are summed in ascending bag order and Adagrad
+ * device-wide sort): occurrences are bucketed by row range (bucket = slot.bucket_base + (id >> slot.bucket_shift); the
+ * placement inside a bucket is STABLE, i.e. in ascending bag order), each multi-row bucket is sorted on (row, bag) by
+ * one workgroup in LDS (single-row buckets need no sort), duplicates are summed in ascending bag order and Adagrad
  * (embedding rows, lr_emb) / FTRL (wide rows and bias_wzn, lr_wide, l1, l2) are applied in the same kernel.
  * emb / wide / bias_wzn may be NULL (deep-only / wide-only).  Workspaces (caller-owned, no initialisation needed):
  * bucket_cnt[(2 * wd_bucket_chunks() + 1) * nbuckets], bucket_start[nbuckets + 1], rank[nnz], pairs[nnz] (uint64).
- * nbuckets = ceil(total_rows / 2^shift) <= wd_bucket_max().  dlogit of example b is dlogit[b * ld_dlogit]; ids < 0
+ * nbuckets = sum over slots of ceil(num_buckets / 2^bucket_shift) <= wd_bucket_max().  dlogit of example b is dlogit[b * ld_dlogit]; ids < 0
  * are padding and are skipped; an embedding slot updates only keys below row_base + num_buckets. */
 int32_t wd_bucket_max(void);
 int32_t wd_bucket_chunks(void);
@@ -195,7 +200,7 @@ int32_t wd_bucket_chunks(void);
  * side stream, concurrently with the tower), apply needs dx / dlogit. */
 int wd_sparse_bucketize(const wd_slot_t *slots, int32_t S, const int32_t *ids, const int32_t *bag_offs, int64_t batch,
                         int64_t nnz, int32_t *bucket_cnt, int32_t *bucket_start, int32_t *rank, uint64_t *pairs,
-                        int32_t nbuckets, int32_t shift, wd_stream_t stream);
+                        int32_t nbuckets, wd_stream_t stream);
 int wd_sparse_apply(float *emb, float *emb_accum, float *wide, float *bias_wzn, const wd_slot_t *slots, int32_t S,
                     const int32_t *bag_offs, int64_t batch, const float *dx, int64_t ldx, const float *dlogit,
                     int64_t ld_dlogit, float lr_emb, float lr_wide, float l1, float l2, const int32_t *bucket_start,
@@ -204,7 +209,7 @@ int wd_sparse_bwd_fused(float *emb, float *emb_accum, float *wide, float *bias_w
                         const int32_t *ids, const int32_t *bag_offs, int64_t batch, int64_t nnz, const float *dx,
                         int64_t ldx, const float *dlogit, int64_t ld_dlogit, float lr_emb, float lr_wide, float l1, float l2,
                         int32_t *bucket_cnt, int32_t *bucket_start, int32_t *rank, uint64_t *pairs, int32_t nbuckets,
-                        int32_t shift, wd_stream_t stream);
+                        wd_stream_t stream);
 
 /* ---- multi-GPU exchange (replaces the PS-partitioned variables of python/lib/joint.py:140-143, train.py:202-225):
  * rows are sharded owner = id % world, local row = row_base_local[slot] + id / world.  All exchange buffers have

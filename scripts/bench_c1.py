@@ -30,7 +30,9 @@ for bt in bts:
 torch.cuda.synchronize(); t_step = time.time() - t0
 print(json.dumps({"config": "C1 repo-default conf, real rows, batch %d" % bs, "rows": n,
                   "train_examples_per_sec": round(n / t_all, 1),
+                  "train_loop_examples_per_sec": round(m.last_train["examples"] / m.last_train["seconds"], 1),
+                  "checkpoint_restore_save_sec": round(t_all - m.last_train["seconds"], 3),
                   "host_parse_rows_per_sec": round(n / t_parse, 1),
                   "gpu_featurize_rows_per_sec": round(n / t_feat, 1),
                   "train_step_only_examples_per_sec": round(n / t_step, 1),
-                  "note": "train = parse + featurize + step + checkpoint; eager launches (no hipGraph) at batch %d" % bs}))
+                  "note": "train = checkpoint restore + loop (parse + featurize + step) + checkpoint save; eager launches (no hipGraph) at batch %d" % bs}))

@@ -32,6 +32,8 @@ class WdSlot(ctypes.Structure):
         ("out_col", ctypes.c_int32),
         ("kind", ctypes.c_int32),
         ("wide", ctypes.c_int32),
+        ("bucket_shift", ctypes.c_int32),
+        ("bucket_base", ctypes.c_int32),
         ("pad_", ctypes.c_int32),
     ]
 
@@ -84,8 +86,8 @@ _PROTOS = {
     "wd_bias_ftrl": [P, P, I64, F32, F32, F32, P],
     "wd_bucket_max": [],
     "wd_bucket_chunks": [],
-    "wd_sparse_bwd_fused": [P, P, P, P, P, I32, P, P, I64, I64, P, I64, P, I64, F32, F32, F32, F32, P, P, P, P, I32, I32, P],
-    "wd_sparse_bucketize": [P, I32, P, P, I64, I64, P, P, P, P, I32, I32, P],
+    "wd_sparse_bwd_fused": [P, P, P, P, P, I32, P, P, I64, I64, P, I64, P, I64, F32, F32, F32, F32, P, P, P, P, I32, P],
+    "wd_sparse_bucketize": [P, I32, P, P, I64, I64, P, P, P, P, I32, P],
     "wd_sparse_apply": [P, P, P, P, P, I32, P, I64, P, I64, P, I64, F32, F32, F32, F32, P, P, I32, P],
     "wd_route_chunks": [],
     "wd_route_build": [P, I32, I32, P, P, I64, I32, P, P, P, P, P, P],

@@ -6,9 +6,9 @@
 // device-wide sort: a device radix/merge sort of the ~2e5 occurrences of a batch costs 15-17 dependent
 // launches (~100-150 us on MI355X) for 1.7 MB of data.  Instead:
 //
-//   K1 k_bucket_hist     occurrence -> bucket = (row_base + id) >> shift; each workgroup histograms its chunk of bags
-//                        in LDS (rank = LDS atomicAdd: device-scope returned atomics on ~1.6k counters measured
-//                        35 us for 2e5 occurrences) and writes its row of the [chunks x buckets] count matrix
+//   K1 k_bucket_hist     occurrence -> bucket = slot.bucket_base + (id >> slot.bucket_shift); each workgroup histograms
+//                        its chunk of bags in LDS with DETERMINISTIC, stable ranks (device-scope returned atomics on
+//                        ~1.6k counters measured 35 us for 2e5 occurrences) and writes its row of the count matrix
 //   K1b k_bucket_colscan per bucket: exclusive prefix over the chunks (column scan) + bucket totals
 //   K2 k_bucket_scatter  every block scans the totals in LDS (nb <= 8192) and scatters (key << 32 | bag) pairs to
 //                        start[bucket] + chunk_prefix + rank: all occurrences of a row range are now contiguous
@@ -34,28 +34,87 @@ constexpr int RANK_MAX = 512;   // buckets up to this size are rank-sorted (O(m^
 constexpr int MAX_SLOTS_LDS = 96;  // slot descriptors cached in LDS by k_bucket_update (more slots: read from HBM)
 constexpr int MAX_CHUNKS = 128; // workgroups of K1 / K2 (rows of the count matrix)
 
-// chunk c = bags [c*bags_per_chunk, (c+1)*bags_per_chunk)
+// chunk c = bags [c*bags_per_chunk, (c+1)*bags_per_chunk); rank = position of an occurrence among the chunk's
+// occurrences of the same bucket.
+//   * buckets that get sorted afterwards (bucket_shift > 0): LDS atomics, arrival order is irrelevant.
+//   * one-row buckets (bucket_shift == 0) are NOT sorted by k_bucket_update, so their order must be reproducible:
+//     occurrences are taken in rounds (256 bags x position-in-bag); inside a round the lanes of a wavefront that share
+//     a bucket find each other with ballots over the bucket bits (a match-any), and the four wavefronts append in
+//     turn -- a bucket's content ends up in ascending bag order whatever the hardware's atomics order is.
 __global__ void __launch_bounds__(256)
 k_bucket_hist(const wd_slot_t *__restrict__ slots, int32_t S, const int32_t *__restrict__ ids,
-              const int32_t *__restrict__ bag_offs, int64_t nbags, int64_t bags_per_chunk, int32_t shift, int32_t nb,
+              const int32_t *__restrict__ bag_offs, int64_t nbags, int64_t bags_per_chunk, int32_t nb,
               int32_t *__restrict__ cntm, int32_t *__restrict__ rank) {
   __shared__ int32_t hist[MAX_NB];
-  for (int i = threadIdx.x; i < nb; i += 256) hist[i] = 0;
+  __shared__ int32_t has_stable, any_left;
+  const int t = threadIdx.x;
+  if (t == 0) has_stable = 0;
+  for (int i = t; i < nb; i += 256) hist[i] = 0;
+  __syncthreads();
+  for (int i = t; i < S; i += 256)
+    if (slots[i].bucket_shift == 0) has_stable = 1;
   __syncthreads();
   const int64_t b0 = (int64_t)blockIdx.x * bags_per_chunk;
   const int64_t b1 = b0 + bags_per_chunk < nbags ? b0 + bags_per_chunk : nbags;
-  for (int64_t bag = b0 + threadIdx.x; bag < b1; bag += 256) {
-    const int64_t base = slots[bag % S].row_base;
-    const int32_t j0 = bag_offs[bag], j1 = bag_offs[bag + 1];
-    for (int32_t j = j0; j < j1; ++j) {
-      if (ids[j] < 0) continue;  // padding entry of a fixed-capacity exchange segment
-      const uint32_t key = (uint32_t)(base + ids[j]);
-      rank[j] = atomicAdd(&hist[key >> shift], 1);
+  if (!has_stable) {
+    for (int64_t bag = b0 + t; bag < b1; bag += 256) {
+      const wd_slot_t sl = slots[bag % S];
+      const int32_t j0 = bag_offs[bag], j1 = bag_offs[bag + 1];
+      for (int32_t j = j0; j < j1; ++j) {
+        const int32_t id = ids[j];
+        if (id < 0) continue;  // padding entry of a fixed-capacity exchange segment
+        rank[j] = atomicAdd(&hist[sl.bucket_base + (id >> sl.bucket_shift)], 1);
+      }
+    }
+  } else {
+    const int bits = 32 - __builtin_clz((unsigned)(nb > 1 ? nb - 1 : 1));
+    const int lane = t & 63, wave = t >> 6;
+    for (int64_t base = b0; base < b1; base += 256) {
+      const int64_t bag = base + t;
+      int32_t j0 = 0, j1 = 0, bshift = 0, bbase = 0;
+      if (bag < b1) {
+        const wd_slot_t sl = slots[bag % S];
+        j0 = bag_offs[bag];
+        j1 = bag_offs[bag + 1];
+        bshift = sl.bucket_shift;
+        bbase = sl.bucket_base;
+      }
+      for (int32_t k = 0;; ++k) {
+        if (t == 0) any_left = 0;
+        __syncthreads();
+        int32_t bk = -1;
+        if (j0 + k < j1) {
+          const int32_t id = ids[j0 + k];
+          if (id >= 0) bk = bbase + (id >> bshift);
+          any_left = 1;
+        }
+        __syncthreads();
+        if (!any_left) break;
+        const bool st = bk >= 0 && bshift == 0;
+        if (bk >= 0 && !st) rank[j0 + k] = atomicAdd(&hist[bk], 1);
+        unsigned long long same = __ballot(st);
+        const int32_t kb = st ? bk : 0;
+        for (int bit = 0; bit < bits; ++bit) {
+          const bool one = (kb >> bit) & 1;
+          const unsigned long long v = __ballot(one);
+          same &= one ? v : ~v;
+        }
+        const int lower = __popcll(same & ((1ull << lane) - 1ull));
+        const int cnt = __popcll(same);
+        for (int w = 0; w < 4; ++w) {
+          if (wave == w && st) {
+            const int32_t r = hist[bk] + lower;   // every lane of the wavefront reads before its last lane writes
+            rank[j0 + k] = r;
+            if (lower == cnt - 1) hist[bk] = r + 1;
+          }
+          __syncthreads();
+        }
+      }
     }
   }
   __syncthreads();
   int32_t *row = cntm + (int64_t)blockIdx.x * nb;
-  for (int i = threadIdx.x; i < nb; i += 256) row[i] = hist[i];
+  for (int i = t; i < nb; i += 256) row[i] = hist[i];
 }
 
 // thread per bucket: cpre[c][b] = sum_{c' < c} cntm[c'][b];  total[b] = column sum.  Out of place and 32 loads
@@ -82,7 +141,7 @@ k_bucket_colscan(const int32_t *__restrict__ cntm, int32_t *__restrict__ cpre, i
 
 __global__ void __launch_bounds__(256)
 k_bucket_scatter(const wd_slot_t *__restrict__ slots, int32_t S, const int32_t *__restrict__ ids,
-                 const int32_t *__restrict__ bag_offs, int64_t nbags, int64_t bags_per_chunk, int32_t shift,
+                 const int32_t *__restrict__ bag_offs, int64_t nbags, int64_t bags_per_chunk,
                  int32_t nb, const int32_t *__restrict__ total, const int32_t *__restrict__ cntm,
                  const int32_t *__restrict__ rank, int32_t *__restrict__ start, uint64_t *__restrict__ pairs) {
   __shared__ int32_t sstart[MAX_NB];
@@ -121,12 +180,13 @@ k_bucket_scatter(const wd_slot_t *__restrict__ slots, int32_t S, const int32_t *
   const int64_t b0 = (int64_t)blockIdx.x * bags_per_chunk;
   const int64_t b1 = b0 + bags_per_chunk < nbags ? b0 + bags_per_chunk : nbags;
   for (int64_t bag = b0 + t; bag < b1; bag += 256) {
-    const int64_t base = slots[bag % S].row_base;
+    const wd_slot_t sl = slots[bag % S];
     const int32_t j0 = bag_offs[bag], j1 = bag_offs[bag + 1];
     for (int32_t j = j0; j < j1; ++j) {
-      if (ids[j] < 0) continue;
-      const uint32_t key = (uint32_t)(base + ids[j]);
-      pairs[sstart[key >> shift] + rank[j]] = ((uint64_t)key << 32) | (uint32_t)bag;
+      const int32_t id = ids[j];
+      if (id < 0) continue;
+      const uint32_t key = (uint32_t)(sl.row_base + id);
+      pairs[sstart[sl.bucket_base + (id >> sl.bucket_shift)] + rank[j]] = ((uint64_t)key << 32) | (uint32_t)bag;
     }
   }
 }
@@ -201,6 +261,8 @@ k_bucket_update(UpdArgs u, const int32_t *__restrict__ start, uint64_t *__restri
   __shared__ float redw[256];
   __shared__ int long_i0[MAX_LONG], long_i1[MAX_LONG];
   __shared__ int nlong;
+  __shared__ int32_t seg_ex[256];
+  __shared__ float seg_scale[256];
   __shared__ wd_slot_t lds_slots[MAX_SLOTS_LDS];   // slot descriptors staged once per workgroup
   const int t = threadIdx.x;
 
@@ -229,7 +291,12 @@ k_bucket_update(UpdArgs u, const int32_t *__restrict__ start, uint64_t *__restri
   const bool slots_in_lds = u.S <= MAX_SLOTS_LDS;
   if (slots_in_lds && t < u.S) lds_slots[t] = u.slots[t];   // overlaps with the pair loads below
   const uint64_t *sp;  // sorted pairs (flat pointer: LDS or global)
-  if (m <= RANK_MAX) {
+  // the scatter is stable (ascending bag order inside a bucket); a bucket of a slot with bucket_shift == 0 holds ONE row
+  const bool single_row = u.slots[(int32_t)(uint32_t)pairs[s0] % u.S].bucket_shift == 0;
+  if (single_row) {
+    __syncthreads();
+    sp = pairs + s0;           // already grouped and ordered: nothing to sort
+  } else if (m <= RANK_MAX) {
     // rank sort: position of element i = number of elements ordered before it (ties by index); every lane reads
     // the same LDS word per step (broadcast, conflict-free), no barriers inside
     for (int i = t; i < m; i += 256) lds_in[i] = pairs[s0 + i];
@@ -258,8 +325,14 @@ k_bucket_update(UpdArgs u, const int32_t *__restrict__ start, uint64_t *__restri
 
   const int S = u.S;
   const int gidx = t >> 2, gl = t & 3;
+  const bool whole_long = single_row && m > LONG_SEG;   // one row, many occurrences: the bucket IS one long segment
+  if (whole_long && t == 0) {
+    nlong = 1;
+    long_i0[0] = 0;
+    long_i1[0] = m;
+  }
   // ---- short segments: one 4-lane group per unique row ------------------------------------------------
-  for (int i = gidx; i < m; i += 64) {
+  for (int i = gidx; i < (whole_long ? 0 : m); i += 64) {
     const uint32_t key = (uint32_t)(sp[i] >> 32);
     if (i > 0 && (uint32_t)(sp[i - 1] >> 32) == key) continue;  // not a segment head
     int e = i + 1;
@@ -383,23 +456,45 @@ k_bucket_update(UpdArgs u, const int32_t *__restrict__ start, uint64_t *__restri
       for (int c0 = 0; c0 < nchunk; c0 += 4) {
         const int c = c0 + gl;
         float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (c < nchunk) {
-          for (int j = i + gidx; j < e; j += 64) {
-            const int32_t bag = (int32_t)(uint32_t)sp[j];
+        // tiles of 256 occurrences: (example, 1/len) staged by all lanes in one round of loads, then every 4-lane
+        // group issues its four gradient-row loads back to back (same summation order as a j += 64 walk)
+        for (int j0 = i; j0 < e; j0 += 256) {
+          const int n = e - j0 < 256 ? e - j0 : 256;
+          if (t < n) {
+            const int32_t bag = (int32_t)(uint32_t)sp[j0 + t];
             const int32_t len = u.bag_offs[bag + 1] - u.bag_offs[bag];
-            const float scale = len > 1 ? 1.0f / (float)len : 1.0f;
-            const float *dp = u.dx + (int64_t)(bag / S) * u.ldx + sl.out_col + 4 * c;
-            float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
-            if ((D & 3) == 0) {
-              d = *reinterpret_cast<const float4 *>(dp);
-            } else {
-              d.x = dp[0];
-              if (4 * c + 1 < D) d.y = dp[1];
-              if (4 * c + 2 < D) d.z = dp[2];
-              if (4 * c + 3 < D) d.w = dp[3];
-            }
-            g.x += d.x * scale; g.y += d.y * scale; g.z += d.z * scale; g.w += d.w * scale;
+            seg_ex[t] = bag / S;
+            seg_scale[t] = len > 1 ? 1.0f / (float)len : 1.0f;
           }
+          __syncthreads();
+          if (c < nchunk) {
+            float4 d[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const int idx = gidx + 64 * q;
+              d[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+              if (idx < n) {
+                const float *dp = u.dx + (int64_t)seg_ex[idx] * u.ldx + sl.out_col + 4 * c;
+                if ((D & 3) == 0) {
+                  d[q] = *reinterpret_cast<const float4 *>(dp);
+                } else {
+                  d[q].x = dp[0];
+                  if (4 * c + 1 < D) d[q].y = dp[1];
+                  if (4 * c + 2 < D) d[q].z = dp[2];
+                  if (4 * c + 3 < D) d[q].w = dp[3];
+                }
+              }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const int idx = gidx + 64 * q;
+              if (idx < n) {
+                const float scale = seg_scale[idx];
+                g.x += d[q].x * scale; g.y += d[q].y * scale; g.z += d[q].z * scale; g.w += d[q].w * scale;
+              }
+            }
+          }
+          __syncthreads();
         }
         red[t] = g;
         __syncthreads();
@@ -426,7 +521,16 @@ k_bucket_update(UpdArgs u, const int32_t *__restrict__ start, uint64_t *__restri
     }
     if (do_wide) {
       float g = 0.f;
-      for (int j = i + t; j < e; j += 256) g += u.dlogit[(int64_t)((int32_t)(uint32_t)sp[j] / S) * u.ld_dlogit];
+      for (int j = i + t; j < e; j += 1024) {   // four independent (pair -> dlogit) chains per lane and round
+        float v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int jj = j + 256 * q;
+          v[q] = jj < e ? u.dlogit[(int64_t)((int32_t)(uint32_t)sp[jj] / S) * u.ld_dlogit] : 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) g += v[q];
+      }
       redw[t] = g;
       __syncthreads();
       for (int st = 128; st >= 1; st >>= 1) {
@@ -452,10 +556,10 @@ extern "C" int32_t wd_bucket_chunks(void) { return MAX_CHUNKS; }
 // engine runs it on a side stream while the tower computes.
 extern "C" int wd_sparse_bucketize(const wd_slot_t *slots, int32_t S, const int32_t *ids, const int32_t *bag_offs,
                                    int64_t batch, int64_t nnz, int32_t *bucket_cnt, int32_t *bucket_start, int32_t *rank,
-                                   uint64_t *pairs, int32_t nbuckets, int32_t shift, wd_stream_t stream) {
+                                   uint64_t *pairs, int32_t nbuckets, wd_stream_t stream) {
   if (batch <= 0) return WD_OK;
   WD_REQUIRE(slots && ids && bag_offs && bucket_cnt && bucket_start && rank && pairs, "null pointer");
-  WD_REQUIRE(S > 0 && nbuckets > 0 && nbuckets <= MAX_NB && shift >= 0 && shift < 32, "bad bucket geometry");
+  WD_REQUIRE(S > 0 && nbuckets > 0 && nbuckets <= MAX_NB, "bad bucket geometry");
   hipStream_t st = wd::as_stream(stream);
   const int64_t nbags = batch * S;
   // bucket_cnt layout: [MAX_CHUNKS][nbuckets] counts, [MAX_CHUNKS][nbuckets] chunk prefixes, total[nbuckets]
@@ -465,13 +569,12 @@ extern "C" int wd_sparse_bucketize(const wd_slot_t *slots, int32_t S, const int3
   int32_t *total = cpre + (int64_t)MAX_CHUNKS * nbuckets;
   if (nchunks > 0) {
     hipLaunchKernelGGL(k_bucket_hist, dim3(nchunks), dim3(256), 0, st, slots, S, ids, bag_offs, nbags, bags_per_chunk,
-                       shift, nbuckets, bucket_cnt, rank);
+                       nbuckets, bucket_cnt, rank);
   }
   hipLaunchKernelGGL(k_bucket_colscan, dim3((unsigned)wd::ceil_div(nbuckets, 256)), dim3(256), 0, st, bucket_cnt,
                      cpre, nchunks, nbuckets, total);
   hipLaunchKernelGGL(k_bucket_scatter, dim3(nchunks > 0 ? nchunks : 1), dim3(256), 0, st, slots, S, ids, bag_offs,
-                     nchunks > 0 ? nbags : (int64_t)0, bags_per_chunk, shift, nbuckets, total, cpre, rank,
-                     bucket_start, pairs);
+                     nchunks > 0 ? nbags : (int64_t)0, bags_per_chunk, nbuckets, total, cpre, rank, bucket_start, pairs);
   return wd::check_launch("wd_sparse_bucketize");
 }
 
@@ -499,9 +602,9 @@ extern "C" int wd_sparse_bwd_fused(float *emb, float *emb_accum, float *wide, fl
                                    int32_t S, const int32_t *ids, const int32_t *bag_offs, int64_t batch, int64_t nnz,
                                    const float *dx, int64_t ldx, const float *dlogit, int64_t ld_dlogit, float lr_emb,
                                    float lr_wide, float l1, float l2, int32_t *bucket_cnt, int32_t *bucket_start,
-                                   int32_t *rank, uint64_t *pairs, int32_t nbuckets, int32_t shift, wd_stream_t stream) {
+                                   int32_t *rank, uint64_t *pairs, int32_t nbuckets, wd_stream_t stream) {
   int rc = wd_sparse_bucketize(slots, S, ids, bag_offs, batch, nnz, bucket_cnt, bucket_start, rank, pairs, nbuckets,
-                               shift, stream);
+                               stream);
   if (rc != WD_OK) return rc;
   return wd_sparse_apply(emb, emb_accum, wide, bias_wzn, slots, S, bag_offs, batch, dx, ldx, dlogit, ld_dlogit, lr_emb,
                          lr_wide, l1, l2, bucket_start, pairs, nbuckets, stream);

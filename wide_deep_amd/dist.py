@@ -19,6 +19,7 @@ The exchange orchestration below is device-agnostic torch plumbing; the compute 
 oracle functions in the CPU tests.
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -27,7 +28,7 @@ import torch.distributed as dist
 from . import capi
 from .capi import call, ptr
 from .engine import DeviceBatch, WideDeepEngine, _stream
-from .plan import CatSlot, FeaturePlan, ModelSpec
+from .plan import CatSlot, FeaturePlan, ModelSpec, bucket_geometry
 
 
 # ---------------------------------------------------------------------------------------------
@@ -203,8 +204,14 @@ class ShardedWideDeepEngine(WideDeepEngine):
                            wide=1 if (spec.has_wide and s.wide) else 0))
         self.xslots_dev = make_slots(xs)
         # owner side: the whole local fused row space is one slot; only rows below n_emb_rows carry embeddings
+        # (its row-range buckets therefore span slots: one geometry over all local rows)
+        osh, _, self.n_buckets = bucket_geometry([max(lp.total_rows, 1)], self.n_req, int(call("wd_bucket_max")),
+                                                 float(os.environ.get("WD_BUCKET_TARGET", "64")))
+        self.bucket_cnt = torch.zeros((2 * int(call("wd_bucket_chunks")) + 1) * self.n_buckets, **i32)
+        self.bucket_start = torch.zeros(self.n_buckets + 2, **i32)
         self.oslot_dev = make_slots([dict(emb_off=0, row_base=0, num_buckets=max(self.n_emb_rows, 1), dim=self.dim,
-                                          out_col=0, kind=capi.SLOT_EMBEDDING if has_emb else capi.SLOT_NONE, wide=1)])
+                                          out_col=0, kind=capi.SLOT_EMBEDDING if has_emb else capi.SLOT_NONE, wide=1,
+                                          bucket_shift=osh[0], bucket_base=0)])
         # bias gradient = sum_b dlogit[b] = bias gradient of the logits layer -> rides in the flat all-reduce
         self._logits_b_off = self.towers[0]["metas"][-1]["b_off"] if spec.has_deep else None
         if spec.has_deep and len(self.towers) != 1:
@@ -280,7 +287,7 @@ class ShardedWideDeepEngine(WideDeepEngine):
              ptr(self.req_offs), self.n_req, self.n_req, g_ptr if has_emb else None, self.RS,
              dl_ptr if spec.has_wide else None, self.RS, float(spec.dnn_opt[1]) if spec.has_deep else 0.0, float(lr),
              float(l1), float(l2), ptr(self.bucket_cnt), ptr(self.bucket_start), ptr(self.occ_rank), ptr(self.pairs),
-             self.n_buckets, self.bucket_shift, st)
+             self.n_buckets, st)
         if spec.has_wide:
             # bias_weights: dense FTRL on the GLOBAL sum of dlogit
             if self._logits_b_off is not None:

@@ -18,7 +18,7 @@ import torch
 
 from . import capi
 from .capi import call, ptr
-from .plan import BN_EPS, FeaturePlan, ModelSpec
+from .plan import BN_EPS, FeaturePlan, ModelSpec, bucket_geometry
 
 
 class DeviceBatch:
@@ -68,6 +68,13 @@ class WideDeepEngine:
 
         # ---- slot descriptors --------------------------------------------------------------
         S = plan.S
+        # bucket geometry of the fused sparse backward (wd_sparse_bucketize): ~64 occurrences per row-range bucket,
+        # one bucket per row for vocabularies too small to be cut (plan.bucket_geometry)
+        exp_nnz = int(expected_nnz) if expected_nnz else self.max_batch * max(S, 1)
+        shifts, bases, self.n_buckets = bucket_geometry(
+            [s.num_buckets for s in plan.slots], exp_nnz / max(S, 1), int(call("wd_bucket_max")),
+            float(os.environ.get("WD_BUCKET_TARGET", "64")))
+        self.bucket_shifts = shifts
         arr = (capi.WdSlot * max(S, 1))()
         for i, s in enumerate(plan.slots):
             is_emb = s.deep == "embedding" and spec.has_deep
@@ -79,6 +86,7 @@ class WideDeepEngine:
             arr[i].out_col = plan.out_col[i]
             arr[i].kind = capi.SLOT_EMBEDDING if is_emb else (capi.SLOT_INDICATOR if is_ind else capi.SLOT_NONE)
             arr[i].wide = 1 if (spec.has_wide and s.wide) else 0
+            arr[i].bucket_shift, arr[i].bucket_base = shifts[i], bases[i]
         raw = np.frombuffer(bytes(arr), dtype=np.uint8).copy()
         self.slots_dev = torch.from_numpy(raw).to(dev)
         self.group_slots = {d: torch.tensor(v, **i32) for d, v in plan.emb_groups.items()}
@@ -249,14 +257,6 @@ class WideDeepEngine:
             raise capi.WdError("wd_sort_workspace_bytes failed")
         self.sort_ws_bytes = max(qs)
         self.sort_ws = torch.zeros(self.sort_ws_bytes, dtype=torch.uint8, device=dev)
-        # bucket geometry of the fused sparse backward (wd_sparse_bwd_fused): ~64 occurrences per bucket
-        exp_nnz = int(expected_nnz) if expected_nnz else self.max_batch * max(plan.S, 1)
-        nb_max = int(call("wd_bucket_max"))
-        target = min(max(64, 1 << max(0, math.ceil(math.log2(max(exp_nnz, 1) / float(os.environ.get("WD_BUCKET_TARGET", "64")))))), nb_max)
-        rows = max(plan.total_rows, 1)
-        self.bucket_shift = max(0, math.ceil(math.log2(rows / target))) if rows > target else 0
-        self.n_buckets = (rows + (1 << self.bucket_shift) - 1) >> self.bucket_shift
-        assert self.n_buckets <= nb_max, (self.n_buckets, nb_max)
         self.bucket_cnt = torch.zeros((2 * int(call("wd_bucket_chunks")) + 1) * self.n_buckets, **i32)
         self.bucket_start = torch.zeros(self.n_buckets + 2, **i32)
         self.occ_rank = torch.zeros(M, **i32)
@@ -577,7 +577,7 @@ class WideDeepEngine:
         self._check_batch(bt)
         call("wd_sparse_bucketize", ptr(self.slots_dev), plan.S, ptr(bt.ids), ptr(bt.bag_offs), bt.B, bt.nnz,
              ptr(self.bucket_cnt), ptr(self.bucket_start), ptr(self.occ_rank), ptr(self.pairs), self.n_buckets,
-             self.bucket_shift, st)
+             st)
 
     def _has_sparse_update(self):
         return (bool(self.group_slots) if self.spec.has_deep else False) or self.spec.has_wide

@@ -107,6 +107,7 @@ class WideAndDeepClassifier(object):
             bt = self._device_batch(raw)
             if n == 0:
                 self._restore()
+                t0 = time.time()       # examples/sec of the loop itself: checkpoint restore / save are reported apart
                 if max_steps is not None and self._engine.global_step >= max_steps:
                     break
             loss = self._engine.train_step(bt)

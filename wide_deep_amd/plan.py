@@ -328,3 +328,24 @@ def criteo_spec(n_dense=13, n_sparse=26, buckets=1_000_000, dim=16, hidden=(256,
     return ModelSpec(model_type=model_type, slots=slots, dense_cols=dense,
                      towers=[TowerSpec(list(hidden), mode)], batch_norm=batch_norm,
                      use_weight_column=use_weight_column, pos_weight=pos_weight, neg_weight=neg_weight)
+
+
+def bucket_geometry(vocab_sizes, occ_per_slot, nb_max, target=64.0):
+    """Row-range buckets of the fused sparse backward (wd_sparse_bucketize): slot s is cut into ceil(V_s / 2^shift_s)
+    buckets of 2^shift_s consecutive rows, sized for ~`target` occurrences per bucket when ids are uniform.  A slot
+    whose vocabulary is smaller than the bucket count it would get keeps one bucket PER ROW (shift 0), which the
+    update kernel handles without sorting -- the tiny vocabularies of the reference's conf/feature.yaml (2-55 rows,
+    thousands of occurrences per row at batch 8192) land there.  Returns (shifts, bases, total buckets <= nb_max)."""
+    vocab_sizes = [max(int(v), 1) for v in vocab_sizes]
+    t = float(target)
+    while True:
+        shifts, bases, total = [], [], 0
+        for v in vocab_sizes:
+            want = max(1.0, float(occ_per_slot) / t)
+            sh = max(0, math.ceil(math.log2(v / want))) if v > want else 0
+            shifts.append(sh)
+            bases.append(total)
+            total += (v + (1 << sh) - 1) >> sh
+        if total <= nb_max:
+            return shifts, bases, max(total, 1)
+        t *= 1.25

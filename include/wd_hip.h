@@ -289,6 +289,13 @@ typedef struct wd_mlp_layer {
   int64_t ld_wft_h;
   const int64_t *cat_off;   /*   [K] element offsets into wcat (< 0: skip): row k of this layer is written to */
   uint16_t *wcat;           /*   wcat[cat_off[k] + n], n < N -- the operand of the segment-gradient GEMM (wd_hgemm_nt) */
+  /* optional MFMA-fragment-packed fp32 copies of the folded kernel for wd_tower_chain (NULL: not written; both need
+   * K % 32 == 0 and N % 32 == 0).  A packed operand B [R reduction rows][C columns] is stored as
+   *   pk[((c/32) * (R/8) + r/8) * 256 + ((r%2) * 32 + c%32) * 4 + (r%8)/2]  =  B[r][c]
+   * i.e. one 16-byte load per lane feeds four consecutive v_mfma_f32_32x32x2_f32 steps of a 32-column tile.
+   *   Wpk  = pack(Wf)    (R = K, C = N: forward products)      WTpk = pack(Wf^T)  (R = N, C = K: gradient chain) */
+  float *Wpk;
+  float *WTpk;
 } wd_mlp_layer_t;
 
 /* wd_fold_affine for every layer of every tower in ONE launch; also zero-fills up to two small buffers
@@ -313,6 +320,36 @@ int wd_logits_head(const float *a, int64_t ld_a, int64_t K, const float *wf, con
                    const float *wide_logit, const float *labels, const float *weights, int64_t batch,
                    float *dnn_logit, float *logit, float *prob, float *dlogit, float *loss_sum, float *out,
                    int64_t ld_out, int32_t act, float *Gpart, wd_stream_t stream);
+
+/* ---- whole `simple` tower in one launch (csrc/mlp_chain.hip) -------------------------------------------------------
+ * python/lib/dnn.py:92-141 (dense -> activation -> BN per hidden layer, BN folded as above), dnn.py:226-232 (logits),
+ * python/lib/joint.py:216-222, 264-269 (joint logit, sigmoid CE) for one 32-example row tile per workgroup:
+ *   a_l = act(a_{l-1} Wf_l + bf_l) (l < L), dnn_logit = a_{L-1} . w_logits + b, head as wd_logits_head, and with labels
+ *   dz_{L-1} = dlogit w_logits^T * act'(a_{L-1}), dz_{l-1} = (dz_l Wf_l^T) * act'(a_{l-1}), dx = dz_0 Wf_0^T.
+ * a_l is written to layers[l].a_out (row stride ld_act, as the per-layer GEMMs do), dz_l to layers[l].dz_out [batch][N_l]
+ * -- the operands of the weight-gradient products wd_gemm_tn_splitk, which stay separate launches -- the first dx_cols
+ * columns of dx to dx[b*ld_dx + k], and the logits-layer gradient partials to Gpart_logits (wd_mlp_finalize layout,
+ * nsplit = wd_tower_chain_blocks(batch)).  labels NULL: forward only.  Shapes: K0 and every N_l multiples of 32 and
+ * wd_tower_chain_lds_bytes(K0, N, L) > 0 (else the call fails: use the per-layer GEMMs). */
+#define WD_CHAIN_MAX_LAYERS 6
+typedef struct wd_chain_layer {
+  const float *Wpk;  /* packed folded kernel (wd_mlp_layer_t.Wpk, written by wd_fold_affine_all) */
+  const float *WTpk; /* packed transposed folded kernel (wd_mlp_layer_t.WTpk); may be NULL without labels */
+  const float *bf;   /* bias_parts x N partial folded biases */
+  float *a_out;      /* activations of this layer inside the tower's activation buffer */
+  float *dz_out;     /* [batch][N] */
+  int32_t K, N;
+} wd_chain_layer_t;
+int64_t wd_tower_chain_lds_bytes(int32_t K0, const int32_t *N, int32_t L);   /* -1: unsupported shape */
+int64_t wd_tower_chain_blocks(int64_t batch);
+/* diagnostics: later launches write shader-clock stamps (start, x tile in LDS, after each forward layer, head, after each
+ * gradient stage, end) of workgroups 0 and 100 to dev_u64x64[0..31] / [32..63]; NULL switches it off */
+int wd_tower_chain_set_stamps(void *dev_u64x64);
+int wd_tower_chain(const float *x, int64_t ld_act, int32_t K0, const wd_chain_layer_t *layers, int32_t L, int32_t act,
+                   int32_t bias_parts, const float *w_logits, const float *b_logits, const float *wide_logit,
+                   const float *labels, const float *weights, int64_t batch, float *dnn_logit, float *logit,
+                   float *prob, float *dlogit, float *loss_sum, float *Gpart_logits, float *dx, int64_t ld_dx,
+                   int32_t dx_cols, wd_stream_t stream);
 
 /* ---- fp16-input MFMA tower (BASELINE configs[4]; csrc/mlp_half.hip).  wd_half_t = IEEE binary16 bit pattern.
  * Operands are half, reduction-contiguous; accumulation, bias, split-K partials and gradient accumulators are fp32.

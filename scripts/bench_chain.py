@@ -1,0 +1,60 @@
+#!/usr/bin/env python
+"""Microbenchmark of the one-launch tower (wd_tower_chain) at the C2 tower shape (run on the GPU box): HIP-event time of
+forward-only / forward + gradient chain without dx / full, so that stage groups can be priced; used under rocprofv3 --pmc."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from wide_deep_amd import synth
+from wide_deep_amd.engine import WideDeepEngine
+from wide_deep_amd.plan import criteo_spec
+
+B = int(os.environ.get("CHAIN_B", "8192"))
+iters = int(os.environ.get("CHAIN_ITERS", "50"))
+hidden = tuple(int(v) for v in os.environ.get("CHAIN_HIDDEN", "256,128,64").split(","))
+spec = criteo_spec(buckets=1000, hidden=hidden)
+eng = WideDeepEngine(spec, max_batch=B, seed=1)
+assert eng.chain
+hb = synth.make_raw_batch(eng.plan, B, seed=3, pos_rate=0.3)
+bt = synth.to_device_ids(eng.plan, hb)
+eng.train_step(bt)
+torch.cuda.synchronize()
+tw = eng.towers[0]
+st = torch.cuda.current_stream().cuda_stream
+
+
+def timeit(fn):
+    for _ in range(5):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record(); e1.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e3   # us
+
+
+fl_f = 2.0 * B * sum(m["K"] * m["N"] for m in tw["metas"][:-1])
+full = timeit(lambda: eng._tower_chain(tw, bt, B, st, True))
+dxc = tw["dx_cols"]
+tw["dx_cols"] = 0
+nodx = timeit(lambda: eng._tower_chain(tw, bt, B, st, True))
+tw["dx_cols"] = dxc
+fwd = timeit(lambda: eng._tower_chain(tw, bt, B, st, False))
+print("chain B=%d hidden=%s: full %.1f us, no dx %.1f us, forward only %.1f us (forward GEMM flops %.2f G)" % (
+    B, hidden, full, nodx, fwd, fl_f / 1e9))
+
+from wide_deep_amd.capi import call
+stamps = torch.zeros(64, dtype=torch.int64, device="cuda")
+call("wd_tower_chain_set_stamps", stamps.data_ptr())
+eng._tower_chain(tw, bt, B, st, True)
+torch.cuda.synchronize()
+call("wd_tower_chain_set_stamps", None)
+names = ["x tile"] + ["F%d" % l for l in range(len(hidden))] + ["head"] + ["B%d" % l for l in range(len(hidden) - 1, 0, -1)] + ["dx"]
+for wg, off in ((0, 0), (100, 32)):
+    v = stamps[off: off + len(names) + 1].cpu().tolist()
+    print("workgroup %d cycles: " % wg + ", ".join("%s %d" % (n, v[i + 1] - v[i]) for i, n in enumerate(names)) + ", total %d" % (v[len(names)] - v[0]))
+v = stamps[16:32].cpu().tolist()
+print("wg0 wave0 F0: mma %d, epilogue x2 %d | dx pair 1: mma %d, epilogue %d; pair 2: mma %d, epilogue %d" % (
+    v[1] - v[0], v[2] - v[1], v[5] - v[4], v[6] - v[5], v[8] - v[7], v[9] - v[8]))

@@ -1,0 +1,80 @@
+"""GPU: the one-launch tower (wd_tower_chain, csrc/mlp_chain.hip) against the CPU oracle and against the per-layer GEMM
+launches it replaces (same engine with WD_CHAIN=0).
+
+Tolerances: as tests/test_gpu_step.py (fp32 summation order is the only difference: MFMA k-order of a 32-row tile vs the
+64x64 tiles of the GEMMs vs BLAS)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _engines(spec, max_batch, seed=5):
+    from wide_deep_amd.engine import WideDeepEngine
+    chain = WideDeepEngine(spec, max_batch=max_batch, seed=seed)
+    os.environ["WD_CHAIN"] = "0"
+    try:
+        layered = WideDeepEngine(spec, max_batch=max_batch, seed=seed)
+    finally:
+        del os.environ["WD_CHAIN"]
+    assert chain.chain and not layered.chain
+    return chain, layered
+
+
+@pytest.mark.parametrize("B,kw", [
+    (100, dict(n_dense=8, n_sparse=3, buckets=500, dim=8, hidden=(64, 32))),               # K0 = 32, ragged last tile
+    (96, dict(n_dense=0, n_sparse=4, buckets=300, dim=16, hidden=(32,))),                  # one hidden layer
+    (257, dict(n_dense=13, n_sparse=26, buckets=2000, dim=16, hidden=(256, 128, 64))),     # BASELINE configs[1] tower
+    (64, dict(n_dense=4, n_sparse=9, buckets=100, dim=16, hidden=(96, 160, 32, 32), activation="tanh")),
+])
+def test_chain_matches_per_layer_launches(B, kw):
+    from wide_deep_amd import synth
+    from wide_deep_amd.plan import criteo_spec
+    from tests.helpers import assert_close
+    kw = dict(kw)
+    activation = kw.pop("activation", None)
+    spec = criteo_spec(**kw)
+    if activation:
+        spec.activation = activation
+    a, b = _engines(spec, max_batch=B + 7)
+    for step in range(2):
+        hb = synth.make_raw_batch(a.plan, B, seed=40 + step, pos_rate=0.3)
+        bta, btb = synth.to_device_ids(a.plan, hb), synth.to_device_ids(b.plan, hb)
+        la, lb = a.train_step(bta), b.train_step(btb)
+        torch.cuda.synchronize()
+        assert_close(a.logit[:B], b.logit[:B], 1e-5, 1e-5, "logits step %d" % step)
+        assert_close(a.prob[:B], b.prob[:B], 1e-5, 1e-6, "prob")
+        assert_close(a.dlogit[:B], b.dlogit[:B], 1e-5, 1e-6, "dlogit")
+        assert abs(float(la) - float(lb)) <= 1e-5 * max(1.0, abs(float(lb)))
+        assert_close(a.G, b.G, 2e-4, 2e-6, "dense gradient step %d" % step)
+    sa, sb = a.export_state(), b.export_state()
+    for k in sb:
+        assert_close(sa[k], sb[k], 2e-4, 2e-6, k)
+    # forward only (evaluate / predict): no labels, nothing but logits and probabilities is written
+    hb = synth.make_raw_batch(a.plan, B, seed=77)
+    bta, btb = synth.to_device_ids(a.plan, hb), synth.to_device_ids(b.plan, hb)
+    bta.labels = btb.labels = None
+    a.forward(bta, need_loss=False); b.forward(btb, need_loss=False)
+    torch.cuda.synchronize()
+    assert_close(a.logit[:B], b.logit[:B], 1e-5, 1e-5, "predict logits")
+
+
+def test_chain_steps_match_oracle():
+    from tests.test_gpu_step import _run
+    from wide_deep_amd.plan import criteo_spec
+    eng, _ = _run(criteo_spec(n_dense=8, n_sparse=3, buckets=300, dim=8, hidden=(64, 32, 32)), B=96, steps=3)
+    assert eng.chain
+    eng, _ = _run(criteo_spec(n_dense=13, n_sparse=26, buckets=500, dim=16, hidden=(256, 128, 64)), B=200, steps=2,
+                  max_batch=256)
+    assert eng.chain
+
+
+def test_chain_unsupported_shapes_fall_back_to_layer_launches():
+    from wide_deep_amd.engine import WideDeepEngine
+    from wide_deep_amd.plan import criteo_spec
+    assert not WideDeepEngine(criteo_spec(n_dense=3, n_sparse=5, buckets=50, dim=16, hidden=(32, 16, 8)), max_batch=64).chain
+    assert not WideDeepEngine(criteo_spec(n_dense=8, n_sparse=3, buckets=50, dim=8, hidden=(64, 32), mode="dense"),
+                              max_batch=64).chain

@@ -49,6 +49,17 @@ class WdMlpLayer(ctypes.Structure):
         ("Wf", ctypes.c_void_p), ("bf", ctypes.c_void_p), ("s", ctypes.c_void_p), ("t", ctypes.c_void_p),
         ("Gpart", ctypes.c_void_p), ("nsplit", ctypes.c_int32), ("pad_", ctypes.c_int32),
         ("WfT_h", ctypes.c_void_p), ("ld_wft_h", ctypes.c_int64), ("cat_off", ctypes.c_void_p), ("wcat", ctypes.c_void_p),
+        ("Wpk", ctypes.c_void_p), ("WTpk", ctypes.c_void_p),
+    ]
+
+
+WD_CHAIN_MAX_LAYERS = 6
+
+
+class WdChainLayer(ctypes.Structure):
+    _fields_ = [
+        ("Wpk", ctypes.c_void_p), ("WTpk", ctypes.c_void_p), ("bf", ctypes.c_void_p), ("a_out", ctypes.c_void_p),
+        ("dz_out", ctypes.c_void_p), ("K", ctypes.c_int32), ("N", ctypes.c_int32),
     ]
 
 
@@ -102,6 +113,10 @@ _PROTOS = {
     "wd_fold_affine_all": [P, P, I32, I64, F32, P, I64, P, I64, P],
     "wd_mlp_finalize_all": [P, I32, I64, P, F32, P, P],
     "wd_logits_head_blocks": [I64, I64],
+    "wd_tower_chain_lds_bytes": [I32, P, I32],
+    "wd_tower_chain_blocks": [I64],
+    "wd_tower_chain_set_stamps": [P],
+    "wd_tower_chain": [P, I64, I32, P, I32, I32, I32, P, P, P, P, P, I64, P, P, P, P, P, P, P, I64, I32, P],
     "wd_logits_head_h": [P, I64, I64, P, P, I32, P, P, P, I64, P, P, P, P, P, P, I64, I32, P, P],
     "wd_hgemm_nn": [P, I64, P, I64, P, I32, I32, P, I64, P, I64, I64, I64, I64, P],
     "wd_hgemm_nt": [P, I64, P, I64, I64, I64, I64, P, I64, I32, P, I64, P, I64, P, I64, I32, P],
@@ -115,7 +130,7 @@ _PROTOS = {
     "wd_fill_f32": [P, F32, I64, P],
     "wd_diag_gather64": [P, P, I64, I32, P, P],
 }
-_RESTYPES = {"wd_sort_workspace_bytes": SZ, "wd_logits_head_blocks": I64, "wd_bucket_max": I32, "wd_bucket_chunks": I32, "wd_route_chunks": I32}
+_RESTYPES = {"wd_sort_workspace_bytes": SZ, "wd_logits_head_blocks": I64, "wd_tower_chain_lds_bytes": I64, "wd_tower_chain_blocks": I64, "wd_bucket_max": I32, "wd_bucket_chunks": I32, "wd_route_chunks": I32}
 
 EXPORTED_SYMBOLS = sorted(list(_PROTOS) + ["wd_last_error"])
 

@@ -373,7 +373,9 @@ __device__ __forceinline__ void fold_affine_body(const float *__restrict__ P, in
                                                  int64_t N, int bx, int by, float (*red)[64],
                                                  _Float16 *__restrict__ WfT_h = nullptr, int64_t ld_wft_h = 0,
                                                  const int64_t *__restrict__ cat_off = nullptr,
-                                                 _Float16 *__restrict__ wcat = nullptr, _Float16 *tileT = nullptr) {
+                                                 _Float16 *__restrict__ wcat = nullptr, _Float16 *tileT = nullptr,
+                                                 float *__restrict__ Wpk = nullptr,
+                                                 float *__restrict__ WTpk = nullptr) {
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   const int64_t n = (int64_t)bx * 64 + tx;
   const int64_t kc = (K + WD_FOLD_PARTS - 1) / WD_FOLD_PARTS;
@@ -402,6 +404,9 @@ __device__ __forceinline__ void fold_affine_body(const float *__restrict__ P, in
         const int64_t o = cat_off[k];
         if (o >= 0) wcat[o + n] = (_Float16)(sk * w);
       }
+      // MFMA-fragment-packed copies for wd_tower_chain (layout: include/wd_hip.h, wd_mlp_layer_t)
+      if (Wpk) Wpk[((n >> 5) * (K >> 3) + (k >> 3)) * 256 + (((k & 1) << 5) + (n & 31)) * 4 + ((k & 7) >> 1)] = sk * w;
+      if (WTpk) WTpk[((k >> 5) * (N >> 3) + (n >> 3)) * 256 + (((n & 1) << 5) + (k & 31)) * 4 + ((n & 7) >> 1)] = sk * w;
       tb += tk * w;
     }
   }
@@ -445,7 +450,7 @@ k_fold_affine_all(const float *__restrict__ P, const wd_mlp_layer_t *__restrict_
   if ((int64_t)blockIdx.x * 64 >= L.N) return;
   fold_affine_body(P, L.w_off, L.b_off, L.gamma_idx, L.beta_idx, inv, L.Wf, L.bf, L.s, L.t, L.K, L.N, blockIdx.x,
                    blockIdx.y, red, reinterpret_cast<_Float16 *>(L.WfT_h), L.ld_wft_h, L.cat_off,
-                   reinterpret_cast<_Float16 *>(L.wcat), tileT);
+                   reinterpret_cast<_Float16 *>(L.wcat), tileT, L.Wpk, L.WTpk);
 }
 
 __global__ void __launch_bounds__(256)

@@ -1,0 +1,476 @@
+// wide_deep_amd/csrc/mlp_chain.hip -- the whole `simple` tower of one 32-example row tile in ONE launch (gfx950).
+//
+// Replaces, for connected_mode `simple` (python/lib/dnn.py:92-141: dense -> activation -> BN per layer, then the
+// units=1 logits layer python/lib/dnn.py:226-232) joined with the head (python/lib/joint.py:216-222 add_n of the wide
+// and deep logits, joint.py:264-269 sigmoid CE), the chain of launches
+//     NN_0 .. NN_{L-1}, logits head, NT_{L-1} .. NT_0
+// of mlp.hip by one kernel: a row tile's forward AND its input-gradient chain depend on nothing but that tile's rows
+// (the loss is a batch SUM, BN is the inference affine folded into the weights), so the tile stays in LDS from the
+// input layer's output x down to the gradient dx that the embedding update consumes.  What remains outside are the
+// weight-gradient products G_l = [a_{l-1} | 1]^T dz_l, which reduce over the whole batch (split-K GEMMs of mlp.hip);
+// the kernel leaves a_l and dz_l in HBM for them.
+//
+// Why: at batch 8192 the tower is 9 GEMM launches of 8-19 us each, and ~11 us of every launch is fixed cost (ramp,
+// cold L2 after the kernel boundary, epilogue; profiles/r1h_gemm_microbench.txt) -- the small layers are pure launch
+// latency.  Per CU the tile's work is ~35 us of v_mfma_f32_32x32x2_f32 at full rate.
+//
+// Data flow per workgroup (256 lanes = 4 wavefronts, ONE per SIMD, one workgroup per CU):
+//   * activations live in LDS reduction-major  [k][33]  (32 examples + 1 pad): the A fragment of MFMA step k is the
+//     conflict-free row read lds[(k + lane/32) * 33 + lane%32]; an accumulator (col = lane%32 per register row) is
+//     written back transposed with bank = (n + m) % 32, also conflict-free.
+//   * weights are NOT staged in LDS: wavefront w owns the output columns [32w, 32w+32) (+128 ..), nobody else reads
+//     them, so the B fragments are loaded straight from L2 into registers.  wd_fold_affine_all writes the folded kernel
+//     (and its transpose, for the gradient chain) in MFMA-fragment order (wd_mlp_layer_t.Wpk / WTpk): ONE 16-byte load
+//     per lane, 1 KB contiguous per wavefront, feeds four MFMA steps.  (One dword per MFMA -- the natural [K][N] layout
+//     -- ran at 118 us: the CU's texture-address unit moves ~16 B/clk of dword loads, exactly what four wavefronts of
+//     back-to-back fp32 MFMAs consume, so the waves sat in s_waitcnt 54 % of the time.)  A register ring keeps 7-11
+//     groups (> 1 us of MFMAs) in flight.
+//   * exact fp32 (v_mfma_f32_32x32x2_f32 == an fmaf chain), same numerics class as the per-layer GEMMs.
+#include "common.h"
+#include <type_traits>
+
+namespace {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+constexpr int RT = 32;        // examples per row tile
+constexpr int P = 33;         // LDS pitch of one reduction row
+#ifndef WD_CHAIN_RING
+#define WD_CHAIN_RING 8
+#endif
+constexpr int RING = WD_CHAIN_RING;   // register ring of 8-row reduction groups: groups in flight + 1
+constexpr int MAXL = WD_CHAIN_MAX_LAYERS;
+
+struct ChainArgs {
+  wd_chain_layer_t layer[MAXL];
+  int32_t a_off[MAXL];   // LDS float offsets of a_l and dz_l
+  int32_t dz_off[MAXL];
+  int32_t L;
+  int32_t act;
+  int32_t bias_parts;
+  int32_t K0;            // width of x
+  int32_t dx_cols;       // gradient columns of x wanted (multiple of 32, <= round32(K0)); 0: none
+  int32_t train;
+  const float *x;        // [batch][ld_act]
+  int64_t ld_act;
+  const float *w_logits; // [K_L]
+  const float *b_logits; // [bias_parts]
+  const float *wide_logit, *labels, *weights;
+  int64_t batch;
+  float *dnn_logit, *logit, *prob, *dlogit, *loss_sum, *Gpart_logits;
+  float *dx;
+  int64_t ld_dx;
+  unsigned long long *stamps;   // diagnostics (wd_tower_chain_set_stamps): shader-clock stamps of workgroups 0 and 100
+};
+
+__device__ __forceinline__ float act_fwd(float v, int act) {
+  switch (act) {
+    case WD_ACT_RELU: return fmaxf(v, 0.f);
+    case WD_ACT_SIGMOID: return 1.0f / (1.0f + expf(-v));
+    case WD_ACT_TANH: return tanhf(v);
+    case WD_ACT_RELU6: return fminf(fmaxf(v, 0.f), 6.f);
+    case WD_ACT_LEAKY_RELU: return v > 0.f ? v : 0.2f * v;
+    case WD_ACT_ELU: return v > 0.f ? v : expm1f(v);
+    case WD_ACT_SELU: return v > 0.f ? 1.0507009873554805f * v : 1.0507009873554805f * 1.6732632423543772f * expm1f(v);
+    case WD_ACT_SOFTPLUS: return v > 20.f ? v : log1pf(expf(v));
+    case WD_ACT_SOFTSIGN: return v / (1.0f + fabsf(v));
+    default: return v;
+  }
+}
+
+__device__ __forceinline__ float act_bwd(float a, int act) {  // derivative through the activation OUTPUT a
+  switch (act) {
+    case WD_ACT_RELU: return a > 0.f ? 1.f : 0.f;
+    case WD_ACT_SIGMOID: return a * (1.f - a);
+    case WD_ACT_TANH: return 1.f - a * a;
+    case WD_ACT_RELU6: return (a > 0.f && a < 6.f) ? 1.f : 0.f;
+    case WD_ACT_LEAKY_RELU: return a > 0.f ? 1.f : 0.2f;
+    case WD_ACT_ELU: return a > 0.f ? 1.f : a + 1.f;
+    case WD_ACT_SELU: return a > 0.f ? 1.0507009873554805f : a + 1.0507009873554805f * 1.6732632423543772f;
+    case WD_ACT_SOFTPLUS: return 1.f - expf(-a);
+    case WD_ACT_SOFTSIGN: { float t = 1.f - fabsf(a); return t * t; }
+    default: return 1.f;
+  }
+}
+
+// Values that are the same in every lane but that the compiler cannot prove uniform (descriptor fields selected by a
+// loop index): pin them to SGPRs, otherwise the reduction loops get exec-masked branches and vmcnt(0) joins.
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// acc[t] += in[32 x K] . B[K x 32-column tile t]  for NT tiles `tstride` float4 apart in the packed operand.
+// inA / WB already carry the lane's (lane%32, lane/32).
+//
+// Ring of D register groups (8 reduction rows each: one 16-byte weight load per tile + four A-fragment LDS reads feed
+// 4 x NT MFMAs): while group c is multiplied, groups c+1 .. c+D-1 are in flight.  With ONE wavefront per SIMD nothing
+// else hides latency, and everything that is not an MFMA has to issue in the shadow of one: region d = {prefetch of
+// group c+D-1, MFMAs of group c} is left to the scheduler as a unit (the prefetch has no consumer inside it, so it is
+// not sunk), a sched_barrier only separates regions.  (A barrier between the prefetch and the MFMAs exposed the ~16
+// address / load instructions of every group while the matrix pipe idled: 110 instead of 64 cycles per MFMA.)
+// Every prefetch is unconditional (past the end it re-reads the last group and is never used): a load inside a branch
+// would make the wait at the join vmcnt(0), i.e. serialise the prefetch with the MFMAs it is meant to overlap.
+template <int NT, bool FULL>
+__device__ __forceinline__ void mma_ring(const float *__restrict__ inA, const float4 *__restrict__ WB, int KG,
+                                         int tstride, floatx16 (&acc)[NT]) {
+  constexpr int D = RING;
+  float fa[D][4];
+  float4 fb[D][NT];
+  auto load = [&](int buf, int c) {
+    const int kg = c < KG ? c : KG - 1;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) fb[buf][t] = WB[kg * 64 + t * tstride];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) fa[buf][j] = inA[(8 * kg + 2 * j) * P];
+  };
+  auto mfmas = [&](int buf) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[buf][0], fb[buf][t].x, acc[t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[buf][1], fb[buf][t].y, acc[t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[buf][2], fb[buf][t].z, acc[t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[buf][3], fb[buf][t].w, acc[t], 0, 0, 0);
+  };
+#pragma unroll
+  for (int i = 0; i < D - 1; ++i) load(i, i);
+  __builtin_amdgcn_sched_barrier(0);
+  for (int c0 = 0; c0 < KG; c0 += D) {
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      load((d + D - 1) % D, c0 + d + D - 1);
+      if (FULL || c0 + d < KG) mfmas(d);   // FULL: KG % D == 0, the body is branch-free
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+}
+
+template <int NT>
+__device__ __forceinline__ void mma_tiles(const float *__restrict__ inA, const float4 *__restrict__ WB, int KG,
+                                          int tstride, floatx16 (&acc)[NT]) {
+  if (KG % RING == 0) mma_ring<NT, true>(inA, WB, KG, tstride, acc);
+  else mma_ring<NT, false>(inA, WB, KG, tstride, acc);
+}
+
+// One product stage: out[32 x N] = epilogue(in[32 x K] . W[K x N]).  Wavefront w takes the 32-column tiles
+// w, w+4, w+8, ... two at a time (shared A fragments, two independent accumulator chains).
+//   MODE 0 (forward):  v = act(acc + bias[n])            -> LDS out + HBM g_out[b][n]
+//   MODE 1 (gradient): v = acc * act'(a_prev LDS [n][m]) -> LDS out + HBM g_out[b][n]
+//   MODE 2 (dx):       v = acc                            -> HBM g_out[b][n] only (n < n_store)
+template <int MODE>
+__device__ __forceinline__ void stage(const float *__restrict__ in, int K, const float *__restrict__ Wpk, int N,
+                                      const float *__restrict__ bias, int bias_parts, int act,
+                                      const float *__restrict__ a_prev, float *__restrict__ out,
+                                      float *__restrict__ g_out, int64_t ld_g, int n_store, int64_t b0, int64_t batch,
+                                      unsigned long long *dbg = nullptr) {
+  const int lane = threadIdx.x & 63, wave = uni((int)(threadIdx.x >> 6));
+  const int c = lane & 31, h = lane >> 5;
+  K = uni(K); N = uni(N);
+  const int KG = K >> 3;
+  const int ntiles = N / 32;
+  const float *inA = in + h * P + c;
+  // folded bias of column n (sum of the fold launch's partials): loaded BEFORE the reduction loop, used after it
+  auto bias_of = [&](int n0) {
+    float bv = 0.f;
+    if (MODE == 0) {
+      if (bias_parts == WD_FOLD_PARTS) {
+        float bp[WD_FOLD_PARTS];
+#pragma unroll
+        for (int p = 0; p < WD_FOLD_PARTS; ++p) bp[p] = bias[p * N + n0 + c];
+#pragma unroll
+        for (int p = 0; p < WD_FOLD_PARTS; ++p) bv += bp[p];
+      } else {
+        for (int p = 0; p < bias_parts; ++p) bv += bias[p * N + n0 + c];
+      }
+    }
+    return bv;
+  };
+  const bool full_rows = b0 + RT <= batch;   // uniform: no per-element row predicate in the common case
+  auto epilogue_t = [&](const floatx16 &acc, int n0, float bv, auto act_c, auto full_c) {
+    constexpr int ACT = decltype(act_c)::value;   // >= 0: activation known at compile time
+    constexpr bool FULLR = decltype(full_c)::value;
+    const int n = n0 + c;
+    const int a_id = ACT >= 0 ? ACT : act;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = (r & 3) + 8 * (r >> 2) + 4 * h;
+      float v = acc[r];
+      if (MODE == 0) v = act_fwd(v + bv, a_id);
+      if (MODE == 1) v *= act_bwd(a_prev[n * P + m], a_id);
+      if (MODE != 2) out[n * P + m] = v;
+      if ((FULLR || b0 + m < batch) && n < n_store) g_out[(b0 + m) * ld_g + n] = v;
+    }
+  };
+  auto epilogue = [&](const floatx16 &acc, int n0, float bv) {
+    using std::integral_constant;
+    if (act == WD_ACT_RELU || MODE == 2) {
+      if (full_rows) epilogue_t(acc, n0, bv, integral_constant<int, WD_ACT_RELU>{}, integral_constant<bool, true>{});
+      else epilogue_t(acc, n0, bv, integral_constant<int, WD_ACT_RELU>{}, integral_constant<bool, false>{});
+    } else {
+      epilogue_t(acc, n0, bv, integral_constant<int, -1>{}, integral_constant<bool, false>{});
+    }
+  };
+  for (int t0 = wave; t0 < ntiles; t0 += 8) {
+    const float4 *WB = reinterpret_cast<const float4 *>(Wpk) + (int64_t)t0 * KG * 64 + lane;
+    if (t0 + 4 < ntiles) {
+      floatx16 acc[2];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[0][i] = acc[1][i] = 0.f;
+      const float bv0 = bias_of(t0 * 32), bv1 = bias_of((t0 + 4) * 32);
+      if (dbg && threadIdx.x == 0) *dbg++ = __builtin_readcyclecounter();
+      mma_tiles<2>(inA, WB, KG, 4 * KG * 64, acc);
+      if (dbg && threadIdx.x == 0) *dbg++ = __builtin_readcyclecounter();
+      epilogue(acc[0], t0 * 32, bv0);
+      epilogue(acc[1], (t0 + 4) * 32, bv1);
+      if (dbg && threadIdx.x == 0) *dbg++ = __builtin_readcyclecounter();
+    } else {
+      floatx16 acc[1];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[0][i] = 0.f;
+      const float bv0 = bias_of(t0 * 32);
+      mma_tiles<1>(inA, WB, KG, 0, acc);
+      epilogue(acc[0], t0 * 32, bv0);
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) k_tower_chain(ChainArgs g) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  __shared__ float sdl[RT];
+  __shared__ float red[8 * RT];
+  __shared__ float swl[512];   // logits-layer kernel
+  const int t = threadIdx.x;
+  const int64_t b0 = (int64_t)blockIdx.x * RT;
+  const int L = uni(g.L);
+  float *regx = lds;  // x, later the dz_l
+  int nstamp = 0;
+  auto stamp = [&]() {
+    if (g.stamps && (blockIdx.x == 0 || blockIdx.x == 100) && t == 0)
+      g.stamps[(blockIdx.x ? 32 : 0) + nstamp] = __builtin_readcyclecounter();
+    ++nstamp;
+  };
+  stamp();
+
+  // ---- head inputs: requested now, consumed after the last hidden layer (no exposed latency there) -------------
+  const int KL = uni(g.layer[L - 1].N);
+  for (int n = t; n < KL; n += 256) swl[n] = g.w_logits[n];
+  float h_wide = 0.f, h_y = 0.f, h_w = 1.0f, h_bias = 0.f;
+  if (t < RT && b0 + t < g.batch) {
+    if (g.wide_logit) h_wide = g.wide_logit[b0 + t];
+    if (g.labels) h_y = g.labels[b0 + t];
+    if (g.weights) h_w = g.weights[b0 + t];
+  }
+  if (t < RT)
+    for (int p = 0; p < g.bias_parts; ++p) h_bias += g.b_logits[p];
+
+  // ---- x tile -> LDS [k][33] (rows beyond the batch read as zero): all loads of a 512-column block in flight, then
+  // the transposing LDS stores ------------------------------------------------------------------------------
+  {
+    const int kq = t & 15, mr = t >> 4;  // 16 float4 (64 columns, 256 B) per example row, 16 rows per pass
+    for (int kb = 0; kb < g.K0; kb += 512) {
+      float4 v[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int m = mr + 16 * (i & 1), k = kb + 64 * (i >> 1) + 4 * kq;
+        const int64_t row = b0 + m < g.batch ? b0 + m : g.batch - 1;   // clamped: the load is unconditional
+        v[i] = *reinterpret_cast<const float4 *>(g.x + row * g.ld_act + (k < g.K0 ? k : 0));
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int m = mr + 16 * (i & 1), k = kb + 64 * (i >> 1) + 4 * kq;
+        if (k < g.K0) {
+          const bool live = b0 + m < g.batch;
+          regx[(k + 0) * P + m] = live ? v[i].x : 0.f;
+          regx[(k + 1) * P + m] = live ? v[i].y : 0.f;
+          regx[(k + 2) * P + m] = live ? v[i].z : 0.f;
+          regx[(k + 3) * P + m] = live ? v[i].w : 0.f;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  stamp();
+
+  // ---- forward --------------------------------------------------------------------------------------------
+  const float *in = regx;
+  int K = g.K0;
+  for (int l = 0; l < L; ++l) {
+    const wd_chain_layer_t &ly = g.layer[l];
+    float *out = lds + g.a_off[l];
+    stage<0>(in, K, ly.Wpk, ly.N, ly.bf, g.bias_parts, g.act, nullptr, out, ly.a_out, g.ld_act, ly.N, b0, g.batch,
+             (g.stamps && blockIdx.x == 0 && l == 0) ? g.stamps + 16 : nullptr);
+    __syncthreads();
+    stamp();
+    in = out;
+    K = ly.N;
+  }
+
+  // ---- logits layer + head (in = a_{L-1} [K][33]) -----------------------------------------------------------
+  {
+    const int m = t & 31, part = t >> 5;
+    float d = 0.f;
+    for (int n = part; n < K; n += 8) d += in[n * P + m] * swl[n];
+    red[part * RT + m] = d;
+    __syncthreads();
+    if (t < RT) {
+      float dn = 0.f;
+#pragma unroll
+      for (int p = 0; p < 8; ++p) dn += red[p * RT + t];
+      dn += h_bias;
+      const int64_t b = b0 + t;
+      float dl = 0.f, ls = 0.f;
+      if (b < g.batch) {
+        const float x = dn + h_wide;
+        const float y = h_y;
+        const float w = h_w;
+        const float e = expf(-fabsf(x));
+        const float p = x >= 0.f ? 1.0f / (1.0f + e) : e / (1.0f + e);
+        dl = w * (p - y);
+        ls = w * (fmaxf(x, 0.f) - x * y + log1pf(e));
+        if (g.dnn_logit) g.dnn_logit[b] = dn;
+        if (g.logit) g.logit[b] = x;
+        if (g.prob) g.prob[b] = p;
+        if (g.train && g.dlogit) g.dlogit[b] = dl;
+      }
+      sdl[t] = dl;
+      if (g.train && g.loss_sum) {
+        for (int off = 16; off > 0; off >>= 1) ls += __shfl_down(ls, off, 64);
+        if (t == 0) atomicAdd(g.loss_sum, ls);
+      }
+    }
+  }
+  if (!g.train) return;
+  __syncthreads();
+
+  // dz_{L-1} = dlogit w^T * act'(a_{L-1});  logits-layer gradient partial of this tile (wd_mlp_finalize layout)
+  {
+    float *dz = lds + g.dz_off[L - 1];
+    float *gdz = g.layer[L - 1].dz_out;
+    float *Gp = g.Gpart_logits ? g.Gpart_logits + (int64_t)blockIdx.x * (K + 1) : nullptr;
+    const int KT = K < 256 ? K : 256;   // lanes along n: coalesced HBM rows, conflict-free LDS
+    const int MQ = 256 / KT;            // K < 256: several example groups in parallel
+    const int nq = t % KT, mq = t / KT;
+    if (mq < MQ) {
+      for (int n = nq; n < K; n += KT) {
+        const float w = swl[n];
+        for (int m = mq; m < RT; m += MQ) {
+          const float v = sdl[m] * w * act_bwd(in[n * P + m], g.act);
+          dz[n * P + m] = v;
+          if (b0 + m < g.batch) gdz[(b0 + m) * K + n] = v;
+        }
+      }
+    }
+    if (Gp) {
+      for (int n = t; n < K; n += 256) {
+        float gw = 0.f;
+#pragma unroll 8
+        for (int m = 0; m < RT; ++m) gw += in[n * P + m] * sdl[m];
+        Gp[n] = gw;
+      }
+      if (t == 0) {
+        float v = 0.f;
+        for (int m = 0; m < RT; ++m) v += sdl[m];
+        Gp[K] = v;
+      }
+    }
+  }
+  __syncthreads();
+  stamp();
+
+  // ---- gradient chain: dz_{l-1} = (dz_l WfT_l) * act'(a_{l-1}),  dx = dz_0 WfT_0 ----------------------------
+  for (int l = L - 1; l >= 1; --l) {
+    const wd_chain_layer_t &ly = g.layer[l];
+    const wd_chain_layer_t &lp = g.layer[l - 1];
+    stage<1>(lds + g.dz_off[l], ly.N, ly.WTpk, lp.N, nullptr, 0, g.act, lds + g.a_off[l - 1], lds + g.dz_off[l - 1],
+             lp.dz_out, lp.N, lp.N, b0, g.batch);
+    __syncthreads();
+    stamp();
+  }
+  if (g.dx && g.dx_cols > 0) {
+    const wd_chain_layer_t &ly = g.layer[0];
+    stage<2>(lds + g.dz_off[0], ly.N, ly.WTpk, g.dx_cols, nullptr, 0, 0, nullptr, nullptr, g.dx, g.ld_dx, g.K0, b0,
+             g.batch, (g.stamps && blockIdx.x == 0) ? g.stamps + 20 : nullptr);
+  }
+  stamp();
+}
+
+inline int round32(int v) { return (v + 31) / 32 * 32; }
+
+// LDS layout: [x | dz_{L-1} .. dz_0 aliasing x] [a_0] [a_1] ...
+int64_t chain_layout(int32_t K0, const int32_t *N, int32_t L, int32_t *a_off, int32_t *dz_off) {
+  if (L < 1 || L > MAXL || K0 <= 0 || K0 % 32) return -1;
+  int64_t sum_n = 0;
+  for (int l = 0; l < L; ++l) {
+    if (N[l] <= 0 || N[l] % 32 || N[l] > 512) return -1;
+    sum_n += N[l];
+  }
+  const int64_t regx = (K0 > sum_n ? K0 : sum_n) * P;
+  int64_t off = 0;
+  for (int l = L - 1; l >= 0; --l) {
+    if (dz_off) dz_off[l] = (int32_t)off;
+    off += (int64_t)N[l] * P;
+  }
+  off = regx;
+  for (int l = 0; l < L; ++l) {
+    if (a_off) a_off[l] = (int32_t)off;
+    off += (int64_t)N[l] * P;
+  }
+  const int64_t bytes = off * 4;
+  return bytes <= 150 * 1024 ? bytes : -1;
+}
+
+}  // namespace
+
+extern "C" int64_t wd_tower_chain_lds_bytes(int32_t K0, const int32_t *N, int32_t L) {
+  return chain_layout(K0, N, L, nullptr, nullptr);
+}
+
+static unsigned long long *g_stamps = nullptr;
+extern "C" int wd_tower_chain_set_stamps(void *dev_u64x64) {
+  g_stamps = static_cast<unsigned long long *>(dev_u64x64);
+  return WD_OK;
+}
+
+extern "C" int64_t wd_tower_chain_blocks(int64_t batch) { return wd::ceil_div(batch, RT); }
+
+extern "C" int wd_tower_chain(const float *x, int64_t ld_act, int32_t K0, const wd_chain_layer_t *layers, int32_t L,
+                              int32_t act, int32_t bias_parts, const float *w_logits, const float *b_logits,
+                              const float *wide_logit, const float *labels, const float *weights, int64_t batch,
+                              float *dnn_logit, float *logit, float *prob, float *dlogit, float *loss_sum,
+                              float *Gpart_logits, float *dx, int64_t ld_dx, int32_t dx_cols, wd_stream_t stream) {
+  if (batch <= 0) return WD_OK;
+  WD_REQUIRE(x && layers && w_logits && b_logits, "null pointer");
+  WD_REQUIRE(L >= 1 && L <= MAXL, "1 <= L <= WD_CHAIN_MAX_LAYERS");
+  WD_REQUIRE(ld_act % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0, "x must be 16-byte aligned with ld % 4 == 0");
+  ChainArgs g{};
+  int32_t N[MAXL];
+  for (int l = 0; l < L; ++l) {
+    g.layer[l] = layers[l];
+    N[l] = layers[l].N;
+    WD_REQUIRE(layers[l].Wpk && layers[l].bf && layers[l].a_out, "layer pointers");
+    WD_REQUIRE(layers[l].K == (l == 0 ? K0 : layers[l - 1].N), "layer K must equal the previous width");
+    if (labels) WD_REQUIRE(layers[l].dz_out && (l == 0 ? (!dx || layers[l].WTpk) : layers[l].WTpk != nullptr), "training needs dz_out / WTpk");
+  }
+  const int64_t bytes = chain_layout(K0, N, L, g.a_off, g.dz_off);
+  WD_REQUIRE(bytes > 0, "unsupported tower shape (widths must be multiples of 32 and fit the LDS; see wd_tower_chain_lds_bytes)");
+  const int dxc = dx ? round32(dx_cols) : 0;
+  WD_REQUIRE(dxc <= K0, "dx_cols must be <= K0");
+  g.L = L; g.act = act; g.bias_parts = bias_parts > 0 ? bias_parts : 1; g.K0 = K0; g.dx_cols = dxc;
+  g.train = labels != nullptr;
+  g.x = x; g.ld_act = ld_act; g.w_logits = w_logits; g.b_logits = b_logits;
+  g.wide_logit = wide_logit; g.labels = labels; g.weights = weights; g.batch = batch;
+  g.dnn_logit = dnn_logit; g.logit = logit; g.prob = prob; g.dlogit = dlogit; g.loss_sum = loss_sum;
+  g.Gpart_logits = Gpart_logits; g.dx = dx; g.ld_dx = ld_dx; g.stamps = g_stamps;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_tower_chain),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    if (e != hipSuccess) {
+      wd::set_error("wd_tower_chain: hipFuncSetAttribute: %s", hipGetErrorString(e));
+      return WD_ERR_LAUNCH;
+    }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(k_tower_chain, dim3((unsigned)wd::ceil_div(batch, RT)), dim3(256), (size_t)bytes,
+                     wd::as_stream(stream), g);
+  return wd::check_launch("wd_tower_chain");
+}

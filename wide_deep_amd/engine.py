@@ -207,6 +207,7 @@ class WideDeepEngine:
                                 co[k] = pj["base"] + u * pj["pitch"] + (zoff[c] - pj["zbeg"])
                         tw["cat_off"].append(torch.from_numpy(co).to(dev))
                 self.towers.append(tw)
+            self._setup_chain()
             # descriptor table of every layer of every tower (wd_fold_affine_all / wd_mlp_finalize_all)
             nl = sum(len(tw["metas"]) for tw in self.towers)
             larr = (capi.WdMlpLayer * nl)()
@@ -220,6 +221,8 @@ class WideDeepEngine:
                     d.Wf, d.bf, d.s, d.t = (tw["Wf"][l].data_ptr(), tw["bf"][l].data_ptr(), tw["s"][l].data_ptr(),
                                             tw["t"][l].data_ptr())
                     d.Gpart, d.nsplit = tw["Gpart"][l].data_ptr(), tw["nsplit"][l]
+                    if self.chain and l < tw["L"]:
+                        d.Wpk, d.WTpk = tw["Wpk"][l].data_ptr(), tw["WTpk"][l].data_ptr()
                     if self.half:
                         d.cat_off, d.wcat = tw["cat_off"][l].data_ptr(), tw["wcat"].data_ptr()
                         if l < tw["L"]:
@@ -283,6 +286,58 @@ class WideDeepEngine:
     # ------------------------------------------------------------------------------------------
     # forward
     # ------------------------------------------------------------------------------------------
+    def _setup_chain(self):
+        """One-launch tower (wd_tower_chain, csrc/mlp_chain.hip): exact-fp32 `simple` towers whose widths are multiples
+        of 32 and whose row tile fits the LDS.  WD_CHAIN=0 keeps the per-layer GEMM launches."""
+        self.chain = False
+        plan = self.plan
+        if self.half or len(self.towers) != 1 or os.environ.get("WD_CHAIN", "1") == "0":
+            return
+        tw = self.towers[0]
+        tl, metas, L = tw["layout"], tw["metas"], tw["L"]
+        if tl.mode != "simple" or L < 1 or L > capi.WD_CHAIN_MAX_LAYERS or tl.in_start[0] % 4 or tl.ld % 4:
+            return
+        dims = [int(metas[l]["N"]) for l in range(L)]
+        K0 = int(metas[0]["K"])
+        if int(call("wd_tower_chain_lds_bytes", K0, (ctypes.c_int32 * L)(*dims), L)) <= 0:
+            return
+        dev, B = self.device, self.max_batch
+        f32 = dict(dtype=torch.float32, device=dev)
+        # folded kernels in MFMA-fragment order, forward and transposed (wd_mlp_layer_t.Wpk / WTpk)
+        tw["Wpk"] = [torch.zeros(metas[l]["N"] * metas[l]["K"], **f32) for l in range(L)]
+        tw["WTpk"] = [torch.zeros(metas[l]["N"] * metas[l]["K"], **f32) for l in range(L)]
+        tw["dzl"] = [torch.zeros(B * metas[l]["N"], **f32) for l in range(L)]
+        # logits-layer gradient partials: one per 32-example row tile
+        ns = int(call("wd_tower_chain_blocks", B))
+        tw["nsplit"][L] = ns
+        tw["Gpart"][L] = torch.zeros(ns * (metas[L]["K"] + 1) * metas[L]["N"], **f32)
+        carr = (capi.WdChainLayer * L)()
+        for l in range(L):
+            c = carr[l]
+            c.Wpk, c.WTpk, c.bf = tw["Wpk"][l].data_ptr(), tw["WTpk"][l].data_ptr(), tw["bf"][l].data_ptr()
+            c.a_out = tw["act"].data_ptr() + 4 * tl.seg_start[l + 1]
+            c.dz_out = tw["dzl"][l].data_ptr()
+            c.K, c.N = int(metas[l]["K"]), dims[l]
+        tw["chain_layers"] = carr
+        # gradient columns of x that anyone reads: the embedding columns (the sparse backward), rounded up by the kernel
+        emb_cols = 0
+        for i, sl in enumerate(plan.slots):
+            if plan.emb_off[i] >= 0:
+                emb_cols = max(emb_cols, plan.out_col[i] + int(sl.dim))
+        tw["dx_cols"] = min(emb_cols, K0)
+        self.chain = True
+
+    def _tower_chain(self, tw, bt, B, st, train):
+        tl, metas, L = tw["layout"], tw["metas"], tw["L"]
+        has_emb = bool(self.group_slots)
+        need_dx = train and has_emb and tw["dx_cols"] > 0
+        call("wd_tower_chain", tw["act"].data_ptr() + 4 * tl.in_start[0], tl.ld, int(metas[0]["K"]), tw["chain_layers"], L,
+             self.act_id, capi.WD_FOLD_PARTS, ptr(tw["Wf"][L]), ptr(tw["bf"][L]), ptr(self.wide_logit),
+             ptr(bt.labels) if train else None, ptr(bt.weights) if train else None, B, ptr(tw["logit"]), ptr(self.logit),
+             ptr(self.prob), ptr(self.dlogit) if train else None, ptr(self.loss) if train else None,
+             ptr(tw["Gpart"][L]) if train else None,
+             tw["dact"].data_ptr() + 4 * tl.in_start[0] if need_dx else None, tl.ld, tw["dx_cols"] if need_dx else 0, st)
+
     def _side(self, i):
         if self._sides is None:
             self._sides = [torch.cuda.Stream(device=self.device), torch.cuda.Stream(device=self.device)]
@@ -361,8 +416,11 @@ class WideDeepEngine:
                     w0 = tl.seg_width[0]
                     tw["act"][:B, tl.seg_start[0]: tl.seg_start[0] + w0].copy_(
                         tw0["act"][:B, tw0["layout"].seg_start[0]: tw0["layout"].seg_start[0] + w0])
-                self._tower_hidden_forward(tw, B, st)
-            if nt == 1:
+                if not self.chain:
+                    self._tower_hidden_forward(tw, B, st)
+            if self.chain:
+                self._tower_chain(tw0, bt, B, st, train)
+            elif nt == 1:
                 self._tower_head(tw0, bt, B, st, train, fused=True)
             else:
                 # multi-DNN (python/lib/dnn.py:260-274): logits are summed over towers BEFORE the head, so each
@@ -453,6 +511,13 @@ class WideDeepEngine:
             return self._tower_backward_h(tw, B, st, need_dx)
         tl, metas, L = tw["layout"], tw["metas"], tw["L"]
         act, dact = tw["act"], tw["dact"]
+        if self.chain:
+            # forward() already ran the input-gradient chain; what is left are the batch reductions G_l = [a_{l-1}|1]^T dz_l
+            for l in range(L - 1, -1, -1):
+                m = metas[l]
+                call("wd_gemm_tn_splitk", act.data_ptr() + 4 * tl.in_start[l], tl.ld, ptr(tw["dzl"][l]), m["N"],
+                     ptr(tw["Gpart"][l]), m["K"], m["N"], B, tw["nsplit"][l], 1, st)
+            return
         simple = tl.mode == "simple"
         if not head_done:
             # multi-tower: dlogit is shared; run this tower's logits-layer backward (dlogit given as `labels`-free input)

@@ -262,6 +262,18 @@ int wd_gemm_nt_actbwd(const float *A, int64_t lda, const float *B, int64_t ldb, 
 int wd_gemm_tn_splitk(const float *A, int64_t lda, const float *B, int64_t ldb, float *Cpart, int64_t M, int64_t N,
                       int64_t K, int32_t nsplit, int32_t append_ones, wd_stream_t stream);
 
+/* wd_gemm_tn_splitk for several layers in ONE launch (the weight-gradient products of a whole tower): job j is exactly
+ * wd_gemm_tn_splitk(A, lda, B, ldb, Cpart, M, N, K, nsplit, append_ones). */
+#define WD_TN_GROUP_MAX 8
+typedef struct wd_tn_job {
+  const float *A;
+  const float *B;
+  float *Cpart;
+  int64_t lda, ldb, M, N, K;
+  int32_t nsplit, append_ones;
+} wd_tn_job_t;
+int wd_gemm_tn_splitk_group(const wd_tn_job_t *jobs, int32_t njobs, wd_stream_t stream);
+
 /* Dense parameters live in ONE flat fp32 buffer P (kernels [K,N] row-major, biases, BN gamma/beta); the
  * gradient buffer Gflat has the same layout.  gamma_idx[k] / beta_idx[k] give, for input column k of a
  * layer, the index in P of the BN gamma / beta of the unit that produced that column (-1: raw input column).

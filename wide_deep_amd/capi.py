@@ -54,6 +54,15 @@ class WdMlpLayer(ctypes.Structure):
 
 
 WD_CHAIN_MAX_LAYERS = 6
+WD_TN_GROUP_MAX = 8
+
+
+class WdTnJob(ctypes.Structure):
+    _fields_ = [
+        ("A", ctypes.c_void_p), ("B", ctypes.c_void_p), ("Cpart", ctypes.c_void_p),
+        ("lda", ctypes.c_int64), ("ldb", ctypes.c_int64), ("M", ctypes.c_int64), ("N", ctypes.c_int64),
+        ("K", ctypes.c_int64), ("nsplit", ctypes.c_int32), ("append_ones", ctypes.c_int32),
+    ]
 
 
 class WdChainLayer(ctypes.Structure):
@@ -113,6 +122,7 @@ _PROTOS = {
     "wd_fold_affine_all": [P, P, I32, I64, F32, P, I64, P, I64, P],
     "wd_mlp_finalize_all": [P, I32, I64, P, F32, P, P],
     "wd_logits_head_blocks": [I64, I64],
+    "wd_gemm_tn_splitk_group": [P, I32, P],
     "wd_tower_chain_lds_bytes": [I32, P, I32],
     "wd_tower_chain_blocks": [I64],
     "wd_tower_chain_set_stamps": [P],

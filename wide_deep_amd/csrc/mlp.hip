@@ -115,7 +115,7 @@ __device__ __forceinline__ float4 mask4(float4 v, int64_t row, int64_t col, int6
 // NV = BK/16 independent 16-byte loads per operand per lane in flight (the BK=16 single-stage version paid
 // one full HBM/L2 latency per 8 MFMAs).
 template <bool A_RC, bool B_RC, int EPI, int BK, bool VEC>
-__global__ void __launch_bounds__(256) k_gemm(GemmArgs g) {
+__device__ __forceinline__ void gemm_body(const GemmArgs &g, const int orig, const int bz) {
   constexpr int LDA = A_RC ? LD_RC : LD_OC;
   constexpr int LDB = B_RC ? LD_RC : LD_OC;
   constexpr int NV = BK / 16;  // float4 per lane per operand per slab
@@ -134,14 +134,13 @@ __global__ void __launch_bounds__(256) k_gemm(GemmArgs g) {
   // XCD-aware tile mapping: hardware places block i on XCD i % 8; give each XCD a contiguous run of
   // tiles (n fastest) so the N-tiles sharing an A panel hit the same L2.  Bijective for any grid.
   const int nwg = g.tiles_m * g.tiles_n;
-  const int orig = blockIdx.x;
   const int q = nwg / wd::kXCDs, r = nwg % wd::kXCDs;
   const int xcd = orig % wd::kXCDs, loc = orig / wd::kXCDs;
   const int vid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
   const int64_t m0 = (int64_t)(vid / g.tiles_n) * BM;
   const int64_t n0 = (int64_t)(vid % g.tiles_n) * BN;
 
-  const int64_t kbeg = (int64_t)blockIdx.z * g.kchunk;
+  const int64_t kbeg = (int64_t)bz * g.kchunk;
   const int64_t kend = kbeg + g.kchunk < g.K ? kbeg + g.kchunk : g.K;
   const int64_t a_cols = g.ones_row >= 0 ? g.ones_row : g.M;  // TN: the appended ones row is synthesised
 
@@ -316,7 +315,7 @@ __global__ void __launch_bounds__(256) k_gemm(GemmArgs g) {
   // C/D layout of 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
   const int64_t n = n0 + wn * 32 + fc;
   if (n >= g.N) return;
-  float *Cz = g.C + (EPI == 2 ? (int64_t)blockIdx.z * g.c_split : 0);
+  float *Cz = g.C + (EPI == 2 ? (int64_t)bz * g.c_split : 0);
   float bv = 0.f;
   if (EPI == 0 && g.bias) {
     for (int p = 0; p < g.bias_parts; ++p) bv += g.bias[(int64_t)p * g.N + n];
@@ -334,6 +333,35 @@ __global__ void __launch_bounds__(256) k_gemm(GemmArgs g) {
     }
     Cz[m * g.ldc + n] = v;
   }
+}
+
+template <bool A_RC, bool B_RC, int EPI, int BK, bool VEC>
+__global__ void __launch_bounds__(256) k_gemm(GemmArgs g) {
+  gemm_body<A_RC, B_RC, EPI, BK, VEC>(g, blockIdx.x, blockIdx.z);
+}
+
+// The weight-gradient products of ALL layers in one launch (wd_gemm_tn_splitk_group): the flat grid is cut into
+// per-job ranges of tiles x splits; each workgroup runs the same body as a stand-alone launch would.  Three launches of
+// 10-30 us, each paying the ~11 us fixed cost of a kernel boundary, become one.
+constexpr int MAX_TN_JOBS = WD_TN_GROUP_MAX;
+struct GroupArgs {
+  GemmArgs job[MAX_TN_JOBS];
+  int32_t first[MAX_TN_JOBS + 1];   // first flat workgroup id of job j (multiple of 8: keeps the XCD-aware tile order
+                                    // of the body valid); [njobs] = grid size
+  int32_t count[MAX_TN_JOBS];       // workgroups of job j (tiles x splits)
+  int32_t njobs;
+};
+
+template <int BK, bool VEC>
+__global__ void __launch_bounds__(256) k_gemm_tn_group(GroupArgs G) {
+  int j = 0;
+  while (j + 1 < G.njobs && (int)blockIdx.x >= G.first[j + 1]) ++j;
+  j = __builtin_amdgcn_readfirstlane(j);
+  const GemmArgs &g = G.job[j];
+  const int rem = blockIdx.x - G.first[j];
+  if (rem >= G.count[j]) return;   // padding of the job's range
+  const int nwg = g.tiles_m * g.tiles_n;
+  gemm_body<false, false, 2, BK, VEC>(g, rem % nwg, rem / nwg);
 }
 
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -724,6 +752,40 @@ extern "C" int wd_gemm_tn_splitk(const float *A, int64_t lda, const float *B, in
   g.c_split = Mo * N;
   g.ones_row = append_ones ? M : -1;
   return launch_gemm<false, false, 2>(g, nsplit, wd::as_stream(stream), "wd_gemm_tn_splitk");
+}
+
+extern "C" int wd_gemm_tn_splitk_group(const wd_tn_job_t *jobs, int32_t njobs, wd_stream_t stream) {
+  if (njobs <= 0) return WD_OK;
+  WD_REQUIRE(jobs, "null pointer");
+  WD_REQUIRE(njobs <= MAX_TN_JOBS, "njobs <= WD_TN_GROUP_MAX");
+  GroupArgs G{};
+  bool vec = true;
+  int total = 0;
+  for (int j = 0; j < njobs; ++j) {
+    const wd_tn_job_t &q = jobs[j];
+    WD_REQUIRE(q.A && q.B && q.Cpart, "null pointer");
+    WD_REQUIRE(q.M > 0 && q.N > 0 && q.K > 0 && q.nsplit > 0, "M, N, K, nsplit must be > 0");
+    GemmArgs &g = G.job[j];
+    const int64_t Mo = q.append_ones ? q.M + 1 : q.M;
+    g.A = q.A; g.B = q.B; g.C = q.Cpart; g.lda = q.lda; g.ldb = q.ldb; g.ldc = q.N;
+    g.M = Mo; g.N = q.N; g.K = q.K;
+    g.kchunk = wd::ceil_div(wd::ceil_div(q.K, q.nsplit), kBK) * kBK;
+    g.c_split = Mo * q.N;
+    g.ones_row = q.append_ones ? q.M : -1;
+    g.tiles_m = (int)wd::ceil_div(g.M, BM);
+    g.tiles_n = (int)wd::ceil_div(g.N, BN);
+    g.a_vec = (g.lda % 4 == 0) && aligned16(g.A);
+    g.b_vec = (g.ldb % 4 == 0) && aligned16(g.B);
+    vec = vec && g.a_vec && g.b_vec;
+    G.first[j] = total;
+    G.count[j] = g.tiles_m * g.tiles_n * q.nsplit;
+    total += (G.count[j] + 7) / 8 * 8;
+  }
+  G.first[njobs] = total;
+  G.njobs = njobs;
+  if (vec) hipLaunchKernelGGL((k_gemm_tn_group<kBK, true>), dim3((unsigned)total), dim3(256), 0, wd::as_stream(stream), G);
+  else hipLaunchKernelGGL((k_gemm_tn_group<kBK, false>), dim3((unsigned)total), dim3(256), 0, wd::as_stream(stream), G);
+  return wd::check_launch("wd_gemm_tn_splitk_group");
 }
 
 extern "C" int wd_fold_affine(const float *P, int64_t w_off, int64_t b_off, const int32_t *gamma_idx,

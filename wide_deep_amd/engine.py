@@ -271,7 +271,9 @@ class WideDeepEngine:
         # Measured on MI355X (ROCm 7.2): every cross-stream edge costs more than it hides at C2's kernel sizes
         # (0.305 ms/step single-stream, 0.317 with the bucketing branch, 0.34 with the TN branch), while the fp16
         # tower at C5 gains 4 % from the TN branch.  Defaults follow the measurements; WD_OVERLAP=none|bucket|tn|both.
-        mode = os.environ.get("WD_OVERLAP", "tn" if self.half else "none")
+        # With the one-launch tower (wd_tower_chain: one wavefront per SIMD for ~75 us, 118 KB of LDS) the bucketing
+        # kernels co-reside on the same CUs: 0.2425 -> 0.232 ms/step at C2, so that branch is on by default there.
+        mode = os.environ.get("WD_OVERLAP", "tn" if self.half else ("bucket" if getattr(self, "chain", False) else "none"))
         self.overlap_bucket = mode in ("both", "bucket")
         self.overlap_tn = mode in ("both", "tn")
         self._sides = None
@@ -513,6 +515,15 @@ class WideDeepEngine:
         act, dact = tw["act"], tw["dact"]
         if self.chain:
             # forward() already ran the input-gradient chain; what is left are the batch reductions G_l = [a_{l-1}|1]^T dz_l
+            if L <= capi.WD_TN_GROUP_MAX:
+                jobs = (capi.WdTnJob * L)()
+                for l in range(L):    # largest product first: its workgroups start while the small ones fill the gaps
+                    m, j = metas[l], jobs[l]
+                    j.A, j.lda = act.data_ptr() + 4 * tl.in_start[l], tl.ld
+                    j.B, j.ldb, j.Cpart = tw["dzl"][l].data_ptr(), m["N"], tw["Gpart"][l].data_ptr()
+                    j.M, j.N, j.K, j.nsplit, j.append_ones = m["K"], m["N"], B, tw["nsplit"][l], 1
+                call("wd_gemm_tn_splitk_group", jobs, L, st)
+                return
             for l in range(L - 1, -1, -1):
                 m = metas[l]
                 call("wd_gemm_tn_splitk", act.data_ptr() + 4 * tl.in_start[l], tl.ld, ptr(tw["dzl"][l]), m["N"],

@@ -211,6 +211,47 @@ int wd_sparse_bwd_fused(float *emb, float *emb_accum, float *wide, float *bias_w
                         int32_t *bucket_cnt, int32_t *bucket_start, int32_t *rank, uint64_t *pairs, int32_t nbuckets,
                         wd_stream_t stream);
 
+/* ---- any optimizer the reference accepts (python/lib/utils/model_util.py:84-90: Adagrad, Adam, Ftrl, RMSProp, SGD =
+ * tf.train.{Adagrad,Adam,Ftrl,RMSProp,GradientDescent}Optimizer, TF 1.x kernels), per scope as python/lib/joint.py:224-262
+ * applies them: `dnn_optimizer` on embeddings + tower variables, `linear_optimizer` on wide weights + bias.
+ * Slots a / b of a variable (same shape; wide lines are {w, a, b, -}):
+ *   SGD      -                              var -= lr g
+ *   Adagrad  b = accumulator                b += g^2; var -= lr g / sqrt(b)
+ *   Ftrl     a = linear, b = accumulator    (as wd_wide_bwd_ftrl; p0 = l1, p1 = l2; lr_power -0.5)
+ *   RMSProp  a = rms (init 1), b = momentum a += (g^2 - a)(1 - p0); b = p1 b + lr g / sqrt(a + p2); var -= b
+ *            (p0 = decay, p1 = momentum, p2 = epsilon; centered = False)
+ *   Adam     a = m, b = v                   p0 = beta1, p1 = beta2, p2 = epsilon, lr_t = lr sqrt(1 - beta2^t) / (1 - beta1^t);
+ *            `pow` = device {beta1^t, beta2^t} of the step being applied (wd_adam_tick multiplies it afterwards).
+ *            Dense variables: ApplyAdam.  Sparsely updated variables: AdamOptimizer._apply_sparse_shared -- EVERY row
+ *            moves (m *= beta1, v *= beta2, var -= lr_t m / (sqrt(v) + eps)); rows with a gradient are done by
+ *            wd_sparse_apply_opt, which marks them in `touched` (bit per fused row), the rest by wd_adam_untouched,
+ *            which also clears the bitmap. */
+#define WD_OPT_SGD 0
+#define WD_OPT_ADAGRAD 1
+#define WD_OPT_FTRL 2
+#define WD_OPT_RMSPROP 3
+#define WD_OPT_ADAM 4
+#define WD_OPT_ADAM_DENSE 5   /* internal */
+typedef struct wd_opt {
+  int32_t kind;
+  float lr;
+  float p0, p1, p2;
+  int32_t pad_;
+  const float *pow;
+} wd_opt_t;
+int wd_sparse_apply_opt(float *emb, float *emb_a, float *emb_b, float *wide, float *bias, const wd_slot_t *slots,
+                        int32_t S, const int32_t *bag_offs, int64_t batch, const float *dx, int64_t ldx,
+                        const float *dlogit, int64_t ld_dlogit, const wd_opt_t *emb_opt, const wd_opt_t *wide_opt,
+                        const int32_t *bucket_start, uint64_t *pairs, int32_t nbuckets, uint32_t *touched,
+                        wd_stream_t stream);
+int wd_opt_dense(float *w, float *slot_a, float *slot_b, const float *g, int64_t n, const wd_opt_t *opt,
+                 wd_stream_t stream);
+/* max_rows = largest slot (grid sizing), total_rows = size of the fused row space (bitmap length in bits) */
+int wd_adam_untouched(float *emb, float *emb_m, float *emb_v, float *wide, const wd_slot_t *slots, int32_t S,
+                      int64_t max_rows, int64_t total_rows, uint32_t *touched, const wd_opt_t *emb_opt,
+                      const wd_opt_t *wide_opt, wd_stream_t stream);
+int wd_adam_tick(float *pow, float beta1, float beta2, wd_stream_t stream);
+
 /* ---- multi-GPU exchange (replaces the PS-partitioned variables of python/lib/joint.py:140-143, train.py:202-225):
  * rows are sharded owner = id % world, local row = row_base_local[slot] + id / world.  All exchange buffers have
  * `world` equal segments of `cap` entries so that the all-to-all split sizes are static (no host sync).

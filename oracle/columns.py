@@ -208,10 +208,21 @@ class Columns(object):
             m = re.search(key + r"\s*=\s*([-+0-9.eE]+)", text)
             return float(m.group(1)) if m else default
 
+        def one(text, default_lr):
+            lr = kw(text, "learning_rate", default_lr)
+            if "Adagrad" in text:
+                return ("Adagrad", lr, kw(text, "initial_accumulator_value", 0.1))
+            if "Ftrl" in text:
+                return ("Ftrl", lr, kw(text, "l1_regularization_strength", 0.0), kw(text, "l2_regularization_strength", 0.0),
+                        kw(text, "initial_accumulator_value", 0.1))
+            if "RMSProp" in text:
+                return ("RMSProp", lr, kw(text, "decay", 0.9), kw(text, "momentum", 0.0), kw(text, "epsilon", 1e-10))
+            if "Adam" in text:
+                return ("Adam", lr, kw(text, "beta1", 0.9), kw(text, "beta2", 0.999), kw(text, "epsilon", 1e-8))
+            if "SGD" in text or "GradientDescent" in text:
+                return ("SGD", lr)
+            raise ValueError("unsupported optimizer `%s`" % text)
+
         d, l = str(self.model["dnn_optimizer"]), str(self.model["linear_optimizer"])
-        dnn_lr = kw(d, "learning_rate", float(self.model.get("dnn_initial_learning_rate") or 0.05))
-        lin_lr = kw(l, "learning_rate", float(self.model.get("linear_initial_learning_rate") or 0.05))
-        assert "Adagrad" in d and "Ftrl" in l, "oracle restates Adagrad (dnn) / Ftrl (linear) only"
-        return (("Adagrad", dnn_lr, kw(d, "initial_accumulator_value", 0.1)),
-                ("Ftrl", lin_lr, kw(l, "l1_regularization_strength", 0.0), kw(l, "l2_regularization_strength", 0.0),
-                 kw(l, "initial_accumulator_value", 0.1)))
+        return (one(d, float(self.model.get("dnn_initial_learning_rate") or 0.05)),
+                one(l, float(self.model.get("linear_initial_learning_rate") or 0.05)))

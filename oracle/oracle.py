@@ -178,6 +178,109 @@ def ftrl_dense(w, z, n, g, lr, l1, l2):
                          ctypes.c_float(l1), ctypes.c_float(l2))
 
 
+# ---------------------------------------------------------------------------
+# the other optimizers the reference accepts (python/lib/utils/model_util.py:84-90), restated from the TF 1.x kernels:
+#   GradientDescent  training_ops ApplyGradientDescent / scatter_sub          var -= lr g
+#   RMSProp          ApplyRMSProp / SparseApplyRMSProp (touched rows only)    ms += (g^2 - ms)(1 - decay);
+#                    mom = mom * momentum + lr g / sqrt(ms + eps); var -= mom     (slots: rms init 1, momentum init 0)
+#   Adam             dense: ApplyAdam  m += (g - m)(1 - b1); v += (g^2 - v)(1 - b2); var -= lr_t m / (sqrt(v) + eps)
+#                    sparse: AdamOptimizer._apply_sparse_shared  m = m b1 (WHOLE variable); m[rows] += (1 - b1) g; same for v;
+#                    var -= lr_t m / (sqrt(v) + eps) (WHOLE variable);  lr_t = lr sqrt(1 - b2^t) / (1 - b1^t)
+# No golden vectors exist for these (parity unpinned, like the rest of the TF semantics: SURVEY 8c); they are checked
+# against hand-computed cases in tests/test_oracle_kat.py.
+# Optimizer tuples: ("SGD", lr) ("Adagrad", lr, init) ("Ftrl", lr, l1, l2, init) ("RMSProp", lr, decay, momentum, eps)
+#                   ("Adam", lr, beta1, beta2, eps)
+# ---------------------------------------------------------------------------
+SLOT_NAMES = {"SGD": (None, None), "Adagrad": (None, "/Adagrad"), "Ftrl": ("/Ftrl_1", "/Ftrl"),
+              "RMSProp": ("/RMSProp", "/RMSProp_1"), "Adam": ("/Adam", "/Adam_1")}
+SLOT_INIT = {"SGD": (None, None), "Adagrad": (None, "init"), "Ftrl": (0.0, "init"), "RMSProp": (1.0, 0.0),
+             "Adam": (0.0, 0.0)}
+
+
+def slot_init_values(opt):
+    """(initial value of slot a, of slot b) or None where the optimizer has no such slot."""
+    a, b = SLOT_INIT[opt[0]]
+    init = float(opt[-1]) if opt[0] in ("Adagrad", "Ftrl") else None
+    return (init if a == "init" else a), (init if b == "init" else b)
+
+
+def opt_apply_dense(opt, state, nm, g, pow_):
+    kind = opt[0]
+    w = state[nm]
+    sa, sb = SLOT_NAMES[kind]
+    if kind == "SGD":
+        w -= opt[1] * g
+    elif kind == "Adagrad":
+        adagrad_dense(w, state[nm + sb], g, opt[1])
+    elif kind == "Ftrl":
+        ftrl_dense(w, state[nm + sa], state[nm + sb], g, opt[1], opt[2], opt[3])
+    elif kind == "RMSProp":
+        _, lr, decay, mom, eps = opt
+        ms, mo = state[nm + sa], state[nm + sb]
+        ms += (g * g - ms) * (1.0 - decay)
+        mo.mul_(mom).add_(lr * g / torch.sqrt(ms + eps))
+        w -= mo
+    elif kind == "Adam":
+        _, lr, b1, b2, eps = opt
+        m, v = state[nm + sa], state[nm + sb]
+        lr_t = np.float32(lr) * np.sqrt(np.float32(1.0) - np.float32(pow_[1])) / (np.float32(1.0) - np.float32(pow_[0]))
+        m += (g - m) * (1.0 - b1)
+        v += (g * g - v) * (1.0 - b2)
+        w -= float(lr_t) * m / (torch.sqrt(v) + eps)
+    else:
+        raise ValueError(kind)
+
+
+def opt_apply_rows(opt, state, nm, uniq, rg, pow_):
+    """Sparse apply of the summed per-row gradients rg [U, D] at rows uniq [U]."""
+    kind = opt[0]
+    w = state[nm]
+    sa, sb = SLOT_NAMES[kind]
+    idx = torch.as_tensor(np.asarray(uniq, dtype=np.int64))
+    w2 = w.reshape(w.shape[0], -1)
+    if len(uniq) == 0 and kind != "Adam":     # no row has a gradient (an all-empty column); Adam still decays / moves
+        return
+    rg = rg.reshape(len(uniq), w2.shape[1])
+    if kind == "SGD":
+        w2[idx] -= opt[1] * rg
+    elif kind == "Adagrad":
+        adagrad_rows(w2, state[nm + sb].reshape(w2.shape), uniq, rg, opt[1])
+    elif kind == "Ftrl":
+        ftrl_rows(w, state[nm + sa], state[nm + sb], uniq, rg, opt[1], opt[2], opt[3])
+    elif kind == "RMSProp":
+        _, lr, decay, mom, eps = opt
+        ms_t, mo_t = state[nm + sa].reshape(w2.shape), state[nm + sb].reshape(w2.shape)
+        ms = ms_t[idx]
+        ms = ms + (rg * rg - ms) * (1.0 - decay)
+        mo = mo_t[idx] * mom + lr * rg / torch.sqrt(ms + eps)
+        ms_t[idx] = ms
+        mo_t[idx] = mo
+        w2[idx] -= mo
+    elif kind == "Adam":
+        _, lr, b1, b2, eps = opt
+        m, v = state[nm + sa].reshape(w2.shape), state[nm + sb].reshape(w2.shape)
+        lr_t = np.float32(lr) * np.sqrt(np.float32(1.0) - np.float32(pow_[1])) / (np.float32(1.0) - np.float32(pow_[0]))
+        m *= b1
+        m[idx] += (1.0 - b1) * rg
+        v *= b2
+        v[idx] += (1.0 - b2) * rg * rg
+        w2 -= float(lr_t) * m / (torch.sqrt(v) + eps)
+    else:
+        raise ValueError(kind)
+
+
+def adam_pow_names(dnn_opt, lin_opt, has_deep=True, has_wide=True):
+    """Names of the non-slot beta-power variables: the first Adam optimizer built by python/lib/joint.py:224-262 (dnn, then
+    linear) owns beta1_power / beta2_power, a second one gets the _1 suffix (TF name uniquification)."""
+    out, n = {}, 0
+    for scope, opt, on in (("dnn", dnn_opt, has_deep), ("linear", lin_opt, has_wide)):
+        if on and opt[0] == "Adam":
+            suf = "" if n == 0 else "_%d" % n
+            out[scope] = ("beta1_power" + suf, "beta2_power" + suf)
+            n += 1
+    return out
+
+
 def bce_sum(logits, labels, weights=None):
     n = logits.numel()
     dl = torch.zeros(n, dtype=torch.float32)
@@ -259,6 +362,28 @@ class OracleWideDeep:
         self.batch_norm = batch_norm
         self.dnn_opt = dnn_opt
         self.lin_opt = lin_opt
+
+    # -- Adam beta powers (non-slot variables, one pair per optimizer instance) ---------------------
+    def _pow_names(self):
+        return adam_pow_names(self.dnn_opt, self.lin_opt, self.model_type in ("deep", "wide_deep"),
+                              self.model_type in ("wide", "wide_deep"))
+
+    def _pow(self, scope):
+        names = self._pow_names().get(scope)
+        if names is None:
+            return None
+        opt = self.dnn_opt if scope == "dnn" else self.lin_opt
+        for nm, b in zip(names, (opt[2], opt[3])):
+            if nm not in self.state:
+                self.state[nm] = torch.tensor(float(b), dtype=torch.float32)
+        return float(self.state[names[0]]), float(self.state[names[1]])
+
+    def _tick(self, scope):
+        names = self._pow_names().get(scope)
+        if names is not None:
+            opt = self.dnn_opt if scope == "dnn" else self.lin_opt
+            self.state[names[0]] = self.state[names[0]] * np.float32(opt[2])
+            self.state[names[1]] = self.state[names[1]] * np.float32(opt[3])
 
     # -- variable names ----------------------------------------------------
     @staticmethod
@@ -354,8 +479,8 @@ class OracleWideDeep:
 
         if "dnn" in cache:
             cache["dnn"].backward(dlogit)
-            _, lr, _ = self.dnn_opt
-            assert self.dnn_opt[0] == "Adagrad"
+            opt = self.dnn_opt
+            pw = self._pow("dnn")
             dx = cache["x"].grad
             # dense tower params
             with torch.no_grad():
@@ -372,7 +497,7 @@ class OracleWideDeep:
                         v = self.state[nm]
                         g = v.grad
                         v.requires_grad_(False)
-                        adagrad_dense(v, self.state[nm + "/Adagrad"], g, lr)
+                        opt_apply_dense(opt, self.state, nm, g, pw)
                         v.grad = None
             # embedding rows
             col0 = 0
@@ -381,21 +506,20 @@ class OracleWideDeep:
                     D = c["dim"]
                     ids, offs = batch["ids"][c["key"]]
                     uniq, rg = embag_row_grads(D, ids, offs, dx[:, col0:col0 + D], mean=True)
-                    nm = self.emb_name(c)
-                    adagrad_rows(self.state[nm], self.state[nm + "/Adagrad"], uniq, rg, lr)
+                    opt_apply_rows(opt, self.state, self.emb_name(c), uniq, rg, pw)
                     col0 += D
                 elif c["kind"] == "indicator":
                     col0 += c["num_buckets"]
                 else:
                     col0 += 1
+            self._tick("dnn")
         if "wide" in cache:
-            assert self.lin_opt[0] == "Ftrl"
-            _, lr, l1, l2, _ = self.lin_opt
+            opt = self.lin_opt
+            pw = self._pow("linear")
             for c in self.wide_cols:
                 ids, offs = batch["ids"][c["key"]]
                 uniq, rg = embag_row_grads(1, ids, offs, dlogit.reshape(-1, 1), mean=False)
-                nm = self.wide_name(c)
-                ftrl_rows(self.state[nm], self.state[nm + "/Ftrl_1"], self.state[nm + "/Ftrl"], uniq, rg, lr, l1, l2)
-            nm = "linear/linear_model/bias_weights"
-            ftrl_dense(self.state[nm], self.state[nm + "/Ftrl_1"], self.state[nm + "/Ftrl"], dlogit.sum().reshape(1), lr, l1, l2)
+                opt_apply_rows(opt, self.state, self.wide_name(c), uniq, rg, pw)
+            opt_apply_dense(opt, self.state, "linear/linear_model/bias_weights", dlogit.sum().reshape(1), pw)
+            self._tick("linear")
         return loss, logits

@@ -233,3 +233,21 @@ def test_buffer_shuffle_semantics():
     pos = np.empty(1000, dtype=np.int64); pos[b] = np.arange(1000)
     assert bool((pos >= np.arange(1000) - 64).all())
     assert np.array_equal(b, DS._buffer_shuffle(1000, 64, seed=123))
+
+
+def test_every_reference_optimizer_name_and_constructor_parses():
+    """model_util.py:84-105: the five names, or a tf.train constructor expression (parsed, never eval'ed)."""
+    from wide_deep_amd.build_estimator import opt_tuple, parse_optimizer
+    import pytest
+    assert opt_tuple(*parse_optimizer("SGD", 0.05)) == ("SGD", 0.05)
+    assert opt_tuple(*parse_optimizer("Adam", 0.05)) == ("Adam", 0.05, 0.9, 0.999, 1e-8)
+    assert opt_tuple(*parse_optimizer("RMSProp", 0.02)) == ("RMSProp", 0.02, 0.9, 0.0, 1e-10)
+    assert opt_tuple(*parse_optimizer("tf.train.AdamOptimizer(beta1=0.8, epsilon=1e-6)", 0.05)) == ("Adam", 0.001, 0.8, 0.999, 1e-6)
+    assert opt_tuple(*parse_optimizer("tf.train.RMSPropOptimizer(0.1, decay=0.5, momentum=0.3)", 0.05)) == (
+        "RMSProp", 0.1, 0.5, 0.3, 1e-10)
+    assert opt_tuple(*parse_optimizer("tf.train.GradientDescentOptimizer(learning_rate=0.3)", 0.05)) == ("SGD", 0.3)
+    assert opt_tuple(*parse_optimizer("Ftrl", 0.2)) == ("Ftrl", 0.2, 0.0, 0.0, 0.1)
+    with pytest.raises(ValueError):
+        parse_optimizer("Adadelta", 0.1)
+    with pytest.raises(NotImplementedError):
+        opt_tuple(*parse_optimizer("tf.train.RMSPropOptimizer(0.1, centered=True)", 0.05))

@@ -133,3 +133,33 @@ def test_train_py_cli_dynamic_mode(tmp_path):
     assert out.returncode == 0, out.stderr[-2000:]
     assert "Using dynamic train mode." in out.stdout and "auc:" in out.stdout and "examples/sec" in out.stdout
     assert any(f.startswith("model.ckpt-") for f in os.listdir(tmp_path / "model" / "wide_deep"))
+
+
+def test_eval_py_and_pred_py_clis(tmp_path):
+    """`python eval.py` / `python pred.py` (reference python/eval.py, python/pred.py) on a model trained by train.py:
+    the printed metrics equal estimator.evaluate, every prediction line carries the winning class and its probability."""
+    import subprocess
+    import sys
+    from wide_deep_amd import build_estimator as BE, dataset as DS
+    lines = open(FIXTURE, "rb").read().splitlines()
+    path = _write(tmp_path, lines)
+    pred_path = _write(tmp_path, [ln.split(b"\t", 1)[1] for ln in lines[:20]], "pred.tsv")
+    model_root = str(tmp_path / "model")
+    m = BE.build_custom_estimator(os.path.join(model_root, "wide_deep"), "wide_deep", max_batch=128)
+    m.train(input_fn=lambda: DS.input_fn(path, None, "train", 128), steps=3)
+    ref = m.evaluate(input_fn=lambda: DS.input_fn(path, None, "eval", 128))
+    root = os.path.dirname(HERE)
+    out = subprocess.run([sys.executable, os.path.join(root, "eval.py"), "--model_dir", model_root, "--test_data", path,
+                          "--batch_size", "128", "--model_type", "wide_deep"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    got = dict(ln.split(": ", 1) for ln in out.stdout.splitlines() if ": " in ln and not ln.startswith(("INFO", "Model")))
+    for key in ("auc", "average_loss", "accuracy", "label/mean", "global_step"):
+        assert abs(float(got[key]) - float(ref[key])) <= 1e-6 * max(1.0, abs(float(ref[key]))), (key, got[key], ref[key])
+    out = subprocess.run([sys.executable, os.path.join(root, "pred.py"), "--model_dir", model_root, "--data_dir", pred_path,
+                          "--batch_size", "128", "--model_type", "wide_deep"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    preds = [ln for ln in out.stdout.splitlines() if ln.startswith("Prediction is")]
+    assert len(preds) == 20 and all(p.startswith('Prediction is "0"') or p.startswith('Prediction is "1"') for p in preds)
+    out = subprocess.run([sys.executable, os.path.join(root, "pred.py"), "--model_dir", model_root], capture_output=True,
+                         text=True, timeout=600)
+    assert out.returncode != 0 and "Must specify prediction data_file by --data_dir" in out.stderr

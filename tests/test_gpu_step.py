@@ -47,9 +47,15 @@ def _spec(**kw):
     return criteo_spec(**base)
 
 
-@pytest.mark.parametrize("mode", ["simple", "dense", "resnet", "last_dense"])
+@pytest.mark.parametrize("mode", ["simple", "dense", "resnet", "last_dense", "first_dense"])
 def test_train_steps_match_oracle_modes(mode):
     _run(_spec(mode=mode))
+
+
+@pytest.mark.parametrize("hidden", [(16,), (32, 16), (32, 16, 8, 12), (16, 8, 8, 4, 12)])
+def test_first_dense_depths(hidden):
+    """first_dense (python/lib/dnn.py:117-133): 1-5 hidden layers -> 0, 0, 1 and 2 extra copies of the deep input."""
+    _run(_spec(mode="first_dense", hidden=hidden))
 
 
 def test_multi_hot_zipf_with_weight_column():

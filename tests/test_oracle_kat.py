@@ -89,3 +89,47 @@ def test_ftrl_and_adagrad_formulas():
     t = torch.ones(2, 3); acc = torch.full((2, 3), 0.1)
     O.adagrad_rows(t, acc, np.asarray([0]), torch.full((1, 3), 0.5), 0.05)
     assert torch.allclose(t[0], torch.full((3,), 1 - 0.05 * 0.5 / np.sqrt(0.35)), atol=1e-6) and torch.all(t[1] == 1)
+
+
+def test_optimizer_restatements_hand_computed():
+    """tf.train.{GradientDescent,RMSProp,Adam} (dense and sparse forms) on numbers small enough to follow by hand."""
+    import numpy as np
+    import torch
+    from oracle import oracle as O
+    f = lambda *v: torch.tensor(v, dtype=torch.float32)
+    # SGD dense / sparse
+    st = {"w": f(1.0, 2.0)}
+    O.opt_apply_dense(("SGD", 0.1), st, "w", f(10.0, -10.0), None)
+    assert torch.allclose(st["w"], f(0.0, 3.0))
+    st = {"t": torch.ones(3, 2)}
+    O.opt_apply_rows(("SGD", 0.5), st, "t", np.asarray([2]), f(1.0, 2.0).reshape(1, 2), None)
+    assert torch.allclose(st["t"], torch.tensor([[1.0, 1.0], [1.0, 1.0], [0.5, 0.0]]))
+    # RMSProp: ms = 1 + (4 - 1) * 0.1 = 1.3; mom = 0.5 * 0 + 0.1 * 2 / sqrt(1.3 + 0) ; var = 1 - mom
+    st = {"w": f(1.0), "w/RMSProp": f(1.0), "w/RMSProp_1": f(0.0)}
+    O.opt_apply_dense(("RMSProp", 0.1, 0.9, 0.5, 0.0), st, "w", f(2.0), None)
+    mom = 0.1 * 2 / np.sqrt(1.3)
+    assert abs(float(st["w/RMSProp"]) - 1.3) < 1e-6 and abs(float(st["w/RMSProp_1"]) - mom) < 1e-6
+    assert abs(float(st["w"]) - (1 - mom)) < 1e-6
+    O.opt_apply_dense(("RMSProp", 0.1, 0.9, 0.5, 0.0), st, "w", f(0.0), None)    # momentum keeps moving it
+    assert abs(float(st["w/RMSProp_1"]) - 0.5 * mom) < 1e-6 and abs(float(st["w"]) - (1 - 1.5 * mom)) < 1e-6
+    # RMSProp sparse: untouched rows keep their slots and values
+    st = {"t": torch.ones(2, 1), "t/RMSProp": torch.ones(2, 1), "t/RMSProp_1": torch.zeros(2, 1)}
+    O.opt_apply_rows(("RMSProp", 0.1, 0.9, 0.0, 0.0), st, "t", np.asarray([1]), f(2.0).reshape(1, 1), None)
+    assert float(st["t"][0]) == 1.0 and float(st["t/RMSProp"][0]) == 1.0 and abs(float(st["t"][1]) - (1 - mom)) < 1e-6
+    # Adam dense, t = 1: m = 0.1 g, v = 0.001 g^2, lr_t = lr sqrt(1 - 0.999) / (1 - 0.9); step = lr * g / |g| (eps -> 0)
+    st = {"w": f(1.0), "w/Adam": f(0.0), "w/Adam_1": f(0.0)}
+    O.opt_apply_dense(("Adam", 0.01, 0.9, 0.999, 0.0), st, "w", f(3.0), (0.9, 0.999))
+    assert abs(float(st["w/Adam"]) - 0.3) < 1e-6 and abs(float(st["w/Adam_1"]) - 0.009) < 1e-7
+    assert abs(float(st["w"]) - 0.99) < 1e-6
+    # Adam sparse: row 0 hit at t = 1, not at t = 2 -> it still moves at t = 2 (m decays, no new gradient)
+    st = {"t": torch.ones(2, 1), "t/Adam": torch.zeros(2, 1), "t/Adam_1": torch.zeros(2, 1)}
+    O.opt_apply_rows(("Adam", 0.01, 0.9, 0.999, 1e-8), st, "t", np.asarray([0]), f(3.0).reshape(1, 1), (0.9, 0.999))
+    assert abs(float(st["t"][0]) - 0.99) < 1e-6 and float(st["t"][1]) == 1.0       # m = v = 0: 0 / (0 + eps) = 0
+    O.opt_apply_rows(("Adam", 0.01, 0.9, 0.999, 1e-8), st, "t", np.asarray([1]), f(-1.0).reshape(1, 1), (0.81, 0.998001))
+    m0, v0 = 0.3 * 0.9, 0.009 * 0.999
+    lr_t = 0.01 * np.sqrt(1 - 0.998001) / (1 - 0.81)
+    assert abs(float(st["t"][0]) - (0.99 - lr_t * m0 / np.sqrt(v0))) < 1e-6
+    assert abs(float(st["t"][1]) - (1.0 + lr_t * 0.1 / np.sqrt(0.001))) < 1e-6
+    assert O.adam_pow_names(("Adam", 1, .9, .999, 1e-8), ("Adam", 1, .9, .999, 1e-8)) == {
+        "dnn": ("beta1_power", "beta2_power"), "linear": ("beta1_power_1", "beta2_power_1")}
+    assert O.adam_pow_names(("Adagrad", 1, .1), ("Adam", 1, .9, .999, 1e-8)) == {"linear": ("beta1_power", "beta2_power")}

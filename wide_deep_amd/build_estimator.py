@@ -42,23 +42,32 @@ def parse_optimizer(opt, default_lr):
         kwargs["learning_rate"] = ast.literal_eval(node.args[0])
     for kw in node.keywords:
         kwargs[kw.arg] = ast.literal_eval(kw.value)
-    kwargs.setdefault("learning_rate", default_lr)
+    # a constructor without learning_rate: AdamOptimizer has a default (0.001); the others require the argument
+    kwargs.setdefault("learning_rate", 0.001 if _OPT_ALIASES[cls] == "Adam" else default_lr)
     return _OPT_ALIASES[cls], kwargs
 
 
-def _dnn_opt_tuple(name, kw):
-    if name != "Adagrad":
-        return (name, float(kw["learning_rate"]), 0.1)
-    return ("Adagrad", float(kw["learning_rate"]), float(kw.get("initial_accumulator_value", 0.1)))
-
-
-def _lin_opt_tuple(name, kw):
-    if name != "Ftrl":
-        return (name, float(kw["learning_rate"]), 0.0, 0.0, 0.1)
-    if float(kw.get("learning_rate_power", -0.5)) != -0.5 or float(kw.get("l2_shrinkage_regularization_strength", 0.0)) != 0.0:
-        raise NotImplementedError("FtrlOptimizer: only learning_rate_power=-0.5 and no l2 shrinkage are implemented")
-    return ("Ftrl", float(kw["learning_rate"]), float(kw.get("l1_regularization_strength", 0.0)),
-            float(kw.get("l2_regularization_strength", 0.0)), float(kw.get("initial_accumulator_value", 0.1)))
+def opt_tuple(name, kw):
+    """(name, kwargs) -> the optimizer tuple of plan.ModelSpec / the oracle, with the tf.train constructor defaults:
+       ("SGD", lr) ("Adagrad", lr, initial_accumulator_value) ("Ftrl", lr, l1, l2, initial_accumulator_value)
+       ("RMSProp", lr, decay, momentum, epsilon) ("Adam", lr, beta1, beta2, epsilon)"""
+    lr = float(kw["learning_rate"])
+    if name == "SGD":
+        return ("SGD", lr)
+    if name == "Adagrad":
+        return ("Adagrad", lr, float(kw.get("initial_accumulator_value", 0.1)))
+    if name == "Ftrl":
+        if float(kw.get("learning_rate_power", -0.5)) != -0.5 or float(kw.get("l2_shrinkage_regularization_strength", 0.0)) != 0.0:
+            raise NotImplementedError("FtrlOptimizer: only learning_rate_power=-0.5 and no l2 shrinkage are implemented")
+        return ("Ftrl", lr, float(kw.get("l1_regularization_strength", 0.0)),
+                float(kw.get("l2_regularization_strength", 0.0)), float(kw.get("initial_accumulator_value", 0.1)))
+    if name == "RMSProp":
+        if kw.get("centered"):
+            raise NotImplementedError("RMSPropOptimizer(centered=True) is not implemented")
+        return ("RMSProp", lr, float(kw.get("decay", 0.9)), float(kw.get("momentum", 0.0)), float(kw.get("epsilon", 1e-10)))
+    if name == "Adam":
+        return ("Adam", lr, float(kw.get("beta1", 0.9)), float(kw.get("beta2", 0.999)), float(kw.get("epsilon", 1e-8)))
+    raise ValueError("Unsupported optimizer: %s" % name)
 
 
 def build_model_spec(conf=None, model_type=None):
@@ -125,7 +134,7 @@ def build_model_spec(conf=None, model_type=None):
     return ModelSpec(model_type=model_type, slots=slots, dense_cols=dense, towers=towers,
                      activation=model.get("dnn_activation_function") or "relu",
                      batch_norm=bool(model.get("dnn_batch_normalization")), dropout=model.get("dnn_dropout") or None,
-                     dnn_opt=_dnn_opt_tuple(dnn_name, dnn_kw), lin_opt=_lin_opt_tuple(lin_name, lin_kw),
+                     dnn_opt=opt_tuple(dnn_name, dnn_kw), lin_opt=opt_tuple(lin_name, lin_kw),
                      use_weight_column=use_w, pos_weight=float(train["pos_sample_loss_weight"] or 1.0),
                      neg_weight=float(train["neg_sample_loss_weight"] or 1.0))
 

@@ -57,6 +57,14 @@ WD_CHAIN_MAX_LAYERS = 6
 WD_TN_GROUP_MAX = 8
 
 
+WD_OPT_KINDS = {"SGD": 0, "Adagrad": 1, "Ftrl": 2, "RMSProp": 3, "Adam": 4}
+
+
+class WdOpt(ctypes.Structure):
+    _fields_ = [("kind", ctypes.c_int32), ("lr", ctypes.c_float), ("p0", ctypes.c_float), ("p1", ctypes.c_float),
+                ("p2", ctypes.c_float), ("pad_", ctypes.c_int32), ("pow", ctypes.c_void_p)]
+
+
 class WdTnJob(ctypes.Structure):
     _fields_ = [
         ("A", ctypes.c_void_p), ("B", ctypes.c_void_p), ("Cpart", ctypes.c_void_p),
@@ -123,6 +131,10 @@ _PROTOS = {
     "wd_mlp_finalize_all": [P, I32, I64, P, F32, P, P],
     "wd_logits_head_blocks": [I64, I64],
     "wd_gemm_tn_splitk_group": [P, I32, P],
+    "wd_sparse_apply_opt": [P, P, P, P, P, P, I32, P, I64, P, I64, P, I64, P, P, P, P, I32, P, P],
+    "wd_opt_dense": [P, P, P, P, I64, P, P],
+    "wd_adam_untouched": [P, P, P, P, P, I32, I64, I64, P, P, P, P],
+    "wd_adam_tick": [P, F32, F32, P],
     "wd_tower_chain_lds_bytes": [I32, P, I32],
     "wd_tower_chain_blocks": [I64],
     "wd_tower_chain_set_stamps": [P],

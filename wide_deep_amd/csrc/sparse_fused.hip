@@ -210,8 +210,49 @@ __device__ __forceinline__ float4 adagrad4(float4 &a, float4 w, float4 g, float 
   return w;
 }
 
+// Any tf.train optimizer the reference accepts (python/lib/utils/model_util.py:84-90), one parameter at a time.
+// Slots: a / b of include/wd_hip.h (wd_opt_t): Adagrad b = accumulator; Ftrl a = linear (z), b = accumulator (n);
+// RMSProp a = rms, b = momentum; Adam a = m, b = v.
+struct OptK {
+  int32_t kind;
+  float lr, p0, p1, p2;
+  float b1p, b2p;   // Adam: beta1^t, beta2^t of this step
+};
+
+__device__ __forceinline__ void ftrl_update(float &w, float &z, float &n, float g, float lr, float l1, float l2);
+
+__device__ __forceinline__ void opt_step(const OptK &o, float &w, float &a, float &b, float g) {
+  switch (o.kind) {
+    case WD_OPT_SGD:       // GradientDescentOptimizer: var -= lr * g
+      w -= o.lr * g;
+      break;
+    case WD_OPT_ADAGRAD:   // accum += g^2; var -= lr * g / sqrt(accum)
+      b += g * g;
+      w -= o.lr * g / sqrtf(b);
+      break;
+    case WD_OPT_FTRL:
+      ftrl_update(w, a, b, g, o.lr, o.p0, o.p1);
+      break;
+    case WD_OPT_RMSPROP:   // ms += (g^2 - ms)(1 - decay); mom = mom*momentum + lr*g/sqrt(ms + eps); var -= mom
+      a += (g * g - a) * (1.0f - o.p0);
+      b = b * o.p1 + o.lr * g / sqrtf(a + o.p2);
+      w -= b;
+      break;
+    default: {             // Adam on a touched row: AdamOptimizer._apply_sparse_shared (m*b1 + (1-b1)g, ...)
+      a = a * o.p0 + (1.0f - o.p0) * g;
+      b = b * o.p1 + (1.0f - o.p1) * g * g;
+      const float lr_t = o.lr * sqrtf(1.0f - o.b2p) / (1.0f - o.b1p);
+      w -= lr_t * a / (sqrtf(b) + o.p2);
+    }
+  }
+}
+
 struct UpdArgs {
   float *emb, *accum, *wide, *bias;
+  float *accum_a;            // second embedding slot table (generic optimizers; `accum` is slot b)
+  uint32_t *touched;         // Adam: bit per fused row updated here (wd_adam_untouched does the others)
+  OptK oe, ow;               // embedding (dnn scope) / wide + bias (linear scope) optimizer
+  const float *pow_e, *pow_w;
   const wd_slot_t *slots;
   const int32_t *bag_offs;
   const float *dx;
@@ -253,8 +294,28 @@ __device__ __forceinline__ void bitonic_sort(PtrT p, int m) {
   }
 }
 
+template <bool GEN>   // GEN: optimizers other than Adagrad (embeddings) + Ftrl (wide); same control flow
 __global__ void __launch_bounds__(256)
 k_bucket_update(UpdArgs u, const int32_t *__restrict__ start, uint64_t *__restrict__ pairs) {
+  if (GEN) {   // Adam: the beta powers live in HBM so that a captured graph sees them advance
+    if (u.pow_e) { u.oe.b1p = u.pow_e[0]; u.oe.b2p = u.pow_e[1]; }
+    if (u.pow_w) { u.ow.b1p = u.pow_w[0]; u.ow.b2p = u.pow_w[1]; }
+  }
+  // generic per-row updates: up to 4 consecutive parameters of an embedding row / one wide {w, a, b, -} line
+  auto emb_apply = [&](int64_t off, int cnt, const float *g) {
+    for (int k2 = 0; k2 < cnt; ++k2) {
+      float w = u.emb[off + k2];
+      float a = u.accum_a ? u.accum_a[off + k2] : 0.f, b = u.accum ? u.accum[off + k2] : 0.f;
+      opt_step(u.oe, w, a, b, g[k2]);
+      u.emb[off + k2] = w;
+      if (u.accum_a) u.accum_a[off + k2] = a;
+      if (u.accum) u.accum[off + k2] = b;
+    }
+  };
+  auto wide_apply = [&](float4 &r, float g) { opt_step(u.ow, r.x, r.y, r.z, g); };
+  auto touch = [&](uint32_t key) {
+    if (GEN && u.touched) atomicOr(&u.touched[key >> 5], 1u << (key & 31));
+  };
   __shared__ uint64_t lds_pairs[CAP_LDS];
   __shared__ float4 red[256];                               // long-segment tree; doubles as the rank-sort input
   uint64_t *lds_in = reinterpret_cast<uint64_t *>(red);     // RANK_MAX * 8 B == 256 * 16 B
@@ -278,7 +339,19 @@ k_bucket_update(UpdArgs u, const int32_t *__restrict__ start, uint64_t *__restri
     }
     if (t == 0) {
       float w = u.bias[0], z = u.bias[1], n = u.bias[2];
-      ftrl_update(w, z, n, redw[0], u.lr_w, u.l1, u.l2);
+      if (GEN) {
+        OptK ob = u.ow;
+        if (ob.kind == WD_OPT_ADAM) ob.kind = WD_OPT_ADAM_DENSE;   // a dense [1] variable: ApplyAdam's form
+        if (ob.kind == WD_OPT_ADAM_DENSE) {
+          z += (redw[0] - z) * (1.0f - ob.p0);
+          n += (redw[0] * redw[0] - n) * (1.0f - ob.p1);
+          w -= ob.lr * sqrtf(1.0f - ob.b2p) / (1.0f - ob.b1p) * z / (sqrtf(n) + ob.p2);
+        } else {
+          opt_step(ob, w, z, n, redw[0]);
+        }
+      } else {
+        ftrl_update(w, z, n, redw[0], u.lr_w, u.l1, u.l2);
+      }
       u.bias[0] = w; u.bias[1] = z; u.bias[2] = n;
     }
     return;
@@ -375,8 +448,10 @@ k_bucket_update(UpdArgs u, const int32_t *__restrict__ start, uint64_t *__restri
       float dl = 0.f;
       if (lane_emb) {
         d = *reinterpret_cast<const float4 *>(u.dx + b * u.ldx + sl.out_col + 4 * gl);
-        a = *reinterpret_cast<float4 *>(u.accum + off);
-        w = *reinterpret_cast<float4 *>(u.emb + off);
+        if (!GEN) {
+          a = *reinterpret_cast<float4 *>(u.accum + off);
+          w = *reinterpret_cast<float4 *>(u.emb + off);
+        }
       }
       if (do_wide && gl == 0) {
         dl = u.dlogit[b * u.ld_dlogit];
@@ -387,16 +462,23 @@ k_bucket_update(UpdArgs u, const int32_t *__restrict__ start, uint64_t *__restri
         const float scale = len > 1 ? 1.0f / (float)len : 1.0f;
         float4 g = make_float4(0.f, 0.f, 0.f, 0.f);   // 0 + d*scale: same rounding as the general loop
         g.x += d.x * scale; g.y += d.y * scale; g.z += d.z * scale; g.w += d.w * scale;
-        const float4 wn = adagrad4(a, w, g, u.lr_emb);
-        *reinterpret_cast<float4 *>(u.accum + off) = a;
-        *reinterpret_cast<float4 *>(u.emb + off) = wn;
+        if (GEN) {
+          const float gg[4] = {g.x, g.y, g.z, g.w};
+          emb_apply(off, 4, gg);
+        } else {
+          const float4 wn = adagrad4(a, w, g, u.lr_emb);
+          *reinterpret_cast<float4 *>(u.accum + off) = a;
+          *reinterpret_cast<float4 *>(u.emb + off) = wn;
+        }
       }
       if (do_wide && gl == 0) {
         float g = 0.f;
         g += dl;
-        ftrl_update(r.x, r.y, r.z, g, u.lr_w, u.l1, u.l2);
+        if (GEN) wide_apply(r, g);
+        else ftrl_update(r.x, r.y, r.z, g, u.lr_w, u.l1, u.l2);
         *reinterpret_cast<float4 *>(u.wide + (int64_t)key * 4) = r;
       }
+      if (gl == 0) touch(key);
       continue;
     }
     if (do_emb && (D & 3) == 0) {
@@ -410,11 +492,16 @@ k_bucket_update(UpdArgs u, const int32_t *__restrict__ start, uint64_t *__restri
           const float4 d = *reinterpret_cast<const float4 *>(u.dx + (int64_t)(bag / S) * u.ldx + sl.out_col + 4 * c);
           g.x += d.x * scale; g.y += d.y * scale; g.z += d.z * scale; g.w += d.w * scale;
         }
-        float4 a = *reinterpret_cast<float4 *>(u.accum + off + 4 * c);
-        const float4 w = *reinterpret_cast<float4 *>(u.emb + off + 4 * c);
-        const float4 wn = adagrad4(a, w, g, u.lr_emb);
-        *reinterpret_cast<float4 *>(u.accum + off + 4 * c) = a;
-        *reinterpret_cast<float4 *>(u.emb + off + 4 * c) = wn;
+        if (GEN) {
+          const float gg[4] = {g.x, g.y, g.z, g.w};
+          emb_apply(off + 4 * c, 4, gg);
+        } else {
+          float4 a = *reinterpret_cast<float4 *>(u.accum + off + 4 * c);
+          const float4 w = *reinterpret_cast<float4 *>(u.emb + off + 4 * c);
+          const float4 wn = adagrad4(a, w, g, u.lr_emb);
+          *reinterpret_cast<float4 *>(u.accum + off + 4 * c) = a;
+          *reinterpret_cast<float4 *>(u.emb + off + 4 * c) = wn;
+        }
       }
     } else if (do_emb) {  // dims that are not a multiple of 4 (opt-in override only)
       const int64_t off = sl.emb_off + ((int64_t)key - sl.row_base) * D;
@@ -426,18 +513,24 @@ k_bucket_update(UpdArgs u, const int32_t *__restrict__ start, uint64_t *__restri
           const float scale = len > 1 ? 1.0f / (float)len : 1.0f;
           g += u.dx[(int64_t)(bag / S) * u.ldx + sl.out_col + d0] * scale;
         }
-        const float a = u.accum[off + d0] + g * g;
-        u.accum[off + d0] = a;
-        u.emb[off + d0] -= u.lr_emb * g / sqrtf(a);
+        if (GEN) {
+          emb_apply(off + d0, 1, &g);
+        } else {
+          const float a = u.accum[off + d0] + g * g;
+          u.accum[off + d0] = a;
+          u.emb[off + d0] -= u.lr_emb * g / sqrtf(a);
+        }
       }
     }
     if (do_wide && gl == 0) {
       float g = 0.f;
       for (int j = i; j < e; ++j) g += u.dlogit[(int64_t)((int32_t)(uint32_t)sp[j] / S) * u.ld_dlogit];
       float4 r = *reinterpret_cast<float4 *>(u.wide + (int64_t)key * 4);  // {w, z, n, -}
-      ftrl_update(r.x, r.y, r.z, g, u.lr_w, u.l1, u.l2);
+      if (GEN) wide_apply(r, g);
+      else ftrl_update(r.x, r.y, r.z, g, u.lr_w, u.l1, u.l2);
       *reinterpret_cast<float4 *>(u.wide + (int64_t)key * 4) = r;
     }
+    if (gl == 0) touch(key);
   }
   __syncthreads();
   // ---- long segments: the whole workgroup per row, 64 lane groups in parallel + fixed-shape tree -------
@@ -445,6 +538,7 @@ k_bucket_update(UpdArgs u, const int32_t *__restrict__ start, uint64_t *__restri
   for (int q = 0; q < nl; ++q) {
     const int i = long_i0[q], e = long_i1[q];
     const uint32_t key = (uint32_t)(sp[i] >> 32);
+    if (t == 0) touch(key);
     const int32_t sidx = (int32_t)(uint32_t)sp[i] % S;
     const wd_slot_t sl = slots_in_lds ? lds_slots[sidx] : u.slots[sidx];
     const bool do_emb = u.emb && sl.kind == WD_SLOT_EMBEDDING && (int64_t)key - sl.row_base < sl.num_buckets;
@@ -509,11 +603,15 @@ k_bucket_update(UpdArgs u, const int32_t *__restrict__ start, uint64_t *__restri
         if (gidx == 0 && c < nchunk) {
           g = red[t];
           float gg[4] = {g.x, g.y, g.z, g.w};
-          for (int k2 = 0; k2 < 4 && 4 * c + k2 < D; ++k2) {
-            const int64_t o = off + 4 * c + k2;
-            const float a = u.accum[o] + gg[k2] * gg[k2];
-            u.accum[o] = a;
-            u.emb[o] -= u.lr_emb * gg[k2] / sqrtf(a);
+          if (GEN) {
+            emb_apply(off + 4 * c, D - 4 * c < 4 ? D - 4 * c : 4, gg);
+          } else {
+            for (int k2 = 0; k2 < 4 && 4 * c + k2 < D; ++k2) {
+              const int64_t o = off + 4 * c + k2;
+              const float a = u.accum[o] + gg[k2] * gg[k2];
+              u.accum[o] = a;
+              u.emb[o] -= u.lr_emb * gg[k2] / sqrtf(a);
+            }
           }
         }
         __syncthreads();
@@ -539,7 +637,8 @@ k_bucket_update(UpdArgs u, const int32_t *__restrict__ start, uint64_t *__restri
       }
       if (t == 0) {
         float4 r = *reinterpret_cast<float4 *>(u.wide + (int64_t)key * 4);
-        ftrl_update(r.x, r.y, r.z, redw[0], u.lr_w, u.l1, u.l2);
+        if (GEN) wide_apply(r, redw[0]);
+        else ftrl_update(r.x, r.y, r.z, redw[0], u.lr_w, u.l1, u.l2);
         *reinterpret_cast<float4 *>(u.wide + (int64_t)key * 4) = r;
       }
       __syncthreads();
@@ -593,9 +692,168 @@ extern "C" int wd_sparse_apply(float *emb, float *emb_accum, float *wide, float 
   u.dx = dx; u.dlogit = dlogit; u.ldx = ldx; u.batch = batch; u.S = S; u.nb = nbuckets;
   u.ld_dlogit = ld_dlogit > 0 ? ld_dlogit : 1;
   u.lr_emb = lr_emb; u.lr_w = lr_wide; u.l1 = l1; u.l2 = l2;
-  hipLaunchKernelGGL(k_bucket_update, dim3((unsigned)nbuckets + 1), dim3(256), 0, wd::as_stream(stream), u,
+  u.accum_a = nullptr; u.touched = nullptr; u.oe = OptK{}; u.ow = OptK{}; u.pow_e = u.pow_w = nullptr;
+  hipLaunchKernelGGL(k_bucket_update<false>, dim3((unsigned)nbuckets + 1), dim3(256), 0, wd::as_stream(stream), u,
                      bucket_start, pairs);
   return wd::check_launch("wd_sparse_apply");
+}
+
+static OptK to_optk(const wd_opt_t *o) {
+  OptK k{};
+  if (o) {
+    k.kind = o->kind; k.lr = o->lr; k.p0 = o->p0; k.p1 = o->p1; k.p2 = o->p2;
+    k.b1p = o->p0; k.b2p = o->p1;   // Adam without a power buffer: first step
+  }
+  return k;
+}
+
+static bool opt_ok(const wd_opt_t *o) { return o && o->kind >= WD_OPT_SGD && o->kind <= WD_OPT_ADAM; }
+
+// wd_sparse_apply with the optimizer of each scope chosen by the caller (model_util.py:84-90).
+extern "C" int wd_sparse_apply_opt(float *emb, float *emb_a, float *emb_b, float *wide, float *bias, const wd_slot_t *slots,
+                                   int32_t S, const int32_t *bag_offs, int64_t batch, const float *dx, int64_t ldx,
+                                   const float *dlogit, int64_t ld_dlogit, const wd_opt_t *emb_opt,
+                                   const wd_opt_t *wide_opt, const int32_t *bucket_start, uint64_t *pairs,
+                                   int32_t nbuckets, uint32_t *touched, wd_stream_t stream) {
+  if (batch <= 0) return WD_OK;
+  WD_REQUIRE(slots && bag_offs && bucket_start && pairs, "null pointer");
+  WD_REQUIRE(S > 0 && nbuckets > 0 && nbuckets <= MAX_NB, "bad bucket geometry");
+  WD_REQUIRE(!emb || (dx && opt_ok(emb_opt)), "embedding update needs dx and a valid optimizer");
+  WD_REQUIRE(!(wide || bias) || (dlogit && opt_ok(wide_opt)), "wide / bias update needs dlogit and a valid optimizer");
+  if (emb) {
+    const int k = emb_opt->kind;
+    WD_REQUIRE(k == WD_OPT_SGD || emb_b, "this optimizer needs slot table b");
+    WD_REQUIRE(k == WD_OPT_SGD || k == WD_OPT_ADAGRAD || emb_a, "this optimizer needs slot table a");
+  }
+  const bool adam = (emb && emb_opt->kind == WD_OPT_ADAM) || ((wide || bias) && wide_opt->kind == WD_OPT_ADAM);
+  WD_REQUIRE(!adam || touched, "Adam needs the touched-row bitmap (wd_adam_untouched updates the other rows)");
+  UpdArgs u;
+  u.emb = emb; u.accum = emb_b; u.accum_a = emb_a; u.wide = wide; u.bias = bias; u.slots = slots; u.bag_offs = bag_offs;
+  u.dx = dx; u.dlogit = dlogit; u.ldx = ldx; u.batch = batch; u.S = S; u.nb = nbuckets;
+  u.ld_dlogit = ld_dlogit > 0 ? ld_dlogit : 1;
+  u.lr_emb = u.lr_w = u.l1 = u.l2 = 0.f;
+  u.touched = adam ? touched : nullptr;
+  u.oe = to_optk(emb ? emb_opt : nullptr); u.ow = to_optk((wide || bias) ? wide_opt : nullptr);
+  u.pow_e = (emb && emb_opt->kind == WD_OPT_ADAM) ? emb_opt->pow : nullptr;
+  u.pow_w = ((wide || bias) && wide_opt->kind == WD_OPT_ADAM) ? wide_opt->pow : nullptr;
+  hipLaunchKernelGGL(k_bucket_update<true>, dim3((unsigned)nbuckets + 1), dim3(256), 0, wd::as_stream(stream), u,
+                     bucket_start, pairs);
+  return wd::check_launch("wd_sparse_apply_opt");
+}
+
+namespace {
+
+// dense variables of a scope (tower kernels / biases / BN affines): one elementwise launch, tf.train kernels' forms
+__global__ void __launch_bounds__(256)
+k_opt_dense(float *__restrict__ w, float *__restrict__ sa, float *__restrict__ sb, const float *__restrict__ g, int64_t n,
+            OptK o, const float *__restrict__ pw) {
+  if (pw) { o.b1p = pw[0]; o.b2p = pw[1]; }
+  const float lr_t = o.kind == WD_OPT_ADAM ? o.lr * sqrtf(1.0f - o.b2p) / (1.0f - o.b1p) : 0.f;
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    float wv = w[i], a = sa ? sa[i] : 0.f, b = sb ? sb[i] : 0.f;
+    const float gi = g[i];
+    if (o.kind == WD_OPT_ADAM) {   // ApplyAdam: m += (g - m)(1 - b1); v += (g^2 - v)(1 - b2); var -= lr_t m / (sqrt(v) + eps)
+      a += (gi - a) * (1.0f - o.p0);
+      b += (gi * gi - b) * (1.0f - o.p1);
+      wv -= lr_t * a / (sqrtf(b) + o.p2);
+    } else {
+      opt_step(o, wv, a, b, gi);
+    }
+    w[i] = wv;
+    if (sa) sa[i] = a;
+    if (sb) sb[i] = b;
+  }
+}
+
+// Adam moves EVERY row of a sparsely updated variable (AdamOptimizer._apply_sparse_shared assigns m*beta1, v*beta2 and
+// the var update over the whole variable): rows without a gradient this step, marked 0 in `touched`, get g = 0 here.
+// One thread per (row, 4-float chunk) of a slot / per wide line; the bitmap is cleared by wd_adam_untouched's memset.
+__global__ void __launch_bounds__(256)
+k_adam_untouched_emb(float *__restrict__ emb, float *__restrict__ m, float *__restrict__ v,
+                     const wd_slot_t *__restrict__ slots, const uint32_t *__restrict__ touched, OptK o,
+                     const float *__restrict__ pw) {
+  const wd_slot_t sl = slots[blockIdx.y];
+  if (sl.emb_off < 0 || sl.kind != WD_SLOT_EMBEDDING) return;
+  if (pw) { o.b1p = pw[0]; o.b2p = pw[1]; }
+  const float lr_t = o.lr * sqrtf(1.0f - o.b2p) / (1.0f - o.b1p);
+  const int64_t n = (int64_t)sl.num_buckets * sl.dim;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const uint32_t key = (uint32_t)(sl.row_base + i / sl.dim);
+    if (touched[key >> 5] & (1u << (key & 31))) continue;
+    const int64_t e = sl.emb_off + i;
+    const float a = m[e] * o.p0, b = v[e] * o.p1;
+    m[e] = a;
+    v[e] = b;
+    emb[e] -= lr_t * a / (sqrtf(b) + o.p2);
+  }
+}
+
+__global__ void __launch_bounds__(256)
+k_adam_untouched_wide(float *__restrict__ wide, const wd_slot_t *__restrict__ slots, const uint32_t *__restrict__ touched,
+                      OptK o, const float *__restrict__ pw) {
+  const wd_slot_t sl = slots[blockIdx.y];
+  if (!sl.wide) return;
+  if (pw) { o.b1p = pw[0]; o.b2p = pw[1]; }
+  const float lr_t = o.lr * sqrtf(1.0f - o.b2p) / (1.0f - o.b1p);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < sl.num_buckets; i += (int64_t)gridDim.x * 256) {
+    const uint32_t key = (uint32_t)(sl.row_base + i);
+    if (touched[key >> 5] & (1u << (key & 31))) continue;
+    float4 r = *reinterpret_cast<float4 *>(wide + (int64_t)key * 4);
+    r.y *= o.p0;
+    r.z *= o.p1;
+    r.x -= lr_t * r.y / (sqrtf(r.z) + o.p2);
+    *reinterpret_cast<float4 *>(wide + (int64_t)key * 4) = r;
+  }
+}
+
+__global__ void k_adam_tick(float *pw, float b1, float b2) {
+  pw[0] *= b1;
+  pw[1] *= b2;
+}
+
+}  // namespace
+
+extern "C" int wd_opt_dense(float *w, float *slot_a, float *slot_b, const float *g, int64_t n, const wd_opt_t *opt,
+                            wd_stream_t stream) {
+  if (n <= 0) return WD_OK;
+  WD_REQUIRE(w && g && opt_ok(opt), "null pointer / bad optimizer");
+  WD_REQUIRE(opt->kind == WD_OPT_SGD || slot_b, "this optimizer needs slot b");
+  WD_REQUIRE(opt->kind == WD_OPT_SGD || opt->kind == WD_OPT_ADAGRAD || slot_a, "this optimizer needs slot a");
+  const int blocks = (int)std::min<int64_t>(wd::ceil_div(n, 256), 2048);
+  hipLaunchKernelGGL(k_opt_dense, dim3(blocks), dim3(256), 0, wd::as_stream(stream), w, slot_a, slot_b, g, n, to_optk(opt),
+                     opt->kind == WD_OPT_ADAM ? opt->pow : nullptr);
+  return wd::check_launch("wd_opt_dense");
+}
+
+extern "C" int wd_adam_untouched(float *emb, float *emb_m, float *emb_v, float *wide, const wd_slot_t *slots, int32_t S,
+                                 int64_t max_rows, int64_t total_rows, uint32_t *touched, const wd_opt_t *emb_opt,
+                                 const wd_opt_t *wide_opt, wd_stream_t stream) {
+  WD_REQUIRE(slots && touched && S > 0 && total_rows > 0, "null pointer");
+  hipStream_t st = wd::as_stream(stream);
+  if (emb && emb_opt && emb_opt->kind == WD_OPT_ADAM) {
+    WD_REQUIRE(emb_m && emb_v, "Adam needs both slot tables");
+    const unsigned gx = (unsigned)std::min<int64_t>(wd::ceil_div(max_rows * 64, 256), 4096);
+    hipLaunchKernelGGL(k_adam_untouched_emb, dim3(gx, (unsigned)S), dim3(256), 0, st, emb, emb_m, emb_v, slots, touched,
+                       to_optk(emb_opt), emb_opt->pow);
+  }
+  if (wide && wide_opt && wide_opt->kind == WD_OPT_ADAM) {
+    const unsigned gx = (unsigned)std::min<int64_t>(wd::ceil_div(max_rows, 256), 4096);
+    hipLaunchKernelGGL(k_adam_untouched_wide, dim3(gx, (unsigned)S), dim3(256), 0, st, wide, slots, touched,
+                       to_optk(wide_opt), wide_opt->pow);
+  }
+  if (hipMemsetAsync(touched, 0, (size_t)((total_rows + 31) / 32) * 4, st) != hipSuccess) {
+    wd::set_error("wd_adam_untouched: hipMemsetAsync failed");
+    return WD_ERR_LAUNCH;
+  }
+  return wd::check_launch("wd_adam_untouched");
+}
+
+extern "C" int wd_adam_tick(float *pow, float beta1, float beta2, wd_stream_t stream) {
+  WD_REQUIRE(pow, "null pointer");
+  hipLaunchKernelGGL(k_adam_tick, dim3(1), dim3(1), 0, wd::as_stream(stream), pow, beta1, beta2);
+  return wd::check_launch("wd_adam_tick");
 }
 
 extern "C" int wd_sparse_bwd_fused(float *emb, float *emb_accum, float *wide, float *bias_wzn, const wd_slot_t *slots,

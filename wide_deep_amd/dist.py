@@ -162,6 +162,9 @@ class ShardedWideDeepEngine(WideDeepEngine):
         # owner side: the received list has n_req entries (padding included) -> capacity of the update workspaces
         super().__init__(local_spec(spec, W), max_batch=max_batch, max_nnz=max(mn, self.n_req), device=device,
                          seed=seed, expected_nnz=self.n_req)
+        if not self.default_opts:
+            raise NotImplementedError("sharded engine: Adagrad (dnn) + Ftrl (linear) only; the other optimizers of "
+                                      "model_util.py:84-90 run on the single-GPU engine")
         self.req_max_nnz = mn
         self.dim = dims.pop() if dims else 0
         if self.dim % 4:

@@ -18,7 +18,8 @@ import torch
 
 from . import capi
 from .capi import call, ptr
-from .plan import BN_EPS, FeaturePlan, ModelSpec, bucket_geometry
+from .plan import (BN_EPS, FeaturePlan, ModelSpec, OPT_SLOT_NAMES, adam_pow_names, bucket_geometry, opt_params,
+                   opt_slot_init)
 
 
 class DeviceBatch:
@@ -47,10 +48,13 @@ class WideDeepEngine:
         capi.load()
         if spec.dropout:
             raise NotImplementedError("dnn_dropout is not implemented yet (reference default is empty)")
-        if spec.has_deep and spec.dnn_opt[0] != "Adagrad":
-            raise NotImplementedError("dnn_optimizer %s: only Adagrad is implemented" % (spec.dnn_opt[0],))
-        if spec.has_wide and spec.lin_opt[0] != "Ftrl":
-            raise NotImplementedError("linear_optimizer %s: only Ftrl is implemented" % (spec.lin_opt[0],))
+        for opt in ([spec.dnn_opt] if spec.has_deep else []) + ([spec.lin_opt] if spec.has_wide else []):
+            if opt[0] not in capi.WD_OPT_KINDS:
+                raise ValueError("unsupported optimizer %r (supported: %s)" % (opt, sorted(capi.WD_OPT_KINDS)))
+        # the reference's defaults (conf/model.yaml: Adagrad on the dnn scope, Ftrl on the linear scope) take the
+        # specialised kernels; any other tf.train optimizer of model_util.py:84-90 the generic ones (wd_opt_t)
+        self.default_opts = ((not spec.has_deep or spec.dnn_opt[0] == "Adagrad") and
+                             (not spec.has_wide or spec.lin_opt[0] == "Ftrl"))
         if tower_dtype not in ("fp32", "fp16"):
             raise ValueError("tower_dtype must be 'fp32' (exact fp32 MFMA) or 'fp16' (half operands, fp32 accumulate)")
         self.half = tower_dtype == "fp16"     # BASELINE configs[4]: fp16 MFMA dense path, fp32 embeddings
@@ -103,9 +107,13 @@ class WideDeepEngine:
         g = torch.Generator(device=dev)
         g.manual_seed(seed)
         self.gen = g
+        dnn_a, dnn_b = opt_slot_init(spec.dnn_opt) if spec.has_deep else (None, None)
+        lin_a, lin_b = opt_slot_init(spec.lin_opt) if spec.has_wide else (None, None)
         if spec.has_deep:
-            self.emb = torch.zeros(max(plan.emb_elems, 4), **f32)
-            self.emb_acc = torch.full((max(plan.emb_elems, 4),), float(spec.dnn_opt[2]), **f32)
+            ne = max(plan.emb_elems, 4)
+            self.emb = torch.zeros(ne, **f32)
+            self.emb_a = torch.full((ne,), dnn_a, **f32) if dnn_a is not None else None      # optimizer slot a
+            self.emb_acc = torch.full((ne,), dnn_b, **f32) if dnn_b is not None else None    # optimizer slot b
             for i, s in enumerate(plan.slots):
                 if plan.emb_off[i] >= 0:
                     v = self.emb[plan.emb_off[i]: plan.emb_off[i] + s.num_buckets * s.dim]
@@ -113,14 +121,30 @@ class WideDeepEngine:
                     # embedding_column initializer: truncated_normal(0, 1/sqrt(dim))  
                     torch.nn.init.trunc_normal_(v, mean=0.0, std=std, a=-2 * std, b=2 * std, generator=g)
         else:
-            self.emb = self.emb_acc = None
+            self.emb = self.emb_a = self.emb_acc = None
         if spec.has_wide:
-            self.wide = torch.zeros(max(plan.total_rows, 1), 4, **f32)   # {w, z, n, -}
-            self.wide[:, 2] = float(spec.lin_opt[4])
+            self.wide = torch.zeros(max(plan.total_rows, 1), 4, **f32)   # {w, slot a, slot b, -}  (Ftrl: {w, z, n, -})
             self.bias = torch.zeros(4, **f32)
-            self.bias[2] = float(spec.lin_opt[4])
+            for col, v in ((1, lin_a), (2, lin_b)):
+                if v is not None:
+                    self.wide[:, col] = v
+                    self.bias[col] = v
         else:
             self.wide = self.bias = None
+        # generic optimizer descriptors (wd_opt_t) + Adam's beta powers (device: a captured graph must see them advance)
+        self.pow_names = adam_pow_names(spec.dnn_opt, spec.lin_opt, spec.has_deep, spec.has_wide)
+        self.pow, self.opt_c = {}, {}
+        for scope, opt, on in (("dnn", spec.dnn_opt, spec.has_deep), ("linear", spec.lin_opt, spec.has_wide)):
+            if not on:
+                continue
+            o = capi.WdOpt()
+            o.kind, o.lr = capi.WD_OPT_KINDS[opt[0]], float(opt[1])
+            o.p0, o.p1, o.p2 = opt_params(opt)
+            if opt[0] == "Adam":
+                self.pow[scope] = torch.tensor([opt[2], opt[3]], **f32)
+                o.pow = self.pow[scope].data_ptr()
+            self.opt_c[scope] = o
+        self.touched = torch.zeros((max(plan.total_rows, 1) + 31) // 32, **i32) if self.pow else None
 
         # ---- dense state -------------------------------------------------------------------
         B = self.max_batch
@@ -128,7 +152,8 @@ class WideDeepEngine:
         if spec.has_deep:
             n = plan.dense_param_elems
             self.P = torch.zeros(n, **f32)
-            self.Pacc = torch.full((n,), float(spec.dnn_opt[2]), **f32)
+            self.Pa = torch.full((n,), dnn_a, **f32) if dnn_a is not None else None       # optimizer slot a
+            self.Pacc = torch.full((n,), dnn_b, **f32) if dnn_b is not None else None     # optimizer slot b
             self.G = torch.zeros(n, **f32)
             for ti, tl in enumerate(plan.towers):
                 metas = plan.layer_meta[ti]
@@ -170,6 +195,8 @@ class WideDeepEngine:
                 if self.half:
                     if len(plan.towers) != 1:
                         raise NotImplementedError("tower_dtype='fp16': one tower")
+                    if tl.mode == "first_dense":
+                        raise NotImplementedError("tower_dtype='fp16': connected_mode first_dense runs on the fp32 tower")
                     f16 = dict(dtype=torch.float16, device=dev)
                     r8 = lambda v: (v + 7) // 8 * 8
                     Bp = (B + 63) // 64 * 64
@@ -236,7 +263,7 @@ class WideDeepEngine:
             self.all_simple = len(self.towers) == 1 and self.towers[0]["layout"].mode == "simple"
             self.dnn_logit = torch.zeros(B, **f32)
         else:
-            self.P = self.Pacc = self.G = None
+            self.P = self.Pa = self.Pacc = self.G = None
             self.dnn_logit = None
 
         # ---- per-step buffers --------------------------------------------------------------
@@ -418,6 +445,12 @@ class WideDeepEngine:
                     w0 = tl.seg_width[0]
                     tw["act"][:B, tl.seg_start[0]: tl.seg_start[0] + w0].copy_(
                         tw0["act"][:B, tw0["layout"].seg_start[0]: tw0["layout"].seg_start[0] + w0])
+                for xs in tl.x_copies:   # first_dense: every second pair of consumers reads its own copy of x
+                    w0 = tl.seg_width[0]
+                    tw["act"][:B, tl.seg_start[xs]: tl.seg_start[xs] + w0].copy_(
+                        tw["act"][:B, tl.seg_start[0]: tl.seg_start[0] + w0])
+                if train and tl.mode == "first_dense":
+                    tw["dact"][:B].zero_()   # windows are accumulated into; the logits window does not cover them all
                 if not self.chain:
                     self._tower_hidden_forward(tw, B, st)
             if self.chain:
@@ -671,16 +704,31 @@ class WideDeepEngine:
             tw0 = self.towers[0]
             tl0 = tw0["layout"]
             dx_ptr, ld = tw0["dact"].data_ptr() + 4 * tl0.seg_start[0], tl0.ld
-        lr, l1, l2 = (spec.lin_opt[1], spec.lin_opt[2], spec.lin_opt[3]) if spec.has_wide else (0.0, 0.0, 0.0)
-        call("wd_sparse_apply", ptr(self.emb) if has_emb else None, ptr(self.emb_acc) if has_emb else None,
-             ptr(self.wide), ptr(self.bias), ptr(self.slots_dev), plan.S, ptr(bt.bag_offs), bt.B, dx_ptr, ld,
-             ptr(self.dlogit), 1, float(spec.dnn_opt[1]) if spec.has_deep else 0.0, float(lr), float(l1), float(l2),
-             ptr(self.bucket_start), ptr(self.pairs), self.n_buckets, st)
+        if self.default_opts:
+            lr, l1, l2 = (spec.lin_opt[1], spec.lin_opt[2], spec.lin_opt[3]) if spec.has_wide else (0.0, 0.0, 0.0)
+            call("wd_sparse_apply", ptr(self.emb) if has_emb else None, ptr(self.emb_acc) if has_emb else None,
+                 ptr(self.wide), ptr(self.bias), ptr(self.slots_dev), plan.S, ptr(bt.bag_offs), bt.B, dx_ptr, ld,
+                 ptr(self.dlogit), 1, float(spec.dnn_opt[1]) if spec.has_deep else 0.0, float(lr), float(l1), float(l2),
+                 ptr(self.bucket_start), ptr(self.pairs), self.n_buckets, st)
+            return
+        od = ctypes.byref(self.opt_c["dnn"]) if has_emb else None
+        ol = ctypes.byref(self.opt_c["linear"]) if spec.has_wide else None
+        call("wd_sparse_apply_opt", ptr(self.emb) if has_emb else None, ptr(self.emb_a) if has_emb else None,
+             ptr(self.emb_acc) if has_emb else None, ptr(self.wide), ptr(self.bias), ptr(self.slots_dev), plan.S,
+             ptr(bt.bag_offs), bt.B, dx_ptr, ld, ptr(self.dlogit), 1, od, ol, ptr(self.bucket_start), ptr(self.pairs),
+             self.n_buckets, ptr(self.touched), st)
+        if self.pow:
+            # Adam moves every row of a sparsely updated variable: the rows without a gradient this step
+            call("wd_adam_untouched", ptr(self.emb) if (has_emb and "dnn" in self.pow) else None, ptr(self.emb_a),
+                 ptr(self.emb_acc), ptr(self.wide) if "linear" in self.pow else None, ptr(self.slots_dev), plan.S,
+                 max(int(s.num_buckets) for s in plan.slots), max(plan.total_rows, 1), ptr(self.touched), od, ol, st)
 
     def _sparse_backward_unfused(self, bt: DeviceBatch, st):
         """Reference path through the separate ABI entry points (device radix sort + one kernel per update);
         kept for cross-checking the fused kernel in tests."""
         plan, spec = self.plan, self.spec
+        if not self.default_opts:
+            raise NotImplementedError("the sort-based reference path implements Adagrad (dnn) + Ftrl (linear) only")
         B, S = bt.B, plan.S
         has_emb = bool(self.group_slots) if spec.has_deep else False
         if bt.nnz > 0 and (has_emb or spec.has_wide):
@@ -717,6 +765,13 @@ class WideDeepEngine:
                     raise NotImplementedError("multi-tower + all-layer finalize")  # guarded in __init__
                 call("wd_mlp_finalize_all", ptr(self.layers_dev), self.n_layers, self.max_layer_k, ptr(self.P), self.inv,
                      ptr(self.G), st)
+            for tw in self.towers:        # first_dense: gradient of x = sum over its copies
+                tl = tw["layout"]
+                if has_emb and tl.x_copies:
+                    w0 = tl.seg_width[0]
+                    dx = tw["dact"][:B, tl.seg_start[0]: tl.seg_start[0] + w0]
+                    for xs in tl.x_copies:
+                        dx.add_(tw["dact"][:B, tl.seg_start[xs]: tl.seg_start[xs] + w0])
             tw0 = self.towers[0]
             tl0 = tw0["layout"]
             if has_emb and len(self.towers) > 1:
@@ -726,13 +781,20 @@ class WideDeepEngine:
                     tl = tw["layout"]
                     dx0.add_(tw["dact"][:B, tl.seg_start[0]: tl.seg_start[0] + w0])
             self._reduce_dense_grads()
-            call("wd_adagrad_dense", ptr(self.P), ptr(self.Pacc), ptr(self.G), self.P.numel(), float(spec.dnn_opt[1]),
-                 st)
+            if self.default_opts:
+                call("wd_adagrad_dense", ptr(self.P), ptr(self.Pacc), ptr(self.G), self.P.numel(), float(spec.dnn_opt[1]),
+                     st)
+            else:
+                call("wd_opt_dense", ptr(self.P), ptr(self.Pa), ptr(self.Pacc), ptr(self.G), self.P.numel(),
+                     ctypes.byref(self.opt_c["dnn"]), st)
         if bucketized:
             torch.cuda.current_stream().wait_stream(self._side(0))
             self._sparse_backward(bt, st, bucketized=True)
         else:
             self._sparse_backward(bt, st)
+        for scope, pw in self.pow.items():     # Adam: beta1^t, beta2^t -> t + 1 (AdamOptimizer._finish)
+            o = spec.dnn_opt if scope == "dnn" else spec.lin_opt
+            call("wd_adam_tick", ptr(pw), float(o[2]), float(o[3]), st)
 
     def train_step(self, bt: DeviceBatch):
         """One step of python/lib/joint.py:224-262: forward, batch-SUM loss, both optimizers."""
@@ -778,23 +840,33 @@ class WideDeepEngine:
     # ------------------------------------------------------------------------------------------
     # state exchange in the reference's checkpoint naming (SURVEY section 5)
     # ------------------------------------------------------------------------------------------
+    def _slot_bufs(self, scope):
+        """[(buffer, checkpoint-name suffix)] of a scope's variable + its optimizer slots."""
+        opt = self.spec.dnn_opt if scope == "dnn" else self.spec.lin_opt
+        sa, sb = OPT_SLOT_NAMES[opt[0]]
+        return sa, sb
+
     def export_state(self):
         plan, spec = self.plan, self.spec
         out = {}
         if spec.has_deep:
+            sa, sb = self._slot_bufs("dnn")
             for i, s in enumerate(plan.slots):
                 if plan.emb_off[i] >= 0:
                     nm = "dnn/input_from_feature_columns/input_layer/%s/embedding_weights" % s.deep_name
                     sl = slice(plan.emb_off[i], plan.emb_off[i] + s.num_buckets * s.dim)
-                    out[nm] = self.emb[sl].view(s.num_buckets, s.dim).cpu().clone()
-                    out[nm + "/Adagrad"] = self.emb_acc[sl].view(s.num_buckets, s.dim).cpu().clone()
+                    for buf, suf in ((self.emb, ""), (self.emb_a, sa), (self.emb_acc, sb)):
+                        if suf is not None:
+                            out[nm + suf] = buf[sl].view(s.num_buckets, s.dim).cpu().clone()
             for ti, tw in enumerate(self.towers):
                 p = "dnn/dnn_%d/" % (ti + 1)
                 for l, m in enumerate(tw["metas"]):
                     K, N = m["K"], m["N"]
                     scope = p + ("hiddenlayer_%d/" % l if l < tw["L"] else "logits/")
                     rows = torch.from_numpy(plan.tf_rows_of_layer(ti, l)).to(self.device)
-                    for buf, suf in ((self.P, ""), (self.Pacc, "/Adagrad")):
+                    for buf, suf in ((self.P, ""), (self.Pa, sa), (self.Pacc, sb)):
+                        if suf is None:
+                            continue
                         out[scope + "kernel" + suf] = buf[m["w_off"]: m["w_off"] + K * N].view(K, N)[rows].cpu().clone()
                         out[scope + "bias" + suf] = buf[m["b_off"]: m["b_off"] + N].cpu().clone()
                         if "gamma_off" in m:
@@ -804,39 +876,44 @@ class WideDeepEngine:
                         out[scope + "batch_normalization/moving_mean"] = torch.zeros(N)
                         out[scope + "batch_normalization/moving_variance"] = torch.ones(N)
         if spec.has_wide:
+            sa, sb = self._slot_bufs("linear")
+            b = self.bias.cpu()
             for i, s in enumerate(plan.slots):
                 if s.wide:
                     nm = "linear/linear_model/%s/weights" % s.name
                     r0 = plan.row_base[i]
                     blk = self.wide[r0: r0 + s.num_buckets].cpu()
-                    out[nm] = blk[:, 0:1].clone()
-                    out[nm + "/Ftrl_1"] = blk[:, 1:2].clone()
-                    out[nm + "/Ftrl"] = blk[:, 2:3].clone()
-            b = self.bias.cpu()
-            out["linear/linear_model/bias_weights"] = b[0:1].clone()
-            out["linear/linear_model/bias_weights/Ftrl_1"] = b[1:2].clone()
-            out["linear/linear_model/bias_weights/Ftrl"] = b[2:3].clone()
+                    for col, suf in ((0, ""), (1, sa), (2, sb)):
+                        if suf is not None:
+                            out[nm + suf] = blk[:, col:col + 1].clone()
+            for col, suf in ((0, ""), (1, sa), (2, sb)):
+                if suf is not None:
+                    out["linear/linear_model/bias_weights" + suf] = b[col:col + 1].clone()
+        for scope, names in self.pow_names.items():
+            pw = self.pow[scope].cpu()
+            out[names[0]], out[names[1]] = pw[0].clone(), pw[1].clone()
         out["global_step"] = torch.tensor(self.global_step, dtype=torch.int64)
         return out
 
     def import_state(self, state):
         plan, spec, dev = self.plan, self.spec, self.device
         if spec.has_deep:
+            sa, sb = self._slot_bufs("dnn")
             for i, s in enumerate(plan.slots):
                 if plan.emb_off[i] >= 0:
                     nm = "dnn/input_from_feature_columns/input_layer/%s/embedding_weights" % s.deep_name
                     sl = slice(plan.emb_off[i], plan.emb_off[i] + s.num_buckets * s.dim)
-                    self.emb[sl] = state[nm].to(dev).reshape(-1)
-                    if nm + "/Adagrad" in state:
-                        self.emb_acc[sl] = state[nm + "/Adagrad"].to(dev).reshape(-1)
+                    for buf, suf in ((self.emb, ""), (self.emb_a, sa), (self.emb_acc, sb)):
+                        if suf is not None and nm + suf in state:
+                            buf[sl] = state[nm + suf].to(dev).reshape(-1)
             for ti, tw in enumerate(self.towers):
                 p = "dnn/dnn_%d/" % (ti + 1)
                 for l, m in enumerate(tw["metas"]):
                     K, N = m["K"], m["N"]
                     scope = p + ("hiddenlayer_%d/" % l if l < tw["L"] else "logits/")
                     rows = torch.from_numpy(plan.tf_rows_of_layer(ti, l)).to(dev)
-                    for buf, suf in ((self.P, ""), (self.Pacc, "/Adagrad")):
-                        if scope + "kernel" + suf not in state:
+                    for buf, suf in ((self.P, ""), (self.Pa, sa), (self.Pacc, sb)):
+                        if suf is None or scope + "kernel" + suf not in state:
                             continue
                         buf[m["w_off"]: m["w_off"] + K * N].view(K, N)[rows] = state[scope + "kernel" + suf].to(dev)
                         buf[m["b_off"]: m["b_off"] + N] = state[scope + "bias" + suf].to(dev)
@@ -844,18 +921,21 @@ class WideDeepEngine:
                             buf[m["gamma_off"]: m["gamma_off"] + N] = state[scope + "batch_normalization/gamma" + suf].to(dev)
                             buf[m["beta_off"]: m["beta_off"] + N] = state[scope + "batch_normalization/beta" + suf].to(dev)
         if spec.has_wide:
+            sa, sb = self._slot_bufs("linear")
             for i, s in enumerate(plan.slots):
                 if s.wide:
                     nm = "linear/linear_model/%s/weights" % s.name
                     r0 = plan.row_base[i]
-                    self.wide[r0: r0 + s.num_buckets, 0:1] = state[nm].to(dev)
-                    if nm + "/Ftrl" in state:
-                        self.wide[r0: r0 + s.num_buckets, 1:2] = state[nm + "/Ftrl_1"].to(dev)
-                        self.wide[r0: r0 + s.num_buckets, 2:3] = state[nm + "/Ftrl"].to(dev)
+                    for col, suf in ((0, ""), (1, sa), (2, sb)):
+                        if suf is not None and nm + suf in state:
+                            self.wide[r0: r0 + s.num_buckets, col:col + 1] = state[nm + suf].to(dev)
             nm = "linear/linear_model/bias_weights"
-            self.bias[0:1] = state[nm].to(dev)
-            if nm + "/Ftrl" in state:
-                self.bias[1:2] = state[nm + "/Ftrl_1"].to(dev)
-                self.bias[2:3] = state[nm + "/Ftrl"].to(dev)
+            for col, suf in ((0, ""), (1, sa), (2, sb)):
+                if suf is not None and nm + suf in state:
+                    self.bias[col:col + 1] = state[nm + suf].to(dev)
+        for scope, names in self.pow_names.items():
+            if names[0] in state:
+                self.pow[scope][0] = float(state[names[0]])
+                self.pow[scope][1] = float(state[names[1]])
         if "global_step" in state:
             self.global_step = int(state["global_step"])

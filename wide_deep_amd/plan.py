@@ -83,8 +83,10 @@ class ModelSpec:
     activation: str = "relu"
     batch_norm: bool = True
     dropout: Optional[float] = None
-    dnn_opt: tuple = ("Adagrad", 0.05, 0.1)            # name, lr, initial_accumulator_value
-    lin_opt: tuple = ("Ftrl", 0.1, 0.5, 1.0, 0.1)      # name, lr, l1, l2, initial_accumulator_value
+    # optimizer tuples (build_estimator.opt_tuple): ("SGD", lr) ("Adagrad", lr, init_accum) ("Ftrl", lr, l1, l2, init_accum)
+    # ("RMSProp", lr, decay, momentum, epsilon) ("Adam", lr, beta1, beta2, epsilon)
+    dnn_opt: tuple = ("Adagrad", 0.05, 0.1)
+    lin_opt: tuple = ("Ftrl", 0.1, 0.5, 1.0, 0.1)
     use_weight_column: bool = False
     pos_weight: float = 1.0
     neg_weight: float = 1.0
@@ -114,13 +116,15 @@ class TowerLayout:
     """
 
     def __init__(self, deep_dim, hidden, mode):
-        if mode not in ("simple", "dense", "resnet", "last_dense"):
+        if mode not in ("simple", "dense", "resnet", "last_dense", "first_dense"):
             raise ValueError("connected_mode `%s` is not supported by the gfx950 engine yet "
-                             "(supported: simple, dense, resnet, last_dense)" % (mode,))
+                             "(supported: simple, first_dense, last_dense, dense, resnet)" % (mode,))
         self.mode = mode
         self.hidden = list(hidden)
         widths = [deep_dim] + self.hidden
         L = len(self.hidden)
+        self.x_copies = []          # first_dense: extra segments (index > L) that hold a copy of segment 0
+        xseg_of = {}                # first_dense: layer l >= 1 -> the x segment inside its window
         if mode in ("dense", "last_dense"):
             starts, c = [], 0
             for w in widths:
@@ -134,6 +138,37 @@ class TowerLayout:
             for l in range(L, -1, -1):
                 starts[l] = c
                 c += widths[l]
+            total = c
+        elif mode == "first_dense":
+            if any(w % 4 for w in self.hidden) or deep_dim % 4:
+                raise ValueError("first_dense: hidden widths and the deep input width must be multiples of 4 "
+                                 "(16-byte aligned windows); got %s / %d" % (self.hidden, deep_dim))
+            # layer l >= 1 (and the logits layer) reads [h_{l-1} | x] (python/lib/dnn.py:117-133).  One copy of x has two
+            # neighbours, so consumers are paired: [h_0 | x | h_1] [h_2 | x' | h_3] ... -- consumer 2g+1 reads
+            # [h_2g | x_g], consumer 2g+2 reads [x_g | h_2g+1]; x' .. are copies (filled after the input layer, their
+            # gradients added back into x's).  The kernel row order inside a window is internal (tf_rows_of_layer).
+            starts = [0] * (L + 1)
+            c = 0
+            for g in range((L + 1) // 2):
+                starts[2 * g + 1] = c                       # h_{2g} = segment 2g+1
+                c += widths[2 * g + 1]
+                if g == 0:
+                    starts[0] = c
+                    xs = 0
+                else:
+                    xs = len(widths)
+                    widths.append(deep_dim)
+                    starts.append(c)
+                    self.x_copies.append(xs)
+                c += deep_dim
+                xseg_of[2 * g + 1] = xs
+                if 2 * g + 2 <= L:                          # consumer 2g+2 exists; its h_{2g+1} is segment 2g+2
+                    xseg_of[2 * g + 2] = xs
+                    starts[2 * g + 2] = c
+                    c += widths[2 * g + 2]
+            if L == 0:
+                starts[0] = 0
+                c = deep_dim
             total = c
         else:  # simple: every segment 16-float aligned, no window spans two segments
             starts, c = [], 0
@@ -150,15 +185,22 @@ class TowerLayout:
             is_logits = l == L
             if mode == "simple" or (mode == "last_dense" and not is_logits):
                 segs = [l]
+            elif mode == "first_dense":
+                segs = [0] if l == 0 else [l, xseg_of[l]]   # TF order: [h_{l-1} | x]
             elif mode in ("dense", "last_dense"):
                 segs = list(range(0, l + 1))
             else:  # resnet
                 segs = list(range(l, -1, -1))
             s0 = min(starts[j] for j in segs)
             e0 = max(starts[j] + widths[j] for j in segs)
+            assert e0 - s0 == sum(widths[j] for j in segs), "a layer's input window must be contiguous"
             self.in_start.append(s0)
             self.in_K.append(e0 - s0)
             self.in_segs.append(segs)
+
+    def canon(self, seg):
+        """Segment whose values `seg` holds: copies of the deep input (first_dense) are segment 0."""
+        return 0 if seg in self.x_copies else seg
 
     def window_cols(self, l):
         """For layer l: list of (segment, unit) for every column of its input window, -1 segment for pad."""
@@ -225,7 +267,7 @@ class FeaturePlan:
         # internal width (may contain alignment holes, see tf_input_perm).  Wide inputs are padded to a multiple of the
         # GEMM reduction slab (64): the pad columns stay zero, their weight rows stay zero (zero gradient), and the
         # first layer then runs on full slabs only (a ragged last slab costs ~3 us per GEMM at C2, three per step)
-        self.deep_dim = _round_up(c, 64) if c > 128 else c
+        self.deep_dim = _round_up(c, 64) if c > 128 else _round_up(c, 4)   # pad columns stay zero (no TF rows map to them)
         self.emb_groups = {}
         for i, s in enumerate(self.slots):
             if s.deep == "embedding" and spec.has_deep:
@@ -276,6 +318,7 @@ class FeaturePlan:
             for l in range(L + 1):
                 gi, bi = [], []
                 for (seg, u) in tl.window_cols(l):
+                    seg = tl.canon(seg)
                     if seg >= 1 and spec.batch_norm:
                         gi.append(metas[seg - 1]["gamma_off"] + u)
                         bi.append(metas[seg - 1]["beta_off"] + u)
@@ -296,13 +339,15 @@ class FeaturePlan:
         s0 = tl.in_start[l]
         if tl.mode in ("simple",) or (tl.mode == "last_dense" and l < len(tl.hidden)):
             order = [l]
+        elif tl.mode == "first_dense":
+            order = list(tl.in_segs[l])                    # [h_{l-1}, x] in the reference's concat order
         elif tl.mode in ("dense", "last_dense"):
             order = list(range(0, l + 1))
         else:
             order = list(range(l, -1, -1))
         for j in order:
             base = tl.seg_start[j] - s0
-            if j == 0:
+            if tl.canon(j) == 0:
                 rows.extend((base + self.tf_input_perm).tolist())
             else:
                 rows.extend(range(base, base + tl.seg_width[j]))
@@ -328,6 +373,51 @@ def criteo_spec(n_dense=13, n_sparse=26, buckets=1_000_000, dim=16, hidden=(256,
     return ModelSpec(model_type=model_type, slots=slots, dense_cols=dense,
                      towers=[TowerSpec(list(hidden), mode)], batch_norm=batch_norm,
                      use_weight_column=use_weight_column, pos_weight=pos_weight, neg_weight=neg_weight)
+
+
+# ---------------------------------------------------------------------------------------------
+# optimizer state layout (tf.train slot names; include/wd_hip.h wd_opt_t: slot a / slot b of a variable)
+# ---------------------------------------------------------------------------------------------
+OPT_SLOT_NAMES = {"SGD": (None, None), "Adagrad": (None, "/Adagrad"), "Ftrl": ("/Ftrl_1", "/Ftrl"),
+                  "RMSProp": ("/RMSProp", "/RMSProp_1"), "Adam": ("/Adam", "/Adam_1")}
+
+
+def opt_slot_init(opt):
+    """Initial values (slot a, slot b) of an optimizer tuple; None: the optimizer has no such slot."""
+    kind = opt[0]
+    if kind == "SGD":
+        return None, None
+    if kind == "Adagrad":
+        return None, float(opt[2])
+    if kind == "Ftrl":
+        return 0.0, float(opt[4])
+    if kind == "RMSProp":
+        return 1.0, 0.0           # rms slot starts at ones, momentum at zeros (RMSPropOptimizer._create_slots)
+    if kind == "Adam":
+        return 0.0, 0.0
+    raise ValueError("unsupported optimizer %r" % (opt,))
+
+
+def opt_params(opt):
+    """(p0, p1, p2) of wd_opt_t."""
+    kind = opt[0]
+    if kind == "Ftrl":
+        return float(opt[2]), float(opt[3]), 0.0
+    if kind in ("RMSProp", "Adam"):
+        return float(opt[2]), float(opt[3]), float(opt[4])
+    return 0.0, 0.0, 0.0
+
+
+def adam_pow_names(dnn_opt, lin_opt, has_deep, has_wide):
+    """Checkpoint names of Adam's non-slot beta powers: the optimizer built first by python/lib/joint.py:224-262 (dnn,
+    then linear) owns beta1_power / beta2_power, a second Adam instance gets the _1 suffix."""
+    out, n = {}, 0
+    for scope, opt, on in (("dnn", dnn_opt, has_deep), ("linear", lin_opt, has_wide)):
+        if on and opt[0] == "Adam":
+            suf = "" if n == 0 else "_%d" % n
+            out[scope] = ("beta1_power" + suf, "beta2_power" + suf)
+            n += 1
+    return out
 
 
 def bucket_geometry(vocab_sizes, occ_per_slot, nb_max, target=64.0):

@@ -436,6 +436,22 @@ int wd_logits_head_h(const wd_half_t *a_h, int64_t ld_a, int64_t K, const float 
 int wd_act_bwd(const float *da, int64_t ldda, const float *a, int64_t lda, int32_t act, float *dz, int64_t lddz,
                int64_t M, int64_t N, wd_stream_t stream);
 
+/* ---- dropout (python/lib/dnn.py:111-112 and the same lines of every connected mode: tf.layers.dropout(net, rate,
+ * training=True) after the activation and before BN, TRAIN mode only; ret = x / keep_prob * keep).
+ * keep(b, n) is a counter-based function of seed_step = device {seed, step}, the layer and b*N + n:
+ *     z = seed + step*0x632BE59BD9B4E019 + (layer+1)*0x9E3779B97F4A7C15 + (b*N+n)*0xD1B54A32D192ED03   (mod 2^64)
+ *     z = (z ^ z>>30) * 0xBF58476D1CE4E5B9;  z = (z ^ z>>27) * 0x94D049BB133111EB;  z ^= z>>31
+ *     keep = (z >> 40) / 2^24 >= rate
+ * so no mask is stored: wd_dropout_fwd rewrites the activations a [M][N] in place, wd_act_bwd_dropout forms
+ * dz = da / keep_prob * keep * act'(a_drop * keep_prob) from the same function, wd_counter_tick advances `step`
+ * (on the device: a captured graph draws a new mask on every replay). */
+int wd_dropout_fwd(float *a, int64_t lda, int64_t M, int64_t N, float rate, const int64_t *seed_step, int32_t layer,
+                   wd_stream_t stream);
+int wd_act_bwd_dropout(const float *da, int64_t ldda, const float *a_drop, int64_t lda, int32_t act, float *dz,
+                       int64_t lddz, int64_t M, int64_t N, float rate, const int64_t *seed_step, int32_t layer,
+                       wd_stream_t stream);
+int wd_counter_tick(int64_t *seed_step, wd_stream_t stream);
+
 /* Reduce the split-K partials G = sum_split Gpart ([K+1, N], row K = db) and un-fold the affine:
  *   Gflat[w_off + k*N + n] = s[k]*G[k,n] + t[k]*db[n];   Gflat[b_off + n] = db[n];
  *   Gflat[gamma_idx[k]] += inv * sum_n W[k,n]*G[k,n];     Gflat[beta_idx[k]] += sum_n W[k,n]*db[n]. */

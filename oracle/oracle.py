@@ -306,9 +306,11 @@ ACTIVATIONS = {
 }
 
 
-def tower_forward(x, tw, mode, act, batch_norm):
+def tower_forward(x, tw, mode, act, batch_norm, dropout=None, masks=None):
     """python/lib/dnn.py:92-234 for one tower.  tw: dict with lists 'kernel','bias','gamma','beta' (hidden
-    layers) and 'logits_kernel','logits_bias'.  BN is the inference-mode affine of SURVEY App. C.1."""
+    layers) and 'logits_kernel','logits_bias'.  BN is the inference-mode affine of SURVEY App. C.1.
+    dropout (rate) + masks (per layer [B, N] of 0 / 1, the keep decisions): tf.layers.dropout in TRAIN mode, between
+    the activation and BN (dnn.py:111-114): x / keep_prob * keep.  The random draw itself is the caller's."""
     f = ACTIVATIONS[act]
     inv = 1.0 / float(np.sqrt(np.float32(1.0) + np.float32(BN_EPS)))
     input_layer = x
@@ -316,6 +318,8 @@ def tower_forward(x, tw, mode, act, batch_norm):
     coll = [x]
     for l in range(len(tw["kernel"])):
         h = f(net @ tw["kernel"][l] + tw["bias"][l])
+        if dropout and masks is not None:
+            h = h / np.float32(1.0 - dropout) * torch.as_tensor(masks[l])
         if batch_norm:
             h = h * (tw["gamma"][l] * inv) + tw["beta"][l]
         if mode == "simple":
@@ -351,7 +355,7 @@ class OracleWideDeep:
     """
 
     def __init__(self, model_type, deep_cols, wide_cols, towers, state, act="relu", batch_norm=True,
-                 dnn_opt=("Adagrad", 0.05, 0.1), lin_opt=("Ftrl", 0.1, 0.5, 1.0, 0.1)):
+                 dnn_opt=("Adagrad", 0.05, 0.1), lin_opt=("Ftrl", 0.1, 0.5, 1.0, 0.1), dropout=None):
         self.model_type = model_type
         # both tf.feature_column.input_layer and linear_model sort columns by name
         self.deep_cols = sorted(deep_cols, key=lambda c: c["name"])
@@ -362,6 +366,7 @@ class OracleWideDeep:
         self.batch_norm = batch_norm
         self.dnn_opt = dnn_opt
         self.lin_opt = lin_opt
+        self.dropout = dropout      # rate; the keep masks of a step come with the batch ("dropout_masks")
 
     # -- Adam beta powers (non-slot variables, one pair per optimizer instance) ---------------------
     def _pow_names(self):
@@ -453,7 +458,9 @@ class OracleWideDeep:
                             v.requires_grad_(True)
                     tw["logits_kernel"].requires_grad_(True)
                     tw["logits_bias"].requires_grad_(True)
-                lg = tower_forward(x, tw, mode, self.act, self.batch_norm)[:, 0]
+                dm = batch.get("dropout_masks") if need_grad else None      # TRAIN mode only
+                lg = tower_forward(x, tw, mode, self.act, self.batch_norm, self.dropout if dm is not None else None,
+                                   dm[t] if dm is not None else None)[:, 0]
                 dnn = lg if dnn is None else dnn + lg
                 params.append(tw)
             cache.update(x=x, dnn=dnn, params=params)

@@ -56,7 +56,8 @@ def oracle_from_engine(eng):
     state = {k: v.clone().float() if v.dtype != torch.int64 else v for k, v in eng.export_state().items()}
     towers = [(t.hidden_units, t.mode) for t in spec.towers]
     return O.OracleWideDeep(spec.model_type, deep_cols, wide_cols, towers, state, act=spec.activation,
-                            batch_norm=spec.batch_norm, dnn_opt=spec.dnn_opt, lin_opt=spec.lin_opt)
+                            batch_norm=spec.batch_norm, dnn_opt=spec.dnn_opt, lin_opt=spec.lin_opt,
+                            dropout=spec.dropout or None)
 
 
 def max_rel_err(a, b, floor=1e-6):

@@ -26,9 +26,12 @@ def _run(spec, B=96, steps=3, mean_len=1, weights=False, dist="uniform", max_bat
         if weights:
             w = np.where(hb["labels"] > 0, spec.pos_weight, spec.neg_weight).astype(np.float32)
         bt = synth.to_device_ids(eng.plan, hb, weights=w)
+        masks = eng.dropout_masks(B)         # keep decisions the step is about to use (None without dnn_dropout)
         loss = eng.train_step(bt)
         torch.cuda.synchronize()
         ob = oracle_batch(eng.plan, bt.ids.cpu().numpy(), bt.bag_offs.cpu().numpy(), B, hb["dense"], hb["labels"], w)
+        if masks is not None:
+            ob["dropout_masks"] = masks
         oloss, ologits = ora.train_step(ob)
         assert_close(eng.logit[:B], ologits, L_RTOL, L_ATOL, "logits step %d" % step)
         assert abs(float(loss) - oloss) <= 1e-3 * max(1.0, abs(oloss)), (float(loss), oloss)
@@ -56,6 +59,52 @@ def test_train_steps_match_oracle_modes(mode):
 def test_first_dense_depths(hidden):
     """first_dense (python/lib/dnn.py:117-133): 1-5 hidden layers -> 0, 0, 1 and 2 extra copies of the deep input."""
     _run(_spec(mode="first_dense", hidden=hidden))
+
+
+@pytest.mark.parametrize("mode,rate,act", [("simple", 0.3, "relu"), ("resnet", 0.1, "tanh"), ("first_dense", 0.5, "relu"),
+                                           ("dense", 0.2, "sigmoid")])
+def test_dropout_train_steps_match_oracle(mode, rate, act):
+    """dnn_dropout (python/lib/dnn.py:111-112): mask after the activation, before BN, TRAIN only; the oracle is driven by
+    the engine's keep decisions (a stateless function of seed, step, layer, element), prediction stays mask-free."""
+    from wide_deep_amd import synth
+    s = _spec(mode=mode, hidden=(32, 16, 8))
+    s.dropout, s.activation = rate, act
+    eng, ora = _run(s, steps=3)
+    assert eng.dropout == rate and not eng.chain
+    m0 = eng.dropout_masks(96)
+    keep = np.mean([m.mean() for m in m0[0]])
+    assert abs(keep - (1 - rate)) < 0.06                    # Bernoulli(keep_prob)
+    # evaluate / predict: no dropout
+    hb = synth.make_raw_batch(eng.plan, 96, seed=999)
+    bt = synth.to_device_ids(eng.plan, hb)
+    from tests.helpers import oracle_batch, assert_close
+    bt.labels = None
+    eng.forward(bt, need_loss=False)
+    torch.cuda.synchronize()
+    ob = oracle_batch(eng.plan, bt.ids.cpu().numpy(), bt.bag_offs.cpu().numpy(), 96, hb["dense"], hb["labels"], None)
+    logits, _ = ora.predict(ob)
+    assert_close(eng.logit[:96], logits, L_RTOL, L_ATOL, "predict logits")
+
+
+def test_dropout_graph_replay_draws_new_masks():
+    from wide_deep_amd import synth
+    from wide_deep_amd.engine import WideDeepEngine
+    s = _spec(mode="simple", hidden=(32, 16))
+    s.dropout = 0.4
+    a, b = WideDeepEngine(s, max_batch=64, seed=4), WideDeepEngine(s, max_batch=64, seed=4)
+    hb = synth.make_raw_batch(a.plan, 64, seed=5, pos_rate=0.4)
+    bta, btb = synth.to_device_ids(a.plan, hb), synth.to_device_ids(b.plan, hb)
+    replay = a.capture_train_step(bta, warmup=1)
+    b.train_step(btb)
+    for _ in range(3):
+        replay()
+        b.train_step(btb)
+    torch.cuda.synchronize()
+    assert int(a.drop_seed[1]) == 4 == int(b.drop_seed[1])
+    sa, sb = a.export_state(), b.export_state()
+    for k in sb:
+        if k != "global_step":
+            assert torch.allclose(sa[k], sb[k], rtol=1e-5, atol=1e-7), k
 
 
 def test_multi_hot_zipf_with_weight_column():

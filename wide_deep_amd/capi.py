@@ -147,6 +147,9 @@ _PROTOS = {
     "wd_logits_head": [P, I64, I64, P, P, I32, P, P, P, I64, P, P, P, P, P, P, I64, I32, P, P],
     "wd_fold_affine": [P, I64, I64, P, P, F32, P, P, P, P, I64, I64, P],
     "wd_act_bwd": [P, I64, P, I64, I32, P, I64, I64, I64, P],
+    "wd_dropout_fwd": [P, I64, I64, I64, F32, P, I32, P],
+    "wd_act_bwd_dropout": [P, I64, P, I64, I32, P, I64, I64, I64, F32, P, I32, P],
+    "wd_counter_tick": [P, P],
     "wd_mlp_finalize": [P, I32, P, I64, I64, P, P, P, P, F32, P, I64, I64, P],
     "wd_adagrad_dense": [P, P, P, I64, F32, P],
     "wd_fill_f32": [P, F32, I64, P],

@@ -490,6 +490,47 @@ k_act_bwd(const float *__restrict__ da, int64_t ldda, const float *__restrict__ 
   dz[m * lddz + n] = da[m * ldda + n] * act_bwd(a[m * lda + n], act);
 }
 
+// ---- dropout (python/lib/dnn.py:111-112 etc.: tf.layers.dropout(net, rate, training=True) after the activation, before
+// BN, TRAIN mode only).  keep(b, n) = u >= rate with u a counter-based uniform of (seed, step, layer, b*N + n) -- the
+// same function is evaluated again in the backward pass (and on the host by the tests), no mask is stored.
+// TF: ret = x / keep_prob * binary_tensor.
+__device__ __forceinline__ bool dropout_keep(uint64_t seed, uint64_t step, uint32_t layer, uint64_t idx, float rate) {
+  uint64_t z = seed + step * 0x632BE59BD9B4E019ull + (uint64_t)(layer + 1) * 0x9E3779B97F4A7C15ull + idx * 0xD1B54A32D192ED03ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  const float u = (float)(uint32_t)(z >> 40) * (1.0f / 16777216.0f);   // 24 bits -> [0, 1)
+  return u >= rate;
+}
+
+__global__ void __launch_bounds__(256)
+k_dropout_fwd(float *__restrict__ a, int64_t lda, int64_t M, int64_t N, float rate, const int64_t *__restrict__ seed,
+              int32_t layer) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= M * N) return;
+  const int64_t m = i / N, n = i - m * N;
+  const float keep_prob = 1.0f - rate;
+  const float v = a[m * lda + n];
+  a[m * lda + n] = dropout_keep((uint64_t)seed[0], (uint64_t)seed[1], layer, (uint64_t)i, rate) ? v / keep_prob : 0.f;
+}
+
+// dz = da * d(dropout(act(z)))/dz with a_drop the stored (post-dropout) activation
+__global__ void __launch_bounds__(256)
+k_act_bwd_dropout(const float *__restrict__ da, int64_t ldda, const float *__restrict__ a, int64_t lda, int32_t act,
+                  float *__restrict__ dz, int64_t lddz, int64_t M, int64_t N, float rate,
+                  const int64_t *__restrict__ seed, int32_t layer) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= M * N) return;
+  const int64_t m = i / N, n = i - m * N;
+  const float keep_prob = 1.0f - rate;
+  float v = 0.f;
+  if (dropout_keep((uint64_t)seed[0], (uint64_t)seed[1], layer, (uint64_t)i, rate))
+    v = da[m * ldda + n] / keep_prob * act_bwd(a[m * lda + n] * keep_prob, act);
+  dz[m * lddz + n] = v;
+}
+
+__global__ void k_counter_tick(int64_t *c) { c[1] += 1; }
+
 // One block per input column k (row of W): reduce the split-K partials, emit dW row, and the
 // affine-parameter gradients of the producer of column k.  `store_affine`: the producer has exactly one
 // consumer (simple mode) -> plain store; otherwise accumulate (launches are stream-ordered and k is unique
@@ -805,6 +846,33 @@ extern "C" int wd_act_bwd(const float *da, int64_t ldda, const float *a, int64_t
   hipLaunchKernelGGL(k_act_bwd, dim3((unsigned)wd::ceil_div(M * N, 256)), dim3(256), 0, wd::as_stream(stream), da,
                      ldda, a, lda, act, dz, lddz, M, N);
   return wd::check_launch("wd_act_bwd");
+}
+
+extern "C" int wd_dropout_fwd(float *a, int64_t lda, int64_t M, int64_t N, float rate, const int64_t *seed_step,
+                              int32_t layer, wd_stream_t stream) {
+  if (M <= 0 || N <= 0) return WD_OK;
+  WD_REQUIRE(a && seed_step, "null pointer");
+  WD_REQUIRE(rate > 0.f && rate < 1.f, "0 < rate < 1");
+  hipLaunchKernelGGL(k_dropout_fwd, dim3((unsigned)wd::ceil_div(M * N, 256)), dim3(256), 0, wd::as_stream(stream), a, lda,
+                     M, N, rate, seed_step, layer);
+  return wd::check_launch("wd_dropout_fwd");
+}
+
+extern "C" int wd_act_bwd_dropout(const float *da, int64_t ldda, const float *a_drop, int64_t lda, int32_t act, float *dz,
+                                  int64_t lddz, int64_t M, int64_t N, float rate, const int64_t *seed_step, int32_t layer,
+                                  wd_stream_t stream) {
+  if (M <= 0 || N <= 0) return WD_OK;
+  WD_REQUIRE(da && a_drop && dz && seed_step, "null pointer");
+  WD_REQUIRE(rate > 0.f && rate < 1.f, "0 < rate < 1");
+  hipLaunchKernelGGL(k_act_bwd_dropout, dim3((unsigned)wd::ceil_div(M * N, 256)), dim3(256), 0, wd::as_stream(stream), da,
+                     ldda, a_drop, lda, act, dz, lddz, M, N, rate, seed_step, layer);
+  return wd::check_launch("wd_act_bwd_dropout");
+}
+
+extern "C" int wd_counter_tick(int64_t *seed_step, wd_stream_t stream) {
+  WD_REQUIRE(seed_step, "null pointer");
+  hipLaunchKernelGGL(k_counter_tick, dim3(1), dim3(1), 0, wd::as_stream(stream), seed_step);
+  return wd::check_launch("wd_counter_tick");
 }
 
 extern "C" int wd_mlp_finalize(const float *Gpart, int32_t nsplit, const float *P, int64_t w_off, int64_t b_off,

@@ -46,8 +46,11 @@ class WideDeepEngine:
         if not torch.cuda.is_available():
             raise capi.WdError("WideDeepEngine needs a GPU (MI355X / gfx950); there is no CPU fallback")
         capi.load()
-        if spec.dropout:
-            raise NotImplementedError("dnn_dropout is not implemented yet (reference default is empty)")
+        self.dropout = float(spec.dropout) if (spec.dropout and spec.has_deep) else 0.0
+        if not 0.0 <= self.dropout < 1.0:
+            raise ValueError("dnn_dropout must be in [0, 1), got %r" % (spec.dropout,))
+        if self.dropout and tower_dtype == "fp16":
+            raise NotImplementedError("tower_dtype='fp16': dnn_dropout runs on the fp32 tower")
         for opt in ([spec.dnn_opt] if spec.has_deep else []) + ([spec.lin_opt] if spec.has_wide else []):
             if opt[0] not in capi.WD_OPT_KINDS:
                 raise ValueError("unsupported optimizer %r (supported: %s)" % (opt, sorted(capi.WD_OPT_KINDS)))
@@ -107,6 +110,8 @@ class WideDeepEngine:
         g = torch.Generator(device=dev)
         g.manual_seed(seed)
         self.gen = g
+        # dropout: device {seed, step}; the keep mask is a function of it (include/wd_hip.h), never stored
+        self.drop_seed = torch.tensor([int(seed) * 0x9E3779B1 + 12345, 0], dtype=torch.int64, device=dev) if self.dropout else None
         dnn_a, dnn_b = opt_slot_init(spec.dnn_opt) if spec.has_deep else (None, None)
         lin_a, lin_b = opt_slot_init(spec.lin_opt) if spec.has_wide else (None, None)
         if spec.has_deep:
@@ -320,7 +325,7 @@ class WideDeepEngine:
         of 32 and whose row tile fits the LDS.  WD_CHAIN=0 keeps the per-layer GEMM launches."""
         self.chain = False
         plan = self.plan
-        if self.half or len(self.towers) != 1 or os.environ.get("WD_CHAIN", "1") == "0":
+        if self.half or self.dropout or len(self.towers) != 1 or os.environ.get("WD_CHAIN", "1") == "0":
             return
         tw = self.towers[0]
         tl, metas, L = tw["layout"], tw["metas"], tw["L"]
@@ -366,6 +371,31 @@ class WideDeepEngine:
              ptr(self.prob), ptr(self.dlogit) if train else None, ptr(self.loss) if train else None,
              ptr(tw["Gpart"][L]) if train else None,
              tw["dact"].data_ptr() + 4 * tl.in_start[0] if need_dx else None, tl.ld, tw["dx_cols"] if need_dx else 0, st)
+
+    def dropout_masks(self, B):
+        """Host copy of the keep masks the NEXT train step will use: [tower][layer] -> float32 [B, N] of 0 / 1 (the
+        function of include/wd_hip.h evaluated with numpy; used by the parity tests to drive the oracle)."""
+        if not self.dropout:
+            return None
+        seed, step = (int(v) for v in self.drop_seed.cpu().tolist())
+        M64 = (1 << 64) - 1
+        out = []
+        for tw in self.towers:
+            per = []
+            for l in range(tw["L"]):
+                N = tw["metas"][l]["N"]
+                idx = np.arange(B * N, dtype=np.uint64)
+                with np.errstate(over="ignore"):
+                    z = (np.uint64(seed & M64) + np.uint64((step * 0x632BE59BD9B4E019) & M64)
+                         + np.uint64(((self._drop_layer(tw, l) + 1) * 0x9E3779B97F4A7C15) & M64)
+                         + idx * np.uint64(0xD1B54A32D192ED03))
+                    z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+                    z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+                    z = z ^ (z >> np.uint64(31))
+                u = (z >> np.uint64(40)).astype(np.float32) * np.float32(1.0 / 16777216.0)
+                per.append((u >= np.float32(self.dropout)).astype(np.float32).reshape(B, N))
+            out.append(per)
+        return out
 
     def _side(self, i):
         if self._sides is None:
@@ -452,7 +482,7 @@ class WideDeepEngine:
                 if train and tl.mode == "first_dense":
                     tw["dact"][:B].zero_()   # windows are accumulated into; the logits window does not cover them all
                 if not self.chain:
-                    self._tower_hidden_forward(tw, B, st)
+                    self._tower_hidden_forward(tw, B, st, train)
             if self.chain:
                 self._tower_chain(tw0, bt, B, st, train)
             elif nt == 1:
@@ -482,7 +512,10 @@ class WideDeepEngine:
             call("wd_bce_sum_fwd_bwd", ptr(dnn_logit), ptr(self.wide_logit), ptr(zeros), None, B, ptr(self.logit),
                  ptr(self.prob), None, None, st)
 
-    def _tower_hidden_forward(self, tw, B, st):
+    def _drop_layer(self, tw, l):
+        return self.towers.index(tw) * 64 + l          # layer id that enters the keep function
+
+    def _tower_hidden_forward(self, tw, B, st, train=False):
         if self.half:
             return self._tower_hidden_forward_h(tw, B, st)
         tl, metas, L = tw["layout"], tw["metas"], tw["L"]
@@ -494,6 +527,8 @@ class WideDeepEngine:
             c_ptr = act.data_ptr() + 4 * tl.seg_start[l + 1]
             call("wd_gemm_nn_bias_act", a_ptr, tl.ld, ptr(tw["Wf"][l]), N, ptr(tw["bf"][l]), capi.WD_FOLD_PARTS,
                  self.act_id, c_ptr, tl.ld, B, N, K, st)
+            if train and self.dropout:     # tf.layers.dropout(net, rate, training=True): TRAIN mode only, before BN
+                call("wd_dropout_fwd", c_ptr, tl.ld, B, N, self.dropout, ptr(self.drop_seed), self._drop_layer(tw, l), st)
 
     def _tower_hidden_forward_h(self, tw, B, st):
         """fp16-input tower: x (fp32, from the gather) -> half + transposed half; every layer writes both copies."""
@@ -514,7 +549,7 @@ class WideDeepEngine:
         """Where the logits layer's input gradient goes: simple mode -> dz of the last hidden layer (act' fused),
         otherwise the logits window of dact (plain store; the window covers every segment later accumulated into)."""
         tl, L = tw["layout"], tw["L"]
-        if tl.mode == "simple" and L > 0:
+        if tl.mode == "simple" and L > 0 and not self.dropout:
             return tw["dz"][0].data_ptr(), tw["metas"][L]["K"], self.act_id
         return tw["dact"].data_ptr() + 4 * tl.in_start[L], tl.ld, 0
 
@@ -562,7 +597,8 @@ class WideDeepEngine:
                 call("wd_gemm_tn_splitk", act.data_ptr() + 4 * tl.in_start[l], tl.ld, ptr(tw["dzl"][l]), m["N"],
                      ptr(tw["Gpart"][l]), m["K"], m["N"], B, tw["nsplit"][l], 1, st)
             return
-        simple = tl.mode == "simple"
+        simple = tl.mode == "simple" and not self.dropout   # dropout: act' is not fused into the GEMM epilogues
+        acc = 0 if tl.mode == "simple" else 1               # simple: every segment has ONE consumer -> plain stores
         if not head_done:
             # multi-tower: dlogit is shared; run this tower's logits-layer backward (dlogit given as `labels`-free input)
             m = metas[L]
@@ -596,8 +632,12 @@ class WideDeepEngine:
                 dz_ptr, lddz = tw["dz"][0].data_ptr(), N
                 if tn_done is not None:
                     main.wait_event(tn_done)            # the previous layer's TN still reads dz[0]
-                call("wd_act_bwd", dact.data_ptr() + 4 * seg, tl.ld, act.data_ptr() + 4 * seg, tl.ld, self.act_id,
-                     dz_ptr, lddz, B, N, st)
+                if self.dropout:
+                    call("wd_act_bwd_dropout", dact.data_ptr() + 4 * seg, tl.ld, act.data_ptr() + 4 * seg, tl.ld, self.act_id,
+                         dz_ptr, lddz, B, N, self.dropout, ptr(self.drop_seed), self._drop_layer(tw, l), st)
+                else:
+                    call("wd_act_bwd", dact.data_ptr() + 4 * seg, tl.ld, act.data_ptr() + 4 * seg, tl.ld, self.act_id,
+                         dz_ptr, lddz, B, N, st)
             a_ptr = act.data_ptr() + 4 * tl.in_start[l]
             ns = tw["nsplit"][l]
             if ov:
@@ -621,7 +661,7 @@ class WideDeepEngine:
                          B, K, N, 0, st)
             elif l > 0 or need_dx:
                 call("wd_gemm_nt", dz_ptr, lddz, ptr(tw["Wf"][l]), N, dact.data_ptr() + 4 * tl.in_start[l], tl.ld, B,
-                     K, N, 1, st)
+                     K, N, acc, st)
         if ov:
             main.wait_stream(s2)
 
@@ -792,6 +832,8 @@ class WideDeepEngine:
             self._sparse_backward(bt, st, bucketized=True)
         else:
             self._sparse_backward(bt, st)
+        if self.dropout:
+            call("wd_counter_tick", ptr(self.drop_seed), st)   # next step draws a new mask
         for scope, pw in self.pow.items():     # Adam: beta1^t, beta2^t -> t + 1 (AdamOptimizer._finish)
             o = spec.dnn_opt if scope == "dnn" else spec.lin_opt
             call("wd_adam_tick", ptr(pw), float(o[2]), float(o[3]), st)

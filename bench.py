@@ -238,8 +238,20 @@ def main():
         bt = tb.batch if args.ids_input else synth.hash_tokens(eng, tb)
         return eng.train_step(bt)
 
-    use_graph = not args.no_graph and world == 1
-    if use_graph:
+    use_graph = not args.no_graph
+    if use_graph and world > 1:
+        # sharded step: hipGraph segments between the collectives (dist._Segments); every rank captures in lock-step
+        try:
+            replays = [eng.capture_train_step(tb.batch, warmup=1,
+                                              pre=None if args.ids_input else (lambda tb=tb: synth.hash_tokens(eng, tb)))
+                       for tb in dev_batches]
+            run = lambda i: replays[i % len(replays)]()
+        except Exception as e:      # capture refused by the runtime: the eager step is the same work, launch by launch
+            print("bench: graph segments unavailable (%s); running the sharded step eagerly" % (e,), file=sys.stderr)
+            torch.cuda.synchronize()
+            use_graph = False
+            run = lambda i: step_eager(dev_batches[i % len(dev_batches)])
+    elif use_graph:
         replays = []
         side = torch.cuda.Stream()
         with torch.cuda.stream(side):

@@ -27,6 +27,8 @@ def _spec(kind):
         return criteo_spec(n_dense=0, n_sparse=6, buckets=97, dim=16, hidden=(8,), model_type="wide"), 2
     if kind == "deeponly":
         return criteo_spec(n_dense=2, n_sparse=3, buckets=50, dim=32, hidden=(16,), model_type="deep"), 4
+    if kind in ("chain", "chain_graph"):   # one-launch tower (widths % 32 == 0): gradient exchange overlapped with the dense branch
+        return criteo_spec(n_dense=16, n_sparse=3, buckets=300, dim=16, hidden=(64, 32)), 1
     return criteo_spec(n_dense=3, n_sparse=5, buckets=300, dim=16, hidden=(32, 16)), 1
 
 
@@ -57,6 +59,9 @@ def _worker(rank, world, port, kind, q):
         sh = ShardedWideDeepEngine(spec, max_batch=B_loc, seed=11)
         sh.import_full_state(full0)
         bs = _batches(ref.plan, kind, steps, B_loc, world)
+        if kind.startswith("chain"):
+            assert sh.chain and ref.chain
+        replay = None
         for st in range(steps):
             hbs = bs[st]
             # single engine: global batch = rank0's examples then rank1's
@@ -64,7 +69,23 @@ def _worker(rank, world, port, kind, q):
                     "raw": np.concatenate([h["raw"] for h in hbs]), "dense": None if hbs[0]["dense"] is None else np.concatenate([h["dense"] for h in hbs], 0),
                     "labels": np.concatenate([h["labels"] for h in hbs])}
             ref.train_step(synth.to_device_ids(ref.plan, glob))
-            sh.train_step(synth.to_device_ids(sh.global_plan, hbs[rank]))
+            if kind == "chain_graph":
+                # graph segments between the collectives: capture once on fixed buffers, refresh their contents per step
+                nb = synth.to_device_ids(sh.global_plan, hbs[rank])
+                if replay is None:
+                    bt = nb
+                    snap = {k: v.clone() for k, v in sh.export_state().items()}
+                    replay = sh.capture_train_step(bt, warmup=1)
+                    sh.import_state(snap)           # undo the warm-up step
+                    sh.global_step = int(snap["global_step"])
+                else:
+                    assert nb.ids.numel() == bt.ids.numel()
+                    bt.ids.copy_(nb.ids); bt.bag_offs.copy_(nb.bag_offs); bt.labels.copy_(nb.labels)
+                    if nb.dense is not None:
+                        bt.dense.copy_(nb.dense)
+                replay()
+            else:
+                sh.train_step(synth.to_device_ids(sh.global_plan, hbs[rank]))
             torch.cuda.synchronize()
             assert_close(sh.logit[:B_loc], ref.logit[rank * B_loc:(rank + 1) * B_loc], 1e-4, 1e-5, "logits step %d" % st)
             sh.check_overflow()
@@ -127,7 +148,7 @@ def test_exchange_overflow_is_reported():
     _run(_overflow_worker, "onehot")
 
 
-@pytest.mark.parametrize("kind", ["onehot", "multihot", "wideonly", "deeponly"])
+@pytest.mark.parametrize("kind", ["onehot", "multihot", "wideonly", "deeponly", "chain", "chain_graph"])
 def test_sharded_world2_equals_single_engine(kind):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()

@@ -34,16 +34,16 @@ from .plan import CatSlot, FeaturePlan, ModelSpec, bucket_geometry
 # ---------------------------------------------------------------------------------------------
 # exchange plumbing (any device, any backend)
 # ---------------------------------------------------------------------------------------------
-def _a2a(out, inp, out_splits, in_splits, group=None):
-    """all_to_all_single that also works for CUDA tensors on the gloo backend (host staging)."""
+def _a2a(out, inp, out_splits, in_splits, group=None, async_op=False):
+    """all_to_all_single that also works for CUDA tensors on the gloo backend (host staging).
+    async_op: returns the work handle (None on the staged path, which completes before it returns)."""
     backend = dist.get_backend(group)
     if inp.is_cuda and backend == "gloo":
         o, i = torch.empty(out.shape, dtype=out.dtype), inp.cpu()
         dist.all_to_all_single(o, i, out_splits, in_splits, group=group)
         out.copy_(o)
-    else:
-        dist.all_to_all_single(out, inp, out_splits, in_splits, group=group)
-    return out
+        return None
+    return dist.all_to_all_single(out, inp, out_splits, in_splits, group=group, async_op=async_op)
 
 
 def _all_reduce_sum(t, group=None):
@@ -55,6 +55,33 @@ def _all_reduce_sum(t, group=None):
     else:
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     return t
+
+
+class _Segments:
+    """A train step as [hipGraph, collective, hipGraph, ...]: the kernels between two collectives are captured once and
+    replayed with one launch each; the collectives themselves stay ordinary torch.distributed calls on the same stream
+    (nothing of RCCL is captured), so the replayed step is the eager step minus ~30 kernel-launch round trips."""
+
+    def __init__(self):
+        self.ops = []
+        self.pool = torch.cuda.graph_pool_handle()
+        self.g = None
+
+    def begin(self):
+        self.g = torch.cuda.CUDAGraph()
+        # thread_local: the process group's watchdog thread polls events while we capture
+        self.g.capture_begin(pool=self.pool, capture_error_mode="thread_local")
+
+    def boundary(self, fn):
+        self.g.capture_end()
+        self.ops.append(self.g.replay)
+        self.ops.append(fn)
+        self.begin()
+
+    def end(self):
+        self.g.capture_end()
+        self.ops.append(self.g.replay)
+        self.g = None
 
 
 class ExchangePlan:
@@ -165,6 +192,8 @@ class ShardedWideDeepEngine(WideDeepEngine):
         if not self.default_opts:
             raise NotImplementedError("sharded engine: Adagrad (dnn) + Ftrl (linear) only; the other optimizers of "
                                       "model_util.py:84-90 run on the single-GPU engine")
+        self._segs = None
+        self._work_c = None
         self.req_max_nnz = mn
         self.dim = dims.pop() if dims else 0
         if self.dim % 4:
@@ -230,6 +259,13 @@ class ShardedWideDeepEngine(WideDeepEngine):
         self.hash_slots_dev = torch.from_numpy(np.frombuffer(bytes(garr), dtype=np.uint8).copy()).to(dev)
         self.hash_plan = gp
 
+    def _collective(self, fn):
+        """Run a collective now, or -- while a step is being captured -- close the current graph segment and record it."""
+        if self._segs is not None:
+            self._segs.boundary(fn)
+        else:
+            fn()
+
     def check_overflow(self):
         n = int(self.overflow.item())
         if n:
@@ -244,11 +280,11 @@ class ShardedWideDeepEngine(WideDeepEngine):
         # A: route every occurrence to its owner's segment, exchange the requested local rows
         call("wd_route_build", ptr(self.slots_dev), S, W, ptr(bt.ids), ptr(bt.bag_offs), B, self.cap, ptr(self.send_rows),
              ptr(self.pos), ptr(self.route_ws), ptr(self.peer_counts), ptr(self.overflow), st)
-        _a2a(self.recv_rows, self.send_rows, None, None, self.group)
+        self._collective(lambda: _a2a(self.recv_rows, self.send_rows, None, None, self.group))
         # B: owners read their rows (+ wide weight), rows travel back
         call("wd_owner_gather", ptr(self.emb) if has_emb else None, self.n_emb_rows, self.dim,
              ptr(self.wide) if spec.has_wide else None, ptr(self.recv_rows), self.n_req, ptr(self.fwd_send), self.RS, st)
-        _a2a(self.fwd_recv, self.fwd_send, None, None, self.group)
+        self._collective(lambda: _a2a(self.fwd_recv, self.fwd_send, None, None, self.group))
         if spec.has_deep:
             tw0 = self.towers[0]
             ld = tw0["layout"].ld
@@ -266,21 +302,35 @@ class ShardedWideDeepEngine(WideDeepEngine):
                  ptr(self.wide_logit), st)
 
     def _reduce_dense_grads(self):
-        _all_reduce_sum(self.G, self.group)
+        self._collective(lambda: _all_reduce_sum(self.G, self.group))
 
-    def _sparse_backward(self, bt: DeviceBatch, st):
+    def _grads_to_owners(self, bt: DeviceBatch, st):
+        """C: per-occurrence gradients to the owners.  Issued asynchronously: RCCL moves them while this stream goes on
+        with the dense branch; `_owner_update` waits for them."""
         lp, spec = self.plan, self.spec
-        B, S = bt.B, lp.S
         has_emb = self.n_emb_slots > 0
         dx_ptr, ld = None, 0
         if has_emb:
             tw0 = self.towers[0]
             tl0 = tw0["layout"]
             dx_ptr, ld = tw0["dact"].data_ptr() + 4 * tl0.seg_start[0], tl0.ld
-        # C: per-occurrence gradients to the owners
-        call("wd_grad_pack", ptr(self.slots_dev), S, ptr(bt.bag_offs), ptr(self.pos), B, dx_ptr, ld,
+        call("wd_grad_pack", ptr(self.slots_dev), lp.S, ptr(bt.bag_offs), ptr(self.pos), bt.B, dx_ptr, ld,
              ptr(self.dlogit) if spec.has_wide else None, self.dim, self.RS, ptr(self.bwd_send), st)
-        _a2a(self.bwd_recv, self.bwd_send, None, None, self.group)
+
+        def send():
+            self._work_c = _a2a(self.bwd_recv, self.bwd_send, None, None, self.group, async_op=True)
+        self._collective(send)
+
+    def _owner_update(self, bt: DeviceBatch, st):
+        lp, spec = self.plan, self.spec
+        B = bt.B
+        has_emb = self.n_emb_slots > 0
+
+        def wait():
+            if self._work_c is not None:
+                self._work_c.wait()      # stream-level wait: the received gradients are complete for what follows
+                self._work_c = None
+        self._collective(wait)
         lr, l1, l2 = (spec.lin_opt[1], spec.lin_opt[2], spec.lin_opt[3]) if spec.has_wide else (0.0, 0.0, 0.0)
         g_ptr = self.bwd_recv.data_ptr()
         dl_ptr = g_ptr + 4 * (self.dim if has_emb else 0)
@@ -297,11 +347,64 @@ class ShardedWideDeepEngine(WideDeepEngine):
                 gsum = self.G[self._logits_b_off: self._logits_b_off + 1]     # already all-reduced with G
             else:
                 torch.sum(self.dlogit[:B], dim=0, keepdim=True, out=self._gsum)
-                gsum = _all_reduce_sum(self._gsum, self.group)
+                self._collective(lambda: _all_reduce_sum(self._gsum, self.group))
+                gsum = self._gsum
             call("wd_bias_ftrl", ptr(self.bias), ptr(gsum), 1, float(lr), float(l1), float(l2), st)
 
-    def capture_train_step(self, bt, warmup=2):
-        raise NotImplementedError("the sharded step is launched eagerly (collectives between the kernels)")
+    def _sparse_backward(self, bt: DeviceBatch, st):
+        self._grads_to_owners(bt, st)
+        self._owner_update(bt, st)
+
+    def backward_and_update(self, bt: DeviceBatch, bucketized=False):
+        """With the one-launch tower dx exists when forward() returns: the gradient exchange starts first and overlaps
+        with the dense branch (weight-gradient GEMMs, finalize, all-reduce, dense Adagrad)."""
+        spec, st = self.spec, _stream()
+        if not (spec.has_deep and self.chain):
+            return super().backward_and_update(bt, bucketized)
+        B = bt.B
+        self._grads_to_owners(bt, st)
+        tw = self.towers[0]
+        self._tower_backward(tw, B, st, need_dx=False, head_done=True)
+        call("wd_mlp_finalize_all", ptr(self.layers_dev), self.n_layers, self.max_layer_k, ptr(self.P), self.inv,
+             ptr(self.G), st)
+        self._reduce_dense_grads()
+        call("wd_adagrad_dense", ptr(self.P), ptr(self.Pacc), ptr(self.G), self.P.numel(), float(spec.dnn_opt[1]), st)
+        self._owner_update(bt, st)
+
+    def capture_train_step(self, bt, warmup=2, pre=None):
+        """Capture the step on `bt`'s buffers as graph segments between the collectives (see _Segments); `pre` = extra
+        launches in front of it (e.g. the token hashing that fills bt.ids).  Returns a replay callable; every rank must
+        capture and replay in lock-step (the collectives are real calls)."""
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                if pre:
+                    pre()
+                self.train_step(bt)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        segs = _Segments()
+        with torch.cuda.stream(side):
+            self._segs = segs
+            segs.begin()
+            try:
+                if pre:
+                    pre()
+                self.train_step(bt)
+            finally:
+                segs.end()
+                self._segs = None
+        torch.cuda.synchronize()
+        bump = 3 if self.spec.model_type == "wide_deep" else 2
+
+        def replay():
+            for op in segs.ops:
+                op()
+            self.global_step += bump
+            return self.loss
+
+        return replay
 
     # ---- state: shard <-> full tables ---------------------------------------------------------------
     def import_full_state(self, state):

@@ -39,6 +39,8 @@ def parse():
     ap.add_argument("--pool", type=int, default=32, help="distinct resident batches cycled through")
     ap.add_argument("--no-graph", action="store_true", help="launch kernels eagerly instead of hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-sharded", action="store_true",
+                    help="diagnostics: run the row-sharded engine even with one rank (one-rank RCCL group)")
     ap.add_argument("--cpu-steps", type=int, default=20)
     ap.add_argument("--ids-input", action="store_true", help="feed pre-hashed ids (skips the hash kernel)")
     ap.add_argument("--tower-dtype", default=None, choices=["fp32", "fp16"],
@@ -197,9 +199,14 @@ def main():
     backend = os.environ.get("WD_DIST_BACKEND", "nccl")
     dev_index = local_rank if backend == "nccl" else local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(dev_index)
-    if world > 1:
+    sharded = world > 1 or args.force_sharded
+    if sharded:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:     # diagnostics: the sharded step with a one-rank RCCL group (exchange kernels + collectives, no peers)
+            os.environ.setdefault("MASTER_PORT", "29541")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
         else:
@@ -211,7 +218,7 @@ def main():
     spec, mean_len = make_spec(args.config)
     tower_dtype = args.tower_dtype or ("fp16" if args.config == "c5" else "fp32")
     B = args.batch
-    if world > 1:
+    if sharded:
         from wide_deep_amd.dist import ShardedWideDeepEngine
         eng = ShardedWideDeepEngine(spec, max_batch=B, max_nnz=B * 26 * (2 * mean_len + 2), seed=0,
                                     expected_nnz=B * 26 * mean_len, slack=1.3)
@@ -239,7 +246,7 @@ def main():
         return eng.train_step(bt)
 
     use_graph = not args.no_graph
-    if use_graph and world > 1:
+    if use_graph and sharded:
         # sharded step: hipGraph segments between the collectives (dist._Segments); every rank captures in lock-step
         try:
             replays = [eng.capture_train_step(tb.batch, warmup=1,
@@ -285,7 +292,7 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
     loss = float(eng.loss)
-    if world > 1:
+    if sharded:
         eng.check_overflow()     # one device->host read AFTER the timed region
     value = args.steps * B * world / elapsed
 
@@ -307,7 +314,7 @@ def main():
                       % (tower_dtype, B),
             }[args.config],
             "global_batch": B * world, "ids": args.dist, "input": "pre-hashed ids" if args.ids_input else "raw string tokens (hashed in step)",
-            "hip_graph": bool(use_graph), "parallelism": "dp%d+row-sharded tables" % world if world > 1 else "single GPU",
+            "hip_graph": bool(use_graph), "parallelism": "dp%d+row-sharded tables" % world if sharded else "single GPU",
             "final_loss_sum": round(loss, 3),
         },
     }
@@ -323,7 +330,7 @@ def main():
             else:
                 out["cpu_baseline"] = None
         print(json.dumps(out))
-    if world > 1:
+    if sharded:
         torch.distributed.destroy_process_group()
 
 

@@ -36,6 +36,12 @@ k_route(const wd_slot_t *__restrict__ slots, int32_t S, int32_t W, const int32_t
   __shared__ int32_t running[MAX_W];
   __shared__ int32_t any_left;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  if (!SCATTER) {   // count pass: every workgroup also clears its share of the send segments (unused entries = row -1)
+    const int64_t n = (int64_t)W * cap;
+    const int64_t per = (n + gridDim.x - 1) / gridDim.x;
+    const int64_t i1 = ((int64_t)blockIdx.x + 1) * per < n ? ((int64_t)blockIdx.x + 1) * per : n;
+    for (int64_t i = (int64_t)blockIdx.x * per + t; i < i1; i += 256) send_rows[i] = -1;
+  }
   if (t < MAX_W) running[t] = (SCATTER && t < W) ? cntm[(int64_t)blockIdx.x * W + t] : 0;
   __syncthreads();
   const int64_t b0 = (int64_t)blockIdx.x * bags_per_chunk;
@@ -89,7 +95,7 @@ k_route(const wd_slot_t *__restrict__ slots, int32_t S, int32_t W, const int32_t
   if (!SCATTER && t < W) cntm[(int64_t)blockIdx.x * W + t] = running[t];
 }
 
-// one workgroup: exclusive prefix over the chunks per owner, overflow check, and -1 fill of the send segments
+// one workgroup: exclusive prefix over the chunks per owner, overflow check
 __global__ void __launch_bounds__(256)
 k_route_scan(int32_t *__restrict__ cntm, int32_t nchunks, int32_t W, int32_t cap, int32_t *__restrict__ send_rows,
              int32_t *__restrict__ overflow, int32_t *__restrict__ peer_counts) {
@@ -104,8 +110,10 @@ k_route_scan(int32_t *__restrict__ cntm, int32_t nchunks, int32_t W, int32_t cap
     peer_counts[t] = run;
     if (run > cap) atomicMax(overflow, run);
   }
-  const int64_t n = (int64_t)W * cap;
-  for (int64_t i = t; i < n; i += 256) send_rows[i] = -1;
+  if (nchunks == 0) {   // empty batch: no count pass ran
+    const int64_t n = (int64_t)W * cap;
+    for (int64_t i = t; i < n; i += 256) send_rows[i] = -1;
+  }
 }
 
 __global__ void __launch_bounds__(256)

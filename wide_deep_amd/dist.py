@@ -194,6 +194,8 @@ class ShardedWideDeepEngine(WideDeepEngine):
                                       "model_util.py:84-90 run on the single-GPU engine")
         self._segs = None
         self._work_c = None
+        self._train_fwd = False       # forward() of a train step: start the owner-side bucketing early
+        self._bucketized = False
         self.req_max_nnz = mn
         self.dim = dims.pop() if dims else 0
         if self.dim % 4:
@@ -285,6 +287,15 @@ class ShardedWideDeepEngine(WideDeepEngine):
         call("wd_owner_gather", ptr(self.emb) if has_emb else None, self.n_emb_rows, self.dim,
              ptr(self.wide) if spec.has_wide else None, ptr(self.recv_rows), self.n_req, ptr(self.fwd_send), self.RS, st)
         self._collective(lambda: _a2a(self.fwd_recv, self.fwd_send, None, None, self.group))
+        if self._train_fwd:
+            # owner side of the backward pass, part 1 (needs only the received row list): bucket the requests on a
+            # side stream under the tower; joined at the top of backward_and_update (same graph segment)
+            main, side = torch.cuda.current_stream(), self._side(0)
+            side.wait_stream(main)
+            call("wd_sparse_bucketize", ptr(self.oslot_dev), 1, ptr(self.recv_rows), ptr(self.req_offs), self.n_req,
+                 self.n_req, ptr(self.bucket_cnt), ptr(self.bucket_start), ptr(self.occ_rank), ptr(self.pairs),
+                 self.n_buckets, side.cuda_stream)
+            self._bucketized = True
         if spec.has_deep:
             tw0 = self.towers[0]
             ld = tw0["layout"].ld
@@ -335,12 +346,20 @@ class ShardedWideDeepEngine(WideDeepEngine):
         g_ptr = self.bwd_recv.data_ptr()
         dl_ptr = g_ptr + 4 * (self.dim if has_emb else 0)
         # owner: dedup by row + Adagrad / FTRL on the received (row, gradient) list; bias handled below
-        call("wd_sparse_bwd_fused", ptr(self.emb) if has_emb else None, ptr(self.emb_acc) if has_emb else None,
-             ptr(self.wide) if spec.has_wide else None, None, ptr(self.oslot_dev), 1, ptr(self.recv_rows),
-             ptr(self.req_offs), self.n_req, self.n_req, g_ptr if has_emb else None, self.RS,
-             dl_ptr if spec.has_wide else None, self.RS, float(spec.dnn_opt[1]) if spec.has_deep else 0.0, float(lr),
-             float(l1), float(l2), ptr(self.bucket_cnt), ptr(self.bucket_start), ptr(self.occ_rank), ptr(self.pairs),
-             self.n_buckets, st)
+        if self._bucketized:
+            self._bucketized = False
+            call("wd_sparse_apply", ptr(self.emb) if has_emb else None, ptr(self.emb_acc) if has_emb else None,
+                 ptr(self.wide) if spec.has_wide else None, None, ptr(self.oslot_dev), 1, ptr(self.req_offs), self.n_req,
+                 g_ptr if has_emb else None, self.RS, dl_ptr if spec.has_wide else None, self.RS,
+                 float(spec.dnn_opt[1]) if spec.has_deep else 0.0, float(lr), float(l1), float(l2),
+                 ptr(self.bucket_start), ptr(self.pairs), self.n_buckets, st)
+        else:
+            call("wd_sparse_bwd_fused", ptr(self.emb) if has_emb else None, ptr(self.emb_acc) if has_emb else None,
+                 ptr(self.wide) if spec.has_wide else None, None, ptr(self.oslot_dev), 1, ptr(self.recv_rows),
+                 ptr(self.req_offs), self.n_req, self.n_req, g_ptr if has_emb else None, self.RS,
+                 dl_ptr if spec.has_wide else None, self.RS, float(spec.dnn_opt[1]) if spec.has_deep else 0.0, float(lr),
+                 float(l1), float(l2), ptr(self.bucket_cnt), ptr(self.bucket_start), ptr(self.occ_rank), ptr(self.pairs),
+                 self.n_buckets, st)
         if spec.has_wide:
             # bias_weights: dense FTRL on the GLOBAL sum of dlogit
             if self._logits_b_off is not None:
@@ -359,8 +378,10 @@ class ShardedWideDeepEngine(WideDeepEngine):
         """With the one-launch tower dx exists when forward() returns: the gradient exchange starts first and overlaps
         with the dense branch (weight-gradient GEMMs, finalize, all-reduce, dense Adagrad)."""
         spec, st = self.spec, _stream()
+        if self._bucketized:
+            torch.cuda.current_stream().wait_stream(self._side(0))     # the early bucketing (see _sparse_forward)
         if not (spec.has_deep and self.chain):
-            return super().backward_and_update(bt, bucketized)
+            return super().backward_and_update(bt, False)
         B = bt.B
         self._grads_to_owners(bt, st)
         tw = self.towers[0]
@@ -370,6 +391,13 @@ class ShardedWideDeepEngine(WideDeepEngine):
         self._reduce_dense_grads()
         call("wd_adagrad_dense", ptr(self.P), ptr(self.Pacc), ptr(self.G), self.P.numel(), float(spec.dnn_opt[1]), st)
         self._owner_update(bt, st)
+
+    def train_step(self, bt: DeviceBatch):
+        self._train_fwd = True
+        try:
+            return super().train_step(bt)
+        finally:
+            self._train_fwd = False
 
     def capture_train_step(self, bt, warmup=2, pre=None):
         """Capture the step on `bt`'s buffers as graph segments between the collectives (see _Segments); `pre` = extra

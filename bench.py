@@ -128,6 +128,34 @@ def gather_roofline(eng, batches, iters=200):
                               "source": "profiles/r1i_ceilings.txt"}}
 
 
+MFMA_F32_PEAK_TFLOPS = 157.3     # v_mfma_f32_32x32x2_f32, dense (MI355X_MICROARCH.md)
+
+
+def tower_roofline(eng, bt, iters=100):
+    """The one-launch tower (k_tower_chain, the kernel with the largest share of the step): algorithmic flops of the
+    forward products and of the input-gradient chain / measured duration (HIP events on the launch stream)."""
+    if not getattr(eng, "chain", False):
+        return None
+    tw = eng.towers[0]
+    st = torch.cuda.current_stream().cuda_stream
+    B = bt.B
+    run = lambda i: eng._tower_chain(tw, bt, B, st, True)
+    for i in range(5):
+        run(i)
+    torch.cuda.synchronize()
+    ms = event_time_ms(run, iters)
+    metas, L = tw["metas"], tw["L"]
+    dxc = (tw["dx_cols"] + 31) // 32 * 32 if eng.group_slots else 0
+    macs = sum(m["K"] * m["N"] for m in metas[:L]) + sum(m["K"] * m["N"] for m in metas[1:L]) + metas[0]["N"] * dxc
+    macs += 2 * metas[L]["K"]                      # logits layer forward + its input gradient
+    fl = 2.0 * B * macs
+    tf = fl / (ms * 1e-3) / 1e12
+    return {"bound": "mfma", "kernel": "k_tower_chain", "achieved": round(tf, 1), "peak": MFMA_F32_PEAK_TFLOPS,
+            "unit": "TFLOP/s", "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4), "algorithmic_flops_per_launch": int(fl),
+            "avg_launch_us": round(ms * 1e3, 2),
+            "note": "forward of all hidden layers + logits + head + input-gradient chain down to dx; exact fp32 MFMA"}
+
+
 def cpu_baseline(eng, host_batches, steps, B):
     """The CPU oracle (oracle/, a port restating the reference's TF semantics -- TF itself is not installable
     here) timed on this box's host cores over `steps` batches of the same workload, hashing included."""
@@ -325,6 +353,8 @@ def main():
                 synth.hash_tokens(eng, tb)
             torch.cuda.synchronize()
             out["roofline"] = gather_roofline(eng, [tb.batch for tb in dev_batches])
+            if not sharded:
+                out["roofline_tower"] = tower_roofline(eng, dev_batches[0].batch)
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(eng, host_batches, args.cpu_steps, B)
             else:

@@ -46,15 +46,14 @@ def _a2a(out, inp, out_splits, in_splits, group=None, async_op=False):
     return dist.all_to_all_single(out, inp, out_splits, in_splits, group=group, async_op=async_op)
 
 
-def _all_reduce_sum(t, group=None):
+def _all_reduce_sum(t, group=None, async_op=False):
     backend = dist.get_backend(group)
     if t.is_cuda and backend == "gloo":
         c = t.cpu()
         dist.all_reduce(c, op=dist.ReduceOp.SUM, group=group)
         t.copy_(c)
-    else:
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
-    return t
+        return None
+    return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
 
 
 class _Segments:
@@ -71,8 +70,12 @@ class _Segments:
         self.g = torch.cuda.CUDAGraph()
         # thread_local: the process group's watchdog thread polls events while we capture
         self.g.capture_begin(pool=self.pool, capture_error_mode="thread_local")
+        self.mark = capi.NCALLS
 
     def boundary(self, fn):
+        if capi.NCALLS == self.mark:      # two collectives back to back: no launch in between, keep the open segment
+            self.ops.append(fn)
+            return
         self.g.capture_end()
         self.ops.append(self.g.replay)
         self.ops.append(fn)
@@ -80,7 +83,8 @@ class _Segments:
 
     def end(self):
         self.g.capture_end()
-        self.ops.append(self.g.replay)
+        if capi.NCALLS != self.mark:
+            self.ops.append(self.g.replay)
         self.g = None
 
 
@@ -194,6 +198,7 @@ class ShardedWideDeepEngine(WideDeepEngine):
                                       "model_util.py:84-90 run on the single-GPU engine")
         self._segs = None
         self._work_c = None
+        self._work_d = None
         self._train_fwd = False       # forward() of a train step: start the owner-side bucketing early
         self._bucketized = False
         self.req_max_nnz = mn
@@ -332,7 +337,7 @@ class ShardedWideDeepEngine(WideDeepEngine):
             self._work_c = _a2a(self.bwd_recv, self.bwd_send, None, None, self.group, async_op=True)
         self._collective(send)
 
-    def _owner_update(self, bt: DeviceBatch, st):
+    def _owner_update(self, bt: DeviceBatch, st, do_bias=True):
         lp, spec = self.plan, self.spec
         B = bt.B
         has_emb = self.n_emb_slots > 0
@@ -360,15 +365,22 @@ class ShardedWideDeepEngine(WideDeepEngine):
                  dl_ptr if spec.has_wide else None, self.RS, float(spec.dnn_opt[1]) if spec.has_deep else 0.0, float(lr),
                  float(l1), float(l2), ptr(self.bucket_cnt), ptr(self.bucket_start), ptr(self.occ_rank), ptr(self.pairs),
                  self.n_buckets, st)
-        if spec.has_wide:
-            # bias_weights: dense FTRL on the GLOBAL sum of dlogit
-            if self._logits_b_off is not None:
-                gsum = self.G[self._logits_b_off: self._logits_b_off + 1]     # already all-reduced with G
-            else:
-                torch.sum(self.dlogit[:B], dim=0, keepdim=True, out=self._gsum)
-                self._collective(lambda: _all_reduce_sum(self._gsum, self.group))
-                gsum = self._gsum
-            call("wd_bias_ftrl", ptr(self.bias), ptr(gsum), 1, float(lr), float(l1), float(l2), st)
+        if do_bias:
+            self._bias_update(bt, st)
+
+    def _bias_update(self, bt: DeviceBatch, st):
+        spec = self.spec
+        if not spec.has_wide:
+            return
+        # bias_weights: dense FTRL on the GLOBAL sum of dlogit
+        lr, l1, l2 = spec.lin_opt[1], spec.lin_opt[2], spec.lin_opt[3]
+        if self._logits_b_off is not None:
+            gsum = self.G[self._logits_b_off: self._logits_b_off + 1]     # already all-reduced with G
+        else:
+            torch.sum(self.dlogit[:bt.B], dim=0, keepdim=True, out=self._gsum)
+            self._collective(lambda: _all_reduce_sum(self._gsum, self.group))
+            gsum = self._gsum
+        call("wd_bias_ftrl", ptr(self.bias), ptr(gsum), 1, float(lr), float(l1), float(l2), st)
 
     def _sparse_backward(self, bt: DeviceBatch, st):
         self._grads_to_owners(bt, st)
@@ -388,9 +400,19 @@ class ShardedWideDeepEngine(WideDeepEngine):
         self._tower_backward(tw, B, st, need_dx=False, head_done=True)
         call("wd_mlp_finalize_all", ptr(self.layers_dev), self.n_layers, self.max_layer_k, ptr(self.P), self.inv,
              ptr(self.G), st)
-        self._reduce_dense_grads()
+        # D (all-reduce of the flat dense gradient) in the background of the owners' sparse update
+        def reduce_async():
+            self._work_d = _all_reduce_sum(self.G, self.group, async_op=True)
+        self._collective(reduce_async)
+        self._owner_update(bt, st, do_bias=False)
+
+        def wait_d():
+            if self._work_d is not None:
+                self._work_d.wait()
+                self._work_d = None
+        self._collective(wait_d)
         call("wd_adagrad_dense", ptr(self.P), ptr(self.Pacc), ptr(self.G), self.P.numel(), float(spec.dnn_opt[1]), st)
-        self._owner_update(bt, st)
+        self._bias_update(bt, st)
 
     def train_step(self, bt: DeviceBatch):
         self._train_fwd = True

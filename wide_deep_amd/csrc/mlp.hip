@@ -412,30 +412,48 @@ __device__ __forceinline__ void fold_affine_body(const float *__restrict__ P, in
   const float *W = P + w_off;
   const bool stage = WfT_h && tileT && kc <= FOLD_TK;
   float tb = 0.f;
-  for (int64_t k = k0 + ty; k < k1; k += 4) {
-    const int32_t gi = gamma_idx ? gamma_idx[k] : -1;
-    const int32_t bi = beta_idx ? beta_idx[k] : -1;
-    const float sk = gi >= 0 ? P[gi] * inv : 1.0f;
-    const float tk = bi >= 0 ? P[bi] : 0.0f;
-    if (bx == 0 && tx == 0) {
-      s_out[k] = sk;
-      t_out[k] = tk;
+  // U rows per trip, in three rounds of independent loads (indices -> affine parameters + kernel row -> stores): the
+  // per-row chain idx -> P[idx] -> store used to cost one exposed round trip per row (128 us at C5's 5 M weights)
+  constexpr int U = 4;
+  for (int64_t kb = k0 + ty; kb < k1; kb += 4 * U) {
+    int32_t gi[U], bi[U];
+    int64_t co[U];
+    float w[U], sk[U], tk[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t k = kb + 4 * u;
+      const bool live = k < k1;
+      gi[u] = (live && gamma_idx) ? gamma_idx[k] : -1;
+      bi[u] = (live && beta_idx) ? beta_idx[k] : -1;
+      co[u] = (live && cat_off) ? cat_off[k] : -1;
+      w[u] = (live && n < N) ? W[k * N + n] : 0.f;
     }
-    if (n < N) {
-      const float w = W[k * N + n];
-      Wf[k * N + n] = sk * w;
-      if (WfT_h) {
-        if (stage) tileT[tx * FOLD_TP + (k - k0)] = (_Float16)(sk * w);
-        else WfT_h[n * ld_wft_h + k] = (_Float16)(sk * w);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      sk[u] = gi[u] >= 0 ? P[gi[u]] * inv : 1.0f;
+      tk[u] = bi[u] >= 0 ? P[bi[u]] : 0.0f;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t k = kb + 4 * u;
+      if (k >= k1) break;
+      if (bx == 0 && tx == 0) {
+        s_out[k] = sk[u];
+        t_out[k] = tk[u];
       }
-      if (cat_off) {
-        const int64_t o = cat_off[k];
-        if (o >= 0) wcat[o + n] = (_Float16)(sk * w);
+      if (n < N) {
+        const float v = sk[u] * w[u];
+        Wf[k * N + n] = v;
+        if (WfT_h) {
+          if (stage) tileT[tx * FOLD_TP + (k - k0)] = (_Float16)v;
+          else WfT_h[n * ld_wft_h + k] = (_Float16)v;
+        }
+        if (co[u] >= 0) wcat[co[u] + n] = (_Float16)v;
+        // MFMA-fragment-packed copies for wd_tower_chain (layout: include/wd_hip.h, wd_mlp_layer_t)
+        if (Wpk) Wpk[((n >> 5) * (K >> 3) + (k >> 3)) * 256 + (((k & 1) << 5) + (n & 31)) * 4 + ((k & 7) >> 1)] = v;
+        if (WTpk) WTpk[((k >> 5) * (N >> 3) + (n >> 3)) * 256 + (((n & 1) << 5) + (k & 31)) * 4 + ((n & 7) >> 1)] = v;
+        tb += tk[u] * w[u];
       }
-      // MFMA-fragment-packed copies for wd_tower_chain (layout: include/wd_hip.h, wd_mlp_layer_t)
-      if (Wpk) Wpk[((n >> 5) * (K >> 3) + (k >> 3)) * 256 + (((k & 1) << 5) + (n & 31)) * 4 + ((k & 7) >> 1)] = sk * w;
-      if (WTpk) WTpk[((k >> 5) * (N >> 3) + (n >> 3)) * 256 + (((n & 1) << 5) + (k & 31)) * 4 + ((n & 7) >> 1)] = sk * w;
-      tb += tk * w;
     }
   }
   red[ty][tx] = tb;

@@ -393,6 +393,27 @@ typedef struct wd_chain_layer {
   float *dz_out;     /* [batch][N] */
   int32_t K, N;
 } wd_chain_layer_t;
+/* Optional: fuse the input layer into the NEXT wd_tower_chain call (one-id-per-bag batches, the Criteo shape): the kernel
+ * then builds its x tile itself -- x[b, out_col_s ..] = emb[emb_off_s + ids[b*S + s]*dim ..] for the slots
+ * [slot0, slot0+ngroup) (id < 0: zeros), the numeric columns (wd_dense_fwd), and the wide logit
+ * bias[0] + sum_s wide[(row_base_s + id)*4] (wd_wide_fwd; NULL: none) -- writes x to x_out (the weight-gradient GEMMs
+ * read it) and the wide logit to wide_out, and ignores the x / wide_logit arguments of wd_tower_chain.  It replaces the
+ * wd_input_layer_fwd launch (python/lib/dnn.py:88-90, python/lib/linear.py:29-36).  NULL clears a pending request. */
+#define WD_CHAIN_MAX_SLOTS 128
+typedef struct wd_chain_input {
+  const float *emb;
+  const wd_slot_t *slots;
+  const int32_t *ids;              /* [batch * S], one id per bag */
+  const float *wide;               /* AoS {w, .., .., -} table or NULL */
+  const float *wide_bias;
+  float *wide_out;                 /* [batch] or NULL */
+  const float *dense;              /* [batch][ld_dense] raw numeric features */
+  const wd_dense_col_t *cols;
+  float *x_out;                    /* [batch][ld_act] */
+  int64_t ld_dense;
+  int32_t S, slot0, ngroup, dim, ncols, pad_;
+} wd_chain_input_t;
+int wd_tower_chain_input(const wd_chain_input_t *in);
 int64_t wd_tower_chain_lds_bytes(int32_t K0, const int32_t *N, int32_t L);   /* -1: unsupported shape */
 int64_t wd_tower_chain_blocks(int64_t batch);
 /* diagnostics: later launches write shader-clock stamps (start, x tile in LDS, after each forward layer, head, after each

@@ -62,6 +62,37 @@ def test_chain_matches_per_layer_launches(B, kw):
     assert_close(a.logit[:B], b.logit[:B], 1e-5, 1e-5, "predict logits")
 
 
+def test_fused_input_layer_and_env_switch():
+    """The tower kernel builds its own x tile (wd_tower_chain_input) for one-id-per-bag batches; WD_CHAIN_INPUT=0 keeps
+    the separate input-layer launch; x is bit-equal between the two, and both train like the per-layer engine."""
+    from wide_deep_amd import synth
+    from wide_deep_amd.plan import criteo_spec
+    from tests.helpers import assert_close
+    spec = criteo_spec(n_dense=16, n_sparse=7, buckets=400, dim=16, hidden=(64, 32))   # K0 = 128
+    a, b = _engines(spec, max_batch=80)
+    hb = synth.make_raw_batch(a.plan, 77, seed=3, pos_rate=0.3)
+    bts = [synth.to_device_ids(e.plan, hb) for e in (a, b)]
+    assert a._chain_input_ok(bts[0]) and not b._chain_input_ok(bts[1])
+    a.train_step(bts[0]); b.train_step(bts[1])
+    os.environ["WD_CHAIN_INPUT"] = "0"
+    try:
+        c, _ = _engines(spec, max_batch=80)
+        btc = synth.to_device_ids(c.plan, hb)
+        assert not c._chain_input_ok(btc)
+        c.train_step(btc)
+    finally:
+        del os.environ["WD_CHAIN_INPUT"]
+    torch.cuda.synchronize()
+    assert_close(a.logit[:77], b.logit[:77], 1e-5, 1e-5, "logits")
+    assert_close(a.wide_logit[:77], b.wide_logit[:77], 1e-6, 1e-6, "wide logit")
+    tl = a.towers[0]["layout"]
+    assert torch.equal(a.towers[0]["act"][:77, : tl.seg_width[0]], c.towers[0]["act"][:77, : tl.seg_width[0]])   # x bit-equal
+    sa, sb, sc = a.export_state(), b.export_state(), c.export_state()
+    for k in sb:
+        assert_close(sa[k], sb[k], 2e-4, 2e-6, k)
+        assert_close(sa[k], sc[k], 2e-4, 2e-6, k)
+
+
 def test_chain_steps_match_oracle():
     from tests.test_gpu_step import _run
     from wide_deep_amd.plan import criteo_spec

@@ -65,6 +65,18 @@ class WdOpt(ctypes.Structure):
                 ("p2", ctypes.c_float), ("pad_", ctypes.c_int32), ("pow", ctypes.c_void_p)]
 
 
+class WdChainInput(ctypes.Structure):
+    _fields_ = [
+        ("emb", ctypes.c_void_p), ("slots", ctypes.c_void_p), ("ids", ctypes.c_void_p), ("wide", ctypes.c_void_p),
+        ("wide_bias", ctypes.c_void_p), ("wide_out", ctypes.c_void_p), ("dense", ctypes.c_void_p), ("cols", ctypes.c_void_p),
+        ("x_out", ctypes.c_void_p), ("ld_dense", ctypes.c_int64), ("S", ctypes.c_int32), ("slot0", ctypes.c_int32),
+        ("ngroup", ctypes.c_int32), ("dim", ctypes.c_int32), ("ncols", ctypes.c_int32), ("pad_", ctypes.c_int32),
+    ]
+
+
+WD_CHAIN_MAX_SLOTS = 128
+
+
 class WdTnJob(ctypes.Structure):
     _fields_ = [
         ("A", ctypes.c_void_p), ("B", ctypes.c_void_p), ("Cpart", ctypes.c_void_p),
@@ -137,6 +149,7 @@ _PROTOS = {
     "wd_adam_tick": [P, F32, F32, P],
     "wd_tower_chain_lds_bytes": [I32, P, I32],
     "wd_tower_chain_blocks": [I64],
+    "wd_tower_chain_input": [P],
     "wd_tower_chain_set_stamps": [P],
     "wd_tower_chain": [P, I64, I32, P, I32, I32, I32, P, P, P, P, P, I64, P, P, P, P, P, P, P, I64, I32, P],
     "wd_logits_head_h": [P, I64, I64, P, P, I32, P, P, P, I64, P, P, P, P, P, P, I64, I32, P, P],

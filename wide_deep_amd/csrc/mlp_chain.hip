@@ -32,6 +32,7 @@
 namespace {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef float floatx4v __attribute__((ext_vector_type(4)));
 
 constexpr int RT = 32;        // examples per row tile
 constexpr int P = 33;         // LDS pitch of one reduction row
@@ -61,6 +62,7 @@ struct ChainArgs {
   float *dx;
   int64_t ld_dx;
   unsigned long long *stamps;   // diagnostics (wd_tower_chain_set_stamps): shader-clock stamps of workgroups 0 and 100
+  wd_chain_input_t in;          // in.emb != NULL: the x tile is built here (input layer fused), see wd_tower_chain_input
 };
 
 __device__ __forceinline__ float act_fwd(float v, int act) {
@@ -238,6 +240,8 @@ __global__ void __launch_bounds__(256) k_tower_chain(ChainArgs g) {
   __shared__ float sdl[RT];
   __shared__ float red[8 * RT];
   __shared__ float swl[512];   // logits-layer kernel
+  __shared__ int64_t s_eoff[WD_CHAIN_MAX_SLOTS], s_rbase[WD_CHAIN_MAX_SLOTS];   // fused input layer: slot descriptors
+  __shared__ int32_t s_ocol[WD_CHAIN_MAX_SLOTS];
   const int t = threadIdx.x;
   const int64_t b0 = (int64_t)blockIdx.x * RT;
   const int L = uni(g.L);
@@ -262,6 +266,94 @@ __global__ void __launch_bounds__(256) k_tower_chain(ChainArgs g) {
   if (t < RT)
     for (int p = 0; p < g.bias_parts; ++p) h_bias += g.b_logits[p];
 
+  float *s_wide = red;   // [RT] wide logit of the tile's examples (gather mode); `red` is free until the head
+  if (g.in.emb) {
+    // ---- input layer of the tile, fused (python/lib/dnn.py:88-90 input_layer + python/lib/linear.py:29-36 linear_model
+    // for one-id-per-bag batches): x[m, out_col_s ..] = E_s[id(m, s)], numeric columns, wide logit.  832 random 64-byte
+    // rows per workgroup (C2): ids first (coalesced), then every row / wide line load of the tile in flight at once.
+    const wd_chain_input_t &I = g.in;
+    const int S = uni(I.S), NG = uni(I.ngroup), D = uni(I.dim), LG = D >> 2;
+    int32_t *s_id = reinterpret_cast<int32_t *>(lds + g.a_off[0]);   // a_0's region is dead until layer 0 writes it
+    float *s_w = lds + g.a_off[0] + RT * S;                          // wide weight per (example, slot)
+    for (int i = t; i < S; i += 256) {                               // slot descriptors -> LDS (48-byte structs in HBM)
+      const wd_slot_t sl = I.slots[i];
+      s_eoff[i] = sl.emb_off;
+      s_ocol[i] = sl.out_col;
+      s_rbase[i] = sl.wide ? (int64_t)sl.row_base : (int64_t)-1;
+    }
+    const int nbag = RT * S;
+    for (int i = t; i < nbag; i += 256) {
+      const int m = i / S;
+      s_id[i] = b0 + m < g.batch ? I.ids[b0 * S + i] : -1;
+      s_w[i] = 0.f;
+    }
+    for (int i = t; i < (int)g.K0 * P; i += 256) regx[i] = 0.f;     // pad columns and dropped ids read as zero
+    __syncthreads();
+    // embedding rows: LG lanes per (example, slot of the group), 8 bags per lane group in flight
+    const int lg = t % LG, grp = t / LG, ngrp = 256 / LG;
+    const int nwork = RT * NG;
+    for (int w0 = grp; w0 < nwork; w0 += 8 * ngrp) {
+      floatx4v r[8];
+      int col[8], mm[8];
+      bool hit[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int w = w0 + q * ngrp;
+        r[q] = floatx4v{0.f, 0.f, 0.f, 0.f};
+        col[q] = -1;
+        mm[q] = 0;
+        hit[q] = false;
+        if (w < nwork) {
+          const int m = w / NG, sidx = I.slot0 + (w - m * NG);
+          const int id = s_id[m * S + sidx];
+          mm[q] = m;
+          col[q] = s_ocol[sidx] + 4 * lg;
+          hit[q] = id >= 0;
+          if (id >= 0) r[q] = __builtin_nontemporal_load(reinterpret_cast<const floatx4v *>(I.emb + s_eoff[sidx] + (int64_t)id * D) + lg);
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        if (col[q] < 0) continue;
+        const int c0 = col[q], m = mm[q];
+        if (hit[q]) {
+          regx[(c0 + 0) * P + m] = r[q].x; regx[(c0 + 1) * P + m] = r[q].y;
+          regx[(c0 + 2) * P + m] = r[q].z; regx[(c0 + 3) * P + m] = r[q].w;
+        }
+        if (b0 + m < g.batch) *reinterpret_cast<floatx4v *>(I.x_out + (b0 + m) * g.ld_act + c0) = r[q];
+      }
+    }
+    // wide weights (one 16-byte line per occurrence, the weight is its first float) and numeric columns
+    if (I.wide) {
+      for (int i = t; i < nbag; i += 256) {
+        const int64_t rb = s_rbase[i % S];
+        const int id = s_id[i];
+        if (rb >= 0 && id >= 0) s_w[i] = I.wide[(rb + id) * 4];
+      }
+    }
+    for (int i = t; i < RT * I.ncols; i += 256) {
+      const int m = i % RT, j = i / RT;
+      if (b0 + m < g.batch) {
+        const wd_dense_col_t c = I.cols[j];
+        float v = I.dense[(b0 + m) * I.ld_dense + j];
+        if (c.kind == 1) v = (v - c.p0) / (c.p1 - c.p0);
+        else if (c.kind == 2) v = (v - c.p0) / c.p1;
+        else if (c.kind == 3) v = logf(v);
+        regx[c.out_col * P + m] = v;
+        I.x_out[(b0 + m) * g.ld_act + c.out_col] = v;
+      }
+    }
+    __syncthreads();
+    if (t < RT) {   // wide logit: slots in order (fixed summation order)
+      float acc = 0.f;
+      if (I.wide) {
+        for (int sidx = 0; sidx < S; ++sidx) acc += s_w[t * S + sidx];
+        acc += I.wide_bias[0];
+      }
+      s_wide[t] = acc;
+      if (I.wide_out && b0 + t < g.batch) I.wide_out[b0 + t] = acc;
+    }
+  } else {
   // ---- x tile -> LDS [k][33] (rows beyond the batch read as zero): all loads of a 512-column block in flight, then
   // the transposing LDS stores ------------------------------------------------------------------------------
   {
@@ -287,6 +379,7 @@ __global__ void __launch_bounds__(256) k_tower_chain(ChainArgs g) {
       }
     }
   }
+  }
   __syncthreads();
   stamp();
 
@@ -309,6 +402,8 @@ __global__ void __launch_bounds__(256) k_tower_chain(ChainArgs g) {
     const int m = t & 31, part = t >> 5;
     float d = 0.f;
     for (int n = part; n < K; n += 8) d += in[n * P + m] * swl[n];
+    const float h_wide_lds = (g.in.emb && t < RT) ? s_wide[t] : 0.f;   // read before `red` is reused below
+    __syncthreads();
     red[part * RT + m] = d;
     __syncthreads();
     if (t < RT) {
@@ -319,7 +414,7 @@ __global__ void __launch_bounds__(256) k_tower_chain(ChainArgs g) {
       const int64_t b = b0 + t;
       float dl = 0.f, ls = 0.f;
       if (b < g.batch) {
-        const float x = dn + h_wide;
+        const float x = dn + (g.in.emb ? h_wide_lds : h_wide);
         const float y = h_y;
         const float w = h_w;
         const float e = expf(-fabsf(x));
@@ -425,6 +520,23 @@ extern "C" int64_t wd_tower_chain_lds_bytes(int32_t K0, const int32_t *N, int32_
 }
 
 static unsigned long long *g_stamps = nullptr;
+static wd_chain_input_t g_input = {};   // consumed (and cleared) by the next wd_tower_chain call
+
+extern "C" int wd_tower_chain_input(const wd_chain_input_t *in) {
+  if (!in) {
+    g_input = wd_chain_input_t{};
+    return WD_OK;
+  }
+  WD_REQUIRE(in->emb && in->slots && in->ids && in->x_out, "null pointer");
+  WD_REQUIRE(in->dim >= 4 && in->dim % 4 == 0 && in->dim <= 256 && 256 % (in->dim / 4) == 0, "dim: multiple of 4 dividing 1024");
+  WD_REQUIRE(in->S > 0 && in->S <= WD_CHAIN_MAX_SLOTS && in->ngroup > 0 && in->slot0 >= 0 && in->slot0 + in->ngroup <= in->S,
+             "bad slot range (S <= WD_CHAIN_MAX_SLOTS)");
+  WD_REQUIRE(in->ncols == 0 || (in->dense && in->cols), "numeric columns need dense + descriptors");
+  WD_REQUIRE(!in->wide || in->wide_bias, "wide needs its bias");
+  g_input = *in;
+  return WD_OK;
+}
+
 extern "C" int wd_tower_chain_set_stamps(void *dev_u64x64) {
   g_stamps = static_cast<unsigned long long *>(dev_u64x64);
   return WD_OK;
@@ -460,6 +572,9 @@ extern "C" int wd_tower_chain(const float *x, int64_t ld_act, int32_t K0, const 
   g.wide_logit = wide_logit; g.labels = labels; g.weights = weights; g.batch = batch;
   g.dnn_logit = dnn_logit; g.logit = logit; g.prob = prob; g.dlogit = dlogit; g.loss_sum = loss_sum;
   g.Gpart_logits = Gpart_logits; g.dx = dx; g.ld_dx = ld_dx; g.stamps = g_stamps;
+  g.in = g_input;
+  g_input = wd_chain_input_t{};
+  if (g.in.emb) WD_REQUIRE((int64_t)2 * RT * g.in.S * 4 <= (int64_t)N[0] * P * 4, "input fusion: ids do not fit the scratch region (2 x 32 x S <= 33 x N_0)");
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_tower_chain),

@@ -305,10 +305,10 @@ int wd_gemm_tn_splitk(const float *A, int64_t lda, const float *B, int64_t ldb, 
 
 /* wd_gemm_tn_splitk for several layers in ONE launch (the weight-gradient products of a whole tower): job j is exactly
  * wd_gemm_tn_splitk(A, lda, B, ldb, Cpart, M, N, K, nsplit, append_ones). */
-#define WD_TN_GROUP_MAX 8
+#define WD_TN_GROUP_MAX 16
 typedef struct wd_tn_job {
   const float *A;
-  const float *B;
+  const float *B;    /* NULL: column-sum job -- Cpart[n] = sum over the K rows of A [K][lda] (n < N), in row order */
   float *Cpart;
   int64_t lda, ldb, M, N, K;
   int32_t nsplit, append_ones;
@@ -349,6 +349,9 @@ typedef struct wd_mlp_layer {
    *   Wpk  = pack(Wf)    (R = K, C = N: forward products)      WTpk = pack(Wf^T)  (R = N, C = K: gradient chain) */
   float *Wpk;
   float *WTpk;
+  /* optional: the bias gradient sum_b dz[b, :] precomputed [N] (wd_tower_chain partials reduced by a column-sum job of
+   * wd_gemm_tn_splitk_group).  Then Gpart holds nsplit x [K][N] (no appended ones row). */
+  const float *db_sum;
 } wd_mlp_layer_t;
 
 /* wd_fold_affine for every layer of every tower in ONE launch; also zero-fills up to two small buffers
@@ -391,6 +394,7 @@ typedef struct wd_chain_layer {
   const float *bf;   /* bias_parts x N partial folded biases */
   float *a_out;      /* activations of this layer inside the tower's activation buffer */
   float *dz_out;     /* [batch][N] */
+  float *db_part;    /* optional [wd_tower_chain_blocks(batch)][N]: per row tile, the column sums of dz (bias gradient partials) */
   int32_t K, N;
 } wd_chain_layer_t;
 /* Optional: fuse the input layer into the NEXT wd_tower_chain call (one-id-per-bag batches, the Criteo shape): the kernel

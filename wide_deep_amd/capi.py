@@ -49,12 +49,12 @@ class WdMlpLayer(ctypes.Structure):
         ("Wf", ctypes.c_void_p), ("bf", ctypes.c_void_p), ("s", ctypes.c_void_p), ("t", ctypes.c_void_p),
         ("Gpart", ctypes.c_void_p), ("nsplit", ctypes.c_int32), ("pad_", ctypes.c_int32),
         ("WfT_h", ctypes.c_void_p), ("ld_wft_h", ctypes.c_int64), ("cat_off", ctypes.c_void_p), ("wcat", ctypes.c_void_p),
-        ("Wpk", ctypes.c_void_p), ("WTpk", ctypes.c_void_p),
+        ("Wpk", ctypes.c_void_p), ("WTpk", ctypes.c_void_p), ("db_sum", ctypes.c_void_p),
     ]
 
 
 WD_CHAIN_MAX_LAYERS = 6
-WD_TN_GROUP_MAX = 8
+WD_TN_GROUP_MAX = 16
 
 
 WD_OPT_KINDS = {"SGD": 0, "Adagrad": 1, "Ftrl": 2, "RMSProp": 3, "Adam": 4}
@@ -88,7 +88,7 @@ class WdTnJob(ctypes.Structure):
 class WdChainLayer(ctypes.Structure):
     _fields_ = [
         ("Wpk", ctypes.c_void_p), ("WTpk", ctypes.c_void_p), ("bf", ctypes.c_void_p), ("a_out", ctypes.c_void_p),
-        ("dz_out", ctypes.c_void_p), ("K", ctypes.c_int32), ("N", ctypes.c_int32),
+        ("dz_out", ctypes.c_void_p), ("db_part", ctypes.c_void_p), ("K", ctypes.c_int32), ("N", ctypes.c_int32),
     ]
 
 

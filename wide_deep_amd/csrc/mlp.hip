@@ -349,6 +349,7 @@ struct GroupArgs {
   int32_t first[MAX_TN_JOBS + 1];   // first flat workgroup id of job j (multiple of 8: keeps the XCD-aware tile order
                                     // of the body valid); [njobs] = grid size
   int32_t count[MAX_TN_JOBS];       // workgroups of job j (tiles x splits)
+  int32_t colsum[MAX_TN_JOBS];      // job j is a column-sum job (B == NULL)
   int32_t njobs;
 };
 
@@ -360,6 +361,27 @@ __global__ void __launch_bounds__(256) k_gemm_tn_group(GroupArgs G) {
   const GemmArgs &g = G.job[j];
   const int rem = blockIdx.x - G.first[j];
   if (rem >= G.count[j]) return;   // padding of the job's range
+  if (G.colsum[j]) {
+    // C[n] = sum_k A[k][n]: 64 columns per workgroup, 4 row groups (k = q, q+4, ..) with 8 independent loads in flight
+    // each, combined in group order -- a fixed summation order, and no chain of exposed load latencies
+    __shared__ float part[4][64];
+    const int c = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int64_t n = (int64_t)rem * 64 + c;
+    float acc = 0.f;
+    if (n < g.N) {
+      for (int64_t k0 = q; k0 < g.K; k0 += 32) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = k0 + 4 * u < g.K ? g.A[(k0 + 4 * u) * g.lda + n] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += v[u];
+      }
+    }
+    part[q][c] = acc;
+    __syncthreads();
+    if (q == 0 && n < g.N) g.C[n] = part[0][c] + part[1][c] + part[2][c] + part[3][c];
+    return;
+  }
   const int nwg = g.tiles_m * g.tiles_n;
   gemm_body<false, false, 2, BK, VEC>(g, rem % nwg, rem / nwg);
 }
@@ -559,22 +581,31 @@ __device__ __forceinline__ void mlp_finalize_body(const float *__restrict__ Gpar
                                                   const int32_t *__restrict__ gamma_idx,
                                                   const int32_t *__restrict__ beta_idx, float inv,
                                                   float *__restrict__ Gflat, int64_t K, int64_t N, int64_t k,
-                                                  bool store_affine, float *red_g, float *red_d) {
+                                                  bool store_affine, float *red_g, float *red_d,
+                                                  const float *__restrict__ db_sum = nullptr) {
   // thread (nx, zq): column nx (+ j*NT), splits zq, zq+ZQ, ...; the ZQ partial sums are combined in fixed order
   const int NT = N >= 256 ? 256 : (N > 128 ? 256 : (N > 64 ? 128 : (N > 32 ? 64 : (N > 16 ? 32 : 16))));
   const int ZQ = 256 / NT;
   const int nx = threadIdx.x % NT, zq = threadIdx.x / NT;
-  const int64_t split_stride = (K + 1) * N;
+  const int64_t split_stride = (db_sum ? K : K + 1) * N;   // db_sum: no ones row in the partials
   const float *W = P + w_off;
   float acc_s = 0.f, acc_t = 0.f;
   for (int64_t n0 = 0; n0 < N; n0 += NT) {
     const int64_t n = n0 + nx;
     float gk = 0.f, db = 0.f;
     if (n < N) {
+      if (db_sum) {          // bias gradient already summed (wd_mlp_layer_t.db_sum): the partials hold K rows
+        if (k < K) {
 #pragma unroll 4
-      for (int32_t z = zq; z < nsplit; z += ZQ) {
-        gk += Gpart[z * split_stride + k * N + n];
-        db += Gpart[z * split_stride + K * N + n];
+          for (int32_t z = zq; z < nsplit; z += ZQ) gk += Gpart[z * split_stride + k * N + n];
+        }
+        if (zq == 0) db = db_sum[n];
+      } else {
+#pragma unroll 4
+        for (int32_t z = zq; z < nsplit; z += ZQ) {
+          gk += Gpart[z * split_stride + k * N + n];
+          db += Gpart[z * split_stride + K * N + n];
+        }
       }
     }
     if (ZQ > 1) {
@@ -646,7 +677,7 @@ k_mlp_finalize_all(const wd_mlp_layer_t *__restrict__ layers, const float *__res
   const wd_mlp_layer_t L = layers[blockIdx.y];
   if ((int64_t)blockIdx.x > L.K) return;
   mlp_finalize_body(L.Gpart, L.nsplit, P, L.w_off, L.b_off, L.s, L.t, L.gamma_idx, L.beta_idx, inv, Gflat, L.K, L.N,
-                    blockIdx.x, true, red_g, red_d);
+                    blockIdx.x, true, red_g, red_d, L.db_sum);
 }
 
 // ---- logits layer + head, forward AND backward of that layer in one launch ------------------------
@@ -822,9 +853,18 @@ extern "C" int wd_gemm_tn_splitk_group(const wd_tn_job_t *jobs, int32_t njobs, w
   int total = 0;
   for (int j = 0; j < njobs; ++j) {
     const wd_tn_job_t &q = jobs[j];
+    GemmArgs &g = G.job[j];
+    if (!q.B) {    // column sums
+      WD_REQUIRE(q.A && q.Cpart && q.N > 0 && q.K > 0, "column-sum job: A, Cpart, N, K");
+      g.A = q.A; g.C = q.Cpart; g.lda = q.lda; g.N = q.N; g.K = q.K;
+      G.colsum[j] = 1;
+      G.first[j] = total;
+      G.count[j] = (int)wd::ceil_div(q.N, 64);
+      total += (G.count[j] + 7) / 8 * 8;
+      continue;
+    }
     WD_REQUIRE(q.A && q.B && q.Cpart, "null pointer");
     WD_REQUIRE(q.M > 0 && q.N > 0 && q.K > 0 && q.nsplit > 0, "M, N, K, nsplit must be > 0");
-    GemmArgs &g = G.job[j];
     const int64_t Mo = q.append_ones ? q.M + 1 : q.M;
     g.A = q.A; g.B = q.B; g.C = q.Cpart; g.lda = q.lda; g.ldb = q.ldb; g.ldc = q.N;
     g.M = Mo; g.N = q.N; g.K = q.K;

@@ -163,7 +163,7 @@ __device__ __forceinline__ void stage(const float *__restrict__ in, int K, const
                                       const float *__restrict__ bias, int bias_parts, int act,
                                       const float *__restrict__ a_prev, float *__restrict__ out,
                                       float *__restrict__ g_out, int64_t ld_g, int n_store, int64_t b0, int64_t batch,
-                                      unsigned long long *dbg = nullptr) {
+                                      unsigned long long *dbg = nullptr, float *__restrict__ db_out = nullptr) {
   const int lane = threadIdx.x & 63, wave = uni((int)(threadIdx.x >> 6));
   const int c = lane & 31, h = lane >> 5;
   K = uni(K); N = uni(N);
@@ -192,6 +192,7 @@ __device__ __forceinline__ void stage(const float *__restrict__ in, int K, const
     constexpr bool FULLR = decltype(full_c)::value;
     const int n = n0 + c;
     const int a_id = ACT >= 0 ? ACT : act;
+    float csum = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int m = (r & 3) + 8 * (r >> 2) + 4 * h;
@@ -200,6 +201,11 @@ __device__ __forceinline__ void stage(const float *__restrict__ in, int K, const
       if (MODE == 1) v *= act_bwd(a_prev[n * P + m], a_id);
       if (MODE != 2) out[n * P + m] = v;
       if ((FULLR || b0 + m < batch) && n < n_store) g_out[(b0 + m) * ld_g + n] = v;
+      if (MODE == 1) csum += v;
+    }
+    if (MODE == 1 && db_out) {   // bias-gradient partial of this tile: column sum over its 32 rows (rows >= batch are 0)
+      csum += __shfl_xor(csum, 32, 64);
+      if (h == 0) db_out[n] = csum;
     }
   };
   auto epilogue = [&](const floatx16 &acc, int n0, float bv) {
@@ -444,14 +450,29 @@ __global__ void __launch_bounds__(256) k_tower_chain(ChainArgs g) {
     const int KT = K < 256 ? K : 256;   // lanes along n: coalesced HBM rows, conflict-free LDS
     const int MQ = 256 / KT;            // K < 256: several example groups in parallel
     const int nq = t % KT, mq = t / KT;
+    float *dbp = g.layer[L - 1].db_part ? g.layer[L - 1].db_part + (int64_t)blockIdx.x * K : nullptr;
     if (mq < MQ) {
       for (int n = nq; n < K; n += KT) {
         const float w = swl[n];
+        float csum = 0.f;
         for (int m = mq; m < RT; m += MQ) {
           const float v = sdl[m] * w * act_bwd(in[n * P + m], g.act);
           dz[n * P + m] = v;
           if (b0 + m < g.batch) gdz[(b0 + m) * K + n] = v;
+          csum += v;
         }
+        if (dbp) {
+          if (MQ == 1) dbp[n] = csum;
+          else red[mq * KT + n] = csum;     // K < 256: MQ * KT == 256 partial sums, combined below in group order
+        }
+      }
+    }
+    if (dbp && MQ > 1) {
+      __syncthreads();
+      if (t < K) {
+        float v = red[t];
+        for (int j = 1; j < MQ; ++j) v += red[j * KT + t];
+        dbp[t] = v;
       }
     }
     if (Gp) {
@@ -476,7 +497,7 @@ __global__ void __launch_bounds__(256) k_tower_chain(ChainArgs g) {
     const wd_chain_layer_t &ly = g.layer[l];
     const wd_chain_layer_t &lp = g.layer[l - 1];
     stage<1>(lds + g.dz_off[l], ly.N, ly.WTpk, lp.N, nullptr, 0, g.act, lds + g.a_off[l - 1], lds + g.dz_off[l - 1],
-             lp.dz_out, lp.N, lp.N, b0, g.batch);
+             lp.dz_out, lp.N, lp.N, b0, g.batch, nullptr, lp.db_part ? lp.db_part + (int64_t)blockIdx.x * lp.N : nullptr);
     __syncthreads();
     stamp();
   }

@@ -255,6 +255,8 @@ class WideDeepEngine:
                     d.Gpart, d.nsplit = tw["Gpart"][l].data_ptr(), tw["nsplit"][l]
                     if self.chain and l < tw["L"]:
                         d.Wpk, d.WTpk = tw["Wpk"][l].data_ptr(), tw["WTpk"][l].data_ptr()
+                        if not self._tn_ones:
+                            d.db_sum = tw["db_sum"][l].data_ptr()
                     if self.half:
                         d.cat_off, d.wcat = tw["cat_off"][l].data_ptr(), tw["wcat"].data_ptr()
                         if l < tw["L"]:
@@ -324,6 +326,7 @@ class WideDeepEngine:
         """One-launch tower (wd_tower_chain, csrc/mlp_chain.hip): exact-fp32 `simple` towers whose widths are multiples
         of 32 and whose row tile fits the LDS.  WD_CHAIN=0 keeps the per-layer GEMM launches."""
         self.chain = False
+        self._tn_ones = os.environ.get("WD_TN_ONES", "0") == "1"   # A/B switch: bias gradients via an appended ones row
         plan = self.plan
         if self.half or self.dropout or len(self.towers) != 1 or os.environ.get("WD_CHAIN", "1") == "0":
             return
@@ -341,6 +344,11 @@ class WideDeepEngine:
         tw["Wpk"] = [torch.zeros(metas[l]["N"] * metas[l]["K"], **f32) for l in range(L)]
         tw["WTpk"] = [torch.zeros(metas[l]["N"] * metas[l]["K"], **f32) for l in range(L)]
         tw["dzl"] = [torch.zeros(B * metas[l]["N"], **f32) for l in range(L)]
+        # bias gradients: per-row-tile column sums of dz from the tower kernel, reduced by a column-sum job of the grouped
+        # weight-gradient launch -- the products then need no appended ones row (449 = 7 x 64 + 1 rows cost an 8th tile row)
+        ntile = int(call("wd_tower_chain_blocks", B))
+        tw["db_part"] = [torch.zeros(ntile * metas[l]["N"], **f32) for l in range(L)]
+        tw["db_sum"] = [torch.zeros(metas[l]["N"], **f32) for l in range(L)]
         # logits-layer gradient partials: one per 32-example row tile
         ns = int(call("wd_tower_chain_blocks", B))
         tw["nsplit"][L] = ns
@@ -351,6 +359,7 @@ class WideDeepEngine:
             c.Wpk, c.WTpk, c.bf = tw["Wpk"][l].data_ptr(), tw["WTpk"][l].data_ptr(), tw["bf"][l].data_ptr()
             c.a_out = tw["act"].data_ptr() + 4 * tl.seg_start[l + 1]
             c.dz_out = tw["dzl"][l].data_ptr()
+            c.db_part = tw["db_part"][l].data_ptr()
             c.K, c.N = int(metas[l]["K"]), dims[l]
         tw["chain_layers"] = carr
         # gradient columns of x that anyone reads: the embedding columns (the sparse backward), rounded up by the kernel
@@ -612,21 +621,22 @@ class WideDeepEngine:
         tl, metas, L = tw["layout"], tw["metas"], tw["L"]
         act, dact = tw["act"], tw["dact"]
         if self.chain:
-            # forward() already ran the input-gradient chain; what is left are the batch reductions G_l = [a_{l-1}|1]^T dz_l
-            if L <= capi.WD_TN_GROUP_MAX:
-                jobs = (capi.WdTnJob * L)()
+            # forward() already ran the input-gradient chain; what is left are the batch reductions G_l = a_{l-1}^T dz_l
+            # (one grouped launch) and the sums of the per-tile bias-gradient partials (column-sum jobs of the same launch)
+            if 2 * L <= capi.WD_TN_GROUP_MAX:
+                jobs = (capi.WdTnJob * (2 * L))()
+                nblk = int(call("wd_tower_chain_blocks", B))
                 for l in range(L):    # largest product first: its workgroups start while the small ones fill the gaps
                     m, j = metas[l], jobs[l]
                     j.A, j.lda = act.data_ptr() + 4 * tl.in_start[l], tl.ld
                     j.B, j.ldb, j.Cpart = tw["dzl"][l].data_ptr(), m["N"], tw["Gpart"][l].data_ptr()
-                    j.M, j.N, j.K, j.nsplit, j.append_ones = m["K"], m["N"], B, tw["nsplit"][l], 1
-                call("wd_gemm_tn_splitk_group", jobs, L, st)
+                    j.M, j.N, j.K, j.nsplit, j.append_ones = m["K"], m["N"], B, tw["nsplit"][l], int(self._tn_ones)
+                    c = jobs[L + l]    # bias gradient: column sums of the tower kernel's per-tile partials
+                    c.A, c.lda, c.B, c.Cpart = tw["db_part"][l].data_ptr(), m["N"], None, tw["db_sum"][l].data_ptr()
+                    c.N, c.K = m["N"], nblk
+                call("wd_gemm_tn_splitk_group", jobs, L if self._tn_ones else 2 * L, st)
                 return
-            for l in range(L - 1, -1, -1):
-                m = metas[l]
-                call("wd_gemm_tn_splitk", act.data_ptr() + 4 * tl.in_start[l], tl.ld, ptr(tw["dzl"][l]), m["N"],
-                     ptr(tw["Gpart"][l]), m["K"], m["N"], B, tw["nsplit"][l], 1, st)
-            return
+            raise NotImplementedError("one-launch tower with more than %d hidden layers" % (capi.WD_TN_GROUP_MAX // 2))
         simple = tl.mode == "simple" and not self.dropout   # dropout: act' is not fused into the GEMM epilogues
         acc = 0 if tl.mode == "simple" else 1               # simple: every segment has ONE consumer -> plain stores
         if not head_done:

@@ -363,6 +363,11 @@ int wd_fold_affine_all(const float *P, const wd_mlp_layer_t *layers_dev, int32_t
  * layer (connected_mode `simple`): the affine gradients are then stored, not accumulated, and Gflat needs no zeroing. */
 int wd_mlp_finalize_all(const wd_mlp_layer_t *layers_dev, int32_t nlayers, int64_t max_k, const float *P, float inv,
                         float *Gflat, wd_stream_t stream);
+/* wd_mlp_finalize_all + wd_adagrad_dense in one launch: every parameter is updated (accum += g^2; w -= lr g / sqrt(accum))
+ * where its gradient becomes final; Gflat is still written.  Only when nothing sits between the two (single GPU: no
+ * all-reduce of Gflat) and the dnn optimizer is Adagrad. */
+int wd_mlp_finalize_adagrad_all(const wd_mlp_layer_t *layers_dev, int32_t nlayers, int64_t max_k, float *P, float *Pacc,
+                                float inv, float *Gflat, float lr, wd_stream_t stream);
 
 /* ---- logits layer + head fused (python/lib/dnn.py:226-232, python/lib/joint.py:216-222,264-269) ----
  * dnn_logit[b] = a[b, 0..K) . wf + sum(bf parts); logit = dnn_logit + wide_logit (may be NULL); sigmoid CE SUM into

@@ -141,6 +141,7 @@ _PROTOS = {
     "wd_gemm_tn_splitk": [P, I64, P, I64, P, I64, I64, I64, I32, I32, P],
     "wd_fold_affine_all": [P, P, I32, I64, F32, P, I64, P, I64, P],
     "wd_mlp_finalize_all": [P, I32, I64, P, F32, P, P],
+    "wd_mlp_finalize_adagrad_all": [P, I32, I64, P, P, F32, P, F32, P],
     "wd_logits_head_blocks": [I64, I64],
     "wd_gemm_tn_splitk_group": [P, I32, P],
     "wd_sparse_apply_opt": [P, P, P, P, P, P, I32, P, I64, P, I64, P, I64, P, P, P, P, I32, P, P],

@@ -576,13 +576,24 @@ __global__ void k_counter_tick(int64_t *c) { c[1] += 1; }
 // consumer (simple mode) -> plain store; otherwise accumulate (launches are stream-ordered and k is unique
 // within a launch, so no atomics are needed).
 __device__ __forceinline__ void mlp_finalize_body(const float *__restrict__ Gpart, int32_t nsplit,
-                                                  const float *__restrict__ P, int64_t w_off, int64_t b_off,
+                                                  const float *P /* may alias Pw */, int64_t w_off, int64_t b_off,
                                                   const float *__restrict__ s, const float *__restrict__ t,
                                                   const int32_t *__restrict__ gamma_idx,
                                                   const int32_t *__restrict__ beta_idx, float inv,
                                                   float *__restrict__ Gflat, int64_t K, int64_t N, int64_t k,
                                                   bool store_affine, float *red_g, float *red_d,
-                                                  const float *__restrict__ db_sum = nullptr) {
+                                                  const float *__restrict__ db_sum = nullptr,
+                                                  float *Pw = nullptr, float *__restrict__ Pacc = nullptr,
+                                                  float lr = 0.f) {
+  // Pw / Pacc: apply dense Adagrad to every parameter right where its gradient is final (single-GPU default
+  // optimizer: saves the separate elementwise launch).  W is read before it is updated by the same lane.
+  auto apply = [&](int64_t idx, float gval) {
+    if (Pacc) {
+      const float a = Pacc[idx] + gval * gval;
+      Pacc[idx] = a;
+      Pw[idx] -= lr * gval / sqrtf(a);
+    }
+  };
   // thread (nx, zq): column nx (+ j*NT), splits zq, zq+ZQ, ...; the ZQ partial sums are combined in fixed order
   const int NT = N >= 256 ? 256 : (N > 128 ? 256 : (N > 64 ? 128 : (N > 32 ? 64 : (N > 16 ? 32 : 16))));
   const int ZQ = 256 / NT;
@@ -623,11 +634,14 @@ __device__ __forceinline__ void mlp_finalize_body(const float *__restrict__ Gpar
     if (zq == 0 && n < N) {
       if (k == K) {
         Gflat[b_off + n] = db;
+        apply(b_off + n, db);
       } else {
-        Gflat[w_off + k * N + n] = s[k] * gk + t[k] * db;
+        const float gw = s[k] * gk + t[k] * db;
+        Gflat[w_off + k * N + n] = gw;
         const float w = W[k * N + n];
         acc_s += w * gk;
         acc_t += w * db;
+        apply(w_off + k * N + n, gw);
       }
     }
   }
@@ -650,8 +664,8 @@ __device__ __forceinline__ void mlp_finalize_body(const float *__restrict__ Gpar
     const float ss = red_g[0] + red_g[1] + red_g[2] + red_g[3];
     const float tt = red_d[0] + red_d[1] + red_d[2] + red_d[3];
     if (store_affine) {
-      if (gi >= 0) Gflat[gi] = ss * inv;
-      if (bi >= 0) Gflat[bi] = tt;
+      if (gi >= 0) { Gflat[gi] = ss * inv; apply(gi, ss * inv); }
+      if (bi >= 0) { Gflat[bi] = tt; apply(bi, tt); }
     } else {
       if (gi >= 0) Gflat[gi] += ss * inv;
       if (bi >= 0) Gflat[bi] += tt;
@@ -671,13 +685,13 @@ k_mlp_finalize(const float *__restrict__ Gpart, int32_t nsplit, const float *__r
 
 // all layers in one launch (blockIdx.y = layer): legal only when every BN gamma/beta has ONE consumer layer
 __global__ void __launch_bounds__(256)
-k_mlp_finalize_all(const wd_mlp_layer_t *__restrict__ layers, const float *__restrict__ P, float inv,
-                   float *__restrict__ Gflat) {
+k_mlp_finalize_all(const wd_mlp_layer_t *__restrict__ layers, const float *P, float inv, float *__restrict__ Gflat,
+                   float *Pw, float *__restrict__ Pacc, float lr) {
   __shared__ float red_g[256], red_d[256];
   const wd_mlp_layer_t L = layers[blockIdx.y];
   if ((int64_t)blockIdx.x > L.K) return;
   mlp_finalize_body(L.Gpart, L.nsplit, P, L.w_off, L.b_off, L.s, L.t, L.gamma_idx, L.beta_idx, inv, Gflat, L.K, L.N,
-                    blockIdx.x, true, red_g, red_d, L.db_sum);
+                    blockIdx.x, true, red_g, red_d, L.db_sum, Pw, Pacc, lr);
 }
 
 // ---- logits layer + head, forward AND backward of that layer in one launch ------------------------
@@ -967,8 +981,17 @@ extern "C" int wd_mlp_finalize_all(const wd_mlp_layer_t *layers_dev, int32_t nla
   WD_REQUIRE(P && layers_dev && Gflat, "null pointer");
   WD_REQUIRE(nlayers > 0 && max_k > 0, "nlayers, max_k must be > 0");
   hipLaunchKernelGGL(k_mlp_finalize_all, dim3((unsigned)(max_k + 1), (unsigned)nlayers), dim3(256), 0,
-                     wd::as_stream(stream), layers_dev, P, inv, Gflat);
+                     wd::as_stream(stream), layers_dev, P, inv, Gflat, (float *)nullptr, (float *)nullptr, 0.f);
   return wd::check_launch("wd_mlp_finalize_all");
+}
+
+extern "C" int wd_mlp_finalize_adagrad_all(const wd_mlp_layer_t *layers_dev, int32_t nlayers, int64_t max_k, float *P,
+                                           float *Pacc, float inv, float *Gflat, float lr, wd_stream_t stream) {
+  WD_REQUIRE(P && Pacc && layers_dev && Gflat, "null pointer");
+  WD_REQUIRE(nlayers > 0 && max_k > 0, "nlayers, max_k must be > 0");
+  hipLaunchKernelGGL(k_mlp_finalize_all, dim3((unsigned)(max_k + 1), (unsigned)nlayers), dim3(256), 0,
+                     wd::as_stream(stream), layers_dev, P, inv, Gflat, P, Pacc, lr);
+  return wd::check_launch("wd_mlp_finalize_adagrad_all");
 }
 
 extern "C" int64_t wd_logits_head_blocks(int64_t batch, int64_t K) { return wd::ceil_div(batch, head_chunk(K)); }

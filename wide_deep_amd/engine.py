@@ -840,11 +840,19 @@ class WideDeepEngine:
             head_done = len(self.towers) == 1
             for tw in self.towers:
                 self._tower_backward(tw, B, st, need_dx=has_emb, head_done=head_done)
+            fused_opt = False
             if self.all_simple:
                 if not head_done:
                     raise NotImplementedError("multi-tower + all-layer finalize")  # guarded in __init__
-                call("wd_mlp_finalize_all", ptr(self.layers_dev), self.n_layers, self.max_layer_k, ptr(self.P), self.inv,
-                     ptr(self.G), st)
+                # single GPU + Adagrad: the dense update rides in the finalize launch (nothing reduces G in between)
+                fused_opt = (self.default_opts and type(self)._reduce_dense_grads is WideDeepEngine._reduce_dense_grads
+                             and os.environ.get("WD_FUSE_ADAGRAD", "1") != "0")
+                if fused_opt:
+                    call("wd_mlp_finalize_adagrad_all", ptr(self.layers_dev), self.n_layers, self.max_layer_k, ptr(self.P),
+                         ptr(self.Pacc), self.inv, ptr(self.G), float(spec.dnn_opt[1]), st)
+                else:
+                    call("wd_mlp_finalize_all", ptr(self.layers_dev), self.n_layers, self.max_layer_k, ptr(self.P),
+                         self.inv, ptr(self.G), st)
             for tw in self.towers:        # first_dense: gradient of x = sum over its copies
                 tl = tw["layout"]
                 if has_emb and tl.x_copies:
@@ -861,7 +869,9 @@ class WideDeepEngine:
                     tl = tw["layout"]
                     dx0.add_(tw["dact"][:B, tl.seg_start[0]: tl.seg_start[0] + w0])
             self._reduce_dense_grads()
-            if self.default_opts:
+            if fused_opt:
+                pass
+            elif self.default_opts:
                 call("wd_adagrad_dense", ptr(self.P), ptr(self.Pacc), ptr(self.G), self.P.numel(), float(spec.dnn_opt[1]),
                      st)
             else:

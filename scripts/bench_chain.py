@@ -36,19 +36,21 @@ def timeit(fn):
 
 
 fl_f = 2.0 * B * sum(m["K"] * m["N"] for m in tw["metas"][:-1])
+fuse = os.environ.get("CHAIN_FUSE", "1") == "1" and eng._chain_input_ok(bt)    # input layer built inside the kernel
+fused = timeit(lambda: eng._tower_chain(tw, bt, B, st, True, fuse)) if fuse else float("nan")
 full = timeit(lambda: eng._tower_chain(tw, bt, B, st, True))
 dxc = tw["dx_cols"]
 tw["dx_cols"] = 0
 nodx = timeit(lambda: eng._tower_chain(tw, bt, B, st, True))
 tw["dx_cols"] = dxc
 fwd = timeit(lambda: eng._tower_chain(tw, bt, B, st, False))
-print("chain B=%d hidden=%s: full %.1f us, no dx %.1f us, forward only %.1f us (forward GEMM flops %.2f G)" % (
-    B, hidden, full, nodx, fwd, fl_f / 1e9))
+print("chain B=%d hidden=%s: with fused input layer %.1f us | x from HBM: full %.1f us, no dx %.1f us, forward only %.1f us "
+      "(forward GEMM flops %.2f G)" % (B, hidden, fused, full, nodx, fwd, fl_f / 1e9))
 
 from wide_deep_amd.capi import call
 stamps = torch.zeros(64, dtype=torch.int64, device="cuda")
 call("wd_tower_chain_set_stamps", stamps.data_ptr())
-eng._tower_chain(tw, bt, B, st, True)
+eng._tower_chain(tw, bt, B, st, True, fuse)
 torch.cuda.synchronize()
 call("wd_tower_chain_set_stamps", None)
 names = ["x tile"] + ["F%d" % l for l in range(len(hidden))] + ["head"] + ["B%d" % l for l in range(len(hidden) - 1, 0, -1)] + ["dx"]

@@ -420,7 +420,12 @@ typedef struct wd_chain_input {
   const wd_dense_col_t *cols;
   float *x_out;                    /* [batch][ld_act] */
   int64_t ld_dense;
-  int32_t S, slot0, ngroup, dim, ncols, pad_;
+  int32_t S, slot0, ngroup, dim, ncols;
+  /* rows that arrived through the exchange instead of the tables (sharded engine): ids = positions in a buffer whose
+   * rows are row_stride floats apart (0: dim; slots then carry emb_off 0) and -- wide_in_row != 0 -- hold their wide
+   * weight at [dim] (`wide` = the same buffer) */
+  int32_t row_stride;
+  int32_t wide_in_row, pad_;
 } wd_chain_input_t;
 int wd_tower_chain_input(const wd_chain_input_t *in);
 int64_t wd_tower_chain_lds_bytes(int32_t K0, const int32_t *N, int32_t L);   /* -1: unsupported shape */

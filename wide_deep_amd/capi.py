@@ -70,7 +70,8 @@ class WdChainInput(ctypes.Structure):
         ("emb", ctypes.c_void_p), ("slots", ctypes.c_void_p), ("ids", ctypes.c_void_p), ("wide", ctypes.c_void_p),
         ("wide_bias", ctypes.c_void_p), ("wide_out", ctypes.c_void_p), ("dense", ctypes.c_void_p), ("cols", ctypes.c_void_p),
         ("x_out", ctypes.c_void_p), ("ld_dense", ctypes.c_int64), ("S", ctypes.c_int32), ("slot0", ctypes.c_int32),
-        ("ngroup", ctypes.c_int32), ("dim", ctypes.c_int32), ("ncols", ctypes.c_int32), ("pad_", ctypes.c_int32),
+        ("ngroup", ctypes.c_int32), ("dim", ctypes.c_int32), ("ncols", ctypes.c_int32), ("row_stride", ctypes.c_int32),
+        ("wide_in_row", ctypes.c_int32), ("pad_", ctypes.c_int32),
     ]
 
 

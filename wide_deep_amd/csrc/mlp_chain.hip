@@ -279,6 +279,7 @@ __global__ void __launch_bounds__(256) k_tower_chain(ChainArgs g) {
     // rows per workgroup (C2): ids first (coalesced), then every row / wide line load of the tile in flight at once.
     const wd_chain_input_t &I = g.in;
     const int S = uni(I.S), NG = uni(I.ngroup), D = uni(I.dim), LG = D >> 2;
+    const int RS_ = uni(I.row_stride > 0 ? I.row_stride : I.dim);   // floats between rows (exchange buffers: dim + 4)
     int32_t *s_id = reinterpret_cast<int32_t *>(lds + g.a_off[0]);   // a_0's region is dead until layer 0 writes it
     float *s_w = lds + g.a_off[0] + RT * S;                          // wide weight per (example, slot)
     for (int i = t; i < S; i += 256) {                               // slot descriptors -> LDS (48-byte structs in HBM)
@@ -315,7 +316,7 @@ __global__ void __launch_bounds__(256) k_tower_chain(ChainArgs g) {
           mm[q] = m;
           col[q] = s_ocol[sidx] + 4 * lg;
           hit[q] = id >= 0;
-          if (id >= 0) r[q] = __builtin_nontemporal_load(reinterpret_cast<const floatx4v *>(I.emb + s_eoff[sidx] + (int64_t)id * D) + lg);
+          if (id >= 0) r[q] = __builtin_nontemporal_load(reinterpret_cast<const floatx4v *>(I.emb + s_eoff[sidx] + (int64_t)id * RS_) + lg);
         }
       }
 #pragma unroll
@@ -334,7 +335,9 @@ __global__ void __launch_bounds__(256) k_tower_chain(ChainArgs g) {
       for (int i = t; i < nbag; i += 256) {
         const int64_t rb = s_rbase[i % S];
         const int id = s_id[i];
-        if (rb >= 0 && id >= 0) s_w[i] = I.wide[(rb + id) * 4];
+        if (rb >= 0 && id >= 0)
+          s_w[i] = I.wide_in_row ? I.wide[s_eoff[i % S] + (int64_t)id * RS_ + D]     // weight travels behind its row
+                                 : I.wide[(rb + id) * 4];
       }
     }
     for (int i = t; i < RT * I.ncols; i += 256) {
@@ -554,6 +557,8 @@ extern "C" int wd_tower_chain_input(const wd_chain_input_t *in) {
              "bad slot range (S <= WD_CHAIN_MAX_SLOTS)");
   WD_REQUIRE(in->ncols == 0 || (in->dense && in->cols), "numeric columns need dense + descriptors");
   WD_REQUIRE(!in->wide || in->wide_bias, "wide needs its bias");
+  WD_REQUIRE(in->row_stride == 0 || (in->row_stride >= in->dim && in->row_stride % 4 == 0), "row_stride: 0 or >= dim, multiple of 4");
+  WD_REQUIRE(!in->wide_in_row || in->row_stride > in->dim, "wide_in_row needs row_stride > dim");
   g_input = *in;
   return WD_OK;
 }

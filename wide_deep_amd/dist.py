@@ -281,6 +281,23 @@ class ShardedWideDeepEngine(WideDeepEngine):
 
     # ---- overrides ------------------------------------------------------------------------------
     def _sparse_forward(self, bt: DeviceBatch, st):
+        self._sparse_exchange(bt, st)
+        self._pool(bt, st)
+
+    def _chain_input_ok(self, bt):
+        # the tower kernel pools the received rows itself: embedding rows + wide weight travel together (needs both)
+        return super()._chain_input_ok(bt) and self.n_emb_slots > 0 and self.n_emb_slots == self.plan.S
+
+    def _chain_input(self, bt, tw):
+        """x tile from the rows that came back through the exchange: `pos` indexes fwd_recv (row stride RS)."""
+        ci = super()._chain_input(bt, tw)
+        ci.emb, ci.slots, ci.ids = ptr(self.fwd_recv), ptr(self.xslots_dev), ptr(self.pos)
+        ci.row_stride = self.RS
+        if self.spec.has_wide:
+            ci.wide, ci.wide_in_row = ptr(self.fwd_recv), 1
+        return ci
+
+    def _sparse_exchange(self, bt: DeviceBatch, st):
         lp, spec = self.plan, self.spec
         B, S, W = bt.B, lp.S, self.world
         has_emb = self.n_emb_slots > 0
@@ -301,6 +318,12 @@ class ShardedWideDeepEngine(WideDeepEngine):
                  self.n_req, ptr(self.bucket_cnt), ptr(self.bucket_start), ptr(self.occ_rank), ptr(self.pairs),
                  self.n_buckets, side.cuda_stream)
             self._bucketized = True
+
+    def _pool(self, bt: DeviceBatch, st):
+        """Requester side of the forward: pool the received rows into x, numeric columns, wide logit."""
+        lp, spec = self.plan, self.spec
+        B, S = bt.B, lp.S
+        has_emb = self.n_emb_slots > 0
         if spec.has_deep:
             tw0 = self.towers[0]
             ld = tw0["layout"].ld

@@ -375,32 +375,39 @@ class WideDeepEngine:
         one embedding group, no indicator columns -- the Criteo shape.  WD_CHAIN_INPUT=0 keeps wd_input_layer_fwd."""
         if not (self.spec.has_deep and self.chain and self._fused_input_layer and bt.one_hot):
             return False
-        if type(self)._sparse_forward is not WideDeepEngine._sparse_forward or os.environ.get("WD_CHAIN_INPUT", "1") == "0":
+        if os.environ.get("WD_CHAIN_INPUT", "1") == "0":
             return False
         (dim, sl), = self.plan.emb_groups.items()
         n0 = self.towers[0]["metas"][0]["N"]
         return (self.plan.S <= capi.WD_CHAIN_MAX_SLOTS and dim % 4 == 0 and 256 % (dim // 4) == 0
                 and 2 * 32 * self.plan.S <= 33 * n0)
 
+    def _sparse_exchange(self, bt, st):
+        """Hook: what has to happen before the tower kernel can build its own x tile (dist.py: the row exchange)."""
+
+    def _chain_input(self, bt, tw):
+        """wd_chain_input_t of this batch: ids index the tables directly."""
+        plan, spec = self.plan, self.spec
+        (dim, sl), = plan.emb_groups.items()
+        nd = len(plan.dense_cols)
+        ci = capi.WdChainInput()
+        ci.emb, ci.slots, ci.ids = ptr(self.emb), ptr(self.slots_dev), ptr(bt.ids)
+        ci.wide = ptr(self.wide) if spec.has_wide else None
+        ci.wide_bias = ptr(self.bias) if spec.has_wide else None
+        ci.wide_out = ptr(self.wide_logit) if spec.has_wide else None
+        ci.dense = ptr(bt.dense) if nd else None
+        ci.cols = ptr(self.dense_cols_dev) if nd else None
+        ci.x_out = self._x_ptr(tw)
+        ci.ld_dense = bt.dense.stride(0) if nd else 0
+        ci.S, ci.slot0, ci.ngroup, ci.dim, ci.ncols = plan.S, sl[0], len(sl), dim, nd
+        return ci
+
     def _tower_chain(self, tw, bt, B, st, train, fuse_in=False):
         tl, metas, L = tw["layout"], tw["metas"], tw["L"]
         has_emb = bool(self.group_slots)
         need_dx = train and has_emb and tw["dx_cols"] > 0
         if fuse_in:
-            plan, spec = self.plan, self.spec
-            (dim, sl), = plan.emb_groups.items()
-            nd = len(plan.dense_cols)
-            ci = capi.WdChainInput()
-            ci.emb, ci.slots, ci.ids = ptr(self.emb), ptr(self.slots_dev), ptr(bt.ids)
-            ci.wide = ptr(self.wide) if spec.has_wide else None
-            ci.wide_bias = ptr(self.bias) if spec.has_wide else None
-            ci.wide_out = ptr(self.wide_logit) if spec.has_wide else None
-            ci.dense = ptr(bt.dense) if nd else None
-            ci.cols = ptr(self.dense_cols_dev) if nd else None
-            ci.x_out = self._x_ptr(tw)
-            ci.ld_dense = bt.dense.stride(0) if nd else 0
-            ci.S, ci.slot0, ci.ngroup, ci.dim, ci.ncols = plan.S, sl[0], len(sl), dim, nd
-            call("wd_tower_chain_input", ctypes.byref(ci))
+            call("wd_tower_chain_input", ctypes.byref(self._chain_input(bt, tw)))
         call("wd_tower_chain", tw["act"].data_ptr() + 4 * tl.in_start[0], tl.ld, int(metas[0]["K"]), tw["chain_layers"], L,
              self.act_id, capi.WD_FOLD_PARTS, ptr(tw["Wf"][L]), ptr(tw["bf"][L]),
              None if fuse_in else ptr(self.wide_logit),
@@ -498,7 +505,9 @@ class WideDeepEngine:
         B = bt.B
         train = bt.labels is not None and need_loss
         fuse_in = self._chain_input_ok(bt)
-        if not fuse_in:
+        if fuse_in:
+            self._sparse_exchange(bt, st)       # rows that have to travel first (sharded engine); nothing on one GPU
+        else:
             self._sparse_forward(bt, st)
         if spec.has_deep:
             # one launch: fold the BN affines of every layer into its consumer's weights; clear loss (+ G when the

@@ -191,7 +191,8 @@ int wd_bias_ftrl(float *bias_wzn, const float *dlogit, int64_t batch, float lr, 
  * one workgroup in LDS (single-row buckets need no sort), duplicates are summed in ascending bag order and Adagrad
  * (embedding rows, lr_emb) / FTRL (wide rows and bias_wzn, lr_wide, l1, l2) are applied in the same kernel.
  * emb / wide / bias_wzn may be NULL (deep-only / wide-only).  Workspaces (caller-owned, no initialisation needed):
- * bucket_cnt[(2 * wd_bucket_chunks() + 1) * nbuckets], bucket_start[nbuckets + 1], rank[nnz], pairs[nnz] (uint64).
+ * bucket_cnt[(2 * wd_bucket_chunks() + 1) * nbuckets], bucket_start[2 * nbuckets + 2] (bucket starts, then the order in
+ * which the update kernel takes the buckets: largest first), rank[nnz], pairs[nnz] (uint64).
  * nbuckets = sum over slots of ceil(num_buckets / 2^bucket_shift) <= wd_bucket_max().  dlogit of example b is dlogit[b * ld_dlogit]; ids < 0
  * are padding and are skipped; an embedding slot updates only keys below row_base + num_buckets. */
 int32_t wd_bucket_max(void);

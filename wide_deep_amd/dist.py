@@ -247,7 +247,7 @@ class ShardedWideDeepEngine(WideDeepEngine):
         osh, _, self.n_buckets = bucket_geometry([max(lp.total_rows, 1)], self.n_req, int(call("wd_bucket_max")),
                                                  float(os.environ.get("WD_BUCKET_TARGET", "64")))
         self.bucket_cnt = torch.zeros((2 * int(call("wd_bucket_chunks")) + 1) * self.n_buckets, **i32)
-        self.bucket_start = torch.zeros(self.n_buckets + 2, **i32)
+        self.bucket_start = torch.zeros(2 * self.n_buckets + 2, **i32)   # starts [nb+1] + launch order [nb]
         self.oslot_dev = make_slots([dict(emb_off=0, row_base=0, num_buckets=max(self.n_emb_rows, 1), dim=self.dim,
                                           out_col=0, kind=capi.SLOT_EMBEDDING if has_emb else capi.SLOT_NONE, wide=1,
                                           bucket_shift=osh[0], bucket_base=0)])

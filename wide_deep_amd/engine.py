@@ -295,7 +295,7 @@ class WideDeepEngine:
         self.sort_ws_bytes = max(qs)
         self.sort_ws = torch.zeros(self.sort_ws_bytes, dtype=torch.uint8, device=dev)
         self.bucket_cnt = torch.zeros((2 * int(call("wd_bucket_chunks")) + 1) * self.n_buckets, **i32)
-        self.bucket_start = torch.zeros(self.n_buckets + 2, **i32)
+        self.bucket_start = torch.zeros(2 * self.n_buckets + 2, **i32)   # starts [nb+1] + launch order [nb]
         self.occ_rank = torch.zeros(M, **i32)
         self.pairs = torch.zeros(M, dtype=torch.int64, device=dev)
         self._graph = None

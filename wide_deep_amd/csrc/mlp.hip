@@ -17,10 +17,11 @@
 //   NN  a_l   = act(a_{l-1} Wf + bf)            A: reduction-contiguous (RC), B: output-contiguous (OC)
 //   NT  da_{l-1} (+)= dz_l Wf^T                 A: RC, B: RC
 //   TN  G     = [a_{l-1} | 1]^T dz_l  (split-K) A: OC, B: OC   (the appended ones row yields db)
-// Tile 64x64x16, 4 waves (2x2) each owning one 32x32 accumulator; LDS tiles are reduction-major so
-// the MFMA fragment reads are conflict-free ds_read_b32 rows; global->register prefetch of the next
-// tile overlaps the 8 MFMAs of the current one; workgroup ids are remapped so the N-tiles that
-// re-read one A row-panel run on the same XCD (shared L2).
+// Tile 64x64, 64-deep slabs double-buffered in LDS, 4 waves (2x2) each owning one 32x32 accumulator; LDS tiles are
+// reduction-major so the MFMA fragment reads are conflict-free ds_read_b32 rows; the global loads of slab i+1 stay in
+// flight across the 32 MFMAs of slab i; workgroup ids are remapped so the N-tiles that re-read one A row-panel run on
+// the same XCD (shared L2).  `simple` towers whose widths fit run through mlp_chain.hip instead (one launch for all NN /
+// NT products + head); what they still take from this file: the fold, the grouped TN launch, the finalize.
 #include "common.h"
 
 namespace {

@@ -7,15 +7,18 @@
 // launches (~100-150 us on MI355X) for 1.7 MB of data.  Instead:
 //
 //   K1 k_bucket_hist     occurrence -> bucket = slot.bucket_base + (id >> slot.bucket_shift); each workgroup histograms
-//                        its chunk of bags in LDS with DETERMINISTIC, stable ranks (device-scope returned atomics on
-//                        ~1.6k counters measured 35 us for 2e5 occurrences) and writes its row of the count matrix
+//                        its chunk of bags in LDS (device-scope returned atomics on ~1.6k counters measured 35 us for
+//                        2e5 occurrences) and writes its row of the count matrix; ranks of one-row buckets are
+//                        deterministic (wave ballots), the others are whatever the LDS atomics return
 //   K1b k_bucket_colscan per bucket: exclusive prefix over the chunks (column scan) + bucket totals
 //   K2 k_bucket_scatter  every block scans the totals in LDS (nb <= 8192) and scatters (key << 32 | bag) pairs to
-//                        start[bucket] + chunk_prefix + rank: all occurrences of a row range are now contiguous
+//                        start[bucket] + chunk_prefix + rank: all occurrences of a row range are now contiguous;
+//                        block 0 also lists the buckets largest-first (launch order of K3: Zipf head rows)
 //   K3 k_bucket_update   one workgroup per bucket: sort of the 64-bit pairs in LDS (rank sort up to 512 pairs,
-//                        bitonic up to 1024 pairs; larger buckets sort in place in HBM/L2), then per
-//                        unique row the gradient is reduced in ascending bag order and the Adagrad / FTRL
-//                        update is applied in the same kernel; the extra last workgroup does bias_weights.
+//                        bitonic up to 1024 pairs; larger buckets sort in place in HBM/L2; one-row buckets need no
+//                        sort), then per unique row the gradient is reduced in ascending bag order and the optimizer
+//                        (Adagrad / FTRL specialised; any of wd_opt_t in the GEN instantiation) is applied in the same
+//                        kernel; the extra last workgroup does bias_weights.
 //
 // The arrival order inside a bucket (atomics) is arbitrary, but the full sort on (row, bag) makes the
 // summation order -- and therefore every updated bit -- independent of it: the step stays deterministic.

@@ -1,0 +1,97 @@
+"""CPU: host-side planning logic of the engine (no GPU): activation-buffer layouts of the connected modes, the row-range
+bucket geometry of the fused sparse update, optimizer slot naming."""
+import numpy as np
+import pytest
+
+from wide_deep_amd.plan import (FeaturePlan, OPT_SLOT_NAMES, TowerLayout, adam_pow_names, bucket_geometry, criteo_spec,
+                                opt_params, opt_slot_init)
+
+
+@pytest.mark.parametrize("mode", ["simple", "dense", "resnet", "last_dense", "first_dense"])
+@pytest.mark.parametrize("hidden", [(8,), (16, 8), (32, 16, 8), (16, 8, 8, 4, 12)])
+def test_every_layer_reads_one_contiguous_window(mode, hidden):
+    """python/lib/dnn.py:92-193: the concat a layer consumes is ONE column window of the activation buffer (free concat),
+    windows list exactly the segments the reference concatenates, and segments never overlap."""
+    deep = 20
+    tl = TowerLayout(deep, hidden, mode)
+    L = len(hidden)
+    spans = sorted((tl.seg_start[j], tl.seg_start[j] + tl.seg_width[j]) for j in range(len(tl.seg_width)))
+    for (a0, a1), (b0, b1) in zip(spans, spans[1:]):
+        assert a1 <= b0, "segments overlap"
+    assert spans[-1][1] <= tl.ld
+    for l in range(L + 1):
+        segs = tl.in_segs[l]
+        assert sum(tl.seg_width[j] for j in segs) == tl.in_K[l]                       # contiguous: no holes
+        canon = [tl.canon(j) for j in segs]
+        if mode == "simple" or (mode == "last_dense" and l < L):
+            want = [l]
+        elif mode == "first_dense":
+            want = [0] if l == 0 else [l, 0]                                             # [h_{l-1} | x]
+        elif mode in ("dense", "last_dense"):
+            want = list(range(l + 1))                                                    # [x | h_0 | ... | h_{l-1}]
+        else:
+            want = list(range(l, -1, -1))                                                # resnet: newest first
+        assert canon == want, (mode, l, canon, want)
+        cols = tl.window_cols(l)
+        assert len(cols) == tl.in_K[l] and all(seg >= 0 for seg, _ in cols)
+    if mode == "first_dense":
+        assert len(tl.x_copies) == max(0, (L + 1) // 2 - 1)                             # one copy of x serves two consumers
+
+
+def test_first_dense_kernel_rows_follow_the_reference_concat_order():
+    spec = criteo_spec(n_dense=3, n_sparse=2, buckets=10, dim=8, hidden=(8, 4, 4), mode="first_dense")
+    plan = FeaturePlan(spec)
+    tl = plan.towers[0]
+    for l in range(1, 4):
+        rows = plan.tf_rows_of_layer(0, l)
+        K_tf = tl.seg_width[l] + plan.tf_deep_dim                     # [h_{l-1} | x] in TF's order
+        assert len(rows) == K_tf and len(set(rows.tolist())) == K_tf
+        h0 = tl.seg_start[l] - tl.in_start[l]
+        assert rows[: tl.seg_width[l]].tolist() == list(range(h0, h0 + tl.seg_width[l]))
+
+
+@pytest.mark.parametrize("vocab,occ", [([1_000_000] * 26, 8192), ([2, 7, 55, 1000, 100_000, 12_000_000], 8192),
+                                       ([50] * 3, 200), ([3_846_154] * 26, 8192 * 5), ([1], 10)])
+def test_bucket_geometry_invariants(vocab, occ):
+    nb_max = 8192
+    shifts, bases, total = bucket_geometry(vocab, occ, nb_max)
+    assert total <= nb_max and len(shifts) == len(bases) == len(vocab)
+    run = 0
+    for v, sh, base in zip(vocab, shifts, bases):
+        assert base == run                                            # buckets of a slot are contiguous, slots in order
+        nb = (v + (1 << sh) - 1) >> sh
+        run += nb
+        if sh == 0:
+            assert nb == v                                            # one bucket per row (no sort in the update kernel)
+        else:
+            assert ((v - 1) >> sh) == nb - 1                          # last row lands in the last bucket
+    assert run == total
+    small = [i for i, v in enumerate(vocab) if v <= occ / 64.0]
+    assert all(shifts[i] == 0 for i in small) or total == nb_max      # tiny vocabularies: per-row buckets
+
+
+def test_optimizer_slot_tables_are_consistent():
+    opts = [("SGD", 0.1), ("Adagrad", 0.05, 0.1), ("Ftrl", 0.1, 0.5, 1.0, 0.2), ("RMSProp", 0.01, 0.9, 0.1, 1e-10),
+            ("Adam", 0.001, 0.9, 0.999, 1e-8)]
+    for o in opts:
+        a, b = opt_slot_init(o)
+        sa, sb = OPT_SLOT_NAMES[o[0]]
+        assert (a is None) == (sa is None) and (b is None) == (sb is None)
+        assert len(opt_params(o)) == 3
+    assert opt_slot_init(opts[1]) == (None, 0.1) and opt_slot_init(opts[2]) == (0.0, 0.2)
+    assert opt_slot_init(opts[3]) == (1.0, 0.0)                       # rms slot starts at ones
+    assert opt_params(opts[2]) == (0.5, 1.0, 0.0) and opt_params(opts[4]) == (0.9, 0.999, 1e-8)
+    assert adam_pow_names(opts[4], opts[4], True, True) == {"dnn": ("beta1_power", "beta2_power"),
+                                                            "linear": ("beta1_power_1", "beta2_power_1")}
+    assert adam_pow_names(opts[4], opts[4], False, True) == {"linear": ("beta1_power", "beta2_power")}
+    assert adam_pow_names(opts[1], opts[2], True, True) == {}
+
+
+def test_deep_input_is_padded_for_aligned_windows():
+    """x is padded to a multiple of 4 (64 beyond 128 columns); pad columns map to no TF row and stay zero."""
+    for n_dense, n_sparse, dim in [(3, 5, 16), (13, 26, 16), (1, 1, 4), (0, 3, 8)]:
+        plan = FeaturePlan(criteo_spec(n_dense=n_dense, n_sparse=n_sparse, buckets=10, dim=dim, hidden=(8,)))
+        c = n_dense + n_sparse * dim
+        assert plan.tf_deep_dim == c and plan.deep_dim >= c and plan.deep_dim % 4 == 0
+        assert plan.deep_dim % 64 == 0 or c <= 128
+        assert len(set(plan.tf_input_perm.tolist())) == c and int(plan.tf_input_perm.max()) < plan.deep_dim

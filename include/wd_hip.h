@@ -429,6 +429,10 @@ typedef struct wd_chain_input {
   int32_t wide_in_row, pad_;
 } wd_chain_input_t;
 int wd_tower_chain_input(const wd_chain_input_t *in);
+/* Optional, for the NEXT wd_tower_chain call: store each row tile's loss to loss_part[tile] (wd_tower_chain_blocks(batch)
+ * floats, plain stores) instead of adding it atomically to loss_sum -- the caller sums them in tile order (e.g. a
+ * column-sum job of wd_gemm_tn_splitk_group): a reproducible loss that needs no zeroed accumulator. */
+int wd_tower_chain_loss_partials(float *loss_part);
 int64_t wd_tower_chain_lds_bytes(int32_t K0, const int32_t *N, int32_t L);   /* -1: unsupported shape */
 int64_t wd_tower_chain_blocks(int64_t batch);
 /* diagnostics: later launches write shader-clock stamps (start, x tile in LDS, after each forward layer, head, after each

@@ -152,6 +152,7 @@ _PROTOS = {
     "wd_tower_chain_lds_bytes": [I32, P, I32],
     "wd_tower_chain_blocks": [I64],
     "wd_tower_chain_input": [P],
+    "wd_tower_chain_loss_partials": [P],
     "wd_tower_chain_set_stamps": [P],
     "wd_tower_chain": [P, I64, I32, P, I32, I32, I32, P, P, P, P, P, I64, P, P, P, P, P, P, P, I64, I32, P],
     "wd_logits_head_h": [P, I64, I64, P, P, I32, P, P, P, I64, P, P, P, P, P, P, I64, I32, P, P],

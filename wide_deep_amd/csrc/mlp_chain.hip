@@ -63,6 +63,7 @@ struct ChainArgs {
   int64_t ld_dx;
   unsigned long long *stamps;   // diagnostics (wd_tower_chain_set_stamps): shader-clock stamps of workgroups 0 and 100
   wd_chain_input_t in;          // in.emb != NULL: the x tile is built here (input layer fused), see wd_tower_chain_input
+  float *loss_part;             // != NULL: this tile's loss is stored to loss_part[tile] (no atomic on loss_sum)
 };
 
 __device__ __forceinline__ float act_fwd(float v, int act) {
@@ -436,9 +437,12 @@ __global__ void __launch_bounds__(256) k_tower_chain(ChainArgs g) {
         if (g.train && g.dlogit) g.dlogit[b] = dl;
       }
       sdl[t] = dl;
-      if (g.train && g.loss_sum) {
+      if (g.train && (g.loss_sum || g.loss_part)) {
         for (int off = 16; off > 0; off >>= 1) ls += __shfl_down(ls, off, 64);
-        if (t == 0) atomicAdd(g.loss_sum, ls);
+        if (t == 0) {
+          if (g.loss_part) g.loss_part[blockIdx.x] = ls;
+          else atomicAdd(g.loss_sum, ls);
+        }
       }
     }
   }
@@ -545,6 +549,13 @@ extern "C" int64_t wd_tower_chain_lds_bytes(int32_t K0, const int32_t *N, int32_
 
 static unsigned long long *g_stamps = nullptr;
 static wd_chain_input_t g_input = {};   // consumed (and cleared) by the next wd_tower_chain call
+static float *g_loss_part = nullptr;    // likewise
+
+extern "C" int wd_tower_chain_loss_partials(float *loss_part) {
+  g_loss_part = loss_part;
+  return WD_OK;
+}
+
 
 extern "C" int wd_tower_chain_input(const wd_chain_input_t *in) {
   if (!in) {
@@ -600,6 +611,8 @@ extern "C" int wd_tower_chain(const float *x, int64_t ld_act, int32_t K0, const 
   g.Gpart_logits = Gpart_logits; g.dx = dx; g.ld_dx = ld_dx; g.stamps = g_stamps;
   g.in = g_input;
   g_input = wd_chain_input_t{};
+  g.loss_part = g_loss_part;
+  g_loss_part = nullptr;
   if (g.in.emb) WD_REQUIRE((int64_t)2 * RT * g.in.S * 4 <= (int64_t)N[0] * P * 4, "input fusion: ids do not fit the scratch region (2 x 32 x S <= 33 x N_0)");
   static bool attr_set = false;
   if (!attr_set) {

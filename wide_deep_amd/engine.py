@@ -362,6 +362,7 @@ class WideDeepEngine:
             c.db_part = tw["db_part"][l].data_ptr()
             c.K, c.N = int(metas[l]["K"]), dims[l]
         tw["chain_layers"] = carr
+        self.loss_part = torch.zeros(ntile, **f32)   # per-row-tile losses, summed in tile order by the grouped launch
         # gradient columns of x that anyone reads: the embedding columns (the sparse backward), rounded up by the kernel
         emb_cols = 0
         for i, sl in enumerate(plan.slots):
@@ -369,6 +370,14 @@ class WideDeepEngine:
                 emb_cols = max(emb_cols, plan.out_col[i] + int(sl.dim))
         tw["dx_cols"] = min(emb_cols, K0)
         self.chain = True
+
+    def _fold(self, train, st):
+        """One launch: fold the BN affines of every layer into its consumer's weights (+ the MFMA-fragment-packed copies
+        of the one-launch tower); clears the loss accumulator of the per-layer paths (the one-launch tower stores per-tile
+        partials instead) and G when the per-layer finalize path accumulates into it."""
+        zero_g = train and not self.all_simple
+        call("wd_fold_affine_all", ptr(self.P), ptr(self.layers_dev), self.n_layers, self.max_layer_n, self.inv,
+             None if self.chain else ptr(self.loss), 1, ptr(self.G) if zero_g else None, self.G.numel() if zero_g else 0, st)
 
     def _chain_input_ok(self, bt):
         """The one-launch tower can build its x tile itself (input layer fused, wd_tower_chain_input): one id per bag,
@@ -408,6 +417,8 @@ class WideDeepEngine:
         need_dx = train and has_emb and tw["dx_cols"] > 0
         if fuse_in:
             call("wd_tower_chain_input", ctypes.byref(self._chain_input(bt, tw)))
+        if train:
+            call("wd_tower_chain_loss_partials", ptr(self.loss_part))
         call("wd_tower_chain", tw["act"].data_ptr() + 4 * tl.in_start[0], tl.ld, int(metas[0]["K"]), tw["chain_layers"], L,
              self.act_id, capi.WD_FOLD_PARTS, ptr(tw["Wf"][L]), ptr(tw["bf"][L]),
              None if fuse_in else ptr(self.wide_logit),
@@ -512,9 +523,7 @@ class WideDeepEngine:
         if spec.has_deep:
             # one launch: fold the BN affines of every layer into its consumer's weights; clear loss (+ G when the
             # per-layer finalize path accumulates into it)
-            zero_g = train and not self.all_simple
-            call("wd_fold_affine_all", ptr(self.P), ptr(self.layers_dev), self.n_layers, self.max_layer_n, self.inv,
-                 ptr(self.loss), 1, ptr(self.G) if zero_g else None, self.G.numel() if zero_g else 0, st)
+            self._fold(train, st)
             tw0 = self.towers[0]
             nt = len(self.towers)
             for ti, tw in enumerate(self.towers):
@@ -632,18 +641,21 @@ class WideDeepEngine:
         if self.chain:
             # forward() already ran the input-gradient chain; what is left are the batch reductions G_l = a_{l-1}^T dz_l
             # (one grouped launch) and the sums of the per-tile bias-gradient partials (column-sum jobs of the same launch)
-            if 2 * L <= capi.WD_TN_GROUP_MAX:
-                jobs = (capi.WdTnJob * (2 * L))()
+            if 2 * L + 1 <= capi.WD_TN_GROUP_MAX:
+                jobs = (capi.WdTnJob * (2 * L + 1))()
                 nblk = int(call("wd_tower_chain_blocks", B))
+                lj = jobs[L if self._tn_ones else 2 * L]     # loss = sum of the per-tile partials, in tile order
+                lj.A, lj.lda, lj.B, lj.Cpart, lj.N, lj.K = self.loss_part.data_ptr(), 1, None, self.loss.data_ptr(), 1, nblk
                 for l in range(L):    # largest product first: its workgroups start while the small ones fill the gaps
                     m, j = metas[l], jobs[l]
                     j.A, j.lda = act.data_ptr() + 4 * tl.in_start[l], tl.ld
                     j.B, j.ldb, j.Cpart = tw["dzl"][l].data_ptr(), m["N"], tw["Gpart"][l].data_ptr()
                     j.M, j.N, j.K, j.nsplit, j.append_ones = m["K"], m["N"], B, tw["nsplit"][l], int(self._tn_ones)
-                    c = jobs[L + l]    # bias gradient: column sums of the tower kernel's per-tile partials
-                    c.A, c.lda, c.B, c.Cpart = tw["db_part"][l].data_ptr(), m["N"], None, tw["db_sum"][l].data_ptr()
-                    c.N, c.K = m["N"], nblk
-                call("wd_gemm_tn_splitk_group", jobs, L if self._tn_ones else 2 * L, st)
+                    if not self._tn_ones:
+                        c = jobs[L + l]    # bias gradient: column sums of the tower kernel's per-tile partials
+                        c.A, c.lda, c.B, c.Cpart = tw["db_part"][l].data_ptr(), m["N"], None, tw["db_sum"][l].data_ptr()
+                        c.N, c.K = m["N"], nblk
+                call("wd_gemm_tn_splitk_group", jobs, (L if self._tn_ones else 2 * L) + 1, st)
                 return
             raise NotImplementedError("one-launch tower with more than %d hidden layers" % (capi.WD_TN_GROUP_MAX // 2))
         simple = tl.mode == "simple" and not self.dropout   # dropout: act' is not fused into the GEMM epilogues

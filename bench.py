@@ -124,6 +124,9 @@ def gather_roofline(eng, batches, iters=200):
             "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": src,
             "algorithmic_bytes_per_launch": int(alg), "avg_launch_us": round(ms * 1e3, 2),
+            "note": "the embedding-gather kernel of the C ABI (wd_embag_fwd) timed as its own launch on the resident "
+                    "batches; inside the step one-id-per-bag batches take the same rows through the gather phase of "
+                    "k_tower_chain (roofline_tower), multi-hot batches through this kernel",
             "ceilings_GBps": {"float4_copy": 5386, "random_64B_rows_16M": 3459, "random_64B_rows_at_batch_size": 2076,
                               "source": "profiles/r1i_ceilings.txt"}}
 

@@ -403,12 +403,12 @@ typedef struct wd_chain_layer {
   float *db_part;    /* optional [wd_tower_chain_blocks(batch)][N]: per row tile, the column sums of dz (bias gradient partials) */
   int32_t K, N;
 } wd_chain_layer_t;
-/* Optional: fuse the input layer into the NEXT wd_tower_chain call (one-id-per-bag batches, the Criteo shape): the kernel
+/* Optional (wd_chain_opts_t.input): fuse the input layer into the call (one-id-per-bag batches, the Criteo shape): the kernel
  * then builds its x tile itself -- x[b, out_col_s ..] = emb[emb_off_s + ids[b*S + s]*dim ..] for the slots
  * [slot0, slot0+ngroup) (id < 0: zeros), the numeric columns (wd_dense_fwd), and the wide logit
  * bias[0] + sum_s wide[(row_base_s + id)*4] (wd_wide_fwd; NULL: none) -- writes x to x_out (the weight-gradient GEMMs
  * read it) and the wide logit to wide_out, and ignores the x / wide_logit arguments of wd_tower_chain.  It replaces the
- * wd_input_layer_fwd launch (python/lib/dnn.py:88-90, python/lib/linear.py:29-36).  NULL clears a pending request. */
+ * wd_input_layer_fwd launch (python/lib/dnn.py:88-90, python/lib/linear.py:29-36). */
 #define WD_CHAIN_MAX_SLOTS 128
 typedef struct wd_chain_input {
   const float *emb;
@@ -428,21 +428,25 @@ typedef struct wd_chain_input {
   int32_t row_stride;
   int32_t wide_in_row, pad_;
 } wd_chain_input_t;
-int wd_tower_chain_input(const wd_chain_input_t *in);
-/* Optional, for the NEXT wd_tower_chain call: store each row tile's loss to loss_part[tile] (wd_tower_chain_blocks(batch)
- * floats, plain stores) instead of adding it atomically to loss_sum -- the caller sums them in tile order (e.g. a
- * column-sum job of wd_gemm_tn_splitk_group): a reproducible loss that needs no zeroed accumulator. */
-int wd_tower_chain_loss_partials(float *loss_part);
+/* Per-call options of wd_tower_chain (pass NULL for none; nothing is remembered between calls):
+ *   input      fused input layer, above
+ *   loss_part  store each row tile's loss to loss_part[tile] (wd_tower_chain_blocks(batch) floats, plain stores) instead of
+ *              adding it atomically to loss_sum -- the caller sums them in tile order (a column-sum job of
+ *              wd_gemm_tn_splitk_group): a reproducible loss that needs no zeroed accumulator
+ *   stamps     diagnostics: device uint64[64]; workgroups 0 and 100 write shader-clock stamps (start, x tile in LDS, after
+ *              each forward layer, head, after each gradient stage, end) to [0..31] / [32..63] */
+typedef struct wd_chain_opts {
+  const wd_chain_input_t *input;
+  float *loss_part;
+  void *stamps;
+} wd_chain_opts_t;
 int64_t wd_tower_chain_lds_bytes(int32_t K0, const int32_t *N, int32_t L);   /* -1: unsupported shape */
 int64_t wd_tower_chain_blocks(int64_t batch);
-/* diagnostics: later launches write shader-clock stamps (start, x tile in LDS, after each forward layer, head, after each
- * gradient stage, end) of workgroups 0 and 100 to dev_u64x64[0..31] / [32..63]; NULL switches it off */
-int wd_tower_chain_set_stamps(void *dev_u64x64);
 int wd_tower_chain(const float *x, int64_t ld_act, int32_t K0, const wd_chain_layer_t *layers, int32_t L, int32_t act,
                    int32_t bias_parts, const float *w_logits, const float *b_logits, const float *wide_logit,
                    const float *labels, const float *weights, int64_t batch, float *dnn_logit, float *logit,
                    float *prob, float *dlogit, float *loss_sum, float *Gpart_logits, float *dx, int64_t ld_dx,
-                   int32_t dx_cols, wd_stream_t stream);
+                   int32_t dx_cols, const wd_chain_opts_t *opts, wd_stream_t stream);
 
 /* ---- fp16-input MFMA tower (BASELINE configs[4]; csrc/mlp_half.hip).  wd_half_t = IEEE binary16 bit pattern.
  * Operands are half, reduction-contiguous; accumulation, bias, split-K partials and gradient accumulators are fp32.

@@ -47,12 +47,12 @@ fwd = timeit(lambda: eng._tower_chain(tw, bt, B, st, False))
 print("chain B=%d hidden=%s: with fused input layer %.1f us | x from HBM: full %.1f us, no dx %.1f us, forward only %.1f us "
       "(forward GEMM flops %.2f G)" % (B, hidden, fused, full, nodx, fwd, fl_f / 1e9))
 
-from wide_deep_amd.capi import call
+
 stamps = torch.zeros(64, dtype=torch.int64, device="cuda")
-call("wd_tower_chain_set_stamps", stamps.data_ptr())
+eng._chain_stamps = stamps.data_ptr()
 eng._tower_chain(tw, bt, B, st, True, fuse)
 torch.cuda.synchronize()
-call("wd_tower_chain_set_stamps", None)
+eng._chain_stamps = None
 names = ["x tile"] + ["F%d" % l for l in range(len(hidden))] + ["head"] + ["B%d" % l for l in range(len(hidden) - 1, 0, -1)] + ["dx"]
 for wg, off in ((0, 0), (100, 32)):
     v = stamps[off: off + len(names) + 1].cpu().tolist()

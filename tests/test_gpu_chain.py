@@ -63,7 +63,7 @@ def test_chain_matches_per_layer_launches(B, kw):
 
 
 def test_fused_input_layer_and_env_switch():
-    """The tower kernel builds its own x tile (wd_tower_chain_input) for one-id-per-bag batches; WD_CHAIN_INPUT=0 keeps
+    """The tower kernel builds its own x tile (wd_chain_opts_t.input) for one-id-per-bag batches; WD_CHAIN_INPUT=0 keeps
     the separate input-layer launch; x is bit-equal between the two, and both train like the per-layer engine."""
     from wide_deep_amd import synth
     from wide_deep_amd.plan import criteo_spec

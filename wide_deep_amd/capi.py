@@ -78,6 +78,10 @@ class WdChainInput(ctypes.Structure):
 WD_CHAIN_MAX_SLOTS = 128
 
 
+class WdChainOpts(ctypes.Structure):
+    _fields_ = [("input", ctypes.c_void_p), ("loss_part", ctypes.c_void_p), ("stamps", ctypes.c_void_p)]
+
+
 class WdTnJob(ctypes.Structure):
     _fields_ = [
         ("A", ctypes.c_void_p), ("B", ctypes.c_void_p), ("Cpart", ctypes.c_void_p),
@@ -151,10 +155,7 @@ _PROTOS = {
     "wd_adam_tick": [P, F32, F32, P],
     "wd_tower_chain_lds_bytes": [I32, P, I32],
     "wd_tower_chain_blocks": [I64],
-    "wd_tower_chain_input": [P],
-    "wd_tower_chain_loss_partials": [P],
-    "wd_tower_chain_set_stamps": [P],
-    "wd_tower_chain": [P, I64, I32, P, I32, I32, I32, P, P, P, P, P, I64, P, P, P, P, P, P, P, I64, I32, P],
+    "wd_tower_chain": [P, I64, I32, P, I32, I32, I32, P, P, P, P, P, I64, P, P, P, P, P, P, P, I64, I32, P, P],
     "wd_logits_head_h": [P, I64, I64, P, P, I32, P, P, P, I64, P, P, P, P, P, P, I64, I32, P, P],
     "wd_hgemm_nn": [P, I64, P, I64, P, I32, I32, P, I64, P, I64, I64, I64, I64, P],
     "wd_hgemm_nt": [P, I64, P, I64, I64, I64, I64, P, I64, I32, P, I64, P, I64, P, I64, I32, P],

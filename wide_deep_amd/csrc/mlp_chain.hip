@@ -61,8 +61,8 @@ struct ChainArgs {
   float *dnn_logit, *logit, *prob, *dlogit, *loss_sum, *Gpart_logits;
   float *dx;
   int64_t ld_dx;
-  unsigned long long *stamps;   // diagnostics (wd_tower_chain_set_stamps): shader-clock stamps of workgroups 0 and 100
-  wd_chain_input_t in;          // in.emb != NULL: the x tile is built here (input layer fused), see wd_tower_chain_input
+  unsigned long long *stamps;   // diagnostics (wd_chain_opts_t.stamps): shader-clock stamps of workgroups 0 and 100
+  wd_chain_input_t in;          // in.emb != NULL: the x tile is built here (input layer fused), wd_chain_opts_t.input
   float *loss_part;             // != NULL: this tile's loss is stored to loss_part[tile] (no atomic on loss_sum)
 };
 
@@ -547,22 +547,8 @@ extern "C" int64_t wd_tower_chain_lds_bytes(int32_t K0, const int32_t *N, int32_
   return chain_layout(K0, N, L, nullptr, nullptr);
 }
 
-static unsigned long long *g_stamps = nullptr;
-static wd_chain_input_t g_input = {};   // consumed (and cleared) by the next wd_tower_chain call
-static float *g_loss_part = nullptr;    // likewise
-
-extern "C" int wd_tower_chain_loss_partials(float *loss_part) {
-  g_loss_part = loss_part;
-  return WD_OK;
-}
-
-
-extern "C" int wd_tower_chain_input(const wd_chain_input_t *in) {
-  if (!in) {
-    g_input = wd_chain_input_t{};
-    return WD_OK;
-  }
-  WD_REQUIRE(in->emb && in->slots && in->ids && in->x_out, "null pointer");
+static int check_chain_input(const wd_chain_input_t *in) {
+  WD_REQUIRE(in->emb && in->slots && in->ids && in->x_out, "wd_chain_input_t: null pointer");
   WD_REQUIRE(in->dim >= 4 && in->dim % 4 == 0 && in->dim <= 256 && 256 % (in->dim / 4) == 0, "dim: multiple of 4 dividing 1024");
   WD_REQUIRE(in->S > 0 && in->S <= WD_CHAIN_MAX_SLOTS && in->ngroup > 0 && in->slot0 >= 0 && in->slot0 + in->ngroup <= in->S,
              "bad slot range (S <= WD_CHAIN_MAX_SLOTS)");
@@ -570,12 +556,6 @@ extern "C" int wd_tower_chain_input(const wd_chain_input_t *in) {
   WD_REQUIRE(!in->wide || in->wide_bias, "wide needs its bias");
   WD_REQUIRE(in->row_stride == 0 || (in->row_stride >= in->dim && in->row_stride % 4 == 0), "row_stride: 0 or >= dim, multiple of 4");
   WD_REQUIRE(!in->wide_in_row || in->row_stride > in->dim, "wide_in_row needs row_stride > dim");
-  g_input = *in;
-  return WD_OK;
-}
-
-extern "C" int wd_tower_chain_set_stamps(void *dev_u64x64) {
-  g_stamps = static_cast<unsigned long long *>(dev_u64x64);
   return WD_OK;
 }
 
@@ -585,7 +565,8 @@ extern "C" int wd_tower_chain(const float *x, int64_t ld_act, int32_t K0, const 
                               int32_t act, int32_t bias_parts, const float *w_logits, const float *b_logits,
                               const float *wide_logit, const float *labels, const float *weights, int64_t batch,
                               float *dnn_logit, float *logit, float *prob, float *dlogit, float *loss_sum,
-                              float *Gpart_logits, float *dx, int64_t ld_dx, int32_t dx_cols, wd_stream_t stream) {
+                              float *Gpart_logits, float *dx, int64_t ld_dx, int32_t dx_cols, const wd_chain_opts_t *opts,
+                              wd_stream_t stream) {
   if (batch <= 0) return WD_OK;
   WD_REQUIRE(x && layers && w_logits && b_logits, "null pointer");
   WD_REQUIRE(L >= 1 && L <= MAXL, "1 <= L <= WD_CHAIN_MAX_LAYERS");
@@ -608,12 +589,18 @@ extern "C" int wd_tower_chain(const float *x, int64_t ld_act, int32_t K0, const 
   g.x = x; g.ld_act = ld_act; g.w_logits = w_logits; g.b_logits = b_logits;
   g.wide_logit = wide_logit; g.labels = labels; g.weights = weights; g.batch = batch;
   g.dnn_logit = dnn_logit; g.logit = logit; g.prob = prob; g.dlogit = dlogit; g.loss_sum = loss_sum;
-  g.Gpart_logits = Gpart_logits; g.dx = dx; g.ld_dx = ld_dx; g.stamps = g_stamps;
-  g.in = g_input;
-  g_input = wd_chain_input_t{};
-  g.loss_part = g_loss_part;
-  g_loss_part = nullptr;
-  if (g.in.emb) WD_REQUIRE((int64_t)2 * RT * g.in.S * 4 <= (int64_t)N[0] * P * 4, "input fusion: ids do not fit the scratch region (2 x 32 x S <= 33 x N_0)");
+  g.Gpart_logits = Gpart_logits; g.dx = dx; g.ld_dx = ld_dx;
+  if (opts) {
+    g.stamps = static_cast<unsigned long long *>(opts->stamps);
+    g.loss_part = opts->loss_part;
+    if (opts->input) {
+      const int rc = check_chain_input(opts->input);
+      if (rc != WD_OK) return rc;
+      g.in = *opts->input;
+      WD_REQUIRE((int64_t)2 * RT * g.in.S * 4 <= (int64_t)N[0] * P * 4,
+                 "input fusion: ids do not fit the scratch region (2 x 32 x S <= 33 x N_0)");
+    }
+  }
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_tower_chain),

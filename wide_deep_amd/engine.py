@@ -326,6 +326,7 @@ class WideDeepEngine:
         """One-launch tower (wd_tower_chain, csrc/mlp_chain.hip): exact-fp32 `simple` towers whose widths are multiples
         of 32 and whose row tile fits the LDS.  WD_CHAIN=0 keeps the per-layer GEMM launches."""
         self.chain = False
+        self._chain_stamps = None    # diagnostics: device int64[64] for the tower kernel's stage stamps (scripts/bench_chain.py)
         self._tn_ones = os.environ.get("WD_TN_ONES", "0") == "1"   # A/B switch: bias gradients via an appended ones row
         plan = self.plan
         if self.half or self.dropout or len(self.towers) != 1 or os.environ.get("WD_CHAIN", "1") == "0":
@@ -380,7 +381,7 @@ class WideDeepEngine:
              None if self.chain else ptr(self.loss), 1, ptr(self.G) if zero_g else None, self.G.numel() if zero_g else 0, st)
 
     def _chain_input_ok(self, bt):
-        """The one-launch tower can build its x tile itself (input layer fused, wd_tower_chain_input): one id per bag,
+        """The one-launch tower can build its x tile itself (input layer fused, wd_chain_opts_t.input): one id per bag,
         one embedding group, no indicator columns -- the Criteo shape.  WD_CHAIN_INPUT=0 keeps wd_input_layer_fwd."""
         if not (self.spec.has_deep and self.chain and self._fused_input_layer and bt.one_hot):
             return False
@@ -415,17 +416,21 @@ class WideDeepEngine:
         tl, metas, L = tw["layout"], tw["metas"], tw["L"]
         has_emb = bool(self.group_slots)
         need_dx = train and has_emb and tw["dx_cols"] > 0
-        if fuse_in:
-            call("wd_tower_chain_input", ctypes.byref(self._chain_input(bt, tw)))
+        opts = capi.WdChainOpts()
+        ci = self._chain_input(bt, tw) if fuse_in else None      # kept alive until the call returns
+        if ci is not None:
+            opts.input = ctypes.addressof(ci)
         if train:
-            call("wd_tower_chain_loss_partials", ptr(self.loss_part))
+            opts.loss_part = ptr(self.loss_part)
+        opts.stamps = self._chain_stamps
         call("wd_tower_chain", tw["act"].data_ptr() + 4 * tl.in_start[0], tl.ld, int(metas[0]["K"]), tw["chain_layers"], L,
              self.act_id, capi.WD_FOLD_PARTS, ptr(tw["Wf"][L]), ptr(tw["bf"][L]),
              None if fuse_in else ptr(self.wide_logit),
              ptr(bt.labels) if train else None, ptr(bt.weights) if train else None, B, ptr(tw["logit"]), ptr(self.logit),
              ptr(self.prob), ptr(self.dlogit) if train else None, ptr(self.loss) if train else None,
              ptr(tw["Gpart"][L]) if train else None,
-             tw["dact"].data_ptr() + 4 * tl.in_start[0] if need_dx else None, tl.ld, tw["dx_cols"] if need_dx else 0, st)
+             tw["dact"].data_ptr() + 4 * tl.in_start[0] if need_dx else None, tl.ld, tw["dx_cols"] if need_dx else 0,
+             ctypes.byref(opts), st)
 
     def dropout_masks(self, B):
         """Host copy of the keep masks the NEXT train step will use: [tower][layer] -> float32 [B, N] of 0 / 1 (the

@@ -206,7 +206,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &g, const int orig, con
   // Fast path (interior tile, full slab, 16-byte loads): no clamps, no masks, addresses = uniform slab pointer +
   // per-lane 32-bit offsets computed once.  Both operand orientations share one offset formula because a
   // 64 x BK (RC) and a BK x 64 (OC) slab are both 16 float4 wide at BK = 64.
-  static_assert(BK == 64, "fast-path offsets assume BK == 64");
+  static_assert(BK == 64 || (BK % 16 == 0 && !A_RC && !B_RC), "fast-path offsets: BK == 64, or any 16-multiple for two OC operands");
   const bool fast_tile = VEC && (m0 + BM <= (A_RC ? g.M : a_cols)) && (n0 + BN <= g.N);
   int32_t offA[NV], offB[NV];
 #pragma unroll
@@ -897,8 +897,16 @@ extern "C" int wd_gemm_tn_splitk_group(const wd_tn_job_t *jobs, int32_t njobs, w
   }
   G.first[njobs] = total;
   G.njobs = njobs;
-  if (vec) hipLaunchKernelGGL((k_gemm_tn_group<kBK, true>), dim3((unsigned)total), dim3(256), 0, wd::as_stream(stream), G);
-  else hipLaunchKernelGGL((k_gemm_tn_group<kBK, false>), dim3((unsigned)total), dim3(256), 0, wd::as_stream(stream), G);
+  // 32-deep slabs: 35 KB of LDS per workgroup instead of 70 -- the sparse update that runs beside this launch keeps
+  // workgroups resident on the same CUs (WD_TN_BK=64 for the deeper slabs)
+  static const bool bk64 = getenv("WD_TN_BK") && atoi(getenv("WD_TN_BK")) == 64;   // (16-deep slabs measured no better)
+  if (bk64) {
+    if (vec) hipLaunchKernelGGL((k_gemm_tn_group<kBK, true>), dim3((unsigned)total), dim3(256), 0, wd::as_stream(stream), G);
+    else hipLaunchKernelGGL((k_gemm_tn_group<kBK, false>), dim3((unsigned)total), dim3(256), 0, wd::as_stream(stream), G);
+  } else {
+    if (vec) hipLaunchKernelGGL((k_gemm_tn_group<32, true>), dim3((unsigned)total), dim3(256), 0, wd::as_stream(stream), G);
+    else hipLaunchKernelGGL((k_gemm_tn_group<32, false>), dim3((unsigned)total), dim3(256), 0, wd::as_stream(stream), G);
+  }
   return wd::check_launch("wd_gemm_tn_splitk_group");
 }
 

@@ -159,7 +159,10 @@ class CsvDataset(object):
         starts = np.concatenate([np.zeros(1, np.int64), nl[:-1] + 1]) if len(nl) else np.zeros(0, np.int64)
         ends = nl + 1
         if self._num_workers > 1:
-            keep = np.arange(len(starts)) % self._num_workers == self._worker_index
+            # every rank gets the same number of lines (the last n % workers lines are dropped): the ranks of the sharded
+            # engine meet in collectives every step, so they must see the same number of equally sized batches
+            per = len(starts) // self._num_workers
+            keep = np.flatnonzero(np.arange(len(starts)) % self._num_workers == self._worker_index)[:per]
             starts, ends = starts[keep], ends[keep]
         return buf, starts, ends
 

@@ -512,8 +512,11 @@ class ShardedWideDeepEngine(WideDeepEngine):
             v = local[k]
             base = k.replace("/Adagrad", "").replace("/Ftrl_1", "").replace("/Ftrl", "")
             if base in full_rows:
+                if dist.get_backend(self.group) != "gloo":
+                    v = v.to(self.device)                       # RCCL moves device tensors only
                 parts = [torch.empty_like(v) for _ in range(W)]
                 dist.all_gather(parts, v.contiguous(), group=self.group)
+                parts, v = [q.cpu() for q in parts], v.cpu()
                 V = full_rows[base]
                 full = torch.empty((V,) + tuple(v.shape[1:]), dtype=v.dtype)
                 for r in range(W):

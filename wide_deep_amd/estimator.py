@@ -48,7 +48,13 @@ class WideAndDeepClassifier(object):
             else:
                 # multi-valued + crossed columns: generous capacity, the featurizer checks every batch against it
                 kw["max_nnz"] = B * max(len(self.spec.slots), 1) * 16
-            self._engine = WideDeepEngine(self.spec, **kw)
+            if self._world() > 1:
+                # one process per GPU (python -m torch.distributed.run ... train.py): tables row-sharded, dense gradients
+                # all-reduced -- N ranks train ONE model on the union of their batches (wide_deep_amd/dist.py)
+                from .dist import ShardedWideDeepEngine
+                self._engine = ShardedWideDeepEngine(self.spec, **kw)
+            else:
+                self._engine = WideDeepEngine(self.spec, **kw)
         if self._featurizer is None:
             self._featurizer = Featurizer(self._engine, self._cross_padding)
         return self._engine
@@ -75,20 +81,46 @@ class WideAndDeepClassifier(object):
                 best, best_step = p, int(m.group(1))
         return best
 
+    @staticmethod
+    def _world():
+        import torch.distributed as td
+        return td.get_world_size() if (td.is_available() and td.is_initialized()) else 1
+
+    @staticmethod
+    def _rank():
+        import torch.distributed as td
+        return td.get_rank() if (td.is_available() and td.is_initialized()) else 0
+
     def _restore(self, checkpoint_path=None):
         path = checkpoint_path or self.latest_checkpoint()
         if path and path != self._restored_from:
-            self._engine.import_state(torch.load(path, map_location="cpu"))
+            state = torch.load(path, map_location="cpu")
+            if self._world() > 1:
+                self._engine.import_full_state(state)      # checkpoints hold FULL tables; a rank keeps its rows
+                self._engine.global_step = int(state.get("global_step", 0))
+            else:
+                self._engine.import_state(state)
             self._restored_from = path
         return path
 
     def save_checkpoint(self):
         if not self.model_dir:
             return None
-        os.makedirs(self.model_dir, exist_ok=True)
         path = os.path.join(self.model_dir, "model.ckpt-%d.pt" % self._engine.global_step)
-        torch.save(self._engine.export_state(), path)
-        self._restored_from = path
+        if self._world() > 1:
+            import torch.distributed as td
+            state = self._engine.export_full_state()        # collective: every rank takes part, rank 0 writes
+            if self._rank() == 0:
+                os.makedirs(self.model_dir, exist_ok=True)
+                torch.save(state, path)
+            td.barrier()
+            self._restored_from = path
+            if self._rank() != 0:
+                return path
+        else:
+            os.makedirs(self.model_dir, exist_ok=True)
+            torch.save(self._engine.export_state(), path)
+            self._restored_from = path
         keep = int(self.runconfig.get("keep_checkpoint_max") or 5)
         ckpts = sorted(glob.glob(os.path.join(self.model_dir, "model.ckpt-*.pt")),
                        key=lambda p: int(re.search(r"-(\d+)\.pt$", p).group(1)))
@@ -113,7 +145,7 @@ class WideAndDeepClassifier(object):
             loss = self._engine.train_step(bt)
             n += 1
             seen += bt.B
-            if log_every and n % log_every == 0:
+            if log_every and n % log_every == 0 and self._rank() == 0:
                 torch.cuda.synchronize()
                 dt = time.time() - t0
                 print("INFO: step %d (global_step %d): loss = %.6f, %.1f examples/sec" % (

@@ -49,7 +49,8 @@ class Featurizer(object):
     def __init__(self, engine, cross_padding="tf_dense"):
         if cross_padding not in ("tf_dense", "ragged"):
             raise ValueError("cross_padding must be 'tf_dense' or 'ragged'")
-        self.engine, self.plan, self.cross_padding = engine, engine.plan, cross_padding
+        # sharded engines hash in the GLOBAL id space (engine.hash_plan); only the engine splits an id into (owner, local row)
+        self.engine, self.plan, self.cross_padding = engine, getattr(engine, "hash_plan", engine.plan), cross_padding
         self.dev = engine.device
         slots = self.plan.slots
         # string features whose fingerprints are needed (hash slots + string cross keys)

@@ -38,6 +38,8 @@ def parse():
     ap.add_argument("--dist", default="uniform", choices=["uniform", "zipf"])
     ap.add_argument("--pool", type=int, default=32, help="distinct resident batches cycled through")
     ap.add_argument("--no-graph", action="store_true", help="launch kernels eagerly instead of hipGraph replay")
+    ap.add_argument("--steps-per-graph", type=int, default=8,
+                    help="train steps captured into one hipGraph (single GPU; each step on its own resident batch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-sharded", action="store_true",
                     help="diagnostics: run the row-sharded engine even with one rank (one-rank RCCL group)")
@@ -277,6 +279,7 @@ def main():
         return eng.train_step(bt)
 
     use_graph = not args.no_graph
+    steps_per_run, run_steps = 1, None
     if use_graph and sharded:
         # sharded step: hipGraph segments between the collectives (dist._Segments); every rank captures in lock-step
         try:
@@ -290,32 +293,52 @@ def main():
             use_graph = False
             run = lambda i: step_eager(dev_batches[i % len(dev_batches)])
     elif use_graph:
-        replays = []
         side = torch.cuda.Stream()
         with torch.cuda.stream(side):
             step_eager(dev_batches[0])
             step_eager(dev_batches[1 % len(dev_batches)])
         torch.cuda.synchronize()
+        # One hipGraph holds `spg` consecutive steps (each the full step on its own resident batch): the ~11 us between two
+        # graph launches is paid once per `spg` steps.  Step counts that are not multiples of spg finish on one-step graphs.
+        spg = max(1, min(args.steps_per_graph, len(dev_batches)))
+        while len(dev_batches) % spg:
+            spg -= 1
+        singles, multis = [], []
+        for j in range(0, len(dev_batches), spg):
+            if spg > 1:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=side):
+                    for tb in dev_batches[j: j + spg]:
+                        step_eager(tb)
+                multis.append(g)
         for tb in dev_batches:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, stream=side):
                 step_eager(tb)
-            replays.append(g)
-        run = lambda i: replays[i % len(replays)].replay()
+            singles.append(g)
+        steps_per_run = spg
+
+        def run_steps(n):
+            for i in range(n // spg if spg > 1 else 0):
+                multis[i % len(multis)].replay()
+            for i in range(n % spg if spg > 1 else n):
+                singles[i % len(singles)].replay()
     else:
         run = lambda i: step_eager(dev_batches[i % len(dev_batches)])
+    if run_steps is None:
+        def run_steps(n):
+            for i in range(n):
+                run(i)
 
     def barrier():
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        run(i)
+    run_steps(args.warmup)
     barrier()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        run(args.warmup + i)
+    run_steps(args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -345,7 +368,7 @@ def main():
                       % (tower_dtype, B),
             }[args.config],
             "global_batch": B * world, "ids": args.dist, "input": "pre-hashed ids" if args.ids_input else "raw string tokens (hashed in step)",
-            "hip_graph": bool(use_graph), "parallelism": "dp%d+row-sharded tables" % world if sharded else "single GPU",
+            "hip_graph": bool(use_graph), "steps_per_graph": steps_per_run, "parallelism": "dp%d+row-sharded tables" % world if sharded else "single GPU",
             "final_loss_sum": round(loss, 3),
         },
     }

@@ -45,6 +45,34 @@ def _bucketize(x, boundaries):
     return np.searchsorted(b, x.astype(np.float32), side="right").astype(np.int32)
 
 
+_NP2T = {np.dtype(np.int32): torch.int32, np.dtype(np.int64): torch.int64, np.dtype(np.float32): torch.float32,
+         np.dtype(np.uint8): torch.uint8}
+
+
+class _Stage(object):
+    """Host arrays of one batch packed into ONE buffer and moved with ONE host-to-device copy (a batch of the repo-default
+    conf needs ~230 small arrays: CSR offsets, values and gather indices per slot and per cross key)."""
+
+    def __init__(self):
+        self.items, self.size = [], 0
+
+    def add(self, arr, dtype):
+        a = np.ascontiguousarray(arr, dtype=dtype)
+        off = (self.size + 15) // 16 * 16
+        self.items.append((off, a))
+        self.size = off + a.nbytes
+        return len(self.items) - 1
+
+    def upload(self, dev):
+        host = np.zeros(max(self.size, 16), dtype=np.uint8)
+        for off, a in self.items:
+            host[off: off + a.nbytes] = a.reshape(-1).view(np.uint8)
+        dbuf = torch.from_numpy(host).to(dev, non_blocking=True)
+        self.dbuf = dbuf
+        return [dbuf[off: off + a.nbytes].view(_NP2T[a.dtype]) if a.nbytes else
+                torch.zeros(0, dtype=_NP2T[a.dtype], device=dev) for off, a in self.items]
+
+
 class Featurizer(object):
     def __init__(self, engine, cross_padding="tf_dense"):
         if cross_padding not in ("tf_dense", "ragged"):
@@ -171,51 +199,59 @@ class Featurizer(object):
                              % (B, nnz, eng.max_batch, eng.max_nnz))
         bag_offs = np.zeros(B * S + 1, dtype=np.int32)
         np.cumsum(lens_bs.reshape(-1), out=bag_offs[1:])
-        d_bag = self._dev(bag_offs, torch.int32)
-        ids = torch.zeros(max(nnz, 1), dtype=torch.int32, device=self.dev)
 
-        # ---- 3. id emission on the device --------------------------------------------------------------------
+        # ---- 3. everything the emission kernels read: one packed host buffer, one copy ----------------------------
         def csr(cnt):
             o = np.zeros(B + 1, dtype=np.int32)
             np.cumsum(cnt, out=o[1:])
-            return self._dev(o, torch.int32)
+            return o
 
-        keep_alive = [d_bytes, d_offs, fp, d_bag]
+        stg = _Stage()
+        h_bag = stg.add(bag_offs, np.int32)
+        todo = []
         for i, kind, payload in emit:
-            s = plan.slots[i]
             if kind == "hash":
                 base, fo, ntok = payload
-                d_fo = self._dev(fo, torch.int32)
-                keep_alive.append(d_fo)
-                call("wd_emit_hash_slot", fp.data_ptr() + 8 * base, ptr(d_fo), B, s.num_buckets, ptr(d_bag), S, i, ptr(ids), st)
+                todo.append((i, kind, (base, stg.add(fo, np.int32))))
             elif kind == "int":
                 vals, cnt = payload
-                d_v = self._dev(vals if len(vals) else np.zeros(1, np.int32), torch.int32)
-                d_fo = csr(cnt)
-                keep_alive += [d_v, d_fo]
-                call("wd_emit_int_slot", ptr(d_v), ptr(d_fo), B, ptr(d_bag), S, i, ptr(ids), st)
+                todo.append((i, kind, (stg.add(vals if len(vals) else np.zeros(1, np.int32), np.int32), stg.add(csr(cnt), np.int32))))
+            else:
+                if len(payload) > capi.WD_MAX_CROSS_KEYS:
+                    raise ValueError("crossed column `%s` has more than %d keys" % (plan.slots[i].name, capi.WD_MAX_CROSS_KEYS))
+                todo.append((i, kind, [(vk, stg.add(v if len(v) else np.zeros(1, np.int64), np.int64), stg.add(csr(cnt), np.int32))
+                                       for vk, v, cnt in payload]))
+        nd = len(plan.dense_cols)
+        h_dense = stg.add(np.stack([raw.floats[d.feature] for d in plan.dense_cols], axis=1), np.float32) if nd else None
+        h_lab = stg.add(raw.labels, np.float32) if raw.labels is not None else None
+        use_w = raw.weights is not None and self.engine.spec.use_weight_column
+        h_wts = stg.add(raw.weights, np.float32) if use_w else None
+        dv = stg.upload(self.dev)
+        d_bag = dv[h_bag]
+        ids = torch.zeros(max(nnz, 1), dtype=torch.int32, device=self.dev)
+
+        # ---- 4. id emission on the device --------------------------------------------------------------------
+        keep_alive = [d_bytes, d_offs, fp, stg.dbuf]
+        for i, kind, payload in todo:
+            s = plan.slots[i]
+            if kind == "hash":
+                base, h_fo = payload
+                call("wd_emit_hash_slot", fp.data_ptr() + 8 * base, ptr(dv[h_fo]), B, s.num_buckets, ptr(d_bag), S, i, ptr(ids), st)
+            elif kind == "int":
+                h_v, h_fo = payload
+                call("wd_emit_int_slot", ptr(dv[h_v]), ptr(dv[h_fo]), B, ptr(d_bag), S, i, ptr(ids), st)
             else:
                 ck = capi.WdCrossKeys()
                 ck.nkeys = len(payload)
-                if ck.nkeys > capi.WD_MAX_CROSS_KEYS:
-                    raise ValueError("crossed column `%s` has more than %d keys" % (s.name, capi.WD_MAX_CROSS_KEYS))
-                for k, (vk, v, cnt) in enumerate(payload):
-                    if vk == "fp":
-                        gi = self._dev(v if len(v) else np.zeros(1, np.int64), torch.int64)
-                        d_v = fp[gi]                                        # fingerprints incl. '' padding
-                    else:
-                        d_v = self._dev(v if len(v) else np.zeros(1, np.int64), torch.int64)
-                    d_fo = csr(cnt)
-                    keep_alive += [d_v, d_fo]
-                    ck.vals[k], ck.offs[k] = d_v.data_ptr(), d_fo.data_ptr()
+                for k, (vk, h_v, h_fo) in enumerate(payload):
+                    d_v = fp[dv[h_v]] if vk == "fp" else dv[h_v]           # "fp": gather of fingerprints incl. '' padding
+                    keep_alive.append(d_v)
+                    ck.vals[k], ck.offs[k] = d_v.data_ptr(), dv[h_fo].data_ptr()
                 call("wd_cross_hash", ctypes.byref(ck), B, s.hash_key, s.num_buckets, ptr(d_bag), S, i, ptr(ids), st)
 
-        nd = len(plan.dense_cols)
-        dense = None
-        if nd:
-            dense = self._dev(np.stack([raw.floats[d.feature] for d in plan.dense_cols], axis=1).astype(np.float32), torch.float32)
-        labels = self._dev(raw.labels, torch.float32) if raw.labels is not None else None
-        weights = self._dev(raw.weights, torch.float32) if (raw.weights is not None and self.engine.spec.use_weight_column) else None
+        dense = dv[h_dense].view(B, nd) if nd else None
+        labels = dv[h_lab] if h_lab is not None else None
+        weights = dv[h_wts] if h_wts is not None else None
         bt = DeviceBatch(B, ids, d_bag, dense, labels, weights, nnz=nnz, one_hot=bool((lens_bs == 1).all()))
         bt._keep = keep_alive   # the emission kernels are asynchronous
         return bt

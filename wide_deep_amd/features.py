@@ -49,14 +49,22 @@ _NP2T = {np.dtype(np.int32): torch.int32, np.dtype(np.int64): torch.int64, np.dt
          np.dtype(np.uint8): torch.uint8}
 
 
+ONES = object()    # count vector of a single-valued column (every example has exactly one value)
+
+
 class _Stage(object):
     """Host arrays of one batch packed into ONE buffer and moved with ONE host-to-device copy (a batch of the repo-default
     conf needs ~230 small arrays: CSR offsets, values and gather indices per slot and per cross key)."""
 
     def __init__(self):
-        self.items, self.size = [], 0
+        self.items, self.size, self.seen, self.refs = [], 0, {}, []
 
     def add(self, arr, dtype):
+        key = (id(arr), np.dtype(dtype))
+        if key in self.seen:                      # the same host array staged once (callers keep it alive until upload)
+            return self.seen[key]
+        self.seen[key] = len(self.items)
+        self.refs.append(arr)                     # pins id(arr) for the life of the stage
         a = np.ascontiguousarray(arr, dtype=dtype)
         off = (self.size + 15) // 16 * 16
         self.items.append((off, a))
@@ -67,10 +75,18 @@ class _Stage(object):
         host = np.zeros(max(self.size, 16), dtype=np.uint8)
         for off, a in self.items:
             host[off: off + a.nbytes] = a.reshape(-1).view(np.uint8)
-        dbuf = torch.from_numpy(host).to(dev, non_blocking=True)
-        self.dbuf = dbuf
-        return [dbuf[off: off + a.nbytes].view(_NP2T[a.dtype]) if a.nbytes else
-                torch.zeros(0, dtype=_NP2T[a.dtype], device=dev) for off, a in self.items]
+        self.dbuf = torch.from_numpy(host).to(dev, non_blocking=True)
+        self.base = self.dbuf.data_ptr()
+
+    def ptr(self, h):
+        """device address of array h (what the C ABI takes)"""
+        return ctypes.c_void_p(self.base + self.items[h][0])
+
+    def tensor(self, h):
+        off, a = self.items[h]
+        if not a.nbytes:
+            return torch.zeros(0, dtype=_NP2T[a.dtype], device=self.dbuf.device)
+        return self.dbuf[off: off + a.nbytes].view(_NP2T[a.dtype])
 
 
 class Featurizer(object):
@@ -134,18 +150,24 @@ class Featurizer(object):
         # ---- 2. bag lengths per (example, slot) on the host --------------------------------------------------
         lens_bs = np.zeros((B, S), dtype=np.int64)
         emit = []   # (slot, kind, payload)
+        lens_cache, str_keys = {}, {}
+
+        def lens_of(feature):
+            if feature not in lens_cache:
+                lens_cache[feature] = np.diff(raw.cat[feature].ex_offs).astype(np.int64)
+            return lens_cache[feature]
         for i, s in enumerate(plan.slots):
             if s.kind == "hash":
                 pc = raw.cat[s.feature]
                 fo = pc.ex_offs
-                lens_bs[:, i] = np.diff(fo)
+                lens_bs[:, i] = lens_of(s.feature)
                 emit.append((i, "hash", (pc.base, fo, pc.n)))
             elif s.kind == "vocab":
                 pc = raw.cat[s.feature]
                 fo = pc.ex_offs
                 idx = self._vocab_lookup(i, pc)
                 keep = idx >= 0
-                ex_of = np.repeat(np.arange(B), np.diff(fo))
+                ex_of = np.repeat(np.arange(B), lens_of(s.feature))
                 cnt = np.bincount(ex_of[keep], minlength=B).astype(np.int64)
                 lens_bs[:, i] = cnt
                 emit.append((i, "int", (idx[keep], cnt)))
@@ -154,42 +176,44 @@ class Featurizer(object):
                 keep = v != -1                                   # -1 is the int ignore_value of the sparse conversion
                 vals = np.where((v >= 0) & (v < s.num_buckets), v, 0).astype(np.int32)
                 lens_bs[:, i] = keep
-                emit.append((i, "int", (vals[keep], keep.astype(np.int64))))
+                emit.append((i, "int", (vals[keep], ONES if keep.all() else keep.astype(np.int64))))
             elif s.kind == "bucket":
                 x = _normalize(raw.floats[s.feature], s.normalizer)
                 lens_bs[:, i] = 1
-                emit.append((i, "int", (_bucketize(x, s.boundaries), np.ones(B, np.int64))))
+                emit.append((i, "int", (_bucketize(x, s.boundaries), ONES)))
             elif s.kind == "cross":
-                cnt = np.ones(B, dtype=np.int64)
+                cnt = ONES
                 keys = []
                 for k in s.cross_keys:
                     if k.kind == "string":
-                        pc = raw.cat[k.feature]
-                        fo = pc.ex_offs
-                        real = np.diff(fo).astype(np.int64)
-                        if self.cross_padding == "tf_dense":
-                            lmax = int(real.max()) if B else 0
-                            kc = np.full(B, lmax, dtype=np.int64)
-                            # gather indices into fp: real tokens then the '' fingerprint up to lmax
-                            col = np.arange(lmax)[None, :]
-                            gi = np.where(col < real[:, None], tok_base[k.feature] + fo[:-1, None] + col, empty_index)
-                            keys.append(("fp", gi.reshape(-1), kc))
-                        else:
-                            gi = tok_base[k.feature] + np.arange(pc.n)
-                            keys.append(("fp", gi, real))
-                            kc = real
+                        if k.feature not in str_keys:            # the same feature is a key of several crossed columns
+                            pc = raw.cat[k.feature]
+                            fo = pc.ex_offs
+                            real = lens_of(k.feature)
+                            if self.cross_padding == "tf_dense":
+                                lmax = int(real.max()) if B else 0
+                                kc = ONES if lmax == 1 else np.full(B, lmax, dtype=np.int64)
+                                # gather indices into fp: real tokens then the '' fingerprint up to lmax
+                                col = np.arange(lmax)[None, :]
+                                gi = np.where(col < real[:, None], tok_base[k.feature] + fo[:-1, None] + col, empty_index)
+                                str_keys[k.feature] = (gi.reshape(-1), kc)
+                            else:
+                                str_keys[k.feature] = (tok_base[k.feature] + np.arange(pc.n), real)
+                        gi, kc = str_keys[k.feature]
+                        keys.append(("fp", gi, kc))
                     elif k.kind == "identity":
                         v = raw.ints[k.feature]
                         keep = v != -1
                         vals = np.where((v >= 0) & (v < k.num_buckets), v, 0).astype(np.int64)
-                        kc = keep.astype(np.int64)
+                        kc = ONES if keep.all() else keep.astype(np.int64)
                         keys.append(("int", vals[keep], kc))
                     else:   # bucketized raw value (un-normalised numeric column inside crosses, quirk C.5)
                         vals = _bucketize(raw.floats[k.feature], k.boundaries).astype(np.int64)
-                        kc = np.ones(B, dtype=np.int64)
+                        kc = ONES
                         keys.append(("int", vals, kc))
-                    cnt = cnt * kc
-                lens_bs[:, i] = cnt
+                    if kc is not ONES:
+                        cnt = kc if cnt is ONES else cnt * kc
+                lens_bs[:, i] = 1 if cnt is ONES else cnt
                 emit.append((i, "cross", keys))
             else:
                 raise ValueError("unknown slot kind %s" % s.kind)
@@ -201,13 +225,16 @@ class Featurizer(object):
         np.cumsum(lens_bs.reshape(-1), out=bag_offs[1:])
 
         # ---- 3. everything the emission kernels read: one packed host buffer, one copy ----------------------------
-        def csr(cnt):
-            o = np.zeros(B + 1, dtype=np.int32)
-            np.cumsum(cnt, out=o[1:])
-            return o
-
         stg = _Stage()
         h_bag = stg.add(bag_offs, np.int32)
+        h_iota = stg.add(np.arange(B + 1, dtype=np.int32), np.int32)     # CSR offsets of every single-valued column
+
+        def csr(cnt):
+            if cnt is ONES:
+                return h_iota
+            o = np.zeros(B + 1, dtype=np.int32)
+            np.cumsum(cnt, out=o[1:])
+            return stg.add(o, np.int32)
         todo = []
         for i, kind, payload in emit:
             if kind == "hash":
@@ -215,43 +242,49 @@ class Featurizer(object):
                 todo.append((i, kind, (base, stg.add(fo, np.int32))))
             elif kind == "int":
                 vals, cnt = payload
-                todo.append((i, kind, (stg.add(vals if len(vals) else np.zeros(1, np.int32), np.int32), stg.add(csr(cnt), np.int32))))
+                todo.append((i, kind, (stg.add(vals if len(vals) else np.zeros(1, np.int32), np.int32), csr(cnt))))
             else:
                 if len(payload) > capi.WD_MAX_CROSS_KEYS:
                     raise ValueError("crossed column `%s` has more than %d keys" % (plan.slots[i].name, capi.WD_MAX_CROSS_KEYS))
-                todo.append((i, kind, [(vk, stg.add(v if len(v) else np.zeros(1, np.int64), np.int64), stg.add(csr(cnt), np.int32))
+                todo.append((i, kind, [(vk, stg.add(v if len(v) else np.zeros(1, np.int64), np.int64), csr(cnt))
                                        for vk, v, cnt in payload]))
         nd = len(plan.dense_cols)
         h_dense = stg.add(np.stack([raw.floats[d.feature] for d in plan.dense_cols], axis=1), np.float32) if nd else None
         h_lab = stg.add(raw.labels, np.float32) if raw.labels is not None else None
         use_w = raw.weights is not None and self.engine.spec.use_weight_column
         h_wts = stg.add(raw.weights, np.float32) if use_w else None
-        dv = stg.upload(self.dev)
-        d_bag = dv[h_bag]
+        stg.upload(self.dev)
+        d_bag = stg.tensor(h_bag)
         ids = torch.zeros(max(nnz, 1), dtype=torch.int32, device=self.dev)
 
         # ---- 4. id emission on the device --------------------------------------------------------------------
         keep_alive = [d_bytes, d_offs, fp, stg.dbuf]
+        p_bag, p_ids = ptr(d_bag), ptr(ids)
+        gathered = {}
         for i, kind, payload in todo:
             s = plan.slots[i]
             if kind == "hash":
                 base, h_fo = payload
-                call("wd_emit_hash_slot", fp.data_ptr() + 8 * base, ptr(dv[h_fo]), B, s.num_buckets, ptr(d_bag), S, i, ptr(ids), st)
+                call("wd_emit_hash_slot", fp.data_ptr() + 8 * base, stg.ptr(h_fo), B, s.num_buckets, p_bag, S, i, p_ids, st)
             elif kind == "int":
                 h_v, h_fo = payload
-                call("wd_emit_int_slot", ptr(dv[h_v]), ptr(dv[h_fo]), B, ptr(d_bag), S, i, ptr(ids), st)
+                call("wd_emit_int_slot", stg.ptr(h_v), stg.ptr(h_fo), B, p_bag, S, i, p_ids, st)
             else:
                 ck = capi.WdCrossKeys()
                 ck.nkeys = len(payload)
                 for k, (vk, h_v, h_fo) in enumerate(payload):
-                    d_v = fp[dv[h_v]] if vk == "fp" else dv[h_v]           # "fp": gather of fingerprints incl. '' padding
-                    keep_alive.append(d_v)
-                    ck.vals[k], ck.offs[k] = d_v.data_ptr(), dv[h_fo].data_ptr()
-                call("wd_cross_hash", ctypes.byref(ck), B, s.hash_key, s.num_buckets, ptr(d_bag), S, i, ptr(ids), st)
+                    if vk == "fp":                                 # gather of fingerprints incl. '' padding
+                        if h_v not in gathered:
+                            gathered[h_v] = fp[stg.tensor(h_v)]
+                        ck.vals[k] = gathered[h_v].data_ptr()
+                    else:
+                        ck.vals[k] = stg.ptr(h_v).value
+                    ck.offs[k] = stg.ptr(h_fo).value
+                call("wd_cross_hash", ctypes.byref(ck), B, s.hash_key, s.num_buckets, p_bag, S, i, p_ids, st)
 
-        dense = dv[h_dense].view(B, nd) if nd else None
-        labels = dv[h_lab] if h_lab is not None else None
-        weights = dv[h_wts] if h_wts is not None else None
+        dense = stg.tensor(h_dense).view(B, nd) if nd else None
+        labels = stg.tensor(h_lab) if h_lab is not None else None
+        weights = stg.tensor(h_wts) if h_wts is not None else None
         bt = DeviceBatch(B, ids, d_bag, dense, labels, weights, nnz=nnz, one_hot=bool((lens_bs == 1).all()))
-        bt._keep = keep_alive   # the emission kernels are asynchronous
+        bt._keep = keep_alive + list(gathered.values())   # the emission kernels are asynchronous
         return bt

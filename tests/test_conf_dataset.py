@@ -251,3 +251,35 @@ def test_every_reference_optimizer_name_and_constructor_parses():
         parse_optimizer("Adadelta", 0.1)
     with pytest.raises(NotImplementedError):
         opt_tuple(*parse_optimizer("tf.train.RMSPropOptimizer(0.1, centered=True)", 0.05))
+
+
+def test_prefetch_keeps_order_content_errors_and_stops_early():
+    """input pipeline tail of the reference (dataset.prefetch, python/lib/dataset.py:185): batches parsed ahead on a thread"""
+    import threading, time
+    a = list(DS.input_fn(FIXTURE, None, "train", 64, prefetch=0))
+    b = list(DS.input_fn(FIXTURE, None, "train", 64, prefetch=2))
+    assert len(a) == len(b) == 9
+    for x, y in zip(a, b):
+        assert x.B == y.B and np.array_equal(x.labels, y.labels) and np.array_equal(x.tok_bytes, y.tok_bytes)
+        assert all(np.array_equal(x.ints[k], y.ints[k]) for k in x.ints) and all(np.array_equal(x.floats[k], y.floats[k]) for k in x.floats)
+
+    def boom():
+        yield 1
+        raise RuntimeError("bad line")
+    it = DS.prefetched(boom())
+    assert next(it) == 1
+    with pytest.raises(RuntimeError, match="bad line"):
+        next(it)
+
+    produced = []
+
+    def slow():
+        for i in range(1000):
+            produced.append(i)
+            yield i
+    n0 = threading.active_count()
+    it = DS.prefetched(slow(), depth=2)
+    assert [next(it), next(it)] == [0, 1]
+    it.close()                                   # the consumer stops early (train(steps=...)): the producer thread ends
+    time.sleep(0.3)
+    assert len(produced) <= 6 and threading.active_count() == n0

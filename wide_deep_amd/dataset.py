@@ -308,8 +308,50 @@ def _buffer_shuffle(n, buffer_size, seed):
     return out
 
 
-def input_fn(csv_data_file, img_data_file, mode, batch_size, conf=None):
-    """Reference signature (python/lib/dataset.py:293-310).  Returns an iterator of RawBatch."""
+def prefetched(gen, depth=2):
+    """The reference ends its tf.data pipeline with `.prefetch(...)` (python/lib/dataset.py:185, 281): batches are parsed ahead of
+    the consumer.  Here: a producer thread runs the generator `depth` batches ahead (the C ingest runs without the GIL), so
+    the TSV parse overlaps the featurizer and the train step of the previous batch.  Order and content are unchanged."""
+    import threading, queue
+    q, stop, END = queue.Queue(maxsize=depth), threading.Event(), object()
+
+    def put(item):
+        while not stop.is_set():
+            try:
+                q.put(item, timeout=0.05)
+                return True
+            except queue.Full:
+                pass
+        return False
+
+    def work():
+        try:
+            for item in gen:
+                if not put((item, None)):
+                    return
+            put((END, None))
+        except BaseException as e:      # surfaces in the consumer
+            put((END, e))
+
+    threading.Thread(target=work, daemon=True).start()
+    try:
+        while True:
+            item, err = q.get()
+            if item is END:
+                if err is not None:
+                    raise err
+                return
+            yield item
+    finally:
+        stop.set()
+
+
+def input_fn(csv_data_file, img_data_file, mode, batch_size, conf=None, prefetch=None):
+    """Reference signature (python/lib/dataset.py:293-310).  Returns an iterator of RawBatch.
+    prefetch: batches parsed ahead on a thread (default 2, env WD_PREFETCH; 0 = parse in the consumer's thread)."""
+    if prefetch is None:
+        prefetch = int(os.environ.get("WD_PREFETCH", "2"))
     if img_data_file:
         raise NotImplementedError("image input (cnn tower) is out of scope of this engine (SURVEY section 2, row 14)")
-    return CsvDataset(csv_data_file, conf).input_fn(mode, batch_size)
+    it = CsvDataset(csv_data_file, conf).input_fn(mode, batch_size)
+    return prefetched(it, prefetch) if prefetch else it

@@ -257,16 +257,16 @@ def test_prefetch_keeps_order_content_errors_and_stops_early():
     """input pipeline tail of the reference (dataset.prefetch, python/lib/dataset.py:185): batches parsed ahead on a thread"""
     import threading, time
     a = list(DS.input_fn(FIXTURE, None, "train", 64, prefetch=0))
-    b = list(DS.input_fn(FIXTURE, None, "train", 64, prefetch=2))
+    b = list(DS.input_fn(FIXTURE, None, "train", 64, prefetch=2))      # 2+ batches in flight on a thread pool
     assert len(a) == len(b) == 9
     for x, y in zip(a, b):
         assert x.B == y.B and np.array_equal(x.labels, y.labels) and np.array_equal(x.tok_bytes, y.tok_bytes)
         assert all(np.array_equal(x.ints[k], y.ints[k]) for k in x.ints) and all(np.array_equal(x.floats[k], y.floats[k]) for k in x.floats)
 
     def boom():
-        yield 1
-        raise RuntimeError("bad line")
-    it = DS.prefetched(boom())
+        yield lambda: 1
+        yield lambda: (_ for _ in ()).throw(RuntimeError("bad line"))
+    it = DS.prefetched(boom(), depth=1)
     assert next(it) == 1
     with pytest.raises(RuntimeError, match="bad line"):
         next(it)
@@ -276,10 +276,14 @@ def test_prefetch_keeps_order_content_errors_and_stops_early():
     def slow():
         for i in range(1000):
             produced.append(i)
-            yield i
+            yield lambda i=i: i
     n0 = threading.active_count()
-    it = DS.prefetched(slow(), depth=2)
+    it = DS.prefetched(slow(), depth=4, workers=3)
     assert [next(it), next(it)] == [0, 1]
-    it.close()                                   # the consumer stops early (train(steps=...)): the producer thread ends
-    time.sleep(0.3)
-    assert len(produced) <= 6 and threading.active_count() == n0
+    it.close()                                   # the consumer stops early (train(steps=...)): the pool is shut down
+    time.sleep(0.1)
+    assert len(produced) <= 8 and threading.active_count() == n0
+    # results come back in submission order whatever the completion order
+    import random
+    jobs = [(lambda i=i: (time.sleep(random.random() * 0.01), i)[1]) for i in range(40)]
+    assert list(DS.prefetched(iter(jobs), depth=8, workers=4)) == list(range(40))

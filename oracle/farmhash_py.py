@@ -3,9 +3,12 @@
 Second, independent pure-Python transcription of TF ``Fingerprint64``
 (= FarmHash ``farmhashna::Hash64``) and ``FingerprintCat64``, written from the
 prose description in SURVEY.md Appendix A.1/A.3 rather than from
-``wd_oracle.c``.  It exists to cross-check the C restatement on the length
-branches (17-32, 33-64, >64 bytes) for which no upstream known-answer vector is
-available offline ("parity unpinned" for those branches).
+``wd_oracle.c``.  It cross-checks the C restatement on every length branch.
+Both are pinned by published known answers of this function (tests/helpers.py:
+Guava FarmHashFingerprint64Test incl. the 3200-message chain over lengths
+0..3199, BigQuery FARM_FINGERPRINT doc examples), by the upstream-TF vectors in
+tests/golden/kat_hash.json and by a compiled CityHash64 for <= 32 bytes
+(tests/golden/kat_city_le32.json).
 
 Reference call sites that select this arithmetic:
 python/lib/build_estimator.py:86-88 (hash buckets) and :138-155 (crosses).

@@ -21,10 +21,13 @@
  * (python/lib/wide_deep_test.py:80-85 only checks loss-down/auc-up).  The
  * integer functions are pinned against upstream-TF known answers
  * (tests/golden/kat_hash.json; Fingerprint64 of strings <= 16 bytes,
- * hash-bucket ids, hashed crosses).  Fingerprint64 for strings > 16 bytes has
- * no known-answer vector available offline: "parity unpinned" for those
- * branches; two independent transcriptions (this file and
- * oracle/farmhash_py.py) are cross-checked instead.
+ * hash-bucket ids, hashed crosses).  Fingerprint64 for strings > 16 bytes is
+ * pinned by published known answers of the same function outside TF (Guava's
+ * FarmHashFingerprint64Test: 32- and 256-byte strings and the 3200-message
+ * chain over lengths 0..3199; tests/helpers.py) and, up to 32 bytes, by a
+ * compiled CityHash64 (tests/golden/kat_city_le32.json); a second independent
+ * transcription (oracle/farmhash_py.py) is cross-checked as well.  The fp32
+ * semantics stay "parity unpinned" against TF itself.
  *
  * Build: oracle/build.sh  (gcc -O2 -fopenmp -shared -fPIC) -> oracle/_build/libwd_oracle.so
  */

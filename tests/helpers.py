@@ -75,3 +75,42 @@ def assert_close(a, b, rtol, atol, what=""):
     bad = err > tol
     assert not bool(bad.any()), "%s: %d/%d out of tolerance, max abs err %.3e (rtol %g atol %g)" % (
         what, int(bad.sum()), a.numel(), float(err.max()), rtol, atol)
+
+
+# ---- published Fingerprint64 known answers that cover EVERY length branch ---------------------------------------------
+# Guava's FarmHashFingerprint64Test (Hashing.farmHashFingerprint64() == farmhashna::Hash64 == TF's Fingerprint64):
+#   testReallySimpleFingerprints: "test" -> 8581389452482819506, "test"*8 -> -4196240717365766262, "test"*64 -> 3500507768004279527
+#   testMultipleLengths: 3200 chained fingerprints of prefixes 0..3200 bytes long fold to 0x7a1d67c50ec7e167
+# BigQuery FARM_FINGERPRINT documentation example: "1footrue" -> -1541654101129638711, "2applefalse" -> 2794438866806483259,
+#   "3true" -> -4880158226897771312
+GUAVA_SIMPLE = [(b"test", 8581389452482819506), (b"test" * 8, -4196240717365766262 + (1 << 64)),
+                (b"test" * 64, 3500507768004279527)]
+BIGQUERY_DOC = [(b"1footrue", -1541654101129638711 + (1 << 64)), (b"2applefalse", 2794438866806483259),
+                (b"3true", -4880158226897771312 + (1 << 64))]
+GUAVA_MULTIPLE_LENGTHS = 0x7a1d67c50ec7e167
+
+
+def guava_multiple_lengths(fp, record=None):
+    """The chain of Guava's testMultipleLengths over a fingerprint function `fp(bytes) -> uint64`; every message hashed is
+    appended to `record` (so a device kernel can hash the same 3200 messages in one launch and the chain be replayed)."""
+    M = (1 << 64) - 1
+
+    def step(h, msg):
+        if record is not None:
+            record.append(msg)
+        h ^= fp(msg)
+        h ^= h >> 41
+        h = (h * 949921979) & M
+        return h, ord("a") + ((h & 0xfffff) % 26)
+
+    iterations = 800
+    buf, n, h = bytearray(iterations * 4), 0, 0
+    for i in range(iterations):
+        for ln in (lambda: i, lambda: i * i % n, lambda: i * i * i % n, lambda: n):
+            h, c = step(h, bytes(buf[: ln()]))
+            buf[n] = c
+            n += 1
+        x0, x1, x2, x3 = buf[n - 1], buf[n - 2], buf[n - 3], buf[n // 2]
+        buf[((x0 << 16) + (x1 << 8) + x2) % n] ^= x3
+        buf[((x1 << 16) + (x2 << 8) + x3) % n] ^= i % 256
+    return h

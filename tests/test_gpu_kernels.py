@@ -52,6 +52,36 @@ def test_golden_kat_on_device():
     assert out.cpu().numpy().view(np.uint64).tolist() == [g["fingerprint64"][t] for t in toks]
 
 
+def test_cityhash_le32_vectors_on_device():
+    """17..32-byte branch against the independent CityHash64 build (tests/golden/kat_city_le32.json)"""
+    import json
+    from wide_deep_amd.capi import call, ptr
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "kat_city_le32.json")))["vectors"]
+    toks = [bytes.fromhex(hx) for hx, _ in g]
+    data, offs = O.pack_tokens(toks)
+    out = torch.zeros(len(toks), dtype=torch.int64, device="cuda")
+    d, o = _dev(data, torch.uint8), _dev(offs, torch.int32)
+    call("wd_fingerprint64", ptr(d), ptr(o), len(toks), ptr(out), torch.cuda.current_stream().cuda_stream)
+    assert out.cpu().numpy().view(np.uint64).tolist() == [e for _, e in g]
+
+
+def test_published_fingerprint_chain_on_device():
+    """Guava's testMultipleLengths (3200 chained fingerprints, lengths 0..3199, every branch) folded from DEVICE results"""
+    from tests.helpers import GUAVA_SIMPLE, BIGQUERY_DOC, GUAVA_MULTIPLE_LENGTHS, guava_multiple_lengths
+    from wide_deep_amd.capi import call, ptr
+    rec = []
+    guava_multiple_lengths(O.fingerprint64, rec)
+    toks = rec + [s for s, _ in GUAVA_SIMPLE + BIGQUERY_DOC]
+    data, offs = O.pack_tokens(toks)
+    out = torch.zeros(len(toks), dtype=torch.int64, device="cuda")
+    d, o = _dev(data, torch.uint8), _dev(offs, torch.int32)
+    call("wd_fingerprint64", ptr(d), ptr(o), len(toks), ptr(out), torch.cuda.current_stream().cuda_stream)
+    got = out.cpu().numpy().view(np.uint64).tolist()
+    it = iter(got[:3200])
+    assert guava_multiple_lengths(lambda m: next(it)) == GUAVA_MULTIPLE_LENGTHS
+    assert got[3200:] == [e for _, e in GUAVA_SIMPLE + BIGQUERY_DOC]
+
+
 def _engine(spec, **kw):
     from wide_deep_amd.engine import WideDeepEngine
     return WideDeepEngine(spec, **kw)

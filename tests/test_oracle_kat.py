@@ -26,6 +26,40 @@ def test_fingerprint64_kat():
         assert F.fingerprint64(s.encode()) == exp
 
 
+def test_fingerprint64_le32_bytes_against_independent_cityhash_build():
+    """farmhashna::Hash64 == CityHash64 v1.1 for len <= 32 (shared HashLen0to16 / HashLen17to32): vectors produced by abseil's
+    compiled CityHash64 (tests/golden/make_city_vectors.py) pin the 17..32-byte branch that no TF known answer covers."""
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "kat_city_le32.json")))["vectors"]
+    lens = set()
+    for hx, exp in g:
+        s = bytes.fromhex(hx)
+        lens.add(len(s))
+        assert O.fingerprint64(s) == exp, len(s)
+        assert F.fingerprint64(s) == exp, len(s)
+    assert lens >= set(range(0, 33))
+    toks = [bytes.fromhex(hx) for hx, _ in g]
+    data, offs = O.pack_tokens(toks)
+    assert O.fingerprint64_batch(data, offs).tolist() == [e for _, e in g]
+
+
+def test_fingerprint64_published_answers_cover_every_length_branch():
+    """Guava FarmHashFingerprint64Test + BigQuery FARM_FINGERPRINT doc examples (tests/helpers.py): 4 / 32 / 256-byte
+    strings and the 3200-message chain over lengths 0..3200 -- the 33..64-byte and > 64-byte branches included."""
+    from tests.helpers import GUAVA_SIMPLE, BIGQUERY_DOC, GUAVA_MULTIPLE_LENGTHS, guava_multiple_lengths
+    for s, exp in GUAVA_SIMPLE + BIGQUERY_DOC:
+        assert O.fingerprint64(s) == exp and F.fingerprint64(s) == exp
+    rec = []
+    assert guava_multiple_lengths(O.fingerprint64, rec) == GUAVA_MULTIPLE_LENGTHS
+    lens = {len(m) for m in rec}
+    assert len(rec) == 3200 and lens >= set(range(0, 800)) and max(lens) == 3199
+    # the independent Python transcription on the same messages (batch C path too)
+    data, offs = O.pack_tokens(rec)
+    fps = O.fingerprint64_batch(data, offs).tolist()
+    assert all(F.fingerprint64(m) == f for m, f in list(zip(rec, fps))[::7])
+    it = iter(fps)
+    assert guava_multiple_lengths(lambda m: next(it)) == GUAVA_MULTIPLE_LENGTHS
+
+
 def test_hash_bucket_kat():
     for toks, exp in GOLD["hash_bucket_10"]:
         assert O.hash_bucket(toks, 10).tolist() == exp

@@ -186,8 +186,9 @@ def ftrl_dense(w, z, n, g, lr, l1, l2):
 #   Adam             dense: ApplyAdam  m += (g - m)(1 - b1); v += (g^2 - v)(1 - b2); var -= lr_t m / (sqrt(v) + eps)
 #                    sparse: AdamOptimizer._apply_sparse_shared  m = m b1 (WHOLE variable); m[rows] += (1 - b1) g; same for v;
 #                    var -= lr_t m / (sqrt(v) + eps) (WHOLE variable);  lr_t = lr sqrt(1 - b2^t) / (1 - b1^t)
-# No golden vectors exist for these (parity unpinned, like the rest of the TF semantics: SURVEY 8c); they are checked
-# against hand-computed cases in tests/test_oracle_kat.py.
+# No golden vectors exist for SGD / RMSProp / Adam (parity unpinned: SURVEY 8c); they are checked against hand-computed
+# cases in tests/test_oracle_kat.py.  Adagrad and Ftrl ARE pinned by the constants of TF's own optimizer tests
+# (tests/golden/kat_tf_fp32.json, tests/test_tf_known_answers.py).
 # Optimizer tuples: ("SGD", lr) ("Adagrad", lr, init) ("Ftrl", lr, l1, l2, init) ("RMSProp", lr, decay, momentum, eps)
 #                   ("Adam", lr, beta1, beta2, eps)
 # ---------------------------------------------------------------------------

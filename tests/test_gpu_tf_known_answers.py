@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 G = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "kat_tf_fp32.json")))
 
 
-def _opt_dense(opt, var, grad, steps):
+def _opt_dense(opt, var, grad, steps, each_step=None):
     from wide_deep_amd import capi
     from wide_deep_amd.capi import call, ptr
     from wide_deep_amd.plan import opt_params, opt_slot_init
@@ -25,8 +25,16 @@ def _opt_dense(opt, var, grad, steps):
     a = torch.full_like(w, 0.0 if ia is None else ia)
     b = torch.full_like(w, 0.0 if ib is None else ib)
     g = torch.tensor(grad, dtype=torch.float32, device="cuda")
-    for _ in range(steps):
-        call("wd_opt_dense", ptr(w), ptr(a), ptr(b), ptr(g), w.numel(), ctypes.byref(o), torch.cuda.current_stream().cuda_stream)
+    st = torch.cuda.current_stream().cuda_stream
+    if opt[0] == "Adam":
+        pw = torch.tensor([opt[2], opt[3]], dtype=torch.float32, device="cuda")     # beta^t of the step being applied
+        o.pow = pw.data_ptr()
+    for t in range(steps):
+        call("wd_opt_dense", ptr(w), ptr(a), ptr(b), ptr(g), w.numel(), ctypes.byref(o), st)
+        if opt[0] == "Adam":
+            call("wd_adam_tick", ptr(pw), float(opt[2]), float(opt[3]), st)
+        if each_step is not None:
+            each_step(t + 1, w.cpu().numpy())
     return w.cpu().numpy()
 
 
@@ -89,3 +97,23 @@ def test_engine_mean_combiner_and_wide_sum_match_tf_feature_column_tests():
     hb = {"B": B, "lens": lens, "raw": np.asarray(l["ids"], np.int64), "dense": None, "labels": np.zeros(B, np.float32)}
     logit = eng.forward(synth.to_device_ids(eng.plan, hb))
     np.testing.assert_allclose(logit.cpu().numpy(), l["expect"], rtol=1e-6)
+
+
+def test_dense_sgd_rmsprop_adam_kernels_match_tf_optimizer_tests():
+    s, r, a = G["sgd"], G["rmsprop"], G["adam"]
+    for c in s["cases"]:
+        np.testing.assert_allclose(_opt_dense(("SGD", s["lr"]), c["var"], c["grad"], s["steps"]), c["expect"], rtol=1e-6)
+    for c in r["cases"]:
+        got = _opt_dense(("RMSProp", r["lr"], r["decay"], r["momentum"], r["epsilon"]), c["var"], c["grad"], r["steps"])
+        np.testing.assert_allclose(got, c["expect"], atol=1e-5)
+    for c in a["cases"]:
+        ref = {"p": np.asarray(c["var"], np.float64), "m": 0.0, "v": 0.0}
+        g = np.asarray(c["grad"], np.float64)
+
+        def check(t, w):          # adam_update_numpy of TF's adam_test.py, step t
+            alpha_t = a["lr"] * np.sqrt(1 - a["beta2"] ** t) / (1 - a["beta1"] ** t)
+            ref["m"] = a["beta1"] * ref["m"] + (1 - a["beta1"]) * g
+            ref["v"] = a["beta2"] * ref["v"] + (1 - a["beta2"]) * g * g
+            ref["p"] = ref["p"] - alpha_t * ref["m"] / (np.sqrt(ref["v"]) + a["epsilon"])
+            np.testing.assert_allclose(w, ref["p"], rtol=1e-6)
+        _opt_dense(("Adam", a["lr"], a["beta1"], a["beta2"], a["epsilon"]), c["var"], c["grad"], a["steps"], check)

@@ -67,3 +67,63 @@ def test_streaming_auc_matches_tf_metrics_tests():
         m = binary_head_metrics(p, np.log(pc / (1 - pc)), y, w, 0, len(p))
         got = m["auc"] if c["curve"] == "ROC" else m["auc_precision_recall"]
         assert abs(got - c["expect"]) < 1e-3, c["name"]       # TF's own delta
+
+
+def test_sgd_rmsprop_and_adam_against_tf_optimizer_tests():
+    s = G["sgd"]
+    r = G["rmsprop"]
+    for rows in (False, True):
+        for c in s["cases"]:
+            np.testing.assert_allclose(_run(("SGD", s["lr"]), c["var"], c["grad"], s["steps"], rows), c["expect"], rtol=1e-6)
+        for c in r["cases"]:
+            got = _run(("RMSProp", r["lr"], r["decay"], r["momentum"], r["epsilon"]), c["var"], c["grad"], r["steps"], rows)
+            np.testing.assert_allclose(got, c["expect"], atol=1e-5)
+
+    def adam_update_numpy(param, g_t, t, m, v, alpha, beta1, beta2, epsilon):     # the oracle of TF's adam_test.py
+        alpha_t = alpha * np.sqrt(1 - beta2 ** t) / (1 - beta1 ** t)
+        m_t = beta1 * m + (1 - beta1) * g_t
+        v_t = beta2 * v + (1 - beta2) * g_t * g_t
+        return param - alpha_t * m_t / (np.sqrt(v_t) + epsilon), m_t, v_t
+
+    a = G["adam"]
+    opt = ("Adam", a["lr"], a["beta1"], a["beta2"], a["epsilon"])
+    for rows in (False, True):           # testSparse: every row has a gradient, so sparse == dense
+        for c in a["cases"]:
+            st = {"v": torch.tensor(c["var"]), "v/Adam": torch.zeros(2), "v/Adam_1": torch.zeros(2)}
+            g = torch.tensor(c["grad"])
+            p, m, v = np.asarray(c["var"], np.float64), 0.0, 0.0
+            pw = [a["beta1"], a["beta2"]]
+            for t in range(1, a["steps"] + 1):
+                if rows:
+                    O.opt_apply_rows(opt, st, "v", np.arange(2), g.reshape(-1, 1), pw)
+                else:
+                    O.opt_apply_dense(opt, st, "v", g, pw)
+                pw = [pw[0] * a["beta1"], pw[1] * a["beta2"]]
+                p, m, v = adam_update_numpy(p, np.asarray(c["grad"], np.float64), t, m, v, a["lr"], a["beta1"], a["beta2"], a["epsilon"])
+                np.testing.assert_allclose(st["v"].numpy(), p, rtol=1e-6)
+
+
+def test_bucketize_and_vocabulary_match_tf_tests():
+    from wide_deep_amd.features import _bucketize
+    b = G["bucketize"]
+    x = np.asarray(b["input"], np.float32)
+    assert _bucketize(x.reshape(-1), b["boundaries"]).reshape(x.shape).tolist() == b["expect"]
+    assert np.asarray(O.bucketize(x.reshape(-1), b["boundaries"])).reshape(x.shape).tolist() == b["expect"]
+    v = G["vocabulary"]
+    vm = {t: i for i, t in enumerate(v["vocab"])}
+    assert [vm.get(t, -1) for t in v["values"]] == v["expect"]
+    # the C lookup of the ingest library (wide_deep_amd/csrc/tsv_ingest.c) on the same tokens
+    import ctypes
+    from wide_deep_amd.dataset import ingest_lib
+    L = ingest_lib()
+    if L is not None:
+        toks = [t.encode() for t in v["values"]]
+        to = np.zeros(len(toks) + 1, np.int32); np.cumsum([len(t) for t in toks], out=to[1:])
+        tb = np.frombuffer(b"".join(toks) + b"\0", np.uint8).copy()
+        vs = [t.encode() for t in v["vocab"]]
+        vo = np.zeros(len(vs) + 1, np.int32); np.cumsum([len(t) for t in vs], out=vo[1:])
+        vb = np.frombuffer(b"".join(vs) + b"\0", np.uint8).copy()
+        out = np.zeros(len(toks), np.int32)
+        P = lambda a: ctypes.c_void_p(a.ctypes.data)
+        L.wd_vocab_lookup(P(tb), P(to), ctypes.c_int64(0), ctypes.c_int64(len(toks)), P(vb), P(vo), ctypes.c_int32(len(vs)), P(out))
+        assert out.tolist() == v["expect"]

@@ -54,12 +54,17 @@ def lib():
     return _lib
 
 
+class _Ptr(ctypes.c_void_p):
+    """address of an array / tensor that also OWNS a reference to it: `_p(x.contiguous())` or `_p(np.ascontiguousarray(x))`
+    may be handed a fresh copy that nothing else refers to -- it has to live until the C call returns."""
+
+
 def _p(a):
     if a is None:
         return None
-    if isinstance(a, torch.Tensor):
-        return ctypes.c_void_p(a.data_ptr())
-    return ctypes.c_void_p(a.ctypes.data)
+    p = _Ptr(a.data_ptr() if isinstance(a, torch.Tensor) else a.ctypes.data)
+    p.keep = a
+    return p
 
 
 # ---------------------------------------------------------------------------
@@ -89,7 +94,8 @@ def fingerprint64_batch(data, offs):
     data = np.ascontiguousarray(data)
     if data.size == 0:
         data = np.zeros(1, np.uint8)
-    lib().wdo_fingerprint64_batch(_p(data), _p(np.ascontiguousarray(offs, dtype=np.int64)), ctypes.c_int64(n), _p(out))
+    offs = np.ascontiguousarray(offs, dtype=np.int64)      # named: the converted copy must outlive the call
+    lib().wdo_fingerprint64_batch(_p(data), _p(offs), ctypes.c_int64(n), _p(out))
     return out
 
 

@@ -49,3 +49,30 @@ def test_ingest_library_exports_its_header():
     out = (ctypes.c_int64 * 8)()
     lib.wd_tsv_scan.restype = ctypes.c_int64
     assert lib.wd_tsv_scan(buf, ctypes.c_int64(len(buf)), out, ctypes.c_int64(7)) == 2 and list(out[:3]) == [0, 4, 8]
+
+
+def test_missing_extension_and_bad_arguments_fail_loudly(monkeypatch):
+    """No CPU fallback: without the HIP library the product path raises; with it, every entry point validates its arguments
+    BEFORE touching the device and reports through the status code + wd_last_error (checked here without a GPU)."""
+    import pytest
+    from wide_deep_amd import capi
+    monkeypatch.setattr(capi, "_lib", None)
+    monkeypatch.setattr(capi, "LIB_PATH", os.path.join(ROOT, "wide_deep_amd", "_lib", "no_such_lib.so"))
+    with pytest.raises(capi.WdError, match="There is no CPU fallback"):
+        capi.call("wd_fingerprint64", None, None, 1, None, None)
+    monkeypatch.undo()
+    capi.load()
+    with pytest.raises(capi.WdError, match=r"wd_fingerprint64 failed .*null pointer"):
+        capi.call("wd_fingerprint64", None, None, 4, None, None)
+    with pytest.raises(capi.WdError, match="slot out of range"):
+        capi.call("wd_emit_int_slot", 64, 64, 2, 64, 3, 7, 64, None)          # slot 7 of S = 3 (pointers never read)
+    with pytest.raises(capi.WdError, match="num_buckets out of range"):
+        capi.call("wd_emit_hash_slot", 64, 64, 2, 1 << 31, 64, 3, 0, 64, None)
+    o = capi.WdOpt()
+    o.kind = 99
+    with pytest.raises(capi.WdError, match="bad optimizer"):
+        capi.call("wd_opt_dense", 64, 64, 64, 64, 8, ctypes.byref(o), None)
+    o.kind = capi.WD_OPT_KINDS["Ftrl"]
+    with pytest.raises(capi.WdError, match="needs slot"):
+        capi.call("wd_opt_dense", 64, None, None, 64, 8, ctypes.byref(o), None)
+    assert b"needs slot" in capi.load().wd_last_error()

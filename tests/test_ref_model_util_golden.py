@@ -1,0 +1,64 @@
+"""CPU: optimizer / activation selection against golden behaviour obtained by EXECUTING the reference's
+python/lib/utils/model_util.py with a stub tensorflow (tests/golden/make_ref_model_util_golden.py ->
+tests/golden/ref_model_util.json): same accepted strings, same constructor arguments, same exception class and message."""
+import json
+import os
+
+import pytest
+
+from wide_deep_amd import build_estimator as BE
+from wide_deep_amd import capi
+
+G = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "ref_model_util.json")))
+CLS = {"AdagradOptimizer": "Adagrad", "AdamOptimizer": "Adam", "FtrlOptimizer": "Ftrl", "RMSPropOptimizer": "RMSProp",
+       "GradientDescentOptimizer": "SGD"}
+TF_DEFAULT_LR = {"Adam": 0.001}          # the only tf.train constructor on this path whose learning_rate has a default
+
+
+@pytest.mark.parametrize("case", G["optimizers"], ids=lambda c: "%s|%s" % (c["opt"][:40], c["learning_rate"]))
+def test_optimizer_strings_behave_like_the_reference(case):
+    exp = case["result"]
+    if "exception" in exp:
+        with pytest.raises(Exception) as ei:
+            BE.parse_optimizer(case["opt"], case["learning_rate"])
+        assert type(ei.value).__name__ == exp["exception"] and str(ei.value) == exp["message"]
+        return
+    if exp["class"] not in CLS:           # a tf.train optimizer the reference would accept and this engine does not build
+        with pytest.raises(ValueError, match="Unsupported optimizer option"):
+            BE.parse_optimizer(case["opt"], case["learning_rate"])
+        return
+    name, kw = BE.parse_optimizer(case["opt"], case["learning_rate"])
+    ref = dict(exp["kwargs"])
+    if exp["args"]:
+        ref["learning_rate"] = exp["args"][0]          # first positional argument of every tf.train optimizer
+        assert len(exp["args"]) == 1
+    assert name == CLS[exp["class"]]
+    if "learning_rate" not in ref:
+        ref["learning_rate"] = TF_DEFAULT_LR[name]
+    assert kw == ref
+    BE.opt_tuple(name, kw)                              # and the engine can build it
+
+
+@pytest.mark.parametrize("case", G["activations"], ids=lambda c: str(c["name"]))
+def test_activation_names_behave_like_the_reference(case):
+    exp = case["result"]
+    if "exception" in exp:
+        with pytest.raises(Exception) as ei:
+            BE.activation_fn(case["name"])
+        assert type(ei.value).__name__ == exp["exception"] and str(ei.value) == exp["message"]
+    elif case["name"] == "crelu":
+        with pytest.raises(NotImplementedError):
+            BE.activation_fn("crelu")
+    else:
+        assert exp["fn"].split(".")[-1] == case["name"]
+        assert BE.activation_fn(case["name"]) == case["name"] and case["name"] in capi.ACT_IDS
+
+
+def test_shipped_model_conf_selects_the_reference_optimizers():
+    from wide_deep_amd.read_conf import Config
+    spec = BE.build_model_spec(Config(), "wide_deep")
+    lin, dnn = G["optimizers"][0]["result"], G["optimizers"][1]["result"]
+    assert lin["class"] == "FtrlOptimizer" and spec.lin_opt == ("Ftrl", lin["kwargs"]["learning_rate"],
+                                                                lin["kwargs"]["l1_regularization_strength"],
+                                                                float(lin["kwargs"]["l2_regularization_strength"]), 0.1)
+    assert dnn["class"] == "AdagradOptimizer" and spec.dnn_opt == ("Adagrad", dnn["kwargs"]["learning_rate"], 0.1)

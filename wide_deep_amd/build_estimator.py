@@ -19,24 +19,50 @@ _OPT_ALIASES = {
 }
 
 
+_OPT_NAMES = ("Adagrad", "Adam", "Ftrl", "RMSProp", "SGD")
+_ACTIVATIONS = ("crelu", "elu", "leaky_relu", "relu", "relu6", "selu", "sigmoid", "softplus", "softsign", "tanh")
+
+
+def activation_fn(opt):
+    """The ten names python/lib/utils/model_util.py:28-59 accepts, same ValueError for anything else.  Nine are built into
+    the tower kernels (capi.ACT_IDS); `crelu` (concat(relu(x), relu(-x)): doubles the width every layer hands to the next)
+    is not."""
+    if opt not in _ACTIVATIONS:
+        raise ValueError("Unsupported activation name: %s. Supported names are: %s" % (opt, _ACTIVATIONS))
+    if opt == "crelu":
+        raise NotImplementedError("activation `crelu` doubles the layer width and is not built into the tower kernels")
+    return opt
+
+
+def _unsupported(opt):
+    return ValueError("Unsupported optimizer option: `%s`. Supported names are: %s or an `Optimizer` instance." % (opt, _OPT_NAMES))
+
+
 def parse_optimizer(opt, default_lr):
     """'Adagrad' | 'tf.train.FtrlOptimizer(learning_rate=0.1, l1_regularization_strength=0.5, ...)' -> (name, kwargs).
-    The reference eval()s constructor strings (python/lib/utils/model_util.py:97-101); here the expression is parsed
-    with `ast` and only literal keyword arguments are accepted."""
+    The reference eval()s constructor strings (python/lib/utils/model_util.py:62-105); here the expression is parsed
+    with `ast` and only literal arguments are accepted.  Same acceptance rule and error messages for the five names, for
+    unknown names / classes and for expressions that are not an optimizer (tests/golden/ref_model_util.json)."""
     if not isinstance(opt, str):
         raise ValueError("optimizer must be a string, got %r" % (opt,))
     text = opt.strip()
-    if "(" not in text:
-        if text not in _OPT_ALIASES:
-            raise ValueError("Unsupported optimizer name: %s. Supported names are: %s" % (text, sorted(set(_OPT_ALIASES.values()))))
-        return _OPT_ALIASES[text], {"learning_rate": default_lr}
-    node = ast.parse(text, mode="eval").body
-    if not isinstance(node, ast.Call):
-        raise ValueError("cannot parse optimizer expression `%s`" % opt)
+    if text in _OPT_NAMES:
+        if default_lr is None:
+            raise ValueError("learning_rate must be specified when opt is supported string.")
+        return text, {"learning_rate": default_lr}
+    try:
+        node = ast.parse(text, mode="eval").body
+    except SyntaxError:
+        raise _unsupported(opt)
+    if isinstance(node, ast.Name):                      # eval() of an unknown bare name: NameError in the reference
+        raise _unsupported(opt)
+    if not isinstance(node, ast.Call):                  # evaluates to something that is not an Optimizer
+        raise ValueError("The given object is not an Optimizer instance. Given: %s" % text)
     fn = node.func
     cls = fn.attr if isinstance(fn, ast.Attribute) else getattr(fn, "id", None)
-    if cls not in _OPT_ALIASES:
-        raise ValueError("Unsupported optimizer: %s" % opt)
+    if cls not in _OPT_ALIASES or not cls.endswith("Optimizer"):
+        # tf.train has no such class (AttributeError in the reference) -- or it has, and this engine does not build it
+        raise _unsupported(opt)
     kwargs = {}
     if node.args:
         kwargs["learning_rate"] = ast.literal_eval(node.args[0])
@@ -132,7 +158,7 @@ def build_model_spec(conf=None, model_type=None):
     # weight column is switched on when EITHER weight is set (build_estimator.py:43-46) ...
     use_w = train["pos_sample_loss_weight"] is not None or train["neg_sample_loss_weight"] is not None
     return ModelSpec(model_type=model_type, slots=slots, dense_cols=dense, towers=towers,
-                     activation=model.get("dnn_activation_function") or "relu",
+                     activation=activation_fn(model.get("dnn_activation_function")),
                      batch_norm=bool(model.get("dnn_batch_normalization")), dropout=model.get("dnn_dropout") or None,
                      dnn_opt=opt_tuple(dnn_name, dnn_kw), lin_opt=opt_tuple(lin_name, lin_kw),
                      use_weight_column=use_w, pos_weight=float(train["pos_sample_loss_weight"] or 1.0),

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Measured ceilings on the GPU box: streaming copy (float4) and random 64-byte row gathers from a 1.66 GB table."""
-import os, sys, json
+import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch

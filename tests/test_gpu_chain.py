@@ -5,7 +5,6 @@ Tolerances: as tests/test_gpu_step.py (fp32 summation order is the only differen
 64x64 tiles of the GEMMs vs BLAS)."""
 import os
 
-import numpy as np
 import pytest
 import torch
 

@@ -2,7 +2,6 @@
 either scope (dnn_optimizer: embeddings + tower variables; linear_optimizer: wide weights + bias), against the CPU oracle
 -- whole train steps, same weights, same batches, duplicates inside the batch (tiny tables), several steps so that slot
 state and Adam's beta powers matter.  Tolerances as tests/test_gpu_step.py."""
-import numpy as np
 import pytest
 import torch
 

@@ -1,6 +1,5 @@
 """CPU: host-side planning logic of the engine (no GPU): activation-buffer layouts of the connected modes, the row-range
 bucket geometry of the fused sparse update, optimizer slot naming."""
-import numpy as np
 import pytest
 
 from wide_deep_amd.plan import (FeaturePlan, OPT_SLOT_NAMES, TowerLayout, adam_pow_names, bucket_geometry, criteo_spec,

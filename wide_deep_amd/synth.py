@@ -6,7 +6,6 @@ ids or as raw string tokens that the hash kernels turn into ids on the device.
 import numpy as np
 import torch
 
-from . import capi
 from .capi import call, ptr
 from .engine import DeviceBatch
 

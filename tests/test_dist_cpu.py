@@ -127,3 +127,80 @@ def test_local_spec_and_full_state_roundtrip_shapes():
     ls = local_spec(spec, 4)
     assert [s.num_buckets for s in ls.slots] == [26, 26, 26] and shard_rows(101, 4) == 26
     assert spec.slots[0].num_buckets == 101   # the global spec is untouched
+
+
+# ---- the Estimator-shaped object under torch.distributed (train.py launched one process per GPU), on CPU ------------------
+def _estimator_worker(rank, world, port, q, tmp):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import types
+        from tests.test_estimator_host_cpu import StandInEngine, FIXTURE
+        from tests.test_featurizer_host_cpu import _fake_call
+        from wide_deep_amd import build_estimator as BE, dataset as DS, estimator as E, features as F
+        from wide_deep_amd.read_conf import Config
+        F.call = _fake_call
+        torch.cuda.current_stream = lambda *a: types.SimpleNamespace(cuda_stream=0)
+        torch.cuda.synchronize = lambda *a: None
+
+        class DataParallelStandIn(StandInEngine):
+            """every rank applies the SUM of all ranks' updates (what the sharded engine's exchange amounts to)"""
+
+            def train_step(self, bt):
+                before = self.w.clone()
+                loss = StandInEngine.train_step(self, bt)
+                delta = self.w - before
+                dist.all_reduce(delta)
+                self.w.copy_(before + delta)
+                return loss
+
+            def export_full_state(self):            # collective in the real engine; every rank must call it
+                dist.barrier()
+                return self.export_state()
+
+            def import_full_state(self, st):
+                self.w.copy_(st["w"])
+
+        spec = BE.build_model_spec(Config(), "wide_deep")
+        model_dir = os.path.join(tmp, "model")
+        m = E.WideAndDeepClassifier(spec, model_dir=model_dir, runconfig=Config().runconfig, engine=DataParallelStandIn(spec, 64))
+        lines = open(FIXTURE, "rb").read().splitlines()[:301]          # odd count: the last line is dropped, 150 per rank
+        path = os.path.join(tmp, "rows.tsv")
+        if rank == 0:
+            open(path, "wb").write(b"\n".join(lines) + b"\n")
+        dist.barrier()
+        seen = [r.B for r in DS.input_fn(path, None, "eval", 64)]
+        assert seen == [64, 64, 22], seen                                # 150 lines on every rank
+        m.train(input_fn=lambda: DS.input_fn(path, None, "train", 64))
+        assert m.engine.global_step == 9 and m.last_train["examples"] == 150
+        ws = [torch.zeros_like(m.engine.w) for _ in range(world)]
+        dist.all_gather(ws, m.engine.w)
+        assert torch.equal(ws[0], ws[1])                                 # one model on both ranks
+        dist.barrier()
+        ck = sorted(f for f in os.listdir(model_dir) if f.startswith("model.ckpt-"))
+        assert ck == ["model.ckpt-9.pt"]                                 # written once, by rank 0
+        # a fresh object on every rank resumes from that checkpoint
+        m2 = E.WideAndDeepClassifier(spec, model_dir=model_dir, runconfig=Config().runconfig, engine=DataParallelStandIn(spec, 64))
+        m2.train(input_fn=lambda: DS.input_fn(path, None, "train", 64), steps=1)
+        assert m2.engine.global_step == 12
+        q.put((rank, "ok"))
+    except Exception as e:  # pragma: no cover
+        import traceback
+        q.put((rank, "FAIL: %s\n%s" % (e, traceback.format_exc())))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_estimator_world2_gloo_lines_checkpoints_and_resume(tmp_path):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_estimator_worker, args=(r, 2, port, q, str(tmp_path))) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(60)
+    for rank, msg in res:
+        assert msg == "ok", "rank %d: %s" % (rank, msg)

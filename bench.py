@@ -240,10 +240,13 @@ def main():
             os.environ.setdefault("MASTER_PORT", "29541")
             os.environ.setdefault("RANK", "0")
             os.environ.setdefault("WORLD_SIZE", "1")
+        # a rank that loses its peers fails after 5 minutes instead of holding the node for the default 10+
+        import datetime
+        limit = datetime.timedelta(minutes=5)
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index), timeout=limit)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=limit)
 
     from wide_deep_amd import synth
     from wide_deep_amd.engine import WideDeepEngine

@@ -28,36 +28,38 @@ k_embag_fwd(const float *__restrict__ emb, const wd_slot_t *__restrict__ slots, 
   if (work >= nwork) return;
   const int64_t b = work / ngroup;
   const int32_t s = group_slots[work - b * ngroup];
-  // only the two fields needed: a by-value copy of the whole wd_slot_t went through 32 B/lane of scratch memory
-  const int64_t emb_off = slots[s].emb_off;
-  const int32_t out_col = slots[s].out_col;
+  const wd_slot_t sl = slots[s];
   const int64_t bag = b * S + s;
   const int32_t j0 = bag_offs[bag], j1 = bag_offs[bag + 1];
-  const float4 *__restrict__ tab = reinterpret_cast<const float4 *>(emb + emb_off);
-  typedef float f4 __attribute__((ext_vector_type(4)));
-  const f4 *__restrict__ tv = reinterpret_cast<const f4 *>(tab);
-  f4 acc = (f4)(0.f);
+  const float4 *__restrict__ tab = reinterpret_cast<const float4 *>(emb + sl.emb_off);
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   int32_t j = j0;
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  // 4 independent row reads in flight per lane group (ids < 0: dropped exchange entries, contribute nothing)
   for (; j + 4 <= j1; j += 4) {
     int32_t i0 = ids[j], i1 = ids[j + 1], i2 = ids[j + 2], i3 = ids[j + 3];
-    f4 r0 = i0 >= 0 ? tv[(int64_t)i0 * RS4 + lane] : (f4)(0.f);
-    f4 r1 = i1 >= 0 ? tv[(int64_t)i1 * RS4 + lane] : (f4)(0.f);
-    f4 r2 = i2 >= 0 ? tv[(int64_t)i2 * RS4 + lane] : (f4)(0.f);
-    f4 r3 = i3 >= 0 ? tv[(int64_t)i3 * RS4 + lane] : (f4)(0.f);
-    acc += r0; acc += r1; acc += r2; acc += r3;
+    float4 r0 = i0 >= 0 ? tab[(int64_t)i0 * RS4 + lane] : zero4;
+    float4 r1 = i1 >= 0 ? tab[(int64_t)i1 * RS4 + lane] : zero4;
+    float4 r2 = i2 >= 0 ? tab[(int64_t)i2 * RS4 + lane] : zero4;
+    float4 r3 = i3 >= 0 ? tab[(int64_t)i3 * RS4 + lane] : zero4;
+    acc.x += r0.x; acc.y += r0.y; acc.z += r0.z; acc.w += r0.w;
+    acc.x += r1.x; acc.y += r1.y; acc.z += r1.z; acc.w += r1.w;
+    acc.x += r2.x; acc.y += r2.y; acc.z += r2.z; acc.w += r2.w;
+    acc.x += r3.x; acc.y += r3.y; acc.z += r3.z; acc.w += r3.w;
   }
   for (; j < j1; ++j) {
     const int32_t i0 = ids[j];
-    acc += i0 >= 0 ? tv[(int64_t)i0 * RS4 + lane] : (f4)(0.f);
+    float4 r = i0 >= 0 ? tab[(int64_t)i0 * RS4 + lane] : zero4;
+    acc.x += r.x; acc.y += r.y; acc.z += r.z; acc.w += r.w;
   }
   const int32_t n = j1 - j0;
   if (n > 1) {  // combiner='mean': sum / count (duplicates counted), SURVEY App. A.6
     const float c = (float)n;
     acc.x /= c; acc.y /= c; acc.z /= c; acc.w /= c;
   }
-  float *o = x + b * ldx + out_col + lane * 4;
+  float *o = x + b * ldx + sl.out_col + lane * 4;
   if ((((uintptr_t)o) & 15) == 0) {
-    *reinterpret_cast<f4 *>(o) = acc;
+    *reinterpret_cast<float4 *>(o) = acc;
   } else {
     o[0] = acc.x; o[1] = acc.y; o[2] = acc.z; o[3] = acc.w;
   }

@@ -51,13 +51,15 @@ def main():
             if m:
                 cur, mix = m.group(1), collections.Counter()
                 continue
+            if cur and ln.startswith(".Lfunc_end"):          # end of the function body (an early s_endpgm is not the end)
+                if mix["other"] or mix["salu"]:
+                    rows.append((f, cur, mix))
+                cur = None
+                continue
             t = ln.strip().split()
             if not cur or not t or t[0].startswith((";", ".", "//")) or t[0].endswith(":"):
                 continue
             mix[classify(t[0])] += 1
-            if t[0] == "s_endpgm":
-                rows.append((f, cur, mix))
-                cur = None
     if not rows:
         sys.exit("no kernels found")
     names = subprocess.run(["c++filt"] + [r[1] for r in rows], capture_output=True, text=True).stdout.splitlines()

@@ -287,3 +287,32 @@ def test_prefetch_keeps_order_content_errors_and_stops_early():
     import random
     jobs = [(lambda i=i: (time.sleep(random.random() * 0.01), i)[1]) for i in range(40)]
     assert list(DS.prefetched(iter(jobs), depth=8, workers=4)) == list(range(40))
+
+
+def test_input_fn_mirrors_the_reference_test_input_fn(tmp_path):
+    """python/lib/wide_deep_test.py:44-57 (`test_input_fn`): one line, batch_size 1, 'eval' mode -- every USED feature key is
+    present with exactly one example whose value is the TSV field (comma-joined for multi-value fields), the label is False."""
+    line = [ln for ln in open(FIXTURE, "rb").read().splitlines() if ln.startswith(b"0\t")][0]    # an unclicked row, as test2's first
+    p = tmp_path / "test.csv"
+    p.write_bytes(line + b"\n")
+    c = Config()
+    keys = c.get_feature_name()                        # all fields in schema order, label removed
+    fields = dict(zip(keys, line.split(b"\t")[1:]))
+    batches = list(DS.input_fn(str(p), None, "eval", 1))
+    assert len(batches) == 1 and batches[0].B == 1
+    b = batches[0]
+    fc = c.read_feature_conf()
+    for key in c.get_feature_name("used"):
+        raw = fields[key]
+        if key in b.cat:
+            toks, offs = b.cat[key]
+            assert list(offs) == [0, len(toks)]
+            exp = [] if raw == b"-" else [t for t in raw.split(b",") if t]      # na_value '-' -> default '' -> no token
+            assert toks == exp, key
+        elif key in b.ints:
+            assert len(b.ints[key]) == 1 and int(b.ints[key][0]) == (0 if raw == b"-" else int(raw)), key
+        else:
+            assert fc[key]["type"] == "continuous" and len(b.floats[key]) == 1
+            assert abs(float(b.floats[key][0]) - (0.0 if raw == b"-" else float(raw))) < 1e-6, key
+    assert set(b.cat) | set(b.ints) | set(b.floats) == set(c.get_feature_name("used"))   # unused fields are dropped
+    assert b.labels.tolist() == [1.0 if line.split(b"\t")[0] == b"1" else 0.0] and not b.labels[0]

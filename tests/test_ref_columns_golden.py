@@ -121,3 +121,26 @@ def test_wide_and_deep_columns_equal_the_reference_wiring():
     assert (n_emb, n_ind, n_num) == (16 + 31, 20, 3) and deep_dim == 734
     assert n_num == len(spec.dense_cols)
     assert sum(1 for s in spec.slots if s.deep == "embedding") == n_emb and sum(1 for s in spec.slots if s.deep == "indicator") == n_ind
+
+
+def test_input_layer_concat_order_follows_sorted_tf_column_names():
+    """tf.feature_column.input_layer concatenates the deep columns sorted by `column.name` (`<cat>_embedding`,
+    `<cat>_indicator`, the numeric key): FeaturePlan.tf_deep_cols / tf_input_perm (the row order of the first kernel in a
+    checkpoint) must list exactly the reference's recorded deep columns, in that order, with their widths."""
+    from wide_deep_amd.plan import FeaturePlan
+    plan = FeaturePlan(BE.build_model_spec(Config(), "wide_deep"))
+    exp = []
+    for col in G["deep"]:
+        fn = col["fn"][len(FC):]
+        if fn == "embedding_column":
+            exp.append((_col_name(col["args"][0]) + "_embedding", col["kwargs"]["dimension"]))
+        elif fn == "indicator_column":
+            inner = col["args"][0]
+            n = len(inner["kwargs"]["vocabulary_list"]) if "vocabulary_list" in inner["kwargs"] else inner["kwargs"]["num_buckets"]
+            exp.append((_col_name(inner) + "_indicator", n))
+        else:
+            exp.append((col["args"][0], 1))
+    exp.sort(key=lambda t: t[0])
+    assert [(n, w) for n, _, w in plan.tf_deep_cols] == exp
+    assert plan.tf_deep_dim == sum(w for _, w in exp) == 734 and len(set(plan.tf_input_perm.tolist())) == 734
+    assert plan.deep_dim >= 734 and plan.deep_dim % 4 == 0          # internal width: alignment holes / slab padding only

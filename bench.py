@@ -41,9 +41,10 @@ def parse():
     ap.add_argument("--steps-per-graph", type=int, default=8,
                     help="train steps captured into one hipGraph (single GPU; each step on its own resident batch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true", help="skip the oracle check of batch 0 before the timed region")
     ap.add_argument("--force-sharded", action="store_true",
                     help="diagnostics: run the row-sharded engine even with one rank (one-rank RCCL group)")
-    ap.add_argument("--cpu-steps", type=int, default=20)
+    ap.add_argument("--cpu-steps", type=int, default=50)
     ap.add_argument("--ids-input", action="store_true", help="feed pre-hashed ids (skips the hash kernel)")
     ap.add_argument("--tower-dtype", default=None, choices=["fp32", "fp16"],
                     help="GEMM operand type of the tower (default: fp32; c5: fp16 = BASELINE configs[4])")
@@ -193,30 +194,66 @@ def cpu_baseline(eng, host_batches, steps, B):
         ob = oracle_batch(plan, ids, bag_offs, hb["B"], hb["dense"], hb["labels"], w)
         return ora.train_step(ob)
 
-    # the port's sparse ops are short OpenMP loops: more threads is not faster.  Pick the best of a
-    # small sweep (one step each) and report the thread count actually used.
-    one(host_batches[0])  # warm-up (page-in)
-    best, cores = None, 1
-    for nt in sorted({min(ncpu, n) for n in (8, 16, 32)}):
+    ora.batched = True      # all sparse columns of a step in one C call each way, columns side by side under OpenMP
+    one(host_batches[0])    # warm-up (page-in)
+
+    def timed(nt, n):
         torch.set_num_threads(nt)
         O.lib().wdo_set_num_threads(nt)
         one(host_batches[0])
         t0 = time.perf_counter()
-        one(host_batches[1 % len(host_batches)])
-        dt = time.perf_counter() - t0
-        if best is None or dt < best:
-            best, cores = dt, nt
-    torch.set_num_threads(cores)
-    O.lib().wdo_set_num_threads(cores)
-    t0 = time.perf_counter()
-    for i in range(steps):
-        one(host_batches[(i + 1) % len(host_batches)])
-    dt = time.perf_counter() - t0
-    return {"value": round(steps * B / dt, 1), "unit": "examples/sec", "cores": cores, "host_cpus": ncpu, "kind": "port",
-            "sample": "%d steps x batch %d of the same synthetic workload (token hashing + full train step), "
-                      "CPU oracle = C/OpenMP sparse ops + torch-CPU fp32 tower; TensorFlow (the reference's runtime) "
-                      "is not installable in this image" % (steps, B),
-            "seconds": round(dt, 2)}
+        for i in range(n):
+            one(host_batches[(i + 1) % len(host_batches)])
+        return time.perf_counter() - t0
+
+    # >= 50 timed steps, one thread AND all cores; a mid-size pool is timed too because the port's sparse ops
+    # are short loops (more threads is not always faster) -- `value` is the best multi-thread figure, `cores` its threads
+    runs = {}
+    for nt in sorted({1, min(ncpu, 32), ncpu}):
+        n = steps if nt > 1 else max(10, steps // 5)      # one thread: a shorter sample of the same steps (bounded time)
+        dt = timed(nt, n)
+        runs[nt] = {"threads": nt, "steps": n, "seconds": round(dt, 2), "examples_per_sec": round(n * B / dt, 1)}
+    multi = [r for nt, r in runs.items() if nt > 1] or list(runs.values())
+    best = max(multi, key=lambda r: r["examples_per_sec"])
+    return {"value": best["examples_per_sec"], "unit": "examples/sec", "cores": best["threads"], "host_cpus": ncpu,
+            "kind": "port", "one_thread": runs[1], "all_cores": runs[ncpu], "runs": list(runs.values()),
+            "sample": "%d steps x batch %d of the same synthetic workload (token hashing + full train step) per thread "
+                      "count; CPU oracle = C/OpenMP sparse ops (columns side by side) + torch-CPU fp32 tower; TensorFlow "
+                      "(the reference's runtime) is not installable in this image" % (steps, B),
+            "seconds": best["seconds"]}
+
+
+def parity_check(eng, spec, tb, hb, step_eager):
+    """One eager step on batch 0 BEFORE anything is timed, against the CPU oracle (the checker; sampled-row tables,
+    tests/helpers.CompactOracle): hashed ids bit-exact, loss and max |logit - oracle logit| of the step."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle import oracle as O
+    from tests.helpers import CompactOracle
+    from wide_deep_amd import synth
+    plan = eng.plan
+    bt = synth.hash_tokens(eng, tb)
+    torch.cuda.synchronize()
+    ids, offs = bt.ids.cpu().numpy()[: bt.nnz].copy(), bt.bag_offs.cpu().numpy()
+    data, toffs = synth.pack_decimal_tokens(hb["raw"])
+    nb = np.asarray([s.num_buckets for s in plan.slots], dtype=np.uint64)
+    slot_of = np.repeat(np.tile(np.arange(plan.S), hb["B"]), hb["lens"].reshape(-1))
+    want = (O.fingerprint64_batch(data, toffs.astype(np.int64)) % nb[slot_of]).astype(np.int64)
+    ids_ok = bool(np.array_equal(ids.astype(np.int64), want))
+    co = CompactOracle(eng, [(ids, offs, hb["B"])])
+    w = None
+    if spec.use_weight_column:
+        w = np.where(hb["labels"] > 0, spec.pos_weight, spec.neg_weight).astype(np.float32)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        loss = float(step_eager(tb))
+    torch.cuda.synchronize()
+    oloss, ologits = co.ora.train_step(co.batch(ids, offs, hb["B"], hb["dense"], hb["labels"], w))
+    d = (eng.logit[: hb["B"]].cpu() - ologits).abs()
+    rel = d / (1.0 + ologits.abs())
+    return {"batch": 0, "hash_ids_bit_exact": ids_ok, "loss": round(loss, 4), "oracle_loss": round(float(oloss), 4),
+            "max_abs_dlogit": float("%.3g" % float(d.max())), "max_rel_dlogit": float("%.3g" % float(rel.max())),
+            "tolerance": "fp32 tower: |dlogit| <= 2e-4 + 2e-4 |logit| (tests/test_gpu_fullsize.py); fp16-operand tower 3e-2 + 2e-2 |logit|",
+            "oracle": "oracle/ CPU restatement on the rows this batch touches (tests/helpers.CompactOracle)"}
 
 
 def main():
@@ -248,7 +285,7 @@ def main():
         else:
             dist.init_process_group(backend, timeout=limit)
 
-    from wide_deep_amd import synth
+    from wide_deep_amd import pipeline, synth
     from wide_deep_amd.engine import WideDeepEngine
 
     spec, mean_len = make_spec(args.config)
@@ -281,8 +318,11 @@ def main():
     torch.cuda.synchronize()
 
     def step_eager(tb):
-        bt = tb.batch if args.ids_input else synth.hash_tokens(eng, tb)
-        return eng.train_step(bt)
+        return pipeline.step_eager(eng, tb, args.ids_input)
+
+    parity = None
+    if world == 1 and not sharded and not args.no_parity:
+        parity = parity_check(eng, spec, dev_batches[0], host_batches[0], step_eager)
 
     use_graph = not args.no_graph
     steps_per_run, run_steps = 1, None
@@ -299,36 +339,27 @@ def main():
             use_graph = False
             run = lambda i: step_eager(dev_batches[i % len(dev_batches)])
     elif use_graph:
-        side = torch.cuda.Stream()
-        with torch.cuda.stream(side):
-            step_eager(dev_batches[0])
-            step_eager(dev_batches[1 % len(dev_batches)])
-        torch.cuda.synchronize()
+        side = pipeline.warm(eng, dev_batches, args.ids_input)
         # One hipGraph holds `spg` consecutive steps (each the full step on its own resident batch): the ~11 us between two
         # graph launches is paid once per `spg` steps.  Step counts that are not multiples of spg finish on one-step graphs.
         spg = max(1, min(args.steps_per_graph, len(dev_batches)))
         while len(dev_batches) % spg:
             spg -= 1
-        singles, multis = [], []
-        for j in range(0, len(dev_batches), spg):
-            if spg > 1:
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, stream=side):
-                    for tb in dev_batches[j: j + spg]:
-                        step_eager(tb)
-                multis.append(g)
-        for tb in dev_batches:
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, stream=side):
-                step_eager(tb)
-            singles.append(g)
+        multis = [pipeline.StepGraph(eng, dev_batches[j: j + spg], args.ids_input, stream=side)
+                  for j in range(0, len(dev_batches), spg)] if spg > 1 else []
+        singles = [pipeline.StepGraph(eng, [tb], args.ids_input, stream=side) for tb in dev_batches]
         steps_per_run = spg
+        # the pool is cycled from where the previous call stopped: a short run (the driver's 20 steps after 5 warm-up
+        # steps) does not land on batches the warm-up has just pulled into the Infinity Cache
+        cursor = {"m": 0, "s": 0}
 
         def run_steps(n):
-            for i in range(n // spg if spg > 1 else 0):
-                multis[i % len(multis)].replay()
-            for i in range(n % spg if spg > 1 else n):
-                singles[i % len(singles)].replay()
+            for _ in range(n // spg if spg > 1 else 0):
+                multis[cursor["m"] % len(multis)].replay()
+                cursor["m"] += 1
+            for _ in range(n % spg if spg > 1 else n):
+                singles[(cursor["m"] * spg + cursor["s"]) % len(singles)].replay()
+                cursor["s"] += 1
     else:
         run = lambda i: step_eager(dev_batches[i % len(dev_batches)])
     if run_steps is None:
@@ -379,6 +410,7 @@ def main():
         },
     }
     if rank == 0:
+        out["parity"] = parity
         if world == 1:
             # dominant-bandwidth kernel named by the metric: the embedding gather
             for tb in dev_batches:

@@ -184,6 +184,57 @@ def ftrl_dense(w, z, n, g, lr, l1, l2):
                          ctypes.c_float(l1), ctypes.c_float(l2))
 
 
+def _ptr_array(ptrs):
+    return (ctypes.c_void_p * len(ptrs))(*[p if isinstance(p, int) else (p.value if p is not None else None) for p in ptrs])
+
+
+def embag_fwd_cols(tables, ids_offs, B, mean, outs, ld_outs):
+    """wdo_embag_fwd for ALL columns in one call, columns side by side (bit-identical to the per-column calls).
+    tables: list of [V, D] tensors; ids_offs: list of (ids int64, offs int32); outs: list of data pointers (int)."""
+    n = len(tables)
+    if n == 0:
+        return
+    keep = []
+    idp, ofp = [], []
+    for ids, offs in ids_offs:
+        i = np.ascontiguousarray(ids, dtype=np.int64)
+        if i.size == 0:
+            i = np.zeros(1, np.int64)
+        o = np.ascontiguousarray(offs, dtype=np.int32)
+        keep += [i, o]
+        idp.append(i.ctypes.data)
+        ofp.append(o.ctypes.data)
+    D = np.asarray([t.shape[1] if t.dim() > 1 else 1 for t in tables], dtype=np.int64)
+    ld = np.asarray(ld_outs, dtype=np.int64)
+    lib().wdo_embag_fwd_cols(ctypes.c_int(n), _ptr_array([t.data_ptr() for t in tables]), _p(D), _ptr_array(idp),
+                             _ptr_array(ofp), ctypes.c_int64(B), ctypes.c_int(1 if mean else 0), _ptr_array(list(outs)),
+                             _p(ld))
+
+
+def sparse_apply_cols(tables, slot_a, slot_b, ids_offs, B, mean, grad_ptrs, ld_grads, kind, lr, l1=0.0, l2=0.0):
+    """Row gradients (duplicates summed) + Adagrad (kind 0) / Ftrl (kind 1) sparse apply for ALL columns in one call."""
+    n = len(tables)
+    if n == 0:
+        return
+    keep, idp, ofp = [], [], []
+    for ids, offs in ids_offs:
+        i = np.ascontiguousarray(ids, dtype=np.int64)
+        if i.size == 0:
+            i = np.zeros(1, np.int64)
+        o = np.ascontiguousarray(offs, dtype=np.int32)
+        keep += [i, o]
+        idp.append(i.ctypes.data)
+        ofp.append(o.ctypes.data)
+    D = np.asarray([t.shape[1] if t.dim() > 1 else 1 for t in tables], dtype=np.int64)
+    ld = np.asarray(ld_grads, dtype=np.int64)
+    pa = _ptr_array([t.data_ptr() if t is not None else None for t in slot_a])
+    lib().wdo_sparse_apply_cols(ctypes.c_int(n), _p(D), _ptr_array(idp), _ptr_array(ofp), ctypes.c_int64(B),
+                                ctypes.c_int(1 if mean else 0), _ptr_array(list(grad_ptrs)), _p(ld),
+                                _ptr_array([t.data_ptr() for t in tables]), pa,
+                                _ptr_array([t.data_ptr() for t in slot_b]), ctypes.c_int(kind), ctypes.c_float(lr),
+                                ctypes.c_float(l1), ctypes.c_float(l2))
+
+
 # ---------------------------------------------------------------------------
 # the other optimizers the reference accepts (python/lib/utils/model_util.py:84-90), restated from the TF 1.x kernels:
 #   GradientDescent  training_ops ApplyGradientDescent / scatter_sub          var -= lr g
@@ -374,6 +425,13 @@ class OracleWideDeep:
         self.dnn_opt = dnn_opt
         self.lin_opt = lin_opt
         self.dropout = dropout      # rate; the keep masks of a step come with the batch ("dropout_masks")
+        # batched: all sparse columns of a step go through ONE C call each way, columns side by side (same per-column
+        # arithmetic, bit-identical results; tests/test_oracle_kat.py) -- the CPU-baseline configuration of bench.py
+        self.batched = False
+
+    def _can_batch(self):
+        return (self.batched and self.dnn_opt[0] == "Adagrad" and self.lin_opt[0] == "Ftrl"
+                and all(c["kind"] != "indicator" for c in self.deep_cols))
 
     # -- Adam beta powers (non-slot variables, one pair per optimizer instance) ---------------------
     def _pow_names(self):
@@ -423,6 +481,21 @@ class OracleWideDeep:
     # -- forward -------------------------------------------------------------
     def input_layer(self, batch):
         B = len(batch["labels"]) if "labels" in batch else batch["batch_size"]
+        if self._can_batch():
+            width = sum(c["dim"] if c["kind"] == "embedding" else 1 for c in self.deep_cols)
+            x = torch.zeros(B, width, dtype=torch.float32)
+            tabs, io, outs, col0 = [], [], [], 0
+            for c in self.deep_cols:
+                if c["kind"] == "embedding":
+                    tabs.append(self.state[self.emb_name(c)])
+                    io.append(batch["ids"][c["key"]])
+                    outs.append(x.data_ptr() + 4 * col0)
+                    col0 += c["dim"]
+                else:
+                    x[:, col0] = torch.as_tensor(np.asarray(batch["dense"][c["key"]], dtype=np.float32))
+                    col0 += 1
+            embag_fwd_cols(tabs, io, B, True, outs, [width] * len(tabs))
+            return x
         parts = []
         for c in self.deep_cols:
             if c["kind"] == "embedding":
@@ -443,6 +516,14 @@ class OracleWideDeep:
     def wide_logits(self, batch):
         B = len(batch["labels"]) if "labels" in batch else batch["batch_size"]
         out = torch.zeros(B, dtype=torch.float32)
+        if self._can_batch() and self.wide_cols:
+            per = torch.zeros(len(self.wide_cols), B, dtype=torch.float32)
+            embag_fwd_cols([self.state[self.wide_name(c)] for c in self.wide_cols],
+                           [batch["ids"][c["key"]] for c in self.wide_cols], B, False,
+                           [per.data_ptr() + 4 * B * j for j in range(len(self.wide_cols))], [1] * len(self.wide_cols))
+            for j in range(len(self.wide_cols)):          # same column order as the per-column path
+                out += per[j]
+            return out + self.state["linear/linear_model/bias_weights"][0]
         for c in self.wide_cols:
             ids, offs = batch["ids"][c["key"]]
             out += embag_fwd(self.state[self.wide_name(c)], ids, offs, mean=False)[:, 0]
@@ -515,7 +596,22 @@ class OracleWideDeep:
                         v.grad = None
             # embedding rows
             col0 = 0
-            for c in self.deep_cols:
+            if self._can_batch():
+                dxc = dx.contiguous()
+                tabs, accs, io, gp = [], [], [], []
+                for c in self.deep_cols:
+                    if c["kind"] == "embedding":
+                        nm = self.emb_name(c)
+                        tabs.append(self.state[nm])
+                        accs.append(self.state[nm + "/Adagrad"])
+                        io.append(batch["ids"][c["key"]])
+                        gp.append(dxc.data_ptr() + 4 * col0)
+                        col0 += c["dim"]
+                    else:
+                        col0 += 1
+                sparse_apply_cols(tabs, [None] * len(tabs), accs, io, len(labels), True, gp, [dxc.shape[1]] * len(tabs),
+                                  0, opt[1])
+            for c in ([] if self._can_batch() else self.deep_cols):
                 if c["kind"] == "embedding":
                     D = c["dim"]
                     ids, offs = batch["ids"][c["key"]]
@@ -530,7 +626,14 @@ class OracleWideDeep:
         if "wide" in cache:
             opt = self.lin_opt
             pw = self._pow("linear")
-            for c in self.wide_cols:
+            if self._can_batch() and self.wide_cols:
+                dl = dlogit.contiguous()
+                names = [self.wide_name(c) for c in self.wide_cols]
+                sparse_apply_cols([self.state[n] for n in names], [self.state[n + "/Ftrl_1"] for n in names],
+                                  [self.state[n + "/Ftrl"] for n in names], [batch["ids"][c["key"]] for c in self.wide_cols],
+                                  len(labels), False, [dl.data_ptr()] * len(names), [1] * len(names), 1, opt[1], opt[2],
+                                  opt[3])
+            for c in ([] if self._can_batch() else self.wide_cols):
                 ids, offs = batch["ids"][c["key"]]
                 uniq, rg = embag_row_grads(1, ids, offs, dlogit.reshape(-1, 1), mean=False)
                 opt_apply_rows(opt, self.state, self.wide_name(c), uniq, rg, pw)

@@ -332,6 +332,58 @@ void wdo_ftrl_dense(float *w, float *z, float *n, const float *g, int64_t cnt, f
 }
 
 /* ------------------------------------------------------------------------- */
+/* All sparse columns of one step in ONE call, columns side by side (what TF's */
+/* inter-op pool does with the per-column subgraphs).  Every column runs the   */
+/* per-column functions above unchanged, so results are bit-identical to the   */
+/* per-column calls; used by bench.py's cpu_baseline leg.                      */
+/* ------------------------------------------------------------------------- */
+void wdo_embag_fwd_cols(int ncols, const float *const *tables, const int64_t *D, const int64_t *const *ids,
+                        const int32_t *const *offs, int64_t nbags, int mean, float *const *outs,
+                        const int64_t *ld_out) {
+  const int64_t chunk = 256;
+  const int64_t nchunk = (nbags + chunk - 1) / chunk;
+#pragma omp parallel for schedule(dynamic, 1)
+  for (int64_t job = 0; job < (int64_t)ncols * nchunk; ++job) {
+    const int c = (int)(job / nchunk);
+    const int64_t b0 = (job % nchunk) * chunk, b1 = b0 + chunk < nbags ? b0 + chunk : nbags;
+    const int64_t d = D[c];
+    for (int64_t b = b0; b < b1; ++b) {
+      float *o = outs[c] + b * ld_out[c];
+      for (int64_t k = 0; k < d; ++k) o[k] = 0.f;
+      int32_t cnt = 0;
+      for (int32_t j = offs[c][b]; j < offs[c][b + 1]; ++j) {
+        if (ids[c][j] < 0) continue;
+        const float *row = tables[c] + ids[c][j] * d;
+        for (int64_t k = 0; k < d; ++k) o[k] += row[k];
+        ++cnt;
+      }
+      if (mean && cnt > 1) {
+        float cf = (float)cnt;
+        for (int64_t k = 0; k < d; ++k) o[k] = o[k] / cf;
+      }
+    }
+  }
+}
+
+/* kind 0: Adagrad rows (slot_b = accumulator); kind 1: Ftrl rows (slot_a = z / linear, slot_b = n / accumulator) */
+void wdo_sparse_apply_cols(int ncols, const int64_t *D, const int64_t *const *ids, const int32_t *const *offs,
+                           int64_t nbags, int mean, const float *const *grads, const int64_t *ld_grad,
+                           float *const *tables, float *const *slot_a, float *const *slot_b, int kind, float lr,
+                           float l1, float l2) {
+#pragma omp parallel for schedule(dynamic, 1)
+  for (int c = 0; c < ncols; ++c) {
+    const int64_t nnz = offs[c][nbags];
+    int64_t *uniq = (int64_t *)malloc(sizeof(int64_t) * (size_t)(nnz > 0 ? nnz : 1));
+    float *rg = (float *)malloc(sizeof(float) * (size_t)((nnz > 0 ? nnz : 1) * D[c]));
+    const int64_t nu = wdo_embag_row_grads(D[c], ids[c], offs[c], nbags, mean, grads[c], ld_grad[c], uniq, rg);
+    if (kind == 0) wdo_adagrad_rows(tables[c], slot_b[c], D[c], uniq, nu, rg, lr);
+    else wdo_ftrl_rows(tables[c], slot_a[c], slot_b[c], D[c], uniq, nu, rg, lr, l1, l2);
+    free(uniq);
+    free(rg);
+  }
+}
+
+/* ------------------------------------------------------------------------- */
 /* Head: sigmoid_cross_entropy_with_logits, loss SUM over batch, weights.     */
 /* loss_b = max(x,0) - x*y + log1p(exp(-|x|)); dloss/dx = w*(sigmoid(x)-y)    */
 /* ------------------------------------------------------------------------- */

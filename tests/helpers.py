@@ -114,3 +114,117 @@ def guava_multiple_lengths(fp, record=None):
         buf[((x0 << 16) + (x1 << 8) + x2) % n] ^= x3
         buf[((x1 << 16) + (x2 << 8) + x3) % n] ^= i % 256
     return h
+
+
+# ---- full-size parity: an oracle over the SAMPLED rows a set of batches touches -------------------------------------------
+class CompactOracle:
+    """OracleWideDeep whose tables hold only the rows that `batches` touch (ids remapped to their rank among the touched
+    rows of the slot -- np.unique keeps them in ascending order, so every per-row summation order of the oracle is the one it
+    would use on the full table).  Lets the full-size configurations (26 x 1M rows, the 100M-row table) be stepped against the
+    CPU oracle in seconds: nothing of size O(table) crosses PCIe.  batches: list of (ids int32[nnz], bag_offs int32[B*S+1], B)
+    as numpy arrays (the ids the DEVICE produced)."""
+
+    def __init__(self, eng, batches):
+        spec, plan = eng.spec, eng.plan
+        self.eng, self.plan = eng, plan
+        S = plan.S
+        self.uniq = []
+        per_slot = [[] for _ in range(S)]
+        for ids, offs, B in batches:
+            csr = slot_csr(plan, ids, offs, B)
+            for si, s in enumerate(plan.slots):
+                per_slot[si].append(csr[s.name][0])
+        for si in range(S):
+            u = np.unique(np.concatenate(per_slot[si])) if per_slot[si] else np.zeros(0, np.int64)
+            self.uniq.append(u[u >= 0])
+        state = {k: (v.clone().float() if v.dtype != torch.int64 else v) for k, v in eng.export_state(tables=False).items()}
+        deep_cols, wide_cols = [], []
+        dsa, dsb = O.SLOT_NAMES[spec.dnn_opt[0]] if spec.has_deep else (None, None)
+        lsa, lsb = O.SLOT_NAMES[spec.lin_opt[0]] if spec.has_wide else (None, None)
+        for si, s in enumerate(plan.slots):
+            nb = max(len(self.uniq[si]), 1)
+            if spec.has_deep and s.deep == "embedding":
+                col = {"name": s.deep_name, "kind": "embedding", "key": s.name, "num_buckets": nb, "dim": s.dim}
+                deep_cols.append(col)
+                nm = O.OracleWideDeep.emb_name(col)
+                for buf, suf in ((eng.emb, ""), (eng.emb_a, dsa), (eng.emb_acc, dsb)):
+                    if suf is not None:
+                        state[nm + suf] = self._emb_rows(buf, si)
+            elif spec.has_deep and s.deep == "indicator":
+                raise NotImplementedError("CompactOracle: indicator columns index the full vocabulary")
+            if spec.has_wide and s.wide:
+                col = {"name": s.name, "key": s.name, "num_buckets": nb}
+                wide_cols.append(col)
+                nm = O.OracleWideDeep.wide_name(col)
+                blk = self._wide_rows(si)
+                for c, suf in ((0, ""), (1, lsa), (2, lsb)):
+                    if suf is not None:
+                        state[nm + suf] = blk[:, c:c + 1].clone()
+        for d in plan.dense_cols:
+            deep_cols.append({"name": d.name, "kind": "numeric", "key": d.name, "num_buckets": 0, "dim": 1})
+        towers = [(t.hidden_units, t.mode) for t in spec.towers]
+        self.ora = O.OracleWideDeep(spec.model_type, deep_cols, wide_cols, towers, state, act=spec.activation,
+                                    batch_norm=spec.batch_norm, dnn_opt=spec.dnn_opt, lin_opt=spec.lin_opt,
+                                    dropout=spec.dropout or None)
+
+    def _idx(self, si):
+        return torch.as_tensor(self.uniq[si], dtype=torch.int64, device=self.eng.device)
+
+    def _emb_rows(self, buf, si):
+        plan, s = self.plan, self.plan.slots[si]
+        v = buf[plan.emb_off[si]: plan.emb_off[si] + s.num_buckets * s.dim].view(s.num_buckets, s.dim)
+        if len(self.uniq[si]) == 0:
+            return torch.zeros(1, s.dim)
+        return v[self._idx(si)].cpu().clone()
+
+    def _wide_rows(self, si):
+        r0 = self.plan.row_base[si]
+        if len(self.uniq[si]) == 0:
+            return torch.zeros(1, 4)
+        return self.eng.wide[r0 + self._idx(si)].cpu().clone()
+
+    def batch(self, ids, bag_offs, B, dense, labels, weights=None):
+        """oracle batch of device ids (remapped to the compact tables)."""
+        ob = oracle_batch(self.plan, ids, bag_offs, B, dense, labels, weights)
+        for si, s in enumerate(self.plan.slots):
+            v, o = ob["ids"][s.name]
+            r = np.searchsorted(self.uniq[si], v)
+            assert len(v) == 0 or np.array_equal(self.uniq[si][np.minimum(r, len(self.uniq[si]) - 1)], v), "id outside the sample"
+            ob["ids"][s.name] = (r.astype(np.int64), o)
+        return ob
+
+    def assert_state_matches(self, rtol, atol):
+        """every touched table row (+ optimizer slots) and every dense parameter of the engine against the oracle."""
+        eng, spec, ora = self.eng, self.eng.spec, self.ora
+        st = eng.export_state(tables=False)
+        for k, v in st.items():
+            if k == "global_step" or "moving_" in k:
+                continue
+            assert_close(v, ora.state[k].detach(), rtol, atol, k)
+        dsa, dsb = O.SLOT_NAMES[spec.dnn_opt[0]] if spec.has_deep else (None, None)
+        lsa, lsb = O.SLOT_NAMES[spec.lin_opt[0]] if spec.has_wide else (None, None)
+        for c in ora.deep_cols:
+            if c["kind"] != "embedding":
+                continue
+            si = [i for i, s in enumerate(self.plan.slots) if s.name == c["key"]][0]
+            nm = ora.emb_name(c)
+            for buf, suf in ((eng.emb, ""), (eng.emb_a, dsa), (eng.emb_acc, dsb)):
+                if suf is not None and len(self.uniq[si]):
+                    assert_close(self._emb_rows(buf, si), ora.state[nm + suf], rtol, atol, nm + suf)
+        for c in ora.wide_cols:
+            si = [i for i, s in enumerate(self.plan.slots) if s.name == c["key"]][0]
+            if not len(self.uniq[si]):
+                continue
+            blk = self._wide_rows(si)
+            nm = ora.wide_name(c)
+            for col, suf in ((0, ""), (1, lsa), (2, lsb)):
+                if suf is not None:
+                    assert_close(blk[:, col:col + 1], ora.state[nm + suf], rtol, atol, nm + suf)
+
+    def touched_mask(self):
+        """bool [total_rows] on the device: rows of the fused row space any sampled batch touches."""
+        m = torch.zeros(max(self.plan.total_rows, 1), dtype=torch.bool, device=self.eng.device)
+        for si in range(self.plan.S):
+            if len(self.uniq[si]):
+                m[self.plan.row_base[si] + self._idx(si)] = True
+        return m

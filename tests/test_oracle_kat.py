@@ -167,3 +167,60 @@ def test_optimizer_restatements_hand_computed():
     assert O.adam_pow_names(("Adam", 1, .9, .999, 1e-8), ("Adam", 1, .9, .999, 1e-8)) == {
         "dnn": ("beta1_power", "beta2_power"), "linear": ("beta1_power_1", "beta2_power_1")}
     assert O.adam_pow_names(("Adagrad", 1, .1), ("Adam", 1, .9, .999, 1e-8)) == {"linear": ("beta1_power", "beta2_power")}
+
+
+def test_batched_column_calls_equal_per_column_calls_bit_for_bit():
+    """OracleWideDeep.batched (bench.py's cpu_baseline configuration: all sparse columns of a step through one C call each
+    way, columns side by side under OpenMP) must be the SAME arithmetic as the per-column path the parity tests use."""
+    import torch
+    rng_b = 300
+    deep = [{"name": "c%d_embedding" % i, "kind": "embedding", "key": "c%d" % i, "num_buckets": 50 + i, "dim": 8} for i in range(4)]
+    deep.append({"name": "x0", "kind": "numeric", "key": "x0", "num_buckets": 0, "dim": 1})
+    wide = [{"name": "c%d" % i, "key": "c%d" % i, "num_buckets": 50 + i} for i in range(4)]
+
+    def mk():
+        st, g = {}, torch.Generator().manual_seed(1)
+        for c in deep[:4]:
+            n = O.OracleWideDeep.emb_name(c)
+            st[n] = torch.randn(c["num_buckets"], 8, generator=g)
+            st[n + "/Adagrad"] = torch.full((c["num_buckets"], 8), 0.1)
+        for c in wide:
+            n = O.OracleWideDeep.wide_name(c)
+            st[n] = torch.zeros(c["num_buckets"], 1)
+            st[n + "/Ftrl"] = torch.full((c["num_buckets"], 1), 0.1)
+            st[n + "/Ftrl_1"] = torch.zeros(c["num_buckets"], 1)
+        b = "linear/linear_model/bias_weights"
+        st[b], st[b + "/Ftrl"], st[b + "/Ftrl_1"] = torch.zeros(1), torch.full((1,), 0.1), torch.zeros(1)
+        p = "dnn/dnn_1/"
+        for l, (k, n) in enumerate([(33, 16), (16, 8)]):
+            st[p + "hiddenlayer_%d/kernel" % l] = torch.randn(k, n, generator=g) * 0.2
+            st[p + "hiddenlayer_%d/bias" % l] = torch.zeros(n)
+            st[p + "hiddenlayer_%d/batch_normalization/gamma" % l] = torch.ones(n)
+            st[p + "hiddenlayer_%d/batch_normalization/beta" % l] = torch.zeros(n)
+        st[p + "logits/kernel"], st[p + "logits/bias"] = torch.randn(8, 1, generator=g) * 0.2, torch.zeros(1)
+        for k in list(st):
+            if k.startswith(p):
+                st[k + "/Adagrad"] = torch.full_like(st[k], 0.1)
+        return st
+
+    def batch(seed):
+        r = np.random.default_rng(seed)
+        ids = {}
+        for i in range(4):
+            lens = r.integers(0, 4, size=rng_b)
+            offs = np.zeros(rng_b + 1, np.int32)
+            offs[1:] = np.cumsum(lens)
+            ids["c%d" % i] = (r.integers(-1, 50 + i, size=int(offs[-1])).astype(np.int64), offs)   # -1: pruned ids, empty bags
+        return {"ids": ids, "dense": {"x0": r.standard_normal(rng_b).astype(np.float32)},
+                "labels": (r.random(rng_b) < 0.3).astype(np.float32), "weights": None}
+
+    a = O.OracleWideDeep("wide_deep", deep, wide, [([16, 8], "simple")], mk())
+    b = O.OracleWideDeep("wide_deep", deep, wide, [([16, 8], "simple")], mk())
+    b.batched = True
+    for s in range(3):
+        bt = batch(s)
+        la, lga = a.train_step(bt)
+        lb, lgb = b.train_step(bt)
+        assert la == lb and torch.equal(lga, lgb)
+    for k in a.state:
+        assert torch.equal(a.state[k], b.state[k]), k

@@ -977,13 +977,15 @@ class WideDeepEngine:
         sa, sb = OPT_SLOT_NAMES[opt[0]]
         return sa, sb
 
-    def export_state(self):
+    def export_state(self, tables=True):
+        """TF-named variables (+ optimizer slots).  tables=False: dense-tower parameters, bias and counters only (the
+        embedding / wide tables of a 100M-row model are tens of GB; tests/helpers.compact_oracle samples their rows)."""
         plan, spec = self.plan, self.spec
         out = {}
         if spec.has_deep:
             sa, sb = self._slot_bufs("dnn")
             for i, s in enumerate(plan.slots):
-                if plan.emb_off[i] >= 0:
+                if tables and plan.emb_off[i] >= 0:
                     nm = "dnn/input_from_feature_columns/input_layer/%s/embedding_weights" % s.deep_name
                     sl = slice(plan.emb_off[i], plan.emb_off[i] + s.num_buckets * s.dim)
                     for buf, suf in ((self.emb, ""), (self.emb_a, sa), (self.emb_acc, sb)):
@@ -1010,7 +1012,7 @@ class WideDeepEngine:
             sa, sb = self._slot_bufs("linear")
             b = self.bias.cpu()
             for i, s in enumerate(plan.slots):
-                if s.wide:
+                if tables and s.wide:
                     nm = "linear/linear_model/%s/weights" % s.name
                     r0 = plan.row_base[i]
                     blk = self.wide[r0: r0 + s.num_buckets].cpu()

@@ -159,6 +159,13 @@ int wd_wide_fwd(const float *wide, int32_t wide_stride, const float *bias, const
 int wd_bce_sum_fwd_bwd(const float *dnn_logit, const float *wide_logit, const float *labels, const float *weights,
                        int64_t batch, float *logit, float *prob, float *dlogit, float *loss_sum, wd_stream_t stream);
 
+/* The same batch-SUM loss (python/lib/joint.py:264-269 -> head loss) from the STORED logits, summed in a
+ * fixed order: loss_sum[0] = sum_b w_b * CE(logit_b, y_b) (stored, not accumulated).  The head kernels add their partial
+ * sums to loss_sum with a float atomic (arrival order); callers that need a bit-reproducible loss pass loss_sum = NULL
+ * there and launch this instead (one workgroup). */
+int wd_bce_loss_sum(const float *logit, const float *labels, const float *weights, int64_t batch, float *loss_sum,
+                    wd_stream_t stream);
+
 /* ---- a12: sparse optimizer apply (python/lib/joint.py:224-262, utils/model_util.py:84-90) ----
  * Step 1: keys[j] = row_base[slot(j)] + ids[j], vals[j] = bag(j); stable radix sort by key.
  * Workspace query then sort. */

@@ -1,4 +1,6 @@
 """Shared helpers for the GPU parity tests: engine batch/state -> oracle batch/model."""
+import os
+
 import numpy as np
 import torch
 
@@ -137,6 +139,15 @@ class CompactOracle:
         for si in range(S):
             u = np.unique(np.concatenate(per_slot[si])) if per_slot[si] else np.zeros(0, np.int64)
             self.uniq.append(u[u >= 0])
+        self.ora = None
+        self.resync()
+
+    def resync(self):
+        """(Re)load the oracle's state from the engine: dense parameters + the sampled table rows + every optimizer slot.
+        Called before a step it makes the comparison a ONE-step comparison from identical state -- the training dynamics of
+        the reference (batch-SUM loss, Adagrad lr 0.05 on accumulators that start at 0.1) amplify fp32 summation-order
+        differences from step to step, which is a property of the model and not of either implementation."""
+        eng, spec, plan = self.eng, self.eng.spec, self.plan
         state = {k: (v.clone().float() if v.dtype != torch.int64 else v) for k, v in eng.export_state(tables=False).items()}
         deep_cols, wide_cols = [], []
         dsa, dsb = O.SLOT_NAMES[spec.dnn_opt[0]] if spec.has_deep else (None, None)
@@ -193,14 +204,36 @@ class CompactOracle:
             ob["ids"][s.name] = (r.astype(np.int64), o)
         return ob
 
-    def assert_state_matches(self, rtol, atol):
-        """every touched table row (+ optimizer slots) and every dense parameter of the engine against the oracle."""
+    def assert_state_matches(self, rtol, atol, kink=None):
+        """every touched table row (+ optimizer slots) and every dense parameter of the engine against the oracle.
+        kink = (max_fraction, rtol2, atol2): up to that fraction of a tensor's elements may miss (rtol, atol) as long as they
+        meet (rtol2, atol2) -- a ReLU pre-activation that rounds to +0 in one summation order and to -0 / -eps in the other
+        flips act' for ONE (example, unit): that unit's kernel column, the example's 26 embedding rows and (by one
+        example's worth) everything below move by a discrete amount (seen ~once per 10 steps at batch 8192)."""
         eng, spec, ora = self.eng, self.eng.spec, self.ora
+
+        def close(a, b, what):
+            if kink is None:
+                return assert_close(a, b, rtol, atol, what)
+            a = torch.as_tensor(a).double().reshape(-1).cpu()
+            b = torch.as_tensor(b).double().reshape(-1).cpu()
+            err = (a - b).abs()
+            bad = err > atol + rtol * b.abs()
+            frac, r2, a2 = kink
+            if os.environ.get("WD_PARITY_VERBOSE") == "1" and a.numel():
+                print("  %-70s n %9d  outside base tol %8d (%.4f%%)  max abs err %.3e  rel L2 %.3e" % (
+                    what[-70:], a.numel(), int(bad.sum()), 100.0 * float(bad.sum()) / a.numel(), float(err.max()),
+                    float(err.norm() / b.norm().clamp_min(1e-30))), flush=True)
+            assert int(bad.sum()) <= frac * a.numel() + 1, "%s: %d/%d outside (rtol %g, atol %g)" % (
+                what, int(bad.sum()), a.numel(), rtol, atol)
+            assert not bool((err > a2 + r2 * b.abs()).any()), "%s: max abs err %.3e outside the kink bound (rtol %g, atol %g)" % (
+                what, float(err.max()), r2, a2)
+
         st = eng.export_state(tables=False)
         for k, v in st.items():
             if k == "global_step" or "moving_" in k:
                 continue
-            assert_close(v, ora.state[k].detach(), rtol, atol, k)
+            close(v, ora.state[k].detach(), k)
         dsa, dsb = O.SLOT_NAMES[spec.dnn_opt[0]] if spec.has_deep else (None, None)
         lsa, lsb = O.SLOT_NAMES[spec.lin_opt[0]] if spec.has_wide else (None, None)
         for c in ora.deep_cols:
@@ -210,7 +243,7 @@ class CompactOracle:
             nm = ora.emb_name(c)
             for buf, suf in ((eng.emb, ""), (eng.emb_a, dsa), (eng.emb_acc, dsb)):
                 if suf is not None and len(self.uniq[si]):
-                    assert_close(self._emb_rows(buf, si), ora.state[nm + suf], rtol, atol, nm + suf)
+                    close(self._emb_rows(buf, si), ora.state[nm + suf], nm + suf)
         for c in ora.wide_cols:
             si = [i for i, s in enumerate(self.plan.slots) if s.name == c["key"]][0]
             if not len(self.uniq[si]):
@@ -219,7 +252,7 @@ class CompactOracle:
             nm = ora.wide_name(c)
             for col, suf in ((0, ""), (1, lsa), (2, lsb)):
                 if suf is not None:
-                    assert_close(blk[:, col:col + 1], ora.state[nm + suf], rtol, atol, nm + suf)
+                    close(blk[:, col:col + 1], ora.state[nm + suf], nm + suf)
 
     def touched_mask(self):
         """bool [total_rows] on the device: rows of the fused row space any sampled batch touches."""

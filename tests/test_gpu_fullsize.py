@@ -1,27 +1,42 @@
 """GPU: the BASELINE configurations AT THEIR OWN SIZE against the CPU oracle, through the path bench.py times.
 
   C2  batch 8192, 13 dense + 26 slots x 1M buckets, D 16, Dnn [256,128,64]: raw tokens -> wd_hash_bucket (ids bit-exact
-      against the oracle's Fingerprint64) -> one-launch tower with the fused input layer -> fused sparse update; three eager
-      steps (logits + loss checked after EVERY step) and then the 8-steps-per-hipGraph replay bench.py uses
-      (wide_deep_amd/pipeline.StepGraph), uniform and Zipf(1.05) ids;
+      against the oracle's Fingerprint64) -> one-launch tower with the fused input layer -> fused sparse update, uniform
+      and Zipf(1.05) ids;
   C3  the same model over ONE 100M-row table (26 x 3,846,154 rows) resident on one GPU;
   C4  multi-hot (mean 5 ids per slot), ResDnn tower, weight column;
   C5  deep-only DenseDnn [1024,512,256,128], D 64, fp16-operand MFMA tower (fp32 accumulate / embeddings).
 
-The oracle sees the SAMPLED rows of the tables (tests/helpers.CompactOracle: exactly the rows the batches touch, same
-arithmetic, same summation orders), every other row of the device tables must stay bit-identical.
+How the comparison is made (measured, scripts/debug_graph_parity*.py):
+  * EVERY step is compared from identical state: before step t the oracle is re-loaded from the engine
+    (tests/helpers.CompactOracle.resync: all dense parameters + the sampled rows of the tables = exactly the rows the
+    batches touch, + every optimizer slot), both sides step, then logits, loss and the whole touched state are compared.
+    Per step the engine is within ~1e-5 of the oracle (logits) / 1e-5 relative (state).
+  * free-running for 8+ steps the two trajectories separate (max |dlogit| 2e-2 after 11 steps at C2): the reference's
+    training dynamics (batch-SUM loss, Adagrad lr 0.05 over accumulators that start at 0.1: every weight moves ~0.05 per
+    step at first) amplify fp32 summation-order differences, and about once per 10 steps a ReLU pre-activation that is
+    +0 in one summation order and -eps in the other flips act' for one (example, unit).  That is a property of the model,
+    not of an implementation -- two CPU runs with different BLAS blocking do the same -- so the multi-step claim is made
+    by transitivity: the 8-steps-per-hipGraph replay bench.py times is BIT-IDENTICAL (torch.equal on every table,
+    accumulator and parameter) to the same steps launched eagerly on a twin engine, and every eager step matches the oracle.
+    The free-running drift is still bounded loosely (loss 1e-3 relative) so that a wrong step cannot hide behind it.
+  * rows no batch touches must stay bit-identical.
 
-Tolerances (north_star "logits within stated fp32 tolerance"): fp32 tower |dlogit| <= 2e-4 + 2e-4 |logit| per step, loss
-1e-3 relative of the batch SUM, touched rows / dense parameters 5e-4 relative + 1e-5; fp16-operand tower (C5): logits
-3e-2 + 2e-2 |logit| (half rounding of the GEMM operands), parameters 2e-2 relative + 2e-3."""
+Tolerances (north_star "logits within stated fp32 tolerance"), per step from identical state: fp32 tower |dlogit| <=
+2e-4 + 2e-4 |logit|, loss 1e-4 relative of the batch SUM, state 5e-4 relative + 1e-5 (<= 0.5 % of a tensor may sit at
+5e-2 / 5e-3: the ReLU event above); fp16-operand tower (C5): logits 3e-2 + 2e-2 |logit|, state 3e-2 relative + 3e-3
+(<= 0.5 % of a tensor within 2 lr: see FP16_TOL)."""
 import numpy as np
 import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
 
-L_RTOL, L_ATOL = 2e-4, 2e-4
-P_RTOL, P_ATOL = 5e-4, 1e-5
+FP32_TOL = dict(l_rtol=2e-4, l_atol=2e-4, loss_rtol=1e-4, p_rtol=5e-4, p_atol=1e-5, kink=(0.005, 5e-2, 5e-3))
+# fp16 operands: a kernel-gradient entry is a sum of 8192 products that mostly cancel; where the half rounding of the operands
+# exceeds what is left, Adagrad (lr 0.05, saturating in g / sqrt(acc + g^2)) moves that weight by up to 2 lr in the other
+# direction -- measured on 0.1 % of the first-layer kernel per step, never on the embedding rows
+FP16_TOL = dict(l_rtol=2e-2, l_atol=3e-2, loss_rtol=2e-3, p_rtol=3e-2, p_atol=3e-3, kink=(0.005, 1.0, 0.11))
 
 
 def _weights(spec, hb):
@@ -48,57 +63,73 @@ def _hash_and_check(eng, tbs, hbs):
         assert np.array_equal(ids.astype(np.int64), want), "hash ids differ from the oracle"
         bt.ids.zero_()           # the step has to produce them itself (hash-in-step)
         out.append((ids, offs, hb["B"]))
+    torch.cuda.synchronize()
     return out
 
 
-def _fullsize(spec, B, mean_len, dist, n_eager, n_graph, tower_dtype="fp32", tol=None, seed=20260925):
+def _bit_identical(a, b):
+    for name in ("emb", "emb_a", "emb_acc", "wide", "bias", "P", "Pa", "Pacc"):
+        x, y = getattr(a, name, None), getattr(b, name, None)
+        if x is not None:
+            assert torch.equal(x, y), "graph replay and eager launches differ in %s" % name
+    assert torch.equal(a.logit, b.logit) and torch.equal(a.loss, b.loss)
+
+
+def _fullsize(spec, B, mean_len, dist, n_steps, n_graph, tower_dtype="fp32", tol=FP32_TOL, seed=20260925):
+    """n_steps eager steps on engine A, each against the re-synchronised oracle; engine B (same seed = same initial state)
+    runs step 0 eagerly and the other steps as hipGraphs of n_graph steps -- the replay bench.py times -- and must end
+    bit-identical to A."""
     from tests.helpers import CompactOracle, assert_close
     from wide_deep_amd import synth
     from wide_deep_amd.engine import WideDeepEngine
     from wide_deep_amd.pipeline import StepGraph, step_eager
-    l_rtol, l_atol, p_rtol, p_atol = tol or (L_RTOL, L_ATOL, P_RTOL, P_ATOL)
     S = len(spec.slots)
-    eng = WideDeepEngine(spec, max_batch=B, max_nnz=B * S * (2 * mean_len + 2), seed=0, tower_dtype=tower_dtype)
-    n = n_eager + n_graph
-    hbs = [synth.make_raw_batch(eng.plan, B, seed=seed + i, mean_len=mean_len, dist=dist) for i in range(n)]
+    mk = lambda: WideDeepEngine(spec, max_batch=B, max_nnz=B * S * (2 * mean_len + 2), seed=0, tower_dtype=tower_dtype)
+    eng = mk()
+    hbs = [synth.make_raw_batch(eng.plan, B, seed=seed + i, mean_len=mean_len, dist=dist) for i in range(n_steps)]
     tbs = [synth.TokenBatch(eng.plan, hb, weights=_weights(spec, hb)) for hb in hbs]
     dev_ids = _hash_and_check(eng, tbs, hbs)
     co = CompactOracle(eng, dev_ids)
     touched = co.touched_mask()
     emb0 = eng.emb.clone() if eng.emb is not None else None
     wide0 = eng.wide.clone() if eng.wide is not None else None
-
-    def oracle_step(i):
-        ids, offs, _ = dev_ids[i]
-        return co.ora.train_step(co.batch(ids, offs, B, hbs[i]["dense"], hbs[i]["labels"], _weights(spec, hbs[i])))
-
-    # ---- eager steps: logits + loss after every step --------------------------------------------------------------
     side = torch.cuda.Stream()
-    with torch.cuda.stream(side):
-        for i in range(n_eager):
+    free = CompactOracle(eng, dev_ids).ora         # a second oracle that is never re-synchronised: the free-running drift
+    for i in range(n_steps):
+        co.resync()
+        with torch.cuda.stream(side):
             loss = step_eager(eng, tbs[i])
-            side.synchronize()
-            oloss, ologits = oracle_step(i)
-            assert_close(eng.logit[:B], ologits, l_rtol, l_atol, "logits eager step %d" % i)
-            assert abs(float(loss) - oloss) <= 1e-3 * max(1.0, abs(oloss)), (i, float(loss), oloss)
-    torch.cuda.synchronize()
-    # ---- the replay bench.py times: n_graph steps in ONE hipGraph, each on its own batch ----------------------------
-    if n_graph:
-        g = StepGraph(eng, tbs[n_eager:], stream=side)
-        loss = g.replay()
         torch.cuda.synchronize()
-        for i in range(n_eager, n):
-            oloss, ologits = oracle_step(i)
-        assert_close(eng.logit[:B], ologits, l_rtol, l_atol, "logits after the %d-step graph" % n_graph)
-        assert abs(float(loss) - oloss) <= 1e-3 * max(1.0, abs(oloss)), (float(loss), oloss)
-    # ---- state: touched rows + dense parameters vs the oracle, untouched rows bit-identical ---------------------------
-    co.assert_state_matches(p_rtol, p_atol)
-    if emb0 is not None:
-        (dim, _), = list(eng.plan.emb_groups.items())[:1]
-        if len(eng.plan.emb_groups) == 1 and all(s.deep == "embedding" for s in eng.plan.slots):
-            assert torch.equal(emb0.view(-1, dim)[: touched.numel()][~touched], eng.emb.view(-1, dim)[: touched.numel()][~touched])
+        ids, offs, _ = dev_ids[i]
+        ob = co.batch(ids, offs, B, hbs[i]["dense"], hbs[i]["labels"], _weights(spec, hbs[i]))
+        oloss, ologits = co.ora.train_step(ob)
+        assert_close(eng.logit[:B], ologits, tol["l_rtol"], tol["l_atol"], "logits step %d" % i)
+        assert abs(float(loss) - oloss) <= tol["loss_rtol"] * max(1.0, abs(oloss)), (i, float(loss), oloss)
+        co.assert_state_matches(tol["p_rtol"], tol["p_atol"], kink=tol["kink"])
+        floss, _ = free.train_step(ob)
+    assert abs(float(loss) - floss) <= 1e-3 * max(1.0, abs(floss)), ("free-running drift", float(loss), floss)
+    # rows no batch touches: bit-identical to the initial tables
+    # (elementwise compare + row reduction: boolean-mask gathers of a 100M-row table are not reliable in this torch build)
+    if emb0 is not None and len(eng.plan.emb_groups) == 1 and all(s.deep == "embedding" for s in eng.plan.slots):
+        (dim, _), = eng.plan.emb_groups.items()
+        n = touched.numel()
+        changed = (emb0.view(-1, dim)[:n] != eng.emb.view(-1, dim)[:n]).any(dim=1)
+        assert not bool((changed & ~touched).any()), "an embedding row no batch touches changed"
     if wide0 is not None:
-        assert torch.equal(wide0[~touched], eng.wide[~touched])
+        changed = (wide0 != eng.wide).any(dim=1)
+        assert not bool((changed & ~touched).any()), "a wide row no batch touches changed"
+    del emb0, wide0, co, free
+    # ---- the replay bench.py times: n_graph steps per hipGraph, each on its own batch, on a twin engine ----------------
+    twin = mk()
+    tbs2 = [synth.TokenBatch(twin.plan, hb, weights=_weights(spec, hb)) for hb in hbs]
+    with torch.cuda.stream(side):
+        step_eager(twin, tbs2[0])
+    torch.cuda.synchronize()
+    graphs = [StepGraph(twin, tbs2[j: j + n_graph], stream=side) for j in range(1, n_steps, n_graph)]
+    for g in graphs:
+        g.replay()
+    torch.cuda.synchronize()
+    _bit_identical(eng, twin)
     return eng
 
 
@@ -109,12 +140,12 @@ def _c2(buckets=1_000_000):
 
 @pytest.mark.parametrize("dist", ["uniform", "zipf"])
 def test_c2_full_size_bench_path_matches_oracle(dist):
-    eng = _fullsize(_c2(), 8192, 1, dist, n_eager=3, n_graph=8)
+    eng = _fullsize(_c2(), 8192, 1, dist, n_steps=9, n_graph=8)
     assert eng.chain and eng._fused_input_layer       # the path bench.py times: one-launch tower, input layer fused
 
 
 def test_c3_100m_row_table_one_gpu_matches_oracle():
-    eng = _fullsize(_c2(buckets=3_846_154), 8192, 1, "uniform", n_eager=1, n_graph=2)
+    eng = _fullsize(_c2(buckets=3_846_154), 8192, 1, "uniform", n_steps=3, n_graph=2)
     assert eng.plan.total_rows == 26 * 3_846_154
 
 
@@ -122,12 +153,12 @@ def test_c4_full_size_multi_hot_resnet_weights_matches_oracle():
     from wide_deep_amd.plan import criteo_spec
     spec = criteo_spec(n_dense=13, n_sparse=26, buckets=1_000_000, dim=16, hidden=(256, 128, 64), mode="resnet",
                        use_weight_column=True)
-    _fullsize(spec, 8192, 5, "zipf", n_eager=2, n_graph=2)
+    _fullsize(spec, 8192, 5, "zipf", n_steps=3, n_graph=2)
 
 
 def test_c5_full_size_fp16_tower_matches_oracle():
     from wide_deep_amd.plan import criteo_spec
     spec = criteo_spec(n_dense=13, n_sparse=26, buckets=1_000_000, dim=64, hidden=(1024, 512, 256, 128), mode="dense",
                        model_type="deep")
-    eng = _fullsize(spec, 8192, 1, "uniform", n_eager=2, n_graph=2, tower_dtype="fp16", tol=(2e-2, 3e-2, 2e-2, 2e-3))
+    eng = _fullsize(spec, 8192, 1, "uniform", n_steps=3, n_graph=2, tower_dtype="fp16", tol=FP16_TOL)
     assert eng.half

@@ -123,6 +123,7 @@ _PROTOS = {
     "wd_dense_fwd": [P, I64, P, I32, I64, P, I64, P],
     "wd_wide_fwd": [P, I32, P, P, I32, P, P, I64, P, P],
     "wd_bce_sum_fwd_bwd": [P, P, P, P, I64, P, P, P, P, P],
+    "wd_bce_loss_sum": [P, P, P, I64, P, P],
     "wd_sort_workspace_bytes": [I64, I32],
     "wd_build_sort_keys": [P, I32, P, P, I64, I64, P, P, P],
     "wd_sort_pairs": [P, P, P, P, I64, I32, P, SZ, P],

@@ -383,7 +383,38 @@ __global__ void k_bce(const float *__restrict__ dnn_logit, const float *__restri
   if ((threadIdx.x & 63) == 0 && loss_sum) atomicAdd(loss_sum, l);
 }
 
+// loss_sum[0] = sum_b w_b * CE(logit_b, y_b), REPRODUCIBLE: one workgroup, thread t adds examples t, t + 1024, ... in
+// that order, then a fixed-shape tree over the 1024 partials (the head kernels above add their per-wave partials with a
+// float atomic, i.e. in arrival order).
+__global__ void __launch_bounds__(1024)
+k_bce_loss_sum(const float *__restrict__ logit, const float *__restrict__ labels, const float *__restrict__ weights,
+               int64_t batch, float *__restrict__ loss_sum) {
+  __shared__ float part[1024];
+  float l = 0.f;
+  for (int64_t i = threadIdx.x; i < batch; i += 1024) {
+    const float x = logit[i], y = labels[i];
+    const float w = weights ? weights[i] : 1.0f;
+    l += w * (fmaxf(x, 0.f) - x * y + log1pf(expf(-fabsf(x))));
+  }
+  part[threadIdx.x] = l;
+  __syncthreads();
+  for (int off = 512; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) part[threadIdx.x] += part[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) loss_sum[0] = part[0];
+}
+
 }  // namespace
+
+extern "C" int wd_bce_loss_sum(const float *logit, const float *labels, const float *weights, int64_t batch,
+                               float *loss_sum, wd_stream_t stream) {
+  WD_REQUIRE(loss_sum, "null pointer");
+  WD_REQUIRE(batch <= 0 || (logit && labels), "null pointer");
+  hipLaunchKernelGGL(k_bce_loss_sum, dim3(1), dim3(1024), 0, wd::as_stream(stream), logit, labels, weights,
+                     batch > 0 ? batch : 0, loss_sum);
+  return wd::check_launch("wd_bce_loss_sum");
+}
 
 static int embag_fwd_impl(const float *emb, int64_t row_stride, const wd_slot_t *slots, int32_t S,
                           const int32_t *group_slots, int32_t ngroup, int32_t dim, const int32_t *ids,

@@ -566,13 +566,18 @@ class WideDeepEngine:
     def _plain_head(self, dnn_logit, bt, B, st, train):
         if train:
             call("wd_bce_sum_fwd_bwd", ptr(dnn_logit), ptr(self.wide_logit), ptr(bt.labels), ptr(bt.weights), B,
-                 ptr(self.logit), ptr(self.prob), ptr(self.dlogit), ptr(self.loss), st)
+                 ptr(self.logit), ptr(self.prob), ptr(self.dlogit), None, st)
+            self._loss_sum(bt, B, st)
         else:
             # logits / probabilities only: reuse the head kernel with a zero label vector
             zeros = self.dlogit
             zeros[:B].zero_()
             call("wd_bce_sum_fwd_bwd", ptr(dnn_logit), ptr(self.wide_logit), ptr(zeros), None, B, ptr(self.logit),
                  ptr(self.prob), None, None, st)
+
+    def _loss_sum(self, bt, B, st):
+        """Batch-SUM loss from the stored logits in a fixed summation order (the head kernels' own sum is a float atomic)."""
+        call("wd_bce_loss_sum", ptr(self.logit), ptr(bt.labels), ptr(bt.weights), B, ptr(self.loss), st)
 
     def _drop_layer(self, tw, l):
         return self.towers.index(tw) * 64 + l          # layer id that enters the keep function
@@ -628,8 +633,9 @@ class WideDeepEngine:
             call(head, a_ptr, tl.ld, m["K"], ptr(tw["Wf"][L]), ptr(tw["bf"][L]), capi.WD_FOLD_PARTS,
                  ptr(self.wide_logit), ptr(bt.labels) if train else None, ptr(bt.weights) if train else None, B,
                  ptr(tw["logit"]), ptr(self.logit), ptr(self.prob), ptr(self.dlogit) if train else None,
-                 ptr(self.loss) if train else None, out_ptr, ld_out, act_id,
-                 ptr(tw["Gpart"][L]) if train else None, st)
+                 None, out_ptr, ld_out, act_id, ptr(tw["Gpart"][L]) if train else None, st)
+            if train:
+                self._loss_sum(bt, B, st)
         else:
             call(head, a_ptr, tl.ld, m["K"], ptr(tw["Wf"][L]), ptr(tw["bf"][L]), capi.WD_FOLD_PARTS,
                  None, None, None, B, ptr(tw["logit"]), None, None, None, None, None, 0, 0, None, st)

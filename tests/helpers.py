@@ -204,7 +204,7 @@ class CompactOracle:
             ob["ids"][s.name] = (r.astype(np.int64), o)
         return ob
 
-    def assert_state_matches(self, rtol, atol, kink=None):
+    def assert_state_matches(self, rtol, atol, kink=None, slot_kink=None):
         """every touched table row (+ optimizer slots) and every dense parameter of the engine against the oracle.
         kink = (max_fraction, rtol2, atol2): up to that fraction of a tensor's elements may miss (rtol, atol) as long as they
         meet (rtol2, atol2) -- a ReLU pre-activation that rounds to +0 in one summation order and to -0 / -eps in the other
@@ -212,7 +212,9 @@ class CompactOracle:
         example's worth) everything below move by a discrete amount (seen ~once per 10 steps at batch 8192)."""
         eng, spec, ora = self.eng, self.eng.spec, self.ora
 
-        def close(a, b, what):
+        def close(a, b, what, kink=kink):
+            if slot_kink is not None and what.rsplit("/", 1)[-1] in ("Adagrad", "Ftrl", "Ftrl_1", "RMSProp", "RMSProp_1", "Adam", "Adam_1"):
+                kink = slot_kink            # optimizer slots (sums of squared gradients) under their own bound
             if kink is None:
                 return assert_close(a, b, rtol, atol, what)
             a = torch.as_tensor(a).double().reshape(-1).cpu()

@@ -405,7 +405,8 @@ def main():
                       % (tower_dtype, B),
             }[args.config],
             "global_batch": B * world, "ids": args.dist, "input": "pre-hashed ids" if args.ids_input else "raw string tokens (hashed in step)",
-            "hip_graph": bool(use_graph), "steps_per_graph": steps_per_run, "parallelism": "dp%d+row-sharded tables" % world if sharded else "single GPU",
+            "hip_graph": bool(use_graph), "steps_per_graph": steps_per_run,
+            "pipelined_graph": bool(use_graph and not sharded and multis and multis[0].pipelined) if use_graph and not sharded else False, "parallelism": "dp%d+row-sharded tables" % world if sharded else "single GPU",
             "final_loss_sum": round(loss, 3),
         },
     }

@@ -344,16 +344,18 @@ typedef struct wd_mlp_layer {
   float *Wf, *bf, *s, *t;   /* folded outputs (as wd_fold_affine) */
   const float *Gpart;       /* split-K partials of this layer (as wd_mlp_finalize) */
   int32_t nsplit;
-  int32_t pad_;
+  int32_t pk_tile;          /* tile of the packed copies Wpk / WTpk below: 0 or 32, or 16 */
   /* optional IEEE-half copies of the folded kernel for the fp16-input tower (NULL: not written): */
   uint16_t *WfT_h;          /*   transposed kernel WfT_h [N][ld_wft_h] (operand of wd_hgemm_nn) */
   int64_t ld_wft_h;
   const int64_t *cat_off;   /*   [K] element offsets into wcat (< 0: skip): row k of this layer is written to */
   uint16_t *wcat;           /*   wcat[cat_off[k] + n], n < N -- the operand of the segment-gradient GEMM (wd_hgemm_nt) */
   /* optional MFMA-fragment-packed fp32 copies of the folded kernel for wd_tower_chain (NULL: not written; both need
-   * K % 32 == 0 and N % 32 == 0).  A packed operand B [R reduction rows][C columns] is stored as
-   *   pk[((c/32) * (R/8) + r/8) * 256 + ((r%2) * 32 + c%32) * 4 + (r%8)/2]  =  B[r][c]
-   * i.e. one 16-byte load per lane feeds four consecutive v_mfma_f32_32x32x2_f32 steps of a 32-column tile.
+   * K and N multiples of pk_tile).  A packed operand B [R reduction rows][C columns] is stored as
+   *   pk_tile 32:  pk[((c/32) * (R/8)  + r/8)  * 256 + ((r%2) * 32 + c%32) * 4 + (r%8)/2 ]  =  B[r][c]
+   *   pk_tile 16:  pk[((c/16) * (R/16) + r/16) * 256 + ((r%4) * 16 + c%16) * 4 + (r%16)/4]  =  B[r][c]
+   * i.e. one 16-byte load per lane feeds four consecutive v_mfma_f32_32x32x2_f32 (v_mfma_f32_16x16x4_f32) steps of a
+   * 32- (16-) column tile.
    *   Wpk  = pack(Wf)    (R = K, C = N: forward products)      WTpk = pack(Wf^T)  (R = N, C = K: gradient chain) */
   float *Wpk;
   float *WTpk;
@@ -377,6 +379,17 @@ int wd_mlp_finalize_all(const wd_mlp_layer_t *layers_dev, int32_t nlayers, int64
 int wd_mlp_finalize_adagrad_all(const wd_mlp_layer_t *layers_dev, int32_t nlayers, int64_t max_k, float *P, float *Pacc,
                                 float inv, float *Gflat, float lr, wd_stream_t stream);
 
+/* wd_mlp_finalize_adagrad_all AND the wd_fold_affine_all of the NEXT step in one launch (connected_mode `simple`, Adagrad on the
+ * dnn scope: python/lib/joint.py:233-241 with model.yaml's dnn_optimizer): per kernel row the split-K partials are summed,
+ * W / b / BN gamma, beta take their Adagrad step, and the folded row of the UPDATED parameters is written (Wf, Wpk / WTpk,
+ * s, t; the half copies are not).  The folded bias comes out as ONE vector bf[0..N) (consumers pass bias_parts = 1): every
+ * workgroup stores a partial column sum to the workspace and the last one of a layer to arrive adds them in workgroup order.
+ * do_update == 0: fold only (first step / after import: no gradient is read, no parameter moves).
+ * ws: wd_dense_update_fold_ws_bytes(nlayers, max_k, max_n) bytes, its first 256 bytes zeroed once by the caller. */
+int64_t wd_dense_update_fold_ws_bytes(int32_t nlayers, int64_t max_k, int64_t max_n);
+int wd_dense_update_fold(const wd_mlp_layer_t *layers_dev, int32_t nlayers, int64_t max_k, int64_t max_n, float *P, float *Pacc,
+                         float inv, float *Gflat, float lr, int32_t do_update, void *ws, wd_stream_t stream);
+
 /* ---- logits layer + head fused (python/lib/dnn.py:226-232, python/lib/joint.py:216-222,264-269) ----
  * dnn_logit[b] = a[b, 0..K) . wf + sum(bf parts); logit = dnn_logit + wide_logit (may be NULL); sigmoid CE SUM into
  * loss_sum (+=), prob, dlogit = w*(p-y).  Backward of the logits layer in the same launch:
@@ -392,14 +405,15 @@ int wd_logits_head(const float *a, int64_t ld_a, int64_t K, const float *wf, con
 
 /* ---- whole `simple` tower in one launch (csrc/mlp_chain.hip) -------------------------------------------------------
  * python/lib/dnn.py:92-141 (dense -> activation -> BN per hidden layer, BN folded as above), dnn.py:226-232 (logits),
- * python/lib/joint.py:216-222, 264-269 (joint logit, sigmoid CE) for one 32-example row tile per workgroup:
+ * python/lib/joint.py:216-222, 264-269 (joint logit, sigmoid CE) for one row tile (wd_chain_opts_t.row_tile: 32 or 16
+ * examples) per workgroup:
  *   a_l = act(a_{l-1} Wf_l + bf_l) (l < L), dnn_logit = a_{L-1} . w_logits + b, head as wd_logits_head, and with labels
  *   dz_{L-1} = dlogit w_logits^T * act'(a_{L-1}), dz_{l-1} = (dz_l Wf_l^T) * act'(a_{l-1}), dx = dz_0 Wf_0^T.
  * a_l is written to layers[l].a_out (row stride ld_act, as the per-layer GEMMs do), dz_l to layers[l].dz_out [batch][N_l]
  * -- the operands of the weight-gradient products wd_gemm_tn_splitk, which stay separate launches -- the first dx_cols
  * columns of dx to dx[b*ld_dx + k], and the logits-layer gradient partials to Gpart_logits (wd_mlp_finalize layout,
- * nsplit = wd_tower_chain_blocks(batch)).  labels NULL: forward only.  Shapes: K0 and every N_l multiples of 32 and
- * wd_tower_chain_lds_bytes(K0, N, L) > 0 (else the call fails: use the per-layer GEMMs). */
+ * nsplit = wd_tower_chain_blocks(batch, row_tile)).  labels NULL: forward only.  Shapes: K0 and every N_l multiples of the
+ * row tile and wd_tower_chain_lds_bytes(K0, N, L, row_tile) > 0 (else the call fails: use the per-layer GEMMs). */
 #define WD_CHAIN_MAX_LAYERS 6
 typedef struct wd_chain_layer {
   const float *Wpk;  /* packed folded kernel (wd_mlp_layer_t.Wpk, written by wd_fold_affine_all) */
@@ -407,7 +421,7 @@ typedef struct wd_chain_layer {
   const float *bf;   /* bias_parts x N partial folded biases */
   float *a_out;      /* activations of this layer inside the tower's activation buffer */
   float *dz_out;     /* [batch][N] */
-  float *db_part;    /* optional [wd_tower_chain_blocks(batch)][N]: per row tile, the column sums of dz (bias gradient partials) */
+  float *db_part;    /* optional [wd_tower_chain_blocks(batch, row_tile)][N]: per row tile, the column sums of dz (bias gradient partials) */
   int32_t K, N;
 } wd_chain_layer_t;
 /* Optional (wd_chain_opts_t.input): fuse the input layer into the call (one-id-per-bag batches, the Criteo shape): the kernel
@@ -437,18 +451,27 @@ typedef struct wd_chain_input {
 } wd_chain_input_t;
 /* Per-call options of wd_tower_chain (pass NULL for none; nothing is remembered between calls):
  *   input      fused input layer, above
- *   loss_part  store each row tile's loss to loss_part[tile] (wd_tower_chain_blocks(batch) floats, plain stores) instead of
+ *   loss_part  store each row tile's loss to loss_part[tile] (wd_tower_chain_blocks(batch, row_tile) floats, plain stores) instead of
  *              adding it atomically to loss_sum -- the caller sums them in tile order (a column-sum job of
  *              wd_gemm_tn_splitk_group): a reproducible loss that needs no zeroed accumulator
  *   stamps     diagnostics: device uint64[64]; workgroups 0 and 100 write shader-clock stamps (start, x tile in LDS, after
- *              each forward layer, head, after each gradient stage, end) to [0..31] / [32..63] */
+ *              each forward layer, head, after each gradient stage, end) to [0..31] / [32..63]
+ *   row_tile   examples per workgroup: 0 or 32 -> v_mfma_f32_32x32x2_f32, one workgroup per CU; 16 -> v_mfma_f32_16x16x4_f32,
+ *              half the LDS, two workgroups per CU (one computes while the other gathers / stores / waits at a barrier).
+ *              Wpk / WTpk must be packed for the same tile (wd_mlp_layer_t.pk_tile); every width a multiple of it
+ *   tile_stamps diagnostics: device uint64[2 * wd_tower_chain_blocks]: every workgroup stores the constant-rate realtime
+ *              clock (100 MHz, chip-wide) at its start and when its x tile is complete in LDS -- bench.py derives the
+ *              in-step gather span from them */
 typedef struct wd_chain_opts {
   const wd_chain_input_t *input;
   float *loss_part;
   void *stamps;
+  void *tile_stamps;
+  int32_t row_tile;
+  int32_t flags;       /* bit 0: row tile 16 without the priority split between the two co-resident workgroups (A/B switch) */
 } wd_chain_opts_t;
-int64_t wd_tower_chain_lds_bytes(int32_t K0, const int32_t *N, int32_t L);   /* -1: unsupported shape */
-int64_t wd_tower_chain_blocks(int64_t batch);
+int64_t wd_tower_chain_lds_bytes(int32_t K0, const int32_t *N, int32_t L, int32_t row_tile);   /* -1: unsupported shape */
+int64_t wd_tower_chain_blocks(int64_t batch, int32_t row_tile);   /* ceil(batch / row_tile) */
 int wd_tower_chain(const float *x, int64_t ld_act, int32_t K0, const wd_chain_layer_t *layers, int32_t L, int32_t act,
                    int32_t bias_parts, const float *w_logits, const float *b_logits, const float *wide_logit,
                    const float *labels, const float *weights, int64_t batch, float *dnn_logit, float *logit,
@@ -516,6 +539,12 @@ int wd_adagrad_dense(float *w, float *accum, const float *g, int64_t n, float lr
 /* Diagnostic (bench-only): n random 64-byte row reads from `table` (row = 16 floats) with `per` independent rows in
  * flight per 4-lane group; writes one float per wavefront to out.  Measures the random-gather ceiling of the part. */
 int wd_diag_gather64(const float *table, const int32_t *ids, int64_t n, int32_t per, float *out, wd_stream_t stream);
+
+/* Diagnostic (bench-only): n items, item j touching bytes[s] bytes at base[s] + ids[j] * stride_bytes[s] in each of nseg <= 3
+ * tables (16-byte pieces, <= 256 bytes per item, `per` items in flight per 16-lane group); rmw != 0 writes every piece back.
+ * Prices table-row layouts (scripts/bench_layouts.py): separate embedding / accumulator / wide lines against one record. */
+int wd_diag_access(float *const *base, const int64_t *stride_bytes, const int32_t *bytes, int32_t nseg, const int32_t *ids,
+                   int64_t n, int32_t per, int32_t rmw, float *out, wd_stream_t stream);
 
 /* misc plumbing */
 int wd_fill_f32(float *p, float v, int64_t n, wd_stream_t stream);

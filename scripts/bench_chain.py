@@ -44,6 +44,7 @@ tw["dx_cols"] = 0
 nodx = timeit(lambda: eng._tower_chain(tw, bt, B, st, True))
 tw["dx_cols"] = dxc
 fwd = timeit(lambda: eng._tower_chain(tw, bt, B, st, False))
+print("row tile %d (WD_CHAIN_RT)" % eng.chain_rt)
 print("chain B=%d hidden=%s: with fused input layer %.1f us | x from HBM: full %.1f us, no dx %.1f us, forward only %.1f us "
       "(forward GEMM flops %.2f G)" % (B, hidden, fused, full, nodx, fwd, fl_f / 1e9))
 
@@ -60,3 +61,17 @@ for wg, off in ((0, 0), (100, 32)):
 v = stamps[16:32].cpu().tolist()
 print("wg0 wave0 F0: mma %d, epilogue x2 %d | dx pair 1: mma %d, epilogue %d; pair 2: mma %d, epilogue %d" % (
     v[1] - v[0], v[2] - v[1], v[5] - v[4], v[6] - v[5], v[8] - v[7], v[9] - v[8]))
+
+
+# in-step gather span from the per-tile realtime stamps (100 MHz): max(x tile ready) - min(start) over all workgroups
+nt = (B + eng.chain_rt - 1) // eng.chain_rt
+ts = torch.zeros(2 * nt, dtype=torch.int64, device="cuda")
+eng._chain_tile_stamps = ts.data_ptr()
+for rep in range(3):
+    eng._tower_chain(tw, bt, B, st, True, fuse)
+    torch.cuda.synchronize()
+    v = ts.cpu().view(nt, 2)
+    print("tile stamps (rep %d): start spread %.2f us, gather span (first start -> last x tile ready) %.2f us, median per-tile %.2f us"
+          % (rep, (v[:, 0].max() - v[:, 0].min()).item() / 100.0, (v[:, 1].max() - v[:, 0].min()).item() / 100.0,
+             (v[:, 1] - v[:, 0]).float().median().item() / 100.0))
+eng._chain_tile_stamps = None

@@ -11,6 +11,13 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=[16, 32])
+def row_tile(request, monkeypatch):
+    """every test of this file runs on both row tiles of the kernel (wd_chain_opts_t.row_tile; engine: WD_CHAIN_RT)"""
+    monkeypatch.setenv("WD_CHAIN_RT", str(request.param))
+    return request.param
+
+
 def _engines(spec, max_batch, seed=5):
     from wide_deep_amd.engine import WideDeepEngine
     chain = WideDeepEngine(spec, max_batch=max_batch, seed=seed)
@@ -19,7 +26,7 @@ def _engines(spec, max_batch, seed=5):
         layered = WideDeepEngine(spec, max_batch=max_batch, seed=seed)
     finally:
         del os.environ["WD_CHAIN"]
-    assert chain.chain and not layered.chain
+    assert chain.chain and not layered.chain and chain.chain_rt == int(os.environ["WD_CHAIN_RT"])
     return chain, layered
 
 

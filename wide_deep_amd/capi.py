@@ -47,7 +47,7 @@ class WdMlpLayer(ctypes.Structure):
         ("w_off", ctypes.c_int64), ("b_off", ctypes.c_int64), ("K", ctypes.c_int64), ("N", ctypes.c_int64),
         ("gamma_idx", ctypes.c_void_p), ("beta_idx", ctypes.c_void_p),
         ("Wf", ctypes.c_void_p), ("bf", ctypes.c_void_p), ("s", ctypes.c_void_p), ("t", ctypes.c_void_p),
-        ("Gpart", ctypes.c_void_p), ("nsplit", ctypes.c_int32), ("pad_", ctypes.c_int32),
+        ("Gpart", ctypes.c_void_p), ("nsplit", ctypes.c_int32), ("pk_tile", ctypes.c_int32),
         ("WfT_h", ctypes.c_void_p), ("ld_wft_h", ctypes.c_int64), ("cat_off", ctypes.c_void_p), ("wcat", ctypes.c_void_p),
         ("Wpk", ctypes.c_void_p), ("WTpk", ctypes.c_void_p), ("db_sum", ctypes.c_void_p),
     ]
@@ -79,7 +79,8 @@ WD_CHAIN_MAX_SLOTS = 128
 
 
 class WdChainOpts(ctypes.Structure):
-    _fields_ = [("input", ctypes.c_void_p), ("loss_part", ctypes.c_void_p), ("stamps", ctypes.c_void_p)]
+    _fields_ = [("input", ctypes.c_void_p), ("loss_part", ctypes.c_void_p), ("stamps", ctypes.c_void_p),
+                ("tile_stamps", ctypes.c_void_p), ("row_tile", ctypes.c_int32), ("flags", ctypes.c_int32)]
 
 
 class WdTnJob(ctypes.Structure):
@@ -149,13 +150,15 @@ _PROTOS = {
     "wd_mlp_finalize_all": [P, I32, I64, P, F32, P, P],
     "wd_mlp_finalize_adagrad_all": [P, I32, I64, P, P, F32, P, F32, P],
     "wd_logits_head_blocks": [I64, I64],
+    "wd_dense_update_fold_ws_bytes": [I32, I64, I64],
+    "wd_dense_update_fold": [P, I32, I64, I64, P, P, F32, P, F32, I32, P, P],
     "wd_gemm_tn_splitk_group": [P, I32, P],
     "wd_sparse_apply_opt": [P, P, P, P, P, P, I32, P, I64, P, I64, P, I64, P, P, P, P, I32, P, P],
     "wd_opt_dense": [P, P, P, P, I64, P, P],
     "wd_adam_untouched": [P, P, P, P, P, I32, I64, I64, P, P, P, P],
     "wd_adam_tick": [P, F32, F32, P],
-    "wd_tower_chain_lds_bytes": [I32, P, I32],
-    "wd_tower_chain_blocks": [I64],
+    "wd_tower_chain_lds_bytes": [I32, P, I32, I32],
+    "wd_tower_chain_blocks": [I64, I32],
     "wd_tower_chain": [P, I64, I32, P, I32, I32, I32, P, P, P, P, P, I64, P, P, P, P, P, P, P, I64, I32, P, P],
     "wd_logits_head_h": [P, I64, I64, P, P, I32, P, P, P, I64, P, P, P, P, P, P, I64, I32, P, P],
     "wd_hgemm_nn": [P, I64, P, I64, P, I32, I32, P, I64, P, I64, I64, I64, I64, P],
@@ -172,8 +175,9 @@ _PROTOS = {
     "wd_adagrad_dense": [P, P, P, I64, F32, P],
     "wd_fill_f32": [P, F32, I64, P],
     "wd_diag_gather64": [P, P, I64, I32, P, P],
+    "wd_diag_access": [P, P, P, I32, P, I64, I32, I32, P, P],
 }
-_RESTYPES = {"wd_sort_workspace_bytes": SZ, "wd_logits_head_blocks": I64, "wd_tower_chain_lds_bytes": I64, "wd_tower_chain_blocks": I64, "wd_bucket_max": I32, "wd_bucket_chunks": I32, "wd_route_chunks": I32}
+_RESTYPES = {"wd_dense_update_fold_ws_bytes": I64, "wd_sort_workspace_bytes": SZ, "wd_logits_head_blocks": I64, "wd_tower_chain_lds_bytes": I64, "wd_tower_chain_blocks": I64, "wd_bucket_max": I32, "wd_bucket_chunks": I32, "wd_route_chunks": I32}
 
 EXPORTED_SYMBOLS = sorted(list(_PROTOS) + ["wd_last_error"])
 
@@ -189,11 +193,12 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    path = os.environ.get("WD_HIP_LIB", LIB_PATH)      # diagnostics: an experiment build of the same ABI
+    if not os.path.exists(path):
         raise WdError(
             "HIP extension %s not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
-            "(wide_deep_amd/csrc/build.sh).  There is no CPU fallback for the hot path." % LIB_PATH)
-    lib = ctypes.CDLL(LIB_PATH)
+            "(wide_deep_amd/csrc/build.sh).  There is no CPU fallback for the hot path." % path)
+    lib = ctypes.CDLL(path)
     lib.wd_last_error.restype = ctypes.c_char_p
     lib.wd_last_error.argtypes = []
     for name, argtypes in _PROTOS.items():

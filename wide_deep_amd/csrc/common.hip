@@ -54,6 +54,76 @@ __global__ void __launch_bounds__(256) k_diag_gather64(const float4 *__restrict_
   if ((threadIdx.x & 63) == 0) out[((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6] = v;
 }
 
+// random accesses to up to three tables per item (bench-only): item j touches, in table s, the n16[s] 16-byte pieces at
+// base[s] + ids[j] * stride16[s]; 16 lanes per item, `PER` items per lane group in flight; rmw: every piece is written back
+// (+1).  Prices the layouts of a table row (separate emb / accumulator / wide lines vs one record).
+struct DiagSegs {
+  float4 *base[3];
+  int64_t stride16[3];
+  int32_t n16[3];
+  int32_t nseg;
+};
+template <int PER>
+__global__ void __launch_bounds__(256) k_diag_access(DiagSegs sg, const int32_t *__restrict__ ids, int64_t n, int rmw,
+                                                     float *__restrict__ out) {
+  const int64_t grp = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 4;
+  const int lane = threadIdx.x & 15;
+  int seg = -1, piece = 0, acc16 = 0;
+  for (int s = 0; s < sg.nseg; ++s) {
+    if (seg < 0 && lane < acc16 + sg.n16[s]) { seg = s; piece = lane - acc16; }
+    acc16 += sg.n16[s];
+  }
+  float4 r[PER];
+  float4 *addr[PER];
+#pragma unroll
+  for (int q = 0; q < PER; ++q) {
+    const int64_t j = grp * PER + q;
+    addr[q] = nullptr;
+    r[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (j < n && seg >= 0) addr[q] = sg.base[seg] + (int64_t)ids[j] * sg.stride16[seg] + piece;
+  }
+#pragma unroll
+  for (int q = 0; q < PER; ++q)
+    if (addr[q]) r[q] = *addr[q];
+  float v = 0.f;
+#pragma unroll
+  for (int q = 0; q < PER; ++q) {
+    if (addr[q] && rmw) {
+      r[q].x += 1.0f;
+      *addr[q] = r[q];
+    }
+    v += r[q].x + r[q].y + r[q].z + r[q].w;
+  }
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  if ((threadIdx.x & 63) == 0) out[(((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6) & 0xFFFF] = v;
+}
+
+extern "C" int wd_diag_access(float *const *base, const int64_t *stride_bytes, const int32_t *bytes, int32_t nseg,
+                              const int32_t *ids, int64_t n, int32_t per, int32_t rmw, float *out, wd_stream_t stream) {
+  if (n <= 0) return WD_OK;
+  WD_REQUIRE(nseg >= 1 && nseg <= 3, "1..3 segments");
+  DiagSegs sg{};
+  int tot = 0;
+  for (int s = 0; s < nseg; ++s) {
+    WD_REQUIRE(bytes[s] % 16 == 0 && stride_bytes[s] % 16 == 0, "16-byte pieces");
+    sg.base[s] = reinterpret_cast<float4 *>(base[s]);
+    sg.stride16[s] = stride_bytes[s] / 16;
+    sg.n16[s] = bytes[s] / 16;
+    tot += sg.n16[s];
+  }
+  WD_REQUIRE(tot <= 16, "at most 256 bytes per item");
+  sg.nseg = nseg;
+  hipStream_t st = wd::as_stream(stream);
+  const unsigned blocks = (unsigned)wd::ceil_div(wd::ceil_div(n, per) * 16, 256);
+  switch (per) {
+    case 1: hipLaunchKernelGGL(k_diag_access<1>, dim3(blocks), dim3(256), 0, st, sg, ids, n, rmw, out); break;
+    case 2: hipLaunchKernelGGL(k_diag_access<2>, dim3(blocks), dim3(256), 0, st, sg, ids, n, rmw, out); break;
+    case 4: hipLaunchKernelGGL(k_diag_access<4>, dim3(blocks), dim3(256), 0, st, sg, ids, n, rmw, out); break;
+    default: wd::set_error("wd_diag_access: per must be 1, 2 or 4"); return WD_ERR_INVALID;
+  }
+  return wd::check_launch("wd_diag_access");
+}
+
 extern "C" int wd_diag_gather64(const float *table, const int32_t *ids, int64_t n, int32_t per, float *out,
                                 wd_stream_t stream) {
   if (n <= 0) return WD_OK;

@@ -14,10 +14,18 @@
 // cold L2 after the kernel boundary, epilogue; profiles/r1h_gemm_microbench.txt) -- the small layers are pure launch
 // latency.  Per CU the tile's work is ~35 us of v_mfma_f32_32x32x2_f32 at full rate.
 //
-// Data flow per workgroup (256 lanes = 4 wavefronts, ONE per SIMD, one workgroup per CU):
-//   * activations live in LDS reduction-major  [k][33]  (32 examples + 1 pad): the A fragment of MFMA step k is the
-//     conflict-free row read lds[(k + lane/32) * 33 + lane%32]; an accumulator (col = lane%32 per register row) is
-//     written back transposed with bank = (n + m) % 32, also conflict-free.
+// Row tile RT = 32 (v_mfma_f32_32x32x2_f32, one workgroup per CU) or RT = 16 (v_mfma_f32_16x16x4_f32, the default since
+// round 2): at batch 8192 a 32-row tile gives exactly 256 workgroups = ONE wavefront per SIMD, and everything that is not
+// an MFMA -- the gather of the x tile, the epilogues, the barriers between stages, the head -- leaves the matrix pipe idle
+// (profiles/r1w_tower_chain_stage_cycles.txt: 177 k cycles per tile of which 76 k are MFMA issue).  A 16-row tile needs
+// half the LDS (61 KB at C2), so TWO workgroups share a CU, drift out of phase, and one computes while the other gathers /
+// stores / waits at a barrier.  Same FLOPs per instruction-cycle (16x16x4 issues every 32 cycles), twice the weight
+// traffic from L2 (every tile streams all weights), half the rows per epilogue.
+//
+// Data flow per workgroup (256 lanes = 4 wavefronts, one per SIMD):
+//   * activations live in LDS reduction-major  [k][RT+1]  (RT examples + 1 pad): the A fragment of MFMA step k is the
+//     row read lds[(k + lane/RT) * (RT+1) + lane%RT]; an accumulator (col = lane%RT per register row) is written back
+//     transposed (2-way bank conflicts at most, free for ds_write_b32).
 //   * weights are NOT staged in LDS: wavefront w owns the output columns [32w, 32w+32) (+128 ..), nobody else reads
 //     them, so the B fragments are loaded straight from L2 into registers.  wd_fold_affine_all writes the folded kernel
 //     (and its transpose, for the gradient chain) in MFMA-fragment order (wd_mlp_layer_t.Wpk / WTpk): ONE 16-byte load
@@ -34,13 +42,31 @@ namespace {
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef float floatx4v __attribute__((ext_vector_type(4)));
 
-constexpr int RT = 32;        // examples per row tile
-constexpr int P = 33;         // LDS pitch of one reduction row
+typedef float floatx4a __attribute__((ext_vector_type(4)));
+
 #ifndef WD_CHAIN_RING
 #define WD_CHAIN_RING 8
 #endif
-constexpr int RING = WD_CHAIN_RING;   // register ring of 8-row reduction groups: groups in flight + 1
+#ifndef WD_CHAIN_RING16
+#define WD_CHAIN_RING16 4
+#endif
 constexpr int MAXL = WD_CHAIN_MAX_LAYERS;
+
+// Geometry of a row tile.  One MFMA covers RT rows x RT columns x KS reduction rows; a "group" is the GK = 4 KS reduction
+// rows that ONE 16-byte weight load per lane feeds (four MFMA steps).
+template <int RT_> struct Tile;
+template <> struct Tile<32> {
+  static constexpr int RT = 32, P = 33, KS = 2, GK = 8, NACC = 16, RING = WD_CHAIN_RING, NTMAX = 2;
+  typedef floatx16 acc_t;
+  static __device__ __forceinline__ acc_t mfma(float a, float b, acc_t c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
+  static __device__ __forceinline__ int row_of(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+};
+template <> struct Tile<16> {
+  static constexpr int RT = 16, P = 17, KS = 4, GK = 16, NACC = 4, RING = WD_CHAIN_RING16, NTMAX = 4;
+  typedef floatx4a acc_t;
+  static __device__ __forceinline__ acc_t mfma(float a, float b, acc_t c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+  static __device__ __forceinline__ int row_of(int r, int h) { return r + 4 * h; }
+};
 
 struct ChainArgs {
   wd_chain_layer_t layer[MAXL];
@@ -62,6 +88,8 @@ struct ChainArgs {
   float *dx;
   int64_t ld_dx;
   unsigned long long *stamps;   // diagnostics (wd_chain_opts_t.stamps): shader-clock stamps of workgroups 0 and 100
+  int32_t prio_split;                // row tile 16: the wavefront in the odd hardware slot of each SIMD runs at priority 3
+  unsigned long long *tile_stamps;   // wd_chain_opts_t.tile_stamps: [tile][2] realtime-clock stamps {start, x tile in LDS}
   wd_chain_input_t in;          // in.emb != NULL: the x tile is built here (input layer fused), wd_chain_opts_t.input
   float *loss_part;             // != NULL: this tile's loss is stored to loss_part[tile] (no atomic on loss_sum)
 };
@@ -111,28 +139,37 @@ __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlan
 // address / load instructions of every group while the matrix pipe idled: 110 instead of 64 cycles per MFMA.)
 // Every prefetch is unconditional (past the end it re-reads the last group and is never used): a load inside a branch
 // would make the wait at the join vmcnt(0), i.e. serialise the prefetch with the MFMAs it is meant to overlap.
-template <int NT, bool FULL>
+template <typename TL, int NT, bool FULL>
 __device__ __forceinline__ void mma_ring(const float *__restrict__ inA, const float4 *__restrict__ WB, int KG,
-                                         int tstride, floatx16 (&acc)[NT]) {
-  constexpr int D = RING;
+                                         int tstride, typename TL::acc_t (&acc)[NT]) {
+  constexpr int D = TL::RING, P = TL::P, GK = TL::GK, KS = TL::KS;
   float fa[D][4];
   float4 fb[D][NT];
+#ifndef WD_CHAIN_EXP
+#define WD_CHAIN_EXP 0      // diagnostics (scripts/gpu_chain_exp.sh): 1 = no MFMAs, 2 = weights loaded once, 3 = A fragments read once
+#endif
   auto load = [&](int buf, int c) {
     const int kg = c < KG ? c : KG - 1;
 #pragma unroll
-    for (int t = 0; t < NT; ++t) fb[buf][t] = WB[kg * 64 + t * tstride];
+    for (int t = 0; t < NT; ++t) fb[buf][t] = WB[(WD_CHAIN_EXP == 2 ? 0 : kg * 64) + t * tstride];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) fa[buf][j] = inA[(8 * kg + 2 * j) * P];
+    for (int j = 0; j < 4; ++j) fa[buf][j] = inA[(WD_CHAIN_EXP == 3 ? 0 : (GK * kg + KS * j)) * P];
   };
   auto mfmas = [&](int buf) {
+#if WD_CHAIN_EXP == 1
 #pragma unroll
-    for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[buf][0], fb[buf][t].x, acc[t], 0, 0, 0);
+    for (int t = 0; t < NT; ++t)
+      acc[t][0] += fa[buf][0] * fb[buf][t].x + fa[buf][1] * fb[buf][t].y + fa[buf][2] * fb[buf][t].z + fa[buf][3] * fb[buf][t].w;
+    return;
+#endif
 #pragma unroll
-    for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[buf][1], fb[buf][t].y, acc[t], 0, 0, 0);
+    for (int t = 0; t < NT; ++t) acc[t] = TL::mfma(fa[buf][0], fb[buf][t].x, acc[t]);
 #pragma unroll
-    for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[buf][2], fb[buf][t].z, acc[t], 0, 0, 0);
+    for (int t = 0; t < NT; ++t) acc[t] = TL::mfma(fa[buf][1], fb[buf][t].y, acc[t]);
 #pragma unroll
-    for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[buf][3], fb[buf][t].w, acc[t], 0, 0, 0);
+    for (int t = 0; t < NT; ++t) acc[t] = TL::mfma(fa[buf][2], fb[buf][t].z, acc[t]);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = TL::mfma(fa[buf][3], fb[buf][t].w, acc[t]);
   };
 #pragma unroll
   for (int i = 0; i < D - 1; ++i) load(i, i);
@@ -147,29 +184,31 @@ __device__ __forceinline__ void mma_ring(const float *__restrict__ inA, const fl
   }
 }
 
-template <int NT>
+template <typename TL, int NT>
 __device__ __forceinline__ void mma_tiles(const float *__restrict__ inA, const float4 *__restrict__ WB, int KG,
-                                          int tstride, floatx16 (&acc)[NT]) {
-  if (KG % RING == 0) mma_ring<NT, true>(inA, WB, KG, tstride, acc);
-  else mma_ring<NT, false>(inA, WB, KG, tstride, acc);
+                                          int tstride, typename TL::acc_t (&acc)[NT]) {
+  if (KG % TL::RING == 0) mma_ring<TL, NT, true>(inA, WB, KG, tstride, acc);
+  else mma_ring<TL, NT, false>(inA, WB, KG, tstride, acc);
 }
 
-// One product stage: out[32 x N] = epilogue(in[32 x K] . W[K x N]).  Wavefront w takes the 32-column tiles
-// w, w+4, w+8, ... two at a time (shared A fragments, two independent accumulator chains).
+// One product stage: out[RT x N] = epilogue(in[RT x K] . W[K x N]).  Wavefront w takes the RT-column tiles
+// w, w+4, w+8, ... NTMAX at a time (shared A fragments, independent accumulator chains).
 //   MODE 0 (forward):  v = act(acc + bias[n])            -> LDS out + HBM g_out[b][n]
 //   MODE 1 (gradient): v = acc * act'(a_prev LDS [n][m]) -> LDS out + HBM g_out[b][n]
 //   MODE 2 (dx):       v = acc                            -> HBM g_out[b][n] only (n < n_store)
-template <int MODE>
+template <typename TL, int MODE>
 __device__ __forceinline__ void stage(const float *__restrict__ in, int K, const float *__restrict__ Wpk, int N,
                                       const float *__restrict__ bias, int bias_parts, int act,
                                       const float *__restrict__ a_prev, float *__restrict__ out,
                                       float *__restrict__ g_out, int64_t ld_g, int n_store, int64_t b0, int64_t batch,
                                       unsigned long long *dbg = nullptr, float *__restrict__ db_out = nullptr) {
+  constexpr int RT = TL::RT, P = TL::P;
+  typedef typename TL::acc_t acc_t;
   const int lane = threadIdx.x & 63, wave = uni((int)(threadIdx.x >> 6));
-  const int c = lane & 31, h = lane >> 5;
+  const int c = lane % RT, h = lane / RT;
   K = uni(K); N = uni(N);
-  const int KG = K >> 3;
-  const int ntiles = N / 32;
+  const int KG = K / TL::GK;
+  const int ntiles = N / RT;
   const float *inA = in + h * P + c;
   // folded bias of column n (sum of the fold launch's partials): loaded BEFORE the reduction loop, used after it
   auto bias_of = [&](int n0) {
@@ -188,15 +227,15 @@ __device__ __forceinline__ void stage(const float *__restrict__ in, int K, const
     return bv;
   };
   const bool full_rows = b0 + RT <= batch;   // uniform: no per-element row predicate in the common case
-  auto epilogue_t = [&](const floatx16 &acc, int n0, float bv, auto act_c, auto full_c) {
+  auto epilogue_t = [&](const acc_t &acc, int n0, float bv, auto act_c, auto full_c) {
     constexpr int ACT = decltype(act_c)::value;   // >= 0: activation known at compile time
     constexpr bool FULLR = decltype(full_c)::value;
     const int n = n0 + c;
     const int a_id = ACT >= 0 ? ACT : act;
     float csum = 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int m = (r & 3) + 8 * (r >> 2) + 4 * h;
+    for (int r = 0; r < TL::NACC; ++r) {
+      const int m = TL::row_of(r, h);
       float v = acc[r];
       if (MODE == 0) v = act_fwd(v + bv, a_id);
       if (MODE == 1) v *= act_bwd(a_prev[n * P + m], a_id);
@@ -204,12 +243,13 @@ __device__ __forceinline__ void stage(const float *__restrict__ in, int K, const
       if ((FULLR || b0 + m < batch) && n < n_store) g_out[(b0 + m) * ld_g + n] = v;
       if (MODE == 1) csum += v;
     }
-    if (MODE == 1 && db_out) {   // bias-gradient partial of this tile: column sum over its 32 rows (rows >= batch are 0)
-      csum += __shfl_xor(csum, 32, 64);
+    if (MODE == 1 && db_out) {   // bias-gradient partial of this tile: column sum over its RT rows (rows >= batch are 0)
+#pragma unroll
+      for (int off = RT; off < 64; off <<= 1) csum += __shfl_xor(csum, off, 64);
       if (h == 0) db_out[n] = csum;
     }
   };
-  auto epilogue = [&](const floatx16 &acc, int n0, float bv) {
+  auto epilogue = [&](const acc_t &acc, int n0, float bv) {
     using std::integral_constant;
     if (act == WD_ACT_RELU || MODE == 2) {
       if (full_rows) epilogue_t(acc, n0, bv, integral_constant<int, WD_ACT_RELU>{}, integral_constant<bool, true>{});
@@ -218,34 +258,43 @@ __device__ __forceinline__ void stage(const float *__restrict__ in, int K, const
       epilogue_t(acc, n0, bv, integral_constant<int, -1>{}, integral_constant<bool, false>{});
     }
   };
-  for (int t0 = wave; t0 < ntiles; t0 += 8) {
+  auto run = [&](int t0, auto nt_c) {
+    constexpr int NT = decltype(nt_c)::value;
     const float4 *WB = reinterpret_cast<const float4 *>(Wpk) + (int64_t)t0 * KG * 64 + lane;
-    if (t0 + 4 < ntiles) {
-      floatx16 acc[2];
+    acc_t acc[NT];
+    float bv[NT];
 #pragma unroll
-      for (int i = 0; i < 16; ++i) acc[0][i] = acc[1][i] = 0.f;
-      const float bv0 = bias_of(t0 * 32), bv1 = bias_of((t0 + 4) * 32);
-      if (dbg && threadIdx.x == 0) *dbg++ = __builtin_readcyclecounter();
-      mma_tiles<2>(inA, WB, KG, 4 * KG * 64, acc);
-      if (dbg && threadIdx.x == 0) *dbg++ = __builtin_readcyclecounter();
-      epilogue(acc[0], t0 * 32, bv0);
-      epilogue(acc[1], (t0 + 4) * 32, bv1);
-      if (dbg && threadIdx.x == 0) *dbg++ = __builtin_readcyclecounter();
-    } else {
-      floatx16 acc[1];
+    for (int i = 0; i < NT; ++i) {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) acc[0][i] = 0.f;
-      const float bv0 = bias_of(t0 * 32);
-      mma_tiles<1>(inA, WB, KG, 0, acc);
-      epilogue(acc[0], t0 * 32, bv0);
+      for (int r = 0; r < TL::NACC; ++r) acc[i][r] = 0.f;
+      bv[i] = bias_of((t0 + 4 * i) * RT);
     }
+    if (dbg && threadIdx.x == 0) *dbg++ = __builtin_readcyclecounter();
+    mma_tiles<TL, NT>(inA, WB, KG, 4 * KG * 64, acc);
+    if (dbg && threadIdx.x == 0) *dbg++ = __builtin_readcyclecounter();
+#pragma unroll
+    for (int i = 0; i < NT; ++i) epilogue(acc[i], (t0 + 4 * i) * RT, bv[i]);
+    if (dbg && threadIdx.x == 0) *dbg++ = __builtin_readcyclecounter();
+  };
+  using std::integral_constant;
+  int t0 = wave;
+  while (t0 < ntiles) {
+    const int left = (ntiles - t0 + 3) / 4;   // tiles of this wavefront still to do
+    if (TL::NTMAX >= 4 && left >= 4) { run(t0, integral_constant<int, (TL::NTMAX >= 4 ? 4 : 1)>{}); t0 += 16; }
+    else if (TL::NTMAX >= 4 && left == 3) { run(t0, integral_constant<int, (TL::NTMAX >= 4 ? 3 : 1)>{}); t0 += 12; }
+    else if (left >= 2) { run(t0, integral_constant<int, 2>{}); t0 += 8; }
+    else { run(t0, integral_constant<int, 1>{}); t0 += 4; }
   }
 }
 
-__global__ void __launch_bounds__(256) k_tower_chain(ChainArgs g) {
+template <int RT_>
+__global__ void __launch_bounds__(256, RT_ == 16 ? 2 : 1) k_tower_chain(ChainArgs g) {
+  typedef Tile<RT_> TL;
+  constexpr int RT = TL::RT, P = TL::P;
+  constexpr int PARTS = 256 / RT;   // lane groups of the head's dot product
   extern __shared__ __attribute__((aligned(16))) float lds[];
   __shared__ float sdl[RT];
-  __shared__ float red[8 * RT];
+  __shared__ float red[256];
   __shared__ float swl[512];   // logits-layer kernel
   __shared__ int64_t s_eoff[WD_CHAIN_MAX_SLOTS], s_rbase[WD_CHAIN_MAX_SLOTS];   // fused input layer: slot descriptors
   __shared__ int32_t s_ocol[WD_CHAIN_MAX_SLOTS];
@@ -260,6 +309,11 @@ __global__ void __launch_bounds__(256) k_tower_chain(ChainArgs g) {
     ++nstamp;
   };
   stamp();
+  if (g.tile_stamps && t == 0) g.tile_stamps[2 * blockIdx.x] = wall_clock64();
+  // Two workgroups per CU (RT = 16) = two wavefronts per SIMD that start together and do the same work: left alone they stay in
+  // lock-step (both gather, both multiply at half rate, both store).  The wavefront in the odd hardware slot gets priority: it
+  // runs its matrix phases at full rate and pulls ahead, the other one fills its gaps.
+  if (RT == 16 && g.prio_split && (__builtin_amdgcn_s_getreg((4) | (0 << 6) | (3 << 11)) & 1u)) __builtin_amdgcn_s_setprio(3);
 
   // ---- head inputs: requested now, consumed after the last hidden layer (no exposed latency there) -------------
   const int KL = uni(g.layer[L - 1].N);
@@ -276,7 +330,7 @@ __global__ void __launch_bounds__(256) k_tower_chain(ChainArgs g) {
   float *s_wide = red;   // [RT] wide logit of the tile's examples (gather mode); `red` is free until the head
   if (g.in.emb) {
     // ---- input layer of the tile, fused (python/lib/dnn.py:88-90 input_layer + python/lib/linear.py:29-36 linear_model
-    // for one-id-per-bag batches): x[m, out_col_s ..] = E_s[id(m, s)], numeric columns, wide logit.  832 random 64-byte
+    // for one-id-per-bag batches): x[m, out_col_s ..] = E_s[id(m, s)], numeric columns, wide logit.  RT x 26 random 64-byte
     // rows per workgroup (C2): ids first (coalesced), then every row / wide line load of the tile in flight at once.
     const wd_chain_input_t &I = g.in;
     const int S = uni(I.S), NG = uni(I.ngroup), D = uni(I.dim), LG = D >> 2;
@@ -297,7 +351,31 @@ __global__ void __launch_bounds__(256) k_tower_chain(ChainArgs g) {
     }
     for (int i = t; i < (int)g.K0 * P; i += 256) regx[i] = 0.f;     // pad columns and dropped ids read as zero
     __syncthreads();
-    // embedding rows: LG lanes per (example, slot of the group), 8 bags per lane group in flight
+    // Everything the tile needs from HBM is requested before anything is waited for: the wide weights (one 16-byte line per
+    // occurrence, the weight is its first float) and the numeric columns first, then the embedding rows (LG lanes per
+    // (example, slot), 8 bags per lane group per round) -- one exposed memory latency instead of three.
+    constexpr int WV = 4, DV = 2;
+    float wv[WV], dv[DV];
+    if (I.wide) {
+#pragma unroll
+      for (int u = 0; u < WV; ++u) {
+        const int i = t + 256 * u;
+        wv[u] = 0.f;
+        if (i < nbag) {
+          const int64_t rb = s_rbase[i % S];
+          const int id = s_id[i];
+          if (rb >= 0 && id >= 0)
+            wv[u] = I.wide_in_row ? I.wide[s_eoff[i % S] + (int64_t)id * RS_ + D]     // weight travels behind its row
+                                  : __builtin_nontemporal_load(I.wide + (rb + id) * 4);
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < DV; ++u) {
+      const int i = t + 256 * u;
+      dv[u] = 0.f;
+      if (i < RT * I.ncols && b0 + i % RT < g.batch) dv[u] = I.dense[(b0 + i % RT) * I.ld_dense + i / RT];
+    }
     const int lg = t % LG, grp = t / LG, ngrp = 256 / LG;
     const int nwork = RT * NG;
     for (int w0 = grp; w0 < nwork; w0 += 8 * ngrp) {
@@ -331,28 +409,33 @@ __global__ void __launch_bounds__(256) k_tower_chain(ChainArgs g) {
         if (b0 + m < g.batch) *reinterpret_cast<floatx4v *>(I.x_out + (b0 + m) * g.ld_act + c0) = r[q];
       }
     }
-    // wide weights (one 16-byte line per occurrence, the weight is its first float) and numeric columns
     if (I.wide) {
-      for (int i = t; i < nbag; i += 256) {
+#pragma unroll
+      for (int u = 0; u < WV; ++u)
+        if (t + 256 * u < nbag) s_w[t + 256 * u] = wv[u];
+      for (int i = t + 256 * WV; i < nbag; i += 256) {     // more than 1024 bags per tile (S > 1024 / RT): the plain loop
         const int64_t rb = s_rbase[i % S];
         const int id = s_id[i];
         if (rb >= 0 && id >= 0)
-          s_w[i] = I.wide_in_row ? I.wide[s_eoff[i % S] + (int64_t)id * RS_ + D]     // weight travels behind its row
-                                 : I.wide[(rb + id) * 4];
+          s_w[i] = I.wide_in_row ? I.wide[s_eoff[i % S] + (int64_t)id * RS_ + D] : I.wide[(rb + id) * 4];
       }
     }
-    for (int i = t; i < RT * I.ncols; i += 256) {
+    auto put_dense = [&](int i, float v) {
       const int m = i % RT, j = i / RT;
-      if (b0 + m < g.batch) {
-        const wd_dense_col_t c = I.cols[j];
-        float v = I.dense[(b0 + m) * I.ld_dense + j];
-        if (c.kind == 1) v = (v - c.p0) / (c.p1 - c.p0);
-        else if (c.kind == 2) v = (v - c.p0) / c.p1;
-        else if (c.kind == 3) v = logf(v);
-        regx[c.out_col * P + m] = v;
-        I.x_out[(b0 + m) * g.ld_act + c.out_col] = v;
-      }
+      const wd_dense_col_t c = I.cols[j];
+      if (c.kind == 1) v = (v - c.p0) / (c.p1 - c.p0);
+      else if (c.kind == 2) v = (v - c.p0) / c.p1;
+      else if (c.kind == 3) v = logf(v);
+      regx[c.out_col * P + m] = v;
+      I.x_out[(b0 + m) * g.ld_act + c.out_col] = v;
+    };
+#pragma unroll
+    for (int u = 0; u < DV; ++u) {
+      const int i = t + 256 * u;
+      if (i < RT * I.ncols && b0 + i % RT < g.batch) put_dense(i, dv[u]);
     }
+    for (int i = t + 256 * DV; i < RT * I.ncols; i += 256)
+      if (b0 + i % RT < g.batch) put_dense(i, I.dense[(b0 + i % RT) * I.ld_dense + i / RT]);
     __syncthreads();
     if (t < RT) {   // wide logit: slots in order (fixed summation order)
       float acc = 0.f;
@@ -364,21 +447,23 @@ __global__ void __launch_bounds__(256) k_tower_chain(ChainArgs g) {
       if (I.wide_out && b0 + t < g.batch) I.wide_out[b0 + t] = acc;
     }
   } else {
-  // ---- x tile -> LDS [k][33] (rows beyond the batch read as zero): all loads of a 512-column block in flight, then
-  // the transposing LDS stores ------------------------------------------------------------------------------
+  // ---- x tile -> LDS [k][P] (rows beyond the batch read as zero): all loads of a column block in flight, then the
+  // transposing LDS stores ----------------------------------------------------------------------------------
   {
-    const int kq = t & 15, mr = t >> 4;  // 16 float4 (64 columns, 256 B) per example row, 16 rows per pass
-    for (int kb = 0; kb < g.K0; kb += 512) {
+    constexpr int RH = RT / 16;           // 16-row passes per tile
+    constexpr int KB = 64 * 16 / RH;      // columns covered by the 16 loads of a lane
+    const int kq = t & 15, mr = t >> 4;   // 16 float4 (64 columns, 256 B) per example row, 16 rows per pass
+    for (int kb = 0; kb < g.K0; kb += KB) {
       float4 v[16];
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        const int m = mr + 16 * (i & 1), k = kb + 64 * (i >> 1) + 4 * kq;
+        const int m = mr + 16 * (i % RH), k = kb + 64 * (i / RH) + 4 * kq;
         const int64_t row = b0 + m < g.batch ? b0 + m : g.batch - 1;   // clamped: the load is unconditional
         v[i] = *reinterpret_cast<const float4 *>(g.x + row * g.ld_act + (k < g.K0 ? k : 0));
       }
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        const int m = mr + 16 * (i & 1), k = kb + 64 * (i >> 1) + 4 * kq;
+        const int m = mr + 16 * (i % RH), k = kb + 64 * (i / RH) + 4 * kq;
         if (k < g.K0) {
           const bool live = b0 + m < g.batch;
           regx[(k + 0) * P + m] = live ? v[i].x : 0.f;
@@ -392,6 +477,7 @@ __global__ void __launch_bounds__(256) k_tower_chain(ChainArgs g) {
   }
   __syncthreads();
   stamp();
+  if (g.tile_stamps && t == 0) g.tile_stamps[2 * blockIdx.x + 1] = wall_clock64();
 
   // ---- forward --------------------------------------------------------------------------------------------
   const float *in = regx;
@@ -399,19 +485,19 @@ __global__ void __launch_bounds__(256) k_tower_chain(ChainArgs g) {
   for (int l = 0; l < L; ++l) {
     const wd_chain_layer_t &ly = g.layer[l];
     float *out = lds + g.a_off[l];
-    stage<0>(in, K, ly.Wpk, ly.N, ly.bf, g.bias_parts, g.act, nullptr, out, ly.a_out, g.ld_act, ly.N, b0, g.batch,
-             (g.stamps && blockIdx.x == 0 && l == 0) ? g.stamps + 16 : nullptr);
+    stage<TL, 0>(in, K, ly.Wpk, ly.N, ly.bf, g.bias_parts, g.act, nullptr, out, ly.a_out, g.ld_act, ly.N, b0, g.batch,
+                 (g.stamps && blockIdx.x == 0 && l == 0) ? g.stamps + 16 : nullptr);
     __syncthreads();
     stamp();
     in = out;
     K = ly.N;
   }
 
-  // ---- logits layer + head (in = a_{L-1} [K][33]) -----------------------------------------------------------
+  // ---- logits layer + head (in = a_{L-1} [K][P]) ------------------------------------------------------------
   {
-    const int m = t & 31, part = t >> 5;
+    const int m = t % RT, part = t / RT;
     float d = 0.f;
-    for (int n = part; n < K; n += 8) d += in[n * P + m] * swl[n];
+    for (int n = part; n < K; n += PARTS) d += in[n * P + m] * swl[n];
     const float h_wide_lds = (g.in.emb && t < RT) ? s_wide[t] : 0.f;   // read before `red` is reused below
     __syncthreads();
     red[part * RT + m] = d;
@@ -419,7 +505,7 @@ __global__ void __launch_bounds__(256) k_tower_chain(ChainArgs g) {
     if (t < RT) {
       float dn = 0.f;
 #pragma unroll
-      for (int p = 0; p < 8; ++p) dn += red[p * RT + t];
+      for (int p = 0; p < PARTS; ++p) dn += red[p * RT + t];
       dn += h_bias;
       const int64_t b = b0 + t;
       float dl = 0.f, ls = 0.f;
@@ -438,7 +524,7 @@ __global__ void __launch_bounds__(256) k_tower_chain(ChainArgs g) {
       }
       sdl[t] = dl;
       if (g.train && (g.loss_sum || g.loss_part)) {
-        for (int off = 16; off > 0; off >>= 1) ls += __shfl_down(ls, off, 64);
+        for (int off = RT / 2; off > 0; off >>= 1) ls += __shfl_down(ls, off, 64);
         if (t == 0) {
           if (g.loss_part) g.loss_part[blockIdx.x] = ls;
           else atomicAdd(g.loss_sum, ls);
@@ -503,27 +589,29 @@ __global__ void __launch_bounds__(256) k_tower_chain(ChainArgs g) {
   for (int l = L - 1; l >= 1; --l) {
     const wd_chain_layer_t &ly = g.layer[l];
     const wd_chain_layer_t &lp = g.layer[l - 1];
-    stage<1>(lds + g.dz_off[l], ly.N, ly.WTpk, lp.N, nullptr, 0, g.act, lds + g.a_off[l - 1], lds + g.dz_off[l - 1],
-             lp.dz_out, lp.N, lp.N, b0, g.batch, nullptr, lp.db_part ? lp.db_part + (int64_t)blockIdx.x * lp.N : nullptr);
+    stage<TL, 1>(lds + g.dz_off[l], ly.N, ly.WTpk, lp.N, nullptr, 0, g.act, lds + g.a_off[l - 1], lds + g.dz_off[l - 1],
+                 lp.dz_out, lp.N, lp.N, b0, g.batch, nullptr, lp.db_part ? lp.db_part + (int64_t)blockIdx.x * lp.N : nullptr);
     __syncthreads();
     stamp();
   }
   if (g.dx && g.dx_cols > 0) {
     const wd_chain_layer_t &ly = g.layer[0];
-    stage<2>(lds + g.dz_off[0], ly.N, ly.WTpk, g.dx_cols, nullptr, 0, 0, nullptr, nullptr, g.dx, g.ld_dx, g.K0, b0,
-             g.batch, (g.stamps && blockIdx.x == 0) ? g.stamps + 20 : nullptr);
+    stage<TL, 2>(lds + g.dz_off[0], ly.N, ly.WTpk, g.dx_cols, nullptr, 0, 0, nullptr, nullptr, g.dx, g.ld_dx, g.K0, b0,
+                 g.batch, (g.stamps && blockIdx.x == 0) ? g.stamps + 20 : nullptr);
   }
   stamp();
 }
 
-inline int round32(int v) { return (v + 31) / 32 * 32; }
+inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+inline bool tile_ok(int rt) { return rt == 16 || rt == 32; }
 
-// LDS layout: [x | dz_{L-1} .. dz_0 aliasing x] [a_0] [a_1] ...
-int64_t chain_layout(int32_t K0, const int32_t *N, int32_t L, int32_t *a_off, int32_t *dz_off) {
-  if (L < 1 || L > MAXL || K0 <= 0 || K0 % 32) return -1;
+// LDS layout: [x | dz_{L-1} .. dz_0 aliasing x] [a_0] [a_1] ...     (rows of P = row_tile + 1 floats)
+int64_t chain_layout(int32_t K0, const int32_t *N, int32_t L, int32_t rt, int32_t *a_off, int32_t *dz_off) {
+  if (!tile_ok(rt) || L < 1 || L > MAXL || K0 <= 0 || K0 % rt) return -1;
+  const int64_t P = rt + 1;
   int64_t sum_n = 0;
   for (int l = 0; l < L; ++l) {
-    if (N[l] <= 0 || N[l] % 32 || N[l] > 512) return -1;
+    if (N[l] <= 0 || N[l] % rt || N[l] > 512) return -1;
     sum_n += N[l];
   }
   const int64_t regx = (K0 > sum_n ? K0 : sum_n) * P;
@@ -543,8 +631,8 @@ int64_t chain_layout(int32_t K0, const int32_t *N, int32_t L, int32_t *a_off, in
 
 }  // namespace
 
-extern "C" int64_t wd_tower_chain_lds_bytes(int32_t K0, const int32_t *N, int32_t L) {
-  return chain_layout(K0, N, L, nullptr, nullptr);
+extern "C" int64_t wd_tower_chain_lds_bytes(int32_t K0, const int32_t *N, int32_t L, int32_t row_tile) {
+  return chain_layout(K0, N, L, row_tile ? row_tile : 32, nullptr, nullptr);
 }
 
 static int check_chain_input(const wd_chain_input_t *in) {
@@ -559,7 +647,26 @@ static int check_chain_input(const wd_chain_input_t *in) {
   return WD_OK;
 }
 
-extern "C" int64_t wd_tower_chain_blocks(int64_t batch) { return wd::ceil_div(batch, RT); }
+extern "C" int64_t wd_tower_chain_blocks(int64_t batch, int32_t row_tile) {
+  return wd::ceil_div(batch, (int64_t)(row_tile ? row_tile : 32));
+}
+
+template <int RT_>
+static int launch_chain(const ChainArgs &g, int64_t bytes, wd_stream_t stream) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_tower_chain<RT_>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    if (e != hipSuccess) {
+      wd::set_error("wd_tower_chain: hipFuncSetAttribute: %s", hipGetErrorString(e));
+      return WD_ERR_LAUNCH;
+    }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(k_tower_chain<RT_>, dim3((unsigned)wd::ceil_div(g.batch, (int64_t)RT_)), dim3(256), (size_t)bytes,
+                     wd::as_stream(stream), g);
+  return wd::check_launch("wd_tower_chain");
+}
 
 extern "C" int wd_tower_chain(const float *x, int64_t ld_act, int32_t K0, const wd_chain_layer_t *layers, int32_t L,
                               int32_t act, int32_t bias_parts, const float *w_logits, const float *b_logits,
@@ -571,6 +678,8 @@ extern "C" int wd_tower_chain(const float *x, int64_t ld_act, int32_t K0, const 
   WD_REQUIRE(x && layers && w_logits && b_logits, "null pointer");
   WD_REQUIRE(L >= 1 && L <= MAXL, "1 <= L <= WD_CHAIN_MAX_LAYERS");
   WD_REQUIRE(ld_act % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0, "x must be 16-byte aligned with ld % 4 == 0");
+  const int rt = (opts && opts->row_tile) ? opts->row_tile : 32;
+  WD_REQUIRE(tile_ok(rt), "wd_chain_opts_t.row_tile must be 0 (= 32), 16 or 32");
   ChainArgs g{};
   int32_t N[MAXL];
   for (int l = 0; l < L; ++l) {
@@ -580,9 +689,9 @@ extern "C" int wd_tower_chain(const float *x, int64_t ld_act, int32_t K0, const 
     WD_REQUIRE(layers[l].K == (l == 0 ? K0 : layers[l - 1].N), "layer K must equal the previous width");
     if (labels) WD_REQUIRE(layers[l].dz_out && (l == 0 ? (!dx || layers[l].WTpk) : layers[l].WTpk != nullptr), "training needs dz_out / WTpk");
   }
-  const int64_t bytes = chain_layout(K0, N, L, g.a_off, g.dz_off);
-  WD_REQUIRE(bytes > 0, "unsupported tower shape (widths must be multiples of 32 and fit the LDS; see wd_tower_chain_lds_bytes)");
-  const int dxc = dx ? round32(dx_cols) : 0;
+  const int64_t bytes = chain_layout(K0, N, L, rt, g.a_off, g.dz_off);
+  WD_REQUIRE(bytes > 0, "unsupported tower shape (widths must be multiples of the row tile and fit the LDS; see wd_tower_chain_lds_bytes)");
+  const int dxc = dx ? round_up(dx_cols, rt) : 0;
   WD_REQUIRE(dxc <= K0, "dx_cols must be <= K0");
   g.L = L; g.act = act; g.bias_parts = bias_parts > 0 ? bias_parts : 1; g.K0 = K0; g.dx_cols = dxc;
   g.train = labels != nullptr;
@@ -592,26 +701,16 @@ extern "C" int wd_tower_chain(const float *x, int64_t ld_act, int32_t K0, const 
   g.Gpart_logits = Gpart_logits; g.dx = dx; g.ld_dx = ld_dx;
   if (opts) {
     g.stamps = static_cast<unsigned long long *>(opts->stamps);
+    g.tile_stamps = static_cast<unsigned long long *>(opts->tile_stamps);
+    g.prio_split = opts->flags & 1 ? 0 : 1;
     g.loss_part = opts->loss_part;
     if (opts->input) {
       const int rc = check_chain_input(opts->input);
       if (rc != WD_OK) return rc;
       g.in = *opts->input;
-      WD_REQUIRE((int64_t)2 * RT * g.in.S * 4 <= (int64_t)N[0] * P * 4,
-                 "input fusion: ids do not fit the scratch region (2 x 32 x S <= 33 x N_0)");
+      WD_REQUIRE((int64_t)2 * rt * g.in.S * 4 <= (int64_t)N[0] * (rt + 1) * 4,
+                 "input fusion: ids do not fit the scratch region (2 x row_tile x S <= (row_tile + 1) x N_0)");
     }
   }
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_tower_chain),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-    if (e != hipSuccess) {
-      wd::set_error("wd_tower_chain: hipFuncSetAttribute: %s", hipGetErrorString(e));
-      return WD_ERR_LAUNCH;
-    }
-    attr_set = true;
-  }
-  hipLaunchKernelGGL(k_tower_chain, dim3((unsigned)wd::ceil_div(batch, RT)), dim3(256), (size_t)bytes,
-                     wd::as_stream(stream), g);
-  return wd::check_launch("wd_tower_chain");
+  return rt == 16 ? launch_chain<16>(g, bytes, stream) : launch_chain<32>(g, bytes, stream);
 }

@@ -186,6 +186,8 @@ class WideDeepEngine:
                         tsz = 128 if (self.half and N > 128) else 64
                         tiles = math.ceil((K + 1) / tsz) * math.ceil(N / tsz)
                         ns = max(1, min(math.ceil(512 / tiles), 64, max(1, B // 256)))
+                        if not self.half:    # fp32 towers: <= 16 partials per element for the finalize / dense tail to sum
+                            ns = min(ns, int(os.environ.get("WD_TN_SPLIT_CAP", "16")))
                     tw["nsplit"].append(ns)
                     tw["Gpart"].append(torch.zeros(ns * (K + 1) * N, **f32))
                     # tf.glorot_uniform_initializer kernel, zero bias, gamma 1, beta 0  
@@ -255,6 +257,7 @@ class WideDeepEngine:
                     d.Gpart, d.nsplit = tw["Gpart"][l].data_ptr(), tw["nsplit"][l]
                     if self.chain and l < tw["L"]:
                         d.Wpk, d.WTpk = tw["Wpk"][l].data_ptr(), tw["WTpk"][l].data_ptr()
+                        d.pk_tile = self.chain_rt
                         if not self._tn_ones:
                             d.db_sum = tw["db_sum"][l].data_ptr()
                     if self.half:
@@ -269,9 +272,17 @@ class WideDeepEngine:
             # one launch finalises all layers iff every BN gamma/beta has a single consumer layer
             self.all_simple = len(self.towers) == 1 and self.towers[0]["layout"].mode == "simple"
             self.dnn_logit = torch.zeros(B, **f32)
+            # one-launch tower on one GPU with the reference's Adagrad: finalize + Adagrad + the fold for the next step are
+            # ONE launch (wd_dense_update_fold), the folded bias a single vector
+            self._merged_dense = (self.chain and self.all_simple and self.default_opts and self.max_layer_n <= 512
+                                  and os.environ.get("WD_MERGED_DENSE", "1") == "1")
+            if self._merged_dense:
+                nb = int(call("wd_dense_update_fold_ws_bytes", self.n_layers, self.max_layer_k, self.max_layer_n))
+                self._dense_ws = torch.zeros(nb, dtype=torch.uint8, device=dev)
         else:
             self.P = self.Pa = self.Pacc = self.G = None
             self.dnn_logit = None
+            self._merged_dense = False
 
         # ---- per-step buffers --------------------------------------------------------------
         self.wide_logit = torch.zeros(B, **f32) if spec.has_wide else None
@@ -294,10 +305,17 @@ class WideDeepEngine:
             raise capi.WdError("wd_sort_workspace_bytes failed")
         self.sort_ws_bytes = max(qs)
         self.sort_ws = torch.zeros(self.sort_ws_bytes, dtype=torch.uint8, device=dev)
-        self.bucket_cnt = torch.zeros((2 * int(call("wd_bucket_chunks")) + 1) * self.n_buckets, **i32)
-        self.bucket_start = torch.zeros(2 * self.n_buckets + 2, **i32)   # starts [nb+1] + launch order [nb]
-        self.occ_rank = torch.zeros(M, **i32)
-        self.pairs = torch.zeros(M, dtype=torch.int64, device=dev)
+        # two sets of bucketing scratch: in a pipelined multi-step graph (pipeline.StepGraph) the occurrences of step t+1
+        # are bucketed while the update of step t still reads its own set
+        self._bucket_sets = []
+        for _ in range(2):
+            self._bucket_sets.append(dict(
+                cnt=torch.zeros((2 * int(call("wd_bucket_chunks")) + 1) * self.n_buckets, **i32),
+                start=torch.zeros(2 * self.n_buckets + 2, **i32),   # starts [nb+1] + launch order [nb]
+                rank=torch.zeros(M, **i32), pairs=torch.zeros(M, dtype=torch.int64, device=dev)))
+        b0 = self._bucket_sets[0]
+        self.bucket_cnt, self.bucket_start, self.occ_rank, self.pairs = b0["cnt"], b0["start"], b0["rank"], b0["pairs"]
+        self._folded = False      # one-launch tower on one GPU: the fold for the NEXT step is launched behind the dense update
         self._graph = None
         # Optional side streams (hipGraph capture turns them into parallel branches):
         #   side 0: bucketing of the occurrences (needs only the ids) under the forward + tower backward
@@ -326,6 +344,7 @@ class WideDeepEngine:
         """One-launch tower (wd_tower_chain, csrc/mlp_chain.hip): exact-fp32 `simple` towers whose widths are multiples
         of 32 and whose row tile fits the LDS.  WD_CHAIN=0 keeps the per-layer GEMM launches."""
         self.chain = False
+        self._chain_tile_stamps = None   # diagnostics: device uint64[2 * tiles] realtime-clock stamps (bench.py: in-step gather span)
         self._chain_stamps = None    # diagnostics: device int64[64] for the tower kernel's stage stamps (scripts/bench_chain.py)
         self._tn_ones = os.environ.get("WD_TN_ONES", "0") == "1"   # A/B switch: bias gradients via an appended ones row
         plan = self.plan
@@ -333,12 +352,18 @@ class WideDeepEngine:
             return
         tw = self.towers[0]
         tl, metas, L = tw["layout"], tw["metas"], tw["L"]
+        self.chain_rt = 32
         if tl.mode != "simple" or L < 1 or L > capi.WD_CHAIN_MAX_LAYERS or tl.in_start[0] % 4 or tl.ld % 4:
             return
         dims = [int(metas[l]["N"]) for l in range(L)]
         K0 = int(metas[0]["K"])
-        if int(call("wd_tower_chain_lds_bytes", K0, (ctypes.c_int32 * L)(*dims), L)) <= 0:
+        # row tile: 16 examples per workgroup (two workgroups share a CU) unless WD_CHAIN_RT=32 (one per CU, round-1 kernel)
+        rt = int(os.environ.get("WD_CHAIN_RT", "16"))
+        if rt not in (16, 32):
+            raise ValueError("WD_CHAIN_RT must be 16 or 32")
+        if int(call("wd_tower_chain_lds_bytes", K0, (ctypes.c_int32 * L)(*dims), L, rt)) <= 0:
             return
+        self.chain_rt = rt
         dev, B = self.device, self.max_batch
         f32 = dict(dtype=torch.float32, device=dev)
         # folded kernels in MFMA-fragment order, forward and transposed (wd_mlp_layer_t.Wpk / WTpk)
@@ -347,11 +372,11 @@ class WideDeepEngine:
         tw["dzl"] = [torch.zeros(B * metas[l]["N"], **f32) for l in range(L)]
         # bias gradients: per-row-tile column sums of dz from the tower kernel, reduced by a column-sum job of the grouped
         # weight-gradient launch -- the products then need no appended ones row (449 = 7 x 64 + 1 rows cost an 8th tile row)
-        ntile = int(call("wd_tower_chain_blocks", B))
+        ntile = int(call("wd_tower_chain_blocks", B, rt))
         tw["db_part"] = [torch.zeros(ntile * metas[l]["N"], **f32) for l in range(L)]
         tw["db_sum"] = [torch.zeros(metas[l]["N"], **f32) for l in range(L)]
         # logits-layer gradient partials: one per 32-example row tile
-        ns = int(call("wd_tower_chain_blocks", B))
+        ns = ntile
         tw["nsplit"][L] = ns
         tw["Gpart"][L] = torch.zeros(ns * (metas[L]["K"] + 1) * metas[L]["N"], **f32)
         carr = (capi.WdChainLayer * L)()
@@ -376,9 +401,23 @@ class WideDeepEngine:
         """One launch: fold the BN affines of every layer into its consumer's weights (+ the MFMA-fragment-packed copies
         of the one-launch tower); clears the loss accumulator of the per-layer paths (the one-launch tower stores per-tile
         partials instead) and G when the per-layer finalize path accumulates into it."""
+        if self._use_merged_dense():      # the same kernel that updates, without a gradient: fold only
+            call("wd_dense_update_fold", ptr(self.layers_dev), self.n_layers, self.max_layer_k, self.max_layer_n, ptr(self.P),
+                 ptr(self.Pacc), self.inv, ptr(self.G), 0.0, 0, ptr(self._dense_ws), st)
+            return
         zero_g = train and not self.all_simple
         call("wd_fold_affine_all", ptr(self.P), ptr(self.layers_dev), self.n_layers, self.max_layer_n, self.inv,
              None if self.chain else ptr(self.loss), 1, ptr(self.G) if zero_g else None, self.G.numel() if zero_g else 0, st)
+
+    def _use_merged_dense(self):
+        return self._merged_dense and self._fold_at_end()
+
+    def _fold_at_end(self):
+        """The fold of step t+1 depends on nothing but the dense update of step t: launched right behind it, it runs beside
+        the sparse update instead of at the head of the next step (profiles/r2d_timeline*.txt: 9 us + a kernel boundary)."""
+        return (self.chain and type(self)._reduce_dense_grads is WideDeepEngine._reduce_dense_grads
+                and type(self).backward_and_update is WideDeepEngine.backward_and_update
+                and os.environ.get("WD_FOLD_AT_END", "1") == "1")
 
     def _chain_input_ok(self, bt):
         """The one-launch tower can build its x tile itself (input layer fused, wd_chain_opts_t.input): one id per bag,
@@ -390,7 +429,7 @@ class WideDeepEngine:
         (dim, sl), = self.plan.emb_groups.items()
         n0 = self.towers[0]["metas"][0]["N"]
         return (self.plan.S <= capi.WD_CHAIN_MAX_SLOTS and dim % 4 == 0 and 256 % (dim // 4) == 0
-                and 2 * 32 * self.plan.S <= 33 * n0)
+                and 2 * self.chain_rt * self.plan.S <= (self.chain_rt + 1) * n0)
 
     def _sparse_exchange(self, bt, st):
         """Hook: what has to happen before the tower kernel can build its own x tile (dist.py: the row exchange)."""
@@ -423,8 +462,11 @@ class WideDeepEngine:
         if train:
             opts.loss_part = ptr(self.loss_part)
         opts.stamps = self._chain_stamps
+        opts.tile_stamps = self._chain_tile_stamps
+        opts.row_tile = self.chain_rt
+        opts.flags = int(os.environ.get("WD_CHAIN_FLAGS", "0"))
         call("wd_tower_chain", tw["act"].data_ptr() + 4 * tl.in_start[0], tl.ld, int(metas[0]["K"]), tw["chain_layers"], L,
-             self.act_id, capi.WD_FOLD_PARTS, ptr(tw["Wf"][L]), ptr(tw["bf"][L]),
+             self.act_id, 1 if self._use_merged_dense() else capi.WD_FOLD_PARTS, ptr(tw["Wf"][L]), ptr(tw["bf"][L]),
              None if fuse_in else ptr(self.wide_logit),
              ptr(bt.labels) if train else None, ptr(bt.weights) if train else None, B, ptr(tw["logit"]), ptr(self.logit),
              ptr(self.prob), ptr(self.dlogit) if train else None, ptr(self.loss) if train else None,
@@ -459,7 +501,7 @@ class WideDeepEngine:
 
     def _side(self, i):
         if self._sides is None:
-            self._sides = [torch.cuda.Stream(device=self.device), torch.cuda.Stream(device=self.device)]
+            self._sides = [torch.cuda.Stream(device=self.device) for _ in range(3)]
         return self._sides[i]
 
     def _check_batch(self, bt):
@@ -527,8 +569,11 @@ class WideDeepEngine:
             self._sparse_forward(bt, st)
         if spec.has_deep:
             # one launch: fold the BN affines of every layer into its consumer's weights; clear loss (+ G when the
-            # per-layer finalize path accumulates into it)
-            self._fold(train, st)
+            # per-layer finalize path accumulates into it).  One-launch tower on one GPU: the folded / packed weights are
+            # already there -- the previous train step launched this fold behind its dense update (_fold_at_end)
+            if not (self._fold_at_end() and self._folded):
+                self._fold(train, st)
+                self._folded = self._fold_at_end()
             tw0 = self.towers[0]
             nt = len(self.towers)
             for ti, tw in enumerate(self.towers):
@@ -654,7 +699,7 @@ class WideDeepEngine:
             # (one grouped launch) and the sums of the per-tile bias-gradient partials (column-sum jobs of the same launch)
             if 2 * L + 1 <= capi.WD_TN_GROUP_MAX:
                 jobs = (capi.WdTnJob * (2 * L + 1))()
-                nblk = int(call("wd_tower_chain_blocks", B))
+                nblk = int(call("wd_tower_chain_blocks", B, self.chain_rt))
                 lj = jobs[L if self._tn_ones else 2 * L]     # loss = sum of the per-tile partials, in tile order
                 lj.A, lj.lda, lj.B, lj.Cpart, lj.N, lj.K = self.loss_part.data_ptr(), 1, None, self.loss.data_ptr(), 1, nblk
                 for l in range(L):    # largest product first: its workgroups start while the small ones fill the gaps
@@ -792,25 +837,26 @@ class WideDeepEngine:
     def _reduce_dense_grads(self):
         """Hook for data-parallel ranks (dist.py: all_reduce(SUM) of the flat gradient buffer)."""
 
-    def _sparse_bucketize(self, bt: DeviceBatch, st):
-        """Phase 1 of the sparse backward (ids only): occurrences -> row-range buckets."""
+    def _sparse_bucketize(self, bt: DeviceBatch, st, pset=0):
+        """Phase 1 of the sparse backward (ids only): occurrences -> row-range buckets (scratch set `pset`)."""
         plan = self.plan
         self._check_batch(bt)
+        bs = self._bucket_sets[pset]
         call("wd_sparse_bucketize", ptr(self.slots_dev), plan.S, ptr(bt.ids), ptr(bt.bag_offs), bt.B, bt.nnz,
-             ptr(self.bucket_cnt), ptr(self.bucket_start), ptr(self.occ_rank), ptr(self.pairs), self.n_buckets,
-             st)
+             ptr(bs["cnt"]), ptr(bs["start"]), ptr(bs["rank"]), ptr(bs["pairs"]), self.n_buckets, st)
 
     def _has_sparse_update(self):
         return (bool(self.group_slots) if self.spec.has_deep else False) or self.spec.has_wide
 
-    def _sparse_backward(self, bt: DeviceBatch, st, bucketized=False):
+    def _sparse_backward(self, bt: DeviceBatch, st, bucketized=False, pset=0):
         """Scatter-add of the row gradients + fused Adagrad (embedding rows) / FTRL (wide rows, bias)."""
         plan, spec = self.plan, self.spec
         has_emb = bool(self.group_slots) if spec.has_deep else False
         if not (has_emb or spec.has_wide):
             return
         if not bucketized:
-            self._sparse_bucketize(bt, st)
+            self._sparse_bucketize(bt, st, pset)
+        bsx = self._bucket_sets[pset]
         dx_ptr, ld = None, 0
         if has_emb:
             tw0 = self.towers[0]
@@ -821,13 +867,13 @@ class WideDeepEngine:
             call("wd_sparse_apply", ptr(self.emb) if has_emb else None, ptr(self.emb_acc) if has_emb else None,
                  ptr(self.wide), ptr(self.bias), ptr(self.slots_dev), plan.S, ptr(bt.bag_offs), bt.B, dx_ptr, ld,
                  ptr(self.dlogit), 1, float(spec.dnn_opt[1]) if spec.has_deep else 0.0, float(lr), float(l1), float(l2),
-                 ptr(self.bucket_start), ptr(self.pairs), self.n_buckets, st)
+                 ptr(bsx["start"]), ptr(bsx["pairs"]), self.n_buckets, st)
             return
         od = ctypes.byref(self.opt_c["dnn"]) if has_emb else None
         ol = ctypes.byref(self.opt_c["linear"]) if spec.has_wide else None
         call("wd_sparse_apply_opt", ptr(self.emb) if has_emb else None, ptr(self.emb_a) if has_emb else None,
              ptr(self.emb_acc) if has_emb else None, ptr(self.wide), ptr(self.bias), ptr(self.slots_dev), plan.S,
-             ptr(bt.bag_offs), bt.B, dx_ptr, ld, ptr(self.dlogit), 1, od, ol, ptr(self.bucket_start), ptr(self.pairs),
+             ptr(bt.bag_offs), bt.B, dx_ptr, ld, ptr(self.dlogit), 1, od, ol, ptr(bsx["start"]), ptr(bsx["pairs"]),
              self.n_buckets, ptr(self.touched), st)
         if self.pow:
             # Adam moves every row of a sparsely updated variable: the rows without a gradient this step
@@ -864,22 +910,17 @@ class WideDeepEngine:
     def _overlap_ok(self):
         return type(self)._sparse_backward is WideDeepEngine._sparse_backward   # subclasses with their own exchange opt out
 
-    def backward_and_update(self, bt: DeviceBatch, bucketized=False):
-        spec, st = self.spec, _stream()
-        B = bt.B
+    def _dense_backward(self, bt: DeviceBatch, st, after_products=None):
+        """Weight-gradient products, finalize + dense optimizer (and, one-launch tower on one GPU, the fold for the next step).
+        after_products: called between the two (pipeline.StepGraph joins the row update there)."""
+        spec, B = self.spec, bt.B
         has_emb = bool(self.group_slots) if spec.has_deep else False
-        # One-launch tower: dx / dlogit exist when forward() returns, so the sparse update depends on nothing of the dense
-        # branch.  It goes to the side stream (graph branch) but is ENQUEUED AFTER the dense branch: started first its
-        # ~3200 small workgroups fill every CU's LDS and the weight-gradient GEMM (critical path) waits -- 0.239 ms --
-        # started behind it the two overlap: 0.2117 -> 0.2028 ms.  WD_SPARSE_SIDE=0: strictly after the dense branch.
-        sparse_side = bucketized and getattr(self, "chain", False) and os.environ.get("WD_SPARSE_SIDE", "1") == "1"
-        if sparse_side:
-            ev_fwd = torch.cuda.Event()
-            ev_fwd.record(torch.cuda.current_stream())
-        if spec.has_deep:
+        if True:
             head_done = len(self.towers) == 1
             for tw in self.towers:
                 self._tower_backward(tw, B, st, need_dx=has_emb, head_done=head_done)
+            if after_products is not None:
+                after_products()
             fused_opt = False
             if self.all_simple:
                 if not head_done:
@@ -887,7 +928,11 @@ class WideDeepEngine:
                 # single GPU + Adagrad: the dense update rides in the finalize launch (nothing reduces G in between)
                 fused_opt = (self.default_opts and type(self)._reduce_dense_grads is WideDeepEngine._reduce_dense_grads
                              and os.environ.get("WD_FUSE_ADAGRAD", "1") != "0")
-                if fused_opt:
+                if fused_opt and self._use_merged_dense():
+                    call("wd_dense_update_fold", ptr(self.layers_dev), self.n_layers, self.max_layer_k, self.max_layer_n,
+                         ptr(self.P), ptr(self.Pacc), self.inv, ptr(self.G), float(spec.dnn_opt[1]), 1, ptr(self._dense_ws), st)
+                    self._folded = True
+                elif fused_opt:
                     call("wd_mlp_finalize_adagrad_all", ptr(self.layers_dev), self.n_layers, self.max_layer_k, ptr(self.P),
                          ptr(self.Pacc), self.inv, ptr(self.G), float(spec.dnn_opt[1]), st)
                 else:
@@ -917,6 +962,24 @@ class WideDeepEngine:
             else:
                 call("wd_opt_dense", ptr(self.P), ptr(self.Pa), ptr(self.Pacc), ptr(self.G), self.P.numel(),
                      ctypes.byref(self.opt_c["dnn"]), st)
+            if self._fold_at_end() and not (fused_opt and self._use_merged_dense()):   # the NEXT step's folded / packed weights
+                self._fold(False, st)
+                self._folded = True
+
+    def backward_and_update(self, bt: DeviceBatch, bucketized=False):
+        spec, st = self.spec, _stream()
+        B = bt.B
+        has_emb = bool(self.group_slots) if spec.has_deep else False
+        # One-launch tower: dx / dlogit exist when forward() returns, so the sparse update depends on nothing of the dense
+        # branch.  It goes to the side stream (graph branch) but is ENQUEUED AFTER the dense branch: started first its
+        # ~3200 small workgroups fill every CU's LDS and the weight-gradient GEMM (critical path) waits -- 0.239 ms --
+        # started behind it the two overlap: 0.2117 -> 0.2028 ms.  WD_SPARSE_SIDE=0: strictly after the dense branch.
+        sparse_side = bucketized and getattr(self, "chain", False) and os.environ.get("WD_SPARSE_SIDE", "1") == "1"
+        if sparse_side:
+            ev_fwd = torch.cuda.Event()
+            ev_fwd.record(torch.cuda.current_stream())
+        if spec.has_deep:
+            self._dense_backward(bt, st)
         if sparse_side:
             side = self._side(0)
             side.wait_event(ev_fwd)
@@ -1036,6 +1099,7 @@ class WideDeepEngine:
 
     def import_state(self, state):
         plan, spec, dev = self.plan, self.spec, self.device
+        self._folded = False
         if spec.has_deep:
             sa, sb = self._slot_bufs("dnn")
             for i, s in enumerate(plan.slots):

@@ -4,10 +4,34 @@ A train step on a resident batch is a fixed sequence of launches on fixed buffer
 so `n` consecutive steps -- each on its OWN batch: raw tokens -> wd_hash_bucket -> forward -> loss -> backward -> both
 optimizers -- can be captured once and replayed; the ~11 us between two graph launches is then paid once per `n` steps.
 Used by bench.py (the timed path) and by tests/test_gpu_fullsize.py (the same path against the CPU oracle).
+
+Pipelined capture (the Criteo-shaped fast path: one-launch tower with the fused input layer, Adagrad + Ftrl).  Captured
+from plain stream order, a step is a chain with one side branch, and every step waits for ALL of the previous one
+(profiles/r2d_timeline_rt32.txt: hash 4 -> fold 9 -> tower 89 -> weight gradients 39 -> finalize 29 || row update 67, then
+6 us of join before the next hash).  The real dependencies are fewer:
+
+    hash(t)                    needs the tokens of batch t only            -> input branch, off the critical path
+    bucketing(t)               needs ids(t) (and the scratch update(t-1) read)    -> sparse branch, under tower(t)
+    tower(t)                   needs ids(t), the rows of update(t-1), the folded weights of dense(t-1)
+    products(t) (weight-gradient GEMMs)                                   needs tower(t)
+    update(t) (rows: Adagrad / Ftrl)                                      needs tower(t) (dx, dlogit) and bucketing(t)
+    tail(t) = finalize + Adagrad + fold for t+1                           needs products(t)
+
+so the graph is built with these edges (three streams + events during capture): the hash leaves the critical path and the
+row update runs beside the MFMA-bound products and the tail (WD_PIPE_TAIL=after joins the update BEFORE the tail, which is
+a chain of dependent loads -- 19 us alone, ~40 us beside the update that keeps the memory queues full -- but the extra
+cross-queue edge costs more than it saves: 0.198 against 0.185 ms/step, profiles/r2i_*).  Every kernel
+still runs once per step on the same operands: results are bit-identical to the eager launches
+(tests/test_gpu_fullsize.py).  WD_PIPELINE=0 captures plain stream order.  (A fourth kind of edge -- the input branch
+waiting for update(t-2) so that bucketing can run a step ahead on a second scratch set -- makes hipStreamEndCapture of
+ROCm 7.2 crash from three steps per graph on; bucketing therefore stays behind update(t-1) in stream order.)
 """
+import os
+
 import torch
 
 from . import synth
+from .engine import WideDeepEngine
 
 
 def step_eager(eng, tb, ids_input=False):
@@ -16,22 +40,89 @@ def step_eager(eng, tb, ids_input=False):
     return eng.train_step(bt)
 
 
+def pipelined_ok(eng, tb):
+    """The fast path the pipelined capture knows: single-GPU engine, one-launch tower building its own x tile, the
+    reference's default optimizers (fused finalize + Adagrad, fused row update)."""
+    bt = tb.batch
+    return (type(eng) is WideDeepEngine and eng.spec.has_deep and eng.chain and eng._chain_input_ok(bt)
+            and eng.default_opts and eng.all_simple and eng._fold_at_end() and not eng.dropout and eng._has_sparse_update()
+            and bt.labels is not None)
+
+
 class StepGraph:
     """`len(token_batches)` consecutive train steps in one hipGraph.  The engine must have run at least one eager step
     on a side stream before (lazy allocations / module loads are not capturable)."""
 
-    def __init__(self, eng, token_batches, ids_input=False, stream=None):
+    def __init__(self, eng, token_batches, ids_input=False, stream=None, pipelined=None):
         self.eng = eng
         self.n = len(token_batches)
         self.stream = stream or torch.cuda.Stream()
         self.graph = torch.cuda.CUDAGraph()
+        if pipelined is None:
+            pipelined = os.environ.get("WD_PIPELINE", "1") != "0"
+        self.pipelined = bool(pipelined) and all(pipelined_ok(eng, tb) for tb in token_batches) and eng._folded
         self.stream.wait_stream(torch.cuda.current_stream())
         gs = eng.global_step            # capturing executes nothing: the counter must not move
         with torch.cuda.graph(self.graph, stream=self.stream):
-            for tb in token_batches:
-                step_eager(eng, tb, ids_input)
+            if self.pipelined:
+                self._capture_pipelined(token_batches, ids_input)
+            else:
+                for tb in token_batches:
+                    step_eager(eng, tb, ids_input)
         eng.global_step = gs
         self._bump = (3 if eng.spec.model_type == "wide_deep" else 2) * self.n
+
+    def _capture_pipelined(self, tbs, ids_input):
+        eng = self.eng
+        main = torch.cuda.current_stream()
+        s_in, s_sp = eng._side(2), eng._side(0)
+        s_in.wait_stream(main)              # fork: everything launched before this graph is complete
+        s_sp.wait_stream(main)
+        tail_after = os.environ.get("WD_PIPE_TAIL", "beside") == "after"
+        pending = []
+        keep = self._events = []            # every event lives as long as the graph (none is destroyed during the capture)
+
+        def event(stream):
+            ev = torch.cuda.Event()
+            ev.record(stream)
+            keep.append(ev)
+            return ev
+
+        for t, tb in enumerate(tbs):
+            bt = tb.batch
+            eng._check_batch(bt)
+            # ---- input branch: tokens -> ids (depends on nothing: the hashes of all steps of the graph may run early) ----
+            with torch.cuda.stream(s_in):
+                if not ids_input:
+                    synth.hash_tokens(eng, tb)
+                ev_ids = event(s_in)
+            # ---- sparse branch, part 1: ids -> row-range buckets, behind update(t-1) in stream order (one scratch set) ----
+            s_sp.wait_event(ev_ids)
+            with torch.cuda.stream(s_sp):
+                eng._sparse_bucketize(bt, s_sp.cuda_stream)
+            # ---- dense chain: tower(t) -> weight gradients || row update -> finalize + Adagrad + fold for t+1 ---------------
+            main.wait_event(ev_ids)
+            while pending:
+                main.wait_event(pending.pop())          # WD_PIPE_TAIL=beside: the update of step t-1 is joined here
+            eng.forward(bt, need_loss=True)             # folded weights are in place (eng._folded): the tower launch only
+            ev_tower = event(main)
+            # ---- weight-gradient GEMMs, then (captured AFTER them: ready nodes are launched in capture order, and the GEMMs'
+            # 512 workgroups have to be resident before the update's 3200 flood the CUs -- launched together the GEMMs take 72 us
+            # instead of 38) the row update on the sparse branch: Adagrad (embedding rows) + Ftrl (wide rows, bias).
+            # The update is joined before tower(t+1) (default) or, WD_PIPE_TAIL=after, between the products and the tail.
+            def update_then_join():
+                s_sp.wait_event(ev_tower)
+                with torch.cuda.stream(s_sp):
+                    eng._sparse_backward(bt, s_sp.cuda_stream, bucketized=True)
+                    ev_upd = event(s_sp)
+                if tail_after:
+                    main.wait_event(ev_upd)
+                else:
+                    pending.append(ev_upd)
+
+            eng._dense_backward(bt, main.cuda_stream, after_products=update_then_join)
+        main.wait_stream(s_in)
+        main.wait_stream(s_sp)
 
     def replay(self):
         self.graph.replay()

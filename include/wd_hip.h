@@ -313,7 +313,7 @@ int wd_gemm_tn_splitk(const float *A, int64_t lda, const float *B, int64_t ldb, 
 
 /* wd_gemm_tn_splitk for several layers in ONE launch (the weight-gradient products of a whole tower): job j is exactly
  * wd_gemm_tn_splitk(A, lda, B, ldb, Cpart, M, N, K, nsplit, append_ones). */
-#define WD_TN_GROUP_MAX 16
+#define WD_TN_GROUP_MAX 20
 typedef struct wd_tn_job {
   const float *A;
   const float *B;    /* NULL: column-sum job -- Cpart[n] = sum over the K rows of A [K][lda] (n < N), in row order */
@@ -344,24 +344,12 @@ typedef struct wd_mlp_layer {
   float *Wf, *bf, *s, *t;   /* folded outputs (as wd_fold_affine) */
   const float *Gpart;       /* split-K partials of this layer (as wd_mlp_finalize) */
   int32_t nsplit;
-  int32_t pk_tile;          /* tile of the packed copies Wpk / WTpk below: 0 or 32, or 16 */
+  int32_t pad_;
   /* optional IEEE-half copies of the folded kernel for the fp16-input tower (NULL: not written): */
   uint16_t *WfT_h;          /*   transposed kernel WfT_h [N][ld_wft_h] (operand of wd_hgemm_nn) */
   int64_t ld_wft_h;
   const int64_t *cat_off;   /*   [K] element offsets into wcat (< 0: skip): row k of this layer is written to */
   uint16_t *wcat;           /*   wcat[cat_off[k] + n], n < N -- the operand of the segment-gradient GEMM (wd_hgemm_nt) */
-  /* optional MFMA-fragment-packed fp32 copies of the folded kernel for wd_tower_chain (NULL: not written; both need
-   * K and N multiples of pk_tile).  A packed operand B [R reduction rows][C columns] is stored as
-   *   pk_tile 32:  pk[((c/32) * (R/8)  + r/8)  * 256 + ((r%2) * 32 + c%32) * 4 + (r%8)/2 ]  =  B[r][c]
-   *   pk_tile 16:  pk[((c/16) * (R/16) + r/16) * 256 + ((r%4) * 16 + c%16) * 4 + (r%16)/4]  =  B[r][c]
-   * i.e. one 16-byte load per lane feeds four consecutive v_mfma_f32_32x32x2_f32 (v_mfma_f32_16x16x4_f32) steps of a
-   * 32- (16-) column tile.
-   *   Wpk  = pack(Wf)    (R = K, C = N: forward products)      WTpk = pack(Wf^T)  (R = N, C = K: gradient chain) */
-  float *Wpk;
-  float *WTpk;
-  /* optional: the bias gradient sum_b dz[b, :] precomputed [N] (wd_tower_chain partials reduced by a column-sum job of
-   * wd_gemm_tn_splitk_group).  Then Gpart holds nsplit x [K][N] (no appended ones row). */
-  const float *db_sum;
 } wd_mlp_layer_t;
 
 /* wd_fold_affine for every layer of every tower in ONE launch; also zero-fills up to two small buffers
@@ -379,17 +367,6 @@ int wd_mlp_finalize_all(const wd_mlp_layer_t *layers_dev, int32_t nlayers, int64
 int wd_mlp_finalize_adagrad_all(const wd_mlp_layer_t *layers_dev, int32_t nlayers, int64_t max_k, float *P, float *Pacc,
                                 float inv, float *Gflat, float lr, wd_stream_t stream);
 
-/* wd_mlp_finalize_adagrad_all AND the wd_fold_affine_all of the NEXT step in one launch (connected_mode `simple`, Adagrad on the
- * dnn scope: python/lib/joint.py:233-241 with model.yaml's dnn_optimizer): per kernel row the split-K partials are summed,
- * W / b / BN gamma, beta take their Adagrad step, and the folded row of the UPDATED parameters is written (Wf, Wpk / WTpk,
- * s, t; the half copies are not).  The folded bias comes out as ONE vector bf[0..N) (consumers pass bias_parts = 1): every
- * workgroup stores a partial column sum to the workspace and the last one of a layer to arrive adds them in workgroup order.
- * do_update == 0: fold only (first step / after import: no gradient is read, no parameter moves).
- * ws: wd_dense_update_fold_ws_bytes(nlayers, max_k, max_n) bytes, its first 256 bytes zeroed once by the caller. */
-int64_t wd_dense_update_fold_ws_bytes(int32_t nlayers, int64_t max_k, int64_t max_n);
-int wd_dense_update_fold(const wd_mlp_layer_t *layers_dev, int32_t nlayers, int64_t max_k, int64_t max_n, float *P, float *Pacc,
-                         float inv, float *Gflat, float lr, int32_t do_update, void *ws, wd_stream_t stream);
-
 /* ---- logits layer + head fused (python/lib/dnn.py:226-232, python/lib/joint.py:216-222,264-269) ----
  * dnn_logit[b] = a[b, 0..K) . wf + sum(bf parts); logit = dnn_logit + wide_logit (may be NULL); sigmoid CE SUM into
  * loss_sum (+=), prob, dlogit = w*(p-y).  Backward of the logits layer in the same launch:
@@ -404,26 +381,57 @@ int wd_logits_head(const float *a, int64_t ld_a, int64_t K, const float *wf, con
                    int64_t ld_out, int32_t act, float *Gpart, wd_stream_t stream);
 
 /* ---- whole `simple` tower in one launch (csrc/mlp_chain.hip) -------------------------------------------------------
- * python/lib/dnn.py:92-141 (dense -> activation -> BN per hidden layer, BN folded as above), dnn.py:226-232 (logits),
- * python/lib/joint.py:216-222, 264-269 (joint logit, sigmoid CE) for one row tile (wd_chain_opts_t.row_tile: 32 or 16
- * examples) per workgroup:
- *   a_l = act(a_{l-1} Wf_l + bf_l) (l < L), dnn_logit = a_{L-1} . w_logits + b, head as wd_logits_head, and with labels
- *   dz_{L-1} = dlogit w_logits^T * act'(a_{L-1}), dz_{l-1} = (dz_l Wf_l^T) * act'(a_{l-1}), dx = dz_0 Wf_0^T.
- * a_l is written to layers[l].a_out (row stride ld_act, as the per-layer GEMMs do), dz_l to layers[l].dz_out [batch][N_l]
- * -- the operands of the weight-gradient products wd_gemm_tn_splitk, which stay separate launches -- the first dx_cols
- * columns of dx to dx[b*ld_dx + k], and the logits-layer gradient partials to Gpart_logits (wd_mlp_finalize layout,
- * nsplit = wd_tower_chain_blocks(batch, row_tile)).  labels NULL: forward only.  Shapes: K0 and every N_l multiples of the
- * row tile and wd_tower_chain_lds_bytes(K0, N, L, row_tile) > 0 (else the call fails: use the per-layer GEMMs). */
+ * python/lib/dnn.py:92-141 (dense -> activation -> BN per hidden layer; BN = the inference affine of SURVEY App. C.1, applied
+ * as written -- nothing is folded), dnn.py:226-232 (logits), python/lib/joint.py:216-222, 264-269 (joint logit, sigmoid CE) for
+ * one row tile (wd_chain_opts_t.row_tile: 32 or 16 examples) per workgroup, with s_l = gamma_l inv, t_l = beta_l:
+ *   a_l = act(bn_{l-1} W_l + b_l),  bn_l = s_l a_l + t_l  (bn_{-1} = x),  dnn_logit = bn_{L-1} . w_logits + b, head as
+ *   wd_logits_head, and with labels  d(bn_{L-1}) = dlogit w_logits^T,  dz_l = d(bn_l) s_l act'(a_l),  d(bn_{l-1}) = dz_l W_l^T,
+ *   dx = dz_0 W_0^T.
+ * bn_l is written to layers[l].a_out (row stride ld_act), dz_l to layers[l].dz_out [batch][N_l] -- the operands of the
+ * weight-gradient products wd_gemm_tn_splitk_group, which stay a separate launch -- the first dx_cols columns of dx to
+ * dx[b*ld_dx + k], the logits-layer gradient partials to Gpart_logits ([tile][K_L + 1], nsplit = wd_tower_chain_blocks(batch,
+ * row_tile)), and per-tile column sums for the bias / BN gradients (wd_chain_layer_t).  labels NULL: forward only.  Shapes: K0
+ * and every N_l multiples of the row tile and wd_tower_chain_lds_bytes(K0, N, L, row_tile) > 0 (else the call fails: use the
+ * per-layer GEMMs).  inv = 1 / sqrt(1 + eps). */
 #define WD_CHAIN_MAX_LAYERS 6
 typedef struct wd_chain_layer {
-  const float *Wpk;  /* packed folded kernel (wd_mlp_layer_t.Wpk, written by wd_fold_affine_all) */
-  const float *WTpk; /* packed transposed folded kernel (wd_mlp_layer_t.WTpk); may be NULL without labels */
-  const float *bf;   /* bias_parts x N partial folded biases */
-  float *a_out;      /* activations of this layer inside the tower's activation buffer */
-  float *dz_out;     /* [batch][N] */
-  float *db_part;    /* optional [wd_tower_chain_blocks(batch, row_tile)][N]: per row tile, the column sums of dz (bias gradient partials) */
+  const float *Wpk;  /* MFMA-packed kernel W [K][N] (layout below, written by wd_chain_tail) */
+  const float *WTpk; /* MFMA-packed transposed kernel; may be NULL without labels */
+  const float *bias; /* [N] (the raw variable; NULL: none) */
+  const float *gamma, *beta;  /* [N] BN affine of this layer's output (python/lib/dnn.py:113-114), both NULL: no BN */
+  float *a_out;      /* [batch] rows of ld_act: bn_l = gamma inv act(..) + beta -- what the next layer reads (the operand of its
+                        weight-gradient product); the kernel keeps the un-normalised activation for act' on chip */
+  float *dz_out;     /* [batch][N] gradient of the loss wrt this layer's pre-activation */
+  /* optional [wd_tower_chain_blocks(batch, row_tile)][N] per-row-tile column sums, reduced by column-sum jobs of
+   * wd_gemm_tn_splitk_group: db_part of dz (bias gradient), dgamma_part of d(bn) * a (x inv = gamma gradient), dbeta_part of d(bn) */
+  float *db_part, *dgamma_part, *dbeta_part;
   int32_t K, N;
 } wd_chain_layer_t;
+/* A packed operand B [R reduction rows][C columns] (Wpk: R = K, C = N; WTpk = pack(W^T): R = N, C = K) is stored as
+ *   row tile 32:  pk[((c/32) * (R/8)  + r/8)  * 256 + ((r%2) * 32 + c%32) * 4 + (r%8)/2 ]  =  B[r][c]
+ *   row tile 16:  pk[((c/16) * (R/16) + r/16) * 256 + ((r%4) * 16 + c%16) * 4 + (r%16)/4]  =  B[r][c]
+ * i.e. one 16-byte load per lane feeds four consecutive v_mfma_f32_32x32x2_f32 (v_mfma_f32_16x16x4_f32) steps of a tile.
+ *
+ * wd_chain_tail -- the dense tail of a step on the one-launch tower (python/lib/joint.py:233-241: Adagrad on the dnn scope).
+ * Nothing is folded, so every dense parameter is on its own: per parameter the split-K partials of its gradient are summed in
+ * split order (kernels: Gpart[z][(K | K+1)][N]; bias: db_sum[N] or the appended row K of the partials; BN: inv * dgamma_sum,
+ * dbeta_sum -- finished column sums), mode & WD_TAIL_GRAD stores the gradient to Gflat, & WD_TAIL_UPDATE takes the Adagrad step
+ * (without GRAD: from Gflat, e.g. after an all-reduce), & WD_TAIL_PACK rewrites Wpk / WTpk from the (updated) kernel.
+ * One launch, one thread per parameter, no ordering between workgroups. */
+#define WD_TAIL_GRAD 1
+#define WD_TAIL_UPDATE 2
+#define WD_TAIL_PACK 4
+typedef struct wd_tail_layer {
+  int64_t w_off, b_off, gamma_off, beta_off;   /* offsets in P / Gflat; gamma_off / beta_off < 0: none */
+  int64_t K, N;
+  const float *Gpart;        /* nsplit partials */
+  const float *db_sum;       /* [N] or NULL (then the partials carry the bias-gradient row K) */
+  const float *dgamma_sum, *dbeta_sum;   /* [N] (when gamma_off / beta_off >= 0) */
+  float *Wpk, *WTpk;         /* NULL: not packed (the logits layer) */
+  int32_t nsplit, pk_tile;
+} wd_tail_layer_t;
+int wd_chain_tail(const wd_tail_layer_t *layers, int32_t nlayers, float *P, float *Pacc, float *Gflat, float inv, float lr,
+                  int32_t mode, wd_stream_t stream);
 /* Optional (wd_chain_opts_t.input): fuse the input layer into the call (one-id-per-bag batches, the Criteo shape): the kernel
  * then builds its x tile itself -- x[b, out_col_s ..] = emb[emb_off_s + ids[b*S + s]*dim ..] for the slots
  * [slot0, slot0+ngroup) (id < 0: zeros), the numeric columns (wd_dense_fwd), and the wide logit
@@ -458,7 +466,7 @@ typedef struct wd_chain_input {
  *              each forward layer, head, after each gradient stage, end) to [0..31] / [32..63]
  *   row_tile   examples per workgroup: 0 or 32 -> v_mfma_f32_32x32x2_f32, one workgroup per CU; 16 -> v_mfma_f32_16x16x4_f32,
  *              half the LDS, two workgroups per CU (one computes while the other gathers / stores / waits at a barrier).
- *              Wpk / WTpk must be packed for the same tile (wd_mlp_layer_t.pk_tile); every width a multiple of it
+ *              Wpk / WTpk must be packed for the same tile (wd_tail_layer_t.pk_tile); every width a multiple of it
  *   tile_stamps diagnostics: device uint64[2 * wd_tower_chain_blocks]: every workgroup stores the constant-rate realtime
  *              clock (100 MHz, chip-wide) at its start and when its x tile is complete in LDS -- bench.py derives the
  *              in-step gather span from them */
@@ -473,7 +481,7 @@ typedef struct wd_chain_opts {
 int64_t wd_tower_chain_lds_bytes(int32_t K0, const int32_t *N, int32_t L, int32_t row_tile);   /* -1: unsupported shape */
 int64_t wd_tower_chain_blocks(int64_t batch, int32_t row_tile);   /* ceil(batch / row_tile) */
 int wd_tower_chain(const float *x, int64_t ld_act, int32_t K0, const wd_chain_layer_t *layers, int32_t L, int32_t act,
-                   int32_t bias_parts, const float *w_logits, const float *b_logits, const float *wide_logit,
+                   float inv, const float *w_logits, const float *b_logits, const float *wide_logit,
                    const float *labels, const float *weights, int64_t batch, float *dnn_logit, float *logit,
                    float *prob, float *dlogit, float *loss_sum, float *Gpart_logits, float *dx, int64_t ld_dx,
                    int32_t dx_cols, const wd_chain_opts_t *opts, wd_stream_t stream);

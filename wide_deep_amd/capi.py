@@ -47,14 +47,13 @@ class WdMlpLayer(ctypes.Structure):
         ("w_off", ctypes.c_int64), ("b_off", ctypes.c_int64), ("K", ctypes.c_int64), ("N", ctypes.c_int64),
         ("gamma_idx", ctypes.c_void_p), ("beta_idx", ctypes.c_void_p),
         ("Wf", ctypes.c_void_p), ("bf", ctypes.c_void_p), ("s", ctypes.c_void_p), ("t", ctypes.c_void_p),
-        ("Gpart", ctypes.c_void_p), ("nsplit", ctypes.c_int32), ("pk_tile", ctypes.c_int32),
+        ("Gpart", ctypes.c_void_p), ("nsplit", ctypes.c_int32), ("pad_", ctypes.c_int32),
         ("WfT_h", ctypes.c_void_p), ("ld_wft_h", ctypes.c_int64), ("cat_off", ctypes.c_void_p), ("wcat", ctypes.c_void_p),
-        ("Wpk", ctypes.c_void_p), ("WTpk", ctypes.c_void_p), ("db_sum", ctypes.c_void_p),
     ]
 
 
 WD_CHAIN_MAX_LAYERS = 6
-WD_TN_GROUP_MAX = 16
+WD_TN_GROUP_MAX = 20
 
 
 WD_OPT_KINDS = {"SGD": 0, "Adagrad": 1, "Ftrl": 2, "RMSProp": 3, "Adam": 4}
@@ -93,8 +92,21 @@ class WdTnJob(ctypes.Structure):
 
 class WdChainLayer(ctypes.Structure):
     _fields_ = [
-        ("Wpk", ctypes.c_void_p), ("WTpk", ctypes.c_void_p), ("bf", ctypes.c_void_p), ("a_out", ctypes.c_void_p),
-        ("dz_out", ctypes.c_void_p), ("db_part", ctypes.c_void_p), ("K", ctypes.c_int32), ("N", ctypes.c_int32),
+        ("Wpk", ctypes.c_void_p), ("WTpk", ctypes.c_void_p), ("bias", ctypes.c_void_p), ("gamma", ctypes.c_void_p),
+        ("beta", ctypes.c_void_p), ("a_out", ctypes.c_void_p), ("dz_out", ctypes.c_void_p), ("db_part", ctypes.c_void_p),
+        ("dgamma_part", ctypes.c_void_p), ("dbeta_part", ctypes.c_void_p), ("K", ctypes.c_int32), ("N", ctypes.c_int32),
+    ]
+
+
+WD_TAIL_GRAD, WD_TAIL_UPDATE, WD_TAIL_PACK = 1, 2, 4
+
+
+class WdTailLayer(ctypes.Structure):
+    _fields_ = [
+        ("w_off", ctypes.c_int64), ("b_off", ctypes.c_int64), ("gamma_off", ctypes.c_int64), ("beta_off", ctypes.c_int64),
+        ("K", ctypes.c_int64), ("N", ctypes.c_int64), ("Gpart", ctypes.c_void_p), ("db_sum", ctypes.c_void_p),
+        ("dgamma_sum", ctypes.c_void_p), ("dbeta_sum", ctypes.c_void_p), ("Wpk", ctypes.c_void_p), ("WTpk", ctypes.c_void_p),
+        ("nsplit", ctypes.c_int32), ("pk_tile", ctypes.c_int32),
     ]
 
 
@@ -150,8 +162,6 @@ _PROTOS = {
     "wd_mlp_finalize_all": [P, I32, I64, P, F32, P, P],
     "wd_mlp_finalize_adagrad_all": [P, I32, I64, P, P, F32, P, F32, P],
     "wd_logits_head_blocks": [I64, I64],
-    "wd_dense_update_fold_ws_bytes": [I32, I64, I64],
-    "wd_dense_update_fold": [P, I32, I64, I64, P, P, F32, P, F32, I32, P, P],
     "wd_gemm_tn_splitk_group": [P, I32, P],
     "wd_sparse_apply_opt": [P, P, P, P, P, P, I32, P, I64, P, I64, P, I64, P, P, P, P, I32, P, P],
     "wd_opt_dense": [P, P, P, P, I64, P, P],
@@ -159,7 +169,8 @@ _PROTOS = {
     "wd_adam_tick": [P, F32, F32, P],
     "wd_tower_chain_lds_bytes": [I32, P, I32, I32],
     "wd_tower_chain_blocks": [I64, I32],
-    "wd_tower_chain": [P, I64, I32, P, I32, I32, I32, P, P, P, P, P, I64, P, P, P, P, P, P, P, I64, I32, P, P],
+    "wd_tower_chain": [P, I64, I32, P, I32, I32, F32, P, P, P, P, P, I64, P, P, P, P, P, P, P, I64, I32, P, P],
+    "wd_chain_tail": [P, I32, P, P, P, F32, F32, I32, P],
     "wd_logits_head_h": [P, I64, I64, P, P, I32, P, P, P, I64, P, P, P, P, P, P, I64, I32, P, P],
     "wd_hgemm_nn": [P, I64, P, I64, P, I32, I32, P, I64, P, I64, I64, I64, I64, P],
     "wd_hgemm_nt": [P, I64, P, I64, I64, I64, I64, P, I64, I32, P, I64, P, I64, P, I64, I32, P],
@@ -177,7 +188,7 @@ _PROTOS = {
     "wd_diag_gather64": [P, P, I64, I32, P, P],
     "wd_diag_access": [P, P, P, I32, P, I64, I32, I32, P, P],
 }
-_RESTYPES = {"wd_dense_update_fold_ws_bytes": I64, "wd_sort_workspace_bytes": SZ, "wd_logits_head_blocks": I64, "wd_tower_chain_lds_bytes": I64, "wd_tower_chain_blocks": I64, "wd_bucket_max": I32, "wd_bucket_chunks": I32, "wd_route_chunks": I32}
+_RESTYPES = {"wd_sort_workspace_bytes": SZ, "wd_logits_head_blocks": I64, "wd_tower_chain_lds_bytes": I64, "wd_tower_chain_blocks": I64, "wd_bucket_max": I32, "wd_bucket_chunks": I32, "wd_route_chunks": I32}
 
 EXPORTED_SYMBOLS = sorted(list(_PROTOS) + ["wd_last_error"])
 

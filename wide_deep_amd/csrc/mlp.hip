@@ -424,9 +424,7 @@ __device__ __forceinline__ void fold_affine_body(const float *__restrict__ P, in
                                                  int64_t N, int bx, int by, float (*red)[64],
                                                  _Float16 *__restrict__ WfT_h = nullptr, int64_t ld_wft_h = 0,
                                                  const int64_t *__restrict__ cat_off = nullptr,
-                                                 _Float16 *__restrict__ wcat = nullptr, _Float16 *tileT = nullptr,
-                                                 float *__restrict__ Wpk = nullptr,
-                                                 float *__restrict__ WTpk = nullptr, int pk_tile = 32) {
+                                                 _Float16 *__restrict__ wcat = nullptr, _Float16 *tileT = nullptr) {
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   const int64_t n = (int64_t)bx * 64 + tx;
   const int64_t kc = (K + WD_FOLD_PARTS - 1) / WD_FOLD_PARTS;
@@ -472,14 +470,6 @@ __device__ __forceinline__ void fold_affine_body(const float *__restrict__ P, in
           else WfT_h[n * ld_wft_h + k] = (_Float16)v;
         }
         if (co[u] >= 0) wcat[co[u] + n] = (_Float16)v;
-        // MFMA-fragment-packed copies for wd_tower_chain (layout: include/wd_hip.h, wd_mlp_layer_t)
-        if (pk_tile == 16) {
-          if (Wpk) Wpk[((n >> 4) * (K >> 4) + (k >> 4)) * 256 + (((k & 3) << 4) + (n & 15)) * 4 + ((k & 15) >> 2)] = v;
-          if (WTpk) WTpk[((k >> 4) * (N >> 4) + (n >> 4)) * 256 + (((n & 3) << 4) + (k & 15)) * 4 + ((n & 15) >> 2)] = v;
-        } else {
-          if (Wpk) Wpk[((n >> 5) * (K >> 3) + (k >> 3)) * 256 + (((k & 1) << 5) + (n & 31)) * 4 + ((k & 7) >> 1)] = v;
-          if (WTpk) WTpk[((k >> 5) * (N >> 3) + (n >> 3)) * 256 + (((n & 1) << 5) + (k & 31)) * 4 + ((n & 7) >> 1)] = v;
-        }
         tb += tk[u] * w[u];
       }
     }
@@ -524,7 +514,7 @@ k_fold_affine_all(const float *__restrict__ P, const wd_mlp_layer_t *__restrict_
   if ((int64_t)blockIdx.x * 64 >= L.N) return;
   fold_affine_body(P, L.w_off, L.b_off, L.gamma_idx, L.beta_idx, inv, L.Wf, L.bf, L.s, L.t, L.K, L.N, blockIdx.x,
                    blockIdx.y, red, reinterpret_cast<_Float16 *>(L.WfT_h), L.ld_wft_h, L.cat_off,
-                   reinterpret_cast<_Float16 *>(L.wcat), tileT, L.Wpk, L.WTpk, L.pk_tile == 16 ? 16 : 32);
+                   reinterpret_cast<_Float16 *>(L.wcat), tileT);
 }
 
 __global__ void __launch_bounds__(256)
@@ -588,7 +578,6 @@ __device__ __forceinline__ void mlp_finalize_body(const float *__restrict__ Gpar
                                                   const int32_t *__restrict__ beta_idx, float inv,
                                                   float *__restrict__ Gflat, int64_t K, int64_t N, int64_t k,
                                                   bool store_affine, float *red_g, float *red_d,
-                                                  const float *__restrict__ db_sum = nullptr,
                                                   float *Pw = nullptr, float *__restrict__ Pacc = nullptr,
                                                   float lr = 0.f) {
   // Pw / Pacc: apply dense Adagrad to every parameter right where its gradient is final (single-GPU default
@@ -604,25 +593,17 @@ __device__ __forceinline__ void mlp_finalize_body(const float *__restrict__ Gpar
   const int NT = N >= 256 ? 256 : (N > 128 ? 256 : (N > 64 ? 128 : (N > 32 ? 64 : (N > 16 ? 32 : 16))));
   const int ZQ = 256 / NT;
   const int nx = threadIdx.x % NT, zq = threadIdx.x / NT;
-  const int64_t split_stride = (db_sum ? K : K + 1) * N;   // db_sum: no ones row in the partials
+  const int64_t split_stride = (K + 1) * N;
   const float *W = P + w_off;
   float acc_s = 0.f, acc_t = 0.f;
   for (int64_t n0 = 0; n0 < N; n0 += NT) {
     const int64_t n = n0 + nx;
     float gk = 0.f, db = 0.f;
     if (n < N) {
-      if (db_sum) {          // bias gradient already summed (wd_mlp_layer_t.db_sum): the partials hold K rows
-        if (k < K) {
 #pragma unroll 4
-          for (int32_t z = zq; z < nsplit; z += ZQ) gk += Gpart[z * split_stride + k * N + n];
-        }
-        if (zq == 0) db = db_sum[n];
-      } else {
-#pragma unroll 4
-        for (int32_t z = zq; z < nsplit; z += ZQ) {
-          gk += Gpart[z * split_stride + k * N + n];
-          db += Gpart[z * split_stride + K * N + n];
-        }
+      for (int32_t z = zq; z < nsplit; z += ZQ) {
+        gk += Gpart[z * split_stride + k * N + n];
+        db += Gpart[z * split_stride + K * N + n];
       }
     }
     if (ZQ > 1) {
@@ -697,216 +678,7 @@ k_mlp_finalize_all(const wd_mlp_layer_t *__restrict__ layers, const float *P, fl
   const wd_mlp_layer_t L = layers[blockIdx.y];
   if ((int64_t)blockIdx.x > L.K) return;
   mlp_finalize_body(L.Gpart, L.nsplit, P, L.w_off, L.b_off, L.s, L.t, L.gamma_idx, L.beta_idx, inv, Gflat, L.K, L.N,
-                    blockIdx.x, true, red_g, red_d, L.db_sum, Pw, Pacc, lr);
-}
-
-// ---- finalize + dense Adagrad + fold for the NEXT step in one launch (wd_dense_update_fold) ----------------------------
-// The step's dense tail used to be two launches on the critical path: k_mlp_finalize_all (one workgroup per kernel row: ~900
-// workgroups that, in the step, queue for CU slots behind the row update running beside them -- 8 us alone, 28 us in the
-// step, profiles/r2e_timeline*.txt) and, at the head of the next step, k_fold_affine_all (8 us).  Everything either does
-// for kernel row k of layer l depends on that row alone:
-//     G[k,:] = sum of the split-K partials;  dW[k,:] = s_k G[k,:] + t_k db;  dgamma_k = inv sum_n G[k,n] W[k,n];
-//     dbeta_k = sum_n db[n] W[k,n]  (s_k = gamma_k inv, t_k = beta_k: the BN affine of the unit that feeds input column k)
-//     Adagrad on W[k,:], gamma_k, beta_k;  then the fold of the UPDATED row: Wf[k,:] = s'_k W'[k,:] (+ the MFMA-packed copies)
-// except the folded bias bf[n] = b'[n] + sum_k t'_k W'[k,n], a column sum over all rows.  One wavefront per row (4 rows per
-// workgroup: 4x fewer workgroups to place), row sums by shuffles; each workgroup stores its partial of the column sum and the
-// LAST workgroup of a layer to arrive (a counter per layer) adds the partials in workgroup order -- a fixed summation order
-// whoever arrives last -- into ONE bias vector (bias_parts = 1 for the consumers).  Partials and counter travel write-through
-// (sc1 stores / loads + vmcnt(0) before the arrival), no device-wide fence.
-constexpr int DU_ROWS = 4;      // rows (wavefronts) per workgroup
-constexpr int DU_MAXC = 8;      // columns per lane: N <= 512
-constexpr int DU_ZU = 16;       // split-K partials loaded per round and column (x up to 4 columns: 64 loads in flight)
-
-// row block `blk` (4 rows, one per wavefront) of layer L; s_part: [DU_ROWS][DU_MAXC * 64] floats of LDS.
-// Returns true in the workgroup that arrived last at its layer (its bias vector is then complete).
-__device__ __forceinline__ bool dense_rows(const wd_mlp_layer_t &L, int layer, int blk, float *P, float *__restrict__ Pacc,
-                                           float inv, float *__restrict__ Gflat, float lr, int do_update, float *bfp,
-                                           int32_t *counters, int64_t max_n, int32_t nblk_max, float *s_part, int *s_last) {
-  const int64_t K = L.K, N = L.N;
-  const int nblk = (int)((K + 1 + DU_ROWS - 1) / DU_ROWS);
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int64_t k = (int64_t)blk * DU_ROWS + wave;
-  // lanes of a row: nx = column (+ NT j), zq = split-K residue class (narrow layers: several classes side by side)
-  int NT = 64;
-  while (NT > 1 && NT / 2 >= N) NT >>= 1;
-  const int ZQ = 64 / NT;
-  const int nx = lane % NT, zq = lane / NT;
-  const int NC = (int)((N + NT - 1) / NT);           // columns per lane (<= DU_MAXC)
-  const bool has_sum = L.db_sum != nullptr;
-  const int64_t split_stride = (has_sum ? K : K + 1) * N;
-  const int32_t nsplit = do_update ? L.nsplit : 0;
-  float *srow = s_part + wave * (DU_MAXC * 64);
-  for (int i = lane; i < DU_MAXC * 64; i += 64) srow[i] = 0.f;
-  if (k <= K) {
-    // everything addressed by (k, n) alone is requested first: the row of W, its accumulators, the bias-gradient sums, and
-    // the index -> value chain of the BN affine; the partials follow, up to 64 loads in flight per lane
-    const bool wrow = k < K;
-    const int32_t gi = (wrow && L.gamma_idx) ? L.gamma_idx[k] : -1;
-    const int32_t bi = (wrow && L.beta_idx) ? L.beta_idx[k] : -1;
-    float w0[DU_MAXC], a0[DU_MAXC], gk[DU_MAXC], db[DU_MAXC];
-#pragma unroll
-    for (int j = 0; j < DU_MAXC; ++j) {
-      const int64_t n = nx + (int64_t)j * NT;
-      const bool own = zq == 0 && j < NC && n < N;
-      const int64_t idx = wrow ? L.w_off + k * N + n : L.b_off + n;
-      w0[j] = own ? P[idx] : 0.f;
-      a0[j] = (own && do_update) ? Pacc[idx] : 0.f;
-      gk[j] = 0.f;
-      db[j] = (has_sum && do_update && j < NC && n < N) ? L.db_sum[n] : 0.f;
-    }
-    const float gam = gi >= 0 ? P[gi] : 0.0f;
-    const float s_old = gi >= 0 ? gam * inv : 1.0f;
-    const float t_old = bi >= 0 ? P[bi] : 0.0f;
-    float ga = 0.f, ba = 0.f;
-    if (do_update && lane == 0) {
-      if (gi >= 0) ga = Pacc[gi];
-      if (bi >= 0) ba = Pacc[bi];
-    }
-    for (int jc = 0; jc < NC; jc += 4) {             // four columns x DU_ZU partials per round
-      for (int32_t z0 = zq; z0 < nsplit; z0 += ZQ * DU_ZU) {
-        float v[4][DU_ZU], d[4][DU_ZU];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-#pragma unroll
-          for (int u = 0; u < DU_ZU; ++u) {
-            const int32_t z = z0 + u * ZQ;
-            const int64_t n = nx + (int64_t)(jc + j) * NT;
-            const bool live = jc + j < NC && n < N && z < nsplit;
-            v[j][u] = (live && wrow) ? L.Gpart[z * split_stride + k * N + n] : 0.f;
-            d[j][u] = (live && !has_sum) ? L.Gpart[z * split_stride + K * N + n] : 0.f;
-          }
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          float sv = 0.f, sd = 0.f;
-#pragma unroll
-          for (int u = 0; u < DU_ZU; ++u) {
-            sv += v[j][u];
-            sd += d[j][u];
-          }
-#pragma unroll
-          for (int jj = 0; jj < DU_MAXC; ++jj) {       // static register index
-            if (jj == jc + j) {
-              gk[jj] += sv;
-              if (!has_sum) db[jj] += sd;
-            }
-          }
-        }
-      }
-    }
-    for (int off = NT; off < 64; off <<= 1) {         // combine the residue classes (fixed tree)
-#pragma unroll
-      for (int j = 0; j < DU_MAXC; ++j) {
-        gk[j] += __shfl_xor(gk[j], off, 64);
-        if (!has_sum) db[j] += __shfl_xor(db[j], off, 64);
-      }
-    }
-    auto adagrad = [&](int64_t idx, float w, float a, float g) -> float {     // returns the updated parameter
-      Gflat[idx] = g;
-      if (do_update) {
-        a += g * g;
-        Pacc[idx] = a;
-        w -= lr * g / sqrtf(a);
-        P[idx] = w;
-      }
-      return w;
-    };
-    if (!wrow) {
-      // bias row: db is the gradient of b; the updated bias opens the folded bias
-#pragma unroll
-      for (int j = 0; j < DU_MAXC; ++j) {
-        const int64_t n = nx + (int64_t)j * NT;
-        if (zq == 0 && j < NC && n < N) srow[n] = adagrad(L.b_off + n, w0[j], a0[j], db[j]);
-      }
-    } else {
-      float wn[DU_MAXC];
-      float acc_s = 0.f, acc_t = 0.f;
-#pragma unroll
-      for (int j = 0; j < DU_MAXC; ++j) {
-        const int64_t n = nx + (int64_t)j * NT;
-        wn[j] = 0.f;
-        if (zq == 0 && j < NC && n < N) {
-          acc_s += w0[j] * gk[j];
-          acc_t += w0[j] * db[j];
-          wn[j] = adagrad(L.w_off + k * N + n, w0[j], a0[j], s_old * gk[j] + t_old * db[j]);
-        }
-      }
-      for (int off = 32; off > 0; off >>= 1) {
-        acc_s += __shfl_xor(acc_s, off, 64);
-        acc_t += __shfl_xor(acc_t, off, 64);
-      }
-      // the BN affine of the producer of input column k has this row as its only consumer (connected_mode simple)
-      float s_new = 1.0f, t_new = 0.0f;
-      if (lane == 0) {
-        if (gi >= 0) s_new = adagrad(gi, gam, ga, acc_s * inv) * inv;
-        if (bi >= 0) t_new = adagrad(bi, t_old, ba, acc_t);
-        if (L.s) L.s[k] = s_new;
-        if (L.t) L.t[k] = t_new;
-      }
-      s_new = __shfl(s_new, 0, 64);
-      t_new = __shfl(t_new, 0, 64);
-      // ---- fold of the updated row ----
-      if (zq == 0) {
-        const bool pk16 = L.pk_tile == 16;
-#pragma unroll
-        for (int j = 0; j < DU_MAXC; ++j) {
-          const int64_t n = nx + (int64_t)j * NT;
-          if (j < NC && n < N) {
-            const float v = s_new * wn[j];
-            L.Wf[k * N + n] = v;
-            if (pk16) {
-              if (L.Wpk) L.Wpk[((n >> 4) * (K >> 4) + (k >> 4)) * 256 + (((k & 3) << 4) + (n & 15)) * 4 + ((k & 15) >> 2)] = v;
-              if (L.WTpk) L.WTpk[((k >> 4) * (N >> 4) + (n >> 4)) * 256 + (((n & 3) << 4) + (k & 15)) * 4 + ((n & 15) >> 2)] = v;
-            } else {
-              if (L.Wpk) L.Wpk[((n >> 5) * (K >> 3) + (k >> 3)) * 256 + (((k & 1) << 5) + (n & 31)) * 4 + ((k & 7) >> 1)] = v;
-              if (L.WTpk) L.WTpk[((k >> 5) * (N >> 3) + (n >> 3)) * 256 + (((n & 1) << 5) + (k & 31)) * 4 + ((n & 7) >> 1)] = v;
-            }
-            srow[n] = t_new * wn[j];
-          }
-        }
-      }
-    }
-  }
-  __syncthreads();
-  // ---- this workgroup's partial of the folded bias, then the arrival ----
-  float *mine = bfp + ((int64_t)layer * nblk_max + blk) * max_n;
-  for (int64_t n = threadIdx.x; n < N; n += 256) {
-    const float v = ((s_part[n] + s_part[DU_MAXC * 64 + n]) + s_part[2 * DU_MAXC * 64 + n]) + s_part[3 * DU_MAXC * 64 + n];
-    __hip_atomic_store(mine + n, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (threadIdx.x == 0)
-    *s_last = __hip_atomic_fetch_add(counters + layer, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nblk - 1;
-  __syncthreads();
-  if (!*s_last) return false;
-  // last arriver of the layer: the partials in workgroup order (32 loads in flight per lane)
-  const float *all = bfp + (int64_t)layer * nblk_max * max_n;
-  for (int64_t n = threadIdx.x; n < N; n += 256) {
-    float v = 0.f;
-    for (int b0 = 0; b0 < nblk; b0 += 32) {
-      float q[32];
-#pragma unroll
-      for (int u = 0; u < 32; ++u)
-        q[u] = b0 + u < nblk ? __hip_atomic_load(all + (int64_t)(b0 + u) * max_n + n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
-#pragma unroll
-      for (int u = 0; u < 32; ++u) v += q[u];
-    }
-    L.bf[n] = v;
-  }
-  if (threadIdx.x == 0) __hip_atomic_store(counters + layer, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  return true;
-}
-
-__global__ void __launch_bounds__(256)
-k_dense_update_fold(const wd_mlp_layer_t *__restrict__ layers, float *P, float *__restrict__ Pacc, float inv,
-                    float *__restrict__ Gflat, float lr, int do_update, float *bfp, int32_t *counters, int64_t max_n,
-                    int32_t nblk_max) {
-  __shared__ float s_part[DU_ROWS * DU_MAXC * 64];
-  __shared__ int s_last;
-  const wd_mlp_layer_t L = layers[blockIdx.y];
-  if ((int)blockIdx.x >= (int)((L.K + 1 + DU_ROWS - 1) / DU_ROWS)) return;
-  dense_rows(L, blockIdx.y, blockIdx.x, P, Pacc, inv, Gflat, lr, do_update, bfp, counters, max_n, nblk_max, s_part, &s_last);
+                    blockIdx.x, true, red_g, red_d, Pw, Pacc, lr);
 }
 
 // ---- logits layer + head, forward AND backward of that layer in one launch ------------------------
@@ -1215,26 +987,6 @@ extern "C" int wd_mlp_finalize_adagrad_all(const wd_mlp_layer_t *layers_dev, int
   hipLaunchKernelGGL(k_mlp_finalize_all, dim3((unsigned)(max_k + 1), (unsigned)nlayers), dim3(256), 0,
                      wd::as_stream(stream), layers_dev, P, inv, Gflat, P, Pacc, lr);
   return wd::check_launch("wd_mlp_finalize_adagrad_all");
-}
-
-extern "C" int64_t wd_dense_update_fold_ws_bytes(int32_t nlayers, int64_t max_k, int64_t max_n) {
-  if (nlayers <= 0 || max_k <= 0 || max_n <= 0) return 0;
-  const int64_t nblk = wd::ceil_div(max_k + 1, (int64_t)DU_ROWS);
-  return 256 + (int64_t)nlayers * nblk * max_n * 4;      // counters (zeroed by the caller once) + the bias partials
-}
-
-extern "C" int wd_dense_update_fold(const wd_mlp_layer_t *layers_dev, int32_t nlayers, int64_t max_k, int64_t max_n, float *P,
-                                    float *Pacc, float inv, float *Gflat, float lr, int32_t do_update, void *ws,
-                                    wd_stream_t stream) {
-  WD_REQUIRE(P && layers_dev && Gflat && ws, "null pointer");
-  WD_REQUIRE(!do_update || Pacc, "the update needs the Adagrad accumulators");
-  WD_REQUIRE(nlayers > 0 && nlayers <= 64 && max_k > 0 && max_n > 0 && max_n <= DU_MAXC * 64,
-             "nlayers in 1..64, max_k > 0, 0 < max_n <= 512");
-  const int64_t nblk = wd::ceil_div(max_k + 1, (int64_t)DU_ROWS);
-  hipLaunchKernelGGL(k_dense_update_fold, dim3((unsigned)nblk, (unsigned)nlayers), dim3(256), 0, wd::as_stream(stream),
-                     layers_dev, P, Pacc, inv, Gflat, lr, do_update ? 1 : 0, reinterpret_cast<float *>(ws) + 64,
-                     reinterpret_cast<int32_t *>(ws), max_n, (int32_t)nblk);
-  return wd::check_launch("wd_dense_update_fold");
 }
 
 extern "C" int64_t wd_logits_head_blocks(int64_t batch, int64_t K) { return wd::ceil_div(batch, head_chunk(K)); }

@@ -72,16 +72,17 @@ struct ChainArgs {
   wd_chain_layer_t layer[MAXL];
   int32_t a_off[MAXL];   // LDS float offsets of a_l and dz_l
   int32_t dz_off[MAXL];
+  int32_t tab_off[MAXL]; // LDS float offset of layer l's BN affine table: s_l[N_l] (= gamma inv) then t_l[N_l] (= beta)
+  float inv;             // 1 / sqrt(1 + eps): the inference-mode BN of SURVEY App. C.1
   int32_t L;
   int32_t act;
-  int32_t bias_parts;
   int32_t K0;            // width of x
   int32_t dx_cols;       // gradient columns of x wanted (multiple of 32, <= round32(K0)); 0: none
   int32_t train;
   const float *x;        // [batch][ld_act]
   int64_t ld_act;
   const float *w_logits; // [K_L]
-  const float *b_logits; // [bias_parts]
+  const float *b_logits; // [1]
   const float *wide_logit, *labels, *weights;
   int64_t batch;
   float *dnn_logit, *logit, *prob, *dlogit, *loss_sum, *Gpart_logits;
@@ -139,37 +140,55 @@ __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlan
 // address / load instructions of every group while the matrix pipe idled: 110 instead of 64 cycles per MFMA.)
 // Every prefetch is unconditional (past the end it re-reads the last group and is never used): a load inside a branch
 // would make the wait at the join vmcnt(0), i.e. serialise the prefetch with the MFMAs it is meant to overlap.
-template <typename TL, int NT, bool FULL>
+// AFF: the input of the product is the BN affine of the stored activations, bn[k] = a[k] * sA[k] + tA[k] (python/lib/dnn.py:
+// 113-114: tf.layers.batch_normalization without training=True = the inference affine), applied to the A
+// fragment as it is read (two more LDS reads and a multiply-add per fragment element, shared by the NT tiles): the kernels
+// stay the reference's raw variables -- nothing is folded, so the step needs no fold launch and no column sum for a
+// folded bias -- and the LDS tile keeps a itself, which the gradient chain needs for act'.
+template <typename TL, int NT, bool FULL, bool AFF>
 __device__ __forceinline__ void mma_ring(const float *__restrict__ inA, const float4 *__restrict__ WB, int KG,
-                                         int tstride, typename TL::acc_t (&acc)[NT]) {
+                                         int tstride, typename TL::acc_t (&acc)[NT], const float *__restrict__ sA,
+                                         const float *__restrict__ tA) {
   constexpr int D = TL::RING, P = TL::P, GK = TL::GK, KS = TL::KS;
-  float fa[D][4];
+  float fa[D][4], fs[AFF ? D : 1][4], ft[AFF ? D : 1][4];
   float4 fb[D][NT];
 #ifndef WD_CHAIN_EXP
-#define WD_CHAIN_EXP 0      // diagnostics (scripts/gpu_chain_exp.sh): 1 = no MFMAs, 2 = weights loaded once, 3 = A fragments read once
+#define WD_CHAIN_EXP 0      // diagnostics (scripts/build_chain_exp.sh): 1 = no MFMAs, 2 = weights loaded once, 3 = A fragments read once
 #endif
+  // the ring holds what was READ (a, and with AFF its s and t); the affine itself is computed where the fragment is used --
+  // computed at load time it waits for its LDS reads inside the prefetch region (+40 cycles per MFMA in the narrow layers)
   auto load = [&](int buf, int c) {
     const int kg = c < KG ? c : KG - 1;
 #pragma unroll
     for (int t = 0; t < NT; ++t) fb[buf][t] = WB[(WD_CHAIN_EXP == 2 ? 0 : kg * 64) + t * tstride];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) fa[buf][j] = inA[(WD_CHAIN_EXP == 3 ? 0 : (GK * kg + KS * j)) * P];
+    for (int j = 0; j < 4; ++j) {
+      const int kr = WD_CHAIN_EXP == 3 ? 0 : (GK * kg + KS * j);
+      fa[buf][j] = inA[kr * P];
+      if (AFF) {
+        fs[buf][j] = sA[kr];
+        ft[buf][j] = tA[kr];
+      }
+    }
   };
   auto mfmas = [&](int buf) {
+    float av[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) av[j] = AFF ? __fadd_rn(__fmul_rn(fa[buf][j], fs[AFF ? buf : 0][j]), ft[AFF ? buf : 0][j]) : fa[buf][j];
 #if WD_CHAIN_EXP == 1
 #pragma unroll
     for (int t = 0; t < NT; ++t)
-      acc[t][0] += fa[buf][0] * fb[buf][t].x + fa[buf][1] * fb[buf][t].y + fa[buf][2] * fb[buf][t].z + fa[buf][3] * fb[buf][t].w;
+      acc[t][0] += av[0] * fb[buf][t].x + av[1] * fb[buf][t].y + av[2] * fb[buf][t].z + av[3] * fb[buf][t].w;
     return;
 #endif
 #pragma unroll
-    for (int t = 0; t < NT; ++t) acc[t] = TL::mfma(fa[buf][0], fb[buf][t].x, acc[t]);
+    for (int t = 0; t < NT; ++t) acc[t] = TL::mfma(av[0], fb[buf][t].x, acc[t]);
 #pragma unroll
-    for (int t = 0; t < NT; ++t) acc[t] = TL::mfma(fa[buf][1], fb[buf][t].y, acc[t]);
+    for (int t = 0; t < NT; ++t) acc[t] = TL::mfma(av[1], fb[buf][t].y, acc[t]);
 #pragma unroll
-    for (int t = 0; t < NT; ++t) acc[t] = TL::mfma(fa[buf][2], fb[buf][t].z, acc[t]);
+    for (int t = 0; t < NT; ++t) acc[t] = TL::mfma(av[2], fb[buf][t].z, acc[t]);
 #pragma unroll
-    for (int t = 0; t < NT; ++t) acc[t] = TL::mfma(fa[buf][3], fb[buf][t].w, acc[t]);
+    for (int t = 0; t < NT; ++t) acc[t] = TL::mfma(av[3], fb[buf][t].w, acc[t]);
   };
 #pragma unroll
   for (int i = 0; i < D - 1; ++i) load(i, i);
@@ -186,22 +205,35 @@ __device__ __forceinline__ void mma_ring(const float *__restrict__ inA, const fl
 
 template <typename TL, int NT>
 __device__ __forceinline__ void mma_tiles(const float *__restrict__ inA, const float4 *__restrict__ WB, int KG,
-                                          int tstride, typename TL::acc_t (&acc)[NT]) {
-  if (KG % TL::RING == 0) mma_ring<TL, NT, true>(inA, WB, KG, tstride, acc);
-  else mma_ring<TL, NT, false>(inA, WB, KG, tstride, acc);
+                                          int tstride, typename TL::acc_t (&acc)[NT], const float *__restrict__ sA,
+                                          const float *__restrict__ tA) {
+  if (sA) {
+    if (KG % TL::RING == 0) mma_ring<TL, NT, true, true>(inA, WB, KG, tstride, acc, sA, tA);
+    else mma_ring<TL, NT, false, true>(inA, WB, KG, tstride, acc, sA, tA);
+  } else {
+    if (KG % TL::RING == 0) mma_ring<TL, NT, true, false>(inA, WB, KG, tstride, acc, sA, tA);
+    else mma_ring<TL, NT, false, false>(inA, WB, KG, tstride, acc, sA, tA);
+  }
 }
 
 // One product stage: out[RT x N] = epilogue(in[RT x K] . W[K x N]).  Wavefront w takes the RT-column tiles
 // w, w+4, w+8, ... NTMAX at a time (shared A fragments, independent accumulator chains).
-//   MODE 0 (forward):  v = act(acc + bias[n])            -> LDS out + HBM g_out[b][n]
-//   MODE 1 (gradient): v = acc * act'(a_prev LDS [n][m]) -> LDS out + HBM g_out[b][n]
-//   MODE 2 (dx):       v = acc                            -> HBM g_out[b][n] only (n < n_store)
+//   MODE 0 (forward):  a = act(acc + bias[n]) -> LDS out; HBM g_out[b][n] = bn = a * s_out[n] + t_out[n] (the operand of the
+//                      next layer's weight-gradient product; s_out NULL: no BN, bn = a).  Input affine: s_in / t_in (or NULL).
+//   MODE 1 (gradient): acc = d(bn) of the producing layer; per-tile column sums of acc (-> d beta) and acc * a (-> d gamma);
+//                      v = acc * s_out[n] * act'(a) -> LDS out + HBM g_out[b][n] (dz), column sum of v (-> d bias)
+//   MODE 2 (dx):       v = acc -> HBM g_out[b][n] only (n < n_store)
+struct StageAff {
+  const float *s_in, *t_in;     // LDS tables of the INPUT's BN affine (forward) or NULL
+  const float *s_out, *t_out;   // LDS tables of the OUTPUT layer's BN affine or NULL
+  float *db_out, *dg_out, *dbeta_out;   // MODE 1: this tile's column-sum partials [N] (HBM) or NULL
+};
 template <typename TL, int MODE>
 __device__ __forceinline__ void stage(const float *__restrict__ in, int K, const float *__restrict__ Wpk, int N,
-                                      const float *__restrict__ bias, int bias_parts, int act,
+                                      const float *__restrict__ bias, int act,
                                       const float *__restrict__ a_prev, float *__restrict__ out,
                                       float *__restrict__ g_out, int64_t ld_g, int n_store, int64_t b0, int64_t batch,
-                                      unsigned long long *dbg = nullptr, float *__restrict__ db_out = nullptr) {
+                                      const StageAff &af, unsigned long long *dbg = nullptr) {
   constexpr int RT = TL::RT, P = TL::P;
   typedef typename TL::acc_t acc_t;
   const int lane = threadIdx.x & 63, wave = uni((int)(threadIdx.x >> 6));
@@ -210,70 +242,76 @@ __device__ __forceinline__ void stage(const float *__restrict__ in, int K, const
   const int KG = K / TL::GK;
   const int ntiles = N / RT;
   const float *inA = in + h * P + c;
-  // folded bias of column n (sum of the fold launch's partials): loaded BEFORE the reduction loop, used after it
-  auto bias_of = [&](int n0) {
-    float bv = 0.f;
-    if (MODE == 0) {
-      if (bias_parts == WD_FOLD_PARTS) {
-        float bp[WD_FOLD_PARTS];
-#pragma unroll
-        for (int p = 0; p < WD_FOLD_PARTS; ++p) bp[p] = bias[p * N + n0 + c];
-#pragma unroll
-        for (int p = 0; p < WD_FOLD_PARTS; ++p) bv += bp[p];
-      } else {
-        for (int p = 0; p < bias_parts; ++p) bv += bias[p * N + n0 + c];
-      }
-    }
-    return bv;
-  };
+  const float *sA = af.s_in ? af.s_in + h : nullptr, *tA = af.s_in ? af.t_in + h : nullptr;
   const bool full_rows = b0 + RT <= batch;   // uniform: no per-element row predicate in the common case
-  auto epilogue_t = [&](const acc_t &acc, int n0, float bv, auto act_c, auto full_c) {
+  auto epilogue_t = [&](const acc_t &acc, int n0, float bv, float sv, float tv, auto act_c, auto full_c) {
     constexpr int ACT = decltype(act_c)::value;   // >= 0: activation known at compile time
     constexpr bool FULLR = decltype(full_c)::value;
     const int n = n0 + c;
     const int a_id = ACT >= 0 ? ACT : act;
-    float csum = 0.f;
+    float csum = 0.f, gsum = 0.f, bsum = 0.f;
 #pragma unroll
     for (int r = 0; r < TL::NACC; ++r) {
       const int m = TL::row_of(r, h);
-      float v = acc[r];
-      if (MODE == 0) v = act_fwd(v + bv, a_id);
-      if (MODE == 1) v *= act_bwd(a_prev[n * P + m], a_id);
+      float v = acc[r], o = 0.f;
+      if (MODE == 0) {
+        v = act_fwd(v + bv, a_id);
+        o = __fadd_rn(__fmul_rn(v, sv), tv);          // bn: what the next layer (and its weight-gradient product) reads
+      }
+      if (MODE == 1) {
+        const float a = a_prev[n * P + m];
+        bsum += v;
+        gsum += v * a;
+        v = v * sv * act_bwd(a, a_id);
+        o = v;
+        csum += v;
+      }
+      if (MODE == 2) o = v;
       if (MODE != 2) out[n * P + m] = v;
-      if ((FULLR || b0 + m < batch) && n < n_store) g_out[(b0 + m) * ld_g + n] = v;
-      if (MODE == 1) csum += v;
+      if ((FULLR || b0 + m < batch) && n < n_store) g_out[(b0 + m) * ld_g + n] = o;
     }
-    if (MODE == 1 && db_out) {   // bias-gradient partial of this tile: column sum over its RT rows (rows >= batch are 0)
+    if (MODE == 1) {   // this tile's partials of the bias / BN gradients: column sums over its RT rows (rows >= batch are 0)
 #pragma unroll
-      for (int off = RT; off < 64; off <<= 1) csum += __shfl_xor(csum, off, 64);
-      if (h == 0) db_out[n] = csum;
+      for (int off = RT; off < 64; off <<= 1) {
+        csum += __shfl_xor(csum, off, 64);
+        gsum += __shfl_xor(gsum, off, 64);
+        bsum += __shfl_xor(bsum, off, 64);
+      }
+      if (h == 0) {
+        if (af.db_out) af.db_out[n] = csum;
+        if (af.dg_out) af.dg_out[n] = gsum;
+        if (af.dbeta_out) af.dbeta_out[n] = bsum;
+      }
     }
   };
-  auto epilogue = [&](const acc_t &acc, int n0, float bv) {
+  auto epilogue = [&](const acc_t &acc, int n0, float bv, float sv, float tv) {
     using std::integral_constant;
     if (act == WD_ACT_RELU || MODE == 2) {
-      if (full_rows) epilogue_t(acc, n0, bv, integral_constant<int, WD_ACT_RELU>{}, integral_constant<bool, true>{});
-      else epilogue_t(acc, n0, bv, integral_constant<int, WD_ACT_RELU>{}, integral_constant<bool, false>{});
+      if (full_rows) epilogue_t(acc, n0, bv, sv, tv, integral_constant<int, WD_ACT_RELU>{}, integral_constant<bool, true>{});
+      else epilogue_t(acc, n0, bv, sv, tv, integral_constant<int, WD_ACT_RELU>{}, integral_constant<bool, false>{});
     } else {
-      epilogue_t(acc, n0, bv, integral_constant<int, -1>{}, integral_constant<bool, false>{});
+      epilogue_t(acc, n0, bv, sv, tv, integral_constant<int, -1>{}, integral_constant<bool, false>{});
     }
   };
   auto run = [&](int t0, auto nt_c) {
     constexpr int NT = decltype(nt_c)::value;
     const float4 *WB = reinterpret_cast<const float4 *>(Wpk) + (int64_t)t0 * KG * 64 + lane;
     acc_t acc[NT];
-    float bv[NT];
+    float bv[NT], sv[NT], tv[NT];
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
 #pragma unroll
       for (int r = 0; r < TL::NACC; ++r) acc[i][r] = 0.f;
-      bv[i] = bias_of((t0 + 4 * i) * RT);
+      const int n = (t0 + 4 * i) * RT + c;
+      bv[i] = (MODE == 0 && bias) ? bias[n] : 0.f;       // requested before the reduction loop, used after it
+      sv[i] = (MODE != 2 && af.s_out) ? af.s_out[n] : 1.0f;
+      tv[i] = (MODE == 0 && af.s_out) ? af.t_out[n] : 0.0f;
     }
     if (dbg && threadIdx.x == 0) *dbg++ = __builtin_readcyclecounter();
-    mma_tiles<TL, NT>(inA, WB, KG, 4 * KG * 64, acc);
+    mma_tiles<TL, NT>(inA, WB, KG, 4 * KG * 64, acc, sA, tA);
     if (dbg && threadIdx.x == 0) *dbg++ = __builtin_readcyclecounter();
 #pragma unroll
-    for (int i = 0; i < NT; ++i) epilogue(acc[i], (t0 + 4 * i) * RT, bv[i]);
+    for (int i = 0; i < NT; ++i) epilogue(acc[i], (t0 + 4 * i) * RT, bv[i], sv[i], tv[i]);
     if (dbg && threadIdx.x == 0) *dbg++ = __builtin_readcyclecounter();
   };
   using std::integral_constant;
@@ -294,7 +332,7 @@ __global__ void __launch_bounds__(256, RT_ == 16 ? 2 : 1) k_tower_chain(ChainArg
   constexpr int PARTS = 256 / RT;   // lane groups of the head's dot product
   extern __shared__ __attribute__((aligned(16))) float lds[];
   __shared__ float sdl[RT];
-  __shared__ float red[256];
+  __shared__ float red[256], red2[256], red3[256];
   __shared__ float swl[512];   // logits-layer kernel
   __shared__ int64_t s_eoff[WD_CHAIN_MAX_SLOTS], s_rbase[WD_CHAIN_MAX_SLOTS];   // fused input layer: slot descriptors
   __shared__ int32_t s_ocol[WD_CHAIN_MAX_SLOTS];
@@ -324,8 +362,16 @@ __global__ void __launch_bounds__(256, RT_ == 16 ? 2 : 1) k_tower_chain(ChainArg
     if (g.labels) h_y = g.labels[b0 + t];
     if (g.weights) h_w = g.weights[b0 + t];
   }
-  if (t < RT)
-    for (int p = 0; p < g.bias_parts; ++p) h_bias += g.b_logits[p];
+  if (t < RT) h_bias = g.b_logits[0];
+  // BN affine tables of every hidden layer -> LDS: s = gamma * inv, t = beta (no BN: the identity, and the stages skip it)
+  for (int l = 0; l < L; ++l) {
+    const wd_chain_layer_t &ly = g.layer[l];
+    float *tab = lds + g.tab_off[l];
+    for (int n = t; n < ly.N; n += 256) {
+      tab[n] = ly.gamma ? ly.gamma[n] * g.inv : 1.0f;
+      tab[ly.N + n] = ly.beta ? ly.beta[n] : 0.0f;
+    }
+  }
 
   float *s_wide = red;   // [RT] wide logit of the tile's examples (gather mode); `red` is free until the head
   if (g.in.emb) {
@@ -485,7 +531,10 @@ __global__ void __launch_bounds__(256, RT_ == 16 ? 2 : 1) k_tower_chain(ChainArg
   for (int l = 0; l < L; ++l) {
     const wd_chain_layer_t &ly = g.layer[l];
     float *out = lds + g.a_off[l];
-    stage<TL, 0>(in, K, ly.Wpk, ly.N, ly.bf, g.bias_parts, g.act, nullptr, out, ly.a_out, g.ld_act, ly.N, b0, g.batch,
+    StageAff af{};
+    if (l > 0 && g.layer[l - 1].gamma) { af.s_in = lds + g.tab_off[l - 1]; af.t_in = af.s_in + g.layer[l - 1].N; }
+    if (ly.gamma) { af.s_out = lds + g.tab_off[l]; af.t_out = af.s_out + ly.N; }
+    stage<TL, 0>(in, K, ly.Wpk, ly.N, ly.bias, g.act, nullptr, out, ly.a_out, g.ld_act, ly.N, b0, g.batch, af,
                  (g.stamps && blockIdx.x == 0 && l == 0) ? g.stamps + 16 : nullptr);
     __syncthreads();
     stamp();
@@ -496,8 +545,9 @@ __global__ void __launch_bounds__(256, RT_ == 16 ? 2 : 1) k_tower_chain(ChainArg
   // ---- logits layer + head (in = a_{L-1} [K][P]) ------------------------------------------------------------
   {
     const int m = t % RT, part = t / RT;
+    const float *sL = lds + g.tab_off[L - 1], *tL = sL + K;     // affine of the last hidden layer (identity without BN)
     float d = 0.f;
-    for (int n = part; n < K; n += PARTS) d += in[n * P + m] * swl[n];
+    for (int n = part; n < K; n += PARTS) d += __fadd_rn(__fmul_rn(in[n * P + m], sL[n]), tL[n]) * swl[n];
     const float h_wide_lds = (g.in.emb && t < RT) ? s_wide[t] : 0.f;   // read before `red` is reused below
     __syncthreads();
     red[part * RT + m] = d;
@@ -535,44 +585,64 @@ __global__ void __launch_bounds__(256, RT_ == 16 ? 2 : 1) k_tower_chain(ChainArg
   if (!g.train) return;
   __syncthreads();
 
-  // dz_{L-1} = dlogit w^T * act'(a_{L-1});  logits-layer gradient partial of this tile (wd_mlp_finalize layout)
+  // d(bn_{L-1}) = dlogit w^T;  dz_{L-1} = d(bn) * s * act'(a_{L-1});  per-tile partials of d beta, d gamma, d bias of layer
+  // L-1 and of the logits-layer kernel gradient (layout of wd_chain_tail: [tile][K + 1], the last entry = sum dlogit)
   {
     float *dz = lds + g.dz_off[L - 1];
-    float *gdz = g.layer[L - 1].dz_out;
+    const wd_chain_layer_t &ll = g.layer[L - 1];
+    float *gdz = ll.dz_out;
+    const float *sL = lds + g.tab_off[L - 1], *tL = sL + K;
     float *Gp = g.Gpart_logits ? g.Gpart_logits + (int64_t)blockIdx.x * (K + 1) : nullptr;
     const int KT = K < 256 ? K : 256;   // lanes along n: coalesced HBM rows, conflict-free LDS
     const int MQ = 256 / KT;            // K < 256: several example groups in parallel
     const int nq = t % KT, mq = t / KT;
-    float *dbp = g.layer[L - 1].db_part ? g.layer[L - 1].db_part + (int64_t)blockIdx.x * K : nullptr;
+    float *dbp = ll.db_part ? ll.db_part + (int64_t)blockIdx.x * K : nullptr;
+    float *dgp = ll.dgamma_part ? ll.dgamma_part + (int64_t)blockIdx.x * K : nullptr;
+    float *dtp = ll.dbeta_part ? ll.dbeta_part + (int64_t)blockIdx.x * K : nullptr;
     if (mq < MQ) {
       for (int n = nq; n < K; n += KT) {
-        const float w = swl[n];
-        float csum = 0.f;
+        const float w = swl[n], sv = sL[n];
+        float csum = 0.f, gsum = 0.f, bsum = 0.f;
         for (int m = mq; m < RT; m += MQ) {
-          const float v = sdl[m] * w * act_bwd(in[n * P + m], g.act);
+          const float a = in[n * P + m];
+          const float dbn = sdl[m] * w;
+          bsum += dbn;
+          gsum += dbn * a;
+          const float v = dbn * sv * act_bwd(a, g.act);
           dz[n * P + m] = v;
           if (b0 + m < g.batch) gdz[(b0 + m) * K + n] = v;
           csum += v;
         }
-        if (dbp) {
-          if (MQ == 1) dbp[n] = csum;
-          else red[mq * KT + n] = csum;     // K < 256: MQ * KT == 256 partial sums, combined below in group order
+        if (MQ == 1) {
+          if (dbp) dbp[n] = csum;
+          if (dgp) dgp[n] = gsum;
+          if (dtp) dtp[n] = bsum;
+        } else {     // K < 256: MQ * KT == 256 partial sums each, combined below in group order
+          red[mq * KT + n] = csum;
+          red2[mq * KT + n] = gsum;
+          red3[mq * KT + n] = bsum;
         }
       }
     }
-    if (dbp && MQ > 1) {
+    if (MQ > 1) {
       __syncthreads();
       if (t < K) {
-        float v = red[t];
-        for (int j = 1; j < MQ; ++j) v += red[j * KT + t];
-        dbp[t] = v;
+        float v = red[t], u = red2[t], x = red3[t];
+        for (int j = 1; j < MQ; ++j) {
+          v += red[j * KT + t];
+          u += red2[j * KT + t];
+          x += red3[j * KT + t];
+        }
+        if (dbp) dbp[t] = v;
+        if (dgp) dgp[t] = u;
+        if (dtp) dtp[t] = x;
       }
     }
-    if (Gp) {
+    if (Gp) {     // logits kernel gradient: its input is bn_{L-1}
       for (int n = t; n < K; n += 256) {
         float gw = 0.f;
 #pragma unroll 8
-        for (int m = 0; m < RT; ++m) gw += in[n * P + m] * sdl[m];
+        for (int m = 0; m < RT; ++m) gw += __fadd_rn(__fmul_rn(in[n * P + m], sL[n]), tL[n]) * sdl[m];
         Gp[n] = gw;
       }
       if (t == 0) {
@@ -585,28 +655,149 @@ __global__ void __launch_bounds__(256, RT_ == 16 ? 2 : 1) k_tower_chain(ChainArg
   __syncthreads();
   stamp();
 
-  // ---- gradient chain: dz_{l-1} = (dz_l WfT_l) * act'(a_{l-1}),  dx = dz_0 WfT_0 ----------------------------
+  // ---- gradient chain: d(bn_{l-1}) = dz_l W_l^T, dz_{l-1} = d(bn_{l-1}) * s_{l-1} * act'(a_{l-1});  dx = dz_0 W_0^T -----
   for (int l = L - 1; l >= 1; --l) {
     const wd_chain_layer_t &ly = g.layer[l];
     const wd_chain_layer_t &lp = g.layer[l - 1];
-    stage<TL, 1>(lds + g.dz_off[l], ly.N, ly.WTpk, lp.N, nullptr, 0, g.act, lds + g.a_off[l - 1], lds + g.dz_off[l - 1],
-                 lp.dz_out, lp.N, lp.N, b0, g.batch, nullptr, lp.db_part ? lp.db_part + (int64_t)blockIdx.x * lp.N : nullptr);
+    StageAff af{};
+    if (lp.gamma) { af.s_out = lds + g.tab_off[l - 1]; af.t_out = af.s_out + lp.N; }
+    af.db_out = lp.db_part ? lp.db_part + (int64_t)blockIdx.x * lp.N : nullptr;
+    af.dg_out = lp.dgamma_part ? lp.dgamma_part + (int64_t)blockIdx.x * lp.N : nullptr;
+    af.dbeta_out = lp.dbeta_part ? lp.dbeta_part + (int64_t)blockIdx.x * lp.N : nullptr;
+    stage<TL, 1>(lds + g.dz_off[l], ly.N, ly.WTpk, lp.N, nullptr, g.act, lds + g.a_off[l - 1], lds + g.dz_off[l - 1],
+                 lp.dz_out, lp.N, lp.N, b0, g.batch, af);
     __syncthreads();
     stamp();
   }
   if (g.dx && g.dx_cols > 0) {
     const wd_chain_layer_t &ly = g.layer[0];
-    stage<TL, 2>(lds + g.dz_off[0], ly.N, ly.WTpk, g.dx_cols, nullptr, 0, 0, nullptr, nullptr, g.dx, g.ld_dx, g.K0, b0,
-                 g.batch, (g.stamps && blockIdx.x == 0) ? g.stamps + 20 : nullptr);
+    StageAff af{};
+    stage<TL, 2>(lds + g.dz_off[0], ly.N, ly.WTpk, g.dx_cols, nullptr, 0, nullptr, nullptr, g.dx, g.ld_dx, g.K0, b0,
+                 g.batch, af, (g.stamps && blockIdx.x == 0) ? g.stamps + 20 : nullptr);
   }
   stamp();
 }
+
+
+// ---- the dense tail of a step: split-K partials -> gradients -> Adagrad -> packed operands of the next tower launch --------
+// With nothing folded every dense parameter's update depends on that parameter alone (python/lib/joint.py:233-241,
+// tf.train.AdagradOptimizer on the dnn scope): one thread per parameter sums its partials in split order, stores the gradient,
+// takes the Adagrad step and, for a hidden-layer kernel element, rewrites the two MFMA-packed copies.  No row or column
+// reductions, no ordering between workgroups -- the BN and bias gradients arrive as finished column sums (column-sum jobs of
+// wd_gemm_tn_splitk_group over the tower kernel's per-tile partials).
+struct TailArgs {
+  wd_tail_layer_t layer[MAXL + 1];
+  int32_t first[MAXL + 2];   // first workgroup of layer l (256 parameters per workgroup)
+  int32_t nlayers;
+  int32_t mode;
+  float *P, *Pacc, *Gflat;
+  float inv, lr;
+};
+
+__global__ void __launch_bounds__(256) k_chain_tail(TailArgs g) {
+  int l = 0;
+  while (l + 1 < g.nlayers && (int)blockIdx.x >= g.first[l + 1]) ++l;
+  l = uni(l);
+  const wd_tail_layer_t &L = g.layer[l];
+  const int64_t K = L.K, N = L.N;
+  const int64_t e = (int64_t)(blockIdx.x - g.first[l]) * 256 + threadIdx.x;
+  const int64_t nW = K * N;
+  const bool grad = g.mode & WD_TAIL_GRAD, upd = g.mode & WD_TAIL_UPDATE, pack = g.mode & WD_TAIL_PACK;
+  if (e >= nW + 3 * N) return;
+  int64_t idx;
+  float gv = 0.f;
+  if (e < nW) {                       // kernel element (k, n)
+    idx = L.w_off + e;
+    if (grad) {
+      const int64_t stride = (L.db_sum ? K : K + 1) * N;
+      float v[16];
+      for (int32_t z0 = 0; z0 < L.nsplit; z0 += 16) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = z0 + u < L.nsplit ? L.Gpart[(z0 + u) * stride + e] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) gv += v[u];
+      }
+    }
+  } else {
+    const int64_t n = (e - nW) % N;
+    const int which = (int)((e - nW) / N);    // 0 bias, 1 gamma, 2 beta
+    if (which == 0) {
+      idx = L.b_off + n;
+      if (grad) {
+        if (L.db_sum) {
+          gv = L.db_sum[n];
+        } else {                       // partials with an appended bias-gradient row (logits layer: one per row tile)
+          const int64_t stride = (K + 1) * N;
+          float v[16];
+          for (int32_t z0 = 0; z0 < L.nsplit; z0 += 16) {
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = z0 + u < L.nsplit ? L.Gpart[(z0 + u) * stride + K * N + n] : 0.f;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) gv += v[u];
+          }
+        }
+      }
+    } else if (which == 1) {
+      if (L.gamma_off < 0) return;
+      idx = L.gamma_off + n;
+      if (grad) gv = L.dgamma_sum[n] * g.inv;
+    } else {
+      if (L.beta_off < 0) return;
+      idx = L.beta_off + n;
+      if (grad) gv = L.dbeta_sum[n];
+    }
+  }
+  float w = g.P[idx];
+  if (grad) g.Gflat[idx] = gv;
+  if (upd) {
+    const float gg = grad ? gv : g.Gflat[idx];      // update without grad: the (all-reduced) gradient buffer
+    const float a = g.Pacc[idx] + gg * gg;
+    g.Pacc[idx] = a;
+    w -= g.lr * gg / sqrtf(a);
+    g.P[idx] = w;
+  }
+  if (pack && e < nW && L.Wpk) {
+    const int64_t k = e / N, n = e - k * N;
+    if (L.pk_tile == 16) {
+      L.Wpk[((n >> 4) * (K >> 4) + (k >> 4)) * 256 + (((k & 3) << 4) + (n & 15)) * 4 + ((k & 15) >> 2)] = w;
+      if (L.WTpk) L.WTpk[((k >> 4) * (N >> 4) + (n >> 4)) * 256 + (((n & 3) << 4) + (k & 15)) * 4 + ((n & 15) >> 2)] = w;
+    } else {
+      L.Wpk[((n >> 5) * (K >> 3) + (k >> 3)) * 256 + (((k & 1) << 5) + (n & 31)) * 4 + ((k & 7) >> 1)] = w;
+      if (L.WTpk) L.WTpk[((k >> 5) * (N >> 3) + (n >> 3)) * 256 + (((n & 1) << 5) + (k & 31)) * 4 + ((n & 7) >> 1)] = w;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int wd_chain_tail(const wd_tail_layer_t *layers, int32_t nlayers, float *P, float *Pacc, float *Gflat, float inv,
+                             float lr, int32_t mode, wd_stream_t stream) {
+  WD_REQUIRE(layers && P && Gflat, "null pointer");
+  WD_REQUIRE(nlayers >= 1 && nlayers <= MAXL + 1, "1 <= nlayers <= WD_CHAIN_MAX_LAYERS + 1");
+  WD_REQUIRE(!(mode & WD_TAIL_UPDATE) || Pacc, "the update needs the Adagrad accumulators");
+  TailArgs g{};
+  int32_t nb = 0;
+  for (int l = 0; l < nlayers; ++l) {
+    g.layer[l] = layers[l];
+    WD_REQUIRE(layers[l].K > 0 && layers[l].N > 0, "layer shape");
+    WD_REQUIRE(!(mode & WD_TAIL_GRAD) || layers[l].Gpart, "gradient mode needs the partials");
+    g.first[l] = nb;
+    nb += (int32_t)wd::ceil_div(layers[l].K * layers[l].N + 3 * layers[l].N, (int64_t)256);
+  }
+  g.first[nlayers] = nb;
+  g.nlayers = nlayers; g.mode = mode; g.P = P; g.Pacc = Pacc; g.Gflat = Gflat; g.inv = inv; g.lr = lr;
+  hipLaunchKernelGGL(k_chain_tail, dim3((unsigned)nb), dim3(256), 0, wd::as_stream(stream), g);
+  return wd::check_launch("wd_chain_tail");
+}
+
+namespace {
 
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 inline bool tile_ok(int rt) { return rt == 16 || rt == 32; }
 
 // LDS layout: [x | dz_{L-1} .. dz_0 aliasing x] [a_0] [a_1] ...     (rows of P = row_tile + 1 floats)
-int64_t chain_layout(int32_t K0, const int32_t *N, int32_t L, int32_t rt, int32_t *a_off, int32_t *dz_off) {
+int64_t chain_layout(int32_t K0, const int32_t *N, int32_t L, int32_t rt, int32_t *a_off, int32_t *dz_off,
+                     int32_t *tab_off = nullptr) {
   if (!tile_ok(rt) || L < 1 || L > MAXL || K0 <= 0 || K0 % rt) return -1;
   const int64_t P = rt + 1;
   int64_t sum_n = 0;
@@ -624,6 +815,10 @@ int64_t chain_layout(int32_t K0, const int32_t *N, int32_t L, int32_t rt, int32_
   for (int l = 0; l < L; ++l) {
     if (a_off) a_off[l] = (int32_t)off;
     off += (int64_t)N[l] * P;
+  }
+  for (int l = 0; l < L; ++l) {       // BN affine tables: s_l[N_l], t_l[N_l]
+    if (tab_off) tab_off[l] = (int32_t)off;
+    off += 2 * (int64_t)N[l];
   }
   const int64_t bytes = off * 4;
   return bytes <= 150 * 1024 ? bytes : -1;
@@ -669,7 +864,7 @@ static int launch_chain(const ChainArgs &g, int64_t bytes, wd_stream_t stream) {
 }
 
 extern "C" int wd_tower_chain(const float *x, int64_t ld_act, int32_t K0, const wd_chain_layer_t *layers, int32_t L,
-                              int32_t act, int32_t bias_parts, const float *w_logits, const float *b_logits,
+                              int32_t act, float inv, const float *w_logits, const float *b_logits,
                               const float *wide_logit, const float *labels, const float *weights, int64_t batch,
                               float *dnn_logit, float *logit, float *prob, float *dlogit, float *loss_sum,
                               float *Gpart_logits, float *dx, int64_t ld_dx, int32_t dx_cols, const wd_chain_opts_t *opts,
@@ -685,15 +880,16 @@ extern "C" int wd_tower_chain(const float *x, int64_t ld_act, int32_t K0, const 
   for (int l = 0; l < L; ++l) {
     g.layer[l] = layers[l];
     N[l] = layers[l].N;
-    WD_REQUIRE(layers[l].Wpk && layers[l].bf && layers[l].a_out, "layer pointers");
+    WD_REQUIRE(layers[l].Wpk && layers[l].a_out, "layer pointers");
+    WD_REQUIRE(!layers[l].gamma == !layers[l].beta, "BN needs both gamma and beta");
     WD_REQUIRE(layers[l].K == (l == 0 ? K0 : layers[l - 1].N), "layer K must equal the previous width");
     if (labels) WD_REQUIRE(layers[l].dz_out && (l == 0 ? (!dx || layers[l].WTpk) : layers[l].WTpk != nullptr), "training needs dz_out / WTpk");
   }
-  const int64_t bytes = chain_layout(K0, N, L, rt, g.a_off, g.dz_off);
+  const int64_t bytes = chain_layout(K0, N, L, rt, g.a_off, g.dz_off, g.tab_off);
   WD_REQUIRE(bytes > 0, "unsupported tower shape (widths must be multiples of the row tile and fit the LDS; see wd_tower_chain_lds_bytes)");
   const int dxc = dx ? round_up(dx_cols, rt) : 0;
   WD_REQUIRE(dxc <= K0, "dx_cols must be <= K0");
-  g.L = L; g.act = act; g.bias_parts = bias_parts > 0 ? bias_parts : 1; g.K0 = K0; g.dx_cols = dxc;
+  g.L = L; g.act = act; g.inv = inv; g.K0 = K0; g.dx_cols = dxc;
   g.train = labels != nullptr;
   g.x = x; g.ld_act = ld_act; g.w_logits = w_logits; g.b_logits = b_logits;
   g.wide_logit = wide_logit; g.labels = labels; g.weights = weights; g.batch = batch;

@@ -421,8 +421,7 @@ class ShardedWideDeepEngine(WideDeepEngine):
         self._grads_to_owners(bt, st)
         tw = self.towers[0]
         self._tower_backward(tw, B, st, need_dx=False, head_done=True)
-        call("wd_mlp_finalize_all", ptr(self.layers_dev), self.n_layers, self.max_layer_k, ptr(self.P), self.inv,
-             ptr(self.G), st)
+        self._chain_tail(capi.WD_TAIL_GRAD, st)      # this rank's dense gradient from the split-K partials -> G
         # D (all-reduce of the flat dense gradient) in the background of the owners' sparse update
         def reduce_async():
             self._work_d = _all_reduce_sum(self.G, self.group, async_op=True)

@@ -255,11 +255,6 @@ class WideDeepEngine:
                     d.Wf, d.bf, d.s, d.t = (tw["Wf"][l].data_ptr(), tw["bf"][l].data_ptr(), tw["s"][l].data_ptr(),
                                             tw["t"][l].data_ptr())
                     d.Gpart, d.nsplit = tw["Gpart"][l].data_ptr(), tw["nsplit"][l]
-                    if self.chain and l < tw["L"]:
-                        d.Wpk, d.WTpk = tw["Wpk"][l].data_ptr(), tw["WTpk"][l].data_ptr()
-                        d.pk_tile = self.chain_rt
-                        if not self._tn_ones:
-                            d.db_sum = tw["db_sum"][l].data_ptr()
                     if self.half:
                         d.cat_off, d.wcat = tw["cat_off"][l].data_ptr(), tw["wcat"].data_ptr()
                         if l < tw["L"]:
@@ -272,17 +267,9 @@ class WideDeepEngine:
             # one launch finalises all layers iff every BN gamma/beta has a single consumer layer
             self.all_simple = len(self.towers) == 1 and self.towers[0]["layout"].mode == "simple"
             self.dnn_logit = torch.zeros(B, **f32)
-            # one-launch tower on one GPU with the reference's Adagrad: finalize + Adagrad + the fold for the next step are
-            # ONE launch (wd_dense_update_fold), the folded bias a single vector
-            self._merged_dense = (self.chain and self.all_simple and self.default_opts and self.max_layer_n <= 512
-                                  and os.environ.get("WD_MERGED_DENSE", "1") == "1")
-            if self._merged_dense:
-                nb = int(call("wd_dense_update_fold_ws_bytes", self.n_layers, self.max_layer_k, self.max_layer_n))
-                self._dense_ws = torch.zeros(nb, dtype=torch.uint8, device=dev)
         else:
             self.P = self.Pa = self.Pacc = self.G = None
             self.dnn_logit = None
-            self._merged_dense = False
 
         # ---- per-step buffers --------------------------------------------------------------
         self.wide_logit = torch.zeros(B, **f32) if spec.has_wide else None
@@ -346,7 +333,6 @@ class WideDeepEngine:
         self.chain = False
         self._chain_tile_stamps = None   # diagnostics: device uint64[2 * tiles] realtime-clock stamps (bench.py: in-step gather span)
         self._chain_stamps = None    # diagnostics: device int64[64] for the tower kernel's stage stamps (scripts/bench_chain.py)
-        self._tn_ones = os.environ.get("WD_TN_ONES", "0") == "1"   # A/B switch: bias gradients via an appended ones row
         plan = self.plan
         if self.half or self.dropout or len(self.towers) != 1 or os.environ.get("WD_CHAIN", "1") == "0":
             return
@@ -357,8 +343,10 @@ class WideDeepEngine:
             return
         dims = [int(metas[l]["N"]) for l in range(L)]
         K0 = int(metas[0]["K"])
-        # row tile: 16 examples per workgroup (two workgroups share a CU) unless WD_CHAIN_RT=32 (one per CU, round-1 kernel)
-        rt = int(os.environ.get("WD_CHAIN_RT", "16"))
+        # row tile: 32 examples per workgroup (one workgroup per CU at batch 8192), or WD_CHAIN_RT=16 (two per CU: same kernel
+        # time alone -- both stream the same 1.2 MB of weights per tile from L2 and are bound there, profiles/r2c_* -- but
+        # slower in the step: 0.200 against 0.187 ms, the second wavefront per SIMD is what the bucketing branch used to get)
+        rt = int(os.environ.get("WD_CHAIN_RT", "32"))
         if rt not in (16, 32):
             raise ValueError("WD_CHAIN_RT must be 16 or 32")
         if int(call("wd_tower_chain_lds_bytes", K0, (ctypes.c_int32 * L)(*dims), L, rt)) <= 0:
@@ -366,28 +354,45 @@ class WideDeepEngine:
         self.chain_rt = rt
         dev, B = self.device, self.max_batch
         f32 = dict(dtype=torch.float32, device=dev)
-        # folded kernels in MFMA-fragment order, forward and transposed (wd_mlp_layer_t.Wpk / WTpk)
+        # the kernels in MFMA-fragment order, forward and transposed (wd_chain_layer_t.Wpk / WTpk: written by wd_chain_tail)
         tw["Wpk"] = [torch.zeros(metas[l]["N"] * metas[l]["K"], **f32) for l in range(L)]
         tw["WTpk"] = [torch.zeros(metas[l]["N"] * metas[l]["K"], **f32) for l in range(L)]
         tw["dzl"] = [torch.zeros(B * metas[l]["N"], **f32) for l in range(L)]
-        # bias gradients: per-row-tile column sums of dz from the tower kernel, reduced by a column-sum job of the grouped
-        # weight-gradient launch -- the products then need no appended ones row (449 = 7 x 64 + 1 rows cost an 8th tile row)
+        # bias / BN gradients: per-row-tile column sums from the tower kernel (dz; d(bn) * a; d(bn)), reduced by column-sum jobs
+        # of the grouped weight-gradient launch -- the products need no appended ones row (449 = 7 x 64 + 1 rows cost an 8th
+        # tile row) and the dense tail no row reductions
         ntile = int(call("wd_tower_chain_blocks", B, rt))
-        tw["db_part"] = [torch.zeros(ntile * metas[l]["N"], **f32) for l in range(L)]
-        tw["db_sum"] = [torch.zeros(metas[l]["N"], **f32) for l in range(L)]
-        # logits-layer gradient partials: one per 32-example row tile
+        for nm in ("db", "dg", "dbeta"):
+            tw[nm + "_part"] = [torch.zeros(ntile * metas[l]["N"], **f32) for l in range(L)]
+            tw[nm + "_sum"] = [torch.zeros(metas[l]["N"], **f32) for l in range(L)]
+        # logits-layer gradient partials: one per row tile
         ns = ntile
         tw["nsplit"][L] = ns
         tw["Gpart"][L] = torch.zeros(ns * (metas[L]["K"] + 1) * metas[L]["N"], **f32)
+        pbase = self.P.data_ptr()
         carr = (capi.WdChainLayer * L)()
-        for l in range(L):
+        tarr = (capi.WdTailLayer * (L + 1))()
+        for l in range(L + 1):
+            m, t = metas[l], tarr[l]
+            t.w_off, t.b_off, t.K, t.N = m["w_off"], m["b_off"], int(m["K"]), int(m["N"])
+            t.gamma_off = m["gamma_off"] if "gamma_off" in m else -1
+            t.beta_off = m["beta_off"] if "beta_off" in m else -1
+            t.Gpart, t.nsplit, t.pk_tile = tw["Gpart"][l].data_ptr(), tw["nsplit"][l], rt
+            if l == L:
+                continue
+            bn = "gamma_off" in m
+            t.db_sum = tw["db_sum"][l].data_ptr()
+            t.dgamma_sum, t.dbeta_sum = (tw["dg_sum"][l].data_ptr(), tw["dbeta_sum"][l].data_ptr()) if bn else (None, None)
+            t.Wpk, t.WTpk = tw["Wpk"][l].data_ptr(), tw["WTpk"][l].data_ptr()
             c = carr[l]
-            c.Wpk, c.WTpk, c.bf = tw["Wpk"][l].data_ptr(), tw["WTpk"][l].data_ptr(), tw["bf"][l].data_ptr()
+            c.Wpk, c.WTpk, c.bias = tw["Wpk"][l].data_ptr(), tw["WTpk"][l].data_ptr(), pbase + 4 * m["b_off"]
+            c.gamma, c.beta = (pbase + 4 * m["gamma_off"], pbase + 4 * m["beta_off"]) if bn else (None, None)
             c.a_out = tw["act"].data_ptr() + 4 * tl.seg_start[l + 1]
             c.dz_out = tw["dzl"][l].data_ptr()
             c.db_part = tw["db_part"][l].data_ptr()
-            c.K, c.N = int(metas[l]["K"]), dims[l]
-        tw["chain_layers"] = carr
+            c.dgamma_part, c.dbeta_part = (tw["dg_part"][l].data_ptr(), tw["dbeta_part"][l].data_ptr()) if bn else (None, None)
+            c.K, c.N = int(m["K"]), dims[l]
+        tw["chain_layers"], tw["tail_layers"] = carr, tarr
         self.loss_part = torch.zeros(ntile, **f32)   # per-row-tile losses, summed in tile order by the grouped launch
         # gradient columns of x that anyone reads: the embedding columns (the sparse backward), rounded up by the kernel
         emb_cols = 0
@@ -401,16 +406,18 @@ class WideDeepEngine:
         """One launch: fold the BN affines of every layer into its consumer's weights (+ the MFMA-fragment-packed copies
         of the one-launch tower); clears the loss accumulator of the per-layer paths (the one-launch tower stores per-tile
         partials instead) and G when the per-layer finalize path accumulates into it."""
-        if self._use_merged_dense():      # the same kernel that updates, without a gradient: fold only
-            call("wd_dense_update_fold", ptr(self.layers_dev), self.n_layers, self.max_layer_k, self.max_layer_n, ptr(self.P),
-                 ptr(self.Pacc), self.inv, ptr(self.G), 0.0, 0, ptr(self._dense_ws), st)
+        if self.chain:      # nothing is folded on the one-launch tower: (re)write the MFMA-packed copies of the kernels
+            self._chain_tail(capi.WD_TAIL_PACK, st)
             return
         zero_g = train and not self.all_simple
         call("wd_fold_affine_all", ptr(self.P), ptr(self.layers_dev), self.n_layers, self.max_layer_n, self.inv,
              None if self.chain else ptr(self.loss), 1, ptr(self.G) if zero_g else None, self.G.numel() if zero_g else 0, st)
 
-    def _use_merged_dense(self):
-        return self._merged_dense and self._fold_at_end()
+    def _chain_tail(self, mode, st):
+        """wd_chain_tail: gradients from the split-K partials / Adagrad / packed kernel copies, any combination."""
+        tw = self.towers[0]
+        call("wd_chain_tail", tw["tail_layers"], tw["L"] + 1, ptr(self.P), ptr(self.Pacc), ptr(self.G), self.inv,
+             float(self.spec.dnn_opt[1]), mode, st)
 
     def _fold_at_end(self):
         """The fold of step t+1 depends on nothing but the dense update of step t: launched right behind it, it runs beside
@@ -466,7 +473,7 @@ class WideDeepEngine:
         opts.row_tile = self.chain_rt
         opts.flags = int(os.environ.get("WD_CHAIN_FLAGS", "0"))
         call("wd_tower_chain", tw["act"].data_ptr() + 4 * tl.in_start[0], tl.ld, int(metas[0]["K"]), tw["chain_layers"], L,
-             self.act_id, 1 if self._use_merged_dense() else capi.WD_FOLD_PARTS, ptr(tw["Wf"][L]), ptr(tw["bf"][L]),
+             self.act_id, self.inv, self.P.data_ptr() + 4 * metas[L]["w_off"], self.P.data_ptr() + 4 * metas[L]["b_off"],
              None if fuse_in else ptr(self.wide_logit),
              ptr(bt.labels) if train else None, ptr(bt.weights) if train else None, B, ptr(tw["logit"]), ptr(self.logit),
              ptr(self.prob), ptr(self.dlogit) if train else None, ptr(self.loss) if train else None,
@@ -695,25 +702,31 @@ class WideDeepEngine:
         tl, metas, L = tw["layout"], tw["metas"], tw["L"]
         act, dact = tw["act"], tw["dact"]
         if self.chain:
-            # forward() already ran the input-gradient chain; what is left are the batch reductions G_l = a_{l-1}^T dz_l
-            # (one grouped launch) and the sums of the per-tile bias-gradient partials (column-sum jobs of the same launch)
-            if 2 * L + 1 <= capi.WD_TN_GROUP_MAX:
-                jobs = (capi.WdTnJob * (2 * L + 1))()
-                nblk = int(call("wd_tower_chain_blocks", B, self.chain_rt))
-                lj = jobs[L if self._tn_ones else 2 * L]     # loss = sum of the per-tile partials, in tile order
-                lj.A, lj.lda, lj.B, lj.Cpart, lj.N, lj.K = self.loss_part.data_ptr(), 1, None, self.loss.data_ptr(), 1, nblk
-                for l in range(L):    # largest product first: its workgroups start while the small ones fill the gaps
-                    m, j = metas[l], jobs[l]
-                    j.A, j.lda = act.data_ptr() + 4 * tl.in_start[l], tl.ld
-                    j.B, j.ldb, j.Cpart = tw["dzl"][l].data_ptr(), m["N"], tw["Gpart"][l].data_ptr()
-                    j.M, j.N, j.K, j.nsplit, j.append_ones = m["K"], m["N"], B, tw["nsplit"][l], int(self._tn_ones)
-                    if not self._tn_ones:
-                        c = jobs[L + l]    # bias gradient: column sums of the tower kernel's per-tile partials
-                        c.A, c.lda, c.B, c.Cpart = tw["db_part"][l].data_ptr(), m["N"], None, tw["db_sum"][l].data_ptr()
-                        c.N, c.K = m["N"], nblk
-                call("wd_gemm_tn_splitk_group", jobs, (L if self._tn_ones else 2 * L) + 1, st)
-                return
-            raise NotImplementedError("one-launch tower with more than %d hidden layers" % (capi.WD_TN_GROUP_MAX // 2))
+            # forward() already ran the input-gradient chain; what is left are the batch reductions G_l = bn_{l-1}^T dz_l
+            # (split-K products) and the sums of the per-tile partials of the bias / BN gradients and of the loss
+            # (column-sum jobs), all in grouped launches of at most WD_TN_GROUP_MAX jobs
+            nblk = int(call("wd_tower_chain_blocks", B, self.chain_rt))
+            spec_jobs = []
+            for l in range(L):    # largest product first: its workgroups start while the small ones fill the gaps
+                m = metas[l]
+                spec_jobs.append(dict(A=act.data_ptr() + 4 * tl.in_start[l], lda=tl.ld, B=tw["dzl"][l].data_ptr(), ldb=m["N"],
+                                      C=tw["Gpart"][l].data_ptr(), M=m["K"], N=m["N"], K=B, nsplit=tw["nsplit"][l]))
+            for l in range(L):
+                m = metas[l]
+                names = ("db", "dg", "dbeta") if "gamma_off" in m else ("db",)
+                for nm in names:
+                    spec_jobs.append(dict(A=tw[nm + "_part"][l].data_ptr(), lda=m["N"], B=None, C=tw[nm + "_sum"][l].data_ptr(),
+                                          N=m["N"], K=nblk))
+            spec_jobs.append(dict(A=self.loss_part.data_ptr(), lda=1, B=None, C=self.loss.data_ptr(), N=1, K=nblk))
+            for i0 in range(0, len(spec_jobs), capi.WD_TN_GROUP_MAX):
+                chunk = spec_jobs[i0: i0 + capi.WD_TN_GROUP_MAX]
+                jobs = (capi.WdTnJob * len(chunk))()
+                for j, d in zip(jobs, chunk):
+                    j.A, j.lda, j.B, j.Cpart, j.N, j.K = d["A"], d["lda"], d["B"], d["C"], d["N"], d["K"]
+                    if d["B"] is not None:
+                        j.ldb, j.M, j.nsplit, j.append_ones = d["ldb"], d["M"], d["nsplit"], 0
+                call("wd_gemm_tn_splitk_group", jobs, len(chunk), st)
+            return
         simple = tl.mode == "simple" and not self.dropout   # dropout: act' is not fused into the GEMM epilogues
         acc = 0 if tl.mode == "simple" else 1               # simple: every segment has ONE consumer -> plain stores
         if not head_done:
@@ -928,10 +941,12 @@ class WideDeepEngine:
                 # single GPU + Adagrad: the dense update rides in the finalize launch (nothing reduces G in between)
                 fused_opt = (self.default_opts and type(self)._reduce_dense_grads is WideDeepEngine._reduce_dense_grads
                              and os.environ.get("WD_FUSE_ADAGRAD", "1") != "0")
-                if fused_opt and self._use_merged_dense():
-                    call("wd_dense_update_fold", ptr(self.layers_dev), self.n_layers, self.max_layer_k, self.max_layer_n,
-                         ptr(self.P), ptr(self.Pacc), self.inv, ptr(self.G), float(spec.dnn_opt[1]), 1, ptr(self._dense_ws), st)
+                if self.chain and fused_opt:
+                    # gradients from the partials + Adagrad + the packed kernels of the next step, one launch
+                    self._chain_tail(capi.WD_TAIL_GRAD | capi.WD_TAIL_UPDATE | capi.WD_TAIL_PACK, st)
                     self._folded = True
+                elif self.chain:
+                    self._chain_tail(capi.WD_TAIL_GRAD, st)
                 elif fused_opt:
                     call("wd_mlp_finalize_adagrad_all", ptr(self.layers_dev), self.n_layers, self.max_layer_k, ptr(self.P),
                          ptr(self.Pacc), self.inv, ptr(self.G), float(spec.dnn_opt[1]), st)
@@ -962,7 +977,7 @@ class WideDeepEngine:
             else:
                 call("wd_opt_dense", ptr(self.P), ptr(self.Pa), ptr(self.Pacc), ptr(self.G), self.P.numel(),
                      ctypes.byref(self.opt_c["dnn"]), st)
-            if self._fold_at_end() and not (fused_opt and self._use_merged_dense()):   # the NEXT step's folded / packed weights
+            if self._fold_at_end() and not (self.chain and fused_opt):   # the NEXT step's packed kernels
                 self._fold(False, st)
                 self._folded = True
 

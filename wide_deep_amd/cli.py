@@ -146,6 +146,8 @@ def train_main(argv=None, out=None):
     if not F.keep_train and int(os.environ.get("RANK", "0")) == 0:
         shutil.rmtree(model_dir, ignore_errors=True)
         print("Remove model directory: {}".format(model_dir), file=out)
+    if world > 1:
+        dist.barrier()      # nobody looks for a checkpoint before rank 0 has removed the old directory
     model = build_custom_estimator(model_dir, F.model_type, conf=conf, max_batch=F.batch_size)
     if world > 1 or conf.distribution.get("is_distribution"):
         steps = schedule_train_only(F)

@@ -28,38 +28,36 @@ k_embag_fwd(const float *__restrict__ emb, const wd_slot_t *__restrict__ slots, 
   if (work >= nwork) return;
   const int64_t b = work / ngroup;
   const int32_t s = group_slots[work - b * ngroup];
-  const wd_slot_t sl = slots[s];
+  // only the two fields needed: a by-value copy of the whole wd_slot_t went through 32 B/lane of scratch memory
+  const int64_t emb_off = slots[s].emb_off;
+  const int32_t out_col = slots[s].out_col;
   const int64_t bag = b * S + s;
   const int32_t j0 = bag_offs[bag], j1 = bag_offs[bag + 1];
-  const float4 *__restrict__ tab = reinterpret_cast<const float4 *>(emb + sl.emb_off);
-  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  const float4 *__restrict__ tab = reinterpret_cast<const float4 *>(emb + emb_off);
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  const f4 *__restrict__ tv = reinterpret_cast<const f4 *>(tab);
+  f4 acc = (f4)(0.f);
   int32_t j = j0;
-  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  // 4 independent row reads in flight per lane group (ids < 0: dropped exchange entries, contribute nothing)
   for (; j + 4 <= j1; j += 4) {
     int32_t i0 = ids[j], i1 = ids[j + 1], i2 = ids[j + 2], i3 = ids[j + 3];
-    float4 r0 = i0 >= 0 ? tab[(int64_t)i0 * RS4 + lane] : zero4;
-    float4 r1 = i1 >= 0 ? tab[(int64_t)i1 * RS4 + lane] : zero4;
-    float4 r2 = i2 >= 0 ? tab[(int64_t)i2 * RS4 + lane] : zero4;
-    float4 r3 = i3 >= 0 ? tab[(int64_t)i3 * RS4 + lane] : zero4;
-    acc.x += r0.x; acc.y += r0.y; acc.z += r0.z; acc.w += r0.w;
-    acc.x += r1.x; acc.y += r1.y; acc.z += r1.z; acc.w += r1.w;
-    acc.x += r2.x; acc.y += r2.y; acc.z += r2.z; acc.w += r2.w;
-    acc.x += r3.x; acc.y += r3.y; acc.z += r3.z; acc.w += r3.w;
+    f4 r0 = i0 >= 0 ? tv[(int64_t)i0 * RS4 + lane] : (f4)(0.f);
+    f4 r1 = i1 >= 0 ? tv[(int64_t)i1 * RS4 + lane] : (f4)(0.f);
+    f4 r2 = i2 >= 0 ? tv[(int64_t)i2 * RS4 + lane] : (f4)(0.f);
+    f4 r3 = i3 >= 0 ? tv[(int64_t)i3 * RS4 + lane] : (f4)(0.f);
+    acc += r0; acc += r1; acc += r2; acc += r3;
   }
   for (; j < j1; ++j) {
     const int32_t i0 = ids[j];
-    float4 r = i0 >= 0 ? tab[(int64_t)i0 * RS4 + lane] : zero4;
-    acc.x += r.x; acc.y += r.y; acc.z += r.z; acc.w += r.w;
+    acc += i0 >= 0 ? tv[(int64_t)i0 * RS4 + lane] : (f4)(0.f);
   }
   const int32_t n = j1 - j0;
   if (n > 1) {  // combiner='mean': sum / count (duplicates counted), SURVEY App. A.6
     const float c = (float)n;
     acc.x /= c; acc.y /= c; acc.z /= c; acc.w /= c;
   }
-  float *o = x + b * ldx + sl.out_col + lane * 4;
+  float *o = x + b * ldx + out_col + lane * 4;
   if ((((uintptr_t)o) & 15) == 0) {
-    *reinterpret_cast<float4 *>(o) = acc;
+    *reinterpret_cast<f4 *>(o) = acc;
   } else {
     o[0] = acc.x; o[1] = acc.y; o[2] = acc.z; o[3] = acc.w;
   }
@@ -70,94 +68,7 @@ k_embag_fwd(const float *__restrict__ emb, const wd_slot_t *__restrict__ slots, 
 // [slot0, slot0 + ngroup)): no group_slots indirection, per-slot metadata staged once per workgroup in LDS while
 // the CSR offsets are already in flight, BPG bags per lane group so that every lane has BPG independent
 // offset -> id -> row chains outstanding.  Dependent global round trips per bag: offsets, ids, row (was 5).
-template <int LANES, int BPG, bool ONEHOT>
-__global__ void __launch_bounds__(256)
-k_embag_fwd_range(const float *__restrict__ emb, const wd_slot_t *__restrict__ slots, int32_t S, int32_t slot0,
-                  int32_t ngroup, const int32_t *__restrict__ ids, const int32_t *__restrict__ bag_offs,
-                  int64_t nwork, float *__restrict__ x, int64_t ldx) {
-  constexpr int MAXG = 128;
-  __shared__ int64_t s_emb_off[MAXG];
-  __shared__ int32_t s_out_col[MAXG];
-  const int t = threadIdx.x;
-  const int lane = t % LANES;
-  const int64_t grp = ((int64_t)blockIdx.x * 256 + t) / LANES;   // lane group index
-  int64_t w[BPG], b[BPG];
-  int32_t g[BPG], j0[BPG], j1[BPG];
-#pragma unroll
-  for (int q = 0; q < BPG; ++q) {
-    w[q] = grp * BPG + q;
-    const int64_t wc = w[q] < nwork ? w[q] : nwork - 1;
-    b[q] = wc / ngroup;
-    g[q] = (int32_t)(wc - b[q] * ngroup);
-    const int64_t bag = b[q] * S + slot0 + g[q];
-    if (ONEHOT) {
-      j0[q] = (int32_t)bag;
-      j1[q] = (int32_t)bag + 1;
-    } else {
-      j0[q] = bag_offs[bag];
-      j1[q] = bag_offs[bag + 1];
-    }
-  }
-  for (int i = t; i < ngroup; i += 256) {
-    const wd_slot_t sl = slots[slot0 + i];
-    s_emb_off[i] = sl.emb_off;
-    s_out_col[i] = sl.out_col;
-  }
-  int32_t id0[BPG];
-#pragma unroll
-  for (int q = 0; q < BPG; ++q) id0[q] = j1[q] > j0[q] ? ids[j0[q]] : 0;
-  __syncthreads();
-  float4 acc[BPG];
-#pragma unroll
-  for (int q = 0; q < BPG; ++q) {
-    const float4 *__restrict__ tab = reinterpret_cast<const float4 *>(emb + s_emb_off[g[q]]);
-    acc[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (j1[q] > j0[q]) {   // rows are touched once per step: nontemporal, do not pollute L2
-      typedef float floatx4 __attribute__((ext_vector_type(4)));
-      const floatx4 r = __builtin_nontemporal_load(reinterpret_cast<const floatx4 *>(&tab[(int64_t)id0[q] * LANES + lane]));
-      acc[q] = make_float4(r.x, r.y, r.z, r.w);
-    }
-  }
-#pragma unroll
-  for (int q = 0; q < BPG; ++q) {
-    const float4 *__restrict__ tab = reinterpret_cast<const float4 *>(emb + s_emb_off[g[q]]);
-    int32_t j = j0[q] + 1;
-    for (; j + 4 <= j1[q]; j += 4) {   // multi-hot tail: 4 independent row reads in flight
-      const int32_t i0 = ids[j], i1 = ids[j + 1], i2 = ids[j + 2], i3 = ids[j + 3];
-      const float4 r0 = tab[(int64_t)i0 * LANES + lane], r1 = tab[(int64_t)i1 * LANES + lane];
-      const float4 r2 = tab[(int64_t)i2 * LANES + lane], r3 = tab[(int64_t)i3 * LANES + lane];
-      acc[q].x += r0.x; acc[q].y += r0.y; acc[q].z += r0.z; acc[q].w += r0.w;
-      acc[q].x += r1.x; acc[q].y += r1.y; acc[q].z += r1.z; acc[q].w += r1.w;
-      acc[q].x += r2.x; acc[q].y += r2.y; acc[q].z += r2.z; acc[q].w += r2.w;
-      acc[q].x += r3.x; acc[q].y += r3.y; acc[q].z += r3.z; acc[q].w += r3.w;
-    }
-    for (; j < j1[q]; ++j) {
-      const float4 r = tab[(int64_t)ids[j] * LANES + lane];
-      acc[q].x += r.x; acc[q].y += r.y; acc[q].z += r.z; acc[q].w += r.w;
-    }
-    const int32_t n = j1[q] - j0[q];
-    if (n > 1) {  // combiner='mean'
-      const float c = (float)n;
-      acc[q].x /= c; acc[q].y /= c; acc[q].z /= c; acc[q].w /= c;
-    }
-    if (w[q] < nwork) {
-      float *o = x + b[q] * ldx + s_out_col[g[q]] + lane * 4;
-      if ((((uintptr_t)o) & 15) == 0) {
-        *reinterpret_cast<float4 *>(o) = acc[q];
-      } else {
-        o[0] = acc[q].x; o[1] = acc[q].y; o[2] = acc[q].z; o[3] = acc[q].w;
-      }
-    }
-  }
-}
-
-// The same gather as a device function for the fused input-layer launch below.  (Kept separate from the kernel
-// above on purpose: routing k_embag_fwd_range through this inlined body produced the same ISA but a kernel that
-// measured 14.4 us instead of 11.8 us on MI355X.)
-// (body) contiguous-slot variant (the engine's layout: the slots of one embedding dim are a contiguous slot range
-// [slot0, slot0 + ngroup)): no group_slots indirection, per-slot metadata staged once per workgroup in LDS while
-// the CSR offsets are already in flight, BPG bags per lane group so that every lane has BPG independent
-// offset -> id -> row chains outstanding.  Dependent global round trips per bag: offsets, ids, row (was 5).
+// One body, two callers: the stand-alone kernel (wd_embag_fwd_range) and the fused input-layer launch below.
 constexpr int MAXG = 128;   // slots per dim group staged in LDS
 
 template <int LANES, int BPG, bool ONEHOT>
@@ -240,6 +151,14 @@ __device__ __forceinline__ void embag_range_body(const float *__restrict__ emb, 
   }
 }
 
+template <int LANES, int BPG, bool ONEHOT>
+__global__ void __launch_bounds__(256)
+k_embag_fwd_range(const float *__restrict__ emb, const wd_slot_t *__restrict__ slots, int32_t S, int32_t slot0,
+                  int32_t ngroup, const int32_t *__restrict__ ids, const int32_t *__restrict__ bag_offs,
+                  int64_t nwork, float *__restrict__ x, int64_t ldx) {
+  embag_range_body<LANES, BPG, ONEHOT>(emb, slots, S, slot0, ngroup, ids, bag_offs, nwork, x, ldx, blockIdx.x);
+}
+
 // dims that are not a multiple of 4 (never produced by the reference's embedding_dim, kept for the
 // opt-in embedding_dim override): one lane per (bag, element).
 __global__ void k_embag_fwd_generic(const float *__restrict__ emb, const wd_slot_t *__restrict__ slots, int32_t S,
@@ -262,19 +181,27 @@ __global__ void k_embag_fwd_generic(const float *__restrict__ emb, const wd_slot
   x[b * ldx + sl.out_col + d] = acc;
 }
 
-__global__ void k_indicator_fwd(const wd_slot_t *__restrict__ slots, int32_t S,
-                                const int32_t *__restrict__ group_slots, int32_t ngroup,
-                                const int32_t *__restrict__ ids, const int32_t *__restrict__ bag_offs, int64_t nwork,
-                                float *__restrict__ x, int64_t ldx) {
-  const int64_t work = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+// indicator_column: multi-hot COUNTS of the bag's ids.  16 lanes per (example, slot): lane c owns the
+// columns c, c + 16, ... and counts the ids equal to each -- no zero-fill pass, no read-modify-write, every column of the
+// slot written exactly once.
+__global__ void __launch_bounds__(256)
+k_indicator_fwd(const wd_slot_t *__restrict__ slots, int32_t S, const int32_t *__restrict__ group_slots, int32_t ngroup,
+                const int32_t *__restrict__ ids, const int32_t *__restrict__ bag_offs, int64_t nwork,
+                float *__restrict__ x, int64_t ldx) {
+  const int64_t work = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+  const int lane = threadIdx.x & 15;
   if (work >= nwork) return;
   const int64_t b = work / ngroup;
   const int32_t s = group_slots[work - b * ngroup];
-  const wd_slot_t sl = slots[s];
-  float *o = x + b * ldx + sl.out_col;
-  for (int32_t c = 0; c < sl.num_buckets; ++c) o[c] = 0.f;
+  const int32_t nb = slots[s].num_buckets, out_col = slots[s].out_col;
+  float *o = x + b * ldx + out_col;
   const int64_t bag = b * S + s;
-  for (int32_t j = bag_offs[bag]; j < bag_offs[bag + 1]; ++j) o[ids[j]] += 1.0f;
+  const int32_t j0 = bag_offs[bag], j1 = bag_offs[bag + 1];
+  for (int32_t c = lane; c < nb; c += 16) {
+    float cnt = 0.f;
+    for (int32_t j = j0; j < j1; ++j) cnt += ids[j] == c ? 1.0f : 0.0f;
+    o[c] = cnt;
+  }
 }
 
 __device__ __forceinline__ void dense_body(const float *__restrict__ dense, int64_t ld_dense,
@@ -463,7 +390,7 @@ extern "C" int wd_indicator_fwd(const wd_slot_t *slots, int32_t S, const int32_t
   if (batch <= 0 || ngroup <= 0) return WD_OK;
   WD_REQUIRE(slots && group_slots && ids && bag_offs && x, "null pointer");
   const int64_t nwork = batch * ngroup;
-  hipLaunchKernelGGL(k_indicator_fwd, dim3((unsigned)wd::ceil_div(nwork, 256)), dim3(256), 0, wd::as_stream(stream),
+  hipLaunchKernelGGL(k_indicator_fwd, dim3((unsigned)wd::ceil_div(nwork * 16, 256)), dim3(256), 0, wd::as_stream(stream),
                      slots, S, group_slots, ngroup, ids, bag_offs, nwork, x, ldx);
   return wd::check_launch("wd_indicator_fwd");
 }

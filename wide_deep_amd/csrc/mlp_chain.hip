@@ -424,12 +424,15 @@ __global__ void __launch_bounds__(256, RT_ == 16 ? 2 : 1) k_tower_chain(ChainArg
     }
     const int lg = t % LG, grp = t / LG, ngrp = 256 / LG;
     const int nwork = RT * NG;
-    for (int w0 = grp; w0 < nwork; w0 += 8 * ngrp) {
-      floatx4v r[8];
-      int col[8], mm[8];
-      bool hit[8];
+    // QB bags per lane group in flight: the whole tile in ONE round at the Criteo shape (RT x 26 bags / 64 lane groups = 13
+    // at RT 32, 7 at RT 16) -- two rounds of 8 were two exposed memory latencies
+    constexpr int QB = RT == 32 ? 16 : 8;
+    for (int w0 = grp; w0 < nwork; w0 += QB * ngrp) {
+      floatx4v r[QB];
+      int col[QB], mm[QB];
+      bool hit[QB];
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
+      for (int q = 0; q < QB; ++q) {
         const int w = w0 + q * ngrp;
         r[q] = floatx4v{0.f, 0.f, 0.f, 0.f};
         col[q] = -1;
@@ -445,7 +448,7 @@ __global__ void __launch_bounds__(256, RT_ == 16 ? 2 : 1) k_tower_chain(ChainArg
         }
       }
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
+      for (int q = 0; q < QB; ++q) {
         if (col[q] < 0) continue;
         const int c0 = col[q], m = mm[q];
         if (hit[q]) {

@@ -42,7 +42,7 @@ def _stream():
 
 class WideDeepEngine:
     def __init__(self, spec: ModelSpec, max_batch=8192, max_nnz=None, device="cuda", seed=0, expected_nnz=None,
-                 tower_dtype="fp32"):
+                 tower_dtype="fp32", table_seed=None):
         if not torch.cuda.is_available():
             raise capi.WdError("WideDeepEngine needs a GPU (MI355X / gfx950); there is no CPU fallback")
         capi.load()
@@ -110,8 +110,15 @@ class WideDeepEngine:
         g = torch.Generator(device=dev)
         g.manual_seed(seed)
         self.gen = g
+        # table_seed (row-sharded ranks): the embedding tables and the dropout stream of THIS rank draw from their own seed
+        # -- with the shared one, local row j would start identical on every rank -- the dense parameters keep `seed`
+        gt = g
+        if table_seed is not None:
+            gt = torch.Generator(device=dev)
+            gt.manual_seed(int(table_seed))
+        dseed = int(seed if table_seed is None else table_seed)
         # dropout: device {seed, step}; the keep mask is a function of it (include/wd_hip.h), never stored
-        self.drop_seed = torch.tensor([int(seed) * 0x9E3779B1 + 12345, 0], dtype=torch.int64, device=dev) if self.dropout else None
+        self.drop_seed = torch.tensor([dseed * 0x9E3779B1 + 12345, 0], dtype=torch.int64, device=dev) if self.dropout else None
         dnn_a, dnn_b = opt_slot_init(spec.dnn_opt) if spec.has_deep else (None, None)
         lin_a, lin_b = opt_slot_init(spec.lin_opt) if spec.has_wide else (None, None)
         if spec.has_deep:
@@ -124,7 +131,7 @@ class WideDeepEngine:
                     v = self.emb[plan.emb_off[i]: plan.emb_off[i] + s.num_buckets * s.dim]
                     std = 1.0 / math.sqrt(s.dim)
                     # embedding_column initializer: truncated_normal(0, 1/sqrt(dim))  
-                    torch.nn.init.trunc_normal_(v, mean=0.0, std=std, a=-2 * std, b=2 * std, generator=g)
+                    torch.nn.init.trunc_normal_(v, mean=0.0, std=std, a=-2 * std, b=2 * std, generator=gt)
         else:
             self.emb = self.emb_a = self.emb_acc = None
         if spec.has_wide:

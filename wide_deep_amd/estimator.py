@@ -52,6 +52,14 @@ class WideAndDeepClassifier(object):
                 # one process per GPU (python -m torch.distributed.run ... train.py): tables row-sharded, dense gradients
                 # all-reduced -- N ranks train ONE model on the union of their batches (wide_deep_amd/dist.py)
                 from .dist import ShardedWideDeepEngine
+                # per-peer exchange segments sized from what a batch really holds (first batch + 50 % slack inside the
+                # engine), not from the max_nnz buffer bound: the all-to-alls always move FULL segments.  A later, much
+                # larger batch trips the overflow flag, which train / evaluate / predict check (check_overflow)
+                nnz0 = int(getattr(first_batch, "nnz", 0) or 0)
+                if nnz0 == 0 and hasattr(first_batch, "B"):
+                    nnz0 = self._featurizer_nnz_estimate(first_batch)
+                if nnz0:
+                    kw["expected_nnz"] = min(int(nnz0 * 1.25) + 1024, kw["max_nnz"])
                 self._engine = ShardedWideDeepEngine(self.spec, **kw)
             else:
                 self._engine = WideDeepEngine(self.spec, **kw)
@@ -62,6 +70,33 @@ class WideAndDeepClassifier(object):
     @property
     def engine(self):
         return self._engine
+
+    def _featurizer_nnz_estimate(self, raw):
+        """occurrences of a raw (host) batch before a featurizer exists: bags x a generous mean length (multi-valued features
+        and their crosses; the reference data has 1.0-3.5 values per feature).  Too small -> check_overflow raises."""
+        return int(getattr(raw, "B", 0)) * max(len(self.spec.slots), 1) * 4
+
+    _CHECK_EVERY = 64     # steps between the periodic multi-rank checks (one device->host read / one broadcast each)
+
+    def _check_overflow(self):
+        """Row-sharded engine: a peer segment that overflowed dropped occurrences (include/wd_hip.h) -- never silently."""
+        if self._engine is not None and hasattr(self._engine, "check_overflow"):
+            self._engine.check_overflow()
+
+    def _save_due(self, n, t_save, save_secs):
+        """Timed checkpoints.  One process: the local clock.  Several ranks: saving is a collective, so rank 0's clock
+        decides for everybody, every _CHECK_EVERY steps (a rank-local decision would desynchronise the collectives)."""
+        if not save_secs:
+            return False
+        if self._world() == 1:
+            return time.time() - t_save >= save_secs
+        if n % self._CHECK_EVERY:
+            return False
+        import torch.distributed as td
+        dev = self._engine.device if td.get_backend() == "nccl" else "cpu"
+        flag = torch.tensor([1 if (self._rank() == 0 and time.time() - t_save >= save_secs) else 0], dtype=torch.int32, device=dev)
+        td.broadcast(flag, src=0)
+        return bool(int(flag.item()))
 
     def _device_batch(self, b):
         if isinstance(b, DeviceBatch):
@@ -150,7 +185,10 @@ class WideAndDeepClassifier(object):
                 dt = time.time() - t0
                 print("INFO: step %d (global_step %d): loss = %.6f, %.1f examples/sec" % (
                     n, self._engine.global_step, float(loss), seen / max(dt, 1e-9)))
-            if save_secs and time.time() - t_save >= save_secs:
+            if n % self._CHECK_EVERY == 0:
+                self._check_overflow()
+            if self._save_due(n, t_save, save_secs):
+                self._check_overflow()
                 self.save_checkpoint()
                 t_save = time.time()
             if steps is not None and n >= steps:
@@ -159,6 +197,7 @@ class WideAndDeepClassifier(object):
                 break
         if n:
             torch.cuda.synchronize()
+            self._check_overflow()
             self.last_train = {"steps": n, "examples": seen, "seconds": time.time() - t0,
                                "loss": float(loss) if loss is not None else None}
             self.save_checkpoint()
@@ -183,6 +222,8 @@ class WideAndDeepClassifier(object):
             n += 1
             if steps is not None and n >= steps:
                 break
+        if n:
+            self._check_overflow()
         cat = lambda xs: torch.cat(xs) if xs else torch.zeros(0)
         return cat(probs), cat(logits), cat(labels), cat(weights)
 

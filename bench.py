@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--steps-per-graph", type=int, default=32,
                     help="train steps captured into one hipGraph (single GPU; each step on its own resident batch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc child passes (roofline traffic = null)")
     ap.add_argument("--no-parity", action="store_true", help="skip the oracle check of batch 0 before the timed region")
     ap.add_argument("--force-sharded", action="store_true",
                     help="diagnostics: run the row-sharded engine even with one rank (one-rank RCCL group)")
@@ -82,14 +83,55 @@ def event_time_ms(fn, iters):
     return e0.elapsed_time(e1) / iters
 
 
-def gather_roofline(eng, batches, iters=200):
-    """Embedding-gather kernel: algorithmic bytes / measured duration (HIP events on the launch stream).
+def gather_alg_bytes(plan, bt, dim, nslots):
+    """SURVEY 8(d) contract: nnz*D*4 (row reads) + nnz*4 (ids) + (B*S+1)*4 (offsets) + B*S*D*4 (pooled write)."""
+    return bt.nnz * dim * 4 + bt.nnz * 4 + (bt.B * plan.S + 1) * 4 + bt.B * nslots * dim * 4
 
-    `traffic` = HBM bytes per launch from the rocprofv3 PMC passes of scripts/gpu_gather.sh (separate FETCH_SIZE and
-    WRITE_SIZE runs of the same kernel on the same workload, committed under profiles/): FETCH_SIZE is kept RAW for
-    the 64-byte row requests (it matches the algorithmic read bytes; the gfx950 x2 correction of the guide applies to
-    128-byte streaming requests, which the calibration copy in the same run confirms) -- see profiles/README.md.
-    `ceilings` are measured on the same part (scripts/bench_ceilings.py): float4 copy and random 64-byte row reads."""
+
+def pmc_traffic(args, bt, plan):
+    """HBM traffic of the stand-alone gather kernel, measured BY THIS RUN: two child passes of the same kernel on the same
+    workload under `rocprofv3 --kernel-trace --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes, as the microarch guide
+    prescribes; counter CSVs parsed here, nothing read from a committed file).  The 256 MiB copy in the same pass calibrates
+    the counters: on gfx950 FETCH_SIZE tallies a 128-byte streaming request at 64 bytes (the copy reads back 1/2), the 64-byte
+    row requests count in full -> traffic = FETCH + WRITE + half of the streamed id / offset bytes.  None on any failure."""
+    import csv, glob, shutil, subprocess, tempfile
+    if shutil.which("rocprofv3") is None:
+        return None, "rocprofv3 not on PATH"
+    env = dict(os.environ, GATHER_ITERS="20", GATHER_POOL="8", GATHER_CONFIG=args.config, GATHER_BATCH=str(args.batch),
+               GATHER_DIST=args.dist, TMPDIR="/tmp")
+    raw, calib = {}, {}
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="wd_pmc_", dir="/tmp")
+        try:
+            subprocess.run(["rocprofv3", "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "pmc", "--",
+                            sys.executable, os.path.join(ROOT, "scripts", "bench_gather.py")], env=env, cwd="/tmp",
+                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240, check=True)
+            f = glob.glob(d + "/**/*counter_collection.csv", recursive=True)
+            g, c = [], []
+            for r in csv.DictReader(open(f[0])):
+                if r["Counter_Name"] != ctr:
+                    continue
+                if "k_embag_fwd" in r["Kernel_Name"]:
+                    g.append(float(r["Counter_Value"]))
+                elif "copy" in r["Kernel_Name"].lower():
+                    c.append(float(r["Counter_Value"]))
+            raw[ctr] = sum(g[-20:]) / len(g[-20:]) * 1024.0        # KiB per launch -> bytes
+            calib[ctr] = max(c) * 1024.0 / float(1 << 28) if c else None    # reported / known bytes of the 256 MiB copy
+        except Exception as e:
+            return None, "PMC pass %s failed: %s" % (ctr, str(e)[:120])
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    streamed = bt.nnz * 4 + (bt.B * plan.S + 1) * 4
+    traffic = int(raw["FETCH_SIZE"] + raw["WRITE_SIZE"] + 0.5 * streamed)
+    return traffic, ("measured by this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE child passes of the kernel; raw "
+                     "%d + %d B per launch, + half of the %d streamed id/offset bytes (calibration copy of 256 MiB in the "
+                     "same passes reads back x%.3f / writes x%.3f)" % (int(raw["FETCH_SIZE"]), int(raw["WRITE_SIZE"]), streamed,
+                                                                      calib["FETCH_SIZE"] or -1, calib["WRITE_SIZE"] or -1))
+
+
+def gather_kernel_roofline(eng, batches, args, iters=200):
+    """The embedding-gather kernel of the C ABI as its own launch (wd_embag_fwd_range) on the resident batches: algorithmic
+    bytes / mean launch duration (HIP events on the launch stream, the pool cycled so ids are never cache-warm)."""
     plan = eng.plan
     tw0 = eng.towers[0]
     ld = tw0["layout"].ld
@@ -105,33 +147,78 @@ def gather_roofline(eng, batches, iters=200):
     torch.cuda.synchronize()
     ms = event_time_ms(run, iters)
     bt = batches[0]
-    nbag = bt.B * gs.numel()
-    # nnz*D*4 (row reads) + nnz*4 (ids) + (B*S+1)*4 (offsets) + B*S*D*4 (pooled write)
-    alg = bt.nnz * dim * 4 + bt.nnz * 4 + (bt.B * plan.S + 1) * 4 + nbag * dim * 4
+    alg = gather_alg_bytes(plan, bt, dim, gs.numel())
     gbs = alg / (ms * 1e-3) / 1e9
-    traffic, src = None, None
-    pmc = os.path.join(ROOT, "profiles", "gather_pmc_summary.json")
-    if os.path.exists(pmc):
-        try:
-            d = json.load(open(pmc))
-            raw = (d["FETCH_SIZE"]["gather"]["mean"] + d["WRITE_SIZE"]["gather"]["mean"]) * 1024
-            # gfx950 correction (MI355X_MICROARCH.md, HBM): 128-byte streaming read requests are tallied at 64 B ->
-            # the id / offset streams count half; the 64-byte row requests count in full (calibrated: raw FETCH_SIZE
-            # = rows + half of the streams to 1.4 %, and the 256 MiB copy in the same pass reads back exactly 1/2)
-            traffic = int(raw + 0.5 * (bt.nnz * 4 + (bt.B * plan.S + 1) * 4))
-            src = ("profiles/gather_pmc_summary.json: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes, KiB per "
-                   "launch; raw sum %d B + half of the streamed id/offset bytes" % int(raw))
-        except Exception:
-            traffic = None
+    traffic, src = (None, "skipped (--no-pmc)") if args.no_pmc else pmc_traffic(args, bt, plan)
     return {"bound": "hbm", "kernel": "k_embag_fwd_range<%d, 2, %s>" % (dim // 4, "true" if bt.one_hot else "false"),
-            "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": src,
-            "algorithmic_bytes_per_launch": int(alg), "avg_launch_us": round(ms * 1e3, 2),
-            "note": "the embedding-gather kernel of the C ABI (wd_embag_fwd) timed as its own launch on the resident "
-                    "batches; inside the step one-id-per-bag batches take the same rows through the gather phase of "
-                    "k_tower_chain (roofline_tower), multi-hot batches through this kernel",
-            "ceilings_GBps": {"float4_copy": 5386, "random_64B_rows_16M": 3459, "random_64B_rows_at_batch_size": 2076,
-                              "source": "profiles/r1i_ceilings.txt"}}
+            "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+            "traffic": traffic, "traffic_source": src, "algorithmic_bytes_per_launch": int(alg),
+            "avg_launch_us": round(ms * 1e3, 2),
+            "note": "wd_embag_fwd_range timed as its own launch; one-id-per-bag batches take the same rows through the gather "
+                    "phase of k_tower_chain inside the step (`roofline`), multi-hot batches through k_input_layer"}
+
+
+def gather_instep_roofline(eng, dev_batches, step_eager, steps=16):
+    """The gather AS IT RUNS IN THE STEP.  One-id-per-bag batches (C2 / C3): the input layer is the first phase of
+    k_tower_chain; every workgroup stores the chip-wide realtime clock (100 MHz) at its start and when its x tile is complete
+    (wd_chain_opts_t.tile_stamps), and the phase's duration is  max(tile complete) - min(start)  over all workgroups of a
+    launch, averaged over `steps` full train steps on different resident batches.  Other batches: k_input_layer (its own
+    launch in the step) timed with HIP events.  achieved = algorithmic gather bytes / that duration."""
+    plan = eng.plan
+    bt0 = dev_batches[0].batch
+    (dim, gs), = list(eng.group_slots.items())[:1]
+    alg = gather_alg_bytes(plan, bt0, dim, gs.numel())
+    side = torch.cuda.Stream()
+    if getattr(eng, "chain", False) and eng._chain_input_ok(bt0):
+        # the steps run exactly as in the timed region: a (pipelined) hipGraph of 4 train steps on 4 resident batches, captured
+        # with the stamp buffer attached; after each replay the buffer holds the stamps of the graph's LAST step
+        from wide_deep_amd import pipeline
+        nt = (bt0.B + eng.chain_rt - 1) // eng.chain_rt
+        ts = torch.zeros(2 * nt, dtype=torch.int64, device="cuda")
+        eng._chain_tile_stamps = ts.data_ptr()
+        spans, spreads = [], []
+        try:
+            nb = len(dev_batches)
+            graphs = [pipeline.StepGraph(eng, [dev_batches[(j + i) % nb] for i in range(4)], stream=side)
+                      for j in range(0, min(nb, 16), 4)]
+            for i in range(steps + 2):
+                graphs[i % len(graphs)].replay()
+                torch.cuda.synchronize()
+                v = ts.cpu().view(nt, 2)
+                if i >= 2:
+                    spans.append(float(v[:, 1].max() - v[:, 0].min()) / 100.0)       # us
+                    spreads.append(float(v[:, 0].max() - v[:, 0].min()) / 100.0)
+            del graphs
+        finally:
+            eng._chain_tile_stamps = None
+        us = sum(spans) / len(spans)
+        kernel = "k_tower_chain<%d> (input-layer phase)" % eng.chain_rt
+        how = ("realtime-clock stamps of all %d workgroups, first start -> last x tile complete, in the last step of a 4-step "
+               "hipGraph replay (as timed), mean of %d replays; the workgroups' start skew of %.2f us is included"
+               % (nt, len(spans), sum(spreads) / len(spreads)))
+    else:
+        st = side.cuda_stream
+        with torch.cuda.stream(side):
+            bts = [synth_hash(eng, tb) for tb in dev_batches]
+            for i in range(5):
+                eng._sparse_forward(bts[i % len(bts)], st)
+            side.synchronize()
+            us = event_time_ms(lambda i: eng._sparse_forward(bts[i % len(bts)], st), 100) * 1e3
+        kernel = "k_input_layer<%d, 2, %s>" % (dim // 4, "true" if bt0.one_hot else "false")
+        how = "HIP events around the launch (its own launch in the step), 100 launches over the resident pool"
+    gbs = alg / us / 1e3
+    return {"bound": "hbm", "kernel": kernel, "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
+            "traffic_source": "no per-phase counter exists; the PMC traffic of the same rows through the stand-alone kernel is in "
+                              "roofline_gather_kernel",
+            "algorithmic_bytes_per_launch": int(alg), "avg_launch_us": round(us, 2), "measured": how,
+            "note": "algorithmic bytes = SURVEY 8(d) gather contract only; the phase also reads one 16-byte wide {w,z,n} line per "
+                    "occurrence and the numeric columns and writes the wide logit (not counted)"}
+
+
+def synth_hash(eng, tb):
+    from wide_deep_amd import synth
+    return synth.hash_tokens(eng, tb)
 
 
 MFMA_F32_PEAK_TFLOPS = 157.3     # v_mfma_f32_32x32x2_f32, dense (MI355X_MICROARCH.md)
@@ -145,7 +232,8 @@ def tower_roofline(eng, bt, iters=100):
     tw = eng.towers[0]
     st = torch.cuda.current_stream().cuda_stream
     B = bt.B
-    run = lambda i: eng._tower_chain(tw, bt, B, st, True)
+    fuse = eng._chain_input_ok(bt)        # as launched in the step: the input layer is the kernel's first phase
+    run = lambda i: eng._tower_chain(tw, bt, B, st, True, fuse)
     for i in range(5):
         run(i)
     torch.cuda.synchronize()
@@ -159,7 +247,9 @@ def tower_roofline(eng, bt, iters=100):
     return {"bound": "mfma", "kernel": "k_tower_chain", "achieved": round(tf, 1), "peak": MFMA_F32_PEAK_TFLOPS,
             "unit": "TFLOP/s", "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4), "algorithmic_flops_per_launch": int(fl),
             "avg_launch_us": round(ms * 1e3, 2),
-            "note": "forward of all hidden layers + logits + head + input-gradient chain down to dx; exact fp32 MFMA"}
+            "note": "the kernel as launched in the step (%s): forward of all hidden layers + logits + head + "
+                    "input-gradient chain down to dx; exact fp32 MFMA; flops of the products only"
+                    % ("input layer fused: gather phase included in the duration" if fuse else "x from HBM")}
 
 
 def cpu_baseline(eng, host_batches, steps, B):
@@ -429,7 +519,11 @@ def main():
             for tb in dev_batches:
                 synth.hash_tokens(eng, tb)
             torch.cuda.synchronize()
-            out["roofline"] = gather_roofline(eng, [tb.batch for tb in dev_batches])
+            if not sharded and eng.spec.has_deep and eng.group_slots:
+                out["roofline"] = gather_instep_roofline(eng, dev_batches, step_eager)
+            out["roofline_gather_kernel"] = gather_kernel_roofline(eng, [tb.batch for tb in dev_batches], args)
+            if "roofline" not in out:
+                out["roofline"] = out["roofline_gather_kernel"]
             if not sharded:
                 out["roofline_tower"] = tower_roofline(eng, dev_batches[0].batch)
             if not args.no_cpu_baseline:

@@ -9,15 +9,16 @@ import torch
 from wide_deep_amd import synth
 from wide_deep_amd.engine import WideDeepEngine
 from wide_deep_amd.plan import criteo_spec
+import bench as _bench
 
-B = 8192
+B = int(os.environ.get("GATHER_BATCH", "8192"))
 iters = int(os.environ.get("GATHER_ITERS", "200"))
 pool = int(os.environ.get("GATHER_POOL", "16"))
 dist = os.environ.get("GATHER_DIST", "uniform")
-spec = criteo_spec(n_dense=13, n_sparse=26, buckets=1_000_000, dim=16, hidden=(256, 128, 64))
-eng = WideDeepEngine(spec, max_batch=B)
+spec, mean_len = _bench.make_spec(os.environ.get("GATHER_CONFIG", "c2"))
+eng = WideDeepEngine(spec, max_batch=B, max_nnz=B * 26 * (2 * mean_len + 2))
 plan = eng.plan
-bts = [synth.to_device_ids(plan, synth.make_raw_batch(plan, B, seed=20260925 + i, dist=dist)) for i in range(pool)]
+bts = [synth.to_device_ids(plan, synth.make_raw_batch(plan, B, seed=20260925 + i, dist=dist, mean_len=mean_len)) for i in range(pool)]
 tw0 = eng.towers[0]
 ld = tw0["layout"].ld
 xp = tw0["act"].data_ptr() + 4 * tw0["layout"].seg_start[0]

@@ -68,7 +68,90 @@ k_embag_fwd(const float *__restrict__ emb, const wd_slot_t *__restrict__ slots, 
 // [slot0, slot0 + ngroup)): no group_slots indirection, per-slot metadata staged once per workgroup in LDS while
 // the CSR offsets are already in flight, BPG bags per lane group so that every lane has BPG independent
 // offset -> id -> row chains outstanding.  Dependent global round trips per bag: offsets, ids, row (was 5).
-// One body, two callers: the stand-alone kernel (wd_embag_fwd_range) and the fused input-layer launch below.
+template <int LANES, int BPG, bool ONEHOT>
+__global__ void __launch_bounds__(256)
+k_embag_fwd_range(const float *__restrict__ emb, const wd_slot_t *__restrict__ slots, int32_t S, int32_t slot0,
+                  int32_t ngroup, const int32_t *__restrict__ ids, const int32_t *__restrict__ bag_offs,
+                  int64_t nwork, float *__restrict__ x, int64_t ldx) {
+  constexpr int MAXG = 128;
+  __shared__ int64_t s_emb_off[MAXG];
+  __shared__ int32_t s_out_col[MAXG];
+  const int t = threadIdx.x;
+  const int lane = t % LANES;
+  const int64_t grp = ((int64_t)blockIdx.x * 256 + t) / LANES;   // lane group index
+  int64_t w[BPG], b[BPG];
+  int32_t g[BPG], j0[BPG], j1[BPG];
+#pragma unroll
+  for (int q = 0; q < BPG; ++q) {
+    w[q] = grp * BPG + q;
+    const int64_t wc = w[q] < nwork ? w[q] : nwork - 1;
+    b[q] = wc / ngroup;
+    g[q] = (int32_t)(wc - b[q] * ngroup);
+    const int64_t bag = b[q] * S + slot0 + g[q];
+    if (ONEHOT) {
+      j0[q] = (int32_t)bag;
+      j1[q] = (int32_t)bag + 1;
+    } else {
+      j0[q] = bag_offs[bag];
+      j1[q] = bag_offs[bag + 1];
+    }
+  }
+  for (int i = t; i < ngroup; i += 256) {
+    const wd_slot_t sl = slots[slot0 + i];
+    s_emb_off[i] = sl.emb_off;
+    s_out_col[i] = sl.out_col;
+  }
+  int32_t id0[BPG];
+#pragma unroll
+  for (int q = 0; q < BPG; ++q) id0[q] = j1[q] > j0[q] ? ids[j0[q]] : 0;
+  __syncthreads();
+  float4 acc[BPG];
+#pragma unroll
+  for (int q = 0; q < BPG; ++q) {
+    const float4 *__restrict__ tab = reinterpret_cast<const float4 *>(emb + s_emb_off[g[q]]);
+    acc[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (j1[q] > j0[q]) {   // rows are touched once per step: nontemporal, do not pollute L2
+      typedef float floatx4 __attribute__((ext_vector_type(4)));
+      const floatx4 r = __builtin_nontemporal_load(reinterpret_cast<const floatx4 *>(&tab[(int64_t)id0[q] * LANES + lane]));
+      acc[q] = make_float4(r.x, r.y, r.z, r.w);
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < BPG; ++q) {
+    const float4 *__restrict__ tab = reinterpret_cast<const float4 *>(emb + s_emb_off[g[q]]);
+    int32_t j = j0[q] + 1;
+    for (; j + 4 <= j1[q]; j += 4) {   // multi-hot tail: 4 independent row reads in flight
+      const int32_t i0 = ids[j], i1 = ids[j + 1], i2 = ids[j + 2], i3 = ids[j + 3];
+      const float4 r0 = tab[(int64_t)i0 * LANES + lane], r1 = tab[(int64_t)i1 * LANES + lane];
+      const float4 r2 = tab[(int64_t)i2 * LANES + lane], r3 = tab[(int64_t)i3 * LANES + lane];
+      acc[q].x += r0.x; acc[q].y += r0.y; acc[q].z += r0.z; acc[q].w += r0.w;
+      acc[q].x += r1.x; acc[q].y += r1.y; acc[q].z += r1.z; acc[q].w += r1.w;
+      acc[q].x += r2.x; acc[q].y += r2.y; acc[q].z += r2.z; acc[q].w += r2.w;
+      acc[q].x += r3.x; acc[q].y += r3.y; acc[q].z += r3.z; acc[q].w += r3.w;
+    }
+    for (; j < j1[q]; ++j) {
+      const float4 r = tab[(int64_t)ids[j] * LANES + lane];
+      acc[q].x += r.x; acc[q].y += r.y; acc[q].z += r.z; acc[q].w += r.w;
+    }
+    const int32_t n = j1[q] - j0[q];
+    if (n > 1) {  // combiner='mean'
+      const float c = (float)n;
+      acc[q].x /= c; acc[q].y /= c; acc[q].z /= c; acc[q].w /= c;
+    }
+    if (w[q] < nwork) {
+      float *o = x + b[q] * ldx + s_out_col[g[q]] + lane * 4;
+      if ((((uintptr_t)o) & 15) == 0) {
+        *reinterpret_cast<float4 *>(o) = acc[q];
+      } else {
+        o[0] = acc[q].x; o[1] = acc[q].y; o[2] = acc[q].z; o[3] = acc[q].w;
+      }
+    }
+  }
+}
+
+// The same gather as a device function for the fused input-layer launch below.  Deliberately NOT shared with the kernel
+// above: routing k_embag_fwd_range through this inlined body gives the same instruction mix but a kernel that measures
+// 14.4 us instead of 11.7 us on MI355X (re-measured in round 2, profiles/r2n_*: code placement, MI355X_MICROARCH.md item 8).
 constexpr int MAXG = 128;   // slots per dim group staged in LDS
 
 template <int LANES, int BPG, bool ONEHOT>
@@ -149,14 +232,6 @@ __device__ __forceinline__ void embag_range_body(const float *__restrict__ emb, 
       }
     }
   }
-}
-
-template <int LANES, int BPG, bool ONEHOT>
-__global__ void __launch_bounds__(256)
-k_embag_fwd_range(const float *__restrict__ emb, const wd_slot_t *__restrict__ slots, int32_t S, int32_t slot0,
-                  int32_t ngroup, const int32_t *__restrict__ ids, const int32_t *__restrict__ bag_offs,
-                  int64_t nwork, float *__restrict__ x, int64_t ldx) {
-  embag_range_body<LANES, BPG, ONEHOT>(emb, slots, S, slot0, ngroup, ids, bag_offs, nwork, x, ldx, blockIdx.x);
 }
 
 // dims that are not a multiple of 4 (never produced by the reference's embedding_dim, kept for the

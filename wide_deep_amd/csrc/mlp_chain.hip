@@ -374,6 +374,7 @@ __global__ void __launch_bounds__(256, RT_ == 16 ? 2 : 1) k_tower_chain(ChainArg
   }
 
   float *s_wide = red;   // [RT] wide logit of the tile's examples (gather mode); `red` is free until the head
+  float wv[4] = {0.f, 0.f, 0.f, 0.f};   // gather mode: this lane's wide weights, in flight from the tile gather to the head
   if (g.in.emb) {
     // ---- input layer of the tile, fused (python/lib/dnn.py:88-90 input_layer + python/lib/linear.py:29-36 linear_model
     // for one-id-per-bag batches): x[m, out_col_s ..] = E_s[id(m, s)], numeric columns, wide logit.  RT x 26 random 64-byte
@@ -382,7 +383,6 @@ __global__ void __launch_bounds__(256, RT_ == 16 ? 2 : 1) k_tower_chain(ChainArg
     const int S = uni(I.S), NG = uni(I.ngroup), D = uni(I.dim), LG = D >> 2;
     const int RS_ = uni(I.row_stride > 0 ? I.row_stride : I.dim);   // floats between rows (exchange buffers: dim + 4)
     int32_t *s_id = reinterpret_cast<int32_t *>(lds + g.a_off[0]);   // a_0's region is dead until layer 0 writes it
-    float *s_w = lds + g.a_off[0] + RT * S;                          // wide weight per (example, slot)
     for (int i = t; i < S; i += 256) {                               // slot descriptors -> LDS (48-byte structs in HBM)
       const wd_slot_t sl = I.slots[i];
       s_eoff[i] = sl.emb_off;
@@ -393,41 +393,22 @@ __global__ void __launch_bounds__(256, RT_ == 16 ? 2 : 1) k_tower_chain(ChainArg
     for (int i = t; i < nbag; i += 256) {
       const int m = i / S;
       s_id[i] = b0 + m < g.batch ? I.ids[b0 * S + i] : -1;
-      s_w[i] = 0.f;
     }
     for (int i = t; i < (int)g.K0 * P; i += 256) regx[i] = 0.f;     // pad columns and dropped ids read as zero
     __syncthreads();
-    // Everything the tile needs from HBM is requested before anything is waited for: the wide weights (one 16-byte line per
-    // occurrence, the weight is its first float) and the numeric columns first, then the embedding rows (LG lanes per
-    // (example, slot), 8 bags per lane group per round) -- one exposed memory latency instead of three.
+    // Request order = the order things are needed in: the embedding rows and the numeric columns (the x tile: needed by the
+    // first product), THEN the wide weights (one 16-byte line per occurrence, needed by the head three products later).  The
+    // x tile is complete as soon as the rows have landed; the wide lines -- as many random requests again -- stay in flight
+    // into the first product (registers wv, written to LDS just before the head), so the tile does not wait for them.
     constexpr int WV = 4, DV = 2;
-    float wv[WV], dv[DV];
-    if (I.wide) {
-#pragma unroll
-      for (int u = 0; u < WV; ++u) {
-        const int i = t + 256 * u;
-        wv[u] = 0.f;
-        if (i < nbag) {
-          const int64_t rb = s_rbase[i % S];
-          const int id = s_id[i];
-          if (rb >= 0 && id >= 0)
-            wv[u] = I.wide_in_row ? I.wide[s_eoff[i % S] + (int64_t)id * RS_ + D]     // weight travels behind its row
-                                  : __builtin_nontemporal_load(I.wide + (rb + id) * 4);
-        }
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < DV; ++u) {
-      const int i = t + 256 * u;
-      dv[u] = 0.f;
-      if (i < RT * I.ncols && b0 + i % RT < g.batch) dv[u] = I.dense[(b0 + i % RT) * I.ld_dense + i / RT];
-    }
+    float dv[DV];
     const int lg = t % LG, grp = t / LG, ngrp = 256 / LG;
     const int nwork = RT * NG;
     // QB bags per lane group in flight: the whole tile in ONE round at the Criteo shape (RT x 26 bags / 64 lane groups = 13
-    // at RT 32, 7 at RT 16) -- two rounds of 8 were two exposed memory latencies
+    // at RT 32, 7 at RT 16)
     constexpr int QB = RT == 32 ? 16 : 8;
-    for (int w0 = grp; w0 < nwork; w0 += QB * ngrp) {
+    bool first_round = true;
+    for (int w0 = grp; w0 < nwork || first_round; w0 += QB * ngrp) {
       floatx4v r[QB];
       int col[QB], mm[QB];
       bool hit[QB];
@@ -447,6 +428,29 @@ __global__ void __launch_bounds__(256, RT_ == 16 ? 2 : 1) k_tower_chain(ChainArg
           if (id >= 0) r[q] = __builtin_nontemporal_load(reinterpret_cast<const floatx4v *>(I.emb + s_eoff[sidx] + (int64_t)id * RS_) + lg);
         }
       }
+      if (first_round) {      // behind the first round of rows: numeric columns, then the wide lines
+        first_round = false;
+#pragma unroll
+        for (int u = 0; u < DV; ++u) {
+          const int i = t + 256 * u;
+          dv[u] = 0.f;
+          if (i < RT * I.ncols && b0 + i % RT < g.batch) dv[u] = I.dense[(b0 + i % RT) * I.ld_dense + i / RT];
+        }
+        if (I.wide) {
+#pragma unroll
+          for (int u = 0; u < WV; ++u) {
+            const int i = t + 256 * u;
+            wv[u] = 0.f;
+            if (i < nbag) {
+              const int64_t rb = s_rbase[i % S];
+              const int id = s_id[i];
+              if (rb >= 0 && id >= 0)
+                wv[u] = I.wide_in_row ? I.wide[s_eoff[i % S] + (int64_t)id * RS_ + D]     // weight travels behind its row
+                                      : __builtin_nontemporal_load(I.wide + (rb + id) * 4);
+            }
+          }
+        }
+      }
 #pragma unroll
       for (int q = 0; q < QB; ++q) {
         if (col[q] < 0) continue;
@@ -456,17 +460,6 @@ __global__ void __launch_bounds__(256, RT_ == 16 ? 2 : 1) k_tower_chain(ChainArg
           regx[(c0 + 2) * P + m] = r[q].z; regx[(c0 + 3) * P + m] = r[q].w;
         }
         if (b0 + m < g.batch) *reinterpret_cast<floatx4v *>(I.x_out + (b0 + m) * g.ld_act + c0) = r[q];
-      }
-    }
-    if (I.wide) {
-#pragma unroll
-      for (int u = 0; u < WV; ++u)
-        if (t + 256 * u < nbag) s_w[t + 256 * u] = wv[u];
-      for (int i = t + 256 * WV; i < nbag; i += 256) {     // more than 1024 bags per tile (S > 1024 / RT): the plain loop
-        const int64_t rb = s_rbase[i % S];
-        const int id = s_id[i];
-        if (rb >= 0 && id >= 0)
-          s_w[i] = I.wide_in_row ? I.wide[s_eoff[i % S] + (int64_t)id * RS_ + D] : I.wide[(rb + id) * 4];
       }
     }
     auto put_dense = [&](int i, float v) {
@@ -485,16 +478,6 @@ __global__ void __launch_bounds__(256, RT_ == 16 ? 2 : 1) k_tower_chain(ChainArg
     }
     for (int i = t + 256 * DV; i < RT * I.ncols; i += 256)
       if (b0 + i % RT < g.batch) put_dense(i, I.dense[(b0 + i % RT) * I.ld_dense + i / RT]);
-    __syncthreads();
-    if (t < RT) {   // wide logit: slots in order (fixed summation order)
-      float acc = 0.f;
-      if (I.wide) {
-        for (int sidx = 0; sidx < S; ++sidx) acc += s_w[t * S + sidx];
-        acc += I.wide_bias[0];
-      }
-      s_wide[t] = acc;
-      if (I.wide_out && b0 + t < g.batch) I.wide_out[b0 + t] = acc;
-    }
   } else {
   // ---- x tile -> LDS [k][P] (rows beyond the batch read as zero): all loads of a column block in flight, then the
   // transposing LDS stores ----------------------------------------------------------------------------------
@@ -549,9 +532,25 @@ __global__ void __launch_bounds__(256, RT_ == 16 ? 2 : 1) k_tower_chain(ChainArg
   {
     const int m = t % RT, part = t / RT;
     const float *sL = lds + g.tab_off[L - 1], *tL = sL + K;     // affine of the last hidden layer (identity without BN)
+    if (g.in.emb && g.in.wide) {
+      // the wide weights requested with the tile have long arrived: registers -> LDS (the x region is dead since the first
+      // product), then the wide logit of each example, slots in order (fixed summation order)
+      const int S = uni(g.in.S), nbag = RT * S;
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (t + 256 * u < nbag) regx[t + 256 * u] = wv[u];
+      __syncthreads();
+      if (t < RT) {
+        float acc = 0.f;
+        for (int sidx = 0; sidx < S; ++sidx) acc += regx[t * S + sidx];
+        acc += g.in.wide_bias[0];
+        s_wide[t] = acc;
+        if (g.in.wide_out && b0 + t < g.batch) g.in.wide_out[b0 + t] = acc;
+      }
+    }
     float d = 0.f;
     for (int n = part; n < K; n += PARTS) d += __fadd_rn(__fmul_rn(in[n * P + m], sL[n]), tL[n]) * swl[n];
-    const float h_wide_lds = (g.in.emb && t < RT) ? s_wide[t] : 0.f;   // read before `red` is reused below
+    const float h_wide_lds = (g.in.emb && g.in.wide && t < RT) ? s_wide[t] : 0.f;   // read before `red` is reused below
     __syncthreads();
     red[part * RT + m] = d;
     __syncthreads();
@@ -907,8 +906,8 @@ extern "C" int wd_tower_chain(const float *x, int64_t ld_act, int32_t K0, const 
       const int rc = check_chain_input(opts->input);
       if (rc != WD_OK) return rc;
       g.in = *opts->input;
-      WD_REQUIRE((int64_t)2 * rt * g.in.S * 4 <= (int64_t)N[0] * (rt + 1) * 4,
-                 "input fusion: ids do not fit the scratch region (2 x row_tile x S <= (row_tile + 1) x N_0)");
+      WD_REQUIRE((int64_t)rt * g.in.S * 4 <= (int64_t)N[0] * (rt + 1) * 4 && rt * g.in.S <= 1024,
+                 "input fusion: row_tile x S ids must fit the scratch region ((row_tile + 1) x N_0 floats) and be <= 1024");
     }
   }
   return rt == 16 ? launch_chain<16>(g, bytes, stream) : launch_chain<32>(g, bytes, stream);

@@ -443,7 +443,7 @@ class WideDeepEngine:
         (dim, sl), = self.plan.emb_groups.items()
         n0 = self.towers[0]["metas"][0]["N"]
         return (self.plan.S <= capi.WD_CHAIN_MAX_SLOTS and dim % 4 == 0 and 256 % (dim // 4) == 0
-                and 2 * self.chain_rt * self.plan.S <= (self.chain_rt + 1) * n0)
+                and self.chain_rt * self.plan.S <= min((self.chain_rt + 1) * n0, 1024))
 
     def _sparse_exchange(self, bt, st):
         """Hook: what has to happen before the tower kernel can build its own x tile (dist.py: the row exchange)."""

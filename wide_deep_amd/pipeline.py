@@ -79,6 +79,8 @@ class StepGraph:
         s_in.wait_stream(main)              # fork: everything launched before this graph is complete
         s_sp.wait_stream(main)
         tail_after = os.environ.get("WD_PIPE_TAIL", "beside") == "after"
+        bucket_early = os.environ.get("WD_PIPE_BUCKET", "early") == "early"
+        ev_tower_prev = None
         pending = []
         keep = self._events = []            # every event lives as long as the graph (none is destroyed during the capture)
 
@@ -96,24 +98,38 @@ class StepGraph:
                 if not ids_input:
                     synth.hash_tokens(eng, tb)
                 ev_ids = event(s_in)
-            # ---- sparse branch, part 1: ids -> row-range buckets, behind update(t-1) in stream order (one scratch set) ----
-            s_sp.wait_event(ev_ids)
-            with torch.cuda.stream(s_sp):
-                eng._sparse_bucketize(bt, s_sp.cuda_stream)
+            # ---- bucketing: ids -> row-range buckets (scratch set t % 2).  WD_PIPE_BUCKET=early: on the input branch, released
+            # by the END of tower(t-1) -- it then runs beside the products / update of step t-1 instead of beside tower(t),
+            # whose one-workgroup-per-CU grid it slows down (99 us in the step against 90 alone)
+            pset = t & 1
+            if bucket_early:
+                if t >= 1:
+                    s_in.wait_event(ev_tower_prev)
+                with torch.cuda.stream(s_in):
+                    eng._sparse_bucketize(bt, s_in.cuda_stream, pset)
+                    ev_buck = event(s_in)
+            else:
+                s_sp.wait_event(ev_ids)
+                with torch.cuda.stream(s_sp):
+                    eng._sparse_bucketize(bt, s_sp.cuda_stream, pset)
+                ev_buck = None
             # ---- dense chain: tower(t) -> weight gradients || row update -> finalize + Adagrad + fold for t+1 ---------------
             main.wait_event(ev_ids)
             while pending:
                 main.wait_event(pending.pop())          # WD_PIPE_TAIL=beside: the update of step t-1 is joined here
             eng.forward(bt, need_loss=True)             # folded weights are in place (eng._folded): the tower launch only
             ev_tower = event(main)
+            ev_tower_prev = ev_tower
             # ---- weight-gradient GEMMs, then (captured AFTER them: ready nodes are launched in capture order, and the GEMMs'
             # 512 workgroups have to be resident before the update's 3200 flood the CUs -- launched together the GEMMs take 72 us
             # instead of 38) the row update on the sparse branch: Adagrad (embedding rows) + Ftrl (wide rows, bias).
             # The update is joined before tower(t+1) (default) or, WD_PIPE_TAIL=after, between the products and the tail.
-            def update_then_join():
+            def update_then_join(ev_tower=ev_tower, ev_buck=ev_buck, pset=pset, bt=bt):
                 s_sp.wait_event(ev_tower)
+                if ev_buck is not None:
+                    s_sp.wait_event(ev_buck)
                 with torch.cuda.stream(s_sp):
-                    eng._sparse_backward(bt, s_sp.cuda_stream, bucketized=True)
+                    eng._sparse_backward(bt, s_sp.cuda_stream, bucketized=True, pset=pset)
                     ev_upd = event(s_sp)
                 if tail_after:
                     main.wait_event(ev_upd)

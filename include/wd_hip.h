@@ -496,7 +496,10 @@ int wd_tower_chain(const float *x, int64_t ld_act, int32_t K0, const wd_chain_la
  *   wd_hgemm_tn_splitk: Gpart[z][(K+1)][N] = [AT ; 1] dZT^T over batch slices; AT [K][ldat], dZT [N][lddzt] (batch
  *                 contiguous); row K = column sums of dZ (bias gradient), as wd_gemm_tn_splitk
  *   wd_cast_transpose_h: dst[r][c] = half(src[r][c] * (act_h ? act'(act_h[r][c]) : 1)) and dstT[c][r] (either NULL)
- *   wd_logits_head_h: wd_logits_head with a half activation window */
+ *   wd_logits_head_h: wd_logits_head with a half activation window
+ * Operand loads are unconditional 16-byte loads clamped to the last 8-half vector of a row's reduction range (16-byte aligned
+ * operands with pitches that are multiples of 8): up to 7 halfs behind the range are read and discarded, so an operand buffer
+ * must extend at least 14 bytes past the reduction range of its LAST row (pitch >= the range rounded up to 8 does it). */
 typedef uint16_t wd_half_t;
 int wd_hgemm_nn(const wd_half_t *A, int64_t lda, const wd_half_t *WT, int64_t ldw, const float *bias, int32_t bias_parts,
                 int32_t act, wd_half_t *C, int64_t ldc, wd_half_t *CT, int64_t ldct, int64_t M, int64_t N, int64_t K,

@@ -18,6 +18,8 @@
 // Tile: 2x2 waves, each wave WT x WT (WT = 64: four 32x32 accumulators; WT = 32 for narrow outputs), BK = 64 halfs,
 // LDS double-buffered, global loads of slab i+1 in flight across the MFMAs of slab i.
 #include "common.h"
+#include <cstdlib>
+#include <type_traits>
 
 namespace {
 
@@ -96,92 +98,93 @@ __device__ __forceinline__ half8 load8(const half_t *__restrict__ P, int64_t row
   return v;
 }
 
+// Epilogue shared by the GEMM kernels: C/D layout of a 32x32 tile: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
 template <int WT, int MODE>
-__global__ void __launch_bounds__(256) k_hgemm(HArgs g) {
-  constexpr int BT = 2 * WT;             // block tile (rows of A and of B)
-  constexpr int NV = BT * 8 / 256;       // 16-byte loads per lane per operand per slab
-  constexpr int NT = WT / 32;            // 32x32 accumulator tiles per wave and dimension
-  __shared__ __attribute__((aligned(16))) half_t As[2][BT * HLD];
-  __shared__ __attribute__((aligned(16))) half_t Bs[2][BT * HLD];
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int fr = lane >> 5, fc = lane & 31;
-
-  // XCD-aware tile order (n fastest inside an XCD's contiguous run), as in mlp.hip
-  const int tiles = g.tiles_m * g.tiles_n;
-  const int bz = blockIdx.x / tiles, orig = blockIdx.x % tiles;
-  const int q = tiles / wd::kXCDs, r = tiles % wd::kXCDs;
-  const int xcd = orig % wd::kXCDs, loc = orig / wd::kXCDs;
-  const int vid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
-  const int64_t m0 = (int64_t)(vid / g.tiles_n) * BT;
-  const int64_t n0 = (int64_t)(vid % g.tiles_n) * BT;
-  const int64_t kbeg = (int64_t)bz * g.kchunk;
-  const int64_t kend = kbeg + g.kchunk < g.K ? kbeg + g.kchunk : g.K;
-  const int64_t a_rows = g.ones_row >= 0 ? g.ones_row : g.M;
-
-  const bool fast_tile = g.vec && (m0 + BT <= a_rows) && (n0 + BT <= g.N);
-  half8 ra[NV], rb[NV];
-  auto load_slab = [&](int64_t k0) {
-    const bool fast = fast_tile && (k0 + HBK <= kend);
+__device__ __forceinline__ void hgemm_epilogue(const HArgs &g, floatx16 (&acc)[WT / 32][WT / 32], int64_t m0, int64_t n0,
+                                               int wm, int wn, int fr, int fc, int bz, half_t *stage = nullptr) {
+  constexpr int NT = WT / 32, BT = 2 * WT;
+  // ---- half outputs (NN, NT -> dz) through LDS: the accumulator layout (one column, 4 consecutive rows per lane) makes the
+  // direct stores 2-byte writes for C [m][n] and 8-byte writes for its transpose -- measured 23 + 13 us of a 76 us launch at
+  // M 8192 x N 1024 whatever K is (scripts/bench_hgemm_k.py).  Staged through the (now idle) operand ring, both copies leave
+  // as 16-byte stores of full rows: pass 1 the tile as [m][n], pass 2 as [n][m].
+  constexpr int PA = BT + 8;   // pitch (halfs) of the [m][n] image: rows 16-byte aligned
+  constexpr int PB = BT + 4;   // pitch of the [n][m] image: 8-byte aligned rows, the b64 column writes hit distinct banks
+  const bool staged = (MODE == H_NN || MODE == H_NT_DZ) && stage != nullptr && (g.ldch % 8 == 0) &&
+                      ((reinterpret_cast<uintptr_t>(g.Ch) & 15) == 0) && (!g.CT || (g.ldct % 8 == 0 &&
+                      (reinterpret_cast<uintptr_t>(g.CT) & 15) == 0));
+  if (staged) {
+    // final values in place (fp32 accumulators), tile by tile -- explicit calls: nested unrolled loops around the runtime
+    // bias loop were not unrolled by hipcc and the per-lane staging array went to scratch (320 B/lane)
+    auto finalize = [&](floatx16 &tile, int i, int j) {
+      const int64_t n = n0 + wn * WT + j * 32 + fc;
+      const bool n_ok = n < g.N;
+      float bv = 0.f;
+      if (MODE == H_NN && g.bias && n_ok)
+        for (int p = 0; p < g.bias_parts; ++p) bv += g.bias[(int64_t)p * g.N + n];
 #pragma unroll
-    for (int v = 0; v < NV; ++v) {
-      const int idx = t + v * 256;
-      const int row = idx >> 3, kc = (idx & 7) * 8;
-      if (fast) {
-        ra[v] = *reinterpret_cast<const half8 *>(g.A + (m0 + row) * g.lda + k0 + kc);
-        rb[v] = *reinterpret_cast<const half8 *>(g.B + (n0 + row) * g.ldb + k0 + kc);
+      for (int e = 0; e < 16; ++e) {
+        const int64_t m = m0 + wm * WT + i * 32 + 8 * (e >> 2) + 4 * fr + (e & 3);
+        float x = tile[e];
+        if (MODE == H_NN) x = hact_fwd(x + bv, g.act);
+        else if (m < g.M && n_ok) x *= hact_bwd((float)g.act_src[m * g.ld_act + n], g.act);
+        tile[e] = x;
+      }
+    };
+    auto put_mn = [&](const floatx16 &tile, int i, int j) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e)
+        stage[(wm * WT + i * 32 + 8 * (e >> 2) + 4 * fr + (e & 3)) * PA + wn * WT + j * 32 + fc] = (half_t)tile[e];
+    };
+    auto put_nm = [&](const floatx16 &tile, int i, int j) {
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        half4v pk;
+        pk[0] = (half_t)tile[4 * g4]; pk[1] = (half_t)tile[4 * g4 + 1]; pk[2] = (half_t)tile[4 * g4 + 2]; pk[3] = (half_t)tile[4 * g4 + 3];
+        *reinterpret_cast<half4v *>(stage + (wn * WT + j * 32 + fc) * PB + wm * WT + i * 32 + 8 * g4 + 4 * fr) = pk;
+      }
+    };
+    finalize(acc[0][0], 0, 0);
+    if constexpr (NT == 2) { finalize(acc[0][1], 0, 1); finalize(acc[1][0], 1, 0); finalize(acc[1][1], 1, 1); }
+    const int t = threadIdx.x;
+    __syncthreads();                 // everybody is done reading the operand ring
+    put_mn(acc[0][0], 0, 0);
+    if constexpr (NT == 2) { put_mn(acc[0][1], 0, 1); put_mn(acc[1][0], 1, 0); put_mn(acc[1][1], 1, 1); }
+    __syncthreads();
+    for (int c = t; c < BT * (BT / 8); c += 256) {
+      const int row = c / (BT / 8), ch = c % (BT / 8);
+      const int64_t m = m0 + row, n = n0 + ch * 8;
+      if (m >= g.M || n >= g.N) continue;
+      const half8 v = *reinterpret_cast<const half8 *>(stage + row * PA + ch * 8);
+      half_t *dst = g.Ch + m * g.ldch + n;
+      if (n + 8 <= g.N) {
+        *reinterpret_cast<half8 *>(dst) = v;
       } else {
-        ra[v] = load8(g.A, m0 + row, k0 + kc, g.lda, a_rows, kend, g.vec, g.ones_row >= 0 && m0 + row == g.ones_row);
-        rb[v] = load8(g.B, n0 + row, k0 + kc, g.ldb, g.N, kend, g.vec, false);
+        for (int e = 0; e < 8 && n + e < g.N; ++e) dst[e] = v[e];
       }
     }
-  };
-  auto store_slab = [&](int buf) {
-#pragma unroll
-    for (int v = 0; v < NV; ++v) {
-      const int idx = t + v * 256;
-      const int row = idx >> 3, kc = (idx & 7) * 8;
-      *reinterpret_cast<half8 *>(&As[buf][row * HLD + kc]) = ra[v];
-      *reinterpret_cast<half8 *>(&Bs[buf][row * HLD + kc]) = rb[v];
+    if (g.CT) {
+      __syncthreads();
+      put_nm(acc[0][0], 0, 0);
+      if constexpr (NT == 2) { put_nm(acc[0][1], 0, 1); put_nm(acc[1][0], 1, 0); put_nm(acc[1][1], 1, 1); }
+      __syncthreads();
+      for (int c = t; c < BT * (BT / 8); c += 256) {
+        const int row = c / (BT / 8), ch = c % (BT / 8);      // row = n, chunk of 8 consecutive m
+        const int64_t n = n0 + row, m = m0 + ch * 8;
+        if (n >= g.N || m >= g.M) continue;
+        const half4v lo = *reinterpret_cast<const half4v *>(stage + row * PB + ch * 8);
+        const half4v hi = *reinterpret_cast<const half4v *>(stage + row * PB + ch * 8 + 4);
+        half_t *dst = g.CT + n * g.ldct + m;
+        if (m + 8 <= g.M) {
+          half8 v;
+          v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3]; v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+          *reinterpret_cast<half8 *>(dst) = v;
+        } else {
+          for (int e = 0; e < 8 && m + e < g.M; ++e) dst[e] = e < 4 ? lo[e] : hi[e - 4];
+        }
+      }
     }
-  };
-
-  floatx16 acc[NT][NT];
-#pragma unroll
-  for (int i = 0; i < NT; ++i)
-#pragma unroll
-    for (int j = 0; j < NT; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-  load_slab(kbeg);
-  store_slab(0);
-  __syncthreads();
-  int cur = 0;
-  for (int64_t k0 = kbeg; k0 < kend; k0 += HBK) {
-    const bool more = k0 + HBK < kend;
-    if (more) load_slab(k0 + HBK);
-    const half_t *Ac = &As[cur][(wm * WT + fc) * HLD + fr * 8];
-    const half_t *Bc = &Bs[cur][(wn * WT + fc) * HLD + fr * 8];
-#pragma unroll
-    for (int ks = 0; ks < HBK / 16; ++ks) {
-      half8 fa[NT], fb[NT];
-#pragma unroll
-      for (int i = 0; i < NT; ++i) fa[i] = *reinterpret_cast<const half8 *>(Ac + i * 32 * HLD + ks * 16);
-#pragma unroll
-      for (int j = 0; j < NT; ++j) fb[j] = *reinterpret_cast<const half8 *>(Bc + j * 32 * HLD + ks * 16);
-#pragma unroll
-      for (int i = 0; i < NT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i], fb[j], acc[i][j], 0, 0, 0);
-    }
-    if (more) store_slab(cur ^ 1);
-    __syncthreads();
-    cur ^= 1;
+    return;
   }
-
-  // C/D layout of a 32x32 tile: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
   auto epilogue = [&](const floatx16 &tile, int i, int j) {
     const int64_t n = n0 + wn * WT + j * 32 + fc;
     const bool n_ok = n < g.N;
@@ -237,6 +240,282 @@ __global__ void __launch_bounds__(256) k_hgemm(HArgs g) {
   }
 }
 
+template <int WT, int MODE, bool VEC>
+__global__ void __launch_bounds__(256, 2) k_hgemm(HArgs g) {
+  constexpr int BT = 2 * WT;             // block tile (rows of A and of B)
+  constexpr int NV = BT * 8 / 256;       // 16-byte loads per lane per operand per slab
+  constexpr int NT = WT / 32;            // 32x32 accumulator tiles per wave and dimension
+  __shared__ __attribute__((aligned(16))) half_t As[2][BT * HLD];
+  __shared__ __attribute__((aligned(16))) half_t Bs[2][BT * HLD];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int fr = lane >> 5, fc = lane & 31;
+
+  // XCD-aware tile order (n fastest inside an XCD's contiguous run), as in mlp.hip
+  const int tiles = g.tiles_m * g.tiles_n;
+  const int bz = blockIdx.x / tiles, orig = blockIdx.x % tiles;
+  const int q = tiles / wd::kXCDs, r = tiles % wd::kXCDs;
+  const int xcd = orig % wd::kXCDs, loc = orig / wd::kXCDs;
+  const int vid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+  const int64_t m0 = (int64_t)(vid / g.tiles_n) * BT;
+  const int64_t n0 = (int64_t)(vid % g.tiles_n) * BT;
+  const int64_t kbeg = (int64_t)bz * g.kchunk;
+  const int64_t kend = kbeg + g.kchunk < g.K ? kbeg + g.kchunk : g.K;
+  const int64_t a_rows = g.ones_row >= 0 ? g.ones_row : g.M;
+
+  const bool fast_tile = (m0 + BT <= a_rows) && (n0 + BT <= g.N);
+  // TWO register sets: the loads of slab i+2 are issued before the MFMAs of slab i and land in LDS after the MFMAs of slab
+  // i+1 -- two slabs (1024 MFMA cycles per wavefront) of latency cover instead of one.  With one set the kernels sat in
+  // s_waitcnt 75 % of the time (profiles/r1p_c5_fp16_mfma_pmc.json: MFMA busy 4-11 %).
+  // The loads are UNCONDITIONAL 16-byte loads at addresses clamped into the matrix (row -> last valid row, k -> the last
+  // 8-half vector of the reduction range; every operand buffer carries >= 16 bytes of slack behind its last row): no branch
+  // between issue and use, so the waits stay counted (vmcnt(N)) and the loop body small; what lies outside the matrix is
+  // zeroed when the registers go to LDS (edge tiles / the last, partial slab only).
+  half8 ra[2][NV], rb[2][NV];
+  const int64_t klast = ((kend - 1) >> 3) << 3;
+  int32_t offA[NV], offB[NV];
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    const int idx = t + v * 256;
+    const int64_t rowa = m0 + (idx >> 3) < a_rows ? m0 + (idx >> 3) : a_rows - 1;
+    const int64_t rowb = n0 + (idx >> 3) < g.N ? n0 + (idx >> 3) : g.N - 1;
+    offA[v] = (int32_t)((rowa - m0) * g.lda);
+    offB[v] = (int32_t)((rowb - n0) * g.ldb);
+  }
+  const int kc = (t & 7) * 8;
+  const half_t *pa0 = g.A + m0 * g.lda, *pb0 = g.B + n0 * g.ldb;
+  auto load_slab = [&](int64_t k0, auto set_c) {
+    constexpr int SET = decltype(set_c)::value;
+    if (VEC) {
+      const int64_t kk = k0 + kc < klast ? k0 + kc : klast;
+      const half_t *pa = pa0 + kk, *pb = pb0 + kk;
+#pragma unroll
+      for (int v = 0; v < NV; ++v) ra[SET][v] = *reinterpret_cast<const half8 *>(pa + offA[v]);
+#pragma unroll
+      for (int v = 0; v < NV; ++v) rb[SET][v] = *reinterpret_cast<const half8 *>(pb + offB[v]);
+    } else {
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        const int row = (t + v * 256) >> 3;
+        ra[SET][v] = load8(g.A, m0 + row, k0 + kc, g.lda, a_rows, kend, false, g.ones_row >= 0 && m0 + row == g.ones_row);
+        rb[SET][v] = load8(g.B, n0 + row, k0 + kc, g.ldb, g.N, kend, false, false);
+      }
+    }
+  };
+  auto store_slab = [&](int buf, int64_t k0, auto set_c) {
+    constexpr int SET = decltype(set_c)::value;
+    const bool plain = !VEC || (fast_tile && k0 + HBK <= kend);
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const int row = (t + v * 256) >> 3;
+      half8 va = ra[SET][v], vb = rb[SET][v];
+      if (!plain) {      // edge tile or last slab: zero what is outside, synthesise the ones row
+        const bool ones = g.ones_row >= 0 && m0 + row == g.ones_row;
+        const bool ra_ok = m0 + row < a_rows, rb_ok = n0 + row < g.N;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const bool k_ok = k0 + kc + e < kend;
+          va[e] = ones ? (k_ok ? (half_t)1.f : (half_t)0.f) : ((ra_ok && k_ok) ? va[e] : (half_t)0.f);
+          vb[e] = (rb_ok && k_ok) ? vb[e] : (half_t)0.f;
+        }
+      }
+      *reinterpret_cast<half8 *>(&As[buf][row * HLD + kc]) = va;
+      *reinterpret_cast<half8 *>(&Bs[buf][row * HLD + kc]) = vb;
+    }
+  };
+
+  floatx16 acc[NT][NT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  auto compute = [&](int cur) {
+    const half_t *Ac = &As[cur][(wm * WT + fc) * HLD + fr * 8];
+    const half_t *Bc = &Bs[cur][(wn * WT + fc) * HLD + fr * 8];
+#pragma unroll
+    for (int ks = 0; ks < HBK / 16; ++ks) {
+      half8 fa[NT], fb[NT];
+#pragma unroll
+      for (int i = 0; i < NT; ++i) fa[i] = *reinterpret_cast<const half8 *>(Ac + i * 32 * HLD + ks * 16);
+#pragma unroll
+      for (int j = 0; j < NT; ++j) fb[j] = *reinterpret_cast<const half8 *>(Bc + j * 32 * HLD + ks * 16);
+#pragma unroll
+      for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+  };
+  using std::integral_constant;
+  typedef integral_constant<int, 0> S0;
+  typedef integral_constant<int, 1> S1;
+  // slab i lives in LDS buffer i % 2 and (before that) in register set i % 2
+  load_slab(kbeg, S0{});
+  if (kbeg + HBK < kend) load_slab(kbeg + HBK, S1{});
+  store_slab(0, kbeg, S0{});
+  __syncthreads();
+  for (int64_t k0 = kbeg; k0 < kend; k0 += 2 * HBK) {
+    // even slab: LDS buffer 0; set 0 is free (stored), set 1 holds slab k0 + HBK
+    if (k0 + 2 * HBK < kend) load_slab(k0 + 2 * HBK, S0{});
+    compute(0);
+    if (k0 + HBK < kend) store_slab(1, k0 + HBK, S1{});
+    __syncthreads();
+    if (k0 + HBK >= kend) break;
+    // odd slab: LDS buffer 1; set 1 is free, set 0 holds slab k0 + 2 HBK
+    if (k0 + 3 * HBK < kend) load_slab(k0 + 3 * HBK, S1{});
+    compute(1);
+    if (k0 + 2 * HBK < kend) store_slab(0, k0 + 2 * HBK, S0{});
+    __syncthreads();
+  }
+
+  hgemm_epilogue<WT, MODE>(g, acc, m0, n0, wm, wn, fr, fc, bz, &As[0][0]);   // 2 BT x 72 halfs >= BT (BT + 8)
+}
+
+// ---- 128x128 tile, operands straight into LDS (global_load_lds_dwordx4), four 32-half stages --------------------------------
+// The register-staged kernel above keeps two slabs in flight per wavefront and pays for them in VGPRs (254: nothing left to
+// pipeline the fragment reads) and in ds_write traffic; measured it parks 59 % of its wave cycles (profiles/r2s_hgemm_pmc.txt:
+// MFMA busy 15 %, L2 hit rate 91 % -- latency, not bandwidth).  Here the tile loads never touch a register:
+//   * stage = 32 reduction halfs of the 128 + 128 tile rows = 16 KB; ring of 4 stages = 64 KB -> two workgroups per CU, each
+//     with THREE stages in flight; one barrier per stage, waits are counted (vmcnt(8): the two younger stages stay out);
+//   * LDS-DMA writes lane-linear (lane l -> 16 bytes at base + 16 l: 16 rows x 64 B per instruction), so the LDS image is the
+//     global access pattern; the 16-byte chunk c of row r is FETCHED into position c ^ ((r >> 2) & 3) (the lanes of a row swap
+//     chunks among themselves: same 64-byte segment, coalescing unchanged) and the MFMA fragment reads -- 16 consecutive rows,
+//     one chunk -- hit 16 different bank quads: conflict-free ds_read_b128 without padding;
+//   * fragment reads of step ks+1 are issued before the MFMAs of step ks (the VGPRs staging used to take).
+// Edge handling: row addresses clamped (rows beyond M / N only feed accumulator rows / columns nobody stores); a partial last
+// stage and the synthesised ones row (TN) are patched in LDS after the stage has landed.
+constexpr int GBK = 32;                 // reduction halfs per stage
+constexpr int GNS = 4;                  // stages
+constexpr int GSTAGE = 2 * 128 * GBK;   // halfs per stage: A then B
+
+template <int MODE>
+__global__ void __launch_bounds__(256, 2) k_hgemm_g(HArgs g) {
+  constexpr int WT = 64, BT = 128;
+  __shared__ __attribute__((aligned(16))) half_t ring[GNS * GSTAGE];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int fr = lane >> 5, fc = lane & 31;
+  const int tiles = g.tiles_m * g.tiles_n;
+  const int bz = blockIdx.x / tiles, orig = blockIdx.x % tiles;
+  const int q = tiles / wd::kXCDs, r = tiles % wd::kXCDs;
+  const int xcd = orig % wd::kXCDs, loc = orig / wd::kXCDs;
+  const int vid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+  const int64_t m0 = (int64_t)(vid / g.tiles_n) * BT;
+  const int64_t n0 = (int64_t)(vid % g.tiles_n) * BT;
+  const int64_t kbeg = (int64_t)bz * g.kchunk;
+  const int64_t kend = kbeg + g.kchunk < g.K ? kbeg + g.kchunk : g.K;
+  const int64_t a_rows = g.ones_row >= 0 ? g.ones_row : g.M;
+  const int64_t klast = ((kend - 1) >> 3) << 3;
+  const int nst = (int)((kend - kbeg + GBK - 1) / GBK);
+
+  // this wavefront's four loads per stage: instruction j covers rows 16 (2 wave + ... ) of A (j < 2) or B (j >= 2)
+  //   piece p = wave * 2 + (j & 1) in 0..7 -> rows [16 p, 16 p + 16) of the operand; lane -> row 16 p + lane / 4, slot lane % 4
+  const half_t *src[4];
+  int kofs[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int p = wave * 2 + (j & 1);
+    const int row = 16 * p + (lane >> 2);
+    const int chunk = (lane & 3) ^ ((row >> 2) & 3);
+    const bool isA = j < 2;
+    const int64_t rr = isA ? (m0 + row < a_rows ? m0 + row : a_rows - 1) : (n0 + row < g.N ? n0 + row : g.N - 1);
+    src[j] = (isA ? g.A + rr * g.lda : g.B + rr * g.ldb);
+    kofs[j] = chunk * 8;
+  }
+  auto issue = [&](int st) {      // stage st (reduction halfs [kbeg + 32 st, +32)) -> ring slot st % GNS
+    const int64_t k0 = kbeg + (int64_t)st * GBK;
+    half_t *slot = ring + (st % GNS) * GSTAGE;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int p = wave * 2 + (j & 1);
+      const int64_t kk = k0 + kofs[j] < klast ? k0 + kofs[j] : klast;
+      half_t *dst = slot + (j < 2 ? 0 : 128 * GBK) + 16 * p * GBK;      // wave-uniform; the hardware adds 16 B x lane
+      __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(src[j] + kk),
+                                       (void __attribute__((address_space(3))) *)dst, 16, 0, 0);
+    }
+  };
+  const bool has_ones = g.ones_row >= m0 && g.ones_row < m0 + BT;
+  auto patch = [&](int st) {      // after the stage has landed (this wavefront's own pieces): zero k >= kend, write the ones row
+    const int64_t k0 = kbeg + (int64_t)st * GBK;
+    const bool partial = k0 + GBK > kend;
+    if (!partial && !has_ones) return;
+    half_t *slot = ring + (st % GNS) * GSTAGE;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int p = wave * 2 + (j & 1);
+      const int row = 16 * p + (lane >> 2);
+      half8 *cell = reinterpret_cast<half8 *>(slot + (j < 2 ? 0 : 128 * GBK) + row * GBK + (lane & 3) * 8);
+      const bool ones = j < 2 && m0 + row == g.ones_row;
+      if (partial || ones) {
+        half8 v = *cell;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const bool k_ok = k0 + kofs[j] + e < kend;
+          v[e] = ones ? (k_ok ? (half_t)1.f : (half_t)0.f) : (k_ok ? v[e] : (half_t)0.f);
+        }
+        *cell = v;
+      }
+    }
+  };
+
+  floatx16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  // fragment of MFMA step ks (16 halfs): chunk 2 ks + fr of row (tile row) -> position chunk ^ ((row >> 2) & 3)
+  auto frag = [&](const half_t *op, int row, int ks) -> half8 {
+    const int pos = (2 * ks + fr) ^ ((row >> 2) & 3);
+    return *reinterpret_cast<const half8 *>(op + row * GBK + pos * 8);
+  };
+
+#pragma unroll
+  for (int st = 0; st < GNS - 1; ++st)
+    if (st < nst) issue(st);
+  for (int st = 0; st < nst; ++st) {
+    // own loads of stage st landed: stages st+1, st+2 (4 instructions each) may stay in flight
+    const int younger = (nst - 1 - st) < 2 ? (nst - 1 - st) : 2;
+    if (younger == 2) __builtin_amdgcn_s_waitcnt(0x0F70 | 8);        // vmcnt(8), lgkmcnt / expcnt untouched
+    else if (younger == 1) __builtin_amdgcn_s_waitcnt(0x0F70 | 4);   // vmcnt(4)
+    else __builtin_amdgcn_s_waitcnt(0x0F70 | 0);                     // vmcnt(0)
+    patch(st);
+    // bare s_barrier (no __syncthreads: its release fence would drain vmcnt to 0 and with it the two stages in flight).  Own
+    // LDS stores of patch() are drained first; LDS-DMA data is visible once its issuer's vmcnt wait has passed.
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    // stage st complete for everybody; everybody is done with stage st-1 -> its slot is free
+    if (st + GNS - 1 < nst) issue(st + GNS - 1);
+    const half_t *As = ring + (st % GNS) * GSTAGE, *Bs = As + 128 * GBK;
+    half8 fa[2][2], fb[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      fa[0][i] = frag(As, wm * WT + i * 32 + fc, 0);
+      fb[0][i] = frag(Bs, wn * WT + i * 32 + fc, 0);
+    }
+#pragma unroll
+    for (int ks = 0; ks < GBK / 16; ++ks) {
+      if (ks + 1 < GBK / 16) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          fa[(ks + 1) & 1][i] = frag(As, wm * WT + i * 32 + fc, ks + 1);
+          fb[(ks + 1) & 1][i] = frag(Bs, wn * WT + i * 32 + fc, ks + 1);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[ks & 1][i], fb[ks & 1][j], acc[i][j], 0, 0, 0);
+    }
+  }
+  hgemm_epilogue<WT, MODE>(g, acc, m0, n0, wm, wn, fr, fc, bz, ring);
+}
+
 // src fp32 [R][C] (ld lds) * optional act'(act_h) -> dst_h [R][ldh] and dstT_h [C][ldt]   (64x64 tiles through LDS)
 __global__ void __launch_bounds__(256)
 k_cast_transpose(const float *__restrict__ src, int64_t lds_, int64_t R, int64_t C, const half_t *__restrict__ act_h,
@@ -269,13 +548,24 @@ template <int MODE>
 int launch_h(HArgs g, int nsplit, hipStream_t st, const char *what) {
   g.vec = (g.lda % 8 == 0) && (g.ldb % 8 == 0) && al16(g.A) && al16(g.B);
   // narrow outputs: 64x64 block tiles keep more workgroups in flight
-  const bool small = (g.M <= 64 || g.N <= 128 || wd::ceil_div(g.M, 128) * wd::ceil_div(g.N, 128) * nsplit < 128);
+  static const int force = getenv("WD_HGEMM_TILE") ? atoi(getenv("WD_HGEMM_TILE")) : 0;     // diagnostics: 64 / 128
+  const int64_t big_wgs = wd::ceil_div(g.M, 128) * wd::ceil_div(g.N, 128) * nsplit;
+  // 128x128 tiles need >= 2 workgroups per CU to hide their slab latency (one slab = 3400 cycles with one workgroup per CU);
+  // below that, 64x64 tiles: a quarter of the arithmetic intensity but 4x the independent load streams
+  const bool small = force ? force == 64 : (g.M <= 64 || g.N <= 128 || big_wgs < 2 * 256);
   const int BT = small ? 64 : 128;
   g.tiles_m = (int)wd::ceil_div(g.M, BT);
   g.tiles_n = (int)wd::ceil_div(g.N, BT);
   dim3 grid((unsigned)(g.tiles_m * g.tiles_n * nsplit));
-  if (small) hipLaunchKernelGGL((k_hgemm<32, MODE>), grid, dim3(256), 0, st, g);
-  else hipLaunchKernelGGL((k_hgemm<64, MODE>), grid, dim3(256), 0, st, g);
+  static const bool use_g = !(getenv("WD_HGEMM_G") && atoi(getenv("WD_HGEMM_G")) == 0);
+  if (g.vec) {
+    if (small) hipLaunchKernelGGL((k_hgemm<32, MODE, true>), grid, dim3(256), 0, st, g);
+    else if (use_g) hipLaunchKernelGGL((k_hgemm_g<MODE>), grid, dim3(256), 0, st, g);
+    else hipLaunchKernelGGL((k_hgemm<64, MODE, true>), grid, dim3(256), 0, st, g);
+  } else {      // unaligned operands (never the engine's buffers): element loads
+    if (small) hipLaunchKernelGGL((k_hgemm<32, MODE, false>), grid, dim3(256), 0, st, g);
+    else hipLaunchKernelGGL((k_hgemm<64, MODE, false>), grid, dim3(256), 0, st, g);
+  }
   return wd::check_launch(what);
 }
 

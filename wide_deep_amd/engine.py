@@ -213,11 +213,18 @@ class WideDeepEngine:
                         raise NotImplementedError("tower_dtype='fp16': connected_mode first_dense runs on the fp32 tower")
                     f16 = dict(dtype=torch.float16, device=dev)
                     r8 = lambda v: (v + 7) // 8 * 8
+
+                    def hzeros(*shape):
+                        """half buffer with 64 halfs of slack behind its last row: the GEMM loaders issue unconditional
+                        16-byte loads at addresses clamped to the last vector of a row (csrc/mlp_half.hip)"""
+                        n = int(np.prod(shape))
+                        return torch.zeros(n + 64, **f16)[:n].view(*shape)
+
                     Bp = (B + 63) // 64 * 64
                     tw["Bp"] = Bp
-                    tw["act_h"] = torch.zeros(B, tl.ld, **f16)            # activations, example-major
-                    tw["actT_h"] = torch.zeros(tl.ld, Bp, **f16)          # and column-major (batch contiguous) for TN
-                    tw["WfT_h"] = [torch.zeros(metas[l]["N"], r8(metas[l]["K"]), **f16) for l in range(L)]
+                    tw["act_h"] = hzeros(B, tl.ld)            # activations, example-major
+                    tw["actT_h"] = hzeros(tl.ld, Bp)          # and column-major (batch contiguous) for TN
+                    tw["WfT_h"] = [hzeros(metas[l]["N"], r8(metas[l]["K"])) for l in range(L)]
                     # Z = [dlogit | dz_{L-1} | ... | dz_0] (blocks 8-aligned), example-major and transposed.  The gradient
                     # of segment j is PULLED in one GEMM  Z[:, zbeg_j:zend_j] . Wcat_j^T  over all its consumer layers
                     # (dense / resnet: every later layer and the logits), so nothing is accumulated in HBM.
@@ -226,8 +233,8 @@ class WideDeepEngine:
                         zoff[l] = z
                         z += r8(metas[l]["N"])
                     tw["zoff"], tw["pZ"] = zoff, z
-                    tw["Z_h"] = torch.zeros(B, z, **f16)
-                    tw["ZT_h"] = torch.zeros(z, Bp, **f16)
+                    tw["Z_h"] = hzeros(B, z)
+                    tw["ZT_h"] = hzeros(z, Bp)
                     pulls, base = {}, 0
                     for j in range(L + 1):
                         cons = [c for c in range(L + 1) if j in tl.in_segs[c]]
@@ -238,7 +245,7 @@ class WideDeepEngine:
                         base += tl.seg_width[j] * pitch
                         base = r8(base)
                     tw["pulls"] = pulls
-                    tw["wcat"] = torch.zeros(max(base, 8), **f16)
+                    tw["wcat"] = hzeros(max(base, 8))
                     tw["cat_off"] = []
                     for c in range(L + 1):
                         co = np.full(metas[c]["K"], -1, dtype=np.int64)

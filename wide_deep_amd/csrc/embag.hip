@@ -151,7 +151,7 @@ k_embag_fwd_range(const float *__restrict__ emb, const wd_slot_t *__restrict__ s
 
 // The same gather as a device function for the fused input-layer launch below.  Deliberately NOT shared with the kernel
 // above: routing k_embag_fwd_range through this inlined body gives the same instruction mix but a kernel that measures
-// 14.4 us instead of 11.7 us on MI355X (re-measured in round 2, profiles/r2n_*: code placement, MI355X_MICROARCH.md item 8).
+// 14.4 us instead of 11.7 us on MI355X (re-measured in round 2, profiles/r2z_bench_c2_uniform.json roofline_gather_kernel: code placement, MI355X_MICROARCH.md item 8).
 constexpr int MAXG = 128;   // slots per dim group staged in LDS
 
 template <int LANES, int BPG, bool ONEHOT>

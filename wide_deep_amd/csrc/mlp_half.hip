@@ -376,7 +376,7 @@ __global__ void __launch_bounds__(256, 2) k_hgemm(HArgs g) {
 
 // ---- 128x128 tile, operands straight into LDS (global_load_lds_dwordx4), four 32-half stages --------------------------------
 // The register-staged kernel above keeps two slabs in flight per wavefront and pays for them in VGPRs (254: nothing left to
-// pipeline the fragment reads) and in ds_write traffic; measured it parks 59 % of its wave cycles (profiles/r2s_hgemm_pmc.txt:
+// pipeline the fragment reads) and in ds_write traffic; measured it parks 59 % of its wave cycles (profiles/r2z_hgemm_pmc.txt:
 // MFMA busy 15 %, L2 hit rate 91 % -- latency, not bandwidth).  Here the tile loads never touch a register:
 //   * stage = 32 reduction halfs of the 128 + 128 tile rows = 16 KB; ring of 4 stages = 64 KB -> two workgroups per CU, each
 //     with THREE stages in flight; one barrier per stage, waits are counted (vmcnt(8): the two younger stages stay out);

@@ -358,7 +358,7 @@ class WideDeepEngine:
         dims = [int(metas[l]["N"]) for l in range(L)]
         K0 = int(metas[0]["K"])
         # row tile: 32 examples per workgroup (one workgroup per CU at batch 8192), or WD_CHAIN_RT=16 (two per CU: same kernel
-        # time alone -- both stream the same 1.2 MB of weights per tile from L2 and are bound there, profiles/r2c_* -- but
+        # time alone -- both stream the same 1.2 MB of weights per tile from L2 and are bound there, profiles/r2c_tower_ablation.txt -- but
         # slower in the step: 0.200 against 0.187 ms, the second wavefront per SIMD is what the bucketing branch used to get)
         rt = int(os.environ.get("WD_CHAIN_RT", "32"))
         if rt not in (16, 32):
@@ -435,7 +435,7 @@ class WideDeepEngine:
 
     def _fold_at_end(self):
         """The fold of step t+1 depends on nothing but the dense update of step t: launched right behind it, it runs beside
-        the sparse update instead of at the head of the next step (profiles/r2d_timeline*.txt: 9 us + a kernel boundary)."""
+        the sparse update instead of at the head of the next step (profiles/r2d_timeline_before_pipelining.txt: 9 us + a kernel boundary)."""
         return (self.chain and type(self)._reduce_dense_grads is WideDeepEngine._reduce_dense_grads
                 and type(self).backward_and_update is WideDeepEngine.backward_and_update
                 and os.environ.get("WD_FOLD_AT_END", "1") == "1")

@@ -7,7 +7,7 @@ Used by bench.py (the timed path) and by tests/test_gpu_fullsize.py (the same pa
 
 Pipelined capture (the Criteo-shaped fast path: one-launch tower with the fused input layer, Adagrad + Ftrl).  Captured
 from plain stream order, a step is a chain with one side branch, and every step waits for ALL of the previous one
-(profiles/r2d_timeline_rt32.txt: hash 4 -> fold 9 -> tower 89 -> weight gradients 39 -> finalize 29 || row update 67, then
+(profiles/r2d_timeline_before_pipelining.txt: hash 4 -> fold 9 -> tower 89 -> weight gradients 39 -> finalize 29 || row update 67, then
 6 us of join before the next hash).  The real dependencies are fewer:
 
     hash(t)                    needs the tokens of batch t only            -> input branch, off the critical path
@@ -20,7 +20,7 @@ from plain stream order, a step is a chain with one side branch, and every step 
 so the graph is built with these edges (three streams + events during capture): the hash leaves the critical path and the
 row update runs beside the MFMA-bound products and the tail (WD_PIPE_TAIL=after joins the update BEFORE the tail, which is
 a chain of dependent loads -- 19 us alone, ~40 us beside the update that keeps the memory queues full -- but the extra
-cross-queue edge costs more than it saves: 0.198 against 0.185 ms/step, profiles/r2i_*).  Every kernel
+cross-queue edge costs more than it saves: 0.198 against 0.185 ms/step, measured in round 2, profiles/README.md).  Every kernel
 still runs once per step on the same operands: results are bit-identical to the eager launches
 (tests/test_gpu_fullsize.py).  WD_PIPELINE=0 captures plain stream order.  (A fourth kind of edge -- the input branch
 waiting for update(t-2) so that bucketing can run a step ahead on a second scratch set -- makes hipStreamEndCapture of

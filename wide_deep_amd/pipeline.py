@@ -11,11 +11,11 @@ from plain stream order, a step is a chain with one side branch, and every step 
 6 us of join before the next hash).  The real dependencies are fewer:
 
     hash(t)                    needs the tokens of batch t only            -> input branch, off the critical path
-    bucketing(t)               needs ids(t) (and the scratch update(t-1) read)    -> sparse branch, under tower(t)
+    bucketing(t)               needs ids(t) (and a scratch set no running update reads)  -> input branch, after tower(t-1)
     tower(t)                   needs ids(t), the rows of update(t-1), the folded weights of dense(t-1)
     products(t) (weight-gradient GEMMs)                                   needs tower(t)
     update(t) (rows: Adagrad / Ftrl)                                      needs tower(t) (dx, dlogit) and bucketing(t)
-    tail(t) = finalize + Adagrad + fold for t+1                           needs products(t)
+    tail(t) = split-K sums + Adagrad + packed kernels for t+1            needs products(t)
 
 so the graph is built with these edges (three streams + events during capture): the hash leaves the critical path and the
 row update runs beside the MFMA-bound products and the tail (WD_PIPE_TAIL=after joins the update BEFORE the tail, which is
@@ -24,7 +24,8 @@ cross-queue edge costs more than it saves: 0.198 against 0.185 ms/step, measured
 still runs once per step on the same operands: results are bit-identical to the eager launches
 (tests/test_gpu_fullsize.py).  WD_PIPELINE=0 captures plain stream order.  (A fourth kind of edge -- the input branch
 waiting for update(t-2) so that bucketing can run a step ahead on a second scratch set -- makes hipStreamEndCapture of
-ROCm 7.2 crash from three steps per graph on; bucketing therefore stays behind update(t-1) in stream order.)
+ROCm 7.2 crash from three steps per graph on; bucketing(t) is therefore released by the end of tower(t-1), which update(t-2)
+precedes through the dense chain, and alternates between two scratch sets.)
 """
 import os
 

@@ -225,9 +225,15 @@ int wd_sparse_bwd_fused(float *emb, float *emb_accum, float *wide, float *bias_w
  * Slots a / b of a variable (same shape; wide lines are {w, a, b, -}):
  *   SGD      -                              var -= lr g
  *   Adagrad  b = accumulator                b += g^2; var -= lr g / sqrt(b)
- *   Ftrl     a = linear, b = accumulator    (as wd_wide_bwd_ftrl; p0 = l1, p1 = l2; lr_power -0.5)
+ *   Ftrl     a = linear, b = accumulator    (as wd_wide_bwd_ftrl; p0 = l1, p1 = l2; p2 = learning_rate_power <= 0: the TF default
+ *            -0.5 takes sqrt(accumulator), anything else accumulator^(-p2), FtrlCompute's general branch -- set it
+ *            explicitly, a zeroed struct means a FIXED learning rate)
  *   RMSProp  a = rms (init 1), b = momentum a += (g^2 - a)(1 - p0); b = p1 b + lr g / sqrt(a + p2); var -= b
  *            (p0 = decay, p1 = momentum, p2 = epsilon; centered = False)
+ *   RMSProp centered (WD_OPT_RMSPROP_CENTERED, TF ApplyCenteredRMSProp / SparseApplyCenteredRMSProp): third slot
+ *            c = mean gradient (init 0): c += (g - c)(1 - p0); b = p1 b + lr g / sqrt(a - c^2 + p2); var -= b.
+ *            c of an embedding table / a dense buffer = wd_opt_t.slot_c (same shape as the variable); of a wide line its
+ *            4th float; of the bias bias[3].
  *   Adam     a = m, b = v                   p0 = beta1, p1 = beta2, p2 = epsilon, lr_t = lr sqrt(1 - beta2^t) / (1 - beta1^t);
  *            `pow` = device {beta1^t, beta2^t} of the step being applied (wd_adam_tick multiplies it afterwards).
  *            Dense variables: ApplyAdam.  Sparsely updated variables: AdamOptimizer._apply_sparse_shared -- EVERY row
@@ -240,12 +246,14 @@ int wd_sparse_bwd_fused(float *emb, float *emb_accum, float *wide, float *bias_w
 #define WD_OPT_RMSPROP 3
 #define WD_OPT_ADAM 4
 #define WD_OPT_ADAM_DENSE 5   /* internal */
+#define WD_OPT_RMSPROP_CENTERED 6
 typedef struct wd_opt {
   int32_t kind;
   float lr;
   float p0, p1, p2;
   int32_t pad_;
   const float *pow;
+  float *slot_c;            /* centered RMSProp: mean-gradient slot of the variable this call updates; else NULL */
 } wd_opt_t;
 int wd_sparse_apply_opt(float *emb, float *emb_a, float *emb_b, float *wide, float *bias, const wd_slot_t *slots,
                         int32_t S, const int32_t *bag_offs, int64_t batch, const float *dx, int64_t ldx,
@@ -356,6 +364,12 @@ typedef struct wd_mlp_layer {
  * (the step's loss accumulator / flat gradient buffer) so a step needs no separate fill launches. */
 int wd_fold_affine_all(const float *P, const wd_mlp_layer_t *layers_dev, int32_t nlayers, int64_t max_n, float inv,
                        float *zero_a, int64_t zero_a_n, float *zero_b, int64_t zero_b_n, wd_stream_t stream);
+
+/* Activation `crelu` (python/lib/utils/model_util.py:52: tf.nn.crelu = concat(relu(z), relu(-z)) on the feature axis): the
+ * host runs the layer as a relu layer of width 2N with kernel [W | -W] [K][2N] and bias [b | -b]; after the weight gradient of
+ * that 2N-wide layer is final in Gflat this ties it back: g = G[k][n] - G[k][N+n]; G[k][n] = g; G[k][N+n] = -g (same for the
+ * bias), N = width of the TF variable. */
+int wd_crelu_tie(float *Gflat, int64_t w_off, int64_t b_off, int64_t K, int64_t N, wd_stream_t stream);
 
 /* wd_mlp_finalize for every layer in ONE launch.  Only valid when every BN gamma/beta feeds exactly one consumer
  * layer (connected_mode `simple`): the affine gradients are then stored, not accumulated, and Gflat needs no zeroing. */

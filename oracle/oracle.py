@@ -246,8 +246,12 @@ def sparse_apply_cols(tables, slot_a, slot_b, ids_offs, B, mean, grad_ptrs, ld_g
 # No golden vectors exist for SGD / RMSProp / Adam (parity unpinned: SURVEY 8c); they are checked against hand-computed
 # cases in tests/test_oracle_kat.py.  Adagrad and Ftrl ARE pinned by the constants of TF's own optimizer tests
 # (tests/golden/kat_tf_fp32.json, tests/test_tf_known_answers.py).
-# Optimizer tuples: ("SGD", lr) ("Adagrad", lr, init) ("Ftrl", lr, l1, l2, init) ("RMSProp", lr, decay, momentum, eps)
-#                   ("Adam", lr, beta1, beta2, eps)
+#   Ftrl, learning_rate_power != -0.5   FtrlCompute's general branch: pow(accum, -lr_power) in place of sqrt(accum)
+#   RMSProp centered  ApplyCenteredRMSProp / SparseApplyCenteredRMSProp: mg += (g - mg)(1 - decay);
+#                    mom = mom * momentum + lr g / sqrt(ms - mg^2 + eps)   (slot mg init 0; TF names the slots in creation
+#                    order rms, mg, momentum = /RMSProp, /RMSProp_1, /RMSProp_2)
+# Optimizer tuples: ("SGD", lr) ("Adagrad", lr, init) ("Ftrl", lr, l1, l2, init[, lr_power])
+#                   ("RMSProp", lr, decay, momentum, eps[, centered]) ("Adam", lr, beta1, beta2, eps)
 # ---------------------------------------------------------------------------
 SLOT_NAMES = {"SGD": (None, None), "Adagrad": (None, "/Adagrad"), "Ftrl": ("/Ftrl_1", "/Ftrl"),
               "RMSProp": ("/RMSProp", "/RMSProp_1"), "Adam": ("/Adam", "/Adam_1")}
@@ -258,25 +262,54 @@ SLOT_INIT = {"SGD": (None, None), "Adagrad": (None, "init"), "Ftrl": (0.0, "init
 def slot_init_values(opt):
     """(initial value of slot a, of slot b) or None where the optimizer has no such slot."""
     a, b = SLOT_INIT[opt[0]]
-    init = float(opt[-1]) if opt[0] in ("Adagrad", "Ftrl") else None
+    init = float(opt[2]) if opt[0] == "Adagrad" else (float(opt[4]) if opt[0] == "Ftrl" else None)
     return (init if a == "init" else a), (init if b == "init" else b)
+
+
+def _centered(opt):
+    return opt[0] == "RMSProp" and len(opt) > 5 and bool(opt[5])
+
+
+def slot_names(opt):
+    """(slot a, slot b, slot c) checkpoint suffixes; slot c only exists for centered RMSProp (mean gradient, init 0)."""
+    if _centered(opt):
+        return "/RMSProp", "/RMSProp_2", "/RMSProp_1"
+    return SLOT_NAMES[opt[0]] + (None,)
+
+
+def _ftrl_general(w, z, n, g, lr, l1, l2, lr_power):
+    """FtrlCompute with lr_power != -0.5 on torch tensors (elementwise, fp32)."""
+    n_new = n + g * g
+    pn = torch.pow(n_new, -lr_power)
+    z_new = z + g - (pn - torch.pow(n, -lr_power)) / lr * w
+    quad = pn / lr + 2.0 * l2
+    w_new = torch.where(z_new.abs() > l1, (torch.sign(z_new) * l1 - z_new) / quad, torch.zeros_like(w))
+    return w_new, z_new, n_new
 
 
 def opt_apply_dense(opt, state, nm, g, pow_):
     kind = opt[0]
     w = state[nm]
-    sa, sb = SLOT_NAMES[kind]
+    sa, sb, sc = slot_names(opt)
     if kind == "SGD":
         w -= opt[1] * g
     elif kind == "Adagrad":
         adagrad_dense(w, state[nm + sb], g, opt[1])
+    elif kind == "Ftrl" and len(opt) > 5 and opt[5] != -0.5:
+        wn, zn, nn = _ftrl_general(w, state[nm + sa], state[nm + sb], g.reshape(w.shape), opt[1], opt[2], opt[3], opt[5])
+        w.copy_(wn); state[nm + sa].copy_(zn); state[nm + sb].copy_(nn)
     elif kind == "Ftrl":
         ftrl_dense(w, state[nm + sa], state[nm + sb], g, opt[1], opt[2], opt[3])
     elif kind == "RMSProp":
-        _, lr, decay, mom, eps = opt
+        lr, decay, mom, eps = opt[1:5]
         ms, mo = state[nm + sa], state[nm + sb]
         ms += (g * g - ms) * (1.0 - decay)
-        mo.mul_(mom).add_(lr * g / torch.sqrt(ms + eps))
+        if sc is not None:
+            mg = state[nm + sc]
+            mg += (g - mg) * (1.0 - decay)
+            mo.mul_(mom).add_(lr * g / torch.sqrt(ms - mg * mg + eps))
+        else:
+            mo.mul_(mom).add_(lr * g / torch.sqrt(ms + eps))
         w -= mo
     elif kind == "Adam":
         _, lr, b1, b2, eps = opt
@@ -293,7 +326,7 @@ def opt_apply_rows(opt, state, nm, uniq, rg, pow_):
     """Sparse apply of the summed per-row gradients rg [U, D] at rows uniq [U]."""
     kind = opt[0]
     w = state[nm]
-    sa, sb = SLOT_NAMES[kind]
+    sa, sb, sc = slot_names(opt)
     idx = torch.as_tensor(np.asarray(uniq, dtype=np.int64))
     w2 = w.reshape(w.shape[0], -1)
     if len(uniq) == 0 and kind != "Adam":     # no row has a gradient (an all-empty column); Adam still decays / moves
@@ -303,14 +336,27 @@ def opt_apply_rows(opt, state, nm, uniq, rg, pow_):
         w2[idx] -= opt[1] * rg
     elif kind == "Adagrad":
         adagrad_rows(w2, state[nm + sb].reshape(w2.shape), uniq, rg, opt[1])
+    elif kind == "Ftrl" and len(opt) > 5 and opt[5] != -0.5:
+        z_t, n_t = state[nm + sa].reshape(w2.shape), state[nm + sb].reshape(w2.shape)
+        wn, zn, nn = _ftrl_general(w2[idx], z_t[idx], n_t[idx], rg, opt[1], opt[2], opt[3], opt[5])
+        w2[idx] = wn
+        z_t[idx] = zn
+        n_t[idx] = nn
     elif kind == "Ftrl":
         ftrl_rows(w, state[nm + sa], state[nm + sb], uniq, rg, opt[1], opt[2], opt[3])
     elif kind == "RMSProp":
-        _, lr, decay, mom, eps = opt
+        lr, decay, mom, eps = opt[1:5]
         ms_t, mo_t = state[nm + sa].reshape(w2.shape), state[nm + sb].reshape(w2.shape)
         ms = ms_t[idx]
         ms = ms + (rg * rg - ms) * (1.0 - decay)
-        mo = mo_t[idx] * mom + lr * rg / torch.sqrt(ms + eps)
+        if sc is not None:
+            mg_t = state[nm + sc].reshape(w2.shape)
+            mg = mg_t[idx]
+            mg = mg + (rg - mg) * (1.0 - decay)
+            mg_t[idx] = mg
+            mo = mo_t[idx] * mom + lr * rg / torch.sqrt(ms - mg * mg + eps)
+        else:
+            mo = mo_t[idx] * mom + lr * rg / torch.sqrt(ms + eps)
         ms_t[idx] = ms
         mo_t[idx] = mo
         w2[idx] -= mo
@@ -361,6 +407,8 @@ ACTIVATIONS = {
     "selu": torch.selu,
     "softplus": torch.nn.functional.softplus,
     "softsign": torch.nn.functional.softsign,
+    # tf.nn.crelu: concat(relu(x), relu(-x)) on the last axis -- the next layer (and this layer's BN) sees 2N features
+    "crelu": lambda x: torch.cat([torch.relu(x), torch.relu(-x)], dim=-1),
 }
 
 
@@ -430,7 +478,7 @@ class OracleWideDeep:
         self.batched = False
 
     def _can_batch(self):
-        return (self.batched and self.dnn_opt[0] == "Adagrad" and self.lin_opt[0] == "Ftrl"
+        return (self.batched and self.dnn_opt[0] == "Adagrad" and self.lin_opt[0] == "Ftrl" and len(self.lin_opt) <= 5
                 and all(c["kind"] != "indicator" for c in self.deep_cols))
 
     # -- Adam beta powers (non-slot variables, one pair per optimizer instance) ---------------------

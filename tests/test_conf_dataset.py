@@ -249,8 +249,16 @@ def test_every_reference_optimizer_name_and_constructor_parses():
     assert opt_tuple(*parse_optimizer("Ftrl", 0.2)) == ("Ftrl", 0.2, 0.0, 0.0, 0.1)
     with pytest.raises(ValueError):
         parse_optimizer("Adadelta", 0.1)
+    assert opt_tuple(*parse_optimizer("tf.train.RMSPropOptimizer(0.1, centered=True)", 0.05)) == (
+        "RMSProp", 0.1, 0.9, 0.0, 1e-10, True)
+    assert opt_tuple(*parse_optimizer("tf.train.RMSPropOptimizer(0.1, centered=False)", 0.05)) == ("RMSProp", 0.1, 0.9, 0.0, 1e-10)
+    assert opt_tuple(*parse_optimizer("tf.train.FtrlOptimizer(0.1, learning_rate_power=-0.7, l1_regularization_strength=0.5)",
+                                      0.05)) == ("Ftrl", 0.1, 0.5, 0.0, 0.1, -0.7)
+    assert opt_tuple(*parse_optimizer("tf.train.FtrlOptimizer(0.1, learning_rate_power=-0.5)", 0.05)) == ("Ftrl", 0.1, 0.0, 0.0, 0.1)
+    with pytest.raises(ValueError, match="needs to be negative or zero"):       # tf.train.FtrlOptimizer.__init__
+        opt_tuple(*parse_optimizer("tf.train.FtrlOptimizer(0.1, learning_rate_power=0.5)", 0.05))
     with pytest.raises(NotImplementedError):
-        opt_tuple(*parse_optimizer("tf.train.RMSPropOptimizer(0.1, centered=True)", 0.05))
+        opt_tuple(*parse_optimizer("tf.train.FtrlOptimizer(0.1, l2_shrinkage_regularization_strength=0.1)", 0.05))
 
 
 def test_prefetch_keeps_order_content_errors_and_stops_early():

@@ -14,6 +14,10 @@ FTRL_DNN = ("Ftrl", 0.05, 0.001, 0.01, 0.1)
 RMSPROP = ("RMSProp", 0.01, 0.9, 0.0, 1e-10)
 RMSPROP_MOM = ("RMSProp", 0.01, 0.8, 0.5, 1e-6)
 ADAM = ("Adam", 0.01, 0.9, 0.999, 1e-8)
+FTRL_POW = ("Ftrl", 0.1, 0.5, 1.0, 0.1, -0.7)                  # learning_rate_power != -0.5: FtrlCompute's general branch
+FTRL_POW_DNN = ("Ftrl", 0.05, 0.001, 0.01, 0.1, -0.3)
+RMSPROP_CENTERED = ("RMSProp", 0.01, 0.9, 0.0, 1e-6, True)     # ApplyCenteredRMSProp: third slot (mean gradient)
+RMSPROP_CENTERED_MOM = ("RMSProp", 0.01, 0.8, 0.5, 1e-6, True)
 
 
 def _spec(dnn, lin, **kw):
@@ -26,7 +30,8 @@ def _spec(dnn, lin, **kw):
 
 
 @pytest.mark.parametrize("dnn,lin", [(SGD, SGD), (RMSPROP, ADAGRAD), (ADAM, ADAM), (FTRL_DNN, RMSPROP_MOM), (ADAGRAD, ADAM),
-                                     (RMSPROP_MOM, FTRL), (ADAM, FTRL)])
+                                     (RMSPROP_MOM, FTRL), (ADAM, FTRL), (ADAGRAD, FTRL_POW), (RMSPROP_CENTERED, FTRL_POW),
+                                     (FTRL_POW_DNN, RMSPROP_CENTERED_MOM), (RMSPROP_CENTERED_MOM, RMSPROP_CENTERED)])
 def test_train_steps_match_oracle(dnn, lin):
     from tests.test_gpu_step import _run
     eng, ora = _run(_spec(dnn, lin), B=96, steps=4)
@@ -96,6 +101,46 @@ def test_graph_replay_advances_beta_powers():
     for k in sb:
         if k != "global_step":
             assert torch.allclose(sa[k], sb[k], rtol=1e-5, atol=1e-7), k
+
+
+def test_centered_rmsprop_slot_names_and_ftrl_power_zero_is_sgd():
+    """TF numbers an optimizer's slot variables in creation order (rms, mg, momentum): centered=True moves the momentum slot to
+    /RMSProp_2; and tf's ftrl_test.py equivalence: lr_power = 0 without regularisation from zero weights is plain SGD."""
+    import ctypes
+    from wide_deep_amd import capi, synth
+    from wide_deep_amd.engine import WideDeepEngine
+    from wide_deep_amd.plan import opt_params
+    eng = WideDeepEngine(_spec(RMSPROP_CENTERED_MOM, RMSPROP_CENTERED, buckets=300), max_batch=64, seed=2)
+    hb = synth.make_raw_batch(eng.plan, 64, seed=5, pos_rate=0.4)
+    eng.train_step(synth.to_device_ids(eng.plan, hb))
+    st = eng.export_state()
+    k = "dnn/dnn_1/hiddenlayer_0/kernel"
+    assert {k + "/RMSProp", k + "/RMSProp_1", k + "/RMSProp_2"} <= set(st)
+    assert float(st[k + "/RMSProp_1"].abs().max()) > 0 and float(st[k + "/RMSProp_1"].abs().max()) < 1.0   # mg: small, signed
+    assert float(st[k + "/RMSProp"].min()) > 0.5                                                            # rms: started at 1
+    assert "linear/linear_model/bias_weights/RMSProp_2" in st
+    b = WideDeepEngine(_spec(RMSPROP_CENTERED_MOM, RMSPROP_CENTERED, buckets=300), max_batch=64, seed=9)
+    b.import_state(st)
+    eng.train_step(synth.to_device_ids(eng.plan, hb)); b.train_step(synth.to_device_ids(b.plan, hb))
+    torch.cuda.synchronize()
+    sa, sb = eng.export_state(), b.export_state()
+    for kk in sa:
+        assert torch.equal(sa[kk], sb[kk]), kk
+    # Ftrl(lr_power = 0, l1 = l2 = 0) from w = 0 == SGD, through wd_opt_dense
+    n = 1000
+    g = torch.Generator(device="cuda").manual_seed(3)
+    w1, z, acc = torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda"), torch.full((n,), 0.1, device="cuda")
+    w2 = torch.zeros(n, device="cuda")
+    of, os_ = capi.WdOpt(), capi.WdOpt()
+    of.kind, of.lr = capi.WD_OPT_KINDS["Ftrl"], 3.0
+    of.p0, of.p1, of.p2 = opt_params(("Ftrl", 3.0, 0.0, 0.0, 0.1, 0.0))
+    os_.kind, os_.lr = capi.WD_OPT_KINDS["SGD"], 3.0
+    for _ in range(3):
+        gr = torch.randn(n, device="cuda", generator=g) * 0.1
+        capi.call("wd_opt_dense", w1.data_ptr(), z.data_ptr(), acc.data_ptr(), gr.data_ptr(), n, ctypes.byref(of), None)
+        capi.call("wd_opt_dense", w2.data_ptr(), None, None, gr.data_ptr(), n, ctypes.byref(os_), None)
+    torch.cuda.synchronize()
+    assert torch.allclose(w1, w2, rtol=1e-5, atol=1e-6)
 
 
 def test_checkpoint_round_trip_restores_slots(tmp_path):

@@ -122,6 +122,49 @@ def test_no_batch_norm_and_other_activation():
     _run(s)
 
 
+@pytest.mark.parametrize("mode,hidden,dnn_opt,dropout", [
+    ("simple", (32, 16, 8), None, 0.0), ("dense", (24, 12), None, 0.0), ("resnet", (16, 8), ("Adam", 0.01, 0.9, 0.999, 1e-8), 0.0),
+    ("first_dense", (16, 8, 8), ("RMSProp", 0.01, 0.8, 0.5, 1e-6, True), 0.2), ("last_dense", (16, 12), ("Ftrl", 0.05, 0.001, 0.01, 0.1), 0.0)])
+def test_crelu_train_steps_match_oracle(mode, hidden, dnn_opt, dropout):
+    """activation `crelu` (python/lib/utils/model_util.py:52, tf.nn.crelu = concat(relu(z), relu(-z))): every layer hands 2N
+    features to its BN and to the next layer; the TF variables stay kernel [K, N] / bias [N].  The engine runs a relu layer of
+    width 2N with tied halves; the oracle computes tf.nn.crelu literally (torch autograd)."""
+    from wide_deep_amd import synth
+    from wide_deep_amd.engine import WideDeepEngine
+    s = _spec(mode=mode, hidden=hidden)
+    s.activation = "crelu"
+    if dnn_opt:
+        s.dnn_opt = dnn_opt
+    if dropout:
+        s.dropout = dropout
+    eng, ora = _run(s, steps=4)
+    assert eng.crelu and not eng.chain
+    st = eng.export_state()
+    # TF shapes: kernel of layer 1 has 2 * hidden[0] (+ whatever the mode concatenates) rows and hidden[1] columns
+    k0, k1 = st["dnn/dnn_1/hiddenlayer_0/kernel"], st["dnn/dnn_1/hiddenlayer_1/kernel"]
+    assert k0.shape[1] == hidden[0] and k1.shape[1] == hidden[1] and st["dnn/dnn_1/hiddenlayer_0/bias"].shape == (hidden[0],)
+    assert st["dnn/dnn_1/hiddenlayer_0/batch_normalization/gamma"].shape == (2 * hidden[0],)
+    if mode in ("simple", "last_dense"):
+        assert k1.shape[0] == 2 * hidden[0]
+    # the mirrored halves stayed exact mirrors (weights odd, accumulators even)
+    m = eng.towers[0]["metas"][0]
+    W = eng.P[m["w_off"]: m["w_off"] + m["K"] * m["N"]].view(m["K"], m["N"])
+    assert torch.equal(W[:, :m["N_tf"]], -W[:, m["N_tf"]:]) and float(W.abs().max()) > 0
+    if eng.Pacc is not None and s.dnn_opt[0] in ("Adagrad", "Ftrl"):
+        A = eng.Pacc[m["w_off"]: m["w_off"] + m["K"] * m["N"]].view(m["K"], m["N"])
+        assert torch.equal(A[:, :m["N_tf"]], A[:, m["N_tf"]:])
+    # checkpoint round trip: a fresh engine restored from the TF-shaped state continues identically
+    b = WideDeepEngine(s, max_batch=128, seed=11)
+    b.import_state(st)
+    hb = synth.make_raw_batch(eng.plan, 96, seed=777, pos_rate=0.3)
+    eng.train_step(synth.to_device_ids(eng.plan, hb)); b.train_step(synth.to_device_ids(b.plan, hb))
+    torch.cuda.synchronize()
+    if not dropout:       # (dropout: the two engines draw from different seeds)
+        sa, sb = eng.export_state(), b.export_state()
+        for k in sa:
+            assert torch.equal(sa[k], sb[k]), k
+
+
 def test_mixed_embedding_dims_and_odd_sizes():
     s = _spec(n_sparse=6, hidden=(20, 10), n_dense=1)
     for i, d in enumerate([4, 8, 16, 32, 64, 8]):

@@ -169,6 +169,80 @@ def test_optimizer_restatements_hand_computed():
     assert O.adam_pow_names(("Adagrad", 1, .1), ("Adam", 1, .9, .999, 1e-8)) == {"linear": ("beta1_power", "beta2_power")}
 
 
+def test_ftrl_learning_rate_power_and_centered_rmsprop_hand_computed():
+    """FtrlCompute's general branch (training_ops.cc) and ApplyCenteredRMSProp on numbers small enough to follow by hand,
+    plus the two equivalences TF's own ftrl_test.py checks: lr_power = -0.5 is the default branch, and lr_power = 0 without
+    regularisation from zero weights is gradient descent (testEquivGradientDescentwithoutRegularization)."""
+    import numpy as np
+    import torch
+    from oracle import oracle as O
+    f = lambda *v: torch.tensor(v, dtype=torch.float32)
+    # lr_power = -1: accum^1.  n: 0.1 -> 4.1; z = 0 + 2 - (4.1 - 0.1) / 0.5 * 1 = -6; quad = 4.1 / 0.5 + 2 * 0.25 = 8.7;
+    # |z| > l1 = 1: w = (sign(z) * 1 - z) / quad = (-1 + 6) / 8.7
+    st = {"w": f(1.0), "w/Ftrl_1": f(0.0), "w/Ftrl": f(0.1)}
+    O.opt_apply_dense(("Ftrl", 0.5, 1.0, 0.25, 0.1, -1.0), st, "w", f(2.0), None)
+    assert abs(float(st["w/Ftrl"]) - 4.1) < 1e-6 and abs(float(st["w/Ftrl_1"]) + 6.0) < 1e-5
+    assert abs(float(st["w"]) - 5.0 / 8.7) < 1e-6
+    # sparse form: only the listed row moves, same numbers
+    st = {"t": torch.ones(2, 1), "t/Ftrl_1": torch.zeros(2, 1), "t/Ftrl": torch.full((2, 1), 0.1)}
+    O.opt_apply_rows(("Ftrl", 0.5, 1.0, 0.25, 0.1, -1.0), st, "t", np.asarray([1]), f(2.0).reshape(1, 1), None)
+    assert float(st["t"][0]) == 1.0 and float(st["t/Ftrl"][0]) == np.float32(0.1) and abs(float(st["t"][1]) - 5.0 / 8.7) < 1e-6
+    # lr_power = -0.5 given explicitly through the general formula == the default branch
+    g = torch.tensor([0.3, -1.2, 2.0, 0.0])
+    a = {"w": f(0.5, -0.2, 0.0, 1.0), "w/Ftrl_1": f(0.1, 0.0, -0.3, 0.2), "w/Ftrl": f(0.1, 0.4, 0.1, 2.0)}
+    wn, zn, nn = O._ftrl_general(a["w"], a["w/Ftrl_1"], a["w/Ftrl"], g, 0.1, 0.05, 0.5, -0.5)
+    O.opt_apply_dense(("Ftrl", 0.1, 0.05, 0.5, 0.1), a, "w", g, None)
+    assert torch.allclose(wn, a["w"], rtol=1e-6, atol=1e-7) and torch.allclose(zn, a["w/Ftrl_1"], rtol=1e-6, atol=1e-7)
+    assert torch.allclose(nn, a["w/Ftrl"])
+    # lr_power = 0, l1 = l2 = 0, w0 = 0: three Ftrl steps == three SGD steps
+    st = {"w": f(0.0, 0.0), "w/Ftrl_1": f(0.0, 0.0), "w/Ftrl": f(0.1, 0.1)}
+    sg = {"w": f(0.0, 0.0)}
+    for gi in (f(0.1, 0.2), f(-0.3, 0.05), f(0.02, -0.04)):
+        O.opt_apply_dense(("Ftrl", 3.0, 0.0, 0.0, 0.1, 0.0), st, "w", gi, None)
+        O.opt_apply_dense(("SGD", 3.0), sg, "w", gi, None)
+    assert torch.allclose(st["w"], sg["w"], rtol=1e-6, atol=1e-7)
+    # centered RMSProp, decay 0.9: ms = 1 + (4 - 1) * 0.1 = 1.3; mg = 0 + (2 - 0) * 0.1 = 0.2;
+    # mom = 0.5 * 0 + 0.1 * 2 / sqrt(1.3 - 0.04 + 0) ; var = 1 - mom
+    opt = ("RMSProp", 0.1, 0.9, 0.5, 0.0, True)
+    assert O.slot_names(opt) == ("/RMSProp", "/RMSProp_2", "/RMSProp_1")     # rms, momentum, mg in TF's creation order
+    st = {"w": f(1.0), "w/RMSProp": f(1.0), "w/RMSProp_1": f(0.0), "w/RMSProp_2": f(0.0)}
+    O.opt_apply_dense(opt, st, "w", f(2.0), None)
+    mom = 0.1 * 2 / np.sqrt(1.26)
+    assert abs(float(st["w/RMSProp"]) - 1.3) < 1e-6 and abs(float(st["w/RMSProp_1"]) - 0.2) < 1e-7
+    assert abs(float(st["w/RMSProp_2"]) - mom) < 1e-6 and abs(float(st["w"]) - (1 - mom)) < 1e-6
+    st = {"t": torch.ones(2, 1), "t/RMSProp": torch.ones(2, 1), "t/RMSProp_1": torch.zeros(2, 1), "t/RMSProp_2": torch.zeros(2, 1)}
+    O.opt_apply_rows(opt, st, "t", np.asarray([1]), f(2.0).reshape(1, 1), None)
+    assert float(st["t"][0]) == 1.0 and float(st["t/RMSProp_1"][0]) == 0.0 and abs(float(st["t"][1]) - (1 - mom)) < 1e-6
+    assert abs(float(st["t/RMSProp_1"][1]) - 0.2) < 1e-7
+
+
+def test_crelu_equals_a_relu_layer_of_twice_the_width_with_tied_halves():
+    """What the engine builds for activation `crelu` (plan.FeaturePlan): relu(x [W | -W] + [b | -b]) IS
+    tf.nn.crelu(x W + b) = concat(relu(z), relu(-z)) bit for bit, and dL/dW = G'[:, :N] - G'[:, N:]."""
+    import torch
+    from oracle import oracle as O
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(37, 19, generator=g)
+    W = torch.randn(19, 8, generator=g).requires_grad_(True)
+    b = torch.randn(8, generator=g).requires_grad_(True)
+    V = torch.randn(16, 3, generator=g)
+    y = O.ACTIVATIONS["crelu"](x @ W + b)
+    assert y.shape == (37, 16)
+    (y @ V).sum().backward()
+    W2 = torch.cat([W.detach(), -W.detach()], dim=1).requires_grad_(True)
+    b2 = torch.cat([b.detach(), -b.detach()]).requires_grad_(True)
+    y2 = torch.relu(x @ W2 + b2)
+    assert torch.equal(y.detach(), y2.detach())
+    (y2 @ V).sum().backward()
+    assert torch.allclose(W.grad, W2.grad[:, :8] - W2.grad[:, 8:], rtol=1e-5, atol=1e-6)
+    assert torch.allclose(b.grad, b2.grad[:8] - b2.grad[8:], rtol=1e-5, atol=1e-6)
+    # tower_forward: BN (2N features) and the next kernel (2N rows) follow the doubled width
+    tw = {"kernel": [W.detach(), torch.randn(16, 4, generator=g)], "bias": [b.detach(), torch.zeros(4)],
+          "gamma": [torch.ones(16), torch.ones(8)], "beta": [torch.zeros(16), torch.zeros(8)],
+          "logits_kernel": torch.randn(8, 1, generator=g), "logits_bias": torch.zeros(1)}
+    assert O.tower_forward(x, tw, "simple", "crelu", True).shape == (37, 1)
+
+
 def test_batched_column_calls_equal_per_column_calls_bit_for_bit():
     """OracleWideDeep.batched (bench.py's cpu_baseline configuration: all sparse columns of a step through one C call each
     way, columns side by side under OpenMP) must be the SAME arithmetic as the per-column path the parity tests use."""

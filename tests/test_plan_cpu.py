@@ -3,7 +3,7 @@ bucket geometry of the fused sparse update, optimizer slot naming."""
 import pytest
 
 from wide_deep_amd.plan import (FeaturePlan, OPT_SLOT_NAMES, TowerLayout, adam_pow_names, bucket_geometry, criteo_spec,
-                                opt_params, opt_slot_init)
+                                opt_params, opt_slot_init, opt_slot_names)
 
 
 @pytest.mark.parametrize("mode", ["simple", "dense", "resnet", "last_dense", "first_dense"])
@@ -79,7 +79,12 @@ def test_optimizer_slot_tables_are_consistent():
         assert len(opt_params(o)) == 3
     assert opt_slot_init(opts[1]) == (None, 0.1) and opt_slot_init(opts[2]) == (0.0, 0.2)
     assert opt_slot_init(opts[3]) == (1.0, 0.0)                       # rms slot starts at ones
-    assert opt_params(opts[2]) == (0.5, 1.0, 0.0) and opt_params(opts[4]) == (0.9, 0.999, 1e-8)
+    assert opt_params(opts[2]) == (0.5, 1.0, -0.5) and opt_params(opts[4]) == (0.9, 0.999, 1e-8)
+    assert opt_params(("Ftrl", 0.1, 0.5, 1.0, 0.2, -0.7)) == (0.5, 1.0, -0.7)          # p2 = learning_rate_power
+    # RMSPropOptimizer._create_slots: rms, [mg,] momentum -> /RMSProp, [/RMSProp_1,] /RMSProp_1 or _2
+    assert opt_slot_names(opts[3]) == ("/RMSProp", "/RMSProp_1", None)
+    assert opt_slot_names(opts[3] + (True,)) == ("/RMSProp", "/RMSProp_2", "/RMSProp_1")
+    assert opt_slot_names(opts[1]) == (None, "/Adagrad", None)
     assert adam_pow_names(opts[4], opts[4], True, True) == {"dnn": ("beta1_power", "beta2_power"),
                                                             "linear": ("beta1_power_1", "beta2_power_1")}
     assert adam_pow_names(opts[4], opts[4], False, True) == {"linear": ("beta1_power", "beta2_power")}

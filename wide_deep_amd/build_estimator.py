@@ -26,11 +26,9 @@ _ACTIVATIONS = ("crelu", "elu", "leaky_relu", "relu", "relu6", "selu", "sigmoid"
 def activation_fn(opt):
     """The ten names python/lib/utils/model_util.py:28-59 accepts, same ValueError for anything else.  Nine are built into
     the tower kernels (capi.ACT_IDS); `crelu` (concat(relu(x), relu(-x)): doubles the width every layer hands to the next)
-    is not."""
+    runs as a relu layer of twice the width with tied halves (plan.FeaturePlan)."""
     if opt not in _ACTIVATIONS:
         raise ValueError("Unsupported activation name: %s. Supported names are: %s" % (opt, _ACTIVATIONS))
-    if opt == "crelu":
-        raise NotImplementedError("activation `crelu` doubles the layer width and is not built into the tower kernels")
     return opt
 
 
@@ -76,21 +74,26 @@ def parse_optimizer(opt, default_lr):
 def opt_tuple(name, kw):
     """(name, kwargs) -> the optimizer tuple of plan.ModelSpec / the oracle, with the tf.train constructor defaults:
        ("SGD", lr) ("Adagrad", lr, initial_accumulator_value) ("Ftrl", lr, l1, l2, initial_accumulator_value)
-       ("RMSProp", lr, decay, momentum, epsilon) ("Adam", lr, beta1, beta2, epsilon)"""
+       ("RMSProp", lr, decay, momentum, epsilon) ("Adam", lr, beta1, beta2, epsilon)
+    Non-default variants append one element: ("Ftrl", ..., learning_rate_power) when it is not -0.5,
+    ("RMSProp", ..., True) for centered=True."""
     lr = float(kw["learning_rate"])
     if name == "SGD":
         return ("SGD", lr)
     if name == "Adagrad":
         return ("Adagrad", lr, float(kw.get("initial_accumulator_value", 0.1)))
     if name == "Ftrl":
-        if float(kw.get("learning_rate_power", -0.5)) != -0.5 or float(kw.get("l2_shrinkage_regularization_strength", 0.0)) != 0.0:
-            raise NotImplementedError("FtrlOptimizer: only learning_rate_power=-0.5 and no l2 shrinkage are implemented")
-        return ("Ftrl", lr, float(kw.get("l1_regularization_strength", 0.0)),
+        if float(kw.get("l2_shrinkage_regularization_strength", 0.0)) != 0.0:
+            raise NotImplementedError("FtrlOptimizer: l2_shrinkage_regularization_strength is not implemented")
+        lr_power = float(kw.get("learning_rate_power", -0.5))
+        if lr_power > 0.0:      # tf.train.FtrlOptimizer.__init__
+            raise ValueError("learning_rate_power %f needs to be negative or zero" % lr_power)
+        base = ("Ftrl", lr, float(kw.get("l1_regularization_strength", 0.0)),
                 float(kw.get("l2_regularization_strength", 0.0)), float(kw.get("initial_accumulator_value", 0.1)))
+        return base if lr_power == -0.5 else base + (lr_power,)
     if name == "RMSProp":
-        if kw.get("centered"):
-            raise NotImplementedError("RMSPropOptimizer(centered=True) is not implemented")
-        return ("RMSProp", lr, float(kw.get("decay", 0.9)), float(kw.get("momentum", 0.0)), float(kw.get("epsilon", 1e-10)))
+        base = ("RMSProp", lr, float(kw.get("decay", 0.9)), float(kw.get("momentum", 0.0)), float(kw.get("epsilon", 1e-10)))
+        return base + (True,) if kw.get("centered") else base
     if name == "Adam":
         return ("Adam", lr, float(kw.get("beta1", 0.9)), float(kw.get("beta2", 0.999)), float(kw.get("epsilon", 1e-8)))
     raise ValueError("Unsupported optimizer: %s" % name)

@@ -57,11 +57,12 @@ WD_TN_GROUP_MAX = 20
 
 
 WD_OPT_KINDS = {"SGD": 0, "Adagrad": 1, "Ftrl": 2, "RMSProp": 3, "Adam": 4}
+WD_OPT_RMSPROP_CENTERED = 6
 
 
 class WdOpt(ctypes.Structure):
     _fields_ = [("kind", ctypes.c_int32), ("lr", ctypes.c_float), ("p0", ctypes.c_float), ("p1", ctypes.c_float),
-                ("p2", ctypes.c_float), ("pad_", ctypes.c_int32), ("pow", ctypes.c_void_p)]
+                ("p2", ctypes.c_float), ("pad_", ctypes.c_int32), ("pow", ctypes.c_void_p), ("slot_c", ctypes.c_void_p)]
 
 
 class WdChainInput(ctypes.Structure):
@@ -160,6 +161,7 @@ _PROTOS = {
     "wd_gemm_tn_splitk": [P, I64, P, I64, P, I64, I64, I64, I32, I32, P],
     "wd_fold_affine_all": [P, P, I32, I64, F32, P, I64, P, I64, P],
     "wd_mlp_finalize_all": [P, I32, I64, P, F32, P, P],
+    "wd_crelu_tie": [P, I64, I64, I64, I64, P],
     "wd_mlp_finalize_adagrad_all": [P, I32, I64, P, P, F32, P, F32, P],
     "wd_logits_head_blocks": [I64, I64],
     "wd_gemm_tn_splitk_group": [P, I32, P],

@@ -960,6 +960,29 @@ extern "C" int wd_adagrad_dense(float *w, float *accum, const float *g, int64_t 
   return wd::check_launch("wd_adagrad_dense");
 }
 
+namespace {
+// crelu layers (python/lib/utils/model_util.py:52, tf.nn.crelu) run as relu layers of width 2N whose kernel is [W | -W]:
+// dL/dW[k][n] = G'[k][n] - G'[k][N + n]; the left half keeps it, the right half its negation (so that any sign-symmetric
+// optimizer keeps the halves exact mirrors).  Row K of the grid = the bias [b | -b].
+__global__ void __launch_bounds__(256)
+k_crelu_tie(float *__restrict__ G, int64_t w_off, int64_t b_off, int64_t K, int64_t N) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (K + 1) * N) return;
+  const int64_t k = i / N, n = i - k * N;
+  float *row = k < K ? G + w_off + k * 2 * N : G + b_off;
+  const float g = row[n] - row[N + n];
+  row[n] = g;
+  row[N + n] = -g;
+}
+}  // namespace
+
+extern "C" int wd_crelu_tie(float *Gflat, int64_t w_off, int64_t b_off, int64_t K, int64_t N, wd_stream_t stream) {
+  WD_REQUIRE(Gflat && K > 0 && N > 0, "null pointer / empty layer");
+  hipLaunchKernelGGL(k_crelu_tie, dim3((unsigned)wd::ceil_div((K + 1) * N, 256)), dim3(256), 0, wd::as_stream(stream),
+                     Gflat, w_off, b_off, K, N);
+  return wd::check_launch("wd_crelu_tie");
+}
+
 extern "C" int wd_fold_affine_all(const float *P, const wd_mlp_layer_t *layers_dev, int32_t nlayers, int64_t max_n,
                                   float inv, float *zero_a, int64_t zero_a_n, float *zero_b, int64_t zero_b_n,
                                   wd_stream_t stream) {

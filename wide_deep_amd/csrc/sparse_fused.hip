@@ -242,7 +242,7 @@ __device__ __forceinline__ float4 adagrad4(float4 &a, float4 w, float4 g, float 
 
 // Any tf.train optimizer the reference accepts (python/lib/utils/model_util.py:84-90), one parameter at a time.
 // Slots: a / b of include/wd_hip.h (wd_opt_t): Adagrad b = accumulator; Ftrl a = linear (z), b = accumulator (n);
-// RMSProp a = rms, b = momentum; Adam a = m, b = v.
+// RMSProp a = rms, b = momentum (centered: c = mean gradient); Adam a = m, b = v.
 struct OptK {
   int32_t kind;
   float lr, p0, p1, p2;
@@ -251,7 +251,21 @@ struct OptK {
 
 __device__ __forceinline__ void ftrl_update(float &w, float &z, float &n, float g, float lr, float l1, float l2);
 
-__device__ __forceinline__ void opt_step(const OptK &o, float &w, float &a, float &b, float g) {
+// FtrlOptimizer with learning_rate_power != -0.5 (TF training_ops.cc FtrlCompute, general branch): accum^(-lr_power) in
+// place of sqrt(accum)
+__device__ __forceinline__ void ftrl_update_pow(float &w, float &z, float &n, float g, float lr, float l1, float l2,
+                                                float lr_power) {
+  const float n_new = n + g * g;
+  const float pn = powf(n_new, -lr_power);
+  z += g - (pn - powf(n, -lr_power)) / lr * w;
+  const float quad = pn / lr + 2.0f * l2;
+  const float sgn = z > 0.f ? 1.f : (z < 0.f ? -1.f : 0.f);
+  const float pre = (sgn * l1 - z) / quad;
+  w = fabsf(z) > l1 ? pre : 0.f;
+  n = n_new;
+}
+
+__device__ __forceinline__ void opt_step(const OptK &o, float &w, float &a, float &b, float &c, float g) {
   switch (o.kind) {
     case WD_OPT_SGD:       // GradientDescentOptimizer: var -= lr * g
       w -= o.lr * g;
@@ -260,8 +274,15 @@ __device__ __forceinline__ void opt_step(const OptK &o, float &w, float &a, floa
       b += g * g;
       w -= o.lr * g / sqrtf(b);
       break;
-    case WD_OPT_FTRL:
-      ftrl_update(w, a, b, g, o.lr, o.p0, o.p1);
+    case WD_OPT_FTRL:      // p2 = learning_rate_power (TF default -0.5; 0 = fixed learning rate)
+      if (o.p2 == -0.5f) ftrl_update(w, a, b, g, o.lr, o.p0, o.p1);
+      else ftrl_update_pow(w, a, b, g, o.lr, o.p0, o.p1, o.p2);
+      break;
+    case WD_OPT_RMSPROP_CENTERED:   // ApplyCenteredRMSProp: + mg += (g - mg)(1 - decay); denominator sqrt(ms - mg^2 + eps)
+      a += (g * g - a) * (1.0f - o.p0);
+      c += (g - c) * (1.0f - o.p0);
+      b = b * o.p1 + o.lr * g / sqrtf(a - c * c + o.p2);
+      w -= b;
       break;
     case WD_OPT_RMSPROP:   // ms += (g^2 - ms)(1 - decay); mom = mom*momentum + lr*g/sqrt(ms + eps); var -= mom
       a += (g * g - a) * (1.0f - o.p0);
@@ -280,6 +301,7 @@ __device__ __forceinline__ void opt_step(const OptK &o, float &w, float &a, floa
 struct UpdArgs {
   float *emb, *accum, *wide, *bias;
   float *accum_a;            // second embedding slot table (generic optimizers; `accum` is slot b)
+  float *accum_c;            // third one (centered RMSProp's mean gradient)
   uint32_t *touched;         // Adam: bit per fused row updated here (wd_adam_untouched does the others)
   OptK oe, ow;               // embedding (dnn scope) / wide + bias (linear scope) optimizer
   const float *pow_e, *pow_w;
@@ -336,13 +358,15 @@ k_bucket_update(UpdArgs u, const int32_t *__restrict__ start, uint64_t *__restri
     for (int k2 = 0; k2 < cnt; ++k2) {
       float w = u.emb[off + k2];
       float a = u.accum_a ? u.accum_a[off + k2] : 0.f, b = u.accum ? u.accum[off + k2] : 0.f;
-      opt_step(u.oe, w, a, b, g[k2]);
+      float c = u.accum_c ? u.accum_c[off + k2] : 0.f;
+      opt_step(u.oe, w, a, b, c, g[k2]);
       u.emb[off + k2] = w;
       if (u.accum_a) u.accum_a[off + k2] = a;
       if (u.accum) u.accum[off + k2] = b;
+      if (u.accum_c) u.accum_c[off + k2] = c;
     }
   };
-  auto wide_apply = [&](float4 &r, float g) { opt_step(u.ow, r.x, r.y, r.z, g); };
+  auto wide_apply = [&](float4 &r, float g) { opt_step(u.ow, r.x, r.y, r.z, r.w, g); };   // line = {w, a, b, c}
   auto touch = [&](uint32_t key) {
     if (GEN && u.touched) atomicOr(&u.touched[key >> 5], 1u << (key & 31));
   };
@@ -368,7 +392,7 @@ k_bucket_update(UpdArgs u, const int32_t *__restrict__ start, uint64_t *__restri
       __syncthreads();
     }
     if (t == 0) {
-      float w = u.bias[0], z = u.bias[1], n = u.bias[2];
+      float w = u.bias[0], z = u.bias[1], n = u.bias[2], c3 = u.bias[3];
       if (GEN) {
         OptK ob = u.ow;
         if (ob.kind == WD_OPT_ADAM) ob.kind = WD_OPT_ADAM_DENSE;   // a dense [1] variable: ApplyAdam's form
@@ -377,12 +401,13 @@ k_bucket_update(UpdArgs u, const int32_t *__restrict__ start, uint64_t *__restri
           n += (redw[0] * redw[0] - n) * (1.0f - ob.p1);
           w -= ob.lr * sqrtf(1.0f - ob.b2p) / (1.0f - ob.b1p) * z / (sqrtf(n) + ob.p2);
         } else {
-          opt_step(ob, w, z, n, redw[0]);
+          opt_step(ob, w, z, n, c3, redw[0]);
         }
       } else {
         ftrl_update(w, z, n, redw[0], u.lr_w, u.l1, u.l2);
       }
       u.bias[0] = w; u.bias[1] = z; u.bias[2] = n;
+      if (GEN) u.bias[3] = c3;
     }
     return;
   }
@@ -723,7 +748,7 @@ extern "C" int wd_sparse_apply(float *emb, float *emb_accum, float *wide, float 
   u.dx = dx; u.dlogit = dlogit; u.ldx = ldx; u.batch = batch; u.S = S; u.nb = nbuckets;
   u.ld_dlogit = ld_dlogit > 0 ? ld_dlogit : 1;
   u.lr_emb = lr_emb; u.lr_w = lr_wide; u.l1 = l1; u.l2 = l2;
-  u.accum_a = nullptr; u.touched = nullptr; u.oe = OptK{}; u.ow = OptK{}; u.pow_e = u.pow_w = nullptr;
+  u.accum_a = u.accum_c = nullptr; u.touched = nullptr; u.oe = OptK{}; u.ow = OptK{}; u.pow_e = u.pow_w = nullptr;
   hipLaunchKernelGGL(k_bucket_update<false>, dim3((unsigned)nbuckets + 1), dim3(256), 0, wd::as_stream(stream), u,
                      bucket_start, pairs);
   return wd::check_launch("wd_sparse_apply");
@@ -738,7 +763,9 @@ static OptK to_optk(const wd_opt_t *o) {
   return k;
 }
 
-static bool opt_ok(const wd_opt_t *o) { return o && o->kind >= WD_OPT_SGD && o->kind <= WD_OPT_ADAM; }
+static bool opt_ok(const wd_opt_t *o) {
+  return o && ((o->kind >= WD_OPT_SGD && o->kind <= WD_OPT_ADAM) || o->kind == WD_OPT_RMSPROP_CENTERED);
+}
 
 // wd_sparse_apply with the optimizer of each scope chosen by the caller (model_util.py:84-90).
 extern "C" int wd_sparse_apply_opt(float *emb, float *emb_a, float *emb_b, float *wide, float *bias, const wd_slot_t *slots,
@@ -755,10 +782,12 @@ extern "C" int wd_sparse_apply_opt(float *emb, float *emb_a, float *emb_b, float
     const int k = emb_opt->kind;
     WD_REQUIRE(k == WD_OPT_SGD || emb_b, "this optimizer needs slot table b");
     WD_REQUIRE(k == WD_OPT_SGD || k == WD_OPT_ADAGRAD || emb_a, "this optimizer needs slot table a");
+    WD_REQUIRE(k != WD_OPT_RMSPROP_CENTERED || emb_opt->slot_c, "centered RMSProp needs wd_opt_t.slot_c (mean-gradient table)");
   }
   const bool adam = (emb && emb_opt->kind == WD_OPT_ADAM) || ((wide || bias) && wide_opt->kind == WD_OPT_ADAM);
   WD_REQUIRE(!adam || touched, "Adam needs the touched-row bitmap (wd_adam_untouched updates the other rows)");
   UpdArgs u;
+  u.accum_c = (emb && emb_opt->kind == WD_OPT_RMSPROP_CENTERED) ? emb_opt->slot_c : nullptr;
   u.emb = emb; u.accum = emb_b; u.accum_a = emb_a; u.wide = wide; u.bias = bias; u.slots = slots; u.bag_offs = bag_offs;
   u.dx = dx; u.dlogit = dlogit; u.ldx = ldx; u.batch = batch; u.S = S; u.nb = nbuckets;
   u.ld_dlogit = ld_dlogit > 0 ? ld_dlogit : 1;
@@ -776,25 +805,26 @@ namespace {
 
 // dense variables of a scope (tower kernels / biases / BN affines): one elementwise launch, tf.train kernels' forms
 __global__ void __launch_bounds__(256)
-k_opt_dense(float *__restrict__ w, float *__restrict__ sa, float *__restrict__ sb, const float *__restrict__ g, int64_t n,
-            OptK o, const float *__restrict__ pw) {
+k_opt_dense(float *__restrict__ w, float *__restrict__ sa, float *__restrict__ sb, float *__restrict__ sc,
+            const float *__restrict__ g, int64_t n, OptK o, const float *__restrict__ pw) {
   if (pw) { o.b1p = pw[0]; o.b2p = pw[1]; }
   const float lr_t = o.kind == WD_OPT_ADAM ? o.lr * sqrtf(1.0f - o.b2p) / (1.0f - o.b1p) : 0.f;
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (; i < n; i += stride) {
-    float wv = w[i], a = sa ? sa[i] : 0.f, b = sb ? sb[i] : 0.f;
+    float wv = w[i], a = sa ? sa[i] : 0.f, b = sb ? sb[i] : 0.f, c = sc ? sc[i] : 0.f;
     const float gi = g[i];
     if (o.kind == WD_OPT_ADAM) {   // ApplyAdam: m += (g - m)(1 - b1); v += (g^2 - v)(1 - b2); var -= lr_t m / (sqrt(v) + eps)
       a += (gi - a) * (1.0f - o.p0);
       b += (gi * gi - b) * (1.0f - o.p1);
       wv -= lr_t * a / (sqrtf(b) + o.p2);
     } else {
-      opt_step(o, wv, a, b, gi);
+      opt_step(o, wv, a, b, c, gi);
     }
     w[i] = wv;
     if (sa) sa[i] = a;
     if (sb) sb[i] = b;
+    if (sc) sc[i] = c;
   }
 }
 
@@ -852,8 +882,10 @@ extern "C" int wd_opt_dense(float *w, float *slot_a, float *slot_b, const float 
   WD_REQUIRE(w && g && opt_ok(opt), "null pointer / bad optimizer");
   WD_REQUIRE(opt->kind == WD_OPT_SGD || slot_b, "this optimizer needs slot b");
   WD_REQUIRE(opt->kind == WD_OPT_SGD || opt->kind == WD_OPT_ADAGRAD || slot_a, "this optimizer needs slot a");
+  WD_REQUIRE(opt->kind != WD_OPT_RMSPROP_CENTERED || opt->slot_c, "centered RMSProp needs wd_opt_t.slot_c");
   const int blocks = (int)std::min<int64_t>(wd::ceil_div(n, 256), 2048);
-  hipLaunchKernelGGL(k_opt_dense, dim3(blocks), dim3(256), 0, wd::as_stream(stream), w, slot_a, slot_b, g, n, to_optk(opt),
+  hipLaunchKernelGGL(k_opt_dense, dim3(blocks), dim3(256), 0, wd::as_stream(stream), w, slot_a, slot_b,
+                     opt->kind == WD_OPT_RMSPROP_CENTERED ? opt->slot_c : nullptr, g, n, to_optk(opt),
                      opt->kind == WD_OPT_ADAM ? opt->pow : nullptr);
   return wd::check_launch("wd_opt_dense");
 }

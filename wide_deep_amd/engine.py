@@ -18,8 +18,8 @@ import torch
 
 from . import capi
 from .capi import call, ptr
-from .plan import (BN_EPS, FeaturePlan, ModelSpec, OPT_SLOT_NAMES, adam_pow_names, bucket_geometry, opt_params,
-                   opt_slot_init)
+from .plan import (BN_EPS, FeaturePlan, ModelSpec, OPT_SLOT_ODD, adam_pow_names, bucket_geometry, ftrl_lr_power, opt_params,
+                   opt_slot_init, opt_slot_names, rmsprop_centered)
 
 
 class DeviceBatch:
@@ -57,7 +57,7 @@ class WideDeepEngine:
         # the reference's defaults (conf/model.yaml: Adagrad on the dnn scope, Ftrl on the linear scope) take the
         # specialised kernels; any other tf.train optimizer of model_util.py:84-90 the generic ones (wd_opt_t)
         self.default_opts = ((not spec.has_deep or spec.dnn_opt[0] == "Adagrad") and
-                             (not spec.has_wide or spec.lin_opt[0] == "Ftrl"))
+                             (not spec.has_wide or (spec.lin_opt[0] == "Ftrl" and ftrl_lr_power(spec.lin_opt) == -0.5)))
         if tower_dtype not in ("fp32", "fp16"):
             raise ValueError("tower_dtype must be 'fp32' (exact fp32 MFMA) or 'fp16' (half operands, fp32 accumulate)")
         self.half = tower_dtype == "fp16"     # BASELINE configs[4]: fp16 MFMA dense path, fp32 embeddings
@@ -67,7 +67,8 @@ class WideDeepEngine:
         self.max_batch = int(max_batch)
         self.max_nnz = int(max_nnz) if max_nnz else self.max_batch * max(plan.S, 1) * 8
         self.inv = 1.0 / math.sqrt(1.0 + BN_EPS)
-        self.act_id = capi.ACT_IDS[spec.activation]
+        self.crelu = plan.crelu      # a relu layer of twice the width with tied halves (plan.py)
+        self.act_id = capi.ACT_IDS["relu" if self.crelu else spec.activation]
         self.global_step = 0
         dev = self.device
         f32 = dict(dtype=torch.float32, device=dev)
@@ -126,6 +127,7 @@ class WideDeepEngine:
             self.emb = torch.zeros(ne, **f32)
             self.emb_a = torch.full((ne,), dnn_a, **f32) if dnn_a is not None else None      # optimizer slot a
             self.emb_acc = torch.full((ne,), dnn_b, **f32) if dnn_b is not None else None    # optimizer slot b
+            self.emb_c = torch.zeros(ne, **f32) if rmsprop_centered(spec.dnn_opt) else None  # slot c (mean gradient)
             for i, s in enumerate(plan.slots):
                 if plan.emb_off[i] >= 0:
                     v = self.emb[plan.emb_off[i]: plan.emb_off[i] + s.num_buckets * s.dim]
@@ -133,9 +135,10 @@ class WideDeepEngine:
                     # embedding_column initializer: truncated_normal(0, 1/sqrt(dim))  
                     torch.nn.init.trunc_normal_(v, mean=0.0, std=std, a=-2 * std, b=2 * std, generator=gt)
         else:
-            self.emb = self.emb_a = self.emb_acc = None
+            self.emb = self.emb_a = self.emb_acc = self.emb_c = None
         if spec.has_wide:
-            self.wide = torch.zeros(max(plan.total_rows, 1), 4, **f32)   # {w, slot a, slot b, -}  (Ftrl: {w, z, n, -})
+            # {w, slot a, slot b, slot c}  (Ftrl: {w, z, n, -}; slot c = centered RMSProp's mean gradient, starts at 0)
+            self.wide = torch.zeros(max(plan.total_rows, 1), 4, **f32)
             self.bias = torch.zeros(4, **f32)
             for col, v in ((1, lin_a), (2, lin_b)):
                 if v is not None:
@@ -151,6 +154,10 @@ class WideDeepEngine:
                 continue
             o = capi.WdOpt()
             o.kind, o.lr = capi.WD_OPT_KINDS[opt[0]], float(opt[1])
+            if rmsprop_centered(opt):
+                o.kind = capi.WD_OPT_RMSPROP_CENTERED
+                if scope == "dnn":
+                    o.slot_c = self.emb_c.data_ptr()
             o.p0, o.p1, o.p2 = opt_params(opt)
             if opt[0] == "Adam":
                 self.pow[scope] = torch.tensor([opt[2], opt[3]], **f32)
@@ -166,6 +173,12 @@ class WideDeepEngine:
             self.P = torch.zeros(n, **f32)
             self.Pa = torch.full((n,), dnn_a, **f32) if dnn_a is not None else None       # optimizer slot a
             self.Pacc = torch.full((n,), dnn_b, **f32) if dnn_b is not None else None     # optimizer slot b
+            self.Pc = torch.zeros(n, **f32) if rmsprop_centered(spec.dnn_opt) else None   # slot c
+            # the dnn-scope optimizer as applied to the flat dense buffer (its slot c is Pc, the tables' is emb_c)
+            od = capi.WdOpt()
+            ctypes.memmove(ctypes.byref(od), ctypes.byref(self.opt_c["dnn"]), ctypes.sizeof(od))
+            od.slot_c = self.Pc.data_ptr() if self.Pc is not None else None
+            self.opt_c["dnn_dense"] = od
             self.G = torch.zeros(n, **f32)
             for ti, tl in enumerate(plan.towers):
                 metas = plan.layer_meta[ti]
@@ -198,12 +211,14 @@ class WideDeepEngine:
                     tw["nsplit"].append(ns)
                     tw["Gpart"].append(torch.zeros(ns * (K + 1) * N, **f32))
                     # tf.glorot_uniform_initializer kernel, zero bias, gamma 1, beta 0  
-                    Ktf = len(plan.tf_rows_of_layer(ti, l))
-                    lim = math.sqrt(6.0 / (Ktf + N))
+                    Ktf, Ntf = len(plan.tf_rows_of_layer(ti, l)), m["N_tf"]
+                    lim = math.sqrt(6.0 / (Ktf + Ntf))
                     W = self.P[m["w_off"]: m["w_off"] + K * N].view(K, N)
                     rows = torch.from_numpy(plan.tf_rows_of_layer(ti, l)).to(dev)
-                    Wtf = (torch.rand(Ktf, N, generator=g, **f32) * 2 - 1) * lim
-                    W[rows] = Wtf
+                    Wtf = (torch.rand(Ktf, Ntf, generator=g, **f32) * 2 - 1) * lim
+                    W[rows, :Ntf] = Wtf
+                    if Ntf != N:       # crelu: mirrored half
+                        W[rows, Ntf:] = -Wtf
                     if "gamma_off" in m:
                         self.P[m["gamma_off"]: m["gamma_off"] + N] = 1.0
                 if self.half:
@@ -282,7 +297,7 @@ class WideDeepEngine:
             self.all_simple = len(self.towers) == 1 and self.towers[0]["layout"].mode == "simple"
             self.dnn_logit = torch.zeros(B, **f32)
         else:
-            self.P = self.Pa = self.Pacc = self.G = None
+            self.P = self.Pa = self.Pacc = self.Pc = self.G = None
             self.dnn_logit = None
 
         # ---- per-step buffers --------------------------------------------------------------
@@ -348,7 +363,7 @@ class WideDeepEngine:
         self._chain_tile_stamps = None   # diagnostics: device uint64[2 * tiles] realtime-clock stamps (bench.py: in-step gather span)
         self._chain_stamps = None    # diagnostics: device int64[64] for the tower kernel's stage stamps (scripts/bench_chain.py)
         plan = self.plan
-        if self.half or self.dropout or len(self.towers) != 1 or os.environ.get("WD_CHAIN", "1") == "0":
+        if self.half or self.dropout or self.crelu or len(self.towers) != 1 or os.environ.get("WD_CHAIN", "1") == "0":
             return
         tw = self.towers[0]
         tl, metas, L = tw["layout"], tw["metas"], tw["L"]
@@ -954,7 +969,7 @@ class WideDeepEngine:
                     raise NotImplementedError("multi-tower + all-layer finalize")  # guarded in __init__
                 # single GPU + Adagrad: the dense update rides in the finalize launch (nothing reduces G in between)
                 fused_opt = (self.default_opts and type(self)._reduce_dense_grads is WideDeepEngine._reduce_dense_grads
-                             and os.environ.get("WD_FUSE_ADAGRAD", "1") != "0")
+                             and not self.crelu and os.environ.get("WD_FUSE_ADAGRAD", "1") != "0")
                 if self.chain and fused_opt:
                     # gradients from the partials + Adagrad + the packed kernels of the next step, one launch
                     self._chain_tail(capi.WD_TAIL_GRAD | capi.WD_TAIL_UPDATE | capi.WD_TAIL_PACK, st)
@@ -983,6 +998,13 @@ class WideDeepEngine:
                     tl = tw["layout"]
                     dx0.add_(tw["dact"][:B, tl.seg_start[0]: tl.seg_start[0] + w0])
             self._reduce_dense_grads()
+            if self.crelu:
+                # tied halves: dL/dW = G'[:, :N] - G'[:, N:]; both halves then take +g / -g through the (sign-symmetric)
+                # optimizer and stay exact mirrors of each other, slots included
+                for tw in self.towers:
+                    for l in range(tw["L"]):
+                        m = tw["metas"][l]
+                        call("wd_crelu_tie", ptr(self.G), m["w_off"], m["b_off"], m["K"], m["N_tf"], st)
             if fused_opt:
                 pass
             elif self.default_opts:
@@ -990,7 +1012,7 @@ class WideDeepEngine:
                      st)
             else:
                 call("wd_opt_dense", ptr(self.P), ptr(self.Pa), ptr(self.Pacc), ptr(self.G), self.P.numel(),
-                     ctypes.byref(self.opt_c["dnn"]), st)
+                     ctypes.byref(self.opt_c["dnn_dense"]), st)
             if self._fold_at_end() and not (self.chain and fused_opt):   # the NEXT step's packed kernels
                 self._fold(False, st)
                 self._folded = True
@@ -1072,8 +1094,7 @@ class WideDeepEngine:
     def _slot_bufs(self, scope):
         """[(buffer, checkpoint-name suffix)] of a scope's variable + its optimizer slots."""
         opt = self.spec.dnn_opt if scope == "dnn" else self.spec.lin_opt
-        sa, sb = OPT_SLOT_NAMES[opt[0]]
-        return sa, sb
+        return opt_slot_names(opt)
 
     def export_state(self, tables=True):
         """TF-named variables (+ optimizer slots).  tables=False: dense-tower parameters, bias and counters only (the
@@ -1081,25 +1102,25 @@ class WideDeepEngine:
         plan, spec = self.plan, self.spec
         out = {}
         if spec.has_deep:
-            sa, sb = self._slot_bufs("dnn")
+            sa, sb, sc = self._slot_bufs("dnn")
             for i, s in enumerate(plan.slots):
                 if tables and plan.emb_off[i] >= 0:
                     nm = "dnn/input_from_feature_columns/input_layer/%s/embedding_weights" % s.deep_name
                     sl = slice(plan.emb_off[i], plan.emb_off[i] + s.num_buckets * s.dim)
-                    for buf, suf in ((self.emb, ""), (self.emb_a, sa), (self.emb_acc, sb)):
+                    for buf, suf in ((self.emb, ""), (self.emb_a, sa), (self.emb_acc, sb), (self.emb_c, sc)):
                         if suf is not None:
                             out[nm + suf] = buf[sl].view(s.num_buckets, s.dim).cpu().clone()
             for ti, tw in enumerate(self.towers):
                 p = "dnn/dnn_%d/" % (ti + 1)
                 for l, m in enumerate(tw["metas"]):
-                    K, N = m["K"], m["N"]
+                    K, N, Ntf = m["K"], m["N"], m["N_tf"]
                     scope = p + ("hiddenlayer_%d/" % l if l < tw["L"] else "logits/")
                     rows = torch.from_numpy(plan.tf_rows_of_layer(ti, l)).to(self.device)
-                    for buf, suf in ((self.P, ""), (self.Pa, sa), (self.Pacc, sb)):
+                    for buf, suf in ((self.P, ""), (self.Pa, sa), (self.Pacc, sb), (self.Pc, sc)):
                         if suf is None:
                             continue
-                        out[scope + "kernel" + suf] = buf[m["w_off"]: m["w_off"] + K * N].view(K, N)[rows].cpu().clone()
-                        out[scope + "bias" + suf] = buf[m["b_off"]: m["b_off"] + N].cpu().clone()
+                        out[scope + "kernel" + suf] = buf[m["w_off"]: m["w_off"] + K * N].view(K, N)[rows][:, :Ntf].cpu().clone()
+                        out[scope + "bias" + suf] = buf[m["b_off"]: m["b_off"] + Ntf].cpu().clone()
                         if "gamma_off" in m:
                             out[scope + "batch_normalization/gamma" + suf] = buf[m["gamma_off"]: m["gamma_off"] + N].cpu().clone()
                             out[scope + "batch_normalization/beta" + suf] = buf[m["beta_off"]: m["beta_off"] + N].cpu().clone()
@@ -1107,17 +1128,17 @@ class WideDeepEngine:
                         out[scope + "batch_normalization/moving_mean"] = torch.zeros(N)
                         out[scope + "batch_normalization/moving_variance"] = torch.ones(N)
         if spec.has_wide:
-            sa, sb = self._slot_bufs("linear")
+            sa, sb, sc = self._slot_bufs("linear")
             b = self.bias.cpu()
             for i, s in enumerate(plan.slots):
                 if tables and s.wide:
                     nm = "linear/linear_model/%s/weights" % s.name
                     r0 = plan.row_base[i]
                     blk = self.wide[r0: r0 + s.num_buckets].cpu()
-                    for col, suf in ((0, ""), (1, sa), (2, sb)):
+                    for col, suf in ((0, ""), (1, sa), (2, sb), (3, sc)):
                         if suf is not None:
                             out[nm + suf] = blk[:, col:col + 1].clone()
-            for col, suf in ((0, ""), (1, sa), (2, sb)):
+            for col, suf in ((0, ""), (1, sa), (2, sb), (3, sc)):
                 if suf is not None:
                     out["linear/linear_model/bias_weights" + suf] = b[col:col + 1].clone()
         for scope, names in self.pow_names.items():
@@ -1130,39 +1151,44 @@ class WideDeepEngine:
         plan, spec, dev = self.plan, self.spec, self.device
         self._folded = False
         if spec.has_deep:
-            sa, sb = self._slot_bufs("dnn")
+            sa, sb, sc = self._slot_bufs("dnn")
             for i, s in enumerate(plan.slots):
                 if plan.emb_off[i] >= 0:
                     nm = "dnn/input_from_feature_columns/input_layer/%s/embedding_weights" % s.deep_name
                     sl = slice(plan.emb_off[i], plan.emb_off[i] + s.num_buckets * s.dim)
-                    for buf, suf in ((self.emb, ""), (self.emb_a, sa), (self.emb_acc, sb)):
+                    for buf, suf in ((self.emb, ""), (self.emb_a, sa), (self.emb_acc, sb), (self.emb_c, sc)):
                         if suf is not None and nm + suf in state:
                             buf[sl] = state[nm + suf].to(dev).reshape(-1)
             for ti, tw in enumerate(self.towers):
                 p = "dnn/dnn_%d/" % (ti + 1)
                 for l, m in enumerate(tw["metas"]):
-                    K, N = m["K"], m["N"]
+                    K, N, Ntf = m["K"], m["N"], m["N_tf"]
                     scope = p + ("hiddenlayer_%d/" % l if l < tw["L"] else "logits/")
                     rows = torch.from_numpy(plan.tf_rows_of_layer(ti, l)).to(dev)
-                    for buf, suf in ((self.P, ""), (self.Pa, sa), (self.Pacc, sb)):
+                    odd_a, odd_b = OPT_SLOT_ODD[spec.dnn_opt[0]]
+                    for buf, suf, odd in ((self.P, "", True), (self.Pa, sa, odd_a), (self.Pacc, sb, odd_b), (self.Pc, sc, True)):
                         if suf is None or scope + "kernel" + suf not in state:
                             continue
-                        buf[m["w_off"]: m["w_off"] + K * N].view(K, N)[rows] = state[scope + "kernel" + suf].to(dev)
-                        buf[m["b_off"]: m["b_off"] + N] = state[scope + "bias" + suf].to(dev)
+                        kv, bv = state[scope + "kernel" + suf].to(dev), state[scope + "bias" + suf].to(dev)
+                        if Ntf != N:      # crelu: the mirrored half (odd quantities negated, accumulators copied)
+                            sg = -1.0 if odd else 1.0
+                            kv, bv = torch.cat([kv, sg * kv], dim=1), torch.cat([bv, sg * bv])
+                        buf[m["w_off"]: m["w_off"] + K * N].view(K, N)[rows] = kv
+                        buf[m["b_off"]: m["b_off"] + N] = bv
                         if "gamma_off" in m:
                             buf[m["gamma_off"]: m["gamma_off"] + N] = state[scope + "batch_normalization/gamma" + suf].to(dev)
                             buf[m["beta_off"]: m["beta_off"] + N] = state[scope + "batch_normalization/beta" + suf].to(dev)
         if spec.has_wide:
-            sa, sb = self._slot_bufs("linear")
+            sa, sb, sc = self._slot_bufs("linear")
             for i, s in enumerate(plan.slots):
                 if s.wide:
                     nm = "linear/linear_model/%s/weights" % s.name
                     r0 = plan.row_base[i]
-                    for col, suf in ((0, ""), (1, sa), (2, sb)):
+                    for col, suf in ((0, ""), (1, sa), (2, sb), (3, sc)):
                         if suf is not None and nm + suf in state:
                             self.wide[r0: r0 + s.num_buckets, col:col + 1] = state[nm + suf].to(dev)
             nm = "linear/linear_model/bias_weights"
-            for col, suf in ((0, ""), (1, sa), (2, sb)):
+            for col, suf in ((0, ""), (1, sa), (2, sb), (3, sc)):
                 if suf is not None and nm + suf in state:
                     self.bias[col:col + 1] = state[nm + suf].to(dev)
         for scope, names in self.pow_names.items():

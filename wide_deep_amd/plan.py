@@ -293,7 +293,14 @@ class FeaturePlan:
         self.tf_deep_dim = len(perm)
 
         # towers + flat dense parameter layout
-        self.towers = [TowerLayout(self.deep_dim, t.hidden_units, t.mode) for t in spec.towers] if spec.has_deep else []
+        # crelu (tf.nn.crelu = concat(relu(z), relu(-z)), python/lib/utils/model_util.py:52) is built as a relu layer of twice
+        # the width whose kernel is tied to [W | -W] and whose bias to [b | -b] (relu(x(-W) - b) = relu(-z) exactly: IEEE
+        # negation commutes with every rounding): the tower kernels see an ordinary 2N-wide relu layer, BN and the next
+        # layer's kernel rows are 2N wide as in TF, the TF variables `kernel [K, N]` / `bias [N]` are the left halves.
+        self.crelu = spec.has_deep and spec.activation == "crelu"
+        wmul = 2 if self.crelu else 1
+        self.towers = ([TowerLayout(self.deep_dim, [wmul * h for h in t.hidden_units], t.mode) for t in spec.towers]
+                       if spec.has_deep else [])
         self.param_segments = []   # (name, offset, shape)
         self.layer_meta = []       # per tower: list of dicts per layer (hidden..., logits)
         off = 0
@@ -304,6 +311,7 @@ class FeaturePlan:
                 K = tl.in_K[l]
                 N = tl.hidden[l] if l < L else 1
                 m = {"K": K, "N": N, "w_off": off}
+                m["N_tf"] = N // 2 if (self.crelu and l < L) else N      # columns of the TF variable (crelu: left half)
                 off += K * N
                 m["b_off"] = off
                 off += N
@@ -382,8 +390,34 @@ OPT_SLOT_NAMES = {"SGD": (None, None), "Adagrad": (None, "/Adagrad"), "Ftrl": ("
                   "RMSProp": ("/RMSProp", "/RMSProp_1"), "Adam": ("/Adam", "/Adam_1")}
 
 
+def ftrl_lr_power(opt):
+    """learning_rate_power of an Ftrl tuple ("Ftrl", lr, l1, l2, init[, lr_power]); TF default -0.5."""
+    return float(opt[5]) if len(opt) > 5 else -0.5
+
+
+def rmsprop_centered(opt):
+    """("RMSProp", lr, decay, momentum, epsilon[, centered])"""
+    return opt[0] == "RMSProp" and len(opt) > 5 and bool(opt[5])
+
+
+def opt_slot_names(opt):
+    """Checkpoint suffixes (slot a, slot b, slot c) of an optimizer tuple -- TF numbers the slot variables of one optimizer in
+    creation order: RMSPropOptimizer._create_slots makes rms, [mg when centered,] momentum, so centered=True shifts
+    momentum from /RMSProp_1 to /RMSProp_2 and the mean gradient (slot c) takes /RMSProp_1."""
+    if rmsprop_centered(opt):
+        return "/RMSProp", "/RMSProp_2", "/RMSProp_1"
+    return OPT_SLOT_NAMES[opt[0]] + (None,)
+
+
+# slots that are ODD functions of the gradient history (they flip sign with the parameter: a crelu layer's mirrored half
+# holds their negation), per optimizer (slot a, slot b); slot c (mean gradient) is odd
+OPT_SLOT_ODD = {"SGD": (False, False), "Adagrad": (False, False), "Ftrl": (True, False), "RMSProp": (False, True),
+                "Adam": (True, False)}
+
+
 def opt_slot_init(opt):
-    """Initial values (slot a, slot b) of an optimizer tuple; None: the optimizer has no such slot."""
+    """Initial values (slot a, slot b) of an optimizer tuple; None: the optimizer has no such slot.  (Slot c -- centered
+    RMSProp's mean gradient -- starts at 0.)"""
     kind = opt[0]
     if kind == "SGD":
         return None, None
@@ -402,7 +436,7 @@ def opt_params(opt):
     """(p0, p1, p2) of wd_opt_t."""
     kind = opt[0]
     if kind == "Ftrl":
-        return float(opt[2]), float(opt[3]), 0.0
+        return float(opt[2]), float(opt[3]), ftrl_lr_power(opt)
     if kind in ("RMSProp", "Adam"):
         return float(opt[2]), float(opt[3]), float(opt[4])
     return 0.0, 0.0, 0.0

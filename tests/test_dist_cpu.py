@@ -97,7 +97,7 @@ def _worker(rank, world, port, q):
         from wide_deep_amd.dist import _all_reduce_sum
         t = torch.full((5,), float(rank + 1))
         _all_reduce_sum(t)
-        assert torch.equal(t, torch.full((5,), 3.0))
+        assert torch.equal(t, torch.full((5,), world * (world + 1) / 2.0))
         q.put((rank, "ok"))
     except Exception as e:  # pragma: no cover
         import traceback
@@ -106,11 +106,16 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_exchange_world2_gloo():
+import pytest
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_exchange_world2_gloo(world):
+    """world 2 and 4 (three peers per all-to-all, four owners per table, vocabularies not divisible by the world size)"""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=240) for _ in procs]
@@ -127,6 +132,28 @@ def test_local_spec_and_full_state_roundtrip_shapes():
     ls = local_spec(spec, 4)
     assert [s.num_buckets for s in ls.slots] == [26, 26, 26] and shard_rows(101, 4) == 26
     assert spec.slots[0].num_buckets == 101   # the global spec is untouched
+
+
+def test_local_spec_keeps_the_deep_input_of_the_default_conf():
+    """The repo-default conf (47 embedding columns of widths 4..32, 20 indicator columns, bucketized wide-only columns) on a
+    row-sharded rank: wide / embedding rows are cut to ceil(V / world), the deep input -- and with it every tower kernel --
+    keeps its shape: an indicator column still spans the whole vocabulary."""
+    from wide_deep_amd.build_estimator import build_model_spec
+    from wide_deep_amd.dist import local_spec, shard_rows
+    from wide_deep_amd.plan import FeaturePlan
+    spec = build_model_spec()
+    gp = FeaturePlan(spec)
+    for world in (2, 4, 8):
+        lp = FeaturePlan(local_spec(spec, world))
+        assert [s.name for s in lp.slots] == [s.name for s in gp.slots]
+        assert lp.deep_dim == gp.deep_dim and lp.out_col == gp.out_col and lp.tf_deep_dim == gp.tf_deep_dim
+        assert np.array_equal(lp.tf_input_perm, gp.tf_input_perm)
+        assert [m["K"] for m in lp.layer_meta[0]] == [m["K"] for m in gp.layer_meta[0]]
+        for a, b in zip(lp.slots, gp.slots):
+            assert a.num_buckets == shard_rows(b.num_buckets, world)
+            if b.deep == "indicator":
+                assert a.ind_width == b.num_buckets
+        assert lp.total_rows <= gp.total_rows // world + gp.S
 
 
 # ---- the Estimator-shaped object under torch.distributed (train.py launched one process per GPU), on CPU ------------------

@@ -1,4 +1,4 @@
-"""GPU: the sharded HIP engine with world_size 2 (both ranks share cuda:0, gloo staging through host)
+"""GPU: the sharded HIP engine with world_size 2 and 4 (all ranks share cuda:0, gloo staging through host)
 must train exactly like ONE engine on the concatenated global batch."""
 import os
 import socket
@@ -21,6 +21,19 @@ def _free_port():
 
 def _spec(kind):
     from wide_deep_amd.plan import criteo_spec
+    kind = kind.rstrip("4")                      # "<kind>4" = the same model on four ranks
+    if kind == "mixed":         # every embedding column its own width (the reference's default rule), ragged vocabularies
+        s = criteo_spec(n_dense=2, n_sparse=5, buckets=101, dim=16, hidden=(24, 12))
+        for sl, d, v in zip(s.slots, (8, 16, 32, 16, 4), (101, 57, 300, 23, 11)):
+            sl.dim, sl.num_buckets = d, v
+        return s, 2
+    if kind == "indicator":     # the repo-default conf's shape: embeddings + indicator columns + a wide-only column
+        s = criteo_spec(n_dense=3, n_sparse=6, buckets=150, dim=8, hidden=(32, 16))
+        for i, v in ((3, 7), (4, 12)):
+            s.slots[i].kind, s.slots[i].deep, s.slots[i].dim, s.slots[i].num_buckets = "identity", "indicator", 0, v
+        s.slots[5].deep, s.slots[5].dim = None, 0
+        s.slots[1].dim = 16
+        return s, 2
     if kind == "multihot":
         return criteo_spec(n_dense=2, n_sparse=4, buckets=101, dim=16, hidden=(16, 8), mode="resnet"), 3
     if kind == "wideonly":
@@ -53,7 +66,7 @@ def _worker(rank, world, port, kind, q):
         from wide_deep_amd.engine import WideDeepEngine
         from tests.helpers import assert_close
         spec, _ = _spec(kind)
-        B_loc, steps = 48, 3
+        B_loc, steps = (48 if world == 2 else 24), 3
         ref = WideDeepEngine(spec, max_batch=B_loc * world, seed=11)
         full0 = ref.export_state()
         sh = ShardedWideDeepEngine(spec, max_batch=B_loc, seed=11)
@@ -61,6 +74,10 @@ def _worker(rank, world, port, kind, q):
         bs = _batches(ref.plan, kind, steps, B_loc, world)
         if kind.startswith("chain"):
             assert sh.chain and ref.chain
+        if kind.startswith("mixed"):
+            assert sh.mixed_dims and sh.dim == 32 and sh.emb.numel() >= sh.n_emb_rows * 32
+        if kind.startswith("indicator"):
+            assert sh.ind_xslots_dev is not None and sh.plan.deep_dim == ref.plan.deep_dim
         replay = None
         for st in range(steps):
             hbs = bs[st]
@@ -148,12 +165,15 @@ def test_exchange_overflow_is_reported():
     _run(_overflow_worker, "onehot")
 
 
-@pytest.mark.parametrize("kind", ["onehot", "multihot", "wideonly", "deeponly", "chain", "chain_graph"])
+@pytest.mark.parametrize("kind", ["onehot", "multihot", "wideonly", "deeponly", "chain", "chain_graph", "mixed", "indicator",
+                                  "onehot4", "chain4", "mixed4", "indicator4"])
 def test_sharded_world2_equals_single_engine(kind):
+    """world 2, and (kinds ending in 4) world 4: four owners per table, three peers per all-to-all"""
+    world = 4 if kind.endswith("4") else 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, kind, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, kind, q)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=600) for _ in procs]

@@ -142,7 +142,8 @@ k_owner_gather(const float *__restrict__ emb, int64_t n_emb_rows, int32_t D, con
 }
 
 // per bag (b, s): every occurrence j gets out[pos[j]*RS + 0..D) = dx[b, col..] * (1/len) and, for wide slots,
-// out[pos[j]*RS + D] = dlogit[b]
+// out[pos[j]*RS + D] = dlogit[b].  D = width of the exchanged record = the LARGEST embedding dim; a slot of a smaller dim
+// fills the rest with zeros (the owner keeps its rows padded to D: zero gradient, the pad columns never move)
 __global__ void __launch_bounds__(256)
 k_grad_pack(const wd_slot_t *__restrict__ slots, int32_t S, const int32_t *__restrict__ bag_offs,
             const int32_t *__restrict__ pos, int64_t nbags, const float *__restrict__ dx, int64_t ldx,
@@ -155,6 +156,7 @@ k_grad_pack(const wd_slot_t *__restrict__ slots, int32_t S, const int32_t *__res
   const int32_t j0 = bag_offs[bag], j1 = bag_offs[bag + 1];
   if (j1 <= j0) return;
   const bool is_emb = dx && sl.kind == WD_SLOT_EMBEDDING;
+  const int dq = is_emb ? (sl.dim >> 2) : 0;
   const float scale = (j1 - j0) > 1 ? 1.0f / (float)(j1 - j0) : 1.0f;
   const float dl = (dlogit && sl.wide) ? dlogit[b] : 0.f;
   for (int32_t j = j0; j < j1; ++j) {
@@ -164,7 +166,7 @@ k_grad_pack(const wd_slot_t *__restrict__ slots, int32_t S, const int32_t *__res
     if (dx) {
       for (int c = lane; c < (D >> 2); c += 4) {
         float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (is_emb) {
+        if (c < dq) {
           g = *reinterpret_cast<const float4 *>(dx + b * ldx + sl.out_col + 4 * c);
           g.x *= scale; g.y *= scale; g.z *= scale; g.w *= scale;
         }

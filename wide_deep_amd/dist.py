@@ -149,6 +149,8 @@ def local_spec(spec: ModelSpec, world):
     for s in spec.slots:
         d = CatSlot(**{k: getattr(s, k) for k in s.__dataclass_fields__})
         d.num_buckets = shard_rows(s.num_buckets, world)
+        if s.deep == "indicator":
+            d.deep_width = int(s.num_buckets)     # the multi-hot vector of the deep input keeps all V columns
         slots.append(d)
     return ModelSpec(model_type=spec.model_type, slots=slots, dense_cols=list(spec.dense_cols),
                      towers=list(spec.towers), activation=spec.activation, batch_norm=spec.batch_norm,
@@ -179,10 +181,13 @@ class ShardedWideDeepEngine(WideDeepEngine):
         self.global_plan = FeaturePlan(spec)
         gp = self.global_plan
         dims = {int(s.dim) for s in gp.slots if s.deep == "embedding"} if spec.has_deep else set()
-        if len(dims) > 1:
-            raise NotImplementedError("sharded engine: embedding slots must share one dim (got %s)" % sorted(dims))
-        if spec.has_deep and gp.ind_slots:
-            raise NotImplementedError("sharded engine: indicator columns are not exchanged yet")
+        if any(d not in (4, 8, 16, 32, 64, 128) for d in dims):
+            raise NotImplementedError("sharded engine: embedding dims must be 4, 8, ..., 128 (got %s)" % sorted(dims))
+        # Mixed embedding dims (the reference's default rule, build_estimator.py:57-59, gives every hashed column its own):
+        # every exchanged record is [Dmax floats | wide], and the OWNER keeps its embedding rows padded to Dmax, so that
+        # "embedding row = local fused row" holds and one slot descriptor covers the whole local row space.  A slot of a
+        # smaller dim sends / receives zeros in the pad columns (zero gradient: they never move).
+        self.mixed_dims = len(dims) > 1
         S = gp.S
         mn = int(max_nnz) if max_nnz else int(max_batch) * max(S, 1) * 8
         W = self.world
@@ -202,15 +207,19 @@ class ShardedWideDeepEngine(WideDeepEngine):
         self._train_fwd = False       # forward() of a train step: start the owner-side bucketing early
         self._bucketized = False
         self.req_max_nnz = mn
-        self.dim = dims.pop() if dims else 0
-        if self.dim % 4:
-            raise NotImplementedError("sharded engine: embedding dim must be a multiple of 4")
+        self.dim = max(dims) if dims else 0       # width of the embedding part of an exchanged record
         dev = self.device
         lp = self.plan
         self.n_emb_slots = lp.n_emb if spec.has_deep else 0
-        # embedding slots come first in the fused row space and share one dim: embedding row == fused local row
+        # embedding slots come first in the fused row space: embedding row == fused local row (rows padded to self.dim)
         self.n_emb_rows = sum(int(s.num_buckets) for s in lp.slots[: self.n_emb_slots])
-        assert all(lp.emb_off[i] == lp.row_base[i] * self.dim for i in range(self.n_emb_slots))
+        if self.mixed_dims:
+            self._pad_tables()
+        else:
+            assert all(lp.emb_off[i] == lp.row_base[i] * self.dim for i in range(self.n_emb_slots))
+        # indicator columns (vocabulary / identity columns in the deep input): computed by the requester from its own ids --
+        # nothing to exchange; descriptors with the GLOBAL vocabulary size as the width of the multi-hot vector
+        self.ind_xslots_dev = None
         has_emb, has_wide = self.n_emb_slots > 0, spec.has_wide
         self.RS = (self.dim if has_emb else 0) + ((4 if has_emb else 1) if has_wide else 0)   # floats per exchanged row
         i32 = dict(dtype=torch.int32, device=dev)
@@ -242,6 +251,10 @@ class ShardedWideDeepEngine(WideDeepEngine):
                            out_col=lp.out_col[i], kind=capi.SLOT_EMBEDDING if is_emb else capi.SLOT_NONE,
                            wide=1 if (spec.has_wide and s.wide) else 0))
         self.xslots_dev = make_slots(xs)
+        if spec.has_deep and lp.ind_slots:
+            self.ind_xslots_dev = make_slots([dict(emb_off=-1, row_base=0, num_buckets=s.ind_width, dim=0,
+                                                   out_col=lp.out_col[i], kind=capi.SLOT_INDICATOR, wide=0)
+                                              for i, s in enumerate(lp.slots)])
         # owner side: the whole local fused row space is one slot; only rows below n_emb_rows carry embeddings
         # (its row-range buckets therefore span slots: one geometry over all local rows)
         osh, _, self.n_buckets = bucket_geometry([max(lp.total_rows, 1)], self.n_req, int(call("wd_bucket_max")),
@@ -265,6 +278,25 @@ class ShardedWideDeepEngine(WideDeepEngine):
             garr[i].kind, garr[i].wide = capi.SLOT_NONE, 0
         self.hash_slots_dev = torch.from_numpy(np.frombuffer(bytes(garr), dtype=np.uint8).copy()).to(dev)
         self.hash_plan = gp
+
+    def _pad_tables(self):
+        """Mixed embedding dims: re-lay the local tables (and the Adagrad accumulator) as [n_emb_rows][Dmax]."""
+        lp, D, n = self.plan, self.dim, self.n_emb_rows
+        for name, fill in (("emb", 0.0), ("emb_acc", float(self.spec.dnn_opt[2]))):
+            old = getattr(self, name)
+            new = torch.full((max(n * D, 4),), fill, dtype=torch.float32, device=self.device)
+            v = new[: n * D].view(n, D)
+            for i in range(self.n_emb_slots):
+                s, r0 = lp.slots[i], lp.row_base[i]
+                v[r0: r0 + s.num_buckets, : s.dim] = old[lp.emb_off[i]: lp.emb_off[i] + s.num_buckets * s.dim].view(
+                    s.num_buckets, s.dim)
+            setattr(self, name, new)
+
+    def _emb_view(self, buf, i):
+        if not self.mixed_dims:
+            return super()._emb_view(buf, i)
+        s, r0 = self.plan.slots[i], self.plan.row_base[i]
+        return buf[: self.n_emb_rows * self.dim].view(self.n_emb_rows, self.dim)[r0: r0 + s.num_buckets, : s.dim]
 
     def _collective(self, fn):
         """Run a collective now, or -- while a step is being captured -- close the current graph segment and record it."""
@@ -328,10 +360,12 @@ class ShardedWideDeepEngine(WideDeepEngine):
             tw0 = self.towers[0]
             ld = tw0["layout"].ld
             xp = self._x_ptr(tw0)
-            if has_emb:
-                gs = next(iter(self.group_slots.values()))
+            for d, gs in (self.group_slots.items() if has_emb else ()):      # one launch per embedding dim
                 call("wd_embag_fwd_strided", ptr(self.fwd_recv), self.RS, ptr(self.xslots_dev), S, ptr(gs), gs.numel(),
-                     self.dim, ptr(self.pos), ptr(bt.bag_offs), B, xp, ld, st)
+                     d, ptr(self.pos), ptr(bt.bag_offs), B, xp, ld, st)
+            if self.ind_xslots_dev is not None:
+                call("wd_indicator_fwd", ptr(self.ind_xslots_dev), S, ptr(self.ind_slots_dev), self.ind_slots_dev.numel(),
+                     ptr(bt.ids), ptr(bt.bag_offs), B, xp, ld, st)
             if self.dense_cols_dev is not None:
                 call("wd_dense_fwd", ptr(bt.dense), bt.dense.stride(0), ptr(self.dense_cols_dev),
                      len(lp.dense_cols), B, xp, ld, st)

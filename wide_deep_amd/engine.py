@@ -1091,6 +1091,11 @@ class WideDeepEngine:
     # ------------------------------------------------------------------------------------------
     # state exchange in the reference's checkpoint naming (SURVEY section 5)
     # ------------------------------------------------------------------------------------------
+    def _emb_view(self, buf, i):
+        """[num_buckets, dim] view of slot i's rows in an embedding-shaped buffer (the table or one of its optimizer slots)."""
+        s, off = self.plan.slots[i], self.plan.emb_off[i]
+        return buf[off: off + s.num_buckets * s.dim].view(s.num_buckets, s.dim)
+
     def _slot_bufs(self, scope):
         """[(buffer, checkpoint-name suffix)] of a scope's variable + its optimizer slots."""
         opt = self.spec.dnn_opt if scope == "dnn" else self.spec.lin_opt
@@ -1106,10 +1111,9 @@ class WideDeepEngine:
             for i, s in enumerate(plan.slots):
                 if tables and plan.emb_off[i] >= 0:
                     nm = "dnn/input_from_feature_columns/input_layer/%s/embedding_weights" % s.deep_name
-                    sl = slice(plan.emb_off[i], plan.emb_off[i] + s.num_buckets * s.dim)
                     for buf, suf in ((self.emb, ""), (self.emb_a, sa), (self.emb_acc, sb), (self.emb_c, sc)):
                         if suf is not None:
-                            out[nm + suf] = buf[sl].view(s.num_buckets, s.dim).cpu().clone()
+                            out[nm + suf] = self._emb_view(buf, i).cpu().clone()
             for ti, tw in enumerate(self.towers):
                 p = "dnn/dnn_%d/" % (ti + 1)
                 for l, m in enumerate(tw["metas"]):
@@ -1155,10 +1159,9 @@ class WideDeepEngine:
             for i, s in enumerate(plan.slots):
                 if plan.emb_off[i] >= 0:
                     nm = "dnn/input_from_feature_columns/input_layer/%s/embedding_weights" % s.deep_name
-                    sl = slice(plan.emb_off[i], plan.emb_off[i] + s.num_buckets * s.dim)
                     for buf, suf in ((self.emb, ""), (self.emb_a, sa), (self.emb_acc, sb), (self.emb_c, sc)):
                         if suf is not None and nm + suf in state:
-                            buf[sl] = state[nm + suf].to(dev).reshape(-1)
+                            self._emb_view(buf, i).copy_(state[nm + suf].to(dev).reshape(s.num_buckets, s.dim))
             for ti, tw in enumerate(self.towers):
                 p = "dnn/dnn_%d/" % (ti + 1)
                 for l, m in enumerate(tw["metas"]):

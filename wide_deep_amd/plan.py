@@ -49,6 +49,13 @@ class CatSlot:
     normalizer: Optional[tuple] = None      # ('min_max'|'standard'|'log', p0, p1) applied BEFORE bucketize (quirk C.5)
     cross_keys: Optional[List[CrossKey]] = None
     hash_key: int = 0xDECAFCAFFE
+    # indicator columns: width of the multi-hot vector in the deep input when it is not num_buckets -- on a row-sharded rank
+    # (dist.local_spec) the slot holds ceil(V / world) wide rows while the deep input still has V columns
+    deep_width: Optional[int] = None
+
+    @property
+    def ind_width(self):
+        return int(self.deep_width or self.num_buckets)
 
     @property
     def deep_name(self):
@@ -258,7 +265,7 @@ class FeaturePlan:
             for i, s in enumerate(self.slots):
                 if s.deep == "indicator":
                     self.out_col[i] = c
-                    c += s.num_buckets
+                    c += s.ind_width
         self.dense_cols = list(spec.dense_cols) if spec.has_deep else []
         self.dense_out_col = []
         for d in self.dense_cols:
@@ -281,7 +288,7 @@ class FeaturePlan:
                 if s.deep == "embedding":
                     tf_cols.append((s.deep_name, self.out_col[i], s.dim))
                 elif s.deep == "indicator":
-                    tf_cols.append((s.deep_name, self.out_col[i], s.num_buckets))
+                    tf_cols.append((s.deep_name, self.out_col[i], s.ind_width))
             for j, d in enumerate(self.dense_cols):
                 tf_cols.append((d.name, self.dense_out_col[j], 1))
         tf_cols.sort(key=lambda t: t[0])

@@ -419,9 +419,10 @@ def main():
     if use_graph and sharded:
         # sharded step: hipGraph segments between the collectives (dist._Segments); every rank captures in lock-step
         try:
-            replays = [eng.capture_train_step(tb.batch, warmup=1,
+            # (one eager warm-up step in front of the first capture only: the batches share every buffer shape)
+            replays = [eng.capture_train_step(tb.batch, warmup=1 if i == 0 else 0,
                                               pre=None if args.ids_input else (lambda tb=tb: synth.hash_tokens(eng, tb)))
-                       for tb in dev_batches]
+                       for i, tb in enumerate(dev_batches)]
             run = lambda i: replays[i % len(replays)]()
         except Exception as e:      # capture refused by the runtime: the eager step is the same work, launch by launch
             print("bench: graph segments unavailable (%s); running the sharded step eagerly" % (e,), file=sys.stderr)

@@ -123,7 +123,7 @@ def test_no_batch_norm_and_other_activation():
 
 
 @pytest.mark.parametrize("mode,hidden,dnn_opt,dropout", [
-    ("simple", (32, 16, 8), None, 0.0), ("dense", (24, 12), None, 0.0), ("resnet", (16, 8), ("Adam", 0.01, 0.9, 0.999, 1e-8), 0.0),
+    ("simple", (32, 16, 8), None, 0.0), ("dense", (24, 12), None, 0.0), ("resnet", (16, 8), ("RMSProp", 0.01, 0.8, 0.5, 1e-6), 0.0),
     ("first_dense", (16, 8, 8), ("RMSProp", 0.01, 0.8, 0.5, 1e-6, True), 0.2), ("last_dense", (16, 12), ("Ftrl", 0.05, 0.001, 0.01, 0.1), 0.0)])
 def test_crelu_train_steps_match_oracle(mode, hidden, dnn_opt, dropout):
     """activation `crelu` (python/lib/utils/model_util.py:52, tf.nn.crelu = concat(relu(z), relu(-z))): every layer hands 2N

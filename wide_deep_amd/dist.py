@@ -490,6 +490,13 @@ class ShardedWideDeepEngine(WideDeepEngine):
                 self.train_step(bt)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        if warmup and dist.get_backend(self.group) == "nccl":
+            # The process group's watchdog thread polls the completion events of the eager collectives above every 100 ms
+            # until it has seen them complete.  A poll that lands inside the capture below intermittently fails with
+            # hipErrorCapturedEvent on ROCm 7.2 (observed: 1 of 2 runs of bench.py --force-sharded) and takes the process
+            # down; the works are complete after the synchronize, so two poll periods later none is left to poll.
+            import time
+            time.sleep(0.25)
         segs = _Segments()
         with torch.cuda.stream(side):
             self._segs = segs

@@ -150,12 +150,15 @@ def gather_kernel_roofline(eng, batches, args, iters=200):
     alg = gather_alg_bytes(plan, bt, dim, gs.numel())
     gbs = alg / (ms * 1e-3) / 1e9
     traffic, src = (None, "skipped (--no-pmc)") if args.no_pmc else pmc_traffic(args, bt, plan)
-    return {"bound": "hbm", "kernel": "k_embag_fwd_range<%d, 2, %s>" % (dim // 4, "true" if bt.one_hot else "false"),
+    kname = ("k_embag_fwd<%d> on %d-byte row records" % (dim // 4, 4 * eng.rec_stride) if eng.rec is not None
+             else "k_embag_fwd_range<%d, 2, %s>" % (dim // 4, "true" if bt.one_hot else "false"))
+    return {"bound": "hbm", "kernel": kname,
             "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
             "traffic": traffic, "traffic_source": src, "algorithmic_bytes_per_launch": int(alg),
             "avg_launch_us": round(ms * 1e3, 2),
-            "note": "wd_embag_fwd_range timed as its own launch; one-id-per-bag batches take the same rows through the gather "
-                    "phase of k_tower_chain inside the step (`roofline`), multi-hot batches through k_input_layer"}
+            "note": "the embedding-bag gather of the C ABI timed as its own launch on the engine's table layout; one-id-per-bag "
+                    "batches take the same rows through the gather phase of k_tower_chain inside the step (`roofline`), "
+                    "multi-hot batches through k_input_layer / this kernel"}
 
 
 def gather_instep_roofline(eng, dev_batches, step_eager, steps=16):
@@ -509,6 +512,8 @@ def main():
             }[args.config],
             "global_batch": B * world, "ids": args.dist, "input": "pre-hashed ids" if args.ids_input else "raw string tokens (hashed in step)",
             "hip_graph": bool(use_graph), "steps_per_graph": steps_per_run,
+            "table_layout": ("row records: %d B = [emb %d f32 | w z n -]" % (4 * eng.rec_stride, eng.emb.shape[1])
+                             if getattr(eng, "rec", None) is not None else "separate tables"),
             "pipelined_graph": bool(use_graph and not sharded and multis and multis[0].pipelined) if use_graph and not sharded else False, "parallelism": "dp%d+row-sharded tables" % world if sharded else "single GPU",
             "final_loss_sum": round(loss, 3),
         },

@@ -213,6 +213,15 @@ int wd_sparse_apply(float *emb, float *emb_accum, float *wide, float *bias_wzn, 
                     const int32_t *bag_offs, int64_t batch, const float *dx, int64_t ldx, const float *dlogit,
                     int64_t ld_dlogit, float lr_emb, float lr_wide, float l1, float l2, const int32_t *bucket_start,
                     uint64_t *pairs, int32_t nbuckets, wd_stream_t stream);
+/* wd_sparse_apply on the ROW-RECORD layout: one table of `rec_stride`-float records indexed by the FUSED row
+ * (slot.row_base + id), record = [embedding row (dim floats) | w, z, n, - | pad]; the Adagrad accumulator keeps the flat
+ * per-slot layout of wd_sparse_apply (slot.emb_off).  An update then touches two random lines per row instead of three, and
+ * the forward finds the wide weight in the line of the embedding row (wd_chain_input_t.wide_in_row, wd_wide_fwd with
+ * wide = rec + dim and stride rec_stride, wd_embag_fwd_strided with slot.emb_off = row_base * rec_stride). */
+int wd_sparse_apply_rec(float *rec, int32_t rec_stride, int32_t dim, float *emb_accum, float *bias_wzn,
+                        const wd_slot_t *slots, int32_t S, const int32_t *bag_offs, int64_t batch, const float *dx,
+                        int64_t ldx, const float *dlogit, int64_t ld_dlogit, float lr_emb, float lr_wide, float l1, float l2,
+                        const int32_t *bucket_start, uint64_t *pairs, int32_t nbuckets, wd_stream_t stream);
 int wd_sparse_bwd_fused(float *emb, float *emb_accum, float *wide, float *bias_wzn, const wd_slot_t *slots, int32_t S,
                         const int32_t *ids, const int32_t *bag_offs, int64_t batch, int64_t nnz, const float *dx,
                         int64_t ldx, const float *dlogit, int64_t ld_dlogit, float lr_emb, float lr_wide, float l1, float l2,

@@ -182,8 +182,8 @@ class CompactOracle:
         return torch.as_tensor(self.uniq[si], dtype=torch.int64, device=self.eng.device)
 
     def _emb_rows(self, buf, si):
-        plan, s = self.plan, self.plan.slots[si]
-        v = buf[plan.emb_off[si]: plan.emb_off[si] + s.num_buckets * s.dim].view(s.num_buckets, s.dim)
+        s = self.plan.slots[si]
+        v = self.eng._emb_view(buf, si)           # [num_buckets, dim] view in either table layout
         if len(self.uniq[si]) == 0:
             return torch.zeros(1, s.dim)
         return v[self._idx(si)].cpu().clone()

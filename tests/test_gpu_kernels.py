@@ -142,12 +142,15 @@ def test_cross_hash_bit_exact_ragged_and_empty():
         assert np.array_equal(ids.cpu().numpy()[: len(exp_ids)].astype(np.int64), exp_ids)
 
 
-@pytest.mark.parametrize("dim", [4, 8, 16, 32, 64, 6])
-def test_embag_fwd_mean_matches_oracle(dim):
+@pytest.mark.parametrize("dim,records", [(4, False), (4, True), (8, False), (8, True), (16, False), (16, True), (32, False),
+                                         (64, False), (6, False)])
+def test_embag_fwd_mean_matches_oracle(dim, records):
+    """records: the row-record table layout (embedding row + wide line of a fused row in one 32 / 64 / 128-byte record)"""
     from wide_deep_amd import synth
     from wide_deep_amd.plan import criteo_spec
     spec = criteo_spec(n_dense=3, n_sparse=4, buckets=500, dim=dim, hidden=(8,))
-    eng = _engine(spec, max_batch=128)
+    eng = _engine(spec, max_batch=128, row_records=records)
+    assert (eng.rec is not None) == records
     rng = np.random.default_rng(dim)
     hb = synth.make_raw_batch(eng.plan, 100, seed=dim, mean_len=3)
     hb["lens"][rng.random(hb["lens"].shape) < 0.2] = 0        # empty bags -> zero vector
@@ -215,7 +218,7 @@ def test_sort_and_sparse_updates_match_oracle():
     from wide_deep_amd.plan import criteo_spec
     from tests.helpers import slot_csr, assert_close
     spec = criteo_spec(n_dense=0, n_sparse=3, buckets=50, dim=16, hidden=(8,))   # tiny tables -> many duplicates
-    eng = _engine(spec, max_batch=256)
+    eng = _engine(spec, max_batch=256, row_records=False)     # the per-op entry points work on separate tables
     hb = synth.make_raw_batch(eng.plan, 200, seed=9, mean_len=4)
     bt = synth.to_device_ids(eng.plan, hb)
     st0 = eng.export_state()
@@ -282,7 +285,9 @@ def test_fused_sparse_backward_matches_sorted_path(B, mean_len, dim):
     from wide_deep_amd.plan import criteo_spec
     from tests.helpers import assert_close
     spec = criteo_spec(n_dense=0, n_sparse=3, buckets=50, dim=dim, hidden=(8,))   # tiny tables -> heavy duplicates
-    engs = [_engine(spec, max_batch=B, max_nnz=B * 3 * 16) for _ in range(2)]
+    # engine 0: fused kernel on the row-record layout where the width allows it (16, 8); engine 1: separate tables, sorted path
+    engs = [_engine(spec, max_batch=B, max_nnz=B * 3 * 16, row_records=None if i == 0 else False) for i in range(2)]
+    assert (engs[0].rec is not None) == (dim in (8, 16)) and engs[1].rec is None
     hb = synth.make_raw_batch(engs[0].plan, B, seed=B + dim, mean_len=mean_len)
     bt = synth.to_device_ids(engs[0].plan, hb)
     ld = engs[0].towers[0]["layout"].ld
@@ -324,7 +329,8 @@ def test_fused_sparse_backward_mixed_vocabularies(B, mean_len):
     spec = criteo_spec(n_dense=0, n_sparse=4, buckets=50, dim=8, hidden=(8,))
     for sl, v in zip(spec.slots, (2, 7, 100000, 300)):
         sl.num_buckets = v
-    engs = [_engine(spec, max_batch=B, max_nnz=B * 4 * 16) for _ in range(3)]
+    engs = [_engine(spec, max_batch=B, max_nnz=B * 4 * 16, row_records=None if i != 1 else False) for i in range(3)]
+    assert engs[0].rec is not None and engs[1].rec is None
     assert engs[0].bucket_shifts[0] == 0 and engs[0].bucket_shifts[1] == 0 and engs[0].bucket_shifts[2] > 0
     hb = synth.make_raw_batch(engs[0].plan, B, seed=B + 11, mean_len=mean_len)
     bt = synth.to_device_ids(engs[0].plan, hb)

@@ -165,6 +165,48 @@ def test_crelu_train_steps_match_oracle(mode, hidden, dnn_opt, dropout):
             assert torch.equal(sa[k], sb[k]), k
 
 
+@pytest.mark.parametrize("hidden,mean_len,dim", [((64, 32), 1, 16), ((32, 16, 8), 1, 8), ((32, 16), 3, 16), ((64, 32), 1, 4)])
+def test_row_record_layout_trains_like_separate_tables(hidden, mean_len, dim):
+    """Two engines from the same seed, one on the row-record layout (embedding row + wide line {w, z, n} of a fused row in
+    ONE record) and one on separate tables: same batches -> same logits and the same tables, accumulators and tower
+    parameters after every step.  One id per bag + widths % 32 == 0: the one-launch tower gathers the records itself."""
+    from wide_deep_amd import synth
+    from wide_deep_amd.engine import WideDeepEngine
+    spec = _spec(hidden=hidden, dim=dim, n_dense=3 if dim != 4 else 13)
+    a = WideDeepEngine(spec, max_batch=128, seed=5, row_records=True)
+    b = WideDeepEngine(spec, max_batch=128, seed=5, row_records=False)
+    assert a.rec is not None and b.rec is None and a.rec.shape[1] == {4: 8, 8: 16, 16: 32}[dim]
+    sa, sb = a.export_state(), b.export_state()
+    for k in sb:
+        assert torch.equal(sa[k], sb[k]), k           # same initial numbers in both layouts
+    for step in range(4):
+        hb = synth.make_raw_batch(a.plan, 96, seed=40 + step, mean_len=mean_len, pos_rate=0.3, dist="zipf" if step == 2 else "uniform")
+        la = a.train_step(synth.to_device_ids(a.plan, hb))
+        lb = b.train_step(synth.to_device_ids(b.plan, hb))
+        torch.cuda.synchronize()
+        if mean_len == 1:
+            assert torch.equal(a.logit[:96], b.logit[:96]), "logits step %d" % step
+            assert float(la) == float(lb)
+        else:       # multi-hot: different gather kernels (strided generic / fused range), same sums up to the last bit
+            assert torch.allclose(a.logit[:96], b.logit[:96], rtol=1e-5, atol=1e-6), "logits step %d" % step
+    sa, sb = a.export_state(), b.export_state()
+    for k in sb:
+        if mean_len == 1:
+            assert torch.equal(sa[k], sb[k]), k
+        else:
+            assert torch.allclose(sa[k].float(), sb[k].float(), rtol=1e-4, atol=1e-6), k
+    sb = sa
+    # pad floats of the records are never written
+    D = dim
+    assert float(a.rec[:, D + 4:].abs().max() if a.rec.shape[1] > D + 4 else 0.0) == 0.0
+    # checkpoint round trip across layouts
+    c = WideDeepEngine(spec, max_batch=128, seed=9, row_records=True)
+    c.import_state(sb)
+    sc = c.export_state()
+    for k in sb:
+        assert torch.equal(sc[k], sb[k]), k
+
+
 def test_mixed_embedding_dims_and_odd_sizes():
     s = _spec(n_sparse=6, hidden=(20, 10), n_dense=1)
     for i, d in enumerate([4, 8, 16, 32, 64, 8]):

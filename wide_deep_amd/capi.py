@@ -149,6 +149,7 @@ _PROTOS = {
     "wd_sparse_bwd_fused": [P, P, P, P, P, I32, P, P, I64, I64, P, I64, P, I64, F32, F32, F32, F32, P, P, P, P, I32, P],
     "wd_sparse_bucketize": [P, I32, P, P, I64, I64, P, P, P, P, I32, P],
     "wd_sparse_apply": [P, P, P, P, P, I32, P, I64, P, I64, P, I64, F32, F32, F32, F32, P, P, I32, P],
+    "wd_sparse_apply_rec": [P, I32, I32, P, P, P, I32, P, I64, P, I64, P, I64, F32, F32, F32, F32, P, P, I32, P],
     "wd_route_chunks": [],
     "wd_route_build": [P, I32, I32, P, P, I64, I32, P, P, P, P, P, P],
     "wd_owner_gather": [P, I64, I32, P, P, I64, P, I32, P],

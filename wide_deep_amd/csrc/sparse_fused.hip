@@ -312,6 +312,10 @@ struct UpdArgs {
   int64_t ldx, batch, ld_dlogit;
   int32_t S, nb;
   float lr_emb, lr_w, l1, l2;
+  // row-record layout (wd_sparse_apply_rec): `emb` points at records of rec_stride floats indexed by the FUSED row (key),
+  // the embedding row in front, {w, z, n, -} behind it at `wide` = emb + dim; the accumulator table keeps its flat layout.
+  // 0: separate tables (emb rows of `dim` floats from sl.emb_off, wide lines of 4 floats).
+  int32_t rec_stride;
 };
 
 // all comparators ascending (mirror first step), so virtual +inf padding beyond m never moves.
@@ -370,6 +374,9 @@ k_bucket_update(UpdArgs u, const int32_t *__restrict__ start, uint64_t *__restri
   auto touch = [&](uint32_t key) {
     if (GEN && u.touched) atomicOr(&u.touched[key >> 5], 1u << (key & 31));
   };
+  const int64_t ws = u.rec_stride ? u.rec_stride : 4;        // floats between two wide lines
+  // offset of a row in the accumulator table (always flat) -> offset of the same row in `emb`
+  auto emb_at = [&](int64_t acc_off, uint32_t key) { return u.rec_stride ? (int64_t)key * u.rec_stride : acc_off; };
   __shared__ uint64_t lds_pairs[CAP_LDS];
   __shared__ float4 red[256];                               // long-segment tree; doubles as the rank-sort input
   uint64_t *lds_in = reinterpret_cast<uint64_t *>(red);     // RANK_MAX * 8 B == 256 * 16 B
@@ -500,18 +507,19 @@ k_bucket_update(UpdArgs u, const int32_t *__restrict__ start, uint64_t *__restri
       const int32_t o0 = u.bag_offs[bag0], o1 = u.bag_offs[bag0 + 1];
       const bool lane_emb = do_emb && gl < (D >> 2);
       const int64_t off = sl.emb_off + ((int64_t)key - sl.row_base) * D + 4 * gl;
+      const int64_t eoff = GEN ? off : emb_at(off - 4 * gl, key) + 4 * gl;
       float4 d = make_float4(0.f, 0.f, 0.f, 0.f), a = d, w = d, r = d;
       float dl = 0.f;
       if (lane_emb) {
         d = *reinterpret_cast<const float4 *>(u.dx + b * u.ldx + sl.out_col + 4 * gl);
         if (!GEN) {
           a = *reinterpret_cast<float4 *>(u.accum + off);
-          w = *reinterpret_cast<float4 *>(u.emb + off);
+          w = *reinterpret_cast<float4 *>(u.emb + eoff);
         }
       }
       if (do_wide && gl == 0) {
         dl = u.dlogit[b * u.ld_dlogit];
-        r = *reinterpret_cast<float4 *>(u.wide + (int64_t)key * 4);
+        r = *reinterpret_cast<float4 *>(u.wide + (int64_t)key * ws);
       }
       if (lane_emb) {
         const int32_t len = o1 - o0;
@@ -524,7 +532,7 @@ k_bucket_update(UpdArgs u, const int32_t *__restrict__ start, uint64_t *__restri
         } else {
           const float4 wn = adagrad4(a, w, g, u.lr_emb);
           *reinterpret_cast<float4 *>(u.accum + off) = a;
-          *reinterpret_cast<float4 *>(u.emb + off) = wn;
+          *reinterpret_cast<float4 *>(u.emb + eoff) = wn;
         }
       }
       if (do_wide && gl == 0) {
@@ -532,13 +540,14 @@ k_bucket_update(UpdArgs u, const int32_t *__restrict__ start, uint64_t *__restri
         g += dl;
         if (GEN) wide_apply(r, g);
         else ftrl_update(r.x, r.y, r.z, g, u.lr_w, u.l1, u.l2);
-        *reinterpret_cast<float4 *>(u.wide + (int64_t)key * 4) = r;
+        *reinterpret_cast<float4 *>(u.wide + (int64_t)key * ws) = r;
       }
       if (gl == 0) touch(key);
       continue;
     }
     if (do_emb && (D & 3) == 0) {
       const int64_t off = sl.emb_off + ((int64_t)key - sl.row_base) * D;
+      const int64_t eoff = GEN ? off : emb_at(off, key);
       for (int c = gl; c < (D >> 2); c += 4) {
         float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int j = i; j < e; ++j) {
@@ -553,14 +562,15 @@ k_bucket_update(UpdArgs u, const int32_t *__restrict__ start, uint64_t *__restri
           emb_apply(off + 4 * c, 4, gg);
         } else {
           float4 a = *reinterpret_cast<float4 *>(u.accum + off + 4 * c);
-          const float4 w = *reinterpret_cast<float4 *>(u.emb + off + 4 * c);
+          const float4 w = *reinterpret_cast<float4 *>(u.emb + eoff + 4 * c);
           const float4 wn = adagrad4(a, w, g, u.lr_emb);
           *reinterpret_cast<float4 *>(u.accum + off + 4 * c) = a;
-          *reinterpret_cast<float4 *>(u.emb + off + 4 * c) = wn;
+          *reinterpret_cast<float4 *>(u.emb + eoff + 4 * c) = wn;
         }
       }
     } else if (do_emb) {  // dims that are not a multiple of 4 (opt-in override only)
       const int64_t off = sl.emb_off + ((int64_t)key - sl.row_base) * D;
+      const int64_t eoff = GEN ? off : emb_at(off, key);
       for (int d0 = gl; d0 < D; d0 += 4) {
         float g = 0.f;
         for (int j = i; j < e; ++j) {
@@ -574,17 +584,17 @@ k_bucket_update(UpdArgs u, const int32_t *__restrict__ start, uint64_t *__restri
         } else {
           const float a = u.accum[off + d0] + g * g;
           u.accum[off + d0] = a;
-          u.emb[off + d0] -= u.lr_emb * g / sqrtf(a);
+          u.emb[eoff + d0] -= u.lr_emb * g / sqrtf(a);
         }
       }
     }
     if (do_wide && gl == 0) {
       float g = 0.f;
       for (int j = i; j < e; ++j) g += u.dlogit[(int64_t)((int32_t)(uint32_t)sp[j] / S) * u.ld_dlogit];
-      float4 r = *reinterpret_cast<float4 *>(u.wide + (int64_t)key * 4);  // {w, z, n, -}
+      float4 r = *reinterpret_cast<float4 *>(u.wide + (int64_t)key * ws);  // {w, z, n, -}
       if (GEN) wide_apply(r, g);
       else ftrl_update(r.x, r.y, r.z, g, u.lr_w, u.l1, u.l2);
-      *reinterpret_cast<float4 *>(u.wide + (int64_t)key * 4) = r;
+      *reinterpret_cast<float4 *>(u.wide + (int64_t)key * ws) = r;
     }
     if (gl == 0) touch(key);
   }
@@ -602,6 +612,7 @@ k_bucket_update(UpdArgs u, const int32_t *__restrict__ start, uint64_t *__restri
     const int D = sl.dim;
     if (do_emb) {
       const int64_t off = sl.emb_off + ((int64_t)key - sl.row_base) * D;
+      const int64_t eoff = GEN ? off : emb_at(off, key);
       const int nchunk = (D + 3) >> 2;
       for (int c0 = 0; c0 < nchunk; c0 += 4) {
         const int c = c0 + gl;
@@ -666,7 +677,7 @@ k_bucket_update(UpdArgs u, const int32_t *__restrict__ start, uint64_t *__restri
               const int64_t o = off + 4 * c + k2;
               const float a = u.accum[o] + gg[k2] * gg[k2];
               u.accum[o] = a;
-              u.emb[o] -= u.lr_emb * gg[k2] / sqrtf(a);
+              u.emb[eoff + 4 * c + k2] -= u.lr_emb * gg[k2] / sqrtf(a);
             }
           }
         }
@@ -692,10 +703,10 @@ k_bucket_update(UpdArgs u, const int32_t *__restrict__ start, uint64_t *__restri
         __syncthreads();
       }
       if (t == 0) {
-        float4 r = *reinterpret_cast<float4 *>(u.wide + (int64_t)key * 4);
+        float4 r = *reinterpret_cast<float4 *>(u.wide + (int64_t)key * ws);
         if (GEN) wide_apply(r, redw[0]);
         else ftrl_update(r.x, r.y, r.z, redw[0], u.lr_w, u.l1, u.l2);
-        *reinterpret_cast<float4 *>(u.wide + (int64_t)key * 4) = r;
+        *reinterpret_cast<float4 *>(u.wide + (int64_t)key * ws) = r;
       }
       __syncthreads();
     }
@@ -749,9 +760,34 @@ extern "C" int wd_sparse_apply(float *emb, float *emb_accum, float *wide, float 
   u.ld_dlogit = ld_dlogit > 0 ? ld_dlogit : 1;
   u.lr_emb = lr_emb; u.lr_w = lr_wide; u.l1 = l1; u.l2 = l2;
   u.accum_a = u.accum_c = nullptr; u.touched = nullptr; u.oe = OptK{}; u.ow = OptK{}; u.pow_e = u.pow_w = nullptr;
+  u.rec_stride = 0;
   hipLaunchKernelGGL(k_bucket_update<false>, dim3((unsigned)nbuckets + 1), dim3(256), 0, wd::as_stream(stream), u,
                      bucket_start, pairs);
   return wd::check_launch("wd_sparse_apply");
+}
+
+// wd_sparse_apply on the row-record layout: ONE table of `rec_stride`-float records indexed by the fused row, each holding
+// the embedding row ([0, dim)) and the wide line {w, z, n, -} ([dim, dim + 4)) of that row -- an update touches two random
+// lines per row (record + accumulator) instead of three (profiles/r2z_layouts.txt: 35 -> 29 us for one C2 batch).
+extern "C" int wd_sparse_apply_rec(float *rec, int32_t rec_stride, int32_t dim, float *emb_accum, float *bias_wzn,
+                                   const wd_slot_t *slots, int32_t S, const int32_t *bag_offs, int64_t batch,
+                                   const float *dx, int64_t ldx, const float *dlogit, int64_t ld_dlogit, float lr_emb,
+                                   float lr_wide, float l1, float l2, const int32_t *bucket_start, uint64_t *pairs,
+                                   int32_t nbuckets, wd_stream_t stream) {
+  if (batch <= 0) return WD_OK;
+  WD_REQUIRE(rec && emb_accum && dx && dlogit && slots && bag_offs && bucket_start && pairs, "null pointer");
+  WD_REQUIRE(S > 0 && nbuckets > 0 && nbuckets <= MAX_NB, "bad bucket geometry");
+  WD_REQUIRE(dim > 0 && dim % 4 == 0 && rec_stride % 4 == 0 && rec_stride >= dim + 4, "record = [dim | w z n -], 16-byte aligned");
+  UpdArgs u;
+  u.emb = rec; u.accum = emb_accum; u.wide = rec + dim; u.bias = bias_wzn; u.slots = slots; u.bag_offs = bag_offs;
+  u.dx = dx; u.dlogit = dlogit; u.ldx = ldx; u.batch = batch; u.S = S; u.nb = nbuckets;
+  u.ld_dlogit = ld_dlogit > 0 ? ld_dlogit : 1;
+  u.lr_emb = lr_emb; u.lr_w = lr_wide; u.l1 = l1; u.l2 = l2;
+  u.accum_a = u.accum_c = nullptr; u.touched = nullptr; u.oe = OptK{}; u.ow = OptK{}; u.pow_e = u.pow_w = nullptr;
+  u.rec_stride = rec_stride;
+  hipLaunchKernelGGL(k_bucket_update<false>, dim3((unsigned)nbuckets + 1), dim3(256), 0, wd::as_stream(stream), u,
+                     bucket_start, pairs);
+  return wd::check_launch("wd_sparse_apply_rec");
 }
 
 static OptK to_optk(const wd_opt_t *o) {
@@ -792,6 +828,7 @@ extern "C" int wd_sparse_apply_opt(float *emb, float *emb_a, float *emb_b, float
   u.dx = dx; u.dlogit = dlogit; u.ldx = ldx; u.batch = batch; u.S = S; u.nb = nbuckets;
   u.ld_dlogit = ld_dlogit > 0 ? ld_dlogit : 1;
   u.lr_emb = u.lr_w = u.l1 = u.l2 = 0.f;
+  u.rec_stride = 0;
   u.touched = adam ? touched : nullptr;
   u.oe = to_optk(emb ? emb_opt : nullptr); u.ow = to_optk((wide || bias) ? wide_opt : nullptr);
   u.pow_e = (emb && emb_opt->kind == WD_OPT_ADAM) ? emb_opt->pow : nullptr;

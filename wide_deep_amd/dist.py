@@ -197,7 +197,8 @@ class ShardedWideDeepEngine(WideDeepEngine):
         self.n_req = W * self.cap
         # owner side: the received list has n_req entries (padding included) -> capacity of the update workspaces
         super().__init__(local_spec(spec, W), max_batch=max_batch, max_nnz=max(mn, self.n_req), device=device,
-                         seed=seed, expected_nnz=self.n_req, table_seed=int(seed) * 1000003 + 7919 * (self.rank + 1))
+                         seed=seed, expected_nnz=self.n_req, table_seed=int(seed) * 1000003 + 7919 * (self.rank + 1),
+                         row_records=False)
         if not self.default_opts:
             raise NotImplementedError("sharded engine: Adagrad (dnn) + Ftrl (linear) only; the other optimizers of "
                                       "model_util.py:84-90 run on the single-GPU engine")

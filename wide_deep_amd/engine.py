@@ -42,7 +42,7 @@ def _stream():
 
 class WideDeepEngine:
     def __init__(self, spec: ModelSpec, max_batch=8192, max_nnz=None, device="cuda", seed=0, expected_nnz=None,
-                 tower_dtype="fp32", table_seed=None):
+                 tower_dtype="fp32", table_seed=None, row_records=None):
         if not torch.cuda.is_available():
             raise capi.WdError("WideDeepEngine needs a GPU (MI355X / gfx950); there is no CPU fallback")
         capi.load()
@@ -68,6 +68,22 @@ class WideDeepEngine:
         self.max_nnz = int(max_nnz) if max_nnz else self.max_batch * max(plan.S, 1) * 8
         self.inv = 1.0 / math.sqrt(1.0 + BN_EPS)
         self.crelu = plan.crelu      # a relu layer of twice the width with tied halves (plan.py)
+        # Row-record layout (Criteo-shaped models: every categorical column is embedded with ONE width <= 16 AND feeds the
+        # linear part, default optimizers, one GPU): the embedding row and the wide line {w, z, n, -} of a fused row share
+        # ONE 32 / 64 / 128-byte record, so that the forward finds the wide weight in the line it fetched for the row and the
+        # update touches two random lines per row (record + accumulator) instead of three (profiles/r2z_layouts.txt).
+        # row_records=None: on when eligible (WD_ROW_RECORDS=0 turns it off); True: required; False: separate tables.
+        dims = sorted(plan.emb_groups) if spec.has_deep else []
+        eligible = (spec.has_deep and spec.has_wide and self.default_opts and type(self) is WideDeepEngine
+                    and len(dims) == 1 and dims[0] in (4, 8, 16) and plan.n_emb == plan.S and plan.S > 0
+                    and all(sl.wide for sl in plan.slots))
+        if row_records and not eligible:
+            raise ValueError("row_records=True: the model is not record-shaped (one embedding width in {4, 8, 16} on every "
+                             "categorical column, all of them wide columns too, Adagrad + Ftrl, single GPU)")
+        if row_records is None:
+            row_records = os.environ.get("WD_ROW_RECORDS", "1") != "0"
+        self.rec_stride = {4: 8, 8: 16, 16: 32}[dims[0]] if (row_records and eligible) else 0
+        self.rec = None
         self.act_id = capi.ACT_IDS["relu" if self.crelu else spec.activation]
         self.global_step = 0
         dev = self.device
@@ -122,23 +138,35 @@ class WideDeepEngine:
         self.drop_seed = torch.tensor([dseed * 0x9E3779B1 + 12345, 0], dtype=torch.int64, device=dev) if self.dropout else None
         dnn_a, dnn_b = opt_slot_init(spec.dnn_opt) if spec.has_deep else (None, None)
         lin_a, lin_b = opt_slot_init(spec.lin_opt) if spec.has_wide else (None, None)
+        if self.rec_stride:
+            # records [total_rows][rec_stride]; self.emb / self.wide are strided VIEWS of it ([rows, D] / [rows, 4])
+            self.rec = torch.zeros(max(plan.total_rows, 1), self.rec_stride, **f32)
+            rarr = (capi.WdSlot * S)()
+            ctypes.memmove(rarr, arr, ctypes.sizeof(rarr))
+            for i in range(S):
+                rarr[i].emb_off = plan.row_base[i] * self.rec_stride       # row of id = rec + emb_off + id * rec_stride
+            self.rslots_dev = torch.from_numpy(np.frombuffer(bytes(rarr), dtype=np.uint8).copy()).to(dev)
         if spec.has_deep:
             ne = max(plan.emb_elems, 4)
-            self.emb = torch.zeros(ne, **f32)
+            self.emb = torch.zeros(ne, **f32) if self.rec is None else self.rec[:, : dims[0]]
             self.emb_a = torch.full((ne,), dnn_a, **f32) if dnn_a is not None else None      # optimizer slot a
             self.emb_acc = torch.full((ne,), dnn_b, **f32) if dnn_b is not None else None    # optimizer slot b
             self.emb_c = torch.zeros(ne, **f32) if rmsprop_centered(spec.dnn_opt) else None  # slot c (mean gradient)
             for i, s in enumerate(plan.slots):
                 if plan.emb_off[i] >= 0:
-                    v = self.emb[plan.emb_off[i]: plan.emb_off[i] + s.num_buckets * s.dim]
                     std = 1.0 / math.sqrt(s.dim)
-                    # embedding_column initializer: truncated_normal(0, 1/sqrt(dim))  
+                    # embedding_column initializer: truncated_normal(0, 1/sqrt(dim))  (SURVEY App. A.6); drawn into a
+                    # contiguous buffer so that both table layouts start from the same numbers
+                    v = torch.empty(s.num_buckets, s.dim, **f32)
                     torch.nn.init.trunc_normal_(v, mean=0.0, std=std, a=-2 * std, b=2 * std, generator=gt)
+                    self._emb_view(self.emb, i).copy_(v)
+                    del v
         else:
             self.emb = self.emb_a = self.emb_acc = self.emb_c = None
         if spec.has_wide:
             # {w, slot a, slot b, slot c}  (Ftrl: {w, z, n, -}; slot c = centered RMSProp's mean gradient, starts at 0)
-            self.wide = torch.zeros(max(plan.total_rows, 1), 4, **f32)
+            self.wide = (torch.zeros(max(plan.total_rows, 1), 4, **f32) if self.rec is None
+                         else self.rec[:, dims[0]: dims[0] + 4])
             self.bias = torch.zeros(4, **f32)
             for col, v in ((1, lin_a), (2, lin_b)):
                 if v is not None:
@@ -485,6 +513,10 @@ class WideDeepEngine:
         ci.x_out = self._x_ptr(tw)
         ci.ld_dense = bt.dense.stride(0) if nd else 0
         ci.S, ci.slot0, ci.ngroup, ci.dim, ci.ncols = plan.S, sl[0], len(sl), dim, nd
+        if self.rec is not None:       # row records: the wide weight sits behind its embedding row, in the same line
+            ci.emb, ci.slots, ci.row_stride = ptr(self.rec), ptr(self.rslots_dev), self.rec_stride
+            if spec.has_wide:
+                ci.wide, ci.wide_in_row = ptr(self.rec), 1
         return ci
 
     def _tower_chain(self, tw, bt, B, st, train, fuse_in=False):
@@ -553,7 +585,7 @@ class WideDeepEngine:
         """Input layer (embedding bags, indicators, numeric columns) into tower 0's x, and the wide logit."""
         plan, spec = self.plan, self.spec
         B, S = bt.B, plan.S
-        if spec.has_deep and self._fused_input_layer:
+        if spec.has_deep and self._fused_input_layer and self.rec is None:
             # one launch: embedding bags + wide sum + numeric columns
             tw0 = self.towers[0]
             (dim, sl), = plan.emb_groups.items()
@@ -577,7 +609,7 @@ class WideDeepEngine:
                 call("wd_dense_fwd", ptr(bt.dense), bt.dense.stride(0), ptr(self.dense_cols_dev),
                      len(plan.dense_cols), B, xp, ld, st)
         if spec.has_wide:
-            call("wd_wide_fwd", ptr(self.wide), 4, ptr(self.bias), ptr(self.slots_dev), S, ptr(bt.ids),
+            call("wd_wide_fwd", ptr(self.wide), self.rec_stride or 4, ptr(self.bias), ptr(self.slots_dev), S, ptr(bt.ids),
                  ptr(bt.bag_offs), B, ptr(self.wide_logit), st)
 
     def embag_fwd(self, dim, gs, bt, xp, ld, st):
@@ -585,7 +617,10 @@ class WideDeepEngine:
         plan = self.plan
         sl = plan.emb_groups[dim]
         contiguous = sl == list(range(sl[0], sl[0] + len(sl)))
-        if contiguous and dim in (4, 8, 16, 32, 64, 128) and len(sl) <= 128:
+        if self.rec is not None:
+            call("wd_embag_fwd_strided", ptr(self.rec), self.rec_stride, ptr(self.rslots_dev), plan.S, ptr(gs), gs.numel(),
+                 dim, ptr(bt.ids), ptr(bt.bag_offs), bt.B, xp, ld, st)
+        elif contiguous and dim in (4, 8, 16, 32, 64, 128) and len(sl) <= 128:
             call("wd_embag_fwd_range", ptr(self.emb), ptr(self.slots_dev), plan.S, sl[0], len(sl), dim, ptr(bt.ids),
                  None if bt.one_hot else ptr(bt.bag_offs), bt.B, xp, ld, st)
         else:
@@ -904,6 +939,12 @@ class WideDeepEngine:
             tw0 = self.towers[0]
             tl0 = tw0["layout"]
             dx_ptr, ld = tw0["dact"].data_ptr() + 4 * tl0.seg_start[0], tl0.ld
+        if self.rec is not None:
+            call("wd_sparse_apply_rec", ptr(self.rec), self.rec_stride, self.emb.shape[1], ptr(self.emb_acc), ptr(self.bias),
+                 ptr(self.slots_dev), plan.S, ptr(bt.bag_offs), bt.B, dx_ptr, ld, ptr(self.dlogit), 1, float(spec.dnn_opt[1]),
+                 float(spec.lin_opt[1]), float(spec.lin_opt[2]), float(spec.lin_opt[3]), ptr(bsx["start"]), ptr(bsx["pairs"]),
+                 self.n_buckets, st)
+            return
         if self.default_opts:
             lr, l1, l2 = (spec.lin_opt[1], spec.lin_opt[2], spec.lin_opt[3]) if spec.has_wide else (0.0, 0.0, 0.0)
             call("wd_sparse_apply", ptr(self.emb) if has_emb else None, ptr(self.emb_acc) if has_emb else None,
@@ -929,6 +970,8 @@ class WideDeepEngine:
         plan, spec = self.plan, self.spec
         if not self.default_opts:
             raise NotImplementedError("the sort-based reference path implements Adagrad (dnn) + Ftrl (linear) only")
+        if self.rec is not None:
+            raise NotImplementedError("the sort-based reference path works on separate tables (row_records=False)")
         B, S = bt.B, plan.S
         has_emb = bool(self.group_slots) if spec.has_deep else False
         if bt.nnz > 0 and (has_emb or spec.has_wide):
@@ -1094,6 +1137,9 @@ class WideDeepEngine:
     def _emb_view(self, buf, i):
         """[num_buckets, dim] view of slot i's rows in an embedding-shaped buffer (the table or one of its optimizer slots)."""
         s, off = self.plan.slots[i], self.plan.emb_off[i]
+        if self.rec is not None and buf is self.emb:       # row-record layout: the table is a strided view of the records
+            r0 = self.plan.row_base[i]
+            return self.rec[r0: r0 + s.num_buckets, : s.dim]
         return buf[off: off + s.num_buckets * s.dim].view(s.num_buckets, s.dim)
 
     def _slot_bufs(self, scope):

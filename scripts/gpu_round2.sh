@@ -3,6 +3,10 @@
 # fp16 GEMM microbench + PMC.  Output -> gpurun_out/<tag>/ ; what is judged is copied into profiles/ (r2z_*).
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; export TMPDIR=/tmp
 TAG=${1:-r2z}; OUT=$PWD/gpurun_out/$TAG; mkdir -p $OUT
+if [ "${PYTEST:-0}" = 1 ]; then
+  timeout 1500 python -m pytest tests -q -m gpu -x > $OUT/pytest_gpu.txt 2>&1; tail -n 3 $OUT/pytest_gpu.txt
+  timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $OUT/smoke.txt 2>&1; tail -n 1 $OUT/smoke.txt
+fi
 timeout 600 python bench.py > $OUT/bench_c2_uniform.json 2> $OUT/bench.err; cut -c1-200 $OUT/bench_c2_uniform.json
 timeout 600 python bench.py --steps 20 --warmup 5 > $OUT/bench_c2_uniform_driver_args.json 2>> $OUT/bench.err; cut -c1-200 $OUT/bench_c2_uniform_driver_args.json
 timeout 300 python bench.py --dist zipf --no-cpu-baseline --no-pmc > $OUT/bench_c2_zipf.json 2>> $OUT/bench.err; cut -c1-200 $OUT/bench_c2_zipf.json
@@ -10,6 +14,8 @@ timeout 300 python bench.py --config c3 --no-cpu-baseline --no-pmc --steps 100 >
 timeout 300 python bench.py --config c4 --no-cpu-baseline --steps 100 > $OUT/bench_c4.json 2>> $OUT/bench.err; cut -c1-200 $OUT/bench_c4.json
 timeout 300 python bench.py --config c5 --no-cpu-baseline --steps 60 > $OUT/bench_c5_fp16.json 2>> $OUT/bench.err; cut -c1-200 $OUT/bench_c5_fp16.json
 timeout 300 python bench.py --no-graph --no-cpu-baseline --no-pmc --no-parity --steps 100 > $OUT/bench_c2_eager_launches.json 2>> $OUT/bench.err; cut -c1-200 $OUT/bench_c2_eager_launches.json
+WD_ROW_RECORDS=0 timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-pmc > $OUT/bench_c2_uniform_separate_tables.json 2>> $OUT/bench.err; cut -c1-200 $OUT/bench_c2_uniform_separate_tables.json
+timeout 300 python bench.py --steps 20 --warmup 5 --force-sharded --no-cpu-baseline --no-pmc --no-parity > $OUT/bench_c2_sharded_one_rank.json 2>> $OUT/bench.err; cut -c1-200 $OUT/bench_c2_sharded_one_rank.json
 scripts/gpu_timeline.sh $TAG/tl --steps 75 > /dev/null 2>&1
 cp $OUT/tl/kernel_stats.md $OUT/c2_uniform_kernel_stats.md; cp $OUT/tl/kernel_stats.csv $OUT/c2_uniform_kernel_stats.csv
 python - $OUT <<'PY'

@@ -292,9 +292,10 @@ class ShardedWideDeepEngine(WideDeepEngine):
                 v[r0: r0 + s.num_buckets, : s.dim] = old[lp.emb_off[i]: lp.emb_off[i] + s.num_buckets * s.dim].view(
                     s.num_buckets, s.dim)
             setattr(self, name, new)
+        self._padded = True
 
     def _emb_view(self, buf, i):
-        if not self.mixed_dims:
+        if not self.mixed_dims or not getattr(self, "_padded", False):     # (the base constructor fills the flat layout first)
             return super()._emb_view(buf, i)
         s, r0 = self.plan.slots[i], self.plan.row_base[i]
         return buf[: self.n_emb_rows * self.dim].view(self.n_emb_rows, self.dim)[r0: r0 + s.num_buckets, : s.dim]

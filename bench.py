@@ -215,8 +215,10 @@ def gather_instep_roofline(eng, dev_batches, step_eager, steps=16):
             "traffic_source": "no per-phase counter exists; the PMC traffic of the same rows through the stand-alone kernel is in "
                               "roofline_gather_kernel",
             "algorithmic_bytes_per_launch": int(alg), "avg_launch_us": round(us, 2), "measured": how,
-            "note": "algorithmic bytes = SURVEY 8(d) gather contract only; the phase also reads one 16-byte wide {w,z,n} line per "
-                    "occurrence and the numeric columns and writes the wide logit (not counted)"}
+            "note": "algorithmic bytes = SURVEY 8(d) gather contract only; the phase also reads the wide weight of every occurrence "
+                    + ("(row records: it sits in the line fetched for the embedding row)" if eng.rec is not None
+                       else "(one more 16-byte {w,z,n} line per occurrence)")
+                    + ", the numeric columns, and writes the wide logit (not counted)"}
 
 
 def synth_hash(eng, tb):

@@ -780,6 +780,129 @@ k_logits_head(const TA *__restrict__ a, int64_t ld_a, int64_t K, const float *__
   }
 }
 
+// Wide logits layers (dense / resnet / last_dense windows: K in the thousands) with 16-byte loads: the scalar geometry above
+// issues one 2- or 4-byte load per element (C5: 106 us for 57 MB of half activations).  Same two phases, same outputs:
+//   phase 1: one wavefront per example (4 at a time), lane <- 16-byte vectors lane, lane + 64, ... of the row
+//   phase 2: thread <- one 16-byte vector of columns for all 16 examples of the workgroup (rows are L2-warm from phase 1)
+// Needs a, wf 16-byte aligned and ld_a a multiple of the vector length (checked by the launcher); columns beyond the last
+// whole vector are done element-wise.
+template <typename TA>
+__global__ void __launch_bounds__(256)
+k_logits_head_wide(const TA *__restrict__ a, int64_t ld_a, int64_t K, const float *__restrict__ wf,
+                   const float *__restrict__ bf, int32_t bias_parts, const float *__restrict__ wide_logit,
+                   const float *__restrict__ labels, const float *__restrict__ weights, int64_t batch,
+                   float *__restrict__ dnn_logit, float *__restrict__ logit, float *__restrict__ prob,
+                   float *__restrict__ dlogit, float *__restrict__ loss_sum, float *__restrict__ out, int64_t ld_out,
+                   int32_t act, float *__restrict__ Gpart) {
+  constexpr int CH = 16;
+  constexpr int V = 16 / (int)sizeof(TA);
+  typedef TA vec_t __attribute__((ext_vector_type(V)));
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  __shared__ float sdl[CH];
+  const int64_t b0 = (int64_t)blockIdx.x * CH;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t KV = K / V;
+  float bias = 0.f;
+  for (int p = 0; p < bias_parts; ++p) bias += bf[p];
+  float lsum = 0.f;
+  for (int ex = wave; ex < CH; ex += 4) {
+    const int64_t b = b0 + ex;
+    const bool live = b < batch;
+    float d = 0.f;
+    if (live) {
+      const TA *ar = a + b * ld_a;
+#pragma unroll 4
+      for (int64_t c = lane; c < KV; c += 64) {
+        const vec_t va = *reinterpret_cast<const vec_t *>(ar + c * V);
+        const f4 *w4 = reinterpret_cast<const f4 *>(wf + c * V);
+#pragma unroll
+        for (int j = 0; j < V / 4; ++j) {
+          const f4 w = w4[j];
+          d += (float)va[4 * j] * w.x;
+          d += (float)va[4 * j + 1] * w.y;
+          d += (float)va[4 * j + 2] * w.z;
+          d += (float)va[4 * j + 3] * w.w;
+        }
+      }
+      for (int64_t k = KV * V + lane; k < K; k += 64) d += (float)ar[k] * wf[k];
+    }
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) d += __shfl_xor(d, off, 64);
+    float dl = 0.f;
+    if (live && lane == 0) {
+      const float dn = d + bias;
+      const float x = dn + (wide_logit ? wide_logit[b] : 0.f);
+      const float y = labels ? labels[b] : 0.f;
+      const float w = weights ? weights[b] : 1.0f;
+      const float e = expf(-fabsf(x));
+      const float p = x >= 0.f ? 1.0f / (1.0f + e) : e / (1.0f + e);
+      dl = w * (p - y);
+      lsum += w * (fmaxf(x, 0.f) - x * y + log1pf(e));
+      if (dnn_logit) dnn_logit[b] = dn;
+      if (logit) logit[b] = x;
+      if (prob) prob[b] = p;
+      if (dlogit) dlogit[b] = dl;
+    }
+    if (lane == 0) sdl[ex] = dl;
+  }
+  for (int off = 32; off > 0; off >>= 1) lsum += __shfl_down(lsum, off, 64);
+  if (lane == 0 && loss_sum) atomicAdd(loss_sum, lsum);
+  if (!out && !Gpart) return;
+  __syncthreads();
+  float *Gp = Gpart ? Gpart + (int64_t)blockIdx.x * (K + 1) : nullptr;
+  const int nlive = (int)(batch - b0 < CH ? batch - b0 : CH);
+  const bool out_vec = out && (reinterpret_cast<uintptr_t>(out) & 15) == 0 && (ld_out & 3) == 0;
+  for (int64_t c = threadIdx.x; c < KV; c += 256) {
+    float w[V], gw[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) { w[j] = wf[c * V + j]; gw[j] = 0.f; }
+#pragma unroll 4
+    for (int i = 0; i < nlive; ++i) {
+      const int64_t b = b0 + i;
+      const vec_t va = *reinterpret_cast<const vec_t *>(a + b * ld_a + c * V);
+      const float dl = sdl[i];
+      float o[V];
+#pragma unroll
+      for (int j = 0; j < V; ++j) {
+        const float av = (float)va[j];
+        gw[j] += av * dl;
+        o[j] = act ? dl * w[j] * act_bwd(av, act) : dl * w[j];
+      }
+      if (out) {
+        float *op = out + b * ld_out + c * V;
+        if (out_vec) {
+#pragma unroll
+          for (int j = 0; j < V / 4; ++j) *reinterpret_cast<f4 *>(op + 4 * j) = f4{o[4 * j], o[4 * j + 1], o[4 * j + 2], o[4 * j + 3]};
+        } else {
+#pragma unroll
+          for (int j = 0; j < V; ++j) op[j] = o[j];
+        }
+      }
+    }
+    if (Gp) {
+#pragma unroll
+      for (int j = 0; j < V; ++j) Gp[c * V + j] = gw[j];
+    }
+  }
+  for (int64_t k = KV * V + threadIdx.x; k < K; k += 256) {
+    const float w = wf[k];
+    float gw = 0.f;
+    for (int i = 0; i < nlive; ++i) {
+      const int64_t b = b0 + i;
+      const float av = (float)a[b * ld_a + k];
+      const float dl = sdl[i];
+      gw += av * dl;
+      if (out) out[b * ld_out + k] = act ? dl * w * act_bwd(av, act) : dl * w;
+    }
+    if (Gp) Gp[k] = gw;
+  }
+  if (threadIdx.x == 0 && Gp) {
+    float v = 0.f;
+    for (int i = 0; i < CH; ++i) v += sdl[i];
+    Gp[K] = v;
+  }
+}
+
 __global__ void __launch_bounds__(256)
 k_adagrad_dense(float *__restrict__ w, float *__restrict__ accum, const float *__restrict__ g, int64_t n, float lr) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1020,7 +1143,13 @@ static void launch_head(hipStream_t st, const TA *a, int64_t ld_a, int64_t K, co
                         int64_t batch, float *dnn_logit, float *logit, float *prob, float *dlogit, float *loss_sum,
                         float *out, int64_t ld_out, int32_t act, float *Gpart) {
   const dim3 grid((unsigned)wd::ceil_div(batch, head_chunk(K)));
-  if (K > HEAD_K_WIDE)
+  constexpr int64_t V = 16 / (int64_t)sizeof(TA);
+  const bool vec_ok = (reinterpret_cast<uintptr_t>(a) & 15) == 0 && (reinterpret_cast<uintptr_t>(wf) & 15) == 0 &&
+                      ld_a % V == 0 && getenv("WD_HEAD_SCALAR") == nullptr;
+  if (K > HEAD_K_WIDE && vec_ok)
+    hipLaunchKernelGGL((k_logits_head_wide<TA>), grid, dim3(256), 0, st, a, ld_a, K, wf, bf, bias_parts, wide_logit,
+                       labels, weights, batch, dnn_logit, logit, prob, dlogit, loss_sum, out, ld_out, act, Gpart);
+  else if (K > HEAD_K_WIDE)
     hipLaunchKernelGGL((k_logits_head<TA, 16, 64>), grid, dim3(256), 0, st, a, ld_a, K, wf, bf, bias_parts, wide_logit,
                        labels, weights, batch, dnn_logit, logit, prob, dlogit, loss_sum, out, ld_out, act, Gpart);
   else

@@ -435,7 +435,11 @@ __device__ __forceinline__ void fold_affine_body(const float *__restrict__ P, in
   float tb = 0.f;
   // U rows per trip, in three rounds of independent loads (indices -> affine parameters + kernel row -> stores): the
   // per-row chain idx -> P[idx] -> store used to cost one exposed round trip per row (128 us at C5's 5 M weights)
-  constexpr int U = 4;
+#ifndef WD_FOLD_U
+#define WD_FOLD_U 8
+#endif
+  constexpr int U = WD_FOLD_U;      // 8: layers with thousands of rows and few column tiles (C5: K 3469 x N 128 = 32 workgroups
+                                    // of 217 rows) are a serial chain of trips; 4 -> 8 rows per trip halves it
   for (int64_t kb = k0 + ty; kb < k1; kb += 4 * U) {
     int32_t gi[U], bi[U];
     int64_t co[U];
@@ -668,6 +672,47 @@ k_mlp_finalize(const float *__restrict__ Gpart, int32_t nsplit, const float *__r
   __shared__ float red_g[256], red_d[256];
   mlp_finalize_body(Gpart, nsplit, P, w_off, b_off, s, t, gamma_idx, beta_idx, inv, Gflat, K, N, blockIdx.x, false,
                     red_g, red_d);
+}
+
+// N == 1 (the logits layer; its partials come one per 16 / 64 examples from wd_logits_head: hundreds of splits): the row-per-
+// workgroup geometry above reads one 4-byte value per 64-byte line (72 us at C5: 3470 rows x 512 splits).  Here a workgroup
+// owns 16 consecutive rows k, thread (kx, zq) sums splits zq, zq + 16, ... of row k0 + kx -- 64-byte segments per split --
+// and the 16 partial sums are combined in the same fixed order as above (bit-identical results).
+__global__ void __launch_bounds__(256)
+k_mlp_finalize_vec(const float *__restrict__ Gpart, int32_t nsplit, const float *__restrict__ P, int64_t w_off,
+                   int64_t b_off, const float *__restrict__ s, const float *__restrict__ t,
+                   const int32_t *__restrict__ gamma_idx, const int32_t *__restrict__ beta_idx, float inv,
+                   float *__restrict__ Gflat, int64_t K) {
+  __shared__ float red_g[256], red_d[256];
+  const int kx = threadIdx.x & 15, zq = threadIdx.x >> 4;
+  const int64_t k = (int64_t)blockIdx.x * 16 + kx;
+  const int64_t stride = K + 1;
+  float gk = 0.f, db = 0.f;
+  if (k <= K) {
+#pragma unroll 8
+    for (int32_t z = zq; z < nsplit; z += 16) {
+      gk += Gpart[z * stride + k];
+      db += Gpart[z * stride + K];
+    }
+  }
+  red_g[zq * 16 + kx] = gk;
+  red_d[zq * 16 + kx] = db;
+  __syncthreads();
+  if (zq != 0 || k > K) return;
+  for (int j = 1; j < 16; ++j) {
+    gk += red_g[j * 16 + kx];
+    db += red_d[j * 16 + kx];
+  }
+  if (k == K) {
+    Gflat[b_off] = db;
+    return;
+  }
+  Gflat[w_off + k] = s[k] * gk + t[k] * db;
+  const float w = P[w_off + k];
+  const int32_t gi = gamma_idx ? gamma_idx[k] : -1;
+  const int32_t bi = beta_idx ? beta_idx[k] : -1;
+  if (gi >= 0) Gflat[gi] += (w * gk) * inv;
+  if (bi >= 0) Gflat[bi] += w * db;
 }
 
 // all layers in one launch (blockIdx.y = layer): legal only when every BN gamma/beta has ONE consumer layer
@@ -1070,8 +1115,12 @@ extern "C" int wd_mlp_finalize(const float *Gpart, int32_t nsplit, const float *
                                float inv, float *Gflat, int64_t K, int64_t N, wd_stream_t stream) {
   WD_REQUIRE(Gpart && P && s && t && Gflat, "null pointer");
   WD_REQUIRE(K > 0 && N > 0 && nsplit > 0, "K, N, nsplit must be > 0");
-  hipLaunchKernelGGL(k_mlp_finalize, dim3((unsigned)(K + 1)), dim3(256), 0, wd::as_stream(stream), Gpart, nsplit, P,
-                     w_off, b_off, s, t, gamma_idx, beta_idx, inv, Gflat, K, N);
+  if (N == 1 && nsplit >= 32 && getenv("WD_FINALIZE_ROWS") == nullptr)
+    hipLaunchKernelGGL(k_mlp_finalize_vec, dim3((unsigned)wd::ceil_div(K + 1, 16)), dim3(256), 0, wd::as_stream(stream),
+                       Gpart, nsplit, P, w_off, b_off, s, t, gamma_idx, beta_idx, inv, Gflat, K);
+  else
+    hipLaunchKernelGGL(k_mlp_finalize, dim3((unsigned)(K + 1)), dim3(256), 0, wd::as_stream(stream), Gpart, nsplit, P,
+                       w_off, b_off, s, t, gamma_idx, beta_idx, inv, Gflat, K, N);
   return wd::check_launch("wd_mlp_finalize");
 }
 

@@ -91,14 +91,30 @@ class StepGraph:
             keep.append(ev)
             return ev
 
+        # ---- hash branch: tokens -> ids of EVERY step of the graph, back to back at its head (WD_PIPE_HASH=ahead, default).
+        # They depend on nothing; hashed one step ahead on the input branch (WD_PIPE_HASH=step) the hash of step t+1 lands in
+        # the gather phase of tower(t) -- both latency-bound -- and takes 12-17 us there instead of 4.
+        hash_ahead = os.environ.get("WD_PIPE_HASH", "ahead") == "ahead" and not ids_input
+        ev_hash = []
+        if hash_ahead:
+            s_h = eng._side(1)
+            s_h.wait_stream(main)
+            with torch.cuda.stream(s_h):
+                for tb in tbs:
+                    synth.hash_tokens(eng, tb)
+                    ev_hash.append(event(s_h))
         for t, tb in enumerate(tbs):
             bt = tb.batch
             eng._check_batch(bt)
-            # ---- input branch: tokens -> ids (depends on nothing: the hashes of all steps of the graph may run early) ----
-            with torch.cuda.stream(s_in):
-                if not ids_input:
-                    synth.hash_tokens(eng, tb)
-                ev_ids = event(s_in)
+            # ---- input branch: tokens -> ids (depends on nothing) ----
+            if hash_ahead:
+                s_in.wait_event(ev_hash[t])
+                ev_ids = ev_hash[t]
+            else:
+                with torch.cuda.stream(s_in):
+                    if not ids_input:
+                        synth.hash_tokens(eng, tb)
+                    ev_ids = event(s_in)
             # ---- bucketing: ids -> row-range buckets (scratch set t % 2).  WD_PIPE_BUCKET=early: on the input branch, released
             # by the END of tower(t-1) -- it then runs beside the products / update of step t-1 instead of beside tower(t),
             # whose one-workgroup-per-CU grid it slows down (99 us in the step against 90 alone)
@@ -140,6 +156,8 @@ class StepGraph:
             eng._dense_backward(bt, main.cuda_stream, after_products=update_then_join)
         main.wait_stream(s_in)
         main.wait_stream(s_sp)
+        if hash_ahead:
+            main.wait_stream(s_h)
 
     def replay(self):
         self.graph.replay()

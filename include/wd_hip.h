@@ -100,6 +100,72 @@ typedef struct wd_cross_keys {
 int wd_cross_hash(const wd_cross_keys_t *keys_host, int64_t batch, uint64_t hash_key, uint64_t num_buckets,
                   const int32_t *bag_offs, int32_t S, int32_t slot, int32_t *ids, wd_stream_t stream);
 
+/* ---- a4-a6 for a WHOLE batch on the device (python/lib/build_estimator.py:83-158: every categorical column of the conf) ----
+ * Instead of one emit launch per column with host-prepared value arrays (wd_emit_*_slot / wd_cross_hash), the host uploads
+ * the parsed batch as it is -- token bytes + offsets of all string features, integer / float features as
+ * [feature][example] matrices -- and four launches build the example-major bag CSR of ids:
+ *   wd_fingerprint64 (all tokens) -> wd_feat_vocab_lookup (per vocabulary_list column) -> wd_feat_lens -> wd_feat_offsets
+ *   -> wd_feat_emit.
+ * Column semantics (same as the per-column entry points; reference lines in the a4-a6 sections above):
+ *   HASH      id = Fingerprint64(token) % num_buckets, one per token
+ *   VOCAB     index in vocabulary_list, out-of-vocabulary tokens dropped
+ *   IDENTITY  v if 0 <= v < num_buckets else 0; v == -1 (missing) gives no id
+ *   BUCKET    number of boundaries <= normalizer(x): the wide twin of a continuous column (quirk C.5: boundaries are raw)
+ *   CROSS     cartesian product over the keys, LAST key fastest, h = hash_key; h = FingerprintCat64(h, v_k); id = h % num_buckets;
+ *             a STRING key contributes its tokens' fingerprints -- with `lmax` (the reference's padded_batch, quirk C.16) every
+ *             example contributes lmax[feature] values, the missing ones being Fingerprint64('') --, an IDENTITY key its id
+ *             (none if -1), a BUCKET key bucketize(raw x). */
+#define WD_FEAT_HASH 0
+#define WD_FEAT_VOCAB 1
+#define WD_FEAT_IDENTITY 2
+#define WD_FEAT_BUCKET 3
+#define WD_FEAT_CROSS 4
+#define WD_FEAT_KEY_STRING 0
+#define WD_FEAT_KEY_IDENTITY 1
+#define WD_FEAT_KEY_BUCKET 2
+typedef struct wd_feat_key {
+  int32_t kind;          /* WD_FEAT_KEY_* */
+  int32_t src;           /* string feature index / row of `ints` / row of `floats` */
+  int32_t num_buckets;   /* IDENTITY: range of valid ids */
+  int32_t nbound;        /* BUCKET: boundaries[bound_off .. bound_off + nbound) of wd_feat_batch_t.bounds */
+  int32_t bound_off;
+  int32_t pad_;
+} wd_feat_key_t;
+typedef struct wd_feat_slot {
+  int32_t kind;          /* WD_FEAT_* */
+  int32_t src;           /* HASH / VOCAB: string feature index; IDENTITY: row of `ints`; BUCKET: row of `floats` */
+  int32_t num_buckets;
+  int32_t nbound, bound_off;
+  int32_t norm_kind;     /* BUCKET: 0 none, 1 (x - p0) / (p1 - p0), 2 (x - p0) / p1 (log: applied by the host) */
+  float p0, p1;
+  int32_t nkeys;         /* CROSS */
+  int32_t pad_;
+  uint64_t hash_key;
+  wd_feat_key_t keys[WD_MAX_CROSS_KEYS];
+} wd_feat_slot_t;
+typedef struct wd_feat_batch {
+  const uint64_t *fp;        /* [T + 1] Fingerprint64 of every token; entry T = the trailing '' token (cross padding) */
+  const int32_t *tok_val;    /* [T] vocabulary index per token (wd_feat_vocab_lookup), -1 = not in the list; NULL: no VOCAB column */
+  const int32_t *ex_offs;    /* [F][batch + 1] token ranges per string feature and example, relative to tok_base[f] */
+  const int32_t *tok_base;   /* [F] first token of feature f in fp / tok_val */
+  const int32_t *lmax;       /* [F] longest token list of feature f in THIS batch (tf_dense cross padding); NULL: ragged */
+  const int64_t *ints;       /* [NI][batch] */
+  const float *floats;       /* [NF][batch] */
+  const float *bounds;       /* boundaries of all bucketized columns / keys */
+  int64_t batch;
+  int32_t S;                 /* slots per example (= rows of the slot table) */
+  int32_t empty_index;       /* T */
+} wd_feat_batch_t;
+int wd_feat_vocab_lookup(const uint8_t *bytes, const int32_t *tok_offs, int64_t tok_begin, int64_t n,
+                         const uint8_t *vocab_bytes, const int32_t *vocab_offs, int32_t nvocab, int32_t *tok_val,
+                         wd_stream_t stream);
+int wd_feat_lens(const wd_feat_slot_t *slots_dev, const wd_feat_batch_t *batch, int32_t *lens, wd_stream_t stream);
+int64_t wd_feat_offsets_workspace_bytes(int64_t n);
+int wd_feat_offsets(const int32_t *lens, int64_t n, int32_t *offs, void *workspace, int64_t workspace_bytes,
+                    wd_stream_t stream);
+int wd_feat_emit(const wd_feat_slot_t *slots_dev, const wd_feat_batch_t *batch, const int32_t *bag_offs, int32_t *ids,
+                 wd_stream_t stream);
+
 /* ---- a8: tf.feature_column.input_layer (python/lib/dnn.py:83-90) ---------------------------
  * Fused multi-slot embedding-bag gather: for every slot g in group_slots (all of one dim D):
  *   x[b, out_col_g .. +D) = mean_{ids in bag(b,g)} emb[emb_off_g + id*D ..]   (empty bag -> 0). */

@@ -79,7 +79,7 @@ def host_featurizer(monkeypatch):
         spec = BE.build_model_spec(Config(), model_type)
         eng = types.SimpleNamespace(plan=PL.FeaturePlan(spec), spec=spec, device=torch.device("cpu"), max_batch=max_batch,
                                     max_nnz=max_batch * len(spec.slots) * 16)
-        return eng, F.Featurizer(eng, cross_padding=padding)
+        return eng, F.Featurizer(eng, cross_padding=padding, mode="host")
     return make
 
 

@@ -28,8 +28,11 @@ def _write(tmp_path, lines, name="rows.tsv"):
     return str(p)
 
 
+@pytest.mark.parametrize("mode", ["device", "host"])
 @pytest.mark.parametrize("padding", ["tf_dense", "ragged"])
-def test_every_column_id_bit_exact_on_real_rows(tmp_path, padding):
+def test_every_column_id_bit_exact_on_real_rows(tmp_path, padding, mode):
+    """mode: the featurizer that builds the whole bag CSR on the GPU from a device-side slot table (default), and round 1's
+    per-column host arithmetic + one emit launch per column; both against oracle/columns.py, and against each other."""
     from oracle import columns as OC
     from tests.helpers import slot_csr
     from wide_deep_amd import build_estimator as BE, dataset as DS
@@ -40,12 +43,18 @@ def test_every_column_id_bit_exact_on_real_rows(tmp_path, padding):
     path = _write(tmp_path, lines)
     spec = BE.build_model_spec(Config(), "wide")          # wide-only: every categorical column, no big embedding tables
     eng = WideDeepEngine(spec, max_batch=512, max_nnz=512 * 70 * 16)
-    fz = Featurizer(eng, cross_padding=padding)
+    fz = Featurizer(eng, cross_padding=padding, mode=mode)
+    other = Featurizer(eng, cross_padding=padding, mode="host" if mode == "device" else "device")
+    assert fz.mode == mode
     oc = OC.Columns(conf_dir())
     k = 0
     for raw in DS.input_fn(path, None, "eval", 512):
         bt = fz.to_device(raw)
+        b2 = other.to_device(raw)
         torch.cuda.synchronize()
+        assert bt.nnz == b2.nnz and bt.one_hot == b2.one_hot and torch.equal(bt.bag_offs, b2.bag_offs)
+        assert torch.equal(bt.ids[:bt.nnz], b2.ids[:b2.nnz]) and torch.equal(bt.labels, b2.labels)
+        assert (bt.dense is None and b2.dense is None) or torch.equal(bt.dense, b2.dense)
         got = slot_csr(eng.plan, bt.ids.cpu().numpy(), bt.bag_offs.cpu().numpy(), raw.B)
         exp = oc.transform(oc.parse(lines[k:k + raw.B]), cross_padding=padding)["ids"]
         k += raw.B

@@ -119,6 +119,29 @@ class WdCrossKeys(ctypes.Structure):
     ]
 
 
+WD_FEAT_KINDS = {"hash": 0, "vocab": 1, "identity": 2, "bucket": 3, "cross": 4}
+WD_FEAT_KEY_KINDS = {"string": 0, "identity": 1, "bucket": 2}
+
+
+class WdFeatKey(ctypes.Structure):
+    _fields_ = [("kind", ctypes.c_int32), ("src", ctypes.c_int32), ("num_buckets", ctypes.c_int32), ("nbound", ctypes.c_int32),
+                ("bound_off", ctypes.c_int32), ("pad_", ctypes.c_int32)]
+
+
+class WdFeatSlot(ctypes.Structure):
+    _fields_ = [("kind", ctypes.c_int32), ("src", ctypes.c_int32), ("num_buckets", ctypes.c_int32), ("nbound", ctypes.c_int32),
+                ("bound_off", ctypes.c_int32), ("norm_kind", ctypes.c_int32), ("p0", ctypes.c_float), ("p1", ctypes.c_float),
+                ("nkeys", ctypes.c_int32), ("pad_", ctypes.c_int32), ("hash_key", ctypes.c_uint64),
+                ("keys", WdFeatKey * WD_MAX_CROSS_KEYS)]
+
+
+class WdFeatBatch(ctypes.Structure):
+    _fields_ = [("fp", ctypes.c_void_p), ("tok_val", ctypes.c_void_p), ("ex_offs", ctypes.c_void_p),
+                ("tok_base", ctypes.c_void_p), ("lmax", ctypes.c_void_p), ("ints", ctypes.c_void_p),
+                ("floats", ctypes.c_void_p), ("bounds", ctypes.c_void_p), ("batch", ctypes.c_int64), ("S", ctypes.c_int32),
+                ("empty_index", ctypes.c_int32)]
+
+
 P = ctypes.c_void_p
 I32, I64, U64, F32, SZ = ctypes.c_int32, ctypes.c_int64, ctypes.c_uint64, ctypes.c_float, ctypes.c_size_t
 
@@ -130,6 +153,11 @@ _PROTOS = {
     "wd_emit_hash_slot": [P, P, I64, U64, P, I32, I32, P, P],
     "wd_emit_int_slot": [P, P, I64, P, I32, I32, P, P],
     "wd_cross_hash": [ctypes.POINTER(WdCrossKeys), I64, U64, U64, P, I32, I32, P, P],
+    "wd_feat_vocab_lookup": [P, P, I64, I64, P, P, I32, P, P],
+    "wd_feat_lens": [P, ctypes.POINTER(WdFeatBatch), P, P],
+    "wd_feat_offsets_workspace_bytes": [I64],
+    "wd_feat_offsets": [P, I64, P, P, I64, P],
+    "wd_feat_emit": [P, ctypes.POINTER(WdFeatBatch), P, P, P],
     "wd_embag_fwd": [P, P, I32, P, I32, I32, P, P, I64, P, I64, P],
     "wd_embag_fwd_range": [P, P, I32, I32, I32, I32, P, P, I64, P, I64, P],
     "wd_input_layer_fwd": [P, P, I32, I32, I32, I32, P, P, I32, I64, P, I64, P, I64, P, I32, P, P, P, P],
@@ -191,7 +219,7 @@ _PROTOS = {
     "wd_diag_gather64": [P, P, I64, I32, P, P],
     "wd_diag_access": [P, P, P, I32, P, I64, I32, I32, P, P],
 }
-_RESTYPES = {"wd_sort_workspace_bytes": SZ, "wd_logits_head_blocks": I64, "wd_tower_chain_lds_bytes": I64, "wd_tower_chain_blocks": I64, "wd_bucket_max": I32, "wd_bucket_chunks": I32, "wd_route_chunks": I32}
+_RESTYPES = {"wd_feat_offsets_workspace_bytes": I64, "wd_sort_workspace_bytes": SZ, "wd_logits_head_blocks": I64, "wd_tower_chain_lds_bytes": I64, "wd_tower_chain_blocks": I64, "wd_bucket_max": I32, "wd_bucket_chunks": I32, "wd_route_chunks": I32}
 
 EXPORTED_SYMBOLS = sorted(list(_PROTOS) + ["wd_last_error"])
 

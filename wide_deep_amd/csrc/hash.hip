@@ -7,6 +7,8 @@
 //
 // Integer, HBM/latency-bound work: one token per lane, tokens packed back to back so a wavefront
 // touches one contiguous span of the byte buffer.  No LDS needed; 64-bit integer VALU only.
+#include <rocprim/device/device_scan.hpp>
+
 #include "common.h"
 
 namespace {
@@ -241,7 +243,202 @@ __global__ void k_cross_hash(CrossArgs a, int64_t batch, uint64_t hash_key, uint
   }
 }
 
+// ---- featurizer on the device (python/lib/build_estimator.py:83-158 for a whole batch in four launches) --------------------
+// One thread per (example, slot).  The slot table says what the column is; the batch descriptor where its raw values are:
+// tokens of string features as fingerprints fp[] (+ vocabulary indices tok_val[] for vocabulary_list columns), integer and
+// float features as [feature][example] matrices.  `feat_count` = how many ids the column gives the example, `feat_emit`
+// writes them at the bag's offset -- the same walk twice, so that no per-slot compacted array ever exists.
+__device__ __forceinline__ int32_t feat_bucketize(const float *__restrict__ bounds, int32_t n, float x) {
+  int32_t lo = 0, hi = n;            // number of boundaries <= x (np.searchsorted(side='right'), tf bucketized_column)
+  while (lo < hi) {
+    const int32_t mid = (lo + hi) >> 1;
+    if (bounds[mid] <= x) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
+__device__ __forceinline__ float feat_normalize(float x, int32_t kind, float p0, float p1) {
+  if (kind == 1) return (x - p0) / (p1 - p0);
+  if (kind == 2) return (x - p0) / p1;
+  return x;                           // (log-normalised columns arrive normalised: the host applies np.log)
+}
+
+// count of key k of a crossed column for example b, and its j-th value (uint64: fingerprint / int64 id)
+__device__ __forceinline__ int32_t feat_key_count(const wd_feat_key_t &k, const wd_feat_batch_t &q, int64_t b) {
+  if (k.kind == WD_FEAT_KEY_STRING) {
+    if (q.lmax) return q.lmax[k.src];                              // tf_dense: padded_batch + '' padding (quirk C.16)
+    const int32_t *eo = q.ex_offs + (int64_t)k.src * (q.batch + 1);
+    return eo[b + 1] - eo[b];
+  }
+  if (k.kind == WD_FEAT_KEY_IDENTITY) return q.ints[(int64_t)k.src * q.batch + b] != -1 ? 1 : 0;
+  return 1;
+}
+
+__device__ __forceinline__ uint64_t feat_key_value(const wd_feat_key_t &k, const wd_feat_batch_t &q, int64_t b, int32_t j) {
+  if (k.kind == WD_FEAT_KEY_STRING) {
+    const int32_t *eo = q.ex_offs + (int64_t)k.src * (q.batch + 1);
+    const int32_t real = eo[b + 1] - eo[b];
+    return j < real ? q.fp[q.tok_base[k.src] + eo[b] + j] : q.fp[q.empty_index];
+  }
+  if (k.kind == WD_FEAT_KEY_IDENTITY) {
+    const int64_t v = q.ints[(int64_t)k.src * q.batch + b];
+    return (uint64_t)((v >= 0 && v < k.num_buckets) ? v : 0);      // default_value = 0 for out-of-range ids
+  }
+  return (uint64_t)feat_bucketize(q.bounds + k.bound_off, k.nbound, q.floats[(int64_t)k.src * q.batch + b]);
+}
+
+template <bool EMIT>
+__global__ void __launch_bounds__(256)
+k_feat(const wd_feat_slot_t *__restrict__ slots, wd_feat_batch_t q, int32_t *__restrict__ lens,
+       const int32_t *__restrict__ bag_offs, int32_t *__restrict__ ids) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= q.batch * q.S) return;
+  const int64_t b = i / q.S;
+  const wd_feat_slot_t &s = slots[i - b * q.S];
+  int32_t *out = EMIT ? ids + bag_offs[i] : nullptr;
+  int32_t n = 0;
+  switch (s.kind) {
+    case WD_FEAT_HASH: {
+      const int32_t *eo = q.ex_offs + (int64_t)s.src * (q.batch + 1);
+      n = eo[b + 1] - eo[b];
+      if (EMIT) {
+        const uint64_t *f = q.fp + q.tok_base[s.src] + eo[b];
+        for (int32_t j = 0; j < n; ++j) out[j] = (int32_t)(f[j] % (uint64_t)s.num_buckets);
+      }
+      break;
+    }
+    case WD_FEAT_VOCAB: {
+      const int32_t *eo = q.ex_offs + (int64_t)s.src * (q.batch + 1);
+      const int32_t *tv = q.tok_val + q.tok_base[s.src] + eo[b];
+      const int32_t m = eo[b + 1] - eo[b];
+      for (int32_t j = 0; j < m; ++j) {
+        const int32_t v = tv[j];
+        if (v >= 0) {                  // out-of-vocabulary tokens are dropped (default_value = -1)
+          if (EMIT) out[n] = v;
+          ++n;
+        }
+      }
+      break;
+    }
+    case WD_FEAT_IDENTITY: {
+      const int64_t v = q.ints[(int64_t)s.src * q.batch + b];
+      if (v != -1) {                   // -1 is the ignore_value of the dense -> sparse conversion
+        if (EMIT) out[0] = (int32_t)((v >= 0 && v < s.num_buckets) ? v : 0);
+        n = 1;
+      }
+      break;
+    }
+    case WD_FEAT_BUCKET: {
+      n = 1;
+      if (EMIT) out[0] = feat_bucketize(q.bounds + s.bound_off, s.nbound,
+                                        feat_normalize(q.floats[(int64_t)s.src * q.batch + b], s.norm_kind, s.p0, s.p1));
+      break;
+    }
+    default: {                         // WD_FEAT_CROSS: cartesian product, LAST key fastest, FingerprintCat64 in key order
+      int32_t cnt[WD_MAX_CROSS_KEYS];
+      int64_t total = 1;
+      for (int k = 0; k < s.nkeys; ++k) {
+        cnt[k] = feat_key_count(s.keys[k], q, b);
+        total *= cnt[k];
+      }
+      n = (int32_t)total;
+      if (EMIT) {
+        const uint64_t m = s.num_buckets > 0 ? (uint64_t)s.num_buckets : (uint64_t)INT64_MAX;
+        for (int64_t j = 0; j < total; ++j) {
+          int32_t idx[WD_MAX_CROSS_KEYS];
+          int64_t r = j;
+          for (int k = s.nkeys - 1; k >= 0; --k) {
+            idx[k] = (int32_t)(r % cnt[k]);
+            r /= cnt[k];
+          }
+          uint64_t h = s.hash_key;
+          for (int k = 0; k < s.nkeys; ++k) h = fingerprint_cat64(h, feat_key_value(s.keys[k], q, b, idx[k]));
+          out[j] = (int32_t)(h % m);
+        }
+      }
+    }
+  }
+  if (!EMIT) lens[i] = n;
+}
+
+// index in vocabulary_list of every token in [t0, t0 + n) (byte-wise equality; -1: not in the list)
+__global__ void __launch_bounds__(256)
+k_feat_vocab(const uint8_t *__restrict__ bytes, const int32_t *__restrict__ tok_offs, int64_t t0, int64_t n,
+             const uint8_t *__restrict__ vbytes, const int32_t *__restrict__ voffs, int32_t nv,
+             int32_t *__restrict__ out) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= n) return;
+  const int32_t o0 = tok_offs[t0 + t], len = tok_offs[t0 + t + 1] - o0;
+  int32_t hit = -1;
+  for (int32_t v = 0; v < nv && hit < 0; ++v) {
+    const int32_t w0 = voffs[v];
+    if (voffs[v + 1] - w0 != len) continue;
+    bool eq = true;
+    for (int32_t c = 0; c < len; ++c) eq = eq && bytes[o0 + c] == vbytes[w0 + c];
+    if (eq) hit = v;
+  }
+  out[t0 + t] = hit;
+}
+
+__global__ void k_feat_first_zero(int32_t *offs) { offs[0] = 0; }
+
 }  // namespace
+
+static bool feat_batch_ok(const wd_feat_batch_t *q) {
+  return q && q->batch >= 0 && q->S > 0 && q->S <= (1 << 16);
+}
+
+extern "C" int wd_feat_vocab_lookup(const uint8_t *bytes, const int32_t *tok_offs, int64_t tok_begin, int64_t n,
+                                    const uint8_t *vocab_bytes, const int32_t *vocab_offs, int32_t nvocab, int32_t *tok_val,
+                                    wd_stream_t stream) {
+  if (n <= 0) return WD_OK;
+  WD_REQUIRE(bytes && tok_offs && vocab_bytes && vocab_offs && tok_val && nvocab > 0, "null pointer");
+  hipLaunchKernelGGL(k_feat_vocab, dim3((unsigned)wd::ceil_div(n, 256)), dim3(256), 0, wd::as_stream(stream), bytes, tok_offs,
+                     tok_begin, n, vocab_bytes, vocab_offs, nvocab, tok_val);
+  return wd::check_launch("wd_feat_vocab_lookup");
+}
+
+extern "C" int wd_feat_lens(const wd_feat_slot_t *slots_dev, const wd_feat_batch_t *batch, int32_t *lens, wd_stream_t stream) {
+  WD_REQUIRE(slots_dev && feat_batch_ok(batch) && lens, "null pointer / bad batch descriptor");
+  if (batch->batch == 0) return WD_OK;
+  hipLaunchKernelGGL((k_feat<false>), dim3((unsigned)wd::ceil_div(batch->batch * batch->S, 256)), dim3(256), 0,
+                     wd::as_stream(stream), slots_dev, *batch, lens, (const int32_t *)nullptr, (int32_t *)nullptr);
+  return wd::check_launch("wd_feat_lens");
+}
+
+extern "C" int wd_feat_emit(const wd_feat_slot_t *slots_dev, const wd_feat_batch_t *batch, const int32_t *bag_offs,
+                            int32_t *ids, wd_stream_t stream) {
+  WD_REQUIRE(slots_dev && feat_batch_ok(batch) && bag_offs && ids, "null pointer / bad batch descriptor");
+  if (batch->batch == 0) return WD_OK;
+  hipLaunchKernelGGL((k_feat<true>), dim3((unsigned)wd::ceil_div(batch->batch * batch->S, 256)), dim3(256), 0,
+                     wd::as_stream(stream), slots_dev, *batch, (int32_t *)nullptr, bag_offs, ids);
+  return wd::check_launch("wd_feat_emit");
+}
+
+// bag CSR from the lengths: offs[0] = 0, offs[i + 1] = lens[0] + ... + lens[i]   (offs[n] = number of ids of the batch)
+extern "C" int64_t wd_feat_offsets_workspace_bytes(int64_t n) {
+  size_t bytes = 0;
+  if (rocprim::inclusive_scan(nullptr, bytes, (const int32_t *)nullptr, (int32_t *)nullptr, (size_t)(n > 0 ? n : 1),
+                              rocprim::plus<int32_t>()) != hipSuccess)
+    return -1;
+  return (int64_t)(bytes ? bytes : 16);
+}
+
+extern "C" int wd_feat_offsets(const int32_t *lens, int64_t n, int32_t *offs, void *workspace, int64_t workspace_bytes,
+                               wd_stream_t stream) {
+  WD_REQUIRE(offs, "null pointer");
+  hipStream_t st = wd::as_stream(stream);
+  hipLaunchKernelGGL(k_feat_first_zero, dim3(1), dim3(1), 0, st, offs);
+  if (n > 0) {
+    WD_REQUIRE(lens && workspace, "null pointer");
+    size_t bytes = (size_t)workspace_bytes;
+    if (rocprim::inclusive_scan(workspace, bytes, lens, offs + 1, (size_t)n, rocprim::plus<int32_t>(), st) != hipSuccess) {
+      wd::set_error("wd_feat_offsets: rocprim::inclusive_scan failed");
+      return WD_ERR_LAUNCH;
+    }
+  }
+  return wd::check_launch("wd_feat_offsets");
+}
 
 extern "C" int wd_fingerprint64(const uint8_t *bytes, const int32_t *tok_offs, int64_t ntok, uint64_t *out_fp,
                                 wd_stream_t stream) {

@@ -14,8 +14,15 @@ Runs the feature-column transforms the reference declares in `_build_model_colum
 padded_batch tensors of their string keys including the '' padding (every example contributes Lmax values per string
 key, Lmax = longest list of that feature IN THE BATCH); 'ragged' crosses only real tokens.
 
-The small per-batch index arithmetic (bag lengths, vocabulary lookups, bucketize of the <= 3 continuous columns) is
-host-side numpy, like the reference's graph-build-time Python; the hashing and all id emission run on the GPU.
+Two implementations of the same transforms:
+
+  mode="device" (default): the host uploads the parsed batch as it is (token bytes + offsets, integer / float features as
+      [feature][example] matrices: ONE staged copy) and the whole bag CSR is built on the GPU from a device-side slot table:
+      wd_fingerprint64 -> wd_feat_vocab_lookup -> wd_feat_lens -> wd_feat_offsets (scan) -> wd_feat_emit, on the featurizer's
+      own stream (it overlaps with the train step of the previous batch; the only host wait is for the id count).
+  mode="host": per-slot numpy for the index arithmetic (bag lengths, vocabulary lookups, bucketize) and one emit launch per
+      column -- round 1's path, kept as the cross-check of the device path (tests/test_gpu_c1.py) and for the CPU test of
+      the host logic (tests/test_featurizer_host_cpu.py).
 """
 import ctypes
 
@@ -90,9 +97,14 @@ class _Stage(object):
 
 
 class Featurizer(object):
-    def __init__(self, engine, cross_padding="tf_dense"):
+    def __init__(self, engine, cross_padding="tf_dense", mode=None):
         if cross_padding not in ("tf_dense", "ragged"):
             raise ValueError("cross_padding must be 'tf_dense' or 'ragged'")
+        import os
+        mode = mode or os.environ.get("WD_FEATURIZER", "device")
+        if mode not in ("device", "host"):
+            raise ValueError("featurizer mode must be 'device' or 'host'")
+        self.mode = mode
         # sharded engines hash in the GLOBAL id space (engine.hash_plan); only the engine splits an id into (owner, local row)
         self.engine, self.plan, self.cross_padding = engine, getattr(engine, "hash_plan", engine.plan), cross_padding
         self.dev = engine.device
@@ -116,6 +128,153 @@ class Featurizer(object):
                 vo = np.zeros(len(bs) + 1, dtype=np.int32)
                 np.cumsum([len(b) for b in bs], out=vo[1:])
                 self.vocab_packed[i] = (np.frombuffer(b"".join(bs) + b"\0", dtype=np.uint8).copy(), vo, len(bs))
+        if mode == "device":
+            self._build_device_tables()
+
+    # ---- device mode: slot table, boundary table, vocabularies -- built once ------------------------------------------------
+    def _build_device_tables(self):
+        slots = self.plan.slots
+        self.str_feats, self.int_feats, self.float_rows, bounds = [], [], [], []
+
+        def sidx(f):
+            if f not in self.str_feats:
+                self.str_feats.append(f)
+            return self.str_feats.index(f)
+
+        def iidx(f):
+            if f not in self.int_feats:
+                self.int_feats.append(f)
+            return self.int_feats.index(f)
+
+        def fidx(f, log):
+            if (f, log) not in self.float_rows:
+                self.float_rows.append((f, log))       # log: the host applies np.log (bit-exact with the oracle's numpy)
+            return self.float_rows.index((f, log))
+
+        def bnd(b):
+            off = len(bounds)
+            bounds.extend(float(x) for x in b)
+            return len(b), off
+        arr = (capi.WdFeatSlot * max(len(slots), 1))()
+        vocab_feats = {}
+        for i, s in enumerate(slots):
+            d = arr[i]
+            d.kind, d.num_buckets = capi.WD_FEAT_KINDS[s.kind], int(s.num_buckets)
+            if s.kind in ("hash", "vocab"):
+                d.src = sidx(s.feature)
+                if s.kind == "vocab":
+                    if vocab_feats.setdefault(s.feature, i) != i:
+                        raise ValueError("feature `%s` feeds two vocabulary columns" % s.feature)
+            elif s.kind == "identity":
+                d.src = iidx(s.feature)
+            elif s.kind == "bucket":
+                kind, p0, p1 = s.normalizer if s.normalizer else (None, 0.0, 1.0)
+                d.src = fidx(s.feature, kind == "log")
+                d.norm_kind = {None: 0, "min_max": 1, "standard": 2, "log": 0}[kind]
+                d.p0, d.p1 = float(p0), float(p1)
+                d.nbound, d.bound_off = bnd(s.boundaries)
+            else:
+                if len(s.cross_keys) > capi.WD_MAX_CROSS_KEYS:
+                    raise ValueError("crossed column `%s` has more than %d keys" % (s.name, capi.WD_MAX_CROSS_KEYS))
+                d.nkeys, d.hash_key = len(s.cross_keys), int(s.hash_key)
+                for k, ck in enumerate(s.cross_keys):
+                    kk = d.keys[k]
+                    kk.kind = capi.WD_FEAT_KEY_KINDS[ck.kind]
+                    if ck.kind == "string":
+                        kk.src = sidx(ck.feature)
+                    elif ck.kind == "identity":
+                        kk.src, kk.num_buckets = iidx(ck.feature), int(ck.num_buckets)
+                    else:       # bucketized RAW value (quirk C.5)
+                        kk.src = fidx(ck.feature, False)
+                        kk.nbound, kk.bound_off = bnd(ck.boundaries)
+        dev = self.dev
+        self.feat_slots_dev = torch.from_numpy(np.frombuffer(bytes(arr), dtype=np.uint8).copy()).to(dev)
+        self.bounds_dev = torch.tensor(bounds if bounds else [0.0], dtype=torch.float32, device=dev)
+        self.vocab_dev = {}
+        for i, (vb, vo, nv) in self.vocab_packed.items():
+            self.vocab_dev[i] = (torch.from_numpy(vb).to(dev), torch.from_numpy(vo).to(dev), nv)
+        self._fs = torch.cuda.Stream(device=dev)
+        self._scan_ws = None
+
+    def _to_device_dev(self, raw):
+        plan, eng = self.plan, self.engine
+        B, S = raw.B, plan.S
+        if B > eng.max_batch:
+            raise ValueError("batch (B=%d) exceeds engine capacity (max_batch=%d)" % (B, eng.max_batch))
+        T = len(raw.tok_offs) - 2
+        F = len(self.str_feats)
+        # ---- 1. the parsed batch, as it is, in one staged buffer ------------------------------------------------------------
+        stg = _Stage()
+        h_bytes, h_toffs = stg.add(raw.tok_bytes, np.uint8), stg.add(raw.tok_offs, np.int32)
+        ex = np.zeros((max(F, 1), B + 1), dtype=np.int32)
+        base = np.zeros(max(F, 1), dtype=np.int32)
+        lmax = np.zeros(max(F, 1), dtype=np.int32)
+        for j, f in enumerate(self.str_feats):
+            pc = raw.cat[f]
+            ex[j], base[j] = pc.ex_offs, pc.base
+            lmax[j] = int(np.diff(pc.ex_offs).max()) if B else 0
+        h_ex, h_base, h_lmax = stg.add(ex, np.int32), stg.add(base, np.int32), stg.add(lmax, np.int32)
+        ints = (np.stack([np.asarray(raw.ints[f], dtype=np.int64) for f in self.int_feats]) if self.int_feats
+                else np.zeros((1, max(B, 1)), np.int64))
+        rows = []
+        for f, log in self.float_rows:
+            x = np.asarray(raw.floats[f], dtype=np.float32)
+            rows.append(np.log(x) if log else x)
+        floats = np.stack(rows) if rows else np.zeros((1, max(B, 1)), np.float32)
+        h_ints, h_floats = stg.add(ints, np.int64), stg.add(floats, np.float32)
+        nd = len(plan.dense_cols)
+        h_dense = stg.add(np.stack([raw.floats[d.feature] for d in plan.dense_cols], axis=1), np.float32) if nd else None
+        h_lab = stg.add(raw.labels, np.float32) if raw.labels is not None else None
+        use_w = raw.weights is not None and self.engine.spec.use_weight_column
+        h_wts = stg.add(raw.weights, np.float32) if use_w else None
+        cur = torch.cuda.current_stream()
+        fs = self._fs
+        fs.wait_stream(cur)
+        with torch.cuda.stream(fs):
+            st = fs.cuda_stream
+            stg.upload(self.dev)
+            i32 = dict(dtype=torch.int32, device=self.dev)
+            # ---- 2. fingerprints of every token (+ the trailing ''), vocabulary indices ------------------------------------
+            fp = torch.empty(T + 1, dtype=torch.int64, device=self.dev)
+            call("wd_fingerprint64", stg.ptr(h_bytes), stg.ptr(h_toffs), T + 1, ptr(fp), st)
+            tok_val = None
+            if self.vocab_dev:
+                tok_val = torch.empty(max(T, 1), **i32)
+                for i, (vb, vo, nv) in self.vocab_dev.items():
+                    pc = raw.cat[plan.slots[i].feature]
+                    call("wd_feat_vocab_lookup", stg.ptr(h_bytes), stg.ptr(h_toffs), pc.base, pc.n, ptr(vb), ptr(vo), nv,
+                         ptr(tok_val), st)
+            # ---- 3. lengths -> bag CSR -> ids ---------------------------------------------------------------------------------
+            q = capi.WdFeatBatch()
+            q.fp, q.tok_val = fp.data_ptr(), (tok_val.data_ptr() if tok_val is not None else None)
+            q.ex_offs, q.tok_base = stg.ptr(h_ex).value, stg.ptr(h_base).value
+            q.lmax = stg.ptr(h_lmax).value if self.cross_padding == "tf_dense" else None
+            q.ints, q.floats, q.bounds = stg.ptr(h_ints).value, stg.ptr(h_floats).value, self.bounds_dev.data_ptr()
+            q.batch, q.S, q.empty_index = B, S, T
+            n = B * S
+            lens = torch.empty(max(n, 1), **i32)
+            bag = torch.empty(n + 1, **i32)
+            call("wd_feat_lens", ptr(self.feat_slots_dev), ctypes.byref(q), ptr(lens), st)
+            need = int(call("wd_feat_offsets_workspace_bytes", max(n, 1)))
+            if self._scan_ws is None or self._scan_ws.numel() < need:
+                self._scan_ws = torch.empty(need, dtype=torch.uint8, device=self.dev)
+            call("wd_feat_offsets", ptr(lens), n, ptr(bag), ptr(self._scan_ws), self._scan_ws.numel(), st)
+            stats = torch.stack([bag[-1].to(torch.int64), (lens[:n] == 1).all().to(torch.int64)]).cpu()   # the one host wait
+            nnz, one_hot = int(stats[0]), bool(stats[1]) if n else True
+            if nnz > eng.max_nnz:
+                raise ValueError("batch (B=%d, nnz=%d) exceeds engine capacity (max_batch=%d, max_nnz=%d)"
+                                 % (B, nnz, eng.max_batch, eng.max_nnz))
+            ids = torch.zeros(max(nnz, 1), **i32)
+            call("wd_feat_emit", ptr(self.feat_slots_dev), ctypes.byref(q), ptr(bag), ptr(ids), st)
+            dense = stg.tensor(h_dense).view(B, nd) if nd else None
+            labels = stg.tensor(h_lab) if h_lab is not None else None
+            weights = stg.tensor(h_wts) if h_wts is not None else None
+        cur.wait_stream(fs)
+        for t in (ids, bag, stg.dbuf):            # allocated on the featurizer's stream, consumed on the caller's
+            t.record_stream(cur)
+        bt = DeviceBatch(B, ids, bag, dense, labels, weights, nnz=nnz, one_hot=one_hot)
+        bt._keep = [fp, tok_val, lens, stg.dbuf]
+        return bt
 
     def _vocab_lookup(self, slot, pc):
         """index in vocabulary_list per token of the feature (-1 = out of vocabulary)"""
@@ -135,6 +294,8 @@ class Featurizer(object):
         return torch.from_numpy(np.ascontiguousarray(a)).to(self.dev, dtype=dtype, non_blocking=True)
 
     def to_device(self, raw):
+        if self.mode == "device":
+            return self._to_device_dev(raw)
         plan, eng = self.plan, self.engine
         B, S = raw.B, plan.S
         st = torch.cuda.current_stream().cuda_stream

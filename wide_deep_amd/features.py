@@ -101,7 +101,8 @@ class Featurizer(object):
         if cross_padding not in ("tf_dense", "ragged"):
             raise ValueError("cross_padding must be 'tf_dense' or 'ragged'")
         import os
-        mode = mode or os.environ.get("WD_FEATURIZER", "device")
+        # (an engine that is not on a GPU only exists as a stub in the CPU tests of the host logic, which replace the entry points)
+        mode = mode or os.environ.get("WD_FEATURIZER", "device" if torch.device(engine.device).type == "cuda" else "host")
         if mode not in ("device", "host"):
             raise ValueError("featurizer mode must be 'device' or 'host'")
         self.mode = mode

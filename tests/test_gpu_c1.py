@@ -67,6 +67,67 @@ def test_every_column_id_bit_exact_on_real_rows(tmp_path, padding, mode):
     assert k == len(lines)
 
 
+@pytest.mark.parametrize("padding", ["tf_dense", "ragged"])
+def test_device_featurizer_on_mutated_rows(tmp_path, padding):
+    """Real rows with randomly damaged fields -- empty / '-' / multi-valued / out-of-vocabulary tokens, ids at and beyond both
+    ends of the identity ranges, -1, missing and extreme floats -- in batches of 1, 7 and 64 (a batch where a multi-valued
+    feature has NO token at all included): the device featurizer == the host featurizer == oracle/columns.py, id for id."""
+    import random
+    from oracle import columns as OC
+    from tests.helpers import slot_csr
+    from wide_deep_amd import build_estimator as BE, dataset as DS
+    from wide_deep_amd.engine import WideDeepEngine
+    from wide_deep_amd.features import Featurizer
+    from wide_deep_amd.read_conf import Config, conf_dir
+    conf = Config()
+    schema, fconf = conf.read_schema(), conf.read_feature_conf()
+    pos = {v: k - 1 for k, v in schema.items()}
+    rng = random.Random(20260926)
+    base = open(FIXTURE, "rb").read().splitlines()
+    words = [b"a", b"w", b"0", b"1", b"2", b"5", b"zz", b"iphone", b"-", b"", b"homepage", b"T1348648756099", b"x" * 40]
+
+    def damage(line):
+        parts = line.split(b"\t")
+        for f, c in fconf.items():
+            if f not in pos or rng.random() > 0.35:
+                continue
+            if c["type"] == "category" and c["transform"] == "identity":
+                n = int(c["parameter"])
+                parts[pos[f]] = str(rng.choice([-1, 0, 1, n - 1, n, n + 5, -7])).encode() if rng.random() < 0.9 else b"-"
+            elif c["type"] == "category":
+                k = rng.choice([0, 1, 1, 2, 3, 6])
+                parts[pos[f]] = b",".join(rng.choice(words) for _ in range(k))
+            else:
+                parts[pos[f]] = rng.choice([b"-", b"", b"0", b"1e-3", b"123456.5", b"0.5", b"7"])
+        return b"\t".join(parts)
+
+    spec = BE.build_model_spec(conf, "wide")
+    eng = WideDeepEngine(spec, max_batch=64, max_nnz=64 * 70 * 64)
+    dev, host = Featurizer(eng, cross_padding=padding, mode="device"), Featurizer(eng, cross_padding=padding, mode="host")
+    oc = OC.Columns(conf_dir())
+    for B in (1, 7, 64, 64):
+        lines = [damage(rng.choice(base)) for _ in range(B)]
+        if B == 7:       # a multi-valued feature without a single token in the whole batch (Lmax = 0: its crosses are empty)
+            for i, ln in enumerate(lines):
+                parts = ln.split(b"\t")
+                parts[pos["ad_cates"]] = b""
+                lines[i] = b"\t".join(parts)
+        path = tmp_path / ("m%d.tsv" % B)
+        path.write_bytes(b"\n".join(lines) + b"\n")
+        raw = next(iter(DS.input_fn(str(path), None, "eval", B, prefetch=0)))
+        assert raw.B == B
+        a, b = dev.to_device(raw), host.to_device(raw)
+        torch.cuda.synchronize()
+        assert a.nnz == b.nnz and a.one_hot == b.one_hot and torch.equal(a.bag_offs, b.bag_offs)
+        assert torch.equal(a.ids[:a.nnz], b.ids[:b.nnz])
+        got = slot_csr(eng.plan, a.ids.cpu().numpy(), a.bag_offs.cpu().numpy(), B)
+        exp = oc.transform(oc.parse(lines), cross_padding=padding)["ids"]
+        assert set(got) == set(exp)
+        for name in exp:
+            assert np.array_equal(got[name][1], exp[name][1]), name
+            assert np.array_equal(got[name][0], np.asarray(exp[name][0], dtype=np.int64)), name
+
+
 def test_default_conf_train_steps_match_oracle(tmp_path):
     """Full default model (70 wide columns, 12.7M rows, 47 embedding columns, tower [1024,512,256]) for 3 steps."""
     from oracle import columns as OC

@@ -438,11 +438,15 @@ def main():
         side = pipeline.warm(eng, dev_batches, args.ids_input)
         # One hipGraph holds `spg` consecutive steps (each the full step on its own resident batch): the 10-30 us between two
         # graph launches is paid once per `spg` steps.  spg = the largest divisor of --steps up to --steps-per-graph (default
-        # 32: the driver's 20 timed steps are ONE replay); other step counts finish on one-step graphs.  A window of spg
+        # 32, but at least two graphs for the timed region: the driver's 20 timed steps are two replays of 10); other step counts finish on one-step graphs.  A window of spg
         # consecutive batches of the resident pool (wrapping around) per multi-step graph.
         nb = len(dev_batches)
         cap = max(1, min(args.steps_per_graph, nb))
         spg = max(d for d in range(1, cap + 1) if args.steps % d == 0)
+        if spg == args.steps and args.steps >= 16:
+            # the timed steps would be ONE graph launch: its launch latency (a few hundred nodes on four streams) is then fully
+            # exposed.  Two graphs: the second is launched while the first runs (measured at --steps 20: 0.184 against 0.187 ms)
+            spg = max(d for d in range(1, args.steps // 2 + 1) if args.steps % d == 0 and d <= cap)
         starts, j = [], 0
         while spg > 1 and j not in starts and len(starts) < 8:
             starts.append(j)

@@ -3,7 +3,7 @@
 set -u
 out=gpurun_out/${1:-ab}; shift
 mkdir -p $out
-B="--steps 40 --warmup 10 --no-pmc --no-cpu-baseline --no-parity"
+B="${BARGS:---steps 40 --warmup 10} --no-pmc --no-cpu-baseline --no-parity"
 for i in 1 2; do
 python bench.py $B > $out/new$i.json 2> $out/new.err
 env "$@" python bench.py $B > $out/old$i.json 2> $out/old.err

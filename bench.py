@@ -455,8 +455,9 @@ def main():
                   for j0 in starts]
         singles = [pipeline.StepGraph(eng, [tb], args.ids_input, stream=side) for tb in dev_batches]
         steps_per_run = spg
-        # the pool is cycled from where the previous call stopped: a short run (the driver's 20 steps after 5 warm-up
-        # steps) does not land on batches the warm-up has just pulled into the Infinity Cache
+        # multi-step graphs walk the pool forwards from batch 0, one-step graphs (warm-up steps that do not fill a graph, the
+        # remainder of an odd step count) backwards from its end: a short run (the driver's 20 steps after 5 warm-up steps)
+        # does not time batches whose rows the warm-up has just pulled into the Infinity Cache
         cursor = {"m": 0, "s": 0}
 
         def run_steps(n):
@@ -464,7 +465,7 @@ def main():
                 multis[cursor["m"] % len(multis)].replay()
                 cursor["m"] += 1
             for _ in range(n % spg if spg > 1 else n):
-                singles[(cursor["m"] * spg + cursor["s"]) % len(singles)].replay()
+                singles[(len(singles) - 1 - cursor["s"]) % len(singles)].replay()
                 cursor["s"] += 1
 
         # clocks, caches and the graph executor's first-replay work are out of the way before the official warm-up: every

@@ -113,6 +113,31 @@ def test_train_steps_checkpoints_resume_and_rotation(tmp_path, make_model):
     assert m3.engine.global_step == 3 and m3.latest_checkpoint() is None
 
 
+def test_resume_from_a_tensorflow_checkpoint_in_model_dir(tmp_path, make_model):
+    """python/train.py:188-191 (`keep_train`): the reference resumes from what tf.estimator left in model_dir.  A model_dir that
+    holds TensorFlow's checkpoint container and none of ours is restored through wide_deep_amd/tf_checkpoint.py; our own
+    checkpoints, once written, take over; export_tf_checkpoint writes the container back."""
+    from wide_deep_amd import dataset as DS, tf_checkpoint as T
+    path, _, n = _files(tmp_path)
+    model_dir = str(tmp_path / "tfmodel")
+    os.makedirs(model_dir)
+    m0 = make_model(None)
+    w = torch.arange(int(m0.engine.plan.total_rows), dtype=torch.float32) * 1e-6
+    T.write_tf_checkpoint(os.path.join(model_dir, "model.ckpt-300"), {"w": w.numpy(), "global_step": np.asarray(300, np.int64)})
+    T.write_tf_checkpoint(os.path.join(model_dir, "model.ckpt-90"), {"w": (w * 0).numpy(), "global_step": np.asarray(90, np.int64)})
+    open(os.path.join(model_dir, "checkpoint"), "w").write('model_checkpoint_path: "model.ckpt-300"\n')
+    m = make_model(model_dir)
+    assert m.latest_checkpoint() == os.path.join(model_dir, "model.ckpt-300.index")
+    m.train(input_fn=lambda: DS.input_fn(path, None, "train", 128), steps=1)
+    assert m.engine.global_step == 303                                   # restored 300, one wide_deep step = +3
+    assert os.path.exists(os.path.join(model_dir, "model.ckpt-303.pt")) and m.latest_checkpoint().endswith("model.ckpt-303.pt")
+    touched = (m.engine.w != w).sum()
+    assert 0 < int(touched) < w.numel() // 2 and torch.equal(m.engine.w[m.engine.w == w], w[m.engine.w == w])
+    prefix = m.export_tf_checkpoint()
+    back = T.read_tf_checkpoint(prefix)
+    assert int(back["global_step"]) == 303 and np.array_equal(back["w"], m.engine.w.numpy())
+
+
 def test_evaluate_and_predict_contract(tmp_path, make_model):
     from wide_deep_amd import dataset as DS
     path, pred_path, n = _files(tmp_path)

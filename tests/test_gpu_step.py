@@ -207,6 +207,30 @@ def test_row_record_layout_trains_like_separate_tables(hidden, mean_len, dim):
         assert torch.equal(sc[k], sb[k]), k
 
 
+def test_tf_checkpoint_container_round_trip_through_the_engine(tmp_path):
+    """engine state -> TensorFlow's checkpoint container (tf_checkpoint.py) -> a fresh engine: identical training afterwards"""
+    from wide_deep_amd import synth, tf_checkpoint as T
+    from wide_deep_amd.engine import WideDeepEngine
+    spec = _spec(hidden=(32, 16))
+    a = WideDeepEngine(spec, max_batch=128, seed=5)
+    hb = synth.make_raw_batch(a.plan, 96, seed=1, pos_rate=0.3)
+    a.train_step(synth.to_device_ids(a.plan, hb))
+    torch.cuda.synchronize()
+    st = a.export_state()
+    prefix = T.write_tf_checkpoint(str(tmp_path / "model.ckpt-%d" % a.global_step), {k: v.cpu().numpy() for k, v in st.items()})
+    back = {k: torch.from_numpy(v) for k, v in T.read_tf_checkpoint(prefix).items()}
+    assert sorted(back) == sorted(st) and all(torch.equal(back[k], st[k].cpu()) for k in st)
+    b = WideDeepEngine(spec, max_batch=128, seed=9)
+    b.import_state(back)
+    assert b.global_step == a.global_step
+    hb2 = synth.make_raw_batch(a.plan, 96, seed=2, pos_rate=0.3)
+    a.train_step(synth.to_device_ids(a.plan, hb2)); b.train_step(synth.to_device_ids(b.plan, hb2))
+    torch.cuda.synchronize()
+    sa, sb = a.export_state(), b.export_state()
+    for k in sa:
+        assert torch.equal(sa[k], sb[k]), k
+
+
 def test_mixed_embedding_dims_and_odd_sizes():
     s = _spec(n_sparse=6, hidden=(20, 10), n_dense=1)
     for i, d in enumerate([4, 8, 16, 32, 64, 8]):

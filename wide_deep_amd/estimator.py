@@ -114,6 +114,13 @@ class WideAndDeepClassifier(object):
             m = re.search(r"model\.ckpt-(\d+)\.pt$", p)
             if m and int(m.group(1)) > best_step:
                 best, best_step = p, int(m.group(1))
+        if best is None:
+            # nothing of ours: a checkpoint the reference's tf.estimator left in model_dir (python/train.py:188-191: `keep_train`
+            # resumes from it) -- TensorFlow's tensor-bundle container, read by wide_deep_amd/tf_checkpoint.py
+            from .tf_checkpoint import latest_tf_checkpoint
+            prefix = latest_tf_checkpoint(self.model_dir)
+            if prefix:
+                return prefix + ".index"
         return best
 
     @staticmethod
@@ -129,7 +136,11 @@ class WideAndDeepClassifier(object):
     def _restore(self, checkpoint_path=None):
         path = checkpoint_path or self.latest_checkpoint()
         if path and path != self._restored_from:
-            state = torch.load(path, map_location="cpu")
+            if path.endswith(".index"):
+                from .tf_checkpoint import read_tf_checkpoint
+                state = {k: torch.from_numpy(v) for k, v in read_tf_checkpoint(path[:-len(".index")]).items()}
+            else:
+                state = torch.load(path, map_location="cpu")
             if self._world() > 1:
                 self._engine.import_full_state(state)      # checkpoints hold FULL tables; a rank keeps its rows
                 self._engine.global_step = int(state.get("global_step", 0))
@@ -162,6 +173,16 @@ class WideAndDeepClassifier(object):
         for old in ckpts[:-keep]:
             os.remove(old)
         return path
+
+    def export_tf_checkpoint(self, prefix=None):
+        """The current state in TensorFlow's checkpoint container (`<prefix>.index` + `.data-00000-of-00001`, variable names of
+        the reference), e.g. to hand weights trained here to the reference's eval / serving code."""
+        from .tf_checkpoint import write_tf_checkpoint
+        prefix = prefix or os.path.join(self.model_dir, "model.ckpt-%d" % self._engine.global_step)
+        state = self._engine.export_full_state() if self._world() > 1 else self._engine.export_state()
+        if self._rank() == 0:
+            write_tf_checkpoint(prefix, {k: v.cpu().numpy() for k, v in state.items()})
+        return prefix
 
     # ---- train / evaluate / predict -----------------------------------------------------------------
     def train(self, input_fn, hooks=None, steps=None, max_steps=None, saving_listeners=None):

@@ -217,7 +217,7 @@ def test_tf_checkpoint_container_round_trip_through_the_engine(tmp_path):
     a.train_step(synth.to_device_ids(a.plan, hb))
     torch.cuda.synchronize()
     st = a.export_state()
-    prefix = T.write_tf_checkpoint(str(tmp_path / "model.ckpt-%d" % a.global_step), {k: v.cpu().numpy() for k, v in st.items()})
+    prefix = T.write_tf_checkpoint(str(tmp_path / ("model.ckpt-%d" % a.global_step)), {k: v.cpu().numpy() for k, v in st.items()})
     back = {k: torch.from_numpy(v) for k, v in T.read_tf_checkpoint(prefix).items()}
     assert sorted(back) == sorted(st) and all(torch.equal(back[k], st[k].cpu()) for k in st)
     b = WideDeepEngine(spec, max_batch=128, seed=9)

@@ -550,7 +550,27 @@ k_bucket_update(UpdArgs u, const int32_t *__restrict__ start, uint64_t *__restri
       const int64_t eoff = GEN ? off : emb_at(off, key);
       for (int c = gl; c < (D >> 2); c += 4) {
         float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int j = i; j < e; ++j) {
+        // four occurrences per round: their (bag length, gradient row) loads are independent and issued together, the adds
+        // keep the order of the plain loop (bit-identical sums).  Rows hit 8-32 times (skewed ids, multi-hot bags) used to be a
+        // chain of that many exposed round trips: Zipf(1.05) 89 -> ~70 us for the update of a C2 batch.
+        int j = i;
+        for (; !GEN && j + 4 <= e; j += 4) {      // (the generic-optimizer instantiation keeps the plain loop: registers)
+          int32_t bag[4], len[4];
+          float4 d[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) bag[q] = (int32_t)(uint32_t)sp[j + q];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            len[q] = u.bag_offs[bag[q] + 1] - u.bag_offs[bag[q]];
+            d[q] = *reinterpret_cast<const float4 *>(u.dx + (int64_t)(bag[q] / S) * u.ldx + sl.out_col + 4 * c);
+          }
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float scale = len[q] > 1 ? 1.0f / (float)len[q] : 1.0f;
+            g.x += d[q].x * scale; g.y += d[q].y * scale; g.z += d[q].z * scale; g.w += d[q].w * scale;
+          }
+        }
+        for (; j < e; ++j) {
           const int32_t bag = (int32_t)(uint32_t)sp[j];
           const int32_t len = u.bag_offs[bag + 1] - u.bag_offs[bag];
           const float scale = len > 1 ? 1.0f / (float)len : 1.0f;
@@ -590,7 +610,15 @@ k_bucket_update(UpdArgs u, const int32_t *__restrict__ start, uint64_t *__restri
     }
     if (do_wide && gl == 0) {
       float g = 0.f;
-      for (int j = i; j < e; ++j) g += u.dlogit[(int64_t)((int32_t)(uint32_t)sp[j] / S) * u.ld_dlogit];
+      int j = i;
+      for (; j + 4 <= e; j += 4) {      // (loads of four occurrences together, adds in order)
+        float v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = u.dlogit[(int64_t)((int32_t)(uint32_t)sp[j + q] / S) * u.ld_dlogit];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) g += v[q];
+      }
+      for (; j < e; ++j) g += u.dlogit[(int64_t)((int32_t)(uint32_t)sp[j] / S) * u.ld_dlogit];
       float4 r = *reinterpret_cast<float4 *>(u.wide + (int64_t)key * ws);  // {w, z, n, -}
       if (GEN) wide_apply(r, g);
       else ftrl_update(r.x, r.y, r.z, g, u.lr_w, u.l1, u.l2);

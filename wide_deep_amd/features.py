@@ -229,9 +229,8 @@ class Featurizer(object):
         use_w = raw.weights is not None and self.engine.spec.use_weight_column
         h_wts = stg.add(raw.weights, np.float32) if use_w else None
         cur = torch.cuda.current_stream()
-        fs = self._fs
-        fs.wait_stream(cur)
-        with torch.cuda.stream(fs):
+        fs = self._fs       # NOT ordered behind `cur`: nothing here reads what the training stream writes, so the kernels below
+        with torch.cuda.stream(fs):     # (and the host's wait for the id count) do not wait for the previous train step
             st = fs.cuda_stream
             stg.upload(self.dev)
             i32 = dict(dtype=torch.int32, device=self.dev)

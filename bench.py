@@ -47,6 +47,11 @@ def parse():
                     help="diagnostics: run the row-sharded engine even with one rank (one-rank RCCL group)")
     ap.add_argument("--cpu-steps", type=int, default=50)
     ap.add_argument("--ids-input", action="store_true", help="feed pre-hashed ids (skips the hash kernel)")
+    ap.add_argument("--repeats", type=int, default=5,
+                    help="the K timed steps are measured this many times back to back (each bracketed by barrier + synchronize); "
+                         "`value` is the median, all of them are printed in `repeats_ms_per_step`")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: --batch examples per GPU; strong: --batch is the GLOBAL batch, split evenly over the ranks")
     ap.add_argument("--tower-dtype", default=None, choices=["fp32", "fp16"],
                     help="GEMM operand type of the tower (default: fp32; c5: fp16 = BASELINE configs[4])")
     return ap.parse_args()
@@ -305,7 +310,7 @@ def cpu_baseline(eng, host_batches, steps, B):
     # are short loops (more threads is not always faster) -- `value` is the best multi-thread figure, `cores` its threads
     runs = {}
     for nt in sorted({1, min(ncpu, 32), ncpu}):
-        n = steps if nt > 1 else max(10, steps // 5)      # one thread: a shorter sample of the same steps (bounded time)
+        n = steps                                          # >= 50 timed steps on every leg (one thread: ~8 s)
         dt = timed(nt, n)
         runs[nt] = {"threads": nt, "steps": n, "seconds": round(dt, 2), "examples_per_sec": round(n * B / dt, 1)}
     multi = [r for nt, r in runs.items() if nt > 1] or list(runs.values())
@@ -351,15 +356,44 @@ def parity_check(eng, spec, tb, hb, step_eager):
             "oracle": "oracle/ CPU restatement on the rows this batch touches (tests/helpers.CompactOracle)"}
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: re-exec the same command line as N ranks of ONE node
+    (python -m torch.distributed.run, rendezvous on 127.0.0.1 and a free port) and wait for them."""
+    import socket
+    import subprocess
+    backend = os.environ.get("WD_DIST_BACKEND", "nccl")
+    have = torch.cuda.device_count()
+    if backend == "nccl" and have < n:
+        raise SystemExit("bench.py --gpus %d: this node has %d GPU(s); RCCL needs one device per rank "
+                         "(WD_DIST_BACKEND=gloo stages the collectives through the host with ranks sharing a GPU: "
+                         "a functional check, not a measurement)" % (n, have))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
 def main():
     args = parse()
+    if os.environ.get("WD_HANG_DUMP"):      # diagnostics: dump every thread's stack and exit if the run takes this many seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["WD_HANG_DUMP"]), exit=True)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # bare `python bench.py --gpus N`: become the launcher -- one rank per GPU through torch.distributed.run on a free
+        # local port; rank 0 prints the one JSON line, this process forwards the ranks' exit status
+        return self_launch(args.gpus)
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..."
-                             % (args.gpus, args.gpus))
+        raise SystemExit("bench.py --gpus %d, but WORLD_SIZE=%d: launch with python -m torch.distributed.run "
+                         "--nproc-per-node %d bench.py --gpus %d ... (or plain `python bench.py --gpus %d`)"
+                         % (args.gpus, world, args.gpus, args.gpus, args.gpus))
     # WD_DIST_BACKEND=gloo: functional smoke test of the N>1 path with all ranks on ONE GPU (host-staged collectives)
     backend = os.environ.get("WD_DIST_BACKEND", "nccl")
     dev_index = local_rank if backend == "nccl" else local_rank % max(torch.cuda.device_count(), 1)
@@ -386,6 +420,10 @@ def main():
     spec, mean_len = make_spec(args.config)
     tower_dtype = args.tower_dtype or ("fp16" if args.config == "c5" else "fp32")
     B = args.batch
+    if args.scaling == "strong":
+        if args.batch % world:
+            raise SystemExit("--scaling strong: --batch %d (global) must be a multiple of the %d ranks" % (args.batch, world))
+        B = args.batch // world
     if sharded:
         from wide_deep_amd.dist import ShardedWideDeepEngine
         eng = ShardedWideDeepEngine(spec, max_batch=B, max_nnz=B * 26 * (2 * mean_len + 2), seed=0,
@@ -420,8 +458,13 @@ def main():
         parity = parity_check(eng, spec, dev_batches[0], host_batches[0], step_eager)
 
     use_graph = not args.no_graph
-    steps_per_run, run_steps = 1, None
-    if use_graph and sharded:
+    steps_per_run, run_steps, run_steps_graph = 1, None, False
+    graph_cls = pipeline.StepGraph
+    if use_graph and sharded and eng._graph_mode() == "full" and eng.chain and eng._chain_input_ok(dev_batches[0].batch):
+        # RCCL backend: the collectives are captured with the kernels -> multi-step pipelined graphs like the single-GPU path
+        from wide_deep_amd.dist import ShardedStepGraph
+        graph_cls = ShardedStepGraph
+    if use_graph and sharded and graph_cls is pipeline.StepGraph:
         # sharded step: hipGraph segments between the collectives (dist._Segments); every rank captures in lock-step
         try:
             # (one eager warm-up step in front of the first capture only: the batches share every buffer shape)
@@ -451,10 +494,10 @@ def main():
         while spg > 1 and j not in starts and len(starts) < 8:
             starts.append(j)
             j = (j + spg) % nb
-        multis = [pipeline.StepGraph(eng, [dev_batches[(j0 + i) % nb] for i in range(spg)], args.ids_input, stream=side)
+        multis = [graph_cls(eng, [dev_batches[(j0 + i) % nb] for i in range(spg)], args.ids_input, stream=side)
                   for j0 in starts]
-        singles = [pipeline.StepGraph(eng, [tb], args.ids_input, stream=side) for tb in dev_batches]
-        steps_per_run = spg
+        singles = [graph_cls(eng, [tb], args.ids_input, stream=side) for tb in dev_batches[:8 if sharded else nb]]
+        steps_per_run, run_steps_graph = spg, True
         # multi-step graphs walk the pool forwards from batch 0, one-step graphs (warm-up steps that do not fill a graph, the
         # remainder of an odd step count) backwards from its end: a short run (the driver's 20 steps after 5 warm-up steps)
         # does not time batches whose rows the warm-up has just pulled into the Infinity Cache
@@ -487,24 +530,36 @@ def main():
         torch.cuda.synchronize()
 
     run_steps(args.warmup)
-    barrier()
-    t0 = time.perf_counter()
-    run_steps(args.steps)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], device="cuda" if backend == "nccl" else "cpu", dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(t.item())
+    # the K timed steps, `--repeats` times back to back; every repeat is bracketed by barrier + synchronize and reduced with MAX
+    # over the ranks.  `value` is the MEDIAN repeat: one stalled lease of the box (seen once in ~35 runs) cannot halve it.
+    reps = []
+    for _ in range(max(1, args.repeats)):
+        barrier()
+        t0 = time.perf_counter()
+        run_steps(args.steps)
+        barrier()
+        el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el], device="cuda" if backend == "nccl" else "cpu", dtype=torch.float64)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            el = float(t.item())
+        reps.append(el)
+    elapsed = sorted(reps)[len(reps) // 2]
     loss = float(eng.loss)
+    overflow = None
     if sharded:
-        eng.check_overflow()     # one device->host read AFTER the timed region
+        try:
+            eng.check_overflow()     # collective; one device->host read AFTER the timed region
+            overflow = "clean"
+        except Exception as e:
+            overflow = str(e)[:160]
     value = args.steps * B * world / elapsed
 
     out = {
         "metric": "examples/sec", "value": round(value, 1), "unit": "examples/sec", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
+        "repeats_ms_per_step": [round(r / args.steps * 1e3, 4) for r in reps],
         "dtype": "f32" if tower_dtype == "fp32" else "f16 tower operands, f32 accumulate / embeddings / optimizer state",
         "data": "synthetic",
         "config": {
@@ -522,10 +577,19 @@ def main():
             "hip_graph": bool(use_graph), "steps_per_graph": steps_per_run,
             "table_layout": ("row records: %d B = [emb %d f32 | w z n -]" % (4 * eng.rec_stride, eng.emb.shape[1])
                              if getattr(eng, "rec", None) is not None else "separate tables"),
-            "pipelined_graph": bool(use_graph and not sharded and multis and multis[0].pipelined) if use_graph and not sharded else False, "parallelism": "dp%d+row-sharded tables" % world if sharded else "single GPU",
+            "pipelined_graph": bool(use_graph and run_steps_graph and (sharded or multis[0].pipelined)),
+            "parallelism": "dp%d+row-sharded tables" % world if sharded else "single GPU",
             "final_loss_sum": round(loss, 3),
         },
     }
+    if sharded:
+        RS, cap, W = eng.RS, eng.cap, world
+        out["config"]["exchange"] = {
+            "graph": eng._graph_mode() if use_graph else "eager",
+            "segment_capacity": cap, "check_overflow": overflow,
+            "payload_bytes_per_rank_per_step": {"A_rows_int32": 4 * W * cap, "B_records_f32": 4 * W * cap * RS,
+                                                "C_gradients_f32": 4 * W * cap * RS, "D_dense_allreduce_f32": 4 * eng.G.numel()},
+            "owner_table_layout": "row records" if eng.rec is not None else "separate tables"}
     if rank == 0:
         out["parity"] = parity
         if world == 1:
@@ -544,9 +608,20 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(eng, host_batches, args.cpu_steps, B)
             else:
                 out["cpu_baseline"] = None
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if sharded:
-        torch.distributed.destroy_process_group()
+        # graphs that hold captured RCCL nodes go first; the teardown itself runs on a helper thread -- on ROCm 7.2 / RCCL 2.26
+        # destroy_process_group() can block forever once collectives have been captured -- and the process leaves regardless
+        import threading
+        multis = singles = replays = run = run_steps = None
+        torch.cuda.synchronize()
+        th = threading.Thread(target=torch.distributed.destroy_process_group, daemon=True)
+        th.start()
+        th.join(10.0)
+        sys.stdout.flush()
+        sys.stderr.flush()
+        if th.is_alive():
+            os._exit(0)
 
 
 if __name__ == "__main__":

@@ -351,6 +351,9 @@ int wd_adam_tick(float *pow, float beta1, float beta2, wd_stream_t stream);
  *   *overflow = max over owners of a count > cap (0: none; caller zeroes it once).  workspace: wd_route_chunks()*world ints.
  * wd_owner_gather: out[r*row_stride + 0..dim) = emb[rows[r]*dim ..] when rows[r] < n_emb_rows (emb may be NULL) and
  *   out[r*row_stride + (emb ? dim : 0)] = wide[rows[r]*4] (wide may be NULL); rows[r] < 0 skipped.
+ * wd_owner_gather_rec: the same on the owner's row-record table (rec[row] = [emb dim f32 | w z n - | pad], rec_stride floats):
+ *   out[r*row_stride + 0..dim+4) = rec[rows[r]*rec_stride + 0..dim+4) -- one copy of dim/4 + 1 float4 per request, the wide
+ *   weight arrives in the line fetched for the row (python/lib/joint.py:140-143: the PS-side read of a partitioned variable).
  * wd_grad_pack: out[pos[j]*row_stride + 0..dim) = dx[b, out_col..] / len(bag) (zeros for non-embedding slots), and
  *   out[pos[j]*row_stride + (dx ? dim : 0)] = dlogit[b] for wide slots (0 otherwise). */
 int32_t wd_route_chunks(void);
@@ -359,6 +362,8 @@ int wd_route_build(const wd_slot_t *local_slots, int32_t S, int32_t world, const
                    int32_t *peer_counts, int32_t *overflow, wd_stream_t stream);
 int wd_owner_gather(const float *emb, int64_t n_emb_rows, int32_t dim, const float *wide, const int32_t *rows, int64_t n,
                     float *out, int32_t row_stride, wd_stream_t stream);
+int wd_owner_gather_rec(const float *rec, int32_t rec_stride, int32_t dim, const int32_t *rows, int64_t n, float *out,
+                        int32_t row_stride, wd_stream_t stream);
 int wd_grad_pack(const wd_slot_t *slots, int32_t S, const int32_t *bag_offs, const int32_t *pos, int64_t batch,
                  const float *dx, int64_t ldx, const float *dlogit, int32_t dim, int32_t row_stride, float *out,
                  wd_stream_t stream);

@@ -181,6 +181,7 @@ _PROTOS = {
     "wd_route_chunks": [],
     "wd_route_build": [P, I32, I32, P, P, I64, I32, P, P, P, P, P, P],
     "wd_owner_gather": [P, I64, I32, P, P, I64, P, I32, P],
+    "wd_owner_gather_rec": [P, I32, I32, P, I64, P, I32, P],
     "wd_grad_pack": [P, I32, P, P, I64, P, I64, P, I32, I32, P, P],
     "wd_fill_i32": [P, I32, I64, P],
     "wd_embag_fwd_strided": [P, I64, P, I32, P, I32, I32, P, P, I64, P, I64, P],

@@ -95,24 +95,33 @@ k_route(const wd_slot_t *__restrict__ slots, int32_t S, int32_t W, const int32_t
   if (!SCATTER && t < W) cntm[(int64_t)blockIdx.x * W + t] = running[t];
 }
 
-// one workgroup: exclusive prefix over the chunks per owner, overflow check
-__global__ void __launch_bounds__(256)
+// one workgroup: exclusive prefix over the chunks per owner, overflow check.  One wavefront-sized lane group per owner walks
+// the chunk counts 64 at a time (two rounds for MAX_CHUNKS = 128): a wave scan instead of a chain of dependent loads.
+__global__ void __launch_bounds__(1024)
 k_route_scan(int32_t *__restrict__ cntm, int32_t nchunks, int32_t W, int32_t cap, int32_t *__restrict__ send_rows,
              int32_t *__restrict__ overflow, int32_t *__restrict__ peer_counts) {
-  const int t = threadIdx.x;
-  if (t < W) {
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;   // wavefront w = owner w (W <= MAX_W = 16 wavefronts)
+  if (w < W) {
     int32_t run = 0;
-    for (int c = 0; c < nchunks; ++c) {
-      const int32_t v = cntm[(int64_t)c * W + t];
-      cntm[(int64_t)c * W + t] = run;
-      run += v;
+    for (int c0 = 0; c0 < nchunks; c0 += 64) {
+      const int c = c0 + lane;
+      const int32_t v = c < nchunks ? cntm[(int64_t)c * W + w] : 0;
+      int32_t incl = v;
+      for (int off = 1; off < 64; off <<= 1) {
+        const int32_t u = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += u;
+      }
+      if (c < nchunks) cntm[(int64_t)c * W + w] = run + incl - v;
+      run += __shfl(incl, 63, 64);
     }
-    peer_counts[t] = run;
-    if (run > cap) atomicMax(overflow, run);
+    if (lane == 0) {
+      peer_counts[w] = run;
+      if (run > cap) atomicMax(overflow, run);
+    }
   }
   if (nchunks == 0) {   // empty batch: no count pass ran
     const int64_t n = (int64_t)W * cap;
-    for (int64_t i = t; i < n; i += 256) send_rows[i] = -1;
+    for (int64_t i = t; i < n; i += 1024) send_rows[i] = -1;
   }
 }
 
@@ -139,6 +148,22 @@ k_owner_gather(const float *__restrict__ emb, int64_t n_emb_rows, int32_t D, con
     for (int c = lane; c < (D >> 2); c += 4) *reinterpret_cast<float4 *>(o + 4 * c) = src[c];
   }
   if (wide && lane == 0) o[emb ? D : 0] = wide[(int64_t)lrow * 4];
+}
+
+// row-record layout on the owner (engine.py: rec[row] = [emb (D f32) | w z n - | pad]): a request is ONE copy of the first
+// `nvec` float4 of the record -- the embedding row and the wide line behind it arrive in the same 128-byte line.
+__global__ void __launch_bounds__(256)
+k_owner_gather_rec(const float *__restrict__ rec, int32_t rec_stride, int32_t nvec, const int32_t *__restrict__ rows,
+                   int64_t n, float *__restrict__ out, int32_t RS) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t r = i / nvec;
+  const int c = (int)(i - r * nvec);
+  if (r >= n) return;
+  const int32_t lrow = rows[r];
+  if (lrow < 0) return;
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  const f4 v = __builtin_nontemporal_load(reinterpret_cast<const f4 *>(rec + (int64_t)lrow * rec_stride) + c);
+  *(reinterpret_cast<f4 *>(out + r * RS) + c) = v;
 }
 
 // per bag (b, s): every occurrence j gets out[pos[j]*RS + 0..D) = dx[b, col..] * (1/len) and, for wide slots,
@@ -193,7 +218,7 @@ extern "C" int wd_route_build(const wd_slot_t *local_slots, int32_t S, int32_t w
   if (nchunks > 0)
     hipLaunchKernelGGL((k_route<false>), dim3(nchunks), dim3(256), 0, st, local_slots, S, world, ids, bag_offs, nbags,
                        bags_per_chunk, cap, workspace, send_rows, pos);
-  hipLaunchKernelGGL(k_route_scan, dim3(1), dim3(256), 0, st, workspace, nchunks, world, cap, send_rows, overflow,
+  hipLaunchKernelGGL(k_route_scan, dim3(1), dim3(1024), 0, st, workspace, nchunks, world, cap, send_rows, overflow,
                      peer_counts);
   if (nchunks > 0)
     hipLaunchKernelGGL((k_route<true>), dim3(nchunks), dim3(256), 0, st, local_slots, S, world, ids, bag_offs, nbags,
@@ -209,6 +234,18 @@ extern "C" int wd_owner_gather(const float *emb, int64_t n_emb_rows, int32_t dim
   hipLaunchKernelGGL(k_owner_gather, dim3((unsigned)wd::ceil_div(n * 4, 256)), dim3(256), 0, wd::as_stream(stream), emb,
                      n_emb_rows, dim, wide, rows, n, out, row_stride);
   return wd::check_launch("wd_owner_gather");
+}
+
+extern "C" int wd_owner_gather_rec(const float *rec, int32_t rec_stride, int32_t dim, const int32_t *rows, int64_t n,
+                                   float *out, int32_t row_stride, wd_stream_t stream) {
+  if (n <= 0) return WD_OK;
+  WD_REQUIRE(rec && rows && out, "null pointer");
+  WD_REQUIRE(dim > 0 && dim % 4 == 0 && rec_stride % 4 == 0 && rec_stride >= dim + 4 && row_stride >= dim + 4 && row_stride % 4 == 0,
+             "record = [dim | w z n -], exchanged row = [dim | w ...], 16-byte aligned");
+  const int nvec = dim / 4 + 1;
+  hipLaunchKernelGGL(k_owner_gather_rec, dim3((unsigned)wd::ceil_div(n * nvec, 256)), dim3(256), 0, wd::as_stream(stream),
+                     rec, rec_stride, nvec, rows, n, out, row_stride);
+  return wd::check_launch("wd_owner_gather_rec");
 }
 
 extern "C" int wd_grad_pack(const wd_slot_t *slots, int32_t S, const int32_t *bag_offs, const int32_t *pos,

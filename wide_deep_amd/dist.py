@@ -194,11 +194,20 @@ class ShardedWideDeepEngine(WideDeepEngine):
         # entries per peer segment: the all-to-alls always move FULL segments, so size them from the occurrences a
         # batch really has (expected_nnz), not from the worst case the buffers could hold
         self.cap = ((int(math.ceil(int(expected_nnz or mn) / W * slack)) + 63) // 64) * 64
+        # the all-to-alls move [W][cap] on every rank: a rank that sized its segments from a different first batch would
+        # hang or corrupt the exchange -- agree on the largest
+        capt = torch.tensor([self.cap], dtype=torch.int64)
+        if dist.get_backend(group) != "gloo":
+            capt = capt.to(device)
+        dist.all_reduce(capt, op=dist.ReduceOp.MAX, group=group)
+        self.cap = int(capt.item())
         self.n_req = W * self.cap
         # owner side: the received list has n_req entries (padding included) -> capacity of the update workspaces
+        # the owner keeps its LOCAL rows as records [emb | w z n - | pad] when the model is record-shaped (engine.py): a request
+        # is answered from one 128-byte line, the update touches two lines per row (WD_ROW_RECORDS=0: separate tables)
+        self._records_ok = not self.mixed_dims
         super().__init__(local_spec(spec, W), max_batch=max_batch, max_nnz=max(mn, self.n_req), device=device,
-                         seed=seed, expected_nnz=self.n_req, table_seed=int(seed) * 1000003 + 7919 * (self.rank + 1),
-                         row_records=False)
+                         seed=seed, expected_nnz=self.n_req, table_seed=int(seed) * 1000003 + 7919 * (self.rank + 1))
         if not self.default_opts:
             raise NotImplementedError("sharded engine: Adagrad (dnn) + Ftrl (linear) only; the other optimizers of "
                                       "model_util.py:84-90 run on the single-GPU engine")
@@ -225,11 +234,14 @@ class ShardedWideDeepEngine(WideDeepEngine):
         self.RS = (self.dim if has_emb else 0) + ((4 if has_emb else 1) if has_wide else 0)   # floats per exchanged row
         i32 = dict(dtype=torch.int32, device=dev)
         f32 = dict(dtype=torch.float32, device=dev)
-        self.send_rows = torch.full((self.n_req,), -1, **i32)
-        self.recv_rows = torch.full((self.n_req,), -1, **i32)
-        self.pos = torch.zeros(self.max_nnz, **i32)
-        self.route_ws = torch.zeros(int(call("wd_route_chunks")) * W, **i32)
-        self.peer_counts = torch.zeros(W, **i32)
+        # two sets of routing state: in a pipelined multi-step graph (ShardedStepGraph) the requests of step t+1 are routed
+        # and exchanged (A) while step t still reads its own set
+        self._xsets = [dict(send_rows=torch.full((self.n_req,), -1, **i32), recv_rows=torch.full((self.n_req,), -1, **i32),
+                            pos=torch.zeros(self.max_nnz, **i32),
+                            route_ws=torch.zeros(int(call("wd_route_chunks")) * W, **i32),
+                            peer_counts=torch.zeros(W, **i32)) for _ in range(2)]
+        self._pset = 0
+        self._skip_exchange = False
         self.overflow = torch.zeros(1, **i32)
         self.fwd_send = torch.zeros(self.n_req * self.RS, **f32)
         self.fwd_recv = torch.zeros(self.n_req * self.RS, **f32)
@@ -260,8 +272,11 @@ class ShardedWideDeepEngine(WideDeepEngine):
         # (its row-range buckets therefore span slots: one geometry over all local rows)
         osh, _, self.n_buckets = bucket_geometry([max(lp.total_rows, 1)], self.n_req, int(call("wd_bucket_max")),
                                                  float(os.environ.get("WD_BUCKET_TARGET", "64")))
-        self.bucket_cnt = torch.zeros((2 * int(call("wd_bucket_chunks")) + 1) * self.n_buckets, **i32)
-        self.bucket_start = torch.zeros(2 * self.n_buckets + 2, **i32)   # starts [nb+1] + launch order [nb]
+        # owner-side bucketing scratch, two sets like the routing state (the base engine's sets follow its own geometry)
+        self._obsets = [dict(cnt=torch.zeros((2 * int(call("wd_bucket_chunks")) + 1) * self.n_buckets, **i32),
+                             start=torch.zeros(2 * self.n_buckets + 2, **i32),   # starts [nb+1] + launch order [nb]
+                             rank=torch.zeros(self.n_req, **i32),
+                             pairs=torch.zeros(self.n_req, dtype=torch.int64, device=dev)) for _ in range(2)]
         self.oslot_dev = make_slots([dict(emb_off=0, row_base=0, num_buckets=max(self.n_emb_rows, 1), dim=self.dim,
                                           out_col=0, kind=capi.SLOT_EMBEDDING if has_emb else capi.SLOT_NONE, wide=1,
                                           bucket_shift=osh[0], bucket_base=0)])
@@ -300,18 +315,37 @@ class ShardedWideDeepEngine(WideDeepEngine):
         s, r0 = self.plan.slots[i], self.plan.row_base[i]
         return buf[: self.n_emb_rows * self.dim].view(self.n_emb_rows, self.dim)[r0: r0 + s.num_buckets, : s.dim]
 
+    # current routing / owner-bucketing set (see _xsets)
+    send_rows = property(lambda self: self._xsets[self._pset]["send_rows"])
+    recv_rows = property(lambda self: self._xsets[self._pset]["recv_rows"])
+    pos = property(lambda self: self._xsets[self._pset]["pos"])
+    route_ws = property(lambda self: self._xsets[self._pset]["route_ws"])
+    peer_counts = property(lambda self: self._xsets[self._pset]["peer_counts"])
+
     def _collective(self, fn):
-        """Run a collective now, or -- while a step is being captured -- close the current graph segment and record it."""
+        """Run a collective now, or -- while a step is being captured as graph segments -- close the current segment and
+        record it (full-graph capture: the collective itself is captured, `fn` simply runs)."""
         if self._segs is not None:
             self._segs.boundary(fn)
         else:
             fn()
 
     def check_overflow(self):
-        n = int(self.overflow.item())
+        """Collective: every rank learns the largest segment any rank was asked to fill, and all raise together (a rank that
+        raised alone would leave its peers hanging in the next all-to-all)."""
+        flag = self.overflow.clone()
+        if dist.get_backend(self.group) == "gloo":
+            flag = flag.cpu()
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.group)
+        n = int(flag.item())
         if n:
             raise capi.WdError("all-to-all segment overflow: a peer received %d requests, capacity %d; "
                                "raise `slack` or `max_nnz`" % (n, self.cap))
+
+    def _fold_at_end(self):
+        # one-launch tower: the dense tail (Adagrad on the all-reduced gradient + the packed kernels of the next step) runs
+        # right behind the all-reduce, so forward() never launches a fold / pack
+        return bool(self.chain) and os.environ.get("WD_FOLD_AT_END", "1") == "1"
 
     # ---- overrides ------------------------------------------------------------------------------
     def _sparse_forward(self, bt: DeviceBatch, st):
@@ -327,30 +361,50 @@ class ShardedWideDeepEngine(WideDeepEngine):
         ci = super()._chain_input(bt, tw)
         ci.emb, ci.slots, ci.ids = ptr(self.fwd_recv), ptr(self.xslots_dev), ptr(self.pos)
         ci.row_stride = self.RS
+        ci.wide, ci.wide_in_row = None, 0
         if self.spec.has_wide:
             ci.wide, ci.wide_in_row = ptr(self.fwd_recv), 1
         return ci
 
-    def _sparse_exchange(self, bt: DeviceBatch, st):
-        lp, spec = self.plan, self.spec
-        B, S, W = bt.B, lp.S, self.world
+    def _route(self, bt: DeviceBatch, st):
+        """A, requester side: every occurrence -> (owner segment, position); needs the ids only."""
+        call("wd_route_build", ptr(self.slots_dev), self.plan.S, self.world, ptr(bt.ids), ptr(bt.bag_offs), bt.B, self.cap,
+             ptr(self.send_rows), ptr(self.pos), ptr(self.route_ws), ptr(self.peer_counts), ptr(self.overflow), st)
+
+    def _exchange_rows(self):
+        """A: the requested local rows travel to their owners."""
+        send, recv = self.send_rows, self.recv_rows
+        self._collective(lambda: _a2a(recv, send, None, None, self.group))
+
+    def _owner_bucketize(self, st):
+        """Owner side of the backward pass, part 1 (needs only the received row list)."""
+        ob = self._obsets[self._pset]
+        call("wd_sparse_bucketize", ptr(self.oslot_dev), 1, ptr(self.recv_rows), ptr(self.req_offs), self.n_req,
+             self.n_req, ptr(ob["cnt"]), ptr(ob["start"]), ptr(ob["rank"]), ptr(ob["pairs"]), self.n_buckets, st)
+
+    def _owner_gather(self, st):
+        """B: owners read the requested rows (+ wide weight) and send them back."""
+        spec = self.spec
         has_emb = self.n_emb_slots > 0
-        # A: route every occurrence to its owner's segment, exchange the requested local rows
-        call("wd_route_build", ptr(self.slots_dev), S, W, ptr(bt.ids), ptr(bt.bag_offs), B, self.cap, ptr(self.send_rows),
-             ptr(self.pos), ptr(self.route_ws), ptr(self.peer_counts), ptr(self.overflow), st)
-        self._collective(lambda: _a2a(self.recv_rows, self.send_rows, None, None, self.group))
-        # B: owners read their rows (+ wide weight), rows travel back
-        call("wd_owner_gather", ptr(self.emb) if has_emb else None, self.n_emb_rows, self.dim,
-             ptr(self.wide) if spec.has_wide else None, ptr(self.recv_rows), self.n_req, ptr(self.fwd_send), self.RS, st)
+        if self.rec is not None:
+            call("wd_owner_gather_rec", ptr(self.rec), self.rec_stride, self.dim, ptr(self.recv_rows), self.n_req,
+                 ptr(self.fwd_send), self.RS, st)
+        else:
+            call("wd_owner_gather", ptr(self.emb) if has_emb else None, self.n_emb_rows, self.dim,
+                 ptr(self.wide) if spec.has_wide else None, ptr(self.recv_rows), self.n_req, ptr(self.fwd_send), self.RS, st)
         self._collective(lambda: _a2a(self.fwd_recv, self.fwd_send, None, None, self.group))
+
+    def _sparse_exchange(self, bt: DeviceBatch, st):
+        if self._skip_exchange:      # ShardedStepGraph has already issued route / A / B of this step on its own branches
+            return
+        self._route(bt, st)
+        self._exchange_rows()
+        self._owner_gather(st)
         if self._train_fwd:
-            # owner side of the backward pass, part 1 (needs only the received row list): bucket the requests on a
-            # side stream under the tower; joined at the top of backward_and_update (same graph segment)
+            # bucket the received requests on a side stream under the tower; joined at the top of backward_and_update
             main, side = torch.cuda.current_stream(), self._side(0)
             side.wait_stream(main)
-            call("wd_sparse_bucketize", ptr(self.oslot_dev), 1, ptr(self.recv_rows), ptr(self.req_offs), self.n_req,
-                 self.n_req, ptr(self.bucket_cnt), ptr(self.bucket_start), ptr(self.occ_rank), ptr(self.pairs),
-                 self.n_buckets, side.cuda_stream)
+            self._owner_bucketize(side.cuda_stream)
             self._bucketized = True
 
     def _pool(self, bt: DeviceBatch, st):
@@ -396,34 +450,38 @@ class ShardedWideDeepEngine(WideDeepEngine):
             self._work_c = _a2a(self.bwd_recv, self.bwd_send, None, None, self.group, async_op=True)
         self._collective(send)
 
-    def _owner_update(self, bt: DeviceBatch, st, do_bias=True):
-        lp, spec = self.plan, self.spec
-        B = bt.B
-        has_emb = self.n_emb_slots > 0
-
+    def _wait_grads(self):
         def wait():
             if self._work_c is not None:
                 self._work_c.wait()      # stream-level wait: the received gradients are complete for what follows
                 self._work_c = None
         self._collective(wait)
+
+    def _owner_apply(self, st, bucketized):
+        """Owner: dedup by row + Adagrad / FTRL on the received (row, gradient) list; bias handled elsewhere."""
+        spec = self.spec
+        has_emb = self.n_emb_slots > 0
         lr, l1, l2 = (spec.lin_opt[1], spec.lin_opt[2], spec.lin_opt[3]) if spec.has_wide else (0.0, 0.0, 0.0)
         g_ptr = self.bwd_recv.data_ptr()
         dl_ptr = g_ptr + 4 * (self.dim if has_emb else 0)
-        # owner: dedup by row + Adagrad / FTRL on the received (row, gradient) list; bias handled below
-        if self._bucketized:
-            self._bucketized = False
-            call("wd_sparse_apply", ptr(self.emb) if has_emb else None, ptr(self.emb_acc) if has_emb else None,
-                 ptr(self.wide) if spec.has_wide else None, None, ptr(self.oslot_dev), 1, ptr(self.req_offs), self.n_req,
-                 g_ptr if has_emb else None, self.RS, dl_ptr if spec.has_wide else None, self.RS,
-                 float(spec.dnn_opt[1]) if spec.has_deep else 0.0, float(lr), float(l1), float(l2),
-                 ptr(self.bucket_start), ptr(self.pairs), self.n_buckets, st)
-        else:
-            call("wd_sparse_bwd_fused", ptr(self.emb) if has_emb else None, ptr(self.emb_acc) if has_emb else None,
-                 ptr(self.wide) if spec.has_wide else None, None, ptr(self.oslot_dev), 1, ptr(self.recv_rows),
-                 ptr(self.req_offs), self.n_req, self.n_req, g_ptr if has_emb else None, self.RS,
-                 dl_ptr if spec.has_wide else None, self.RS, float(spec.dnn_opt[1]) if spec.has_deep else 0.0, float(lr),
-                 float(l1), float(l2), ptr(self.bucket_cnt), ptr(self.bucket_start), ptr(self.occ_rank), ptr(self.pairs),
-                 self.n_buckets, st)
+        ob = self._obsets[self._pset]
+        if not bucketized:
+            self._owner_bucketize(st)
+        if self.rec is not None:
+            call("wd_sparse_apply_rec", ptr(self.rec), self.rec_stride, self.dim, ptr(self.emb_acc), None, ptr(self.oslot_dev),
+                 1, ptr(self.req_offs), self.n_req, g_ptr, self.RS, dl_ptr, self.RS, float(spec.dnn_opt[1]), float(lr),
+                 float(l1), float(l2), ptr(ob["start"]), ptr(ob["pairs"]), self.n_buckets, st)
+            return
+        call("wd_sparse_apply", ptr(self.emb) if has_emb else None, ptr(self.emb_acc) if has_emb else None,
+             ptr(self.wide) if spec.has_wide else None, None, ptr(self.oslot_dev), 1, ptr(self.req_offs), self.n_req,
+             g_ptr if has_emb else None, self.RS, dl_ptr if spec.has_wide else None, self.RS,
+             float(spec.dnn_opt[1]) if spec.has_deep else 0.0, float(lr), float(l1), float(l2),
+             ptr(ob["start"]), ptr(ob["pairs"]), self.n_buckets, st)
+
+    def _owner_update(self, bt: DeviceBatch, st, do_bias=True):
+        self._wait_grads()
+        bucketized, self._bucketized = self._bucketized, False
+        self._owner_apply(st, bucketized)
         if do_bias:
             self._bias_update(bt, st)
 
@@ -445,32 +503,42 @@ class ShardedWideDeepEngine(WideDeepEngine):
         self._grads_to_owners(bt, st)
         self._owner_update(bt, st)
 
-    def backward_and_update(self, bt: DeviceBatch, bucketized=False):
-        """With the one-launch tower dx exists when forward() returns: the gradient exchange starts first and overlaps
-        with the dense branch (weight-gradient GEMMs, finalize, all-reduce, dense Adagrad)."""
-        spec, st = self.spec, _stream()
-        if self._bucketized:
-            torch.cuda.current_stream().wait_stream(self._side(0))     # the early bucketing (see _sparse_forward)
-        if not (spec.has_deep and self.chain):
-            return super().backward_and_update(bt, False)
-        B = bt.B
-        self._grads_to_owners(bt, st)
+    def _dense_tail(self, bt, st):
+        """Products -> this rank's dense gradient -> D (all-reduce) -> Adagrad + the packed kernels of the next step."""
         tw = self.towers[0]
-        self._tower_backward(tw, B, st, need_dx=False, head_done=True)
+        self._tower_backward(tw, bt.B, st, need_dx=False, head_done=True)
         self._chain_tail(capi.WD_TAIL_GRAD, st)      # this rank's dense gradient from the split-K partials -> G
-        # D (all-reduce of the flat dense gradient) in the background of the owners' sparse update
+
         def reduce_async():
             self._work_d = _all_reduce_sum(self.G, self.group, async_op=True)
         self._collective(reduce_async)
-        self._owner_update(bt, st, do_bias=False)
 
+    def _dense_finish(self, bt, st):
         def wait_d():
             if self._work_d is not None:
                 self._work_d.wait()
                 self._work_d = None
         self._collective(wait_d)
-        call("wd_adagrad_dense", ptr(self.P), ptr(self.Pacc), ptr(self.G), self.P.numel(), float(spec.dnn_opt[1]), st)
+        if self._fold_at_end():
+            # Adagrad on the all-reduced gradient + the MFMA-packed kernels the next tower launch reads, one launch
+            self._chain_tail(capi.WD_TAIL_UPDATE | capi.WD_TAIL_PACK, st)
+            self._folded = True
+        else:
+            call("wd_adagrad_dense", ptr(self.P), ptr(self.Pacc), ptr(self.G), self.P.numel(), float(self.spec.dnn_opt[1]), st)
         self._bias_update(bt, st)
+
+    def backward_and_update(self, bt: DeviceBatch, bucketized=False):
+        """With the one-launch tower dx exists when forward() returns: the gradient exchange starts first and overlaps
+        with the dense branch (weight-gradient GEMMs, all-reduce, dense tail)."""
+        spec, st = self.spec, _stream()
+        if self._bucketized:
+            torch.cuda.current_stream().wait_stream(self._side(0))     # the early bucketing (see _sparse_exchange)
+        if not (spec.has_deep and self.chain):
+            return super().backward_and_update(bt, False)
+        self._grads_to_owners(bt, st)
+        self._dense_tail(bt, st)         # D (all-reduce of the flat dense gradient) in the background of the owners' update
+        self._owner_update(bt, st, do_bias=False)
+        self._dense_finish(bt, st)
 
     def train_step(self, bt: DeviceBatch):
         self._train_fwd = True
@@ -479,10 +547,26 @@ class ShardedWideDeepEngine(WideDeepEngine):
         finally:
             self._train_fwd = False
 
+    def _graph_mode(self):
+        """How a captured step treats the collectives: "full" = RCCL calls are captured into the hipGraph with everything else
+        (one launch per replay; verified on ROCm 7.2 / RCCL 2.26 with a one-rank group, scripts/rccl_graph_probe.py),
+        "segments" = graphs between the collectives, which stay ordinary calls (gloo staging; WD_DIST_GRAPH=segments)."""
+        mode = os.environ.get("WD_DIST_GRAPH", "full")
+        return mode if dist.get_backend(self.group) == "nccl" else "segments"
+
+    def _quiesce(self):
+        torch.cuda.synchronize()
+        if dist.get_backend(self.group) == "nccl":
+            # The process group's watchdog thread polls the completion events of the eager collectives every 100 ms until it
+            # has seen them complete.  A poll that lands inside a capture intermittently fails with hipErrorCapturedEvent on
+            # ROCm 7.2 and takes the process down; the works are complete after the synchronize, so two poll periods later
+            # none is left to poll.
+            import time
+            time.sleep(0.25)
+
     def capture_train_step(self, bt, warmup=2, pre=None):
-        """Capture the step on `bt`'s buffers as graph segments between the collectives (see _Segments); `pre` = extra
-        launches in front of it (e.g. the token hashing that fills bt.ids).  Returns a replay callable; every rank must
-        capture and replay in lock-step (the collectives are real calls)."""
+        """Capture the step on `bt`'s buffers; `pre` = extra launches in front of it (e.g. the token hashing that fills
+        bt.ids).  Returns a replay callable; every rank must capture and replay in lock-step."""
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -491,14 +575,26 @@ class ShardedWideDeepEngine(WideDeepEngine):
                     pre()
                 self.train_step(bt)
         torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        if warmup and dist.get_backend(self.group) == "nccl":
-            # The process group's watchdog thread polls the completion events of the eager collectives above every 100 ms
-            # until it has seen them complete.  A poll that lands inside the capture below intermittently fails with
-            # hipErrorCapturedEvent on ROCm 7.2 (observed: 1 of 2 runs of bench.py --force-sharded) and takes the process
-            # down; the works are complete after the synchronize, so two poll periods later none is left to poll.
-            import time
-            time.sleep(0.25)
+        if warmup:
+            self._quiesce()
+        bump = 3 if self.spec.model_type == "wide_deep" else 2
+        if self._graph_mode() == "full":
+            graph = torch.cuda.CUDAGraph()
+            gs = self.global_step
+            with torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local"):
+                if pre:
+                    pre()
+                self.train_step(bt)
+            self.global_step = gs
+            torch.cuda.synchronize()
+            self._graph = graph
+
+            def replay_full():
+                graph.replay()
+                self.global_step += bump
+                return self.loss
+
+            return replay_full
         segs = _Segments()
         with torch.cuda.stream(side):
             self._segs = segs
@@ -511,7 +607,6 @@ class ShardedWideDeepEngine(WideDeepEngine):
                 segs.end()
                 self._segs = None
         torch.cuda.synchronize()
-        bump = 3 if self.spec.model_type == "wide_deep" else 2
 
         def replay():
             for op in segs.ops:
@@ -568,3 +663,118 @@ class ShardedWideDeepEngine(WideDeepEngine):
             else:
                 out[k] = v
         return out
+
+
+class ShardedStepGraph:
+    """`len(token_batches)` consecutive SHARDED train steps in one hipGraph, RCCL collectives captured with the kernels
+    (one launch per replay on every rank; ranks must build and replay in lock-step -- the captured collectives meet their
+    peers' in issue order).  Two graph branches:
+
+        main     owner gather(t) -> B(t): rows back to the requesters -> tower(t) (pools the received rows itself) -> pack ->
+                 C(t): gradients to the owners (async) -> products -> tail(GRAD) -> D(t): all-reduce (async) ->
+                 tail(UPDATE|PACK) + bias -> hash(t+1) -> route(t+1) -> A(t+1): requested rows to their owners
+        sparse   owner-side bucketing of the requests of step t (under tower(t)) | wait C(t) -> owner update(t): Adagrad /
+                 Ftrl on the received (row, gradient) list, beside the products and the input work of step t+1
+
+    Needs the one-launch tower with the fused input (Criteo-shaped model, one id per bag) and the RCCL backend
+    (`eng._graph_mode() == "full"`); dist.py's per-step capture_train_step covers everything else."""
+
+    def __init__(self, eng, token_batches, ids_input=False, stream=None):
+        from . import synth
+        if eng._graph_mode() != "full":
+            raise capi.WdError("ShardedStepGraph needs the RCCL backend with captured collectives (WD_DIST_GRAPH=full)")
+        if not all(eng.chain and eng._chain_input_ok(tb.batch) and tb.batch.labels is not None for tb in token_batches):
+            raise capi.WdError("ShardedStepGraph: one-launch tower with the fused input layer only")
+        if not eng._folded:
+            raise capi.WdError("ShardedStepGraph: run one eager train step first (packed kernels, lazy allocations)")
+        self.eng, self.n = eng, len(token_batches)
+        self.stream = stream or torch.cuda.Stream()
+        self.graph = torch.cuda.CUDAGraph()
+        self._events = []
+        self.stream.wait_stream(torch.cuda.current_stream())
+        eng._quiesce()
+        gs = eng.global_step
+        try:
+            with torch.cuda.graph(self.graph, stream=self.stream, capture_error_mode="thread_local"):
+                self._capture(token_batches, ids_input, synth)
+        finally:
+            eng._pset, eng._skip_exchange = 0, False
+            eng.global_step = gs
+        torch.cuda.synchronize()
+        self._bump = (3 if eng.spec.model_type == "wide_deep" else 2) * self.n
+
+    def _capture(self, tbs, ids_input, synth):
+        eng = self.eng
+        main = torch.cuda.current_stream()
+        n = len(tbs)
+        if os.environ.get("WD_SHARD_PIPE", "1") == "0":     # plain stream order, collectives captured: no cross-step overlap
+            for tb in tbs:
+                if not ids_input:
+                    synth.hash_tokens(eng, tb)
+                eng.train_step(tb.batch)
+            return
+        # Two branches: main and sparse (owner-side bucketing + owner update).  What hipStreamEndCapture of ROCm 7.2 / torch 2.10
+        # / RCCL 2.26 survives was found by bisection (round 3): every collective is issued from the MAIN branch; the requested
+        # rows (A) travel with a SYNCHRONOUS call -- an asynchronous A whose Work is waited for on another branch segfaults the
+        # end of the capture, while C and D (asynchronous, waited for once) are fine; a third branch for hash / route joined
+        # in front of A segfaults as well.  The input work of step t+1 (hash, route, A) therefore sits on the main branch
+        # behind the dense tail of step t, where main would otherwise idle until the owner update of step t is done, and the
+        # owner-side bucketing of what arrived goes to the sparse branch, under the tower of step t+1.
+        s_sp = eng._side(0)
+        s_sp.wait_stream(main)
+        keep = self._events
+
+        def event(stream):
+            ev = torch.cuda.Event()
+            ev.record(stream)
+            keep.append(ev)
+            return ev
+
+        ev_upd = [None] * n
+
+        def input_work(t):
+            """hash -> route -> A of step t on the main branch (routing / bucketing set t & 1: step t-2, its last reader, is
+            complete -- main has joined update(t-2) before the owner gather of step t-1), bucketing on the sparse branch."""
+            tb = tbs[t]
+            eng._pset = t & 1
+            if not ids_input:
+                synth.hash_tokens(eng, tb)
+            eng._route(tb.batch, main.cuda_stream)
+            eng._exchange_rows()                              # A
+            s_sp.wait_event(event(main))
+            with torch.cuda.stream(s_sp):
+                eng._owner_bucketize(s_sp.cuda_stream)
+
+        input_work(0)
+        for t, tb in enumerate(tbs):
+            bt = tb.batch
+            eng._pset = t & 1
+            st = main.cuda_stream
+            if t >= 1:
+                main.wait_event(ev_upd[t - 1])                # the rows this step reads are final
+            eng._owner_gather(st)                             # + B
+            eng._skip_exchange = True
+            eng.forward(bt, need_loss=True)                   # the tower launch (packed kernels in place)
+            eng._skip_exchange = False
+            eng._grads_to_owners(bt, st)                      # pack + C (async)
+            ev_pack = event(main)
+            tw = eng.towers[0]
+            eng._tower_backward(tw, bt.B, st, need_dx=False, head_done=True)      # weight-gradient products
+            # the owner update is captured BEHIND the products (ready nodes launch in capture order; its thousands of small
+            # workgroups would otherwise occupy the CUs first -- pipeline.py)
+            s_sp.wait_event(ev_pack)
+            with torch.cuda.stream(s_sp):
+                eng._wait_grads()
+                eng._owner_apply(s_sp.cuda_stream, True)
+                ev_upd[t] = event(s_sp)
+            eng._chain_tail(capi.WD_TAIL_GRAD, st)
+            eng._work_d = _all_reduce_sum(eng.G, eng.group, async_op=True)      # D
+            eng._dense_finish(bt, st)
+            if t + 1 < n:
+                input_work(t + 1)                             # beside the owner update of this step
+        main.wait_stream(s_sp)
+
+    def replay(self):
+        self.graph.replay()
+        self.eng.global_step += self._bump
+        return self.eng.loss

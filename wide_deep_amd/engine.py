@@ -74,12 +74,14 @@ class WideDeepEngine:
         # update touches two random lines per row (record + accumulator) instead of three (profiles/r2z_layouts.txt).
         # row_records=None: on when eligible (WD_ROW_RECORDS=0 turns it off); True: required; False: separate tables.
         dims = sorted(plan.emb_groups) if spec.has_deep else []
-        eligible = (spec.has_deep and spec.has_wide and self.default_opts and type(self) is WideDeepEngine
+        # (the row-sharded engine lays its LOCAL rows out the same way: dist.py sets _records_ok before it gets here)
+        eligible = (spec.has_deep and spec.has_wide and self.default_opts
+                    and getattr(self, "_records_ok", type(self) is WideDeepEngine)
                     and len(dims) == 1 and dims[0] in (4, 8, 16) and plan.n_emb == plan.S and plan.S > 0
                     and all(sl.wide for sl in plan.slots))
         if row_records and not eligible:
             raise ValueError("row_records=True: the model is not record-shaped (one embedding width in {4, 8, 16} on every "
-                             "categorical column, all of them wide columns too, Adagrad + Ftrl, single GPU)")
+                             "categorical column, all of them wide columns too, Adagrad + Ftrl)")
         if row_records is None:
             row_records = os.environ.get("WD_ROW_RECORDS", "1") != "0"
         self.rec_stride = {4: 8, 8: 16, 16: 32}[dims[0]] if (row_records and eligible) else 0
@@ -1246,3 +1248,8 @@ class WideDeepEngine:
                 self.pow[scope][1] = float(state[names[1]])
         if "global_step" in state:
             self.global_step = int(state["global_step"])
+        if spec.has_deep and self.chain:
+            # the one-launch tower reads MFMA-packed COPIES of the kernels, and a captured step (pipeline.StepGraph, dist.py)
+            # bakes in "the copies are current": rewrite them now instead of leaving it to the next eager forward()
+            self._chain_tail(capi.WD_TAIL_PACK, _stream())
+            self._folded = self._fold_at_end()

@@ -183,6 +183,97 @@ def test_sharded_world2_equals_single_engine(kind):
         assert msg == "ok", "rank %d: %s" % (rank, msg)
 
 
+# ---- the sharded step AT BASELINE SIZE (C2: 26 x 1M rows; C3: 26 x 3,846,154 = the 100M-row table), 4096 examples per rank ----
+def _copy_shard(ref, sh):
+    """Device-side copy of the single engine's whole state into this rank's shard (rows id % world == rank), dense part as is;
+    nothing of size O(table) crosses PCIe."""
+    W, r = sh.world, sh.rank
+    lp, gp = sh.plan, ref.plan
+    for i, s in enumerate(gp.slots):
+        n = len(range(r, int(s.num_buckets), W))
+        for name in ("emb", "emb_acc"):
+            sh._emb_view(getattr(sh, name), i)[:n].copy_(ref._emb_view(getattr(ref, name), i)[r::W])
+        g0, l0 = gp.row_base[i], lp.row_base[i]
+        sh.wide[l0: l0 + n].copy_(ref.wide[g0: g0 + int(s.num_buckets)][r::W])
+    for name in ("P", "Pacc", "bias"):
+        getattr(sh, name).copy_(getattr(ref, name))
+    from wide_deep_amd import capi
+    sh._chain_tail(capi.WD_TAIL_PACK, torch.cuda.current_stream().cuda_stream)
+    sh._folded = True
+    sh.global_step = ref.global_step
+
+
+def _fullsize_worker(rank, world, port, kind, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        from wide_deep_amd import synth
+        from wide_deep_amd.dist import ShardedWideDeepEngine
+        from wide_deep_amd.engine import WideDeepEngine
+        from wide_deep_amd.plan import criteo_spec
+        from tests.helpers import assert_close
+        cfg, idist = kind.split("_")
+        buckets = 1_000_000 if cfg == "c2" else 3_846_154
+        spec = criteo_spec(n_dense=13, n_sparse=26, buckets=buckets, dim=16, hidden=(256, 128, 64), mode="simple")
+        B_loc, steps = 4096, 3
+        ref = WideDeepEngine(spec, max_batch=B_loc * world, seed=3)
+        sh = ShardedWideDeepEngine(spec, max_batch=B_loc, max_nnz=B_loc * 26 * 4, seed=3, expected_nnz=B_loc * 26,
+                                   slack=1.3 if idist == "uniform" else 2.5)
+        assert sh.chain and ref.chain and sh.rec is not None and ref.rec is not None
+        S = ref.plan.S
+        for st in range(steps):
+            hbs = [synth.make_raw_batch(ref.plan, B_loc, seed=7000 + 10 * st + r, mean_len=1, dist=idist) for r in range(world)]
+            glob = {"B": B_loc * world, "lens": np.concatenate([h["lens"] for h in hbs], 0),
+                    "raw": np.concatenate([h["raw"] for h in hbs]), "dense": np.concatenate([h["dense"] for h in hbs], 0),
+                    "labels": np.concatenate([h["labels"] for h in hbs])}
+            # every step from IDENTICAL state (tests/test_gpu_fullsize.py explains why free-running trajectories separate)
+            _copy_shard(ref, sh)
+            gbt = synth.to_device_ids(ref.plan, glob)
+            lbt = synth.to_device_ids(sh.global_plan, hbs[rank])
+            assert gbt.one_hot and lbt.one_hot and sh._chain_input_ok(lbt)
+            ref.train_step(gbt)
+            sh.train_step(lbt)
+            torch.cuda.synchronize()
+            sh.check_overflow()
+            lg, want = sh.logit[:B_loc], ref.logit[rank * B_loc:(rank + 1) * B_loc]
+            bad = ((lg - want).abs() > 2e-4 + 2e-4 * want.abs()).sum().item()
+            assert bad == 0, "step %d: %d logits out of 2e-4 + 2e-4 |logit| (max |d| %.3g)" % (st, bad, float((lg - want).abs().max()))
+            # the rows this rank OWNS among the ones the global batch touched: table, accumulator and {w, z, n} after the step
+            ids = gbt.ids.view(-1, S).long()
+            for i in range(0, S, 5):
+                mine = torch.unique(ids[:, i])
+                mine = mine[mine % world == rank]
+                loc = mine // world
+                for name in ("emb", "emb_acc"):
+                    assert_close(sh._emb_view(getattr(sh, name), i)[loc], ref._emb_view(getattr(ref, name), i)[mine],
+                                 5e-4, 1e-5, "%s slot %d step %d" % (name, i, st))
+                assert_close(sh.wide[sh.plan.row_base[i] + loc], ref.wide[ref.plan.row_base[i] + mine], 5e-4, 1e-5,
+                             "wide slot %d step %d" % (i, st))
+            # dense parameters: <= 0.5 % of the entries may sit at the ReLU-kink tolerance (tests/test_gpu_fullsize.py)
+            d = (sh.P - ref.P).abs()
+            out = d > 1e-5 + 5e-4 * ref.P.abs()
+            assert out.float().mean().item() <= 0.005 and not bool((d > 5e-3 + 5e-2 * ref.P.abs()).any()), \
+                "dense parameters step %d: %d entries out of tolerance, max |d| %.3g" % (st, int(out.sum()), float(d.max()))
+            assert_close(sh.bias[:3], ref.bias[:3], 5e-4, 1e-5, "bias_weights step %d" % st)
+        q.put((rank, "ok"))
+    except Exception as e:  # pragma: no cover
+        import traceback
+        q.put((rank, "FAIL: %s\n%s" % (e, traceback.format_exc())))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kind", ["c2_uniform", "c2_zipf", "c3_uniform"])
+def test_sharded_world2_at_baseline_size(kind):
+    """BASELINE configs[1] / configs[2] shape through the sharded engine: world 2 on one GPU (gloo staging), 4096 examples per
+    rank, uniform and Zipf(1.05) ids, segment overflow checked, against the full-size single engine on the 8192-example
+    global batch -- logits, the touched rows of the owned shard, dense parameters."""
+    _run(_fullsize_worker, kind)
+
+
 # ---- python train.py under torch.distributed: the Estimator-shaped object on the sharded engine -----------------------
 def _write_conf(dst):
     """A conf directory the sharded engine accepts: the repo conf restricted to hash_bucket + continuous features, one

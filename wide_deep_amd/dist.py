@@ -433,7 +433,7 @@ class ShardedWideDeepEngine(WideDeepEngine):
     def _reduce_dense_grads(self):
         self._collective(lambda: _all_reduce_sum(self.G, self.group))
 
-    def _grads_to_owners(self, bt: DeviceBatch, st):
+    def _pack_grads(self, bt: DeviceBatch, st):
         """C: per-occurrence gradients to the owners.  Issued asynchronously: RCCL moves them while this stream goes on
         with the dense branch; `_owner_update` waits for them."""
         lp, spec = self.plan, self.spec
@@ -446,9 +446,14 @@ class ShardedWideDeepEngine(WideDeepEngine):
         call("wd_grad_pack", ptr(self.slots_dev), lp.S, ptr(bt.bag_offs), ptr(self.pos), bt.B, dx_ptr, ld,
              ptr(self.dlogit) if spec.has_wide else None, self.dim, self.RS, ptr(self.bwd_send), st)
 
+    def _send_grads(self):
         def send():
             self._work_c = _a2a(self.bwd_recv, self.bwd_send, None, None, self.group, async_op=True)
         self._collective(send)
+
+    def _grads_to_owners(self, bt: DeviceBatch, st):
+        self._pack_grads(bt, st)
+        self._send_grads()
 
     def _wait_grads(self):
         def wait():
@@ -704,6 +709,8 @@ class ShardedStepGraph:
         self._bump = (3 if eng.spec.model_type == "wide_deep" else 2) * self.n
 
     def _capture(self, tbs, ids_input, synth):
+        if os.environ.get("WD_SHARD_LAYOUT", "v2") == "v2" and os.environ.get("WD_SHARD_PIPE", "1") != "0":
+            return self._capture_v2(tbs, ids_input, synth)
         eng = self.eng
         main = torch.cuda.current_stream()
         n = len(tbs)
@@ -732,20 +739,33 @@ class ShardedStepGraph:
 
         ev_upd = [None] * n
 
-        def input_work(t):
-            """hash -> route -> A of step t on the main branch (routing / bucketing set t & 1: step t-2, its last reader, is
-            complete -- main has joined update(t-2) before the owner gather of step t-1), bucketing on the sparse branch."""
+        early = os.environ.get("WD_SHARD_ROUTE", "early") == "early"
+        ev_route = [None] * n
+
+        def route_work(t, stream):
+            """hash -> route of step t (routing / bucketing set t & 1: step t-2, its last reader, is complete -- main has
+            joined update(t-2) before the owner gather of step t-1, which precedes every caller)."""
             tb = tbs[t]
             eng._pset = t & 1
-            if not ids_input:
-                synth.hash_tokens(eng, tb)
-            eng._route(tb.batch, main.cuda_stream)
+            with torch.cuda.stream(stream):
+                if not ids_input:
+                    synth.hash_tokens(eng, tb)
+                eng._route(tb.batch, stream.cuda_stream)
+                if stream is not main:
+                    ev_route[t] = event(stream)
+
+        def exchange_rows(t):
+            """A of step t (synchronous, from the main branch), owner-side bucketing of what arrived on the sparse branch."""
+            eng._pset = t & 1
+            if ev_route[t] is not None:
+                main.wait_event(ev_route[t])
             eng._exchange_rows()                              # A
             s_sp.wait_event(event(main))
             with torch.cuda.stream(s_sp):
                 eng._owner_bucketize(s_sp.cuda_stream)
 
-        input_work(0)
+        route_work(0, main)
+        exchange_rows(0)
         for t, tb in enumerate(tbs):
             bt = tb.batch
             eng._pset = t & 1
@@ -753,6 +773,12 @@ class ShardedStepGraph:
             if t >= 1:
                 main.wait_event(ev_upd[t - 1])                # the rows this step reads are final
             eng._owner_gather(st)                             # + B
+            if early and t + 1 < n:
+                # hash / route of the NEXT step on the sparse branch, under this step's tower (behind the bucketing of this
+                # step's requests, in front of the wait for C)
+                s_sp.wait_event(event(main))
+                route_work(t + 1, s_sp)
+                eng._pset = t & 1
             eng._skip_exchange = True
             eng.forward(bt, need_loss=True)                   # the tower launch (packed kernels in place)
             eng._skip_exchange = False
@@ -771,8 +797,93 @@ class ShardedStepGraph:
             eng._work_d = _all_reduce_sum(eng.G, eng.group, async_op=True)      # D
             eng._dense_finish(bt, st)
             if t + 1 < n:
-                input_work(t + 1)                             # beside the owner update of this step
+                if not early:
+                    route_work(t + 1, main)                   # beside the owner update of this step
+                exchange_rows(t + 1)
         main.wait_stream(s_sp)
+
+    def _capture_v2(self, tbs, ids_input, synth):
+        """Three branches; the main one carries ONLY the exchange (collectives are issued from it) and what the owner does:
+
+            main     owner gather(t) -> B(t) | A(t+1) (under the tower) | C(t) (async) -> wait C -> owner update(t) -> D(t) (async)
+            compute  tower(t) -> pack | products(t) -> tail(GRAD) | wait D -> tail(UPDATE|PACK) + bias
+            input    hash(t+1) -> route(t+1) | owner-side bucketing of the requests A(t+1) delivered
+
+        so that what separates two towers is  pack, C, owner update, owner gather, B  and nothing else."""
+        eng = self.eng
+        main = torch.cuda.current_stream()
+        comp, s_r = eng._side(0), eng._side(1)
+        comp.wait_stream(main)
+        s_r.wait_stream(main)
+        keep = self._events
+        n = len(tbs)
+
+        def event(stream):
+            ev = torch.cuda.Event()
+            ev.record(stream)
+            keep.append(ev)
+            return ev
+
+        def route_work(t, stream):
+            tb = tbs[t]
+            eng._pset = t & 1
+            with torch.cuda.stream(stream):
+                if not ids_input:
+                    synth.hash_tokens(eng, tb)
+                eng._route(tb.batch, stream.cuda_stream)
+                return event(stream)
+
+        def exchange_rows(t, ev_route):
+            """A of step t from the main branch; the owner-side bucketing of what arrived goes to the input branch."""
+            eng._pset = t & 1
+            if ev_route is not None:
+                main.wait_event(ev_route)
+            eng._exchange_rows()                              # A (synchronous)
+            s_r.wait_event(event(main))
+            with torch.cuda.stream(s_r):
+                eng._owner_bucketize(s_r.cuda_stream)
+                return event(s_r)
+
+        route_work(0, main)
+        ev_buck = exchange_rows(0, None)
+        ev_dense = None
+        for t, tb in enumerate(tbs):
+            bt = tb.batch
+            eng._pset = t & 1
+            eng._owner_gather(main.cuda_stream)               # + B   (main order: behind the owner update of step t-1)
+            ev_b = event(main)
+            # ---- compute branch: tower(t) -> pack ---------------------------------------------------------------------------
+            comp.wait_event(ev_b)                             # (its own order: behind the dense tail of step t-1)
+            with torch.cuda.stream(comp):
+                eng._skip_exchange = True
+                eng.forward(bt, need_loss=True)               # the tower launch
+                eng._skip_exchange = False
+                eng._pack_grads(bt, comp.cuda_stream)
+                ev_pack = event(comp)
+            # ---- input branch + A of the NEXT step, under the tower -----------------------------------------------------------
+            ev_buck_next = None
+            if t + 1 < n:
+                s_r.wait_event(ev_b)                          # routing set (t+1) & 1: step t-1 is complete
+                ev_route = route_work(t + 1, s_r)
+                ev_buck_next = exchange_rows(t + 1, ev_route)
+                eng._pset = t & 1
+            # ---- C, products, owner update ---------------------------------------------------------------------------------------
+            main.wait_event(ev_pack)
+            eng._send_grads()                                 # C (async)
+            with torch.cuda.stream(comp):
+                eng._tower_backward(eng.towers[0], bt.B, comp.cuda_stream, need_dx=False, head_done=True)   # products
+                eng._chain_tail(capi.WD_TAIL_GRAD, comp.cuda_stream)
+                ev_tg = event(comp)
+            main.wait_event(ev_buck)
+            eng._wait_grads()
+            eng._owner_apply(main.cuda_stream, True)          # owner update (captured behind the products)
+            main.wait_event(ev_tg)
+            eng._work_d = _all_reduce_sum(eng.G, eng.group, async_op=True)      # D
+            with torch.cuda.stream(comp):
+                eng._dense_finish(bt, comp.cuda_stream)       # wait D, Adagrad + packed kernels, bias
+            ev_buck = ev_buck_next
+        main.wait_stream(comp)
+        main.wait_stream(s_r)
 
     def replay(self):
         self.graph.replay()

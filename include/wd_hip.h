@@ -75,6 +75,10 @@ int wd_fingerprint64(const uint8_t *bytes, const int32_t *tok_offs, int64_t ntok
  * the slot of bag g is g % S.  Fuses fingerprint + modulo for the pure hash-bucket configs. */
 int wd_hash_bucket(const uint8_t *bytes, const int32_t *tok_offs, int64_t ntok, const int32_t *token_bag_offs,
                    int64_t nbags, const wd_slot_t *slots, int32_t S, int32_t *out_ids, wd_stream_t stream);
+/* One token per bag (nbags = batch * S tokens): as above, plus a SLOT-MAJOR copy out_ids_cols[s * batch + b] = ids[b * S + s]
+ * (the id column of every slot contiguous: what wd_bucket_onehot reads). */
+int wd_hash_bucket_cols(const uint8_t *bytes, const int32_t *tok_offs, int64_t nbags, const wd_slot_t *slots, int32_t S,
+                        int32_t *out_ids, int32_t *out_ids_cols, wd_stream_t stream);
 
 /* Emit the ids of ONE slot from precomputed fingerprints of one feature's tokens:
  * feature CSR feat_offs[B+1] into fp[]; writes ids[bag_offs[b*S+slot] + j] = fp % num_buckets. */
@@ -284,10 +288,66 @@ int wd_sparse_apply(float *emb, float *emb_accum, float *wide, float *bias_wzn, 
  * per-slot layout of wd_sparse_apply (slot.emb_off).  An update then touches two random lines per row instead of three, and
  * the forward finds the wide weight in the line of the embedding row (wd_chain_input_t.wide_in_row, wd_wide_fwd with
  * wide = rec + dim and stride rec_stride, wd_embag_fwd_strided with slot.emb_off = row_base * rec_stride). */
+/* `next` (may be NULL), for the pipelined step of one-id-per-bag batches (wide_deep_amd/pipeline.py):
+ *   unsorted_buckets != 0: `pairs` came from wd_bucket_onehot (arrival order inside a bucket): one-row buckets are sorted too;
+ *   bucket_start != NULL: the input layer of the NEXT batch has already been gathered (wd_prefetch_onehot into x / wide_vals)
+ *   from the tables as they were BEFORE this update; `bucket_start` / `pairs` are the next batch's buckets (same geometry).
+ *   Every row rewritten here that the next batch holds too is stored again -- x[b'*ldx + out_col + 0..dim) = new row,
+ *   wide_vals[bag'] = new w -- so that the next forward reads exactly what a gather AFTER this update would have read
+ *   (python/lib/joint.py:233-262: the reference applies both optimizers before the next session.run reads a variable). */
+typedef struct wd_apply_next {
+  const int32_t *bucket_start;
+  const uint64_t *pairs;
+  float *x;
+  float *wide_vals;
+  int64_t ldx;
+  int32_t unsorted_buckets, pad_;
+} wd_apply_next_t;
 int wd_sparse_apply_rec(float *rec, int32_t rec_stride, int32_t dim, float *emb_accum, float *bias_wzn,
                         const wd_slot_t *slots, int32_t S, const int32_t *bag_offs, int64_t batch, const float *dx,
                         int64_t ldx, const float *dlogit, int64_t ld_dlogit, float lr_emb, float lr_wide, float l1, float l2,
-                        const int32_t *bucket_start, uint64_t *pairs, int32_t nbuckets, wd_stream_t stream);
+                        const int32_t *bucket_start, uint64_t *pairs, int32_t nbuckets, const wd_apply_next_t *next,
+                        wd_stream_t stream);
+/* One-id-per-bag batches (bag (b, s) holds exactly ids[b*S + s] >= 0): the bucketing of wd_sparse_bucketize in ONE launch
+ * (csrc/onehot_path.hip).  Every slot owns `batch` occurrences, so slot s fills pairs[s*batch, (s+1)*batch); inside a bucket
+ * the pairs are in ARRIVAL order (wd_sparse_apply_rec: wd_apply_next_t.unsorted_buckets).  bucket_start as above
+ * ([2 * nbuckets + 2]); max_slot_buckets = the largest per-slot bucket count (LDS of the launch); ticket: one int32 that is
+ * 0 before the first call (the last workgroup of a launch lists the buckets largest-first and resets it).
+ * ids_slot_major != 0: `ids` is the slot-major copy of wd_hash_bucket_cols (ids[s * batch + b]; coalesced column reads).
+ * ticket NULL: no launch order is written.  zero_word (may be NULL): two int32 this launch sets to 0 (wd_bucket_sort's counters). */
+int wd_bucket_onehot(const wd_slot_t *slots, int32_t S, const int32_t *ids, int32_t ids_slot_major, int64_t batch,
+                     int32_t *bucket_start, uint64_t *pairs, int32_t nbuckets, int32_t max_slot_buckets, int32_t *ticket,
+                     int32_t *zero_word, wd_stream_t stream);
+/* The id-only part of the sparse update, off the critical path of the step (csrc/onehot_path.hip; python/lib/joint.py:233-248:
+ * the duplicate-summing of the IndexedSlices gradient these lists prepare).
+ * wd_bucket_sort: every bucket of wd_bucket_onehot sorted in place on (row, bag), two launches (buckets of up to 256 pairs; the
+ *   larger ones, listed in big_list[nbuckets], with the LDS a 1024-pair sort needs); long_list[0] and [1] (zeroed by the caller,
+ *   e.g. wd_bucket_onehot's zero_word) count the rows with more than 32 occurrences and the large buckets, long_list[2 + 2k],
+ *   [3 + 2k] = position and length of such a row (long_capacity entries: batch * S / 32 + 1 always suffice); prev_* (all three or none): for every sorted position i of the PREVIOUS
+ *   batch (same bucket geometry) prev_patch[2i], [2i + 1] = position of the first pair of the same row in THIS batch (-1: none)
+ *   and the number of its pairs (prev_patch: 2 * batch * S int32, 8-byte aligned).
+ * wd_row_update: Adagrad (embedding rows, accumulators flat per slot as in wd_sparse_apply_rec) + FTRL ({w, z, n} behind the
+ *   row, and bias_wzn) over the sorted pairs of a one-id-per-bag batch on the row-record table: duplicates of a row summed in
+ *   ascending bag order, the optimizer applied once per row -- the arithmetic of wd_sparse_apply_rec, bit for bit -- as a
+ *   flat launch (4 lanes per sorted position) with two dependent memory round trips.  patch (may be NULL) = the array the NEXT
+ *   batch's wd_bucket_sort filled for this one: rows the next batch reads too are stored into its prefetched input again
+ *   (next->pairs = its SORTED pairs, next->x, next->wide_vals, next->ldx; next->bucket_start unused). */
+int wd_bucket_sort(const int32_t *bucket_start, uint64_t *pairs, int32_t nbuckets, int32_t *long_list, int32_t long_capacity,
+                   int32_t *big_list, int64_t batch, int32_t S, const int32_t *prev_bucket_start,
+                   const uint64_t *prev_pairs, int32_t *prev_patch, wd_stream_t stream);
+int wd_row_update(float *rec, int32_t rec_stride, int32_t dim, float *emb_accum, float *bias_wzn, const wd_slot_t *slots,
+                  int32_t S, int64_t batch, const float *dx, int64_t ldx, const float *dlogit, float lr_emb, float lr_wide,
+                  float l1, float l2, const uint64_t *pairs, const int32_t *long_list, int32_t long_capacity,
+                  const int32_t *patch, const wd_apply_next_t *next, wd_stream_t stream);
+/* The input layer of a one-id-per-bag batch on the row-record tables, as its own launch (python/lib/dnn.py:83-91,
+ * python/lib/linear.py:29-36): x[b*ldx + out_col_s + 0..dim) = rec[row(b,s)][0..dim), wide_vals[b*S + s] = rec[row(b,s)][dim]
+ * (the wide weight, NOT summed: wd_tower_chain adds them up with the bias, wd_chain_opts_t.wide_vals), numeric columns as
+ * wd_dense_fwd.  rec_slots: slot descriptors with emb_off = row_base * rec_stride.  dim in {4, 8, 16}.
+ * span (diagnostics, may be NULL): device uint64[2], the chip-wide 100 MHz realtime clock at the start of the first
+ * (atomic min into span[0]) and the end of the last workgroup (atomic max into span[1]); the caller resets {~0, 0}. */
+int wd_prefetch_onehot(const float *rec, int32_t rec_stride, int32_t dim, const wd_slot_t *rec_slots, int32_t S,
+                       const int32_t *ids, int64_t batch, float *x, int64_t ldx, float *wide_vals, const float *dense,
+                       int64_t ld_dense, const wd_dense_col_t *dense_cols, int32_t ncols, void *span, wd_stream_t stream);
 int wd_sparse_bwd_fused(float *emb, float *emb_accum, float *wide, float *bias_wzn, const wd_slot_t *slots, int32_t S,
                         const int32_t *ids, const int32_t *bag_offs, int64_t batch, int64_t nnz, const float *dx,
                         int64_t ldx, const float *dlogit, int64_t ld_dlogit, float lr_emb, float lr_wide, float l1, float l2,
@@ -571,6 +631,12 @@ typedef struct wd_chain_opts {
   void *tile_stamps;
   int32_t row_tile;
   int32_t flags;       /* bit 0: row tile 16 without the priority split between the two co-resident workgroups (A/B switch) */
+  /* wide logit from a per-occurrence weight list (wd_prefetch_onehot): wide_logit[b] = wide_bias[0] + sum_s wide_vals[b*wide_S + s],
+   * slots in order; replaces the wide_logit argument (input must be NULL); also stored to wide_out when that is not NULL */
+  const float *wide_vals;
+  const float *wide_bias;
+  float *wide_out;
+  int32_t wide_S, pad_;
 } wd_chain_opts_t;
 int64_t wd_tower_chain_lds_bytes(int32_t K0, const int32_t *N, int32_t L, int32_t row_tile);   /* -1: unsupported shape */
 int64_t wd_tower_chain_blocks(int64_t batch, int32_t row_tile);   /* ceil(batch / row_tile) */

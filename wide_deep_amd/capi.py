@@ -80,7 +80,15 @@ WD_CHAIN_MAX_SLOTS = 128
 
 class WdChainOpts(ctypes.Structure):
     _fields_ = [("input", ctypes.c_void_p), ("loss_part", ctypes.c_void_p), ("stamps", ctypes.c_void_p),
-                ("tile_stamps", ctypes.c_void_p), ("row_tile", ctypes.c_int32), ("flags", ctypes.c_int32)]
+                ("tile_stamps", ctypes.c_void_p), ("row_tile", ctypes.c_int32), ("flags", ctypes.c_int32),
+                ("wide_vals", ctypes.c_void_p), ("wide_bias", ctypes.c_void_p), ("wide_out", ctypes.c_void_p),
+                ("wide_S", ctypes.c_int32), ("pad_", ctypes.c_int32)]
+
+
+class WdApplyNext(ctypes.Structure):
+    _fields_ = [("bucket_start", ctypes.c_void_p), ("pairs", ctypes.c_void_p), ("x", ctypes.c_void_p),
+                ("wide_vals", ctypes.c_void_p), ("ldx", ctypes.c_int64), ("unsorted_buckets", ctypes.c_int32),
+                ("pad_", ctypes.c_int32)]
 
 
 class WdTnJob(ctypes.Structure):
@@ -177,7 +185,12 @@ _PROTOS = {
     "wd_sparse_bwd_fused": [P, P, P, P, P, I32, P, P, I64, I64, P, I64, P, I64, F32, F32, F32, F32, P, P, P, P, I32, P],
     "wd_sparse_bucketize": [P, I32, P, P, I64, I64, P, P, P, P, I32, P],
     "wd_sparse_apply": [P, P, P, P, P, I32, P, I64, P, I64, P, I64, F32, F32, F32, F32, P, P, I32, P],
-    "wd_sparse_apply_rec": [P, I32, I32, P, P, P, I32, P, I64, P, I64, P, I64, F32, F32, F32, F32, P, P, I32, P],
+    "wd_sparse_apply_rec": [P, I32, I32, P, P, P, I32, P, I64, P, I64, P, I64, F32, F32, F32, F32, P, P, I32, P, P],
+    "wd_bucket_onehot": [P, I32, P, I32, I64, P, P, I32, I32, P, P, P],
+    "wd_bucket_sort": [P, P, I32, P, I32, P, I64, I32, P, P, P, P],
+    "wd_row_update": [P, I32, I32, P, P, P, I32, I64, P, I64, P, F32, F32, F32, F32, P, P, I32, P, P, P],
+    "wd_hash_bucket_cols": [P, P, I64, P, I32, P, P, P],
+    "wd_prefetch_onehot": [P, I32, I32, P, I32, P, I64, P, I64, P, P, I64, P, I32, P, P],
     "wd_route_chunks": [],
     "wd_route_build": [P, I32, I32, P, P, I64, I32, P, P, P, P, P, P],
     "wd_owner_gather": [P, I64, I32, P, P, I64, P, I32, P],

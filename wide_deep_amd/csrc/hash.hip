@@ -169,14 +169,17 @@ __device__ __forceinline__ int64_t bag_of_token(const int32_t *__restrict__ offs
 
 __global__ void k_hash_bucket(const uint8_t *__restrict__ bytes, const int32_t *__restrict__ tok_offs, int64_t ntok,
                               const int32_t *__restrict__ token_bag_offs, int64_t nbags,
-                              const wd_slot_t *__restrict__ slots, int32_t S, int32_t *__restrict__ out_ids) {
+                              const wd_slot_t *__restrict__ slots, int32_t S, int32_t *__restrict__ out_ids,
+                              int32_t *__restrict__ out_cols) {
   int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= ntok) return;
   int32_t o0 = tok_offs[t], o1 = tok_offs[t + 1];
   uint64_t fp = fingerprint64(bytes + o0, (uint32_t)(o1 - o0));
   int64_t bag = token_bag_offs ? bag_of_token(token_bag_offs, nbags, (int32_t)t) : t;
   uint64_t nb = (uint64_t)slots[bag % S].num_buckets;
-  out_ids[t] = (int32_t)(fp % nb);
+  const int32_t id = (int32_t)(fp % nb);
+  out_ids[t] = id;
+  if (out_cols) out_cols[(bag % S) * (nbags / S) + bag / S] = id;   // slot-major copy (one token per bag): column s = ids of slot s
 }
 
 __global__ void k_emit_hash_slot(const uint64_t *__restrict__ fp, const int32_t *__restrict__ feat_offs, int64_t batch,
@@ -457,8 +460,18 @@ extern "C" int wd_hash_bucket(const uint8_t *bytes, const int32_t *tok_offs, int
   WD_REQUIRE(S > 0, "S must be > 0");
   WD_REQUIRE(token_bag_offs || nbags == ntok, "one-token-per-bag mode needs nbags == ntok");
   hipLaunchKernelGGL(k_hash_bucket, dim3((unsigned)wd::ceil_div(ntok, 256)), dim3(256), 0, wd::as_stream(stream),
-                     bytes, tok_offs, ntok, token_bag_offs, nbags, slots, S, out_ids);
+                     bytes, tok_offs, ntok, token_bag_offs, nbags, slots, S, out_ids, (int32_t *)nullptr);
   return wd::check_launch("wd_hash_bucket");
+}
+
+extern "C" int wd_hash_bucket_cols(const uint8_t *bytes, const int32_t *tok_offs, int64_t nbags, const wd_slot_t *slots,
+                                   int32_t S, int32_t *out_ids, int32_t *out_ids_cols, wd_stream_t stream) {
+  if (nbags <= 0) return WD_OK;
+  WD_REQUIRE(bytes && tok_offs && slots && out_ids && out_ids_cols, "null pointer");
+  WD_REQUIRE(S > 0 && nbags % S == 0, "nbags must be batch * S");
+  hipLaunchKernelGGL(k_hash_bucket, dim3((unsigned)wd::ceil_div(nbags, 256)), dim3(256), 0, wd::as_stream(stream),
+                     bytes, tok_offs, nbags, (const int32_t *)nullptr, nbags, slots, S, out_ids, out_ids_cols);
+  return wd::check_launch("wd_hash_bucket_cols");
 }
 
 extern "C" int wd_emit_hash_slot(const uint64_t *fp, const int32_t *feat_offs, int64_t batch, uint64_t num_buckets,

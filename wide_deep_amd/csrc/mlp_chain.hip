@@ -93,6 +93,10 @@ struct ChainArgs {
   unsigned long long *tile_stamps;   // wd_chain_opts_t.tile_stamps: [tile][2] realtime-clock stamps {start, x tile in LDS}
   wd_chain_input_t in;          // in.emb != NULL: the x tile is built here (input layer fused), wd_chain_opts_t.input
   float *loss_part;             // != NULL: this tile's loss is stored to loss_part[tile] (no atomic on loss_sum)
+  const float *wv;              // wd_chain_opts_t.wide_vals: per-occurrence wide weights [batch][wv_S] (x from HBM)
+  const float *wv_bias;
+  float *wv_out;
+  int32_t wv_S;
 };
 
 __device__ __forceinline__ float act_fwd(float v, int act) {
@@ -359,6 +363,14 @@ __global__ void __launch_bounds__(256, RT_ == 16 ? 2 : 1) k_tower_chain(ChainArg
   float h_wide = 0.f, h_y = 0.f, h_w = 1.0f, h_bias = 0.f;
   if (t < RT && b0 + t < g.batch) {
     if (g.wide_logit) h_wide = g.wide_logit[b0 + t];
+    if (g.wv) {      // wide logit = sum of the prefetched weights of the example's bags, slots in order, + bias (fixed order)
+      const float *wp = g.wv + (b0 + t) * g.wv_S;
+      float acc = 0.f;
+      for (int sidx = 0; sidx < g.wv_S; ++sidx) acc += wp[sidx];
+      acc += g.wv_bias[0];
+      h_wide = acc;
+      if (g.wv_out) g.wv_out[b0 + t] = acc;
+    }
     if (g.labels) h_y = g.labels[b0 + t];
     if (g.weights) h_w = g.weights[b0 + t];
   }
@@ -902,6 +914,10 @@ extern "C" int wd_tower_chain(const float *x, int64_t ld_act, int32_t K0, const 
     g.tile_stamps = static_cast<unsigned long long *>(opts->tile_stamps);
     g.prio_split = opts->flags & 1 ? 0 : 1;
     g.loss_part = opts->loss_part;
+    if (opts->wide_vals) {
+      WD_REQUIRE(!opts->input && opts->wide_bias && opts->wide_S > 0, "wide_vals: needs wide_bias, wide_S > 0 and no fused input");
+      g.wv = opts->wide_vals; g.wv_bias = opts->wide_bias; g.wv_out = opts->wide_out; g.wv_S = opts->wide_S;
+    }
     if (opts->input) {
       const int rc = check_chain_input(opts->input);
       if (rc != WD_OK) return rc;

@@ -1,0 +1,920 @@
+// wide_deep_amd/csrc/onehot_path.hip -- the sparse side of the Criteo-shaped step (ONE id per bag, row-record tables).
+//
+// Two kernels that take the input layer and the bucketing of the NEXT batch off the critical path of the train step
+// (python/lib/dnn.py:83-91 input_layer, python/lib/linear.py:29-36 linear_model, python/lib/joint.py:233-248 the sparse
+// apply ops whose duplicate-summing this bucketing prepares):
+//
+//   k_bucket_onehot    occurrence (b, s) -> row-range bucket of slot s, in ONE launch.  With exactly one id per bag every
+//                      slot owns B occurrences, so slot s' region of `pairs` is [s*B, (s+1)*B) -- a static offset -- and a
+//                      workgroup (slot s, chunk r) needs nothing from other slots: it histograms the whole id column of its
+//                      slot in LDS (which gives the bucket starts AND what the chunks in front of it put into every bucket),
+//                      then scatters its own chunk.  (wd_sparse_bucketize -- three launches around a [chunks][buckets] count
+//                      matrix -- took 22 + 30 + 31 us for the same 3.4 MB; it stays for ragged batches.)  The last
+//                      workgroup to finish lists the buckets largest-first for k_bucket_update's launch order.
+//   k_prefetch_onehot  x[b, out_col_s ..] = rec[row].emb, wv[b*S + s] = rec[row].w (the wide weight sits in the line fetched
+//                      for the row), numeric columns normalised into x -- the input layer of a batch as its own launch at
+//                      full occupancy.  pipeline.StepGraph runs it for batch t+1 beside the tower of batch t; the rows that
+//                      the update of batch t rewrites afterwards are patched by that update (k_bucket_update, `next`), so
+//                      the tower of batch t+1 reads exactly what a gather after the update would have read.
+#include "common.h"
+
+namespace {
+
+constexpr int MAX_NB = 8192;          // buckets (wd_bucket_max)
+constexpr int ONEHOT_CHUNKS = 4;      // workgroups per slot
+
+// counter[cls] += (lanes of the wavefront with this cls), one LDS atomic per distinct class and wavefront; returns the lane's
+// position (old value + rank among its peers) or -1.  (3328 same-address LDS atomics -- the bucket sizes of a uniform batch all
+// fall into two classes -- serialise: 28 us of the 33 this kernel first took.)
+__device__ __forceinline__ int wave_class_add(int32_t *counter, int cls, bool valid) {
+  const int lane = threadIdx.x & 63;
+  unsigned long long todo = __ballot(valid);
+  int pos = -1;
+  while (todo) {
+    const int leader = __ffsll((long long)todo) - 1;
+    const int c = __shfl(cls, leader, 64);
+    const unsigned long long peers = __ballot(valid && cls == c);
+    int base = 0;
+    if (lane == leader) base = atomicAdd(&counter[c], __popcll(peers));
+    base = __shfl(base, leader, 64);
+    if (valid && cls == c) pos = base + __popcll(peers & ((1ull << lane) - 1ull));
+    todo &= ~peers;
+  }
+  return pos;
+}
+
+// slot s, chunk r = blockIdx.x % CH: examples [r * per, (r+1) * per)
+__global__ void __launch_bounds__(512)
+k_bucket_onehot(const wd_slot_t *__restrict__ slots, int32_t S, const int32_t *__restrict__ ids, int64_t sb, int64_t ss,
+                int64_t B, int32_t nb, int32_t *__restrict__ start, uint64_t *__restrict__ pairs,
+                int32_t *__restrict__ ticket, int32_t *__restrict__ zero_word) {
+  extern __shared__ int32_t lds_i[];
+  __shared__ int32_t wsum[8];
+  __shared__ int32_t is_last;
+  const int t = threadIdx.x;
+  const int s = blockIdx.x / ONEHOT_CHUNKS, r = blockIdx.x % ONEHOT_CHUNKS;
+  if (zero_word && blockIdx.x == 0 && t < 2) zero_word[t] = 0;     // the two counters of wd_bucket_sort (next launch)
+  const wd_slot_t sl = slots[s];
+  const int32_t nbk = (s + 1 < S ? slots[s + 1].bucket_base : nb) - sl.bucket_base;   // buckets of this slot
+  int32_t *total = lds_i, *base = lds_i + nbk;     // counts of the whole column / of the chunks in front of this one
+  for (int i = t; i < 2 * nbk; i += 512) lds_i[i] = 0;
+  __syncthreads();
+  const int64_t per = (B + ONEHOT_CHUNKS - 1) / ONEHOT_CHUNKS;
+  const int64_t c0 = (int64_t)r * per, c1 = c0 + per < B ? c0 + per : B;
+  // pass 1: the whole id column of the slot (stride S: 852 KB in all, L2-resident, read by the 4 chunks of the slot)
+  constexpr int U = 8;
+  for (int64_t b0 = t; b0 < B; b0 += 512 * U) {
+    int32_t id[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t b = b0 + 512 * u;
+      id[u] = b < B ? ids[b * sb + s * ss] : -1;       // (sb, ss) = (S, 1) example-major, (1, B) slot-major
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t b = b0 + 512 * u;
+      if (id[u] < 0) continue;
+      const int32_t bk = id[u] >> sl.bucket_shift;
+      atomicAdd(&total[bk], 1);
+      if (b < c0) atomicAdd(&base[bk], 1);
+    }
+  }
+  __syncthreads();
+  // exclusive scan of total[0..nbk): thread t owns E consecutive counters
+  const int E = (nbk + 511) / 512;
+  int32_t local = 0;
+  for (int e = 0; e < E; ++e) {
+    const int i = t * E + e;
+    if (i < nbk) local += total[i];
+  }
+  int32_t incl = local;
+  for (int off = 1; off < 64; off <<= 1) {
+    const int32_t v = __shfl_up(incl, off, 64);
+    if ((t & 63) >= off) incl += v;
+  }
+  if ((t & 63) == 63) wsum[t >> 6] = incl;
+  __syncthreads();
+  int32_t run = (int32_t)((int64_t)s * B) + incl - local;
+  for (int w = 0; w < (t >> 6); ++w) run += wsum[w];
+  for (int e = 0; e < E; ++e) {
+    const int i = t * E + e;
+    if (i < nbk) {
+      const int32_t c = total[i];
+      // (device-scope store: the last workgroup reads it in THIS launch; a __threadfence() instead writes back the whole L2
+      // of the XCD -- tens of MB of dirty rows / activations of the step -- and cost 20 of this kernel's 33 us)
+      if (r == 0) __hip_atomic_store(&start[sl.bucket_base + i], run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      base[i] += run;          // first position of THIS chunk's occurrences in bucket i
+      run += c;
+    }
+  }
+  if (r == 0 && s == S - 1 && t == 511)
+    __hip_atomic_store(&start[nb], (int32_t)((int64_t)S * B), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  // pass 2: scatter the chunk (arrival order inside a bucket is arbitrary: k_bucket_update sorts every bucket on (row, bag))
+  for (int64_t b0 = c0 + t; b0 < c1; b0 += 512 * U) {
+    int32_t id[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t b = b0 + 512 * u;
+      id[u] = b < c1 ? ids[b * sb + s * ss] : -1;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t b = b0 + 512 * u;
+      if (id[u] < 0) continue;
+      const int32_t p = atomicAdd(&base[id[u] >> sl.bucket_shift], 1);
+      pairs[p] = ((uint64_t)(uint32_t)(sl.row_base + id[u]) << 32) | (uint32_t)(b * S + s);
+    }
+  }
+  if (!ticket) return;     // no launch order wanted (wd_row_update walks the sorted pairs, not the buckets)
+  // ---- the last workgroup to get here lists the buckets largest-first (start[nb + 2 ..]: launch order of k_bucket_update; a
+  // bucket holding a Zipf head row takes several times longer than the rest and must not start last).  Binned by
+  // floor(log2(size)); the order inside a bin is whatever the LDS atomics give -- it only schedules workgroups.
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");     // this wavefront's stores are complete (no cache write-back)
+  __syncthreads();
+  if (t == 0) {
+    const int32_t n = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    is_last = n == (int32_t)gridDim.x - 1;
+    if (is_last) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // ready for the next launch
+  }
+  __syncthreads();
+  if (!is_last) return;
+  __shared__ int32_t cls_cnt[33], cls_pos[33];
+  if (t < 33) cls_cnt[t] = 0;
+  __syncthreads();
+  // bucket sizes from the starts the other workgroups wrote: device-scope loads (past this CU's L1), all in flight at once
+  constexpr int PER = MAX_NB / 512;
+  int32_t cl[PER];
+#pragma unroll
+  for (int q = 0; q < PER; ++q) {
+    const int i = t + 512 * q;
+    cl[q] = -1;
+    if (i < nb) {
+      const int32_t c = __hip_atomic_load(&start[i + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) -
+                        __hip_atomic_load(&start[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      cl[q] = c > 0 ? 32 - __builtin_clz((unsigned)c) : 0;
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < PER; ++q) wave_class_add(cls_cnt, cl[q], cl[q] >= 0);
+  __syncthreads();
+  if (t == 0) {
+    int32_t run2 = 0;
+    for (int c = 32; c >= 0; --c) {
+      cls_pos[c] = run2;
+      run2 += cls_cnt[c];
+    }
+  }
+  __syncthreads();
+  int32_t *order = start + nb + 2;
+#pragma unroll
+  for (int q = 0; q < PER; ++q) {
+    const int p = wave_class_add(cls_pos, cl[q], cl[q] >= 0);
+    if (p >= 0) order[p] = t + 512 * q;
+  }
+}
+
+// LANES = dim / 4 lanes per bag, BPG bags per lane group in flight (independent id -> record chains)
+template <int LANES, int BPG>
+__global__ void __launch_bounds__(256)
+k_prefetch_onehot(const float *__restrict__ rec, int32_t rec_stride, const wd_slot_t *__restrict__ rslots, int32_t S,
+                  const int32_t *__restrict__ ids, int64_t B, float *__restrict__ x, int64_t ldx, float *__restrict__ wv,
+                  const float *__restrict__ dense, int64_t ld_dense, const wd_dense_col_t *__restrict__ cols,
+                  int32_t ncols, int32_t gather_blocks, unsigned long long *__restrict__ span) {
+  constexpr int MAXS = 128;
+  __shared__ int64_t s_off[MAXS];
+  __shared__ int32_t s_col[MAXS];
+  const int t = threadIdx.x;
+  // diagnostics (bench.py: the duration of this launch AS IT RUNS INSIDE the pipelined step): chip-wide realtime clock
+  // (100 MHz) at the start of the first and the end of the last workgroup
+  if (span && t == 0) atomicMin(&span[0], (unsigned long long)wall_clock64());
+  if ((int)blockIdx.x >= gather_blocks) {
+    // numeric columns (python/lib/build_estimator.py:61-68 normalizers): one thread per (example, column)
+    const int64_t i = ((int64_t)blockIdx.x - gather_blocks) * 256 + t;
+    if (i >= B * ncols) return;
+    const int64_t b = i / ncols;
+    const int j = (int)(i - b * ncols);
+    const wd_dense_col_t c = cols[j];
+    float v = dense[b * ld_dense + j];
+    if (c.kind == 1) v = (v - c.p0) / (c.p1 - c.p0);
+    else if (c.kind == 2) v = (v - c.p0) / c.p1;
+    else if (c.kind == 3) v = logf(v);
+    x[b * ldx + c.out_col] = v;
+    return;
+  }
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  const int lane = t % LANES;
+  const int64_t grp = ((int64_t)blockIdx.x * 256 + t) / LANES;
+  const int64_t nwork = B * S;
+  int64_t w[BPG];
+  int32_t id[BPG], sidx[BPG];
+#pragma unroll
+  for (int q = 0; q < BPG; ++q) {
+    w[q] = grp * BPG + q;
+    const int64_t wc = w[q] < nwork ? w[q] : nwork - 1;
+    id[q] = ids[wc];
+    sidx[q] = (int32_t)(wc % S);
+  }
+  for (int i = t; i < S; i += 256) {       // slot descriptors -> LDS while the ids are in flight
+    s_off[i] = rslots[i].emb_off;
+    s_col[i] = rslots[i].out_col;
+  }
+  __syncthreads();
+  f4 r[BPG];
+  float wq[BPG];
+#pragma unroll
+  for (int q = 0; q < BPG; ++q) {
+    r[q] = (f4)(0.f);
+    wq[q] = 0.f;
+    if (id[q] >= 0) {
+      const float *p = rec + s_off[sidx[q]] + (int64_t)id[q] * rec_stride;
+      r[q] = __builtin_nontemporal_load(reinterpret_cast<const f4 *>(p) + lane);
+      if (lane == 0) wq[q] = __builtin_nontemporal_load(p + 4 * LANES);     // {w, z, n, -} behind the row, same line
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < BPG; ++q) {
+    if (w[q] >= nwork) continue;
+    const int64_t b = w[q] / S;
+    *reinterpret_cast<f4 *>(x + b * ldx + s_col[sidx[q]] + 4 * lane) = r[q];
+    if (lane == 0) wv[w[q]] = wq[q];
+  }
+  if (span) {
+    __syncthreads();       // (every lane's stores are issued; the stamp is a lower bound on their completion by one store latency)
+    if (t == 0) atomicMax(&span[1], (unsigned long long)wall_clock64());
+  }
+}
+
+
+// ======================================================================================================================
+// Sorted row lists: everything of the sparse update that needs only the IDS -- bucketing, the sort of every bucket on
+// (row, bag), the detection of heavily repeated rows, and which rows of the previous batch this batch reads too -- runs
+// beside the tower of the previous step (pipeline.StepGraph); what is left between two towers is k_row_update, a flat
+// gather / read-modify-write over the sorted pairs with two dependent memory round trips.
+//
+//   k_bucket_sort   one workgroup per bucket: pairs sorted in place (rank sort up to 512 pairs, bitonic up to 1024 in LDS,
+//                   larger buckets in place in HBM/L2); segments of more than LONG_SEG occurrences are listed for the
+//                   cooperative reduction; and -- `prev` -- for every pair of the PREVIOUS batch in the same row range:
+//                   patch[i] = position of that row's first pair in THIS batch's sorted list, or -1.
+//   k_row_update    4 lanes per sorted position: a position that starts a row (its predecessor holds another key) sums the
+//                   row's gradient over its occurrences in ascending bag order and applies Adagrad (row) / FTRL ({w, z, n});
+//                   then stores the new row into the next batch's prefetched x tile wherever patch[] says that batch reads
+//                   it.  Listed long segments: one workgroup each, 64 lane groups + a fixed-shape tree; the last workgroup
+//                   does bias_weights.  The arithmetic is k_bucket_update's, operation for operation (bit-identical rows).
+constexpr int ROW_LONG_SEG = 32;
+constexpr int LONG_WORKERS = 256;
+
+__device__ __forceinline__ uint32_t key_of(uint64_t p) { return (uint32_t)(p >> 32); }
+
+template <typename PtrT, int NT>
+__device__ __forceinline__ void bitonic_sort_nt(PtrT p, int m) {     // all comparators ascending (virtual +inf padding never moves)
+  int lgP = 0;
+  while ((1 << lgP) < m) ++lgP;
+  const int half = (1 << lgP) >> 1;
+  for (int lk = 1; lk <= lgP; ++lk) {
+    const int k = 1 << lk, kh = k >> 1;
+    for (int tq = threadIdx.x; tq < half; tq += NT) {
+      const int blk = tq >> (lk - 1), off = tq & (kh - 1);
+      const int i1 = (blk << lk) + off, i2 = (blk << lk) + k - 1 - off;
+      if (i2 < m) {
+        const uint64_t a = p[i1], b = p[i2];
+        if (a > b) { p[i1] = b; p[i2] = a; }
+      }
+    }
+    __syncthreads();
+    for (int lj = lk - 2; lj >= 0; --lj) {
+      const int j = 1 << lj;
+      for (int tq = threadIdx.x; tq < half; tq += NT) {
+        const int i1 = ((tq >> lj) << (lj + 1)) | (tq & (j - 1)), i2 = i1 + j;
+        if (i2 < m) {
+          const uint64_t a = p[i1], b = p[i2];
+          if (a > b) { p[i1] = b; p[i2] = a; }
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// rank[q] of the lane's q-th element (index t + NT q) among arr[0 .. m): number of smaller elements (all distinct).  NQ = elements
+// per lane that exist -- a compile-time bound, so that a 300-pair bucket in a 1024-pair workgroup pays for two, not four.
+template <typename T, int NQ, int NT>
+__device__ __forceinline__ void rank_loop(const T *arr, int m, int t, int *r) {
+  T x[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    x[q] = t + NT * q < m ? arr[t + NT * q] : (T)~(T)0;
+    r[q] = 0;
+  }
+  for (int j = 0; j < m; ++j) {
+    const T y = arr[j];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) r[q] += y < x[q] ? 1 : 0;
+  }
+}
+
+template <typename T, int MAXQ, int NT>
+__device__ __forceinline__ void rank_dispatch(const T *arr, int m, int nq, int t, int *r) {
+#pragma unroll
+  for (int q = 0; q < MAXQ; ++q) r[q] = 0;
+  if (MAXQ >= 4 && nq > 2) {
+    if (nq == 3) rank_loop<T, (MAXQ >= 3 ? 3 : 1), NT>(arr, m, t, r);
+    else rank_loop<T, (MAXQ >= 4 ? 4 : 1), NT>(arr, m, t, r);
+  } else if (MAXQ >= 2 && nq == 2) {
+    rank_loop<T, (MAXQ >= 2 ? 2 : 1), NT>(arr, m, t, r);
+  } else {
+    rank_loop<T, 1, NT>(arr, m, t, r);
+  }
+}
+
+struct SortArgs {
+  const int32_t *start;
+  uint64_t *pairs;
+  int32_t *long_list;        // [0] long-segment count, [1] big-bucket count, [2 + 2k], [3 + 2k] = (position, length)
+  int32_t *big_list;         // buckets with more than SMALL_CAP pairs: left to the second launch
+  const int32_t *pstart;
+  const uint64_t *ppairs;
+  int2 *ppatch;
+  int32_t long_cap, bag_bits, nb, S;
+  int64_t batch;
+};
+
+// One bucket, CAP pairs rank-sorted in LDS (2 x CAP x 8 bytes).  false: the bucket is larger (SMALL launch: the caller lists it).
+template <int CAP, bool SMALL, int NT>
+__device__ __forceinline__ bool sort_bucket(const SortArgs &g, int bkt, uint64_t *lds_pairs, uint64_t *lds_in, uint32_t *s_kmin,
+                                            uint32_t *s_kmax, int32_t *s_dom) {
+  const int32_t *__restrict__ start = g.start;
+  uint64_t *__restrict__ pairs = g.pairs;
+  int32_t *__restrict__ long_list = g.long_list;
+  const int32_t *__restrict__ pstart = g.pstart;
+  const uint64_t *__restrict__ ppairs = g.ppairs;
+  int2 *__restrict__ ppatch = g.ppatch;
+  const int32_t long_cap = g.long_cap, bag_bits = g.bag_bits;
+  constexpr int SORT_CAP = CAP;
+  const int t = threadIdx.x;
+  const int32_t s0 = start[bkt];
+  const int m = start[bkt + 1] - s0;
+  if (SMALL && m > CAP) return false;
+  int32_t a0 = 0, mA = 0;
+  if (ppatch) {
+    a0 = pstart[bkt];
+    mA = pstart[bkt + 1] - a0;
+  }
+  uint64_t a_cur = 0, a_prev = ~0ull;
+  if (t < mA) {       // the previous batch's (sorted) pairs of this row range: in flight during the sort
+    a_cur = ppairs[a0 + t];
+    if (t > 0) a_prev = ppairs[a0 + t - 1];
+  }
+  const uint64_t *sp = lds_pairs;
+  if (m <= 0) {
+  } else if (m <= SORT_CAP) {
+    // rank sort: position of element i = number of elements ordered before it; every lane reads the same LDS word per step
+    // (broadcast, conflict-free), no barriers inside.  O(m^2 / 256) per lane; the 900-pair bucket of a Zipf head row is what
+    // bounds the launch, so the pairs of a bucket are first packed into 32 bits -- (row - first row of the bucket) above the
+    // bag index -- whenever they fit (a 64-bit compare costs four times a 32-bit one); 64-bit pairs otherwise.
+    uint32_t kmin = 0xffffffffu, kmax = 0;
+    for (int i = t; i < m; i += NT) {
+      const uint64_t p = pairs[s0 + i];
+      lds_in[i] = p;
+      kmin = min(kmin, key_of(p));
+      kmax = max(kmax, key_of(p));
+    }
+    for (int off = 32; off >= 1; off >>= 1) {
+      kmin = min(kmin, (uint32_t)__shfl_xor((int)kmin, off, 64));
+      kmax = max(kmax, (uint32_t)__shfl_xor((int)kmax, off, 64));
+    }
+    if ((t & 63) == 0) { s_kmin[t >> 6] = kmin; s_kmax[t >> 6] = kmax; }
+    __syncthreads();
+    kmin = s_kmin[0]; kmax = s_kmax[0];
+    for (int w = 1; w < NT / 64; ++w) { kmin = min(kmin, s_kmin[w]); kmax = max(kmax, s_kmax[w]); }
+    int r[SORT_CAP / NT];
+    bool ranked = false;
+    if (!SMALL && SORT_CAP >= 1024 && NT == 256 && g.batch <= 16384) {
+      // ---- a bucket dominated by ONE row K (a Zipf head row: ~780 of ~900 pairs): O(m) instead of O(m^2).  The pairs of a row
+      // are distinct EXAMPLES (one id per bag), so their order by bag is a rank in a bitmap over the examples:
+      // rank = (pairs of smaller rows) + popcount(bits below example b); the few other pairs rank among themselves.
+      uint32_t *bits = reinterpret_cast<uint32_t *>(lds_pairs);       // [512] words: 16384 examples
+      uint32_t *wpre = bits + 512;                                    // [512] pairs of K in the words before
+      uint64_t *others = lds_pairs + 512;                             // [512] pairs of other rows
+      const int lane = t & 63;
+      const uint32_t K = key_of(lds_in[m >> 1]);
+      const int nw = (int)((g.batch + 31) >> 5);
+      if (t < 3) s_dom[t] = 0;
+      for (int i = t; i < 2 * 512; i += NT) bits[i] = 0;             // (bits and wpre)
+      __syncthreads();
+      uint64_t x[SORT_CAP / NT];
+      int cK = 0, cLt = 0;
+#pragma unroll
+      for (int q = 0; q < SORT_CAP / NT; ++q) {
+        const bool v = t + NT * q < m;
+        x[q] = v ? lds_in[t + NT * q] : ~0ull;
+        cK += __popcll(__ballot(v && key_of(x[q]) == K));
+        cLt += __popcll(__ballot(v && key_of(x[q]) < K));
+      }
+      if (lane == 0) { atomicAdd(&s_dom[0], cK); atomicAdd(&s_dom[1], cLt); }
+      __syncthreads();
+      const int c = s_dom[0], nlt = s_dom[1];
+      if (2 * c >= m && m - c <= 512) {
+#pragma unroll
+        for (int q = 0; q < SORT_CAP / NT; ++q) {
+          if (t + NT * q >= m) continue;
+          if (key_of(x[q]) == K) {
+            const uint32_t b = (uint32_t)x[q] / (uint32_t)g.S;
+            atomicOr(&bits[b >> 5], 1u << (b & 31));
+          } else {
+            others[atomicAdd(&s_dom[2], 1)] = x[q];
+          }
+        }
+        __syncthreads();
+        {   // exclusive prefix of the words' popcounts: two words per lane
+          const int w0 = 2 * t;
+          const int v0 = w0 < nw ? __popc(bits[w0]) : 0, v1 = w0 + 1 < nw ? __popc(bits[w0 + 1]) : 0;
+          int incl = v0 + v1;
+          for (int off = 1; off < 64; off <<= 1) {
+            const int u = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += u;
+          }
+          if (lane == 63) s_dom[4 + (t >> 6)] = incl;
+          __syncthreads();
+          int base = incl - (v0 + v1);
+          for (int w = 0; w < (t >> 6); ++w) base += s_dom[4 + w];
+          wpre[w0] = base;
+          wpre[w0 + 1] = base + v0;
+        }
+        __syncthreads();
+        const int no = m - c;
+#pragma unroll
+        for (int q = 0; q < SORT_CAP / NT; ++q) {
+          r[q] = 0;
+          if (t + NT * q >= m) continue;
+          const uint32_t kx = key_of(x[q]);
+          if (kx == K) {
+            const uint32_t b = (uint32_t)x[q] / (uint32_t)g.S;
+            r[q] = nlt + (int)wpre[b >> 5] + __popc(bits[b >> 5] & ((1u << (b & 31)) - 1u));
+          } else {
+            int rr = kx > K ? c : 0;
+            for (int j = 0; j < no; ++j) rr += others[j] < x[q] ? 1 : 0;
+            r[q] = rr;
+          }
+        }
+        ranked = true;
+      }
+      __syncthreads();      // (the scratch in lds_pairs is dead from here on)
+    }
+    const int nq = (m + NT - 1) / NT;          // elements per lane that exist: the compare loop is instantiated for 1 .. CAP / NT
+    if (ranked) {
+    } else if (bag_bits < 32 && (uint64_t)(kmax - kmin) < (1ull << (32 - bag_bits))) {
+      uint32_t *ck = reinterpret_cast<uint32_t *>(lds_pairs);       // (the sorted pairs are written behind the barrier below)
+      for (int i = t; i < m; i += NT) {
+        const uint64_t p = lds_in[i];
+        ck[i] = ((key_of(p) - kmin) << bag_bits) | (uint32_t)p;
+      }
+      __syncthreads();
+      rank_dispatch<uint32_t, SORT_CAP / NT, NT>(ck, m, nq, t, r);
+    } else {
+      rank_dispatch<uint64_t, SORT_CAP / NT, NT>(lds_in, m, nq, t, r);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < SORT_CAP / NT; ++q)
+      if (t + NT * q < m) {
+        const uint64_t p = lds_in[t + NT * q];
+        lds_pairs[r[q]] = p;
+        pairs[s0 + r[q]] = p;
+      }
+    __syncthreads();
+  } else {
+    bitonic_sort_nt<uint64_t *, NT>(pairs + s0, m);      // (more than CAP pairs in one row range: in place in HBM / L2)
+    sp = pairs + s0;
+  }
+  // rows repeated more than ROW_LONG_SEG times: (position, length) -> long_list[1 + 2k ..]; long_list[0] counts (zeroed by
+  // wd_bucket_onehot).  Arrival order of the entries is free: every segment is reduced on its own.
+  for (int i = t; i < m; i += NT) {
+    const uint32_t key = key_of(sp[i]);
+    if (i > 0 && key_of(sp[i - 1]) == key) continue;
+    if (i + ROW_LONG_SEG >= m || key_of(sp[i + ROW_LONG_SEG]) != key) continue;
+    int lo = i + ROW_LONG_SEG, hi = m;       // upper bound of the key
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (key_of(sp[mid]) == key) lo = mid + 1; else hi = mid;
+    }
+    const int32_t q = atomicAdd(&long_list[0], 1);
+    if (q < long_cap) {       // (cannot overflow when long_list[0] was zeroed: at most nnz / 33 such rows)
+      long_list[2 + 2 * q] = s0 + i;
+      long_list[3 + 2 * q] = lo - i;
+    }
+  }
+  // the previous batch's rows that this batch reads too: (position of the row's first pair here, number of its pairs)
+  for (int i = t; i < mA; i += NT) {
+    const uint64_t a = i == t ? a_cur : ppairs[a0 + i];
+    const uint64_t ap = i == t ? a_prev : ppairs[a0 + i - 1];
+    int2 res = make_int2(-1, 0);
+    const uint32_t key = key_of(a);
+    if ((i == 0 || key_of(ap) != key) && m > 0) {
+      int lo = 0, hi = m;
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (key_of(sp[mid]) < key) lo = mid + 1; else hi = mid;
+      }
+      if (lo < m && key_of(sp[lo]) == key) {
+        int l2 = lo + 1, h2 = m;
+        while (l2 < h2) {
+          const int mid = (l2 + h2) >> 1;
+          if (key_of(sp[mid]) == key) l2 = mid + 1; else h2 = mid;
+        }
+        res = make_int2(s0 + lo, l2 - lo);
+      }
+    }
+    ppatch[a0 + i] = res;
+  }
+  return true;
+}
+
+constexpr int SMALL_CAP = 256;       // 4 KB of LDS: seven workgroups per CU beside the one-launch tower
+constexpr int BIG_CAP = 1024;        // 16 KB
+constexpr int BIG_WORKERS = 256;
+
+// first launch: one workgroup per bucket; buckets of more than SMALL_CAP pairs (Zipf head rows, "missing value" tokens) are
+// listed for the second launch, whose workgroups carry the LDS a 1024-pair rank sort needs -- with it in every workgroup, one
+// workgroup per CU fits beside the tower and the launch took 62 us for a uniform batch instead of 10.
+__global__ void __launch_bounds__(256) k_bucket_sort_small(SortArgs g) {
+  __shared__ uint64_t lds_pairs[SMALL_CAP];
+  __shared__ uint64_t lds_in[SMALL_CAP];
+  __shared__ uint32_t s_kmin[4], s_kmax[4];
+  const int bkt = blockIdx.x;
+  if (!sort_bucket<SMALL_CAP, true, 256>(g, bkt, lds_pairs, lds_in, s_kmin, s_kmax, nullptr) && threadIdx.x == 0)
+    g.big_list[atomicAdd(&g.long_list[1], 1)] = bkt;
+}
+
+// (256 lanes: a 1024-lane workgroup does not fit beside the tower's wavefronts and waited for them -- 55 us for nothing)
+__global__ void __launch_bounds__(256) k_bucket_sort_big(SortArgs g) {
+  __shared__ uint64_t lds_pairs[BIG_CAP];
+  __shared__ uint64_t lds_in[BIG_CAP];
+  __shared__ uint32_t s_kmin[4], s_kmax[4];
+  __shared__ int32_t s_dom[8];
+  const int nbig = g.long_list[1];
+  for (int q = blockIdx.x; q < nbig; q += BIG_WORKERS) {
+    sort_bucket<BIG_CAP, false, 256>(g, g.big_list[q], lds_pairs, lds_in, s_kmin, s_kmax, s_dom);
+    __syncthreads();
+  }
+}
+
+
+struct RowUpd {
+  float *rec, *accum, *bias;
+  const wd_slot_t *slots;
+  const float *dx, *dlogit;
+  const uint64_t *pairs;
+  const int32_t *long_list;
+  const int2 *patch;          // [nnz] (position, count) in the next batch's sorted pairs, or NULL
+  const uint64_t *npairs;     // the next batch's sorted pairs
+  float *nx, *nwv;
+  int64_t ldx, nldx, nnz, batch;
+  int32_t rec_stride, dim, S, flat_blocks, long_cap;
+  float lr_emb, lr_w, l1, l2;
+};
+
+__device__ __forceinline__ void ftrl_row(float &w, float &z, float &n, float g, float lr, float l1, float l2) {
+  const float n_new = n + g * g;
+  z += g - (sqrtf(n_new) - sqrtf(n)) / lr * w;
+  const float quad = sqrtf(n_new) / lr + 2.0f * l2;
+  const float sgn = z > 0.f ? 1.f : (z < 0.f ? -1.f : 0.f);
+  const float pre = (sgn * l1 - z) / quad;
+  w = fabsf(z) > l1 ? pre : 0.f;
+  n = n_new;
+}
+
+__device__ __forceinline__ float4 adagrad_row4(float4 &a, float4 w, float4 g, float lr) {
+  a.x += g.x * g.x; a.y += g.y * g.y; a.z += g.z * g.z; a.w += g.w * g.w;
+  w.x -= lr * g.x / sqrtf(a.x);
+  w.y -= lr * g.y / sqrtf(a.y);
+  w.z -= lr * g.z / sqrtf(a.z);
+  w.w -= lr * g.w / sqrtf(a.w);
+  return w;
+}
+
+__global__ void __launch_bounds__(256)
+k_row_update(RowUpd u) {
+  constexpr int MAXS = 128;
+  __shared__ int64_t s_acc_off[MAXS];     // accumulator offset of the slot's first row, minus row_base * dim
+  __shared__ int32_t s_col[MAXS];
+  __shared__ float4 red[256];
+  __shared__ float redw[256];
+  __shared__ int32_t seg_ex[256];
+  __shared__ float new_row[20];           // long segments: the row's new value (16 floats at most) + its wide weight
+  const int t = threadIdx.x;
+  const int S = u.S, D = u.dim, LG = D >> 2;
+  const int64_t RS = u.rec_stride;
+  // new value of a row -> the next batch's prefetched input, wherever that batch reads the row (its pairs from `pj` on: all
+  // occurrences of a row are adjacent in the sorted list).  `row` = the D new floats, `wnew` the new wide weight; the callers
+  // spread the run over `nl` lanes (lane `l` takes every nl-th pair): a hot row is read hundreds of times by the next batch.
+  auto patch_run = [&](int2 pj, int l, int nl, const float *row, float wnew, int32_t out_col) {
+    for (int k = l; k < pj.y; k += nl) {
+      const int32_t bag2 = (int32_t)(uint32_t)u.npairs[pj.x + k];
+      float *dst = u.nx + (int64_t)(bag2 / S) * u.nldx + out_col;
+      for (int c = 0; c < LG; ++c) *reinterpret_cast<float4 *>(dst + 4 * c) = make_float4(row[4 * c], row[4 * c + 1], row[4 * c + 2], row[4 * c + 3]);
+      u.nwv[bag2] = wnew;
+    }
+  };
+  if ((int)blockIdx.x == u.flat_blocks + LONG_WORKERS) {     // (grid: long-segment workers first, flat blocks, this one) bias_weights: g = sum_b dlogit[b] (fixed-shape tree), dense FTRL
+    if (!u.bias) return;
+    float acc = 0.f;
+    for (int64_t i = t; i < u.batch; i += 256) acc += u.dlogit[i];
+    redw[t] = acc;
+    __syncthreads();
+    for (int st = 128; st >= 1; st >>= 1) {
+      if (t < st) redw[t] += redw[t + st];
+      __syncthreads();
+    }
+    if (t == 0) {
+      float w = u.bias[0], z = u.bias[1], n = u.bias[2];
+      ftrl_row(w, z, n, redw[0], u.lr_w, u.l1, u.l2);
+      u.bias[0] = w; u.bias[1] = z; u.bias[2] = n;
+    }
+    return;
+  }
+  for (int i = t; i < S; i += 256) {
+    const wd_slot_t sl = u.slots[i];
+    s_acc_off[i] = sl.emb_off - sl.row_base * (int64_t)D;
+    s_col[i] = sl.out_col;
+  }
+  if ((int)blockIdx.x < LONG_WORKERS) {
+    // ---- long segments (the first workgroups of the grid: they take longest): the whole workgroup per row, 64 lane groups in parallel + fixed-shape tree (k_bucket_update's) -----
+    __syncthreads();
+    const int gidx = t >> 2, gl = t & 3;
+    const int nl = u.long_list[0] < u.long_cap ? u.long_list[0] : u.long_cap;
+    for (int q = nl - 1 - (int)blockIdx.x; q >= 0; q -= LONG_WORKERS) {    // from the END of the list: the large buckets' rows (the
+                                                                          // second launch of wd_bucket_sort), the longest, are listed last
+      const int64_t i = u.long_list[2 + 2 * q], e = i + u.long_list[3 + 2 * q];
+      const uint64_t p0 = u.pairs[i];
+      const uint32_t key = key_of(p0);
+      const int32_t sidx = (int32_t)(uint32_t)p0 % S;
+      const int32_t out_col = s_col[sidx];
+      const int2 pj = u.patch ? u.patch[i] : make_int2(-1, 0);
+      const int64_t off = s_acc_off[sidx] + (int64_t)key * D;
+      const int64_t eoff = (int64_t)key * RS;
+      const int c = gl;
+      float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int64_t j0 = i; j0 < e; j0 += 256) {
+        const int n = e - j0 < 256 ? (int)(e - j0) : 256;
+        if (t < n) seg_ex[t] = (int32_t)(uint32_t)u.pairs[j0 + t] / S;
+        __syncthreads();
+        if (c < LG) {
+          float4 d[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int idx = gidx + 64 * k;
+            d[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (idx < n) d[k] = *reinterpret_cast<const float4 *>(u.dx + (int64_t)seg_ex[idx] * u.ldx + out_col + 4 * c);
+          }
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int idx = gidx + 64 * k;
+            if (idx < n) {
+              const float scale = 1.0f;
+              g.x += d[k].x * scale; g.y += d[k].y * scale; g.z += d[k].z * scale; g.w += d[k].w * scale;
+            }
+          }
+        }
+        __syncthreads();
+      }
+      red[t] = g;
+      __syncthreads();
+      for (int st = 32; st >= 1; st >>= 1) {
+        if (gidx < st) {
+          float4 a = red[t], b = red[t + 4 * st];
+          a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+          red[t] = a;
+        }
+        __syncthreads();
+      }
+      if (gidx == 0 && c < LG) {
+        g = red[t];
+        const float gg[4] = {g.x, g.y, g.z, g.w};
+        for (int k2 = 0; k2 < 4; ++k2) {
+          const int64_t o = off + 4 * c + k2;
+          const float a = u.accum[o] + gg[k2] * gg[k2];
+          u.accum[o] = a;
+          float wn = u.rec[eoff + 4 * c + k2];
+          wn -= u.lr_emb * gg[k2] / sqrtf(a);
+          u.rec[eoff + 4 * c + k2] = wn;
+          new_row[4 * c + k2] = wn;
+        }
+      }
+      __syncthreads();
+      float gw = 0.f;
+      for (int64_t j = i + t; j < e; j += 1024) {   // four independent (pair -> dlogit) chains per lane and round
+        float v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int64_t jj = j + 256 * k;
+          v[k] = jj < e ? u.dlogit[(int32_t)(uint32_t)u.pairs[jj] / S] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) gw += v[k];
+      }
+      redw[t] = gw;
+      __syncthreads();
+      for (int st = 128; st >= 1; st >>= 1) {
+        if (t < st) redw[t] += redw[t + st];
+        __syncthreads();
+      }
+      if (t == 0) {
+        float4 r = *reinterpret_cast<float4 *>(u.rec + eoff + D);
+        ftrl_row(r.x, r.y, r.z, redw[0], u.lr_w, u.l1, u.l2);
+        *reinterpret_cast<float4 *>(u.rec + eoff + D) = r;
+        new_row[16] = r.x;
+      }
+      __syncthreads();
+      if (pj.y > 0) patch_run(pj, t, 256, new_row, new_row[16], out_col);      // the whole workgroup over the run
+      __syncthreads();
+    }
+    return;
+  }
+  // ---- flat part: 4 lanes per sorted position ------------------------------------------------------------------------
+  const int gl = t & 3;
+  const int64_t i = (((int64_t)blockIdx.x - LONG_WORKERS) * 256 + t) >> 2;
+  uint64_t pr = 0, prv = ~0ull, nxt = ~0ull, far = ~0ull;
+  int2 pj = make_int2(-1, 0);
+  if (i < u.nnz) {
+    pr = u.pairs[i];
+    if (i > 0) prv = u.pairs[i - 1];
+    if (i + 1 < u.nnz) nxt = u.pairs[i + 1];
+    if (i + ROW_LONG_SEG < u.nnz) far = u.pairs[i + ROW_LONG_SEG];
+    if (u.patch) pj = u.patch[i];
+  }
+  __syncthreads();          // slot tables
+  if (i >= u.nnz) return;
+  const uint32_t key = key_of(pr);
+  if (key_of(prv) == key) return;            // not the first occurrence of its row
+  if (key_of(far) == key) return;            // more than ROW_LONG_SEG occurrences: listed by k_bucket_sort, reduced above
+  int64_t e = i + 1;
+  if (key_of(nxt) == key) {                  // (sorted: the row's pairs end inside (i + 1, i + ROW_LONG_SEG])
+    int64_t lo = i + 2, hi = i + ROW_LONG_SEG < u.nnz ? i + ROW_LONG_SEG : u.nnz;
+    while (lo < hi) {
+      const int64_t mid = (lo + hi) >> 1;
+      if (key_of(u.pairs[mid]) == key) lo = mid + 1; else hi = mid;
+    }
+    e = lo;
+  }
+  const int32_t bag0 = (int32_t)(uint32_t)pr;
+  const int32_t sidx = bag0 % S;
+  const int32_t out_col = s_col[sidx];
+  const bool lane_emb = gl < LG;
+  const int64_t off = s_acc_off[sidx] + (int64_t)key * D + 4 * gl;
+  const int64_t eoff = (int64_t)key * RS + 4 * gl;
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f), w = a, r = a;
+  if (lane_emb) {
+    a = *reinterpret_cast<float4 *>(u.accum + off);
+    w = *reinterpret_cast<float4 *>(u.rec + eoff);
+  }
+  if (gl == 0) r = *reinterpret_cast<float4 *>(u.rec + (int64_t)key * RS + D);
+  float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+  float gw = 0.f;
+  const float scale = 1.0f;                  // one id per bag: the mean of one
+  if (e - i == 1) {
+    const int64_t b = bag0 / S;
+    if (lane_emb) {
+      const float4 d = *reinterpret_cast<const float4 *>(u.dx + b * u.ldx + out_col + 4 * gl);
+      g.x += d.x * scale; g.y += d.y * scale; g.z += d.z * scale; g.w += d.w * scale;
+    }
+    if (gl == 0) gw += u.dlogit[b];
+  } else {
+    if (lane_emb) {
+      int64_t j = i;
+      for (; j + 4 <= e; j += 4) {             // four occurrences per round: loads together, adds in ascending bag order
+        int32_t bag[4];
+        float4 d[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) bag[k] = (int32_t)(uint32_t)u.pairs[j + k];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) d[k] = *reinterpret_cast<const float4 *>(u.dx + (int64_t)(bag[k] / S) * u.ldx + out_col + 4 * gl);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          g.x += d[k].x * scale; g.y += d[k].y * scale; g.z += d[k].z * scale; g.w += d[k].w * scale;
+        }
+      }
+      for (; j < e; ++j) {
+        const int32_t bag = (int32_t)(uint32_t)u.pairs[j];
+        const float4 d = *reinterpret_cast<const float4 *>(u.dx + (int64_t)(bag / S) * u.ldx + out_col + 4 * gl);
+        g.x += d.x * scale; g.y += d.y * scale; g.z += d.z * scale; g.w += d.w * scale;
+      }
+    }
+    if (gl == 0) {
+      int64_t j = i;
+      for (; j + 4 <= e; j += 4) {
+        float v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = u.dlogit[(int32_t)(uint32_t)u.pairs[j + k] / S];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) gw += v[k];
+      }
+      for (; j < e; ++j) gw += u.dlogit[(int32_t)(uint32_t)u.pairs[j] / S];
+    }
+  }
+  float4 wn = w;
+  if (lane_emb) {
+    wn = adagrad_row4(a, w, g, u.lr_emb);
+    *reinterpret_cast<float4 *>(u.accum + off) = a;
+    *reinterpret_cast<float4 *>(u.rec + eoff) = wn;
+  }
+  if (gl == 0) {
+    ftrl_row(r.x, r.y, r.z, gw, u.lr_w, u.l1, u.l2);
+    *reinterpret_cast<float4 *>(u.rec + (int64_t)key * RS + D) = r;
+  }
+  if (pj.y > 0) {     // every lane of the group gets the whole new row (shuffles) and takes every 4th pair of the run
+    float row[16];
+    const int l0 = (t & 63) & ~3;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      row[4 * c + 0] = __shfl(wn.x, l0 + c, 64); row[4 * c + 1] = __shfl(wn.y, l0 + c, 64);
+      row[4 * c + 2] = __shfl(wn.z, l0 + c, 64); row[4 * c + 3] = __shfl(wn.w, l0 + c, 64);
+    }
+    const float wnew = __shfl(r.x, l0, 64);
+    patch_run(pj, gl, 4, row, wnew, out_col);
+  }
+}
+
+}  // namespace
+
+extern "C" int wd_bucket_onehot(const wd_slot_t *slots, int32_t S, const int32_t *ids, int32_t ids_slot_major, int64_t batch,
+                                int32_t *bucket_start, uint64_t *pairs, int32_t nbuckets, int32_t max_slot_buckets,
+                                int32_t *ticket, int32_t *zero_word, wd_stream_t stream) {
+  if (batch <= 0) return WD_OK;
+  WD_REQUIRE(slots && ids && bucket_start && pairs, "null pointer");
+  WD_REQUIRE(S > 0 && nbuckets > 0 && nbuckets <= MAX_NB && max_slot_buckets > 0 && max_slot_buckets <= nbuckets,
+             "bad bucket geometry");
+  WD_REQUIRE(batch * S < ((int64_t)1 << 31), "batch * S must fit 31 bits");
+  hipLaunchKernelGGL(k_bucket_onehot, dim3((unsigned)(S * ONEHOT_CHUNKS)), dim3(512), (size_t)max_slot_buckets * 8,
+                     wd::as_stream(stream), slots, S, ids, ids_slot_major ? (int64_t)1 : (int64_t)S,
+                     ids_slot_major ? batch : (int64_t)1, batch, nbuckets, bucket_start, pairs, ticket, zero_word);
+  return wd::check_launch("wd_bucket_onehot");
+}
+
+extern "C" int wd_prefetch_onehot(const float *rec, int32_t rec_stride, int32_t dim, const wd_slot_t *rec_slots, int32_t S,
+                                  const int32_t *ids, int64_t batch, float *x, int64_t ldx, float *wide_vals,
+                                  const float *dense, int64_t ld_dense, const wd_dense_col_t *dense_cols, int32_t ncols,
+                                  void *span, wd_stream_t stream) {
+  if (batch <= 0) return WD_OK;
+  WD_REQUIRE(rec && rec_slots && ids && x && wide_vals, "null pointer");
+  WD_REQUIRE(S > 0 && S <= 128, "1 <= S <= 128");
+  WD_REQUIRE((dim == 4 || dim == 8 || dim == 16) && rec_stride % 4 == 0 && rec_stride >= dim + 4, "record = [dim | w z n -], dim in {4, 8, 16}");
+  WD_REQUIRE(ldx % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0, "x must be 16-byte aligned with ldx % 4 == 0");
+  WD_REQUIRE(ncols == 0 || (dense && dense_cols), "numeric columns need dense + descriptors");
+  hipStream_t st = wd::as_stream(stream);
+  constexpr int BPG = 4;
+  const int lanes = dim / 4;
+  const int64_t groups = wd::ceil_div(batch * S, BPG);
+  const int gb = (int)wd::ceil_div(groups * lanes, 256);
+  const int db = ncols > 0 ? (int)wd::ceil_div(batch * ncols, 256) : 0;
+#define WD_LAUNCH_PF(L)                                                                                                     \
+  hipLaunchKernelGGL((k_prefetch_onehot<L, BPG>), dim3((unsigned)(gb + db)), dim3(256), 0, st, rec, rec_stride, rec_slots, \
+                     S, ids, batch, x, ldx, wide_vals, dense, ld_dense, dense_cols, ncols, gb,                              \
+                     static_cast<unsigned long long *>(span))
+  if (lanes == 4) WD_LAUNCH_PF(4);
+  else if (lanes == 2) WD_LAUNCH_PF(2);
+  else WD_LAUNCH_PF(1);
+#undef WD_LAUNCH_PF
+  return wd::check_launch("wd_prefetch_onehot");
+}
+
+extern "C" int wd_bucket_sort(const int32_t *bucket_start, uint64_t *pairs, int32_t nbuckets, int32_t *long_list,
+                              int32_t long_capacity, int32_t *big_list, int64_t batch, int32_t S,
+                              const int32_t *prev_bucket_start, const uint64_t *prev_pairs, int32_t *prev_patch,
+                              wd_stream_t stream) {
+  WD_REQUIRE(bucket_start && pairs && long_list && big_list && nbuckets > 0 && nbuckets <= MAX_NB, "null pointer / bad bucket geometry");
+  WD_REQUIRE(!prev_patch || (prev_bucket_start && prev_pairs), "prev_patch needs the previous batch's buckets");
+  WD_REQUIRE(long_capacity > 0 && batch > 0 && S > 0, "long_capacity, batch, S");
+  const int64_t nnz = batch * S;
+  SortArgs g{};
+  g.S = S; g.batch = batch;
+  g.start = bucket_start; g.pairs = pairs; g.long_list = long_list; g.big_list = big_list; g.pstart = prev_bucket_start;
+  g.ppairs = prev_pairs; g.ppatch = reinterpret_cast<int2 *>(prev_patch); g.long_cap = long_capacity; g.nb = nbuckets;
+  g.bag_bits = 1;
+  while (g.bag_bits < 32 && ((int64_t)1 << g.bag_bits) < nnz) ++g.bag_bits;
+  hipStream_t st = wd::as_stream(stream);
+  hipLaunchKernelGGL(k_bucket_sort_small, dim3((unsigned)nbuckets), dim3(256), 0, st, g);
+  hipLaunchKernelGGL(k_bucket_sort_big, dim3(BIG_WORKERS), dim3(256), 0, st, g);
+  return wd::check_launch("wd_bucket_sort");
+}
+
+extern "C" int wd_row_update(float *rec, int32_t rec_stride, int32_t dim, float *emb_accum, float *bias_wzn,
+                             const wd_slot_t *slots, int32_t S, int64_t batch, const float *dx, int64_t ldx,
+                             const float *dlogit, float lr_emb, float lr_wide, float l1, float l2, const uint64_t *pairs,
+                             const int32_t *long_list, int32_t long_capacity, const int32_t *patch,
+                             const wd_apply_next_t *next, wd_stream_t stream) {
+  if (batch <= 0) return WD_OK;
+  WD_REQUIRE(rec && emb_accum && slots && dx && dlogit && pairs && long_list, "null pointer");
+  WD_REQUIRE(S > 0 && S <= 128 && (dim == 4 || dim == 8 || dim == 16) && rec_stride % 4 == 0 && rec_stride >= dim + 4,
+             "record = [dim | w z n -], dim in {4, 8, 16}, S <= 128");
+  WD_REQUIRE(!patch || (next && next->pairs && next->x && next->wide_vals && next->ldx > 0),
+             "patch needs the next batch's sorted pairs, x tile and wide-weight list");
+  RowUpd u{};
+  u.rec = rec; u.accum = emb_accum; u.bias = bias_wzn; u.slots = slots; u.dx = dx; u.dlogit = dlogit; u.pairs = pairs;
+  u.long_list = long_list; u.long_cap = long_capacity; u.patch = reinterpret_cast<const int2 *>(patch); u.ldx = ldx; u.nnz = batch * S; u.batch = batch; u.rec_stride = rec_stride;
+  u.dim = dim; u.S = S; u.lr_emb = lr_emb; u.lr_w = lr_wide; u.l1 = l1; u.l2 = l2;
+  if (patch) { u.npairs = next->pairs; u.nx = next->x; u.nwv = next->wide_vals; u.nldx = next->ldx; }
+  u.flat_blocks = (int32_t)wd::ceil_div(u.nnz * 4, 256);
+  hipLaunchKernelGGL(k_row_update, dim3((unsigned)(u.flat_blocks + LONG_WORKERS + 1)), dim3(256), 0, wd::as_stream(stream), u);
+  return wd::check_launch("wd_row_update");
+}

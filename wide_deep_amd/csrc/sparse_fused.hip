@@ -316,7 +316,17 @@ struct UpdArgs {
   // the embedding row in front, {w, z, n, -} behind it at `wide` = emb + dim; the accumulator table keeps its flat layout.
   // 0: separate tables (emb rows of `dim` floats from sl.emb_off, wide lines of 4 floats).
   int32_t rec_stride;
+  // pairs that do NOT arrive in ascending bag order inside a bucket (wd_bucket_onehot): one-row buckets are sorted as well
+  int32_t unstable;
+  // patch of the NEXT batch's prefetched input layer (wd_prefetch_onehot ran before this update): every row rewritten here
+  // that the next batch reads too -- found in the next batch's bucket of the same row range -- is stored into the next x
+  // tile / wide-weight list from the registers that hold its new value.  nstart == NULL: off.
+  const int32_t *nstart;
+  const uint64_t *npairs;
+  float *nx, *nwv;
+  int64_t nldx;
 };
+
 
 // all comparators ascending (mirror first step), so virtual +inf padding beyond m never moves.
 // k and j are powers of two: indices by shifts/masks.
@@ -422,13 +432,30 @@ k_bucket_update(UpdArgs u, const int32_t *__restrict__ start, uint64_t *__restri
   const int bkt = start[u.nb + 2 + blockIdx.x];   // largest buckets first (order list written by k_bucket_scatter)
   const int32_t s0 = start[bkt];
   const int m = start[bkt + 1] - s0;
+  int32_t nst0 = 0, nst1 = 0;
+  if (!GEN && u.nstart) {      // (with the loads above: same dependency, one round trip)
+    nst0 = u.nstart[bkt];
+    nst1 = u.nstart[bkt + 1];
+  }
   if (t == 0) nlong = 0;
   if (m == 0) return;
+  // The same row range of the NEXT batch (its input layer was gathered before this update): a row rewritten here has to be
+  // stored into the next x tile again iff the next batch holds it too -- 1.6 % of the rows with uniform ids.  Every lane takes
+  // one of the next batch's pairs of this bucket (loaded here, next to the bucket's own: one more dependent round trip per
+  // workgroup costs 30 % of this kernel) and, when all updates of the bucket are done, looks its row up in the sorted list.
+  int32_t n0 = 0, m2 = 0;
+  uint64_t np0 = 0;
+  if (!GEN && u.nstart) {
+    n0 = nst0;
+    m2 = nst1 - nst0;
+    if (t < m2) np0 = u.npairs[n0 + t];
+  }
   const bool slots_in_lds = u.S <= MAX_SLOTS_LDS;
   if (slots_in_lds && t < u.S) lds_slots[t] = u.slots[t];   // overlaps with the pair loads below
   const uint64_t *sp;  // sorted pairs (flat pointer: LDS or global)
   // the scatter is stable (ascending bag order inside a bucket); a bucket of a slot with bucket_shift == 0 holds ONE row
-  const bool single_row = u.slots[(int32_t)(uint32_t)pairs[s0] % u.S].bucket_shift == 0;
+  const bool one_row = u.slots[(int32_t)(uint32_t)pairs[s0] % u.S].bucket_shift == 0;
+  const bool single_row = one_row && !u.unstable;
   if (single_row) {
     __syncthreads();
     sp = pairs + s0;           // already grouped and ordered: nothing to sort
@@ -461,7 +488,7 @@ k_bucket_update(UpdArgs u, const int32_t *__restrict__ start, uint64_t *__restri
 
   const int S = u.S;
   const int gidx = t >> 2, gl = t & 3;
-  const bool whole_long = single_row && m > LONG_SEG;   // one row, many occurrences: the bucket IS one long segment
+  const bool whole_long = one_row && m > LONG_SEG;   // one row, many occurrences: the bucket IS one long segment
   if (whole_long && t == 0) {
     nlong = 1;
     long_i0[0] = 0;
@@ -739,6 +766,29 @@ k_bucket_update(UpdArgs u, const int32_t *__restrict__ start, uint64_t *__restri
       __syncthreads();
     }
   }
+  // ---- patch of the next batch's prefetched input layer: every pair (row, bag') of the next batch in this row range whose row
+  // was rewritten above -- found by binary search in the sorted list -- is stored again from the table (device-scope loads:
+  // the rows were written by other wavefronts of this workgroup, complete behind the barrier, but not through this CU's L1)
+  if (GEN || m2 == 0) return;
+  __syncthreads();
+  for (int i = t; i < m2; i += 256) {
+    const uint64_t pr = i == t ? np0 : u.npairs[n0 + i];
+    const uint32_t key = (uint32_t)(pr >> 32);
+    int lo = 0, hi = m;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if ((uint32_t)(sp[mid] >> 32) < key) lo = mid + 1; else hi = mid;
+    }
+    if (lo >= m || (uint32_t)(sp[lo] >> 32) != key) continue;
+    const int32_t bag2 = (int32_t)(uint32_t)pr;
+    const int32_t sidx = bag2 % S;
+    const wd_slot_t sl = slots_in_lds ? lds_slots[sidx] : u.slots[sidx];
+    const float *src = u.emb + (int64_t)key * u.rec_stride;
+    float *dst = u.nx + (int64_t)(bag2 / S) * u.nldx + sl.out_col;
+    for (int d = 0; d < sl.dim; ++d) dst[d] = __hip_atomic_load(src + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (sl.wide)
+      u.nwv[bag2] = __hip_atomic_load(u.wide + (int64_t)key * ws, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
 }
 
 }  // namespace
@@ -789,6 +839,7 @@ extern "C" int wd_sparse_apply(float *emb, float *emb_accum, float *wide, float 
   u.lr_emb = lr_emb; u.lr_w = lr_wide; u.l1 = l1; u.l2 = l2;
   u.accum_a = u.accum_c = nullptr; u.touched = nullptr; u.oe = OptK{}; u.ow = OptK{}; u.pow_e = u.pow_w = nullptr;
   u.rec_stride = 0;
+  u.unstable = 0; u.nstart = nullptr; u.npairs = nullptr; u.nx = u.nwv = nullptr; u.nldx = 0;
   hipLaunchKernelGGL(k_bucket_update<false>, dim3((unsigned)nbuckets + 1), dim3(256), 0, wd::as_stream(stream), u,
                      bucket_start, pairs);
   return wd::check_launch("wd_sparse_apply");
@@ -801,7 +852,7 @@ extern "C" int wd_sparse_apply_rec(float *rec, int32_t rec_stride, int32_t dim, 
                                    const wd_slot_t *slots, int32_t S, const int32_t *bag_offs, int64_t batch,
                                    const float *dx, int64_t ldx, const float *dlogit, int64_t ld_dlogit, float lr_emb,
                                    float lr_wide, float l1, float l2, const int32_t *bucket_start, uint64_t *pairs,
-                                   int32_t nbuckets, wd_stream_t stream) {
+                                   int32_t nbuckets, const wd_apply_next_t *next, wd_stream_t stream) {
   if (batch <= 0) return WD_OK;
   WD_REQUIRE(rec && emb_accum && dx && dlogit && slots && bag_offs && bucket_start && pairs, "null pointer");
   WD_REQUIRE(S > 0 && nbuckets > 0 && nbuckets <= MAX_NB, "bad bucket geometry");
@@ -813,6 +864,15 @@ extern "C" int wd_sparse_apply_rec(float *rec, int32_t rec_stride, int32_t dim, 
   u.lr_emb = lr_emb; u.lr_w = lr_wide; u.l1 = l1; u.l2 = l2;
   u.accum_a = u.accum_c = nullptr; u.touched = nullptr; u.oe = OptK{}; u.ow = OptK{}; u.pow_e = u.pow_w = nullptr;
   u.rec_stride = rec_stride;
+  u.unstable = 0; u.nstart = nullptr; u.npairs = nullptr; u.nx = u.nwv = nullptr; u.nldx = 0;
+  if (next) {
+    u.unstable = next->unsorted_buckets;
+    if (next->bucket_start) {
+      WD_REQUIRE(next->pairs && next->x && next->wide_vals && next->ldx > 0 && dim <= 16,
+                 "wd_apply_next_t: the next batch's pairs, x tile and wide-weight list (dim <= 16)");
+      u.nstart = next->bucket_start; u.npairs = next->pairs; u.nx = next->x; u.nwv = next->wide_vals; u.nldx = next->ldx;
+    }
+  }
   hipLaunchKernelGGL(k_bucket_update<false>, dim3((unsigned)nbuckets + 1), dim3(256), 0, wd::as_stream(stream), u,
                      bucket_start, pairs);
   return wd::check_launch("wd_sparse_apply_rec");
@@ -857,6 +917,7 @@ extern "C" int wd_sparse_apply_opt(float *emb, float *emb_a, float *emb_b, float
   u.ld_dlogit = ld_dlogit > 0 ? ld_dlogit : 1;
   u.lr_emb = u.lr_w = u.l1 = u.l2 = 0.f;
   u.rec_stride = 0;
+  u.unstable = 0; u.nstart = nullptr; u.npairs = nullptr; u.nx = u.nwv = nullptr; u.nldx = 0;
   u.touched = adam ? touched : nullptr;
   u.oe = to_optk(emb ? emb_opt : nullptr); u.ow = to_optk((wide || bias) ? wide_opt : nullptr);
   u.pow_e = (emb && emb_opt->kind == WD_OPT_ADAM) ? emb_opt->pow : nullptr;

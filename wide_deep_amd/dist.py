@@ -475,7 +475,7 @@ class ShardedWideDeepEngine(WideDeepEngine):
         if self.rec is not None:
             call("wd_sparse_apply_rec", ptr(self.rec), self.rec_stride, self.dim, ptr(self.emb_acc), None, ptr(self.oslot_dev),
                  1, ptr(self.req_offs), self.n_req, g_ptr, self.RS, dl_ptr, self.RS, float(spec.dnn_opt[1]), float(lr),
-                 float(l1), float(l2), ptr(ob["start"]), ptr(ob["pairs"]), self.n_buckets, st)
+                 float(l1), float(l2), ptr(ob["start"]), ptr(ob["pairs"]), self.n_buckets, None, st)
             return
         call("wd_sparse_apply", ptr(self.emb) if has_emb else None, ptr(self.emb_acc) if has_emb else None,
              ptr(self.wide) if spec.has_wide else None, None, ptr(self.oslot_dev), 1, ptr(self.req_offs), self.n_req,

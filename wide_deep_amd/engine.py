@@ -34,6 +34,7 @@ class DeviceBatch:
         self.labels = labels        # float32 [B] or None
         self.weights = weights      # float32 [B] or None
         self.nnz = int(nnz if nnz is not None else ids.numel())
+        self.ids_cols = None        # optional slot-major copy of a one-id-per-bag batch: ids_cols[s * B + b] (wd_hash_bucket_cols)
 
 
 def _stream():
@@ -354,8 +355,13 @@ class WideDeepEngine:
         # two sets of bucketing scratch: in a pipelined multi-step graph (pipeline.StepGraph) the occurrences of step t+1
         # are bucketed while the update of step t still reads its own set
         self._bucket_sets = []
+        self.max_slot_buckets = max([((int(sl.num_buckets) + (1 << sh) - 1) >> sh) for sl, sh in zip(plan.slots, shifts)] + [1])
         for _ in range(2):
             self._bucket_sets.append(dict(
+                ticket=torch.zeros(4, **i32), unsorted=False,      # wd_bucket_onehot: last-workgroup ticket; arrival-order pairs
+                sorted=False,                                      # pairs sorted in place by wd_bucket_sort (flat row update)
+                long_list=torch.zeros(2 * (M // 32 + 2) + 2, **i32), big_list=torch.zeros(self.n_buckets, **i32),
+                patch=torch.zeros(2 * M, **i32),
                 cnt=torch.zeros((2 * int(call("wd_bucket_chunks")) + 1) * self.n_buckets, **i32),
                 start=torch.zeros(2 * self.n_buckets + 2, **i32),   # starts [nb+1] + launch order [nb]
                 rank=torch.zeros(M, **i32), pairs=torch.zeros(M, dtype=torch.int64, device=dev)))
@@ -382,6 +388,8 @@ class WideDeepEngine:
             (gdim, gsl), = plan.emb_groups.items()
             self._fused_input_layer = (gsl == list(range(gsl[0], gsl[0] + len(gsl))) and gdim in (4, 8, 16, 32, 64, 128)
                                        and len(gsl) <= 128)
+        if spec.has_deep:
+            self._setup_prefetch()
 
     # ------------------------------------------------------------------------------------------
     # forward
@@ -390,6 +398,9 @@ class WideDeepEngine:
         """One-launch tower (wd_tower_chain, csrc/mlp_chain.hip): exact-fp32 `simple` towers whose widths are multiples
         of 32 and whose row tile fits the LDS.  WD_CHAIN=0 keeps the per-layer GEMM launches."""
         self.chain = False
+        self.prefetch, self._apar, self._prefetched = False, 0, False
+        self.flat_update = False
+        self._prefetch_span = None       # diagnostics: device pointer of uint64[2] {first start, last end} of wd_prefetch_onehot
         self._chain_tile_stamps = None   # diagnostics: device uint64[2 * tiles] realtime-clock stamps (bench.py: in-step gather span)
         self._chain_stamps = None    # diagnostics: device int64[64] for the tower kernel's stage stamps (scripts/bench_chain.py)
         plan = self.plan
@@ -452,6 +463,8 @@ class WideDeepEngine:
             c.dgamma_part, c.dbeta_part = (tw["dg_part"][l].data_ptr(), tw["dbeta_part"][l].data_ptr()) if bn else (None, None)
             c.K, c.N = int(m["K"]), dims[l]
         tw["chain_layers"], tw["tail_layers"] = carr, tarr
+        tw["acts"], tw["chain_layers_p"] = [tw["act"]], [carr]
+        self.prefetch, self._apar, self._prefetched = False, 0, False
         self.loss_part = torch.zeros(ntile, **f32)   # per-row-tile losses, summed in tile order by the grouped launch
         # gradient columns of x that anyone reads: the embedding columns (the sparse backward), rounded up by the kernel
         emb_cols = 0
@@ -460,6 +473,49 @@ class WideDeepEngine:
                 emb_cols = max(emb_cols, plan.out_col[i] + int(sl.dim))
         tw["dx_cols"] = min(emb_cols, K0)
         self.chain = True
+
+    def _setup_prefetch(self):
+        """Prefetched input layer (one-id-per-bag batches on row records, single GPU): x and the wide weights of a batch are
+        gathered by their own launch (wd_prefetch_onehot) -- in a pipelined multi-step graph one step AHEAD, beside the
+        previous tower, into the other of two activation buffers; the rows the update in between rewrites are patched by
+        that update (wd_apply_next_t).  WD_PREFETCH=0: the tower kernel gathers its own x tile (wd_chain_input_t)."""
+        self._apar = 0                 # activation buffer / wide-weight list the current step uses
+        self._prefetched = False       # pipeline.StepGraph: x / wv of the batch forward() is called with are already in place
+        self.prefetch = bool(self.spec.has_deep and self.chain and self.rec is not None and type(self) is WideDeepEngine
+                             and self._fused_input_layer and os.environ.get("WD_PREFETCH", "1") != "0")
+        if not self.prefetch:
+            return
+        tw = self.towers[0]
+        tl, L, B = tw["layout"], tw["L"], self.max_batch
+        f32 = dict(dtype=torch.float32, device=self.device)
+        carr = tw["chain_layers"]
+        # THREE activation buffers / weight lists: the gather of batch t+1 (sparse branch, behind update(t-1)) overwrites the
+        # buffer the products of step t-2 read -- complete before tower(t-1) even started -- so no event has to sit between the
+        # products and the tail of a step to release it (one graph node less on the dense chain)
+        self.n_act = 3
+        for _ in range(self.n_act - 1):
+            act2 = torch.zeros(B, tl.ld, **f32)
+            carr2 = (capi.WdChainLayer * L)()
+            ctypes.memmove(carr2, carr, ctypes.sizeof(carr))
+            for l in range(L):
+                carr2[l].a_out = act2.data_ptr() + 4 * tl.seg_start[l + 1]
+            tw["acts"].append(act2)
+            tw["chain_layers_p"].append(carr2)
+        self.wv = [torch.zeros(B * self.plan.S, **f32) for _ in range(self.n_act)]
+        # Flat row update: every id-only part of the sparse update (bucketing, the sort of every bucket, long segments, which
+        # rows the next batch shares) runs with the bucketing -- beside the previous tower in a pipelined graph -- and the
+        # update itself is a flat launch over the sorted pairs (wd_row_update).  WD_FLAT_UPDATE=0: wd_sparse_apply_rec.
+        self.flat_update = os.environ.get("WD_FLAT_UPDATE", "1") != "0" and self.plan.S <= 128
+
+    def _prefetch_input(self, bt, st, p):
+        """Input layer of `bt` into activation buffer p: embedding rows + numeric columns -> x, wide weights -> wv[p]."""
+        plan, tw = self.plan, self.towers[0]
+        (dim, sl), = plan.emb_groups.items()
+        nd = len(plan.dense_cols)
+        call("wd_prefetch_onehot", ptr(self.rec), self.rec_stride, dim, ptr(self.rslots_dev), plan.S, ptr(bt.ids), bt.B,
+             tw["acts"][p].data_ptr() + 4 * tw["layout"].seg_start[0], tw["layout"].ld, ptr(self.wv[p]),
+             ptr(bt.dense) if nd else None, bt.dense.stride(0) if nd else 0, ptr(self.dense_cols_dev) if nd else None, nd,
+             self._prefetch_span, st)
 
     def _fold(self, train, st):
         """One launch: fold the BN affines of every layer into its consumer's weights (+ the MFMA-fragment-packed copies
@@ -526,16 +582,20 @@ class WideDeepEngine:
         has_emb = bool(self.group_slots)
         need_dx = train and has_emb and tw["dx_cols"] > 0
         opts = capi.WdChainOpts()
-        ci = self._chain_input(bt, tw) if fuse_in else None      # kept alive until the call returns
+        pf = fuse_in and self.prefetch       # x / wide weights of this batch are in activation buffer self._apar
+        p = self._apar if pf else 0
+        ci = self._chain_input(bt, tw) if (fuse_in and not pf) else None      # kept alive until the call returns
         if ci is not None:
             opts.input = ctypes.addressof(ci)
+        if pf and self.spec.has_wide:
+            opts.wide_vals, opts.wide_bias, opts.wide_out, opts.wide_S = ptr(self.wv[p]), ptr(self.bias), ptr(self.wide_logit), self.plan.S
         if train:
             opts.loss_part = ptr(self.loss_part)
         opts.stamps = self._chain_stamps
         opts.tile_stamps = self._chain_tile_stamps
         opts.row_tile = self.chain_rt
         opts.flags = int(os.environ.get("WD_CHAIN_FLAGS", "0"))
-        call("wd_tower_chain", tw["act"].data_ptr() + 4 * tl.in_start[0], tl.ld, int(metas[0]["K"]), tw["chain_layers"], L,
+        call("wd_tower_chain", tw["acts"][p].data_ptr() + 4 * tl.in_start[0], tl.ld, int(metas[0]["K"]), tw["chain_layers_p"][p], L,
              self.act_id, self.inv, self.P.data_ptr() + 4 * metas[L]["w_off"], self.P.data_ptr() + 4 * metas[L]["b_off"],
              None if fuse_in else ptr(self.wide_logit),
              ptr(bt.labels) if train else None, ptr(bt.weights) if train else None, B, ptr(tw["logit"]), ptr(self.logit),
@@ -636,7 +696,10 @@ class WideDeepEngine:
         B = bt.B
         train = bt.labels is not None and need_loss
         fuse_in = self._chain_input_ok(bt)
-        if fuse_in:
+        if fuse_in and self.prefetch:
+            if not self._prefetched:            # (pipeline.StepGraph gathers a step ahead and patches: nothing to do here)
+                self._prefetch_input(bt, st, self._apar)
+        elif fuse_in:
             self._sparse_exchange(bt, st)       # rows that have to travel first (sharded engine); nothing on one GPU
         else:
             self._sparse_forward(bt, st)
@@ -768,6 +831,7 @@ class WideDeepEngine:
         tl, metas, L = tw["layout"], tw["metas"], tw["L"]
         act, dact = tw["act"], tw["dact"]
         if self.chain:
+            act = tw["acts"][self._apar if self.prefetch else 0]
             # forward() already ran the input-gradient chain; what is left are the batch reductions G_l = bn_{l-1}^T dz_l
             # (split-K products) and the sums of the per-tile partials of the bias / BN gradients and of the loss
             # (column-sum jobs), all in grouped launches of at most WD_TN_GROUP_MAX jobs
@@ -916,18 +980,38 @@ class WideDeepEngine:
     def _reduce_dense_grads(self):
         """Hook for data-parallel ranks (dist.py: all_reduce(SUM) of the flat gradient buffer)."""
 
-    def _sparse_bucketize(self, bt: DeviceBatch, st, pset=0):
-        """Phase 1 of the sparse backward (ids only): occurrences -> row-range buckets (scratch set `pset`)."""
+    def _sparse_bucketize(self, bt: DeviceBatch, st, pset=0, prev=None):
+        """Phase 1 of the sparse backward (ids only): occurrences -> row-range buckets (scratch set `pset`).  Flat row update:
+        + the sort of every bucket; prev = scratch set of the batch stepped BEFORE this one (pipelined graph): its patch list
+        (rows this batch reads too) is filled as well."""
         plan = self.plan
         self._check_batch(bt)
         bs = self._bucket_sets[pset]
+        if self._bucket_onehot_ok(bt):
+            # one id per bag: every slot owns B occurrences -> one launch, no count matrix (csrc/onehot_path.hip)
+            cols = bt.ids_cols is not None
+            flat = self.flat_update and self.prefetch
+            call("wd_bucket_onehot", ptr(self.slots_dev), plan.S, ptr(bt.ids_cols if cols else bt.ids), 1 if cols else 0, bt.B,
+                 ptr(bs["start"]), ptr(bs["pairs"]), self.n_buckets, self.max_slot_buckets,
+                 None if flat else ptr(bs["ticket"]), ptr(bs["long_list"]) if flat else None, st)
+            bs["unsorted"], bs["sorted"] = True, flat
+            if flat:
+                bp = self._bucket_sets[prev] if prev is not None else None
+                call("wd_bucket_sort", ptr(bs["start"]), ptr(bs["pairs"]), self.n_buckets, ptr(bs["long_list"]),
+                     (bs["long_list"].numel() - 2) // 2, ptr(bs["big_list"]), bt.B, plan.S, ptr(bp["start"]) if bp else None, ptr(bp["pairs"]) if bp else None, ptr(bp["patch"]) if bp else None, st)
+            return
+        bs["unsorted"] = bs["sorted"] = False
         call("wd_sparse_bucketize", ptr(self.slots_dev), plan.S, ptr(bt.ids), ptr(bt.bag_offs), bt.B, bt.nnz,
              ptr(bs["cnt"]), ptr(bs["start"]), ptr(bs["rank"]), ptr(bs["pairs"]), self.n_buckets, st)
+
+    def _bucket_onehot_ok(self, bt):
+        return (bt.one_hot and self.rec is not None and type(self) is WideDeepEngine and bt.nnz == bt.B * self.plan.S
+                and os.environ.get("WD_BUCKET_ONEHOT", "1") != "0")
 
     def _has_sparse_update(self):
         return (bool(self.group_slots) if self.spec.has_deep else False) or self.spec.has_wide
 
-    def _sparse_backward(self, bt: DeviceBatch, st, bucketized=False, pset=0):
+    def _sparse_backward(self, bt: DeviceBatch, st, bucketized=False, pset=0, patch=None):
         """Scatter-add of the row gradients + fused Adagrad (embedding rows) / FTRL (wide rows, bias)."""
         plan, spec = self.plan, self.spec
         has_emb = bool(self.group_slots) if spec.has_deep else False
@@ -941,11 +1025,36 @@ class WideDeepEngine:
             tw0 = self.towers[0]
             tl0 = tw0["layout"]
             dx_ptr, ld = tw0["dact"].data_ptr() + 4 * tl0.seg_start[0], tl0.ld
+        if self.rec is not None and bsx["sorted"]:
+            nx, pa = None, None
+            if patch is not None:
+                bn, pn = self._bucket_sets[patch[0]], patch[1]
+                tw0 = self.towers[0]
+                nx = capi.WdApplyNext()
+                nx.pairs = ptr(bn["pairs"])
+                nx.x, nx.ldx = tw0["acts"][pn].data_ptr() + 4 * tw0["layout"].seg_start[0], tw0["layout"].ld
+                nx.wide_vals = ptr(self.wv[pn])
+                pa = ptr(bsx["patch"])
+            call("wd_row_update", ptr(self.rec), self.rec_stride, self.emb.shape[1], ptr(self.emb_acc), ptr(self.bias),
+                 ptr(self.slots_dev), plan.S, bt.B, dx_ptr, ld, ptr(self.dlogit), float(spec.dnn_opt[1]),
+                 float(spec.lin_opt[1]), float(spec.lin_opt[2]), float(spec.lin_opt[3]), ptr(bsx["pairs"]),
+                 ptr(bsx["long_list"]), (bsx["long_list"].numel() - 2) // 2, pa, ctypes.byref(nx) if nx is not None else None, st)
+            return
         if self.rec is not None:
+            nx = capi.WdApplyNext()
+            nx.unsorted_buckets = 1 if bsx["unsorted"] else 0
+            if patch is not None:
+                # (pset_next, p_next): the next batch's buckets and the activation buffer / weight list its input layer was
+                # prefetched into BEFORE this update -- rows rewritten here are stored there again
+                bn, pn = self._bucket_sets[patch[0]], patch[1]
+                tw0 = self.towers[0]
+                nx.bucket_start, nx.pairs = ptr(bn["start"]), ptr(bn["pairs"])
+                nx.x, nx.ldx = tw0["acts"][pn].data_ptr() + 4 * tw0["layout"].seg_start[0], tw0["layout"].ld
+                nx.wide_vals = ptr(self.wv[pn])
             call("wd_sparse_apply_rec", ptr(self.rec), self.rec_stride, self.emb.shape[1], ptr(self.emb_acc), ptr(self.bias),
                  ptr(self.slots_dev), plan.S, ptr(bt.bag_offs), bt.B, dx_ptr, ld, ptr(self.dlogit), 1, float(spec.dnn_opt[1]),
                  float(spec.lin_opt[1]), float(spec.lin_opt[2]), float(spec.lin_opt[3]), ptr(bsx["start"]), ptr(bsx["pairs"]),
-                 self.n_buckets, st)
+                 self.n_buckets, ctypes.byref(nx), st)
             return
         if self.default_opts:
             lr, l1, l2 = (spec.lin_opt[1], spec.lin_opt[2], spec.lin_opt[3]) if spec.has_wide else (0.0, 0.0, 0.0)

@@ -65,7 +65,12 @@ class StepGraph:
         self.stream.wait_stream(torch.cuda.current_stream())
         gs = eng.global_step            # capturing executes nothing: the counter must not move
         with torch.cuda.graph(self.graph, stream=self.stream):
-            if self.pipelined:
+            if self.pipelined and eng.prefetch:
+                try:
+                    self._capture_prefetched(token_batches, ids_input)
+                finally:
+                    eng._apar, eng._prefetched = 0, False
+            elif self.pipelined:
                 self._capture_pipelined(token_batches, ids_input)
             else:
                 for tb in token_batches:
@@ -155,6 +160,82 @@ class StepGraph:
 
             eng._dense_backward(bt, main.cuda_stream, after_products=update_then_join)
         main.wait_stream(s_in)
+        main.wait_stream(s_sp)
+        if hash_ahead:
+            main.wait_stream(s_h)
+
+    def _capture_prefetched(self, tbs, ids_input):
+        """The pipelined step with the input layer taken out of the tower launch (engine.prefetch).  The sparse branch carries,
+        in stream order,  update(t-1) -> bucket(t+1) -> prefetch(t+1) -> update(t):  while tower(t) runs on the main branch
+        the sparse branch -- idle until dx(t) exists -- buckets batch t+1 (one launch, wd_bucket_onehot) and gathers its rows +
+        wide weights into the OTHER activation buffer (wd_prefetch_onehot); update(t) then stores the rows it rewrites into
+        that buffer again (wd_apply_next_t), so tower(t+1) -- which reads x from HBM -- sees exactly the tables after update(t):
+
+            hash branch    tokens -> ids of every step of the graph, ahead
+            main           tower(t) -> products(t) -> tail(t)                          tower(t) waits for update(t-1)
+            sparse branch  update(t-1) | bucket(t+1) -> prefetch(t+1) | update(t) + patch of x(t+1)
+
+        No event sits between update(t-1) and tower(t) except the join itself, and the input work needs no edge of its own
+        (edges from the sparse branch into a third one two steps ahead crash hipStreamEndCapture of ROCm 7.2).  Every step's
+        results are bit-identical to the eager launches (gather -> tower -> ...), tests/test_gpu_prefetch.py."""
+        eng = self.eng
+        main = torch.cuda.current_stream()
+        s_sp = eng._side(0)
+        s_sp.wait_stream(main)
+        keep = self._events = []
+        n = len(tbs)
+
+        def event(stream):
+            ev = torch.cuda.Event()
+            ev.record(stream)
+            keep.append(ev)
+            return ev
+
+        hash_ahead = not ids_input
+        ev_hash = []
+        if hash_ahead:
+            s_h = eng._side(1)
+            s_h.wait_stream(main)
+            with torch.cuda.stream(s_h):
+                for tb in tbs:
+                    synth.hash_tokens(eng, tb)
+                    ev_hash.append(event(s_h))
+
+        na = eng.n_act      # 3 activation buffers: the one batch t+1 is gathered into was last read by the products of step t-2
+
+        def input_work(t):
+            """bucket(t) (+ sort, + which rows of batch t-1 it shares) -> set t & 1, prefetch(t) -> activation buffer t % 3, on the
+            sparse branch behind update(t-2): the set's last reader; the buffer's last readers -- tower and products of step
+            t-3 -- completed before tower(t-2), which update(t-2) waited for."""
+            bt = tbs[t].batch
+            eng._check_batch(bt)
+            if hash_ahead:
+                s_sp.wait_event(ev_hash[t])
+            with torch.cuda.stream(s_sp):
+                eng._sparse_bucketize(bt, s_sp.cuda_stream, t & 1, prev=(t - 1) & 1 if t >= 1 else None)
+                eng._prefetch_input(bt, s_sp.cuda_stream, t % na)
+
+        input_work(0)
+        ev_upd = event(s_sp)            # x(0) in place
+        for t, tb in enumerate(tbs):
+            bt = tb.batch
+            main.wait_event(ev_upd)                     # update(t-1), with its patch of this step's x
+            if t + 1 < n:
+                input_work(t + 1)                       # sparse branch, behind update(t-1): runs beside tower(t)
+            eng._apar, eng._prefetched = t % na, True
+            eng.forward(bt, need_loss=True)             # the tower launch: x from HBM, wide logit from the weight list
+            ev_tower = event(main)
+            hold = {}
+
+            def update_then_join(t=t, bt=bt, ev_tower=ev_tower, hold=hold):
+                s_sp.wait_event(ev_tower)
+                nxt = ((t + 1) & 1, (t + 1) % na) if t + 1 < n else None
+                with torch.cuda.stream(s_sp):
+                    eng._sparse_backward(bt, s_sp.cuda_stream, bucketized=True, pset=t & 1, patch=nxt)
+                    hold["upd"] = event(s_sp)
+
+            eng._dense_backward(bt, main.cuda_stream, after_products=update_then_join)
+            ev_upd = hold["upd"]
         main.wait_stream(s_sp)
         if hash_ahead:
             main.wait_stream(s_h)

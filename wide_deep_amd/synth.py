@@ -99,6 +99,8 @@ class TokenBatch:
         self.ids = torch.zeros(max(self.ntok, 1), dtype=torch.int32, device=device)
         self.batch = DeviceBatch(self.B, self.ids, self.bag_offs, t(hb["dense"]), t(hb["labels"]), t(weights),
                                  nnz=self.ntok, one_hot=self.one_per_bag)
+        if self.one_per_bag:        # slot-major copy of the ids for the one-launch bucketing (wd_hash_bucket_cols)
+            self.batch.ids_cols = torch.zeros(max(self.ntok, 1), dtype=torch.int32, device=device)
 
 
 def hash_tokens(engine, tb: TokenBatch):
@@ -106,6 +108,10 @@ def hash_tokens(engine, tb: TokenBatch):
     plan = getattr(engine, "hash_plan", engine.plan)            # sharded engines hash in the global id space
     slots_dev = getattr(engine, "hash_slots_dev", engine.slots_dev)
     st = torch.cuda.current_stream().cuda_stream
+    if tb.batch.ids_cols is not None and tb.ntok == tb.B * plan.S:
+        call("wd_hash_bucket_cols", ptr(tb.bytes), ptr(tb.tok_offs), tb.ntok, ptr(slots_dev), plan.S, ptr(tb.ids),
+             ptr(tb.batch.ids_cols), st)
+        return tb.batch
     call("wd_hash_bucket", ptr(tb.bytes), ptr(tb.tok_offs), tb.ntok, None if tb.one_per_bag else ptr(tb.bag_offs),
          tb.B * plan.S, ptr(slots_dev), plan.S, ptr(tb.ids), st)
     return tb.batch

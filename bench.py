@@ -116,7 +116,7 @@ def pmc_traffic(args, bt, plan):
             for r in csv.DictReader(open(f[0])):
                 if r["Counter_Name"] != ctr:
                     continue
-                if "k_embag_fwd" in r["Kernel_Name"]:
+                if "k_embag_fwd" in r["Kernel_Name"] or "k_prefetch_onehot" in r["Kernel_Name"]:
                     g.append(float(r["Counter_Value"]))
                 elif "copy" in r["Kernel_Name"].lower():
                     c.append(float(r["Counter_Value"]))
@@ -144,8 +144,13 @@ def gather_kernel_roofline(eng, batches, args, iters=200):
     st = torch.cuda.current_stream().cuda_stream
     (dim, gs), = list(eng.group_slots.items())[:1]
 
+    pf = bool(getattr(eng, "prefetch", False) and batches[0].one_hot)
+
     def run(i):
-        eng.embag_fwd(dim, gs, batches[i % len(batches)], xp, ld, st)
+        if pf:       # the input layer as the step launches it: records -> x, wide weights, numeric columns
+            eng._prefetch_input(batches[i % len(batches)], st, i % eng.n_act)
+        else:
+            eng.embag_fwd(dim, gs, batches[i % len(batches)], xp, ld, st)
 
     for i in range(10):
         run(i)
@@ -155,15 +160,18 @@ def gather_kernel_roofline(eng, batches, args, iters=200):
     alg = gather_alg_bytes(plan, bt, dim, gs.numel())
     gbs = alg / (ms * 1e-3) / 1e9
     traffic, src = (None, "skipped (--no-pmc)") if args.no_pmc else pmc_traffic(args, bt, plan)
-    kname = ("k_embag_fwd<%d> on %d-byte row records" % (dim // 4, 4 * eng.rec_stride) if eng.rec is not None
+    kname = ("k_prefetch_onehot<%d, 1> on %d-byte row records" % (dim // 4, 4 * eng.rec_stride) if pf
+             else "k_embag_fwd<%d> on %d-byte row records" % (dim // 4, 4 * eng.rec_stride) if eng.rec is not None
              else "k_embag_fwd_range<%d, 2, %s>" % (dim // 4, "true" if bt.one_hot else "false"))
     return {"bound": "hbm", "kernel": kname,
             "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
             "traffic": traffic, "traffic_source": src, "algorithmic_bytes_per_launch": int(alg),
             "avg_launch_us": round(ms * 1e3, 2),
-            "note": "the embedding-bag gather of the C ABI timed as its own launch on the engine's table layout; one-id-per-bag "
-                    "batches take the same rows through the gather phase of k_tower_chain inside the step (`roofline`), "
-                    "multi-hot batches through k_input_layer / this kernel"}
+            "note": ("the input-layer launch of the step (wd_prefetch_onehot: one 128-byte record per id -> embedding row into x, wide "
+                     "weight into the per-occurrence list, numeric columns) timed alone, back to back over the resident pool; the "
+                     "same launch inside the pipelined step, beside the tower of the previous batch, is `roofline`" if pf else
+                     "the embedding-bag gather of the C ABI timed as its own launch on the engine's table layout; multi-hot "
+                     "batches take it (or k_input_layer) inside the step")}
 
 
 def gather_instep_roofline(eng, dev_batches, step_eager, steps=16):
@@ -177,7 +185,34 @@ def gather_instep_roofline(eng, dev_batches, step_eager, steps=16):
     (dim, gs), = list(eng.group_slots.items())[:1]
     alg = gather_alg_bytes(plan, bt0, dim, gs.numel())
     side = torch.cuda.Stream()
-    if getattr(eng, "chain", False) and eng._chain_input_ok(bt0):
+    if getattr(eng, "prefetch", False) and eng._chain_input_ok(bt0):
+        # the input layer is its own launch (wd_prefetch_onehot), issued one step ahead beside the tower of the previous batch:
+        # every workgroup stores the chip-wide realtime clock (100 MHz) at its start and end (per activation buffer);
+        # a 3-step pipelined hipGraph (as timed) runs the launches of steps 1 and 2 beside towers 0 and 1
+        from wide_deep_amd import pipeline
+        nblk = eng.prefetch_blocks(bt0.B)
+        span = torch.zeros(eng.n_act, nblk, 2, dtype=torch.int64, device="cuda")
+        eng._prefetch_span = span.data_ptr()
+        durs = []
+        try:
+            nb = len(dev_batches)
+            graphs = [pipeline.StepGraph(eng, [dev_batches[(j + i) % nb] for i in range(3)], stream=side)
+                      for j in range(0, min(nb, 12), 3)]
+            for i in range(steps + 2):
+                graphs[i % len(graphs)].replay()
+                torch.cuda.synchronize()
+                v = span.cpu()
+                if i >= 2:
+                    durs += [float(v[p, :, 1].max() - v[p, :, 0].min()) / 100.0 for p in (1, 2)]
+            del graphs
+        finally:
+            eng._prefetch_span = None
+        us = sum(durs) / len(durs)
+        kernel = "k_prefetch_onehot<%d, 1> (the input layer of batch t+1, launched beside the tower of batch t)" % (dim // 4)
+        how = ("realtime-clock stamps of the launch's workgroups, first start -> last end, for the two overlapped launches of a "
+               "3-step pipelined hipGraph replay (as timed), mean of %d launches (min %.2f, max %.2f us)"
+               % (len(durs), min(durs), max(durs)))
+    elif getattr(eng, "chain", False) and eng._chain_input_ok(bt0):
         # the steps run exactly as in the timed region: a (pipelined) hipGraph of 4 train steps on 4 resident batches, captured
         # with the stamp buffer attached; after each replay the buffer holds the stamps of the graph's LAST step
         from wide_deep_amd import pipeline
@@ -217,13 +252,15 @@ def gather_instep_roofline(eng, dev_batches, step_eager, steps=16):
     gbs = alg / us / 1e3
     return {"bound": "hbm", "kernel": kernel, "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
-            "traffic_source": "no per-phase counter exists; the PMC traffic of the same rows through the stand-alone kernel is in "
-                              "roofline_gather_kernel",
+            "traffic_source": "PMC counters are per launch, not per overlap window: the traffic of this launch, measured alone, is "
+                              "in roofline_gather_kernel",
             "algorithmic_bytes_per_launch": int(alg), "avg_launch_us": round(us, 2), "measured": how,
-            "note": "algorithmic bytes = SURVEY 8(d) gather contract only; the phase also reads the wide weight of every occurrence "
+            "note": "algorithmic bytes = SURVEY 8(d) gather contract only; the launch also reads the wide weight of every occurrence "
                     + ("(row records: it sits in the line fetched for the embedding row)" if eng.rec is not None
                        else "(one more 16-byte {w,z,n} line per occurrence)")
-                    + ", the numeric columns, and writes the wide logit (not counted)"}
+                    + ", the numeric columns, and writes the wide weights / logit (not counted)"
+                    + ("; it shares the chip with the tower kernel of the previous batch, off the critical path of the step"
+                       if getattr(eng, "prefetch", False) else "")}
 
 
 def synth_hash(eng, tb):

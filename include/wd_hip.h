@@ -343,8 +343,9 @@ int wd_row_update(float *rec, int32_t rec_stride, int32_t dim, float *emb_accum,
  * python/lib/linear.py:29-36): x[b*ldx + out_col_s + 0..dim) = rec[row(b,s)][0..dim), wide_vals[b*S + s] = rec[row(b,s)][dim]
  * (the wide weight, NOT summed: wd_tower_chain adds them up with the bias, wd_chain_opts_t.wide_vals), numeric columns as
  * wd_dense_fwd.  rec_slots: slot descriptors with emb_off = row_base * rec_stride.  dim in {4, 8, 16}.
- * span (diagnostics, may be NULL): device uint64[2], the chip-wide 100 MHz realtime clock at the start of the first
- * (atomic min into span[0]) and the end of the last workgroup (atomic max into span[1]); the caller resets {~0, 0}. */
+ * span (diagnostics, may be NULL): device uint64[wd_prefetch_onehot_blocks(..)][2], the chip-wide 100 MHz realtime clock at the
+ * start and at the end of every workgroup of the launch. */
+int64_t wd_prefetch_onehot_blocks(int64_t batch, int32_t S, int32_t dim, int32_t ncols);
 int wd_prefetch_onehot(const float *rec, int32_t rec_stride, int32_t dim, const wd_slot_t *rec_slots, int32_t S,
                        const int32_t *ids, int64_t batch, float *x, int64_t ldx, float *wide_vals, const float *dense,
                        int64_t ld_dense, const wd_dense_col_t *dense_cols, int32_t ncols, void *span, wd_stream_t stream);

@@ -43,6 +43,10 @@ int wd_tsv_fill(const uint8_t *buf, const int64_t *starts, const int64_t *ends, 
 void wd_vocab_lookup(const uint8_t *tok_bytes, const int32_t *tok_offs, int64_t t0, int64_t t1, const uint8_t *vocab_bytes,
                      const int32_t *vocab_offs, int32_t nvocab, int32_t *out);
 
+/* CRC-32C of data[0..n) continued from `crc` (0 to start; unmasked) -- the per-entry / per-block checksum of TensorFlow's
+ * checkpoint container (wide_deep_amd/tf_checkpoint.py: python/train.py:188-191 leaves such files in model_dir). */
+uint32_t wd_crc32c(const uint8_t *data, int64_t n, uint32_t crc);
+
 #ifdef __cplusplus
 }
 #endif

@@ -32,16 +32,24 @@ for _ in range(3):
     dst.copy_(src)
 torch.cuda.synchronize()
 
+# the gather as the engine launches it: wd_prefetch_onehot (row records + wide weights + numeric columns: what the step runs
+# for one-id-per-bag batches) or the embedding-bag kernel of the C ABI
+if eng.prefetch and bts[0].one_hot:
+    run = lambda i: eng._prefetch_input(bts[i % pool], st, i % eng.n_act)
+    kname = "prefetch_onehot"
+else:
+    run = lambda i: eng.embag_fwd(dim, gs, bts[i % pool], xp, ld, st)
+    kname = "embag_fwd"
 for i in range(10):
-    eng.embag_fwd(dim, gs, bts[i % pool], xp, ld, st)
+    run(i)
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
 for i in range(iters):
-    eng.embag_fwd(dim, gs, bts[i % pool], xp, ld, st)
+    run(i)
 e1.record(); e1.synchronize()
 us = e0.elapsed_time(e1) / iters * 1e3
 bt = bts[0]
 alg = bt.nnz * dim * 4 + bt.nnz * 4 + (bt.B * plan.S + 1) * 4 + bt.B * gs.numel() * dim * 4
-print(json.dumps({"kernel": "embag_fwd", "ids": dist, "avg_us": round(us, 2), "alg_bytes": alg,
+print(json.dumps({"kernel": kname, "ids": dist, "avg_us": round(us, 2), "alg_bytes": alg,
                   "GBps": round(alg / us / 1e3, 1), "frac_of_8TBps": round(alg / us / 1e3 / 8000, 4)}))

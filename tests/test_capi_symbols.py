@@ -38,7 +38,7 @@ def test_ingest_library_exports_its_header():
     src = open(os.path.join(ROOT, "include", "wd_ingest.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     names = sorted(set(re.findall(r"\b(wd_[a-z0-9_]+)\s*\(", src)))
-    assert names == ["wd_tsv_count", "wd_tsv_fill", "wd_tsv_scan", "wd_vocab_lookup"]
+    assert names == ["wd_crc32c", "wd_tsv_count", "wd_tsv_fill", "wd_tsv_scan", "wd_vocab_lookup"]
     if not os.path.exists(dataset._INGEST_PATH):
         import __graft_entry__
         __graft_entry__.build()

@@ -109,9 +109,20 @@ def test_bundle_round_trip_with_the_engines_variable_names(tmp_path):
     for k, v in state.items():
         assert got[k].dtype == v.dtype and got[k].shape == v.shape and np.array_equal(got[k], v), k
     assert got["global_step"].shape == () and int(got["global_step"]) == 1234
-    # keys are stored in byte order; the header entry comes first
-    keys = [k for k, _ in T.read_table(prefix + ".index")]
-    assert keys[0] == b"" and keys[1:] == sorted(k.encode() for k in state)
+    # keys are stored in byte order; the header entry comes first; the variables of the dnn / linear scopes are stored the way
+    # the reference's partitioner scopes make TensorFlow store them: an entry with the full shape + a slice, the data under the slice key
+    table = T.read_table(prefix + ".index")
+    keys = [k for k, _ in table]
+    assert keys[0] == b"" and keys[1:] == sorted(keys[1:])
+    assert sorted(k for k in keys[1:] if k[:1] != b"\0") == sorted(k.encode() for k in state)
+    ent = {k: T.parse_entry(v) for k, v in table[1:]}
+    nm = b"dnn/dnn_1/hiddenlayer_0/kernel"
+    assert ent[nm]["slices"] == [[(0, 29), (0, 8)]] and ent[nm]["shape"] == (29, 8) and ent[nm]["size"] == 0
+    sk = T.encode_tensor_name_slice(nm, [(0, 29), (0, 8)])
+    assert ent[sk]["shape"] == (29, 8) and ent[sk]["size"] == 29 * 8 * 4 and not ent[sk]["slices"]
+    assert not ent[b"global_step"]["slices"] and not ent[b"d"]["slices"]
+    # the state file tf.train.latest_checkpoint reads
+    assert open(str(tmp_path / "m" / "checkpoint")).read().startswith('model_checkpoint_path: "model.ckpt-1234"')
     # corrupted tensor bytes are caught by the entry checksum
     data = bytearray(open(prefix + ".data-00000-of-00001", "rb").read())
     data[3] ^= 1
@@ -119,9 +130,7 @@ def test_bundle_round_trip_with_the_engines_variable_names(tmp_path):
     with pytest.raises(ValueError, match="data checksum"):
         T.read_tf_checkpoint(prefix)
     assert sorted(T.read_tf_checkpoint(prefix, verify_checksums=False)) == sorted(state)
-    # partitioned variables (entries with `slices`) and string tensors are refused, not misread
-    e = T.encode_entry(1, (4,), 0, 16, 0) + T._pb_bytes(7, b"\x0a\x02\x08\x01")
-    assert T.parse_entry(e)["slices"] == 1
+    # string tensors are refused, not misread
     with pytest.raises(ValueError, match="dtype"):
         T.write_tf_checkpoint(str(tmp_path / "s"), {"s": np.asarray(["a"])})
 
@@ -130,9 +139,65 @@ def test_latest_tf_checkpoint_follows_the_state_file(tmp_path):
     d = str(tmp_path)
     assert T.latest_tf_checkpoint(d) is None
     for step in (10, 200, 30):
-        T.write_tf_checkpoint(os.path.join(d, "model.ckpt-%d" % step), {"global_step": np.asarray(step, np.int64)})
-    assert T.latest_tf_checkpoint(d) == os.path.join(d, "model.ckpt-200")
+        T.write_tf_checkpoint(os.path.join(d, "model.ckpt-%d" % step), {"global_step": np.asarray(step, np.int64)}, state_file=False)
+    assert T.latest_tf_checkpoint(d) == os.path.join(d, "model.ckpt-200")         # no state file: the highest step
+    T.write_tf_checkpoint(os.path.join(d, "model.ckpt-30"), {"global_step": np.asarray(30, np.int64)})
+    assert T.latest_tf_checkpoint(d) == os.path.join(d, "model.ckpt-30")          # the writer's own state file points at its prefix
     open(os.path.join(d, "checkpoint"), "w").write('model_checkpoint_path: "model.ckpt-30"\nall_model_checkpoint_paths: "model.ckpt-10"\n')
     assert T.latest_tf_checkpoint(d) == os.path.join(d, "model.ckpt-30")
     open(os.path.join(d, "checkpoint"), "w").write('model_checkpoint_path: "model.ckpt-99"\n')      # stale pointer
     assert T.latest_tf_checkpoint(d) == os.path.join(d, "model.ckpt-200")
+
+
+def test_ordered_code_and_slice_keys_hand_assembled():
+    """tensorflow/core/lib/strings/ordered_code.cc, restated: NumIncreasing = length byte + big-endian bytes; String = escaped
+    + 00 01; SignedNumIncreasing = one byte 0x80 ^ v for -64 <= v < 64, else ceil-ish(bits / 7) + 1 bytes of the two's complement
+    with a unary length header (0xc0 for 2 bytes, 0xe0 for 3 ...; inverted for negatives)."""
+    assert T._oc_num_increasing(0) == b"\x00" and T._oc_num_increasing(2) == b"\x01\x02" and T._oc_num_increasing(0x1234) == b"\x02\x12\x34"
+    assert T._oc_string(b"a\x00b\xffc") == b"a\x00\xffb\xff\x00c\x00\x01"
+    for v, enc in ((0, "80"), (1, "81"), (63, "bf"), (-1, "7f"), (-64, "40"), (64, "c040"), (-65, "3fbf"), (8191, "dfff"), (8192, "e02000"),
+                   (1000000, "ef4240"), (-1000000, "10bdc0")):
+        assert T._oc_signed_num_increasing(v).hex() == enc, v
+    # increasing: the byte strings order like the numbers
+    vals = [-(1 << 40), -70000, -8193, -8192, -65, -64, -1, 0, 1, 63, 64, 8191, 8192, 1 << 20, 1 << 40]
+    encs = [T._oc_signed_num_increasing(v) for v in vals]
+    assert encs == sorted(encs)
+    # the key of slice [0, 1000000) x [0, 16) of "a/b": 0 | "a/b" | rank 2 | (0, 1000000) | (0, 16)
+    assert T.encode_tensor_name_slice("a/b", [(0, 1000000), (0, 16)]).hex() == "00" + "612f62" + "0001" + "0102" + "80" + "ef4240" + "80" + "90"
+    # a slice that takes a whole dimension is written with start 0 ... here as TF's TensorSlice (-1 = full) would: (0, -1) -> 80 7f
+    assert T.encode_tensor_name_slice("v", [(0, -1)]).hex() == "00" + "76" + "0001" + "0101" + "80" + "7f"
+
+
+def test_partitioned_variables_multi_slice_round_trip_and_missing_slice(tmp_path):
+    rng = np.random.default_rng(5)
+    state = {"linear/linear_model/C01/weights": rng.standard_normal((1001, 1)).astype(np.float32),
+             "dnn/input_from_feature_columns/input_layer/C01_embedding/embedding_weights": rng.standard_normal((1001, 8)).astype(np.float32),
+             "dnn/dnn_1/hiddenlayer_0/bias": rng.standard_normal(7).astype(np.float32),
+             "global_step": np.asarray(9, np.int64)}
+    prefix = str(tmp_path / "model.ckpt-9")
+    T.write_tf_checkpoint(prefix, state, partitions=3)
+    table = dict(T.read_table(prefix + ".index"))
+    e = T.parse_entry(table[b"linear/linear_model/C01/weights"])
+    assert e["slices"] == [[(0, 333), (0, 1)], [(333, 334), (0, 1)], [(667, 334), (0, 1)]] and e["shape"] == (1001, 1)
+    assert T.parse_entry(table[b"dnn/dnn_1/hiddenlayer_0/bias"])["slices"] == [[(0, 2)], [(2, 2)], [(4, 3)]]
+    got = T.read_tf_checkpoint(prefix)
+    for k, v in state.items():
+        assert np.array_equal(got[k], v), k
+    # an index without one of the slices' data entries is refused
+    pairs = [(k, v) for k, v in T.read_table(prefix + ".index")
+             if k != T.encode_tensor_name_slice("linear/linear_model/C01/weights", [(333, 334), (0, 1)])]
+    T.write_table(prefix + ".index", pairs)
+    with pytest.raises(ValueError, match="slice"):
+        T.read_tf_checkpoint(prefix)
+
+
+def test_large_tensors_carry_a_checksum(tmp_path):
+    """tensors above 4 MB used to be written with crc32c = 0, which TensorFlow's BundleReader rejects."""
+    a = np.arange(3 << 20, dtype=np.float32).reshape(-1, 16)         # 12 MB
+    prefix = str(tmp_path / "model.ckpt-1")
+    T.write_tf_checkpoint(prefix, {"dnn/t/embedding_weights": a})
+    table = dict(T.read_table(prefix + ".index"))
+    sk = T.encode_tensor_name_slice("dnn/t/embedding_weights", [(0, a.shape[0]), (0, 16)])
+    e = T.parse_entry(table[sk])
+    assert e["crc32c"] != 0 and T.unmask_crc(e["crc32c"]) == T.crc32c(a.tobytes())
+    assert np.array_equal(T.read_tf_checkpoint(prefix)["dnn/t/embedding_weights"], a)

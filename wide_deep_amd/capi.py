@@ -190,6 +190,7 @@ _PROTOS = {
     "wd_bucket_sort": [P, P, I32, P, I32, P, I64, I32, P, P, P, P],
     "wd_row_update": [P, I32, I32, P, P, P, I32, I64, P, I64, P, F32, F32, F32, F32, P, P, I32, P, P, P],
     "wd_hash_bucket_cols": [P, P, I64, P, I32, P, P, P],
+    "wd_prefetch_onehot_blocks": [I64, I32, I32, I32],
     "wd_prefetch_onehot": [P, I32, I32, P, I32, P, I64, P, I64, P, P, I64, P, I32, P, P],
     "wd_route_chunks": [],
     "wd_route_build": [P, I32, I32, P, P, I64, I32, P, P, P, P, P, P],
@@ -233,7 +234,7 @@ _PROTOS = {
     "wd_diag_gather64": [P, P, I64, I32, P, P],
     "wd_diag_access": [P, P, P, I32, P, I64, I32, I32, P, P],
 }
-_RESTYPES = {"wd_feat_offsets_workspace_bytes": I64, "wd_sort_workspace_bytes": SZ, "wd_logits_head_blocks": I64, "wd_tower_chain_lds_bytes": I64, "wd_tower_chain_blocks": I64, "wd_bucket_max": I32, "wd_bucket_chunks": I32, "wd_route_chunks": I32}
+_RESTYPES = {"wd_prefetch_onehot_blocks": I64, "wd_feat_offsets_workspace_bytes": I64, "wd_sort_workspace_bytes": SZ, "wd_logits_head_blocks": I64, "wd_tower_chain_lds_bytes": I64, "wd_tower_chain_blocks": I64, "wd_bucket_max": I32, "wd_bucket_chunks": I32, "wd_route_chunks": I32}
 
 EXPORTED_SYMBOLS = sorted(list(_PROTOS) + ["wd_last_error"])
 

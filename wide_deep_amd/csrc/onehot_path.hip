@@ -174,77 +174,79 @@ k_bucket_onehot(const wd_slot_t *__restrict__ slots, int32_t S, const int32_t *_
   }
 }
 
-// LANES = dim / 4 lanes per bag, BPG bags per lane group in flight (independent id -> record chains)
+// LANES = dim / 4 lanes per bag, BPG bags per lane group (independent id -> record chains).  One bag per lane group and no LDS
+// staging of the slot descriptors: the launch is 213 k random 128-byte lines for a C2 batch, and what it needs is wavefronts in
+// flight -- 13 per SIMD this way; four bags per group behind a barrier (3 per SIMD) was 12.5 us instead of 10.
 template <int LANES, int BPG>
 __global__ void __launch_bounds__(256)
 k_prefetch_onehot(const float *__restrict__ rec, int32_t rec_stride, const wd_slot_t *__restrict__ rslots, int32_t S,
                   const int32_t *__restrict__ ids, int64_t B, float *__restrict__ x, int64_t ldx, float *__restrict__ wv,
                   const float *__restrict__ dense, int64_t ld_dense, const wd_dense_col_t *__restrict__ cols,
                   int32_t ncols, int32_t gather_blocks, unsigned long long *__restrict__ span) {
-  constexpr int MAXS = 128;
-  __shared__ int64_t s_off[MAXS];
-  __shared__ int32_t s_col[MAXS];
   const int t = threadIdx.x;
-  // diagnostics (bench.py: the duration of this launch AS IT RUNS INSIDE the pipelined step): chip-wide realtime clock
-  // (100 MHz) at the start of the first and the end of the last workgroup
-  if (span && t == 0) atomicMin(&span[0], (unsigned long long)wall_clock64());
+  // diagnostics (bench.py: the duration of this launch AS IT RUNS INSIDE the pipelined step): every workgroup stores the
+  // chip-wide realtime clock (100 MHz) at its start and end, span[2 * block], [2 * block + 1] (one min / max word for all of
+  // them -- 7500 same-address atomics -- stretched the launch from 11 to 86 us)
+  if (span && t == 0) span[2 * blockIdx.x] = (unsigned long long)wall_clock64();
   if ((int)blockIdx.x >= gather_blocks) {
     // numeric columns (python/lib/build_estimator.py:61-68 normalizers): one thread per (example, column)
     const int64_t i = ((int64_t)blockIdx.x - gather_blocks) * 256 + t;
-    if (i >= B * ncols) return;
-    const int64_t b = i / ncols;
-    const int j = (int)(i - b * ncols);
-    const wd_dense_col_t c = cols[j];
-    float v = dense[b * ld_dense + j];
-    if (c.kind == 1) v = (v - c.p0) / (c.p1 - c.p0);
-    else if (c.kind == 2) v = (v - c.p0) / c.p1;
-    else if (c.kind == 3) v = logf(v);
-    x[b * ldx + c.out_col] = v;
-    return;
-  }
-  typedef float f4 __attribute__((ext_vector_type(4)));
-  const int lane = t % LANES;
-  const int64_t grp = ((int64_t)blockIdx.x * 256 + t) / LANES;
-  const int64_t nwork = B * S;
-  int64_t w[BPG];
-  int32_t id[BPG], sidx[BPG];
-#pragma unroll
-  for (int q = 0; q < BPG; ++q) {
-    w[q] = grp * BPG + q;
-    const int64_t wc = w[q] < nwork ? w[q] : nwork - 1;
-    id[q] = ids[wc];
-    sidx[q] = (int32_t)(wc % S);
-  }
-  for (int i = t; i < S; i += 256) {       // slot descriptors -> LDS while the ids are in flight
-    s_off[i] = rslots[i].emb_off;
-    s_col[i] = rslots[i].out_col;
-  }
-  __syncthreads();
-  f4 r[BPG];
-  float wq[BPG];
-#pragma unroll
-  for (int q = 0; q < BPG; ++q) {
-    r[q] = (f4)(0.f);
-    wq[q] = 0.f;
-    if (id[q] >= 0) {
-      const float *p = rec + s_off[sidx[q]] + (int64_t)id[q] * rec_stride;
-      r[q] = __builtin_nontemporal_load(reinterpret_cast<const f4 *>(p) + lane);
-      if (lane == 0) wq[q] = __builtin_nontemporal_load(p + 4 * LANES);     // {w, z, n, -} behind the row, same line
+    if (i < B * ncols) {
+      const int64_t b = i / ncols;
+      const int j = (int)(i - b * ncols);
+      const wd_dense_col_t c = cols[j];
+      float v = dense[b * ld_dense + j];
+      if (c.kind == 1) v = (v - c.p0) / (c.p1 - c.p0);
+      else if (c.kind == 2) v = (v - c.p0) / c.p1;
+      else if (c.kind == 3) v = logf(v);
+      x[b * ldx + c.out_col] = v;
     }
-  }
+  } else {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const int lane = t % LANES;
+    const int64_t grp = ((int64_t)blockIdx.x * 256 + t) / LANES;
+    const int64_t nwork = B * S;
+    int64_t w[BPG];
+    int32_t id[BPG], sidx[BPG];
 #pragma unroll
-  for (int q = 0; q < BPG; ++q) {
-    if (w[q] >= nwork) continue;
-    const int64_t b = w[q] / S;
-    *reinterpret_cast<f4 *>(x + b * ldx + s_col[sidx[q]] + 4 * lane) = r[q];
-    if (lane == 0) wv[w[q]] = wq[q];
+    for (int q = 0; q < BPG; ++q) {
+      w[q] = grp * BPG + q;
+      const int64_t wc = w[q] < nwork ? w[q] : nwork - 1;
+      id[q] = ids[wc];
+      sidx[q] = (int32_t)(wc % S);
+    }
+    int64_t off[BPG];
+    int32_t col[BPG];
+#pragma unroll
+    for (int q = 0; q < BPG; ++q) {          // (two fields of a 48-byte descriptor: L1 hits, requested with the ids)
+      off[q] = rslots[sidx[q]].emb_off;
+      col[q] = rslots[sidx[q]].out_col;
+    }
+    f4 r[BPG];
+    float wq[BPG];
+#pragma unroll
+    for (int q = 0; q < BPG; ++q) {
+      r[q] = (f4)(0.f);
+      wq[q] = 0.f;
+      if (id[q] >= 0) {
+        const float *p = rec + off[q] + (int64_t)id[q] * rec_stride;
+        r[q] = __builtin_nontemporal_load(reinterpret_cast<const f4 *>(p) + lane);
+        if (lane == 0) wq[q] = __builtin_nontemporal_load(p + 4 * LANES);     // {w, z, n, -} behind the row, same line
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < BPG; ++q) {
+      if (w[q] >= nwork) continue;
+      const int64_t b = w[q] / S;
+      *reinterpret_cast<f4 *>(x + b * ldx + col[q] + 4 * lane) = r[q];
+      if (lane == 0) wv[w[q]] = wq[q];
+    }
   }
   if (span) {
     __syncthreads();       // (every lane's stores are issued; the stamp is a lower bound on their completion by one store latency)
-    if (t == 0) atomicMax(&span[1], (unsigned long long)wall_clock64());
+    if (t == 0) span[2 * blockIdx.x + 1] = (unsigned long long)wall_clock64();
   }
 }
-
 
 // ======================================================================================================================
 // Sorted row lists: everything of the sparse update that needs only the IDS -- bucketing, the sort of every bucket on
@@ -608,9 +610,10 @@ k_row_update(RowUpd u) {
   // new value of a row -> the next batch's prefetched input, wherever that batch reads the row (its pairs from `pj` on: all
   // occurrences of a row are adjacent in the sorted list).  `row` = the D new floats, `wnew` the new wide weight; the callers
   // spread the run over `nl` lanes (lane `l` takes every nl-th pair): a hot row is read hundreds of times by the next batch.
-  auto patch_run = [&](int2 pj, int l, int nl, const float *row, float wnew, int32_t out_col) {
+  // (`first`: the lane's first pair of the run, loaded by the caller with the row -- no extra dependent round trip)
+  auto patch_run = [&](int2 pj, int l, int nl, const float *row, float wnew, int32_t out_col, uint64_t first, bool have_first) {
     for (int k = l; k < pj.y; k += nl) {
-      const int32_t bag2 = (int32_t)(uint32_t)u.npairs[pj.x + k];
+      const int32_t bag2 = (int32_t)(uint32_t)((have_first && k == l) ? first : u.npairs[pj.x + k]);
       float *dst = u.nx + (int64_t)(bag2 / S) * u.nldx + out_col;
       for (int c = 0; c < LG; ++c) *reinterpret_cast<float4 *>(dst + 4 * c) = make_float4(row[4 * c], row[4 * c + 1], row[4 * c + 2], row[4 * c + 3]);
       u.nwv[bag2] = wnew;
@@ -726,7 +729,7 @@ k_row_update(RowUpd u) {
         new_row[16] = r.x;
       }
       __syncthreads();
-      if (pj.y > 0) patch_run(pj, t, 256, new_row, new_row[16], out_col);      // the whole workgroup over the run
+      if (pj.y > 0) patch_run(pj, t, 256, new_row, new_row[16], out_col, 0, false);      // the whole workgroup over the run
       __syncthreads();
     }
     return;
@@ -764,6 +767,8 @@ k_row_update(RowUpd u) {
   const int64_t off = s_acc_off[sidx] + (int64_t)key * D + 4 * gl;
   const int64_t eoff = (int64_t)key * RS + 4 * gl;
   float4 a = make_float4(0.f, 0.f, 0.f, 0.f), w = a, r = a;
+  uint64_t tgt0 = 0;
+  if (gl < pj.y) tgt0 = u.npairs[pj.x + gl];       // the lane's first patch target: in flight with the row
   if (lane_emb) {
     a = *reinterpret_cast<float4 *>(u.accum + off);
     w = *reinterpret_cast<float4 *>(u.rec + eoff);
@@ -831,7 +836,7 @@ k_row_update(RowUpd u) {
       row[4 * c + 2] = __shfl(wn.z, l0 + c, 64); row[4 * c + 3] = __shfl(wn.w, l0 + c, 64);
     }
     const float wnew = __shfl(r.x, l0, 64);
-    patch_run(pj, gl, 4, row, wnew, out_col);
+    patch_run(pj, gl, 4, row, wnew, out_col, tgt0, true);
   }
 }
 
@@ -851,6 +856,11 @@ extern "C" int wd_bucket_onehot(const wd_slot_t *slots, int32_t S, const int32_t
   return wd::check_launch("wd_bucket_onehot");
 }
 
+extern "C" int64_t wd_prefetch_onehot_blocks(int64_t batch, int32_t S, int32_t dim, int32_t ncols) {
+  if (batch <= 0 || S <= 0 || dim <= 0) return 0;
+  return wd::ceil_div(batch * S * (dim / 4), 256) + (ncols > 0 ? wd::ceil_div(batch * ncols, 256) : 0);
+}
+
 extern "C" int wd_prefetch_onehot(const float *rec, int32_t rec_stride, int32_t dim, const wd_slot_t *rec_slots, int32_t S,
                                   const int32_t *ids, int64_t batch, float *x, int64_t ldx, float *wide_vals,
                                   const float *dense, int64_t ld_dense, const wd_dense_col_t *dense_cols, int32_t ncols,
@@ -862,7 +872,7 @@ extern "C" int wd_prefetch_onehot(const float *rec, int32_t rec_stride, int32_t 
   WD_REQUIRE(ldx % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0, "x must be 16-byte aligned with ldx % 4 == 0");
   WD_REQUIRE(ncols == 0 || (dense && dense_cols), "numeric columns need dense + descriptors");
   hipStream_t st = wd::as_stream(stream);
-  constexpr int BPG = 4;
+  constexpr int BPG = 1;
   const int lanes = dim / 4;
   const int64_t groups = wd::ceil_div(batch * S, BPG);
   const int gb = (int)wd::ceil_div(groups * lanes, 256);

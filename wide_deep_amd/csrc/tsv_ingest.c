@@ -212,3 +212,34 @@ void wd_vocab_lookup(const uint8_t *tok_bytes, const int32_t *tok_offs, int64_t 
     out[t - t0] = hit;
   }
 }
+
+
+/* CRC-32C (Castagnoli, reflected 0x82F63B78), slice-by-8: the checksum TensorFlow's tensor bundle stores per entry and per table
+ * block (tensorflow/core/lib/hash/crc32c).  crc = running value (0 to start); returns the updated CRC (not masked). */
+static uint32_t crc_tab[8][256];
+static int crc_ready = 0;
+
+static void crc_init(void) {
+  for (uint32_t i = 0; i < 256; ++i) {
+    uint32_t c = i;
+    for (int k = 0; k < 8; ++k) c = (c & 1) ? (c >> 1) ^ 0x82F63B78u : c >> 1;
+    crc_tab[0][i] = c;
+  }
+  for (uint32_t i = 0; i < 256; ++i)
+    for (int t = 1; t < 8; ++t) crc_tab[t][i] = (crc_tab[t - 1][i] >> 8) ^ crc_tab[0][crc_tab[t - 1][i] & 0xff];
+  crc_ready = 1;
+}
+
+uint32_t wd_crc32c(const uint8_t *data, int64_t n, uint32_t crc) {
+  if (!crc_ready) crc_init();
+  uint32_t c = crc ^ 0xFFFFFFFFu;
+  int64_t i = 0;
+  for (; i + 8 <= n; i += 8) {
+    const uint32_t lo = ((uint32_t)data[i] | (uint32_t)data[i + 1] << 8 | (uint32_t)data[i + 2] << 16 | (uint32_t)data[i + 3] << 24) ^ c;
+    const uint32_t hi = (uint32_t)data[i + 4] | (uint32_t)data[i + 5] << 8 | (uint32_t)data[i + 6] << 16 | (uint32_t)data[i + 7] << 24;
+    c = crc_tab[7][lo & 0xff] ^ crc_tab[6][(lo >> 8) & 0xff] ^ crc_tab[5][(lo >> 16) & 0xff] ^ crc_tab[4][lo >> 24] ^
+        crc_tab[3][hi & 0xff] ^ crc_tab[2][(hi >> 8) & 0xff] ^ crc_tab[1][(hi >> 16) & 0xff] ^ crc_tab[0][hi >> 24];
+  }
+  for (; i < n; ++i) c = crc_tab[0][(c ^ data[i]) & 0xff] ^ (c >> 8);
+  return c ^ 0xFFFFFFFFu;
+}

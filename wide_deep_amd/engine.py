@@ -400,7 +400,7 @@ class WideDeepEngine:
         self.chain = False
         self.prefetch, self._apar, self._prefetched = False, 0, False
         self.flat_update = False
-        self._prefetch_span = None       # diagnostics: device pointer of uint64[2] {first start, last end} of wd_prefetch_onehot
+        self._prefetch_span = None       # diagnostics: device pointer of uint64[n_act][prefetch_blocks][2] {start, end} of every workgroup of wd_prefetch_onehot
         self._chain_tile_stamps = None   # diagnostics: device uint64[2 * tiles] realtime-clock stamps (bench.py: in-step gather span)
         self._chain_stamps = None    # diagnostics: device int64[64] for the tower kernel's stage stamps (scripts/bench_chain.py)
         plan = self.plan
@@ -507,6 +507,11 @@ class WideDeepEngine:
         # update itself is a flat launch over the sorted pairs (wd_row_update).  WD_FLAT_UPDATE=0: wd_sparse_apply_rec.
         self.flat_update = os.environ.get("WD_FLAT_UPDATE", "1") != "0" and self.plan.S <= 128
 
+    def prefetch_blocks(self, B):
+        """workgroups of a wd_prefetch_onehot launch (size of its diagnostic stamp array)"""
+        (dim, sl), = self.plan.emb_groups.items()
+        return int(call("wd_prefetch_onehot_blocks", B, self.plan.S, dim, len(self.plan.dense_cols)))
+
     def _prefetch_input(self, bt, st, p):
         """Input layer of `bt` into activation buffer p: embedding rows + numeric columns -> x, wide weights -> wv[p]."""
         plan, tw = self.plan, self.towers[0]
@@ -515,7 +520,7 @@ class WideDeepEngine:
         call("wd_prefetch_onehot", ptr(self.rec), self.rec_stride, dim, ptr(self.rslots_dev), plan.S, ptr(bt.ids), bt.B,
              tw["acts"][p].data_ptr() + 4 * tw["layout"].seg_start[0], tw["layout"].ld, ptr(self.wv[p]),
              ptr(bt.dense) if nd else None, bt.dense.stride(0) if nd else 0, ptr(self.dense_cols_dev) if nd else None, nd,
-             self._prefetch_span, st)
+             self._prefetch_span + 16 * p * self.prefetch_blocks(bt.B) if self._prefetch_span else None, st)
 
     def _fold(self, train, st):
         """One launch: fold the BN affines of every layer into its consumer's weights (+ the MFMA-fragment-packed copies

@@ -139,6 +139,7 @@ class WideAndDeepClassifier(object):
             if path.endswith(".index"):
                 from .tf_checkpoint import read_tf_checkpoint
                 state = {k: torch.from_numpy(v) for k, v in read_tf_checkpoint(path[:-len(".index")]).items()}
+                self._check_tf_state(state, path)
             else:
                 state = torch.load(path, map_location="cpu")
             if self._world() > 1:
@@ -148,6 +149,42 @@ class WideAndDeepClassifier(object):
                 self._engine.import_state(state)
             self._restored_from = path
         return path
+
+    def _check_tf_state(self, state, path):
+        """A TensorFlow bundle is matched BY NAME: a variable this model expects that the file does not hold (a naming or
+        partitioning difference) must not silently resume from fresh weights while global_step is restored -- raise, naming
+        what is missing; shapes are checked before anything is copied; variables of the file nobody reads are listed."""
+        if self._world() > 1:
+            gp = self._engine.global_plan
+            rows = {}
+            for sl in gp.slots:
+                rows["dnn/input_from_feature_columns/input_layer/%s/embedding_weights" % sl.deep_name] = int(sl.num_buckets)
+                rows["linear/linear_model/%s/weights" % sl.name] = int(sl.num_buckets)
+            want = {}
+            for k, v in self._engine.export_state().items():
+                shape = tuple(v.shape)
+                base = k
+                for suf in ("/Adagrad", "/Ftrl_1", "/Ftrl"):
+                    if base.endswith(suf):
+                        base = base[: -len(suf)]
+                if base in rows:
+                    shape = (rows[base],) + shape[1:]
+                want[k] = shape
+        else:
+            want = {k: tuple(v.shape) for k, v in self._engine.export_state().items()}
+        skip = lambda k: k == "global_step" or k.endswith("/moving_mean") or k.endswith("/moving_variance")
+        missing = sorted(k for k in want if k not in state and not skip(k))
+        if missing:
+            raise ValueError("%s does not hold %d of the variables this model restores by name (first: %s); variables of the "
+                             "file: %s ..." % (path, len(missing), ", ".join(missing[:4]), ", ".join(sorted(state)[:4])))
+        bad = [(k, tuple(state[k].shape), want[k]) for k in want
+               if k in state and not skip(k) and int(np.prod(state[k].shape)) != int(np.prod(want[k]))]
+        if bad:
+            raise ValueError("%s: shape mismatch for %s" % (path, "; ".join("%s is %s, the model has %s" % b for b in bad[:4])))
+        unused = sorted(k for k in state if k not in want)
+        if unused and self._rank() == 0:
+            print("INFO: %d variables of %s are not part of this model and are ignored (first: %s)"
+                  % (len(unused), path, ", ".join(unused[:4])))
 
     def save_checkpoint(self):
         if not self.model_dir:

@@ -195,6 +195,9 @@ class Featurizer(object):
         for i, (vb, vo, nv) in self.vocab_packed.items():
             self.vocab_dev[i] = (torch.from_numpy(vb).to(dev), torch.from_numpy(vo).to(dev), nv)
         self._fs = torch.cuda.Stream(device=dev)
+        # the tables above were uploaded on the caller's stream: one edge, once, so that the featurizer's own stream -- which is
+        # deliberately NOT ordered behind the training stream per batch -- never reads them before they have arrived
+        self._fs.wait_stream(torch.cuda.current_stream(dev))
         self._scan_ws = None
 
     def _to_device_dev(self, raw):

@@ -16,9 +16,18 @@ known answers and the container against itself):
     size = 5, crc32c = 6 (fixed32, masked), slices = 7}  (tensorflow/core/protobuf/tensor_bundle.proto).
   * `.data-SSSSS-of-NNNNN` holds the raw little-endian tensor bytes at [offset, offset + size).
 
-Only what the reference's checkpoints contain is handled: float / double / int32 / int64 / bool tensors that are not
-partitioned (an entry with `slices` raises).  Variable names are the reference's, i.e. exactly the keys of
-WideDeepEngine.export_state() / import_state().
+  * PARTITIONED variables -- every variable of the reference's `dnn` and `linear` scopes, which are created under a partitioner
+    (python/lib/joint.py:140-143, 165-168, 186-189), even with a single partition -- are stored as SLICES: the entry under the
+    variable's full name carries dtype, the FULL shape and `slices` (repeated TensorSliceProto {repeated Extent {start = 1,
+    length = 2}}) and no data; each slice's data sits under the key  EncodeTensorNameSlice(full name, slice)
+    (tensorflow/core/util/saved_tensor_slice_util.cc) = OrderedCode[ NumIncreasing(0), String(name), NumIncreasing(rank),
+    then per dimension SignedNumIncreasing(start), SignedNumIncreasing(length) ]  with its own BundleEntryProto (shape = the
+    slice's).  The reader assembles the full tensor; the writer stores the `dnn/` and `linear/` variables that way (one slice
+    covering the variable, or `partitions` row ranges).  Optimizer slots of a partitioned variable are sliced under
+    "<full name>/<slot>" (tf.train slot_creator), i.e. the names export_state() already uses.
+
+Only what the reference's checkpoints contain is handled: float / double / int32 / int64 / bool tensors.  Variable names are the
+reference's, i.e. exactly the keys of WideDeepEngine.export_state() / import_state().
 """
 import os
 import struct
@@ -45,8 +54,33 @@ def _crc_table():
 _CRC = _crc_table()
 
 
+_native_crc = None
+
+
+def _native():
+    """wd_crc32c of libwd_ingest.so (slice-by-8 in C: gigabytes of embedding tables per second), or False."""
+    global _native_crc
+    if _native_crc is None:
+        _native_crc = False
+        try:
+            import ctypes
+            path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_lib", "libwd_ingest.so")
+            if os.path.exists(path):
+                fn = ctypes.CDLL(path).wd_crc32c
+                fn.restype = ctypes.c_uint32
+                fn.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_uint32]
+                _native_crc = fn
+        except (OSError, AttributeError):
+            _native_crc = False
+    return _native_crc
+
+
 def crc32c(data, crc=0):
     """CRC-32C (Castagnoli, reflected polynomial 0x82F63B78), the checksum of leveldb tables and bundle entries."""
+    fn = _native()
+    if fn and len(data) >= 64:
+        a = np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else np.ascontiguousarray(data).view(np.uint8).reshape(-1)
+        return int(fn(a.ctypes.data, a.size, crc))
     c = crc ^ 0xFFFFFFFF
     for b in bytes(data):
         c = _CRC[(c ^ b) & 0xFF] ^ (c >> 8)
@@ -179,8 +213,71 @@ def _encode_shape(shape):
     return b"".join(_pb_bytes(2, _pb_varint(1, int(d))) for d in shape)
 
 
+# ---- OrderedCode (tensorflow/core/lib/strings/ordered_code.cc) and slice keys -----------------------------------------------------
+def _oc_num_increasing(v):
+    """WriteNumIncreasing: one length byte n (0..8) + the n significant big-endian bytes of the unsigned value."""
+    b = int(v).to_bytes(8, "big").lstrip(b"\0")
+    return bytes([len(b)]) + b
+
+
+def _oc_string(sv):
+    """WriteString: 0x00 -> 00 ff, 0xff -> ff 00, terminated by 00 01."""
+    return b"".join((b"\x00\xff" if c == 0 else b"\xff\x00" if c == 0xff else bytes([c])) for c in bytes(sv)) + b"\x00\x01"
+
+
+_OC_HEADER = [(0, 0), (0x80, 0), (0xc0, 0), (0xe0, 0), (0xf0, 0), (0xf8, 0), (0xfc, 0), (0xfe, 0), (0xff, 0), (0xff, 0x80),
+              (0xff, 0xc0)]
+
+
+def _oc_signed_num_increasing(val):
+    """WriteSignedNumIncreasing: the value's two's-complement big-endian bytes, shortened to len = bits / 7 + 1 bytes, the
+    leading bits replaced by a unary length header (x < 64: the single byte 0x80 ^ val)."""
+    val = int(val)
+    x = ~val if val < 0 else val
+    if x < 64:
+        return bytes([(0x80 ^ val) & 0xff])
+    bits = x.bit_length()
+    ln = bits // 7 + 1
+    buf = bytearray((b"\xff" if val < 0 else b"\x00") * 2 + (val & ((1 << 64) - 1)).to_bytes(8, "big"))
+    begin = len(buf) - ln
+    buf[begin] ^= _OC_HEADER[ln][0]
+    buf[begin + 1] ^= _OC_HEADER[ln][1]
+    return bytes(buf[begin:])
+
+
+def encode_tensor_name_slice(name, extents):
+    """Key of a slice's data entry; extents = [(start, length)] per dimension ((0, -1) = the whole dimension)."""
+    out = _oc_num_increasing(0) + _oc_string(name.encode() if isinstance(name, str) else name) + _oc_num_increasing(len(extents))
+    for start, length in extents:
+        out += _oc_signed_num_increasing(start) + _oc_signed_num_increasing(length)
+    return out
+
+
+def _parse_slice(buf):
+    """TensorSliceProto -> [(start, length)], length -1 = the full dimension."""
+    ext = []
+    for num, wt, v in _pb_fields(buf):
+        if num == 1 and wt == 2:
+            start, length = 0, -1
+            for n2, w2, v2 in _pb_fields(v):
+                if n2 == 1 and w2 == 0:
+                    start = _signed64(v2)
+                elif n2 == 2 and w2 == 0:
+                    length = _signed64(v2)
+            ext.append((start, length))
+    return ext
+
+
+def _encode_slice(extents):
+    out = b""
+    for start, length in extents:
+        e = (_pb_varint(1, start) if start else b"") + (_pb_varint(2, length) if length >= 0 else b"")
+        out += _pb_bytes(1, e)
+    return out
+
+
 def parse_entry(buf):
-    e = {"dtype": 0, "shape": (), "shard_id": 0, "offset": 0, "size": 0, "crc32c": 0, "slices": 0}
+    e = {"dtype": 0, "shape": (), "shard_id": 0, "offset": 0, "size": 0, "crc32c": 0, "slices": []}
     for num, wt, v in _pb_fields(buf):
         if num == 1 and wt == 0:
             e["dtype"] = v
@@ -194,13 +291,15 @@ def parse_entry(buf):
             e["size"] = v
         elif num == 6 and wt == 5:
             e["crc32c"] = v
-        elif num == 7:
-            e["slices"] += 1
+        elif num == 7 and wt == 2:
+            e["slices"].append(_parse_slice(v))
     return e
 
 
-def encode_entry(dtype_id, shape, offset, size, crc_masked):
+def encode_entry(dtype_id, shape, offset, size, crc_masked, slices=None):
     out = _pb_varint(1, dtype_id) + _pb_bytes(2, _encode_shape(shape))
+    if slices:          # the entry of a partitioned variable: full shape + its slices, no data of its own
+        return out + b"".join(_pb_bytes(7, _encode_slice(sl)) for sl in slices)
     if offset:
         out += _pb_varint(4, offset)
     out += _pb_varint(5, size) + put_varint((6 << 3) | 5) + struct.pack("<I", crc_masked)
@@ -323,14 +422,11 @@ def read_tf_checkpoint(prefix, verify_checksums=True):
     if endian != 0:
         raise ValueError("big-endian checkpoints are not supported")
     shards = {}
-    out = {}
-    for key, val in entries[1:]:
-        e = parse_entry(val)
-        name = key.decode()
-        if e["slices"]:
-            raise ValueError("variable `%s` is stored as slices of a partitioned variable; not supported" % name)
+    parsed = {key: parse_entry(val) for key, val in entries[1:]}
+
+    def load(key, e, what):
         if e["dtype"] not in _DTYPES:
-            raise ValueError("variable `%s`: unsupported dtype enum %d" % (name, e["dtype"]))
+            raise ValueError("variable `%s`: unsupported dtype enum %d" % (what, e["dtype"]))
         sid = e["shard_id"]
         if sid not in shards:
             shards[sid] = np.memmap(_data_path(prefix, sid, nshards), dtype=np.uint8, mode="r")
@@ -338,32 +434,90 @@ def read_tf_checkpoint(prefix, verify_checksums=True):
         dt = _DTYPES[e["dtype"]]
         n = int(np.prod(e["shape"])) if e["shape"] else 1
         if n * dt.itemsize != e["size"]:
-            raise ValueError("variable `%s`: %d bytes for shape %s" % (name, e["size"], e["shape"]))
-        if verify_checksums and e["crc32c"] and e["size"] <= (1 << 22):     # (pure-Python CRC: small tensors only)
-            if unmask_crc(e["crc32c"]) != crc32c(raw.tobytes()):
-                raise ValueError("variable `%s`: data checksum mismatch" % name)
-        out[name] = np.frombuffer(raw.tobytes(), dtype=dt).reshape(e["shape"]).copy()
+            raise ValueError("variable `%s`: %d bytes for shape %s" % (what, e["size"], e["shape"]))
+        if verify_checksums and e["crc32c"] and (e["size"] <= (1 << 22) or _native()):   # (pure-Python CRC: small tensors only)
+            if unmask_crc(e["crc32c"]) != crc32c(raw):
+                raise ValueError("variable `%s`: data checksum mismatch" % what)
+        return np.frombuffer(raw.tobytes(), dtype=dt).reshape(e["shape"]).copy()
+
+    out = {}
+    for key, e in parsed.items():
+        if key[:1] == b"\0":            # the data entry of a slice: read through its variable's entry
+            continue
+        name = key.decode()
+        if not e["slices"]:
+            out[name] = load(key, e, name)
+            continue
+        # a partitioned variable: assemble the full tensor from its slices (disjoint hyper-rectangles covering it)
+        if e["dtype"] not in _DTYPES:
+            raise ValueError("variable `%s`: unsupported dtype enum %d" % (name, e["dtype"]))
+        full = np.zeros(e["shape"], dtype=_DTYPES[e["dtype"]])
+        covered = 0
+        for ext in e["slices"]:
+            skey = encode_tensor_name_slice(key, ext)
+            if skey not in parsed:
+                raise ValueError("variable `%s`: the data of slice %s is missing from the index" % (name, ext))
+            part = load(skey, parsed[skey], "%s %s" % (name, ext))
+            idx = tuple(slice(st, None if ln < 0 else st + ln) for st, ln in ext)
+            if full[idx].shape != part.shape:
+                raise ValueError("variable `%s`: slice %s has shape %s" % (name, ext, part.shape))
+            full[idx] = part
+            covered += part.size
+        if covered != full.size:
+            raise ValueError("variable `%s`: its slices cover %d of %d elements" % (name, covered, full.size))
+        out[name] = full
     return out
 
 
-def write_tf_checkpoint(prefix, tensors, checksum_limit=1 << 22):
-    """Write {name: array} as a one-shard bundle.  Tensors larger than `checksum_limit` bytes get crc32c = 0 (a pure-Python CRC
-    over gigabytes of embedding tables is not practical); readers that verify entry checksums will reject those."""
+def reference_partitioned(name):
+    """The variables the reference creates under a partitioner scope (python/lib/joint.py:140-143, 165-168, 186-189): everything
+    of the `dnn` and `linear` scopes, optimizer slots included -- stored as slices even when there is one partition."""
+    return name.startswith("dnn/") or name.startswith("linear/")
+
+
+def write_tf_checkpoint(prefix, tensors, sliced=reference_partitioned, partitions=1, state_file=True):
+    """Write {name: array} as a one-shard bundle.  `sliced(name)`: store the variable the way TensorFlow stores a partitioned
+    one -- `partitions` row ranges (axis 0; scalars and 1-row variables: one), each under its slice key -- default: what the
+    reference partitions.  state_file: also write `<dir>/checkpoint` (tf.train.CheckpointState) pointing at this prefix, which
+    is how tf.estimator / tf.train.latest_checkpoint find it."""
     names = sorted(tensors, key=lambda s: s.encode())
     os.makedirs(os.path.dirname(os.path.abspath(prefix)), exist_ok=True)
     index = [(b"", _pb_varint(1, 1) + _pb_bytes(3, _pb_varint(1, 1)))]      # num_shards = 1, little endian, version.producer = 1
     off = 0
+    if not _native():
+        import warnings
+        warnings.warn("libwd_ingest.so is not built: CRC-32C of the checkpoint tensors in pure Python (slow for large tables)")
     with open(_data_path(prefix, 0, 1), "wb") as fd:
         for nm in names:
             a = np.asarray(tensors[nm])                 # (not ascontiguousarray: it would turn a scalar into shape (1,))
             if a.dtype not in _DTYPE_IDS:
                 raise ValueError("variable `%s`: dtype %s cannot be stored" % (nm, a.dtype))
-            raw = a.astype(a.dtype.newbyteorder("<"), copy=False).tobytes(order="C")
-            fd.write(raw)
-            crc = mask_crc(crc32c(raw)) if len(raw) <= checksum_limit else 0
-            index.append((nm.encode(), encode_entry(_DTYPE_IDS[a.dtype], a.shape, off, len(raw), crc)))
-            off += len(raw)
+            a = a.astype(a.dtype.newbyteorder("<"), copy=False)
+            did = _DTYPE_IDS[a.dtype]
+            if not (sliced and sliced(nm)) or a.ndim == 0:
+                raw = a.tobytes(order="C")
+                fd.write(raw)
+                index.append((nm.encode(), encode_entry(did, a.shape, off, len(raw), mask_crc(crc32c(raw)))))
+                off += len(raw)
+                continue
+            nparts = max(1, min(int(partitions), a.shape[0]))
+            bounds = [a.shape[0] * k // nparts for k in range(nparts + 1)]
+            slices = []
+            for k in range(nparts):
+                ext = [(bounds[k], bounds[k + 1] - bounds[k])] + [(0, d) for d in a.shape[1:]]
+                part = np.ascontiguousarray(a[bounds[k]: bounds[k + 1]])
+                raw = part.tobytes(order="C")
+                fd.write(raw)
+                index.append((encode_tensor_name_slice(nm, ext), encode_entry(did, part.shape, off, len(raw), mask_crc(crc32c(raw)))))
+                off += len(raw)
+                slices.append(ext)
+            index.append((nm.encode(), encode_entry(did, a.shape, 0, 0, 0, slices=slices)))
+    index.sort(key=lambda kv: kv[0])
     write_table(prefix + ".index", index)
+    if state_file:
+        base = os.path.basename(prefix)
+        with open(os.path.join(os.path.dirname(os.path.abspath(prefix)), "checkpoint"), "w") as fh:
+            fh.write('model_checkpoint_path: "%s"\nall_model_checkpoint_paths: "%s"\n' % (base, base))
     return prefix
 
 

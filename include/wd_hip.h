@@ -638,6 +638,13 @@ typedef struct wd_chain_opts {
   const float *wide_bias;
   float *wide_out;
   int32_t wide_S, pad_;
+  /* gradients straight into the per-occurrence records of the row exchange (sharded engine; one id per bag, the embedding columns
+   * of slot s at x columns [s * dx_dim, (s + 1) * dx_dim)): dx[b, s * dx_dim + c] goes to dx_scatter[dx_pos[b * dx_S + s] * dx_rs + c]
+   * and dlogit[b] to dx_scatter[dx_pos[b * dx_S + s] * dx_rs + dx_dim] for every s (dx_pos < 0: dropped) -- what wd_grad_pack does
+   * in a launch of its own; the dx argument is then only a switch (its buffer is not written). */
+  const int32_t *dx_pos;
+  float *dx_scatter;
+  int32_t dx_S, dx_rs, dx_dim, pad2_;
 } wd_chain_opts_t;
 int64_t wd_tower_chain_lds_bytes(int32_t K0, const int32_t *N, int32_t L, int32_t row_tile);   /* -1: unsupported shape */
 int64_t wd_tower_chain_blocks(int64_t batch, int32_t row_tile);   /* ceil(batch / row_tile) */

@@ -2,7 +2,7 @@
 
   * wd_bucket_onehot (one launch) builds the same buckets as wd_sparse_bucketize (three launches);
   * the input layer as its own launch (wd_prefetch_onehot) + the tower reading x from HBM is BIT-identical to the tower that
-    gathers its own x tile (WD_PREFETCH=0);
+    gathers its own x tile (WD_INPUT_AHEAD=0);
   * the pipelined multi-step hipGraph -- gather of batch t+1 BEFORE update(t), rewritten rows patched by update(t) -- is
     bit-identical to eager launches (gather after the update), also when consecutive batches share most of their rows
     (tiny vocabularies, Zipf ids: every second row is patched)."""
@@ -127,7 +127,7 @@ def test_prefetched_input_and_patched_graph_are_bit_identical(kw, B, dist):
     spec = criteo_spec(**kw)
     a = _engine(spec, B)                       # prefetch + patch, graph
     b = _engine(spec, B)                       # prefetch, eager launches
-    c = _engine(spec, B, WD_PREFETCH=0)        # the tower gathers its own x tile
+    c = _engine(spec, B, WD_INPUT_AHEAD=0)        # the tower gathers its own x tile
     assert a.prefetch and b.prefetch and not c.prefetch and a.chain and c.chain
     hbs = [synth.make_raw_batch(a.plan, B, seed=100 + i, dist=dist, pos_rate=0.3) for i in range(8)]
     tbs = {e: [synth.TokenBatch(e.plan, hb) for hb in hbs] for e in (a, b, c)}

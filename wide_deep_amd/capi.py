@@ -82,7 +82,9 @@ class WdChainOpts(ctypes.Structure):
     _fields_ = [("input", ctypes.c_void_p), ("loss_part", ctypes.c_void_p), ("stamps", ctypes.c_void_p),
                 ("tile_stamps", ctypes.c_void_p), ("row_tile", ctypes.c_int32), ("flags", ctypes.c_int32),
                 ("wide_vals", ctypes.c_void_p), ("wide_bias", ctypes.c_void_p), ("wide_out", ctypes.c_void_p),
-                ("wide_S", ctypes.c_int32), ("pad_", ctypes.c_int32)]
+                ("wide_S", ctypes.c_int32), ("pad_", ctypes.c_int32),
+                ("dx_pos", ctypes.c_void_p), ("dx_scatter", ctypes.c_void_p), ("dx_S", ctypes.c_int32),
+                ("dx_rs", ctypes.c_int32), ("dx_dim", ctypes.c_int32), ("pad2_", ctypes.c_int32)]
 
 
 class WdApplyNext(ctypes.Structure):

@@ -5,8 +5,9 @@
 // and deep logits, joint.py:264-269 sigmoid CE), the chain of launches
 //     NN_0 .. NN_{L-1}, logits head, NT_{L-1} .. NT_0
 // of mlp.hip by one kernel: a row tile's forward AND its input-gradient chain depend on nothing but that tile's rows
-// (the loss is a batch SUM, BN is the inference affine folded into the weights), so the tile stays in LDS from the
-// input layer's output x down to the gradient dx that the embedding update consumes.  What remains outside are the
+// (the loss is a batch SUM, BN is the inference affine -- applied as written, bn = gamma inv a + beta, to the A fragment as
+// it is read: nothing is folded into the weights since round 2), so the tile stays in LDS from the input layer's output x
+// down to the gradient dx that the embedding update consumes.  What remains outside are the
 // weight-gradient products G_l = [a_{l-1} | 1]^T dz_l, which reduce over the whole batch (split-K GEMMs of mlp.hip);
 // the kernel leaves a_l and dz_l in HBM for them.
 //
@@ -14,21 +15,25 @@
 // cold L2 after the kernel boundary, epilogue; profiles/r1h_gemm_microbench.txt) -- the small layers are pure launch
 // latency.  Per CU the tile's work is ~35 us of v_mfma_f32_32x32x2_f32 at full rate.
 //
-// Row tile RT = 32 (v_mfma_f32_32x32x2_f32, one workgroup per CU) or RT = 16 (v_mfma_f32_16x16x4_f32, the default since
-// round 2): at batch 8192 a 32-row tile gives exactly 256 workgroups = ONE wavefront per SIMD, and everything that is not
+// Row tile RT = 32 (v_mfma_f32_32x32x2_f32, one workgroup per CU; the default) or RT = 16 (v_mfma_f32_16x16x4_f32, WD_CHAIN_RT=16:
+// faster alone, slower inside the step where its second wavefront per SIMD is what the side branches need): at batch 8192 a 32-row tile gives exactly 256 workgroups = ONE wavefront per SIMD, and everything that is not
 // an MFMA -- the gather of the x tile, the epilogues, the barriers between stages, the head -- leaves the matrix pipe idle
 // (profiles/r1w_tower_chain_stage_cycles.txt: 177 k cycles per tile of which 76 k are MFMA issue).  A 16-row tile needs
 // half the LDS (61 KB at C2), so TWO workgroups share a CU, drift out of phase, and one computes while the other gathers /
 // stores / waits at a barrier.  Same FLOPs per instruction-cycle (16x16x4 issues every 32 cycles), twice the weight
 // traffic from L2 (every tile streams all weights), half the rows per epilogue.
 //
+// The x tile comes from HBM (the input layer is its own launch, wd_prefetch_onehot, issued one step ahead -- round 3 -- or any
+// other producer of x) or, wd_chain_opts_t.input, is gathered by the kernel itself (the rows that arrived through the exchange
+// of the sharded engine; WD_INPUT_AHEAD=0 on one GPU).
+//
 // Data flow per workgroup (256 lanes = 4 wavefronts, one per SIMD):
 //   * activations live in LDS reduction-major  [k][RT+1]  (RT examples + 1 pad): the A fragment of MFMA step k is the
 //     row read lds[(k + lane/RT) * (RT+1) + lane%RT]; an accumulator (col = lane%RT per register row) is written back
 //     transposed (2-way bank conflicts at most, free for ds_write_b32).
 //   * weights are NOT staged in LDS: wavefront w owns the output columns [32w, 32w+32) (+128 ..), nobody else reads
-//     them, so the B fragments are loaded straight from L2 into registers.  wd_fold_affine_all writes the folded kernel
-//     (and its transpose, for the gradient chain) in MFMA-fragment order (wd_mlp_layer_t.Wpk / WTpk): ONE 16-byte load
+//     them, so the B fragments are loaded straight from L2 into registers.  wd_chain_tail writes the kernel (and its
+//     transpose, for the gradient chain) in MFMA-fragment order (wd_chain_layer_t.Wpk / WTpk) as it updates the parameter: ONE 16-byte load
 //     per lane, 1 KB contiguous per wavefront, feeds four MFMA steps.  (One dword per MFMA -- the natural [K][N] layout
 //     -- ran at 118 us: the CU's texture-address unit moves ~16 B/clk of dword loads, exactly what four wavefronts of
 //     back-to-back fp32 MFMAs consume, so the waves sat in s_waitcnt 54 % of the time.)  A register ring keeps 7-11
@@ -93,6 +98,9 @@ struct ChainArgs {
   unsigned long long *tile_stamps;   // wd_chain_opts_t.tile_stamps: [tile][2] realtime-clock stamps {start, x tile in LDS}
   wd_chain_input_t in;          // in.emb != NULL: the x tile is built here (input layer fused), wd_chain_opts_t.input
   float *loss_part;             // != NULL: this tile's loss is stored to loss_part[tile] (no atomic on loss_sum)
+  const int32_t *sc_pos;        // wd_chain_opts_t.dx_pos: scatter dx / dlogit into per-occurrence records instead of dx[batch][ld]
+  float *sc_out;
+  int32_t sc_S, sc_RS, sc_dim, sc_shift;
   const float *wv;              // wd_chain_opts_t.wide_vals: per-occurrence wide weights [batch][wv_S] (x from HBM)
   const float *wv_bias;
   float *wv_out;
@@ -231,6 +239,11 @@ struct StageAff {
   const float *s_in, *t_in;     // LDS tables of the INPUT's BN affine (forward) or NULL
   const float *s_out, *t_out;   // LDS tables of the OUTPUT layer's BN affine or NULL
   float *db_out, *dg_out, *dbeta_out;   // MODE 1: this tile's column-sum partials [N] (HBM) or NULL
+  // MODE 2 (optional): column n of example b belongs to occurrence b * sc_S + (n >> sc_shift) and goes to
+  // sc_out[sc_pos[occurrence] * sc_RS + (n & (sc_dim - 1))] (sc_pos < 0: dropped) instead of g_out
+  const int32_t *sc_pos;
+  float *sc_out;
+  int32_t sc_S, sc_RS, sc_dim, sc_shift;
 };
 template <typename TL, int MODE>
 __device__ __forceinline__ void stage(const float *__restrict__ in, int K, const float *__restrict__ Wpk, int N,
@@ -272,7 +285,12 @@ __device__ __forceinline__ void stage(const float *__restrict__ in, int K, const
       }
       if (MODE == 2) o = v;
       if (MODE != 2) out[n * P + m] = v;
-      if ((FULLR || b0 + m < batch) && n < n_store) g_out[(b0 + m) * ld_g + n] = o;
+      if (MODE == 2 && af.sc_pos) {
+        if ((FULLR || b0 + m < batch) && n < af.sc_S * af.sc_dim) {
+          const int32_t p = af.sc_pos[(b0 + m) * af.sc_S + (n >> af.sc_shift)];
+          if (p >= 0) af.sc_out[(int64_t)p * af.sc_RS + (n & (af.sc_dim - 1))] = o;
+        }
+      } else if ((FULLR || b0 + m < batch) && n < n_store) g_out[(b0 + m) * ld_g + n] = o;
     }
     if (MODE == 1) {   // this tile's partials of the bias / BN gradients: column sums over its RT rows (rows >= batch are 0)
 #pragma unroll
@@ -585,6 +603,11 @@ __global__ void __launch_bounds__(256, RT_ == 16 ? 2 : 1) k_tower_chain(ChainArg
         if (g.logit) g.logit[b] = x;
         if (g.prob) g.prob[b] = p;
         if (g.train && g.dlogit) g.dlogit[b] = dl;
+        if (g.train && g.sc_pos)       // the example's dlogit behind the gradient row of each of its occurrences (wide part)
+          for (int sidx = 0; sidx < g.sc_S; ++sidx) {
+            const int32_t p = g.sc_pos[b * g.sc_S + sidx];
+            if (p >= 0) g.sc_out[(int64_t)p * g.sc_RS + g.sc_dim] = dl;
+          }
       }
       sdl[t] = dl;
       if (g.train && (g.loss_sum || g.loss_part)) {
@@ -686,6 +709,7 @@ __global__ void __launch_bounds__(256, RT_ == 16 ? 2 : 1) k_tower_chain(ChainArg
   if (g.dx && g.dx_cols > 0) {
     const wd_chain_layer_t &ly = g.layer[0];
     StageAff af{};
+    af.sc_pos = g.sc_pos; af.sc_out = g.sc_out; af.sc_S = g.sc_S; af.sc_RS = g.sc_RS; af.sc_dim = g.sc_dim; af.sc_shift = g.sc_shift;
     stage<TL, 2>(lds + g.dz_off[0], ly.N, ly.WTpk, g.dx_cols, nullptr, 0, nullptr, nullptr, g.dx, g.ld_dx, g.K0, b0,
                  g.batch, af, (g.stamps && blockIdx.x == 0) ? g.stamps + 20 : nullptr);
   }
@@ -914,6 +938,14 @@ extern "C" int wd_tower_chain(const float *x, int64_t ld_act, int32_t K0, const 
     g.tile_stamps = static_cast<unsigned long long *>(opts->tile_stamps);
     g.prio_split = opts->flags & 1 ? 0 : 1;
     g.loss_part = opts->loss_part;
+    if (opts->dx_pos) {
+      WD_REQUIRE(opts->dx_scatter && opts->dx_S > 0 && opts->dx_rs > opts->dx_dim && opts->dx_dim >= 4 &&
+                 (opts->dx_dim & (opts->dx_dim - 1)) == 0 && opts->dx_S * opts->dx_dim <= K0,
+                 "dx scatter: power-of-two dim, records of more than dim floats, S * dim columns of x");
+      g.sc_pos = opts->dx_pos; g.sc_out = opts->dx_scatter; g.sc_S = opts->dx_S; g.sc_RS = opts->dx_rs; g.sc_dim = opts->dx_dim;
+      g.sc_shift = 0;
+      while ((1 << g.sc_shift) < opts->dx_dim) ++g.sc_shift;
+    }
     if (opts->wide_vals) {
       WD_REQUIRE(!opts->input && opts->wide_bias && opts->wide_S > 0, "wide_vals: needs wide_bias, wide_S > 0 and no fused input");
       g.wv = opts->wide_vals; g.wv_bias = opts->wide_bias; g.wv_out = opts->wide_out; g.wv_S = opts->wide_S;

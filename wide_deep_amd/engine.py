@@ -478,11 +478,11 @@ class WideDeepEngine:
         """Prefetched input layer (one-id-per-bag batches on row records, single GPU): x and the wide weights of a batch are
         gathered by their own launch (wd_prefetch_onehot) -- in a pipelined multi-step graph one step AHEAD, beside the
         previous tower, into the other of two activation buffers; the rows the update in between rewrites are patched by
-        that update (wd_apply_next_t).  WD_PREFETCH=0: the tower kernel gathers its own x tile (wd_chain_input_t)."""
+        that update (wd_apply_next_t).  WD_INPUT_AHEAD=0: the tower kernel gathers its own x tile (wd_chain_input_t)."""
         self._apar = 0                 # activation buffer / wide-weight list the current step uses
         self._prefetched = False       # pipeline.StepGraph: x / wv of the batch forward() is called with are already in place
         self.prefetch = bool(self.spec.has_deep and self.chain and self.rec is not None and type(self) is WideDeepEngine
-                             and self._fused_input_layer and os.environ.get("WD_PREFETCH", "1") != "0")
+                             and self._fused_input_layer and os.environ.get("WD_INPUT_AHEAD", "1") != "0")
         if not self.prefetch:
             return
         tw = self.towers[0]
@@ -594,6 +594,7 @@ class WideDeepEngine:
             opts.input = ctypes.addressof(ci)
         if pf and self.spec.has_wide:
             opts.wide_vals, opts.wide_bias, opts.wide_out, opts.wide_S = ptr(self.wv[p]), ptr(self.bias), ptr(self.wide_logit), self.plan.S
+        self._chain_scatter(opts, bt, fuse_in and train)
         if train:
             opts.loss_part = ptr(self.loss_part)
         opts.stamps = self._chain_stamps
@@ -608,6 +609,9 @@ class WideDeepEngine:
              ptr(tw["Gpart"][L]) if train else None,
              tw["dact"].data_ptr() + 4 * tl.in_start[0] if need_dx else None, tl.ld, tw["dx_cols"] if need_dx else 0,
              ctypes.byref(opts), st)
+
+    def _chain_scatter(self, opts, bt, on):
+        """Hook (dist.py): let the tower kernel write dx / dlogit straight into the records of the gradient exchange."""
 
     def dropout_masks(self, B):
         """Host copy of the keep masks the NEXT train step will use: [tower][layer] -> float32 [B, N] of 0 / 1 (the

@@ -718,6 +718,11 @@ int wd_adagrad_dense(float *w, float *accum, const float *g, int64_t n, float lr
 /* Diagnostic (bench-only): n random 64-byte row reads from `table` (row = 16 floats) with `per` independent rows in
  * flight per 4-lane group; writes one float per wavefront to out.  Measures the random-gather ceiling of the part. */
 int wd_diag_gather64(const float *table, const int32_t *ids, int64_t n, int32_t per, float *out, wd_stream_t stream);
+/* Diagnostic (bench-only): the gather of n rows (16 floats at records rec_stride floats apart) into out[n][16] with the request
+ * issued in eight different ways (csrc/common.hip lists them: 4 / 8 / 1 lanes per row, nontemporal loads / stores, LDS-DMA,
+ * read side alone, 4 rows in flight per lane group): the table behind profiles/r3_gather_modes.txt. */
+int wd_diag_gather_modes(const float *rec, int64_t rec_stride, const int32_t *ids, int64_t n, int32_t mode, float *out,
+                         wd_stream_t stream);
 
 /* Diagnostic (bench-only): n items, item j touching bytes[s] bytes at base[s] + ids[j] * stride_bytes[s] in each of nseg <= 3
  * tables (16-byte pieces, <= 256 bytes per item, `per` items in flight per 16-lane group); rmw != 0 writes every piece back.

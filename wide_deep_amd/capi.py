@@ -234,6 +234,7 @@ _PROTOS = {
     "wd_adagrad_dense": [P, P, P, I64, F32, P],
     "wd_fill_f32": [P, F32, I64, P],
     "wd_diag_gather64": [P, P, I64, I32, P, P],
+    "wd_diag_gather_modes": [P, I64, P, I64, I32, P, P],
     "wd_diag_access": [P, P, P, I32, P, I64, I32, I32, P, P],
 }
 _RESTYPES = {"wd_prefetch_onehot_blocks": I64, "wd_feat_offsets_workspace_bytes": I64, "wd_sort_workspace_bytes": SZ, "wd_logits_head_blocks": I64, "wd_tower_chain_lds_bytes": I64, "wd_tower_chain_blocks": I64, "wd_bucket_max": I32, "wd_bucket_chunks": I32, "wd_route_chunks": I32}

@@ -139,3 +139,90 @@ extern "C" int wd_diag_gather64(const float *table, const int32_t *ids, int64_t 
   }
   return wd::check_launch("wd_diag_gather64");
 }
+
+// ---- gather-strategy ceilings (bench-only, scripts/bench_gather_modes.py -> profiles/r3_gather_modes.txt) ----------------------
+// n random rows of 16 floats out of records `rstride` floats apart, written to out[j][16] (the pooled write of the input
+// layer) -- the work of wd_prefetch_onehot without slots / wide weights / numeric columns -- with the request issued in
+// different ways:
+//   0  4 lanes x 16 B per row, plain loads                     1  the same, nontemporal loads (what the step's launch does)
+//   2  8 lanes x 16 B: the WHOLE 128-byte record is requested   3  one lane per row: four 16-byte loads per lane, 64 rows per
+//      (64 bytes of it kept)                                       wavefront instruction group in flight
+//   4  LDS-DMA: global_load_lds_dwordx4, 16 B per lane straight 5  mode 1 with nontemporal STORES of the rows
+//      into LDS (no VGPR round trip), then LDS -> HBM
+//   6  mode 1 without the row write (one float per wavefront):  7  mode 1 with `per` = 4 rows per lane group in flight
+//      the read side alone
+__global__ void __launch_bounds__(256) k_diag_gather_modes(const float *__restrict__ rec, int64_t rstride,
+                                                           const int32_t *__restrict__ ids, int64_t n, int mode,
+                                                           float *__restrict__ out) {
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  __shared__ f4 stage[256];
+  const int t = threadIdx.x;
+  const int64_t gt = (int64_t)blockIdx.x * 256 + t;
+  if (mode == 2) {
+    const int64_t j = gt >> 3;
+    const int l = t & 7;
+    if (j >= n) return;
+    const f4 v = *(reinterpret_cast<const f4 *>(rec + (int64_t)ids[j] * rstride) + l);
+    if (l < 4) *(reinterpret_cast<f4 *>(out + j * 16) + l) = v;
+    else if (v.x == 12345.678f) out[0] = v.y;          // (keeps the upper half of the record a real request)
+    return;
+  }
+  if (mode == 3) {
+    const int64_t j = gt;
+    if (j >= n) return;
+    const f4 *src = reinterpret_cast<const f4 *>(rec + (int64_t)ids[j] * rstride);
+    const f4 a = src[0], b = src[1], c = src[2], d = src[3];
+    f4 *dst = reinterpret_cast<f4 *>(out + j * 16);
+    dst[0] = a; dst[1] = b; dst[2] = c; dst[3] = d;
+    return;
+  }
+  if (mode == 7) {
+    const int64_t g0 = (gt >> 2) * 4;
+    const int l = t & 3;
+    f4 v[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      v[q] = g0 + q < n ? __builtin_nontemporal_load(reinterpret_cast<const f4 *>(rec + (int64_t)ids[g0 + q] * rstride) + l) : (f4)(0.f);
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (g0 + q < n) *(reinterpret_cast<f4 *>(out + (g0 + q) * 16) + l) = v[q];
+    return;
+  }
+  const int64_t j = gt >> 2;
+  const int l = t & 3;
+  if (mode == 4) {
+    // every lane names its own 16 bytes; the hardware writes lane i's data at (wave-uniform LDS base) + 16 * i
+    const int64_t jj = j < n ? j : n - 1;
+    const f4 *src = reinterpret_cast<const f4 *>(rec + (int64_t)ids[jj] * rstride) + l;
+    f4 *dst = stage + (t & ~63);
+    __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)src,
+                                     (void __attribute__((address_space(3))) *)dst, 16, 0, 0);
+    __builtin_amdgcn_s_waitcnt(0);      // vmcnt(0)
+    __syncthreads();
+    if (j < n) *(reinterpret_cast<f4 *>(out + j * 16) + l) = stage[t];
+    return;
+  }
+  if (j >= n) return;
+  const f4 *src = reinterpret_cast<const f4 *>(rec + (int64_t)ids[j] * rstride) + l;
+  const f4 v = mode == 0 ? *src : __builtin_nontemporal_load(src);
+  if (mode == 6) {
+    float x = v.x + v.y + v.z + v.w;
+    for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+    if ((t & 63) == 0) out[(gt >> 6) & 0xFFFF] = x;
+  } else if (mode == 5) {
+    __builtin_nontemporal_store(v, reinterpret_cast<f4 *>(out + j * 16) + l);
+  } else {
+    *(reinterpret_cast<f4 *>(out + j * 16) + l) = v;
+  }
+}
+
+extern "C" int wd_diag_gather_modes(const float *rec, int64_t rec_stride, const int32_t *ids, int64_t n, int32_t mode,
+                                    float *out, wd_stream_t stream) {
+  if (n <= 0) return WD_OK;
+  WD_REQUIRE(rec && ids && out && rec_stride >= 16 && rec_stride % 4 == 0 && mode >= 0 && mode <= 7, "bad arguments");
+  const int lanes = mode == 2 ? 8 : (mode == 3 ? 1 : 4);
+  const int64_t threads = mode == 7 ? wd::ceil_div(n, 4) * 4 : n * lanes;
+  hipLaunchKernelGGL(k_diag_gather_modes, dim3((unsigned)wd::ceil_div(threads, 256)), dim3(256), 0, wd::as_stream(stream), rec,
+                     rec_stride, ids, n, mode, out);
+  return wd::check_launch("wd_diag_gather_modes");
+}

@@ -391,7 +391,10 @@ __device__ __forceinline__ bool sort_bucket(const SortArgs &g, int bkt, uint64_t
     for (int w = 1; w < NT / 64; ++w) { kmin = min(kmin, s_kmin[w]); kmax = max(kmax, s_kmax[w]); }
     int r[SORT_CAP / NT];
     bool ranked = false;
-    if (!SMALL && SORT_CAP >= 1024 && NT == 256 && g.batch <= 16384) {
+    uint64_t o_pair[(512 + NT - 1) / NT];      // dominant-row path: the pairs of OTHER rows this lane places, and where
+    int o_rank[(512 + NT - 1) / NT];
+    int n_other = 0;
+    if (!SMALL && SORT_CAP >= 1024 && NT >= 256 && g.batch <= 16384) {
       // ---- a bucket dominated by ONE row K (a Zipf head row: ~780 of ~900 pairs): O(m) instead of O(m^2).  The pairs of a row
       // are distinct EXAMPLES (one id per bag), so their order by bag is a rank in a bitmap over the examples:
       // rank = (pairs of smaller rows) + popcount(bits below example b); the few other pairs rank among themselves.
@@ -428,38 +431,45 @@ __device__ __forceinline__ bool sort_bucket(const SortArgs &g, int bkt, uint64_t
           }
         }
         __syncthreads();
-        {   // exclusive prefix of the words' popcounts: two words per lane
+        {   // exclusive prefix of the words' popcounts: two words per lane of the first 256 lanes
           const int w0 = 2 * t;
-          const int v0 = w0 < nw ? __popc(bits[w0]) : 0, v1 = w0 + 1 < nw ? __popc(bits[w0 + 1]) : 0;
+          const bool live = t < 256;
+          const int v0 = live && w0 < nw ? __popc(bits[w0]) : 0, v1 = live && w0 + 1 < nw ? __popc(bits[w0 + 1]) : 0;
           int incl = v0 + v1;
           for (int off = 1; off < 64; off <<= 1) {
             const int u = __shfl_up(incl, off, 64);
             if (lane >= off) incl += u;
           }
-          if (lane == 63) s_dom[4 + (t >> 6)] = incl;
+          if (live && lane == 63) s_dom[8 + (t >> 6)] = incl;
           __syncthreads();
-          int base = incl - (v0 + v1);
-          for (int w = 0; w < (t >> 6); ++w) base += s_dom[4 + w];
-          wpre[w0] = base;
-          wpre[w0 + 1] = base + v0;
+          if (live) {
+            int base = incl - (v0 + v1);
+            for (int w = 0; w < (t >> 6); ++w) base += s_dom[8 + w];
+            wpre[w0] = base;
+            wpre[w0 + 1] = base + v0;
+          }
         }
         __syncthreads();
         const int no = m - c;
 #pragma unroll
         for (int q = 0; q < SORT_CAP / NT; ++q) {
-          r[q] = 0;
+          r[q] = -1;                                   // (pairs of other rows are placed by the lanes below)
           if (t + NT * q >= m) continue;
-          const uint32_t kx = key_of(x[q]);
-          if (kx == K) {
+          if (key_of(x[q]) == K) {
             const uint32_t b = (uint32_t)x[q] / (uint32_t)g.S;
             r[q] = nlt + (int)wpre[b >> 5] + __popc(bits[b >> 5] & ((1u << (b & 31)) - 1u));
-          } else {
-            int rr = kx > K ? c : 0;
-            for (int j = 0; j < no; ++j) rr += others[j] < x[q] ? 1 : 0;
-            r[q] = rr;
           }
         }
+        // the other rows' pairs: lane i takes others[i] and counts the smaller ones among them (no <= 512)
+        for (int i = t; i < no; i += NT) {
+          const uint64_t xo = others[i];
+          int rr = key_of(xo) > K ? c : 0;
+          for (int j = 0; j < no; ++j) rr += others[j] < xo ? 1 : 0;
+          o_pair[i / NT] = xo;
+          o_rank[i / NT] = rr;
+        }
         ranked = true;
+        n_other = no;
       }
       __syncthreads();      // (the scratch in lds_pairs is dead from here on)
     }
@@ -479,10 +489,16 @@ __device__ __forceinline__ bool sort_bucket(const SortArgs &g, int bkt, uint64_t
     __syncthreads();
 #pragma unroll
     for (int q = 0; q < SORT_CAP / NT; ++q)
-      if (t + NT * q < m) {
+      if (t + NT * q < m && r[q] >= 0) {
         const uint64_t p = lds_in[t + NT * q];
         lds_pairs[r[q]] = p;
         pairs[s0 + r[q]] = p;
+      }
+#pragma unroll
+    for (int q = 0; q < (512 + NT - 1) / NT; ++q)
+      if (t + NT * q < n_other) {
+        lds_pairs[o_rank[q]] = o_pair[q];
+        pairs[s0 + o_rank[q]] = o_pair[q];
       }
     __syncthreads();
   } else {
@@ -532,7 +548,7 @@ __device__ __forceinline__ bool sort_bucket(const SortArgs &g, int bkt, uint64_t
   return true;
 }
 
-constexpr int SMALL_CAP = 256;       // 4 KB of LDS: seven workgroups per CU beside the one-launch tower
+constexpr int SMALL_CAP = 256;       // 4 KB of LDS: seven workgroups per CU beside the one-launch tower (512: three, and the launch took 47 us for Zipf ids instead of 29)
 constexpr int BIG_CAP = 1024;        // 16 KB
 constexpr int BIG_WORKERS = 256;
 
@@ -548,15 +564,16 @@ __global__ void __launch_bounds__(256) k_bucket_sort_small(SortArgs g) {
     g.big_list[atomicAdd(&g.long_list[1], 1)] = bkt;
 }
 
-// (256 lanes: a 1024-lane workgroup does not fit beside the tower's wavefronts and waited for them -- 55 us for nothing)
-__global__ void __launch_bounds__(256) k_bucket_sort_big(SortArgs g) {
+// (512 lanes, two pairs per lane; a 1024-lane workgroup does not fit beside the tower's wavefronts -- registers -- and waited for
+// them to finish: 55 us for nothing)
+__global__ void __launch_bounds__(512) k_bucket_sort_big(SortArgs g) {
   __shared__ uint64_t lds_pairs[BIG_CAP];
   __shared__ uint64_t lds_in[BIG_CAP];
-  __shared__ uint32_t s_kmin[4], s_kmax[4];
-  __shared__ int32_t s_dom[8];
+  __shared__ uint32_t s_kmin[8], s_kmax[8];
+  __shared__ int32_t s_dom[16];
   const int nbig = g.long_list[1];
   for (int q = blockIdx.x; q < nbig; q += BIG_WORKERS) {
-    sort_bucket<BIG_CAP, false, 256>(g, g.big_list[q], lds_pairs, lds_in, s_kmin, s_kmax, s_dom);
+    sort_bucket<BIG_CAP, false, 512>(g, g.big_list[q], lds_pairs, lds_in, s_kmin, s_kmax, s_dom);
     __syncthreads();
   }
 }
@@ -785,36 +802,41 @@ k_row_update(RowUpd u) {
     }
     if (gl == 0) gw += u.dlogit[b];
   } else {
-    if (lane_emb) {
-      int64_t j = i;
-      for (; j + 4 <= e; j += 4) {             // four occurrences per round: loads together, adds in ascending bag order
-        int32_t bag[4];
-        float4 d[4];
+    // 2 .. 32 occurrences: their bag indices in ONE round of loads (lane gl of the group takes pairs i + gl, + 4, ...; a bag
+    // travels to the other lanes by shuffle), then four gradient rows per round -- 1 + ceil(n / 4) dependent round trips
+    // instead of two per occurrence for the remainder of a count that is not a multiple of four; the adds keep ascending bag
+    // order (bit-identical sums)
+    const int n = (int)(e - i);
+    const int l0 = (t & 63) & ~3;
+    uint32_t mybag[ROW_LONG_SEG / 4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) bag[k] = (int32_t)(uint32_t)u.pairs[j + k];
+    for (int k = 0; k < ROW_LONG_SEG / 4; ++k) {
+      const int64_t idx = i + gl + 4 * k;
+      mybag[k] = idx < e ? (uint32_t)u.pairs[idx] : 0u;
+    }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) d[k] = *reinterpret_cast<const float4 *>(u.dx + (int64_t)(bag[k] / S) * u.ldx + out_col + 4 * gl);
+    for (int c = 0; c < ROW_LONG_SEG / 4; ++c) {
+      if (4 * c >= n) break;
+      int32_t bag[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          g.x += d[k].x * scale; g.y += d[k].y * scale; g.z += d[k].z * scale; g.w += d[k].w * scale;
+      for (int k = 0; k < 4; ++k) bag[k] = (int32_t)__shfl((int)mybag[c], l0 + k, 64);
+      float4 d[4];
+      float v[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        d[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        v[k] = 0.f;
+        if (4 * c + k < n) {
+          if (lane_emb) d[k] = *reinterpret_cast<const float4 *>(u.dx + (int64_t)(bag[k] / S) * u.ldx + out_col + 4 * gl);
+          if (gl == 0) v[k] = u.dlogit[bag[k] / S];
         }
       }
-      for (; j < e; ++j) {
-        const int32_t bag = (int32_t)(uint32_t)u.pairs[j];
-        const float4 d = *reinterpret_cast<const float4 *>(u.dx + (int64_t)(bag / S) * u.ldx + out_col + 4 * gl);
-        g.x += d.x * scale; g.y += d.y * scale; g.z += d.z * scale; g.w += d.w * scale;
-      }
-    }
-    if (gl == 0) {
-      int64_t j = i;
-      for (; j + 4 <= e; j += 4) {
-        float v[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] = u.dlogit[(int32_t)(uint32_t)u.pairs[j + k] / S];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) gw += v[k];
-      }
-      for (; j < e; ++j) gw += u.dlogit[(int32_t)(uint32_t)u.pairs[j] / S];
+      for (int k = 0; k < 4; ++k)
+        if (4 * c + k < n) {
+          g.x += d[k].x * scale; g.y += d[k].y * scale; g.z += d[k].z * scale; g.w += d[k].w * scale;
+          gw += v[k];
+        }
     }
   }
   float4 wn = w;
@@ -904,7 +926,7 @@ extern "C" int wd_bucket_sort(const int32_t *bucket_start, uint64_t *pairs, int3
   while (g.bag_bits < 32 && ((int64_t)1 << g.bag_bits) < nnz) ++g.bag_bits;
   hipStream_t st = wd::as_stream(stream);
   hipLaunchKernelGGL(k_bucket_sort_small, dim3((unsigned)nbuckets), dim3(256), 0, st, g);
-  hipLaunchKernelGGL(k_bucket_sort_big, dim3(BIG_WORKERS), dim3(256), 0, st, g);
+  hipLaunchKernelGGL(k_bucket_sort_big, dim3(BIG_WORKERS), dim3(512), 0, st, g);
   return wd::check_launch("wd_bucket_sort");
 }
 

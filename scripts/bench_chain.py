@@ -45,8 +45,9 @@ nodx = timeit(lambda: eng._tower_chain(tw, bt, B, st, True))
 tw["dx_cols"] = dxc
 fwd = timeit(lambda: eng._tower_chain(tw, bt, B, st, False))
 print("row tile %d (WD_CHAIN_RT)" % eng.chain_rt)
-print("chain B=%d hidden=%s: with fused input layer %.1f us | x from HBM: full %.1f us, no dx %.1f us, forward only %.1f us "
-      "(forward GEMM flops %.2f G)" % (B, hidden, fused, full, nodx, fwd, fl_f / 1e9))
+print("chain B=%d hidden=%s: %s %.1f us | x from HBM + given wide logit: full %.1f us, no dx %.1f us, forward only %.1f us "
+      "(forward GEMM flops %.2f G)" % (B, hidden, "as launched in the step (x from HBM, wide logit from the prefetched weight list)"
+                                       if eng.prefetch else "with fused input layer", fused, full, nodx, fwd, fl_f / 1e9))
 
 
 stamps = torch.zeros(64, dtype=torch.int64, device="cuda")

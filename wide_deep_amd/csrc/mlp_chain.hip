@@ -94,6 +94,7 @@ struct ChainArgs {
   float *dx;
   int64_t ld_dx;
   unsigned long long *stamps;   // diagnostics (wd_chain_opts_t.stamps): shader-clock stamps of workgroups 0 and 100
+  int32_t flags_nosplit;             // wd_chain_opts_t.flags bit 1: dx stage without the split last tile (A/B switch)
   int32_t prio_split;                // row tile 16: the wavefront in the odd hardware slot of each SIMD runs at priority 3
   unsigned long long *tile_stamps;   // wd_chain_opts_t.tile_stamps: [tile][2] realtime-clock stamps {start, x tile in LDS}
   wd_chain_input_t in;          // in.emb != NULL: the x tile is built here (input layer fused), wd_chain_opts_t.input
@@ -244,6 +245,11 @@ struct StageAff {
   const int32_t *sc_pos;
   float *sc_out;
   int32_t sc_S, sc_RS, sc_dim, sc_shift;
+  // MODE 2 (optional): LDS scratch of 4 x RT x P floats.  When the stage has 4 q + 1 column tiles -- dx at the Criteo shape:
+  // 416 columns = 13 tiles, i.e. 4 + 3 + 3 + 3 over the four wavefronts: three of them idle for a quarter of the stage --
+  // the LAST tile is split over the reduction instead: every wavefront multiplies a quarter of the k range, the partial tiles
+  // meet in this scratch and are added in wavefront order (fixed summation order)
+  float *split_scratch;
 };
 template <typename TL, int MODE>
 __device__ __forceinline__ void stage(const float *__restrict__ in, int K, const float *__restrict__ Wpk, int N,
@@ -337,13 +343,46 @@ __device__ __forceinline__ void stage(const float *__restrict__ in, int K, const
     if (dbg && threadIdx.x == 0) *dbg++ = __builtin_readcyclecounter();
   };
   using std::integral_constant;
+  const bool split = MODE == 2 && TL::RT == 32 && af.split_scratch && (ntiles & 3) == 1 && ntiles > 4 && (KG & 3) == 0;
+  const int ntl = split ? ntiles - 1 : ntiles;
   int t0 = wave;
-  while (t0 < ntiles) {
-    const int left = (ntiles - t0 + 3) / 4;   // tiles of this wavefront still to do
+  while (t0 < ntl) {
+    const int left = (ntl - t0 + 3) / 4;   // tiles of this wavefront still to do
     if (TL::NTMAX >= 4 && left >= 4) { run(t0, integral_constant<int, (TL::NTMAX >= 4 ? 4 : 1)>{}); t0 += 16; }
     else if (TL::NTMAX >= 4 && left == 3) { run(t0, integral_constant<int, (TL::NTMAX >= 4 ? 3 : 1)>{}); t0 += 12; }
     else if (left >= 2) { run(t0, integral_constant<int, 2>{}); t0 += 8; }
     else { run(t0, integral_constant<int, 1>{}); t0 += 4; }
+  }
+  if (split) {
+    // the last column tile, a quarter of the reduction per wavefront
+    const int tl = ntiles - 1, kq = KG / 4;
+    acc_t acc[1];
+#pragma unroll
+    for (int r = 0; r < TL::NACC; ++r) acc[0][r] = 0.f;
+    const float4 *WB = reinterpret_cast<const float4 *>(Wpk) + ((int64_t)tl * KG + (int64_t)wave * kq) * 64 + lane;
+    mma_tiles<TL, 1>(inA + (int64_t)wave * kq * TL::GK * P, WB, kq, 0, acc, nullptr, nullptr);
+    float *scr = af.split_scratch + wave * (RT * P);
+#pragma unroll
+    for (int r = 0; r < TL::NACC; ++r) scr[c * P + TL::row_of(r, h)] = acc[0][r];
+    __syncthreads();
+    for (int i = threadIdx.x; i < RT * RT; i += 256) {
+      const int m = i / RT, cc = i % RT;
+      const float *p0 = af.split_scratch + cc * P + m;
+      float v = p0[0];
+      v += p0[RT * P];
+      v += p0[2 * RT * P];
+      v += p0[3 * RT * P];
+      const int n = tl * RT + cc;
+      if (!(full_rows || b0 + m < batch)) continue;
+      if (af.sc_pos) {
+        if (n < af.sc_S * af.sc_dim) {
+          const int32_t pp = af.sc_pos[(b0 + m) * af.sc_S + (n >> af.sc_shift)];
+          if (pp >= 0) af.sc_out[(int64_t)pp * af.sc_RS + (n & (af.sc_dim - 1))] = v;
+        }
+      } else if (n < n_store) {
+        g_out[(b0 + m) * ld_g + n] = v;
+      }
+    }
   }
 }
 
@@ -381,14 +420,7 @@ __global__ void __launch_bounds__(256, RT_ == 16 ? 2 : 1) k_tower_chain(ChainArg
   float h_wide = 0.f, h_y = 0.f, h_w = 1.0f, h_bias = 0.f;
   if (t < RT && b0 + t < g.batch) {
     if (g.wide_logit) h_wide = g.wide_logit[b0 + t];
-    if (g.wv) {      // wide logit = sum of the prefetched weights of the example's bags, slots in order, + bias (fixed order)
-      const float *wp = g.wv + (b0 + t) * g.wv_S;
-      float acc = 0.f;
-      for (int sidx = 0; sidx < g.wv_S; ++sidx) acc += wp[sidx];
-      acc += g.wv_bias[0];
-      h_wide = acc;
-      if (g.wv_out) g.wv_out[b0 + t] = acc;
-    }
+
     if (g.labels) h_y = g.labels[b0 + t];
     if (g.weights) h_w = g.weights[b0 + t];
   }
@@ -405,6 +437,16 @@ __global__ void __launch_bounds__(256, RT_ == 16 ? 2 : 1) k_tower_chain(ChainArg
 
   float *s_wide = red;   // [RT] wide logit of the tile's examples (gather mode); `red` is free until the head
   float wv[4] = {0.f, 0.f, 0.f, 0.f};   // gather mode: this lane's wide weights, in flight from the tile gather to the head
+  if (g.wv) {
+    // prefetched input layer: the tile's RT x S wide weights are one contiguous run of the per-occurrence list -- requested here,
+    // coalesced, consumed in the head (registers -> LDS -> per-example sum, the code path of the fused gather)
+    const int nbag = RT * g.wv_S;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = t + 256 * u;
+      if (i < nbag && b0 * g.wv_S + i < g.batch * g.wv_S) wv[u] = g.wv[b0 * g.wv_S + i];
+    }
+  }
   if (g.in.emb) {
     // ---- input layer of the tile, fused (python/lib/dnn.py:88-90 input_layer + python/lib/linear.py:29-36 linear_model
     // for one-id-per-bag batches): x[m, out_col_s ..] = E_s[id(m, s)], numeric columns, wide logit.  RT x 26 random 64-byte
@@ -562,10 +604,13 @@ __global__ void __launch_bounds__(256, RT_ == 16 ? 2 : 1) k_tower_chain(ChainArg
   {
     const int m = t % RT, part = t / RT;
     const float *sL = lds + g.tab_off[L - 1], *tL = sL + K;     // affine of the last hidden layer (identity without BN)
-    if (g.in.emb && g.in.wide) {
+    const bool wlist = (g.in.emb && g.in.wide) || g.wv;      // wide weights of the tile's occurrences in the wv registers
+    if (wlist) {
       // the wide weights requested with the tile have long arrived: registers -> LDS (the x region is dead since the first
       // product), then the wide logit of each example, slots in order (fixed summation order)
-      const int S = uni(g.in.S), nbag = RT * S;
+      const int S = uni(g.wv ? g.wv_S : g.in.S), nbag = RT * S;
+      const float *wbias = g.wv ? g.wv_bias : g.in.wide_bias;
+      float *wout = g.wv ? g.wv_out : g.in.wide_out;
 #pragma unroll
       for (int u = 0; u < 4; ++u)
         if (t + 256 * u < nbag) regx[t + 256 * u] = wv[u];
@@ -573,14 +618,14 @@ __global__ void __launch_bounds__(256, RT_ == 16 ? 2 : 1) k_tower_chain(ChainArg
       if (t < RT) {
         float acc = 0.f;
         for (int sidx = 0; sidx < S; ++sidx) acc += regx[t * S + sidx];
-        acc += g.in.wide_bias[0];
+        acc += wbias[0];
         s_wide[t] = acc;
-        if (g.in.wide_out && b0 + t < g.batch) g.in.wide_out[b0 + t] = acc;
+        if (wout && b0 + t < g.batch) wout[b0 + t] = acc;
       }
     }
     float d = 0.f;
     for (int n = part; n < K; n += PARTS) d += __fadd_rn(__fmul_rn(in[n * P + m], sL[n]), tL[n]) * swl[n];
-    const float h_wide_lds = (g.in.emb && g.in.wide && t < RT) ? s_wide[t] : 0.f;   // read before `red` is reused below
+    const float h_wide_lds = (wlist && t < RT) ? s_wide[t] : 0.f;   // read before `red` is reused below
     __syncthreads();
     red[part * RT + m] = d;
     __syncthreads();
@@ -592,7 +637,7 @@ __global__ void __launch_bounds__(256, RT_ == 16 ? 2 : 1) k_tower_chain(ChainArg
       const int64_t b = b0 + t;
       float dl = 0.f, ls = 0.f;
       if (b < g.batch) {
-        const float x = dn + (g.in.emb ? h_wide_lds : h_wide);
+        const float x = dn + ((g.in.emb || g.wv) ? h_wide_lds : h_wide);
         const float y = h_y;
         const float w = h_w;
         const float e = expf(-fabsf(x));
@@ -710,6 +755,8 @@ __global__ void __launch_bounds__(256, RT_ == 16 ? 2 : 1) k_tower_chain(ChainArg
     const wd_chain_layer_t &ly = g.layer[0];
     StageAff af{};
     af.sc_pos = g.sc_pos; af.sc_out = g.sc_out; af.sc_S = g.sc_S; af.sc_RS = g.sc_RS; af.sc_dim = g.sc_dim; af.sc_shift = g.sc_shift;
+    // (a_0's LDS region is dead since the gradient stage of layer 1 read it for act')
+    if (ly.N >= 4 * RT && !(g.flags_nosplit)) af.split_scratch = lds + g.a_off[0];
     stage<TL, 2>(lds + g.dz_off[0], ly.N, ly.WTpk, g.dx_cols, nullptr, 0, nullptr, nullptr, g.dx, g.ld_dx, g.K0, b0,
                  g.batch, af, (g.stamps && blockIdx.x == 0) ? g.stamps + 20 : nullptr);
   }
@@ -937,6 +984,7 @@ extern "C" int wd_tower_chain(const float *x, int64_t ld_act, int32_t K0, const 
     g.stamps = static_cast<unsigned long long *>(opts->stamps);
     g.tile_stamps = static_cast<unsigned long long *>(opts->tile_stamps);
     g.prio_split = opts->flags & 1 ? 0 : 1;
+    g.flags_nosplit = opts->flags & 2 ? 1 : 0;
     g.loss_part = opts->loss_part;
     if (opts->dx_pos) {
       WD_REQUIRE(opts->dx_scatter && opts->dx_S > 0 && opts->dx_rs > opts->dx_dim && opts->dx_dim >= 4 &&
@@ -948,6 +996,7 @@ extern "C" int wd_tower_chain(const float *x, int64_t ld_act, int32_t K0, const 
     }
     if (opts->wide_vals) {
       WD_REQUIRE(!opts->input && opts->wide_bias && opts->wide_S > 0, "wide_vals: needs wide_bias, wide_S > 0 and no fused input");
+      WD_REQUIRE(rt * opts->wide_S <= 1024, "wide_vals: row_tile x wide_S must be <= 1024");
       g.wv = opts->wide_vals; g.wv_bias = opts->wide_bias; g.wv_out = opts->wide_out; g.wv_S = opts->wide_S;
     }
     if (opts->input) {

@@ -495,7 +495,7 @@ def main():
         parity = parity_check(eng, spec, dev_batches[0], host_batches[0], step_eager)
 
     use_graph = not args.no_graph
-    steps_per_run, run_steps, run_steps_graph = 1, None, False
+    steps_per_run, run_steps, run_steps_graph, chain = 1, None, False, False
     graph_cls = pipeline.StepGraph
     if use_graph and sharded and eng._graph_mode() == "full" and eng.chain and eng._chain_input_ok(dev_batches[0].batch):
         # RCCL backend: the collectives are captured with the kernels -> multi-step pipelined graphs like the single-GPU path
@@ -527,12 +527,28 @@ def main():
             # the timed steps would be ONE graph launch: its launch latency (a few hundred nodes on four streams) is then fully
             # exposed.  Two graphs: the second is launched while the first runs (measured at --steps 20: 0.184 against 0.187 ms)
             spg = max(d for d in range(1, args.steps // 2 + 1) if args.steps % d == 0 and d <= cap)
+        chain = (spg > 1 and graph_cls is pipeline.StepGraph and eng.prefetch and os.environ.get("WD_GRAPH_CHAIN", "1") != "0"
+                 and all(pipeline.pipelined_ok(eng, tb) for tb in dev_batches))
         starts, j = [], 0
-        while spg > 1 and j not in starts and len(starts) < 8:
+        while spg > 1 and (len(starts) < 6 if chain else (j not in starts and len(starts) < 8)):
             starts.append(j)
             j = (j + spg) % nb
-        multis = [graph_cls(eng, [dev_batches[(j0 + i) % nb] for i in range(spg)], args.ids_input, stream=side)
-                  for j0 in starts]
+        if chain:
+            # consecutive multi-step graphs are chained like the steps inside one: a graph also does the input work (hash,
+            # buckets, sort, gather) of the NEXT graph's first batch beside its last tower, and its last row update patches the
+            # rows both share; the next graph starts with its tower (pipeline.StepGraph: lookahead / phase / primed).  Without
+            # it every graph starts with ~80 us of serial input work, 10 us per step at the driver's 2 x 10 steps.  Six
+            # graphs close the cycle of (bucket set, activation buffer) phases for any spg: 6 * spg = 0 mod 2 and mod 3.
+            multis, phase = [], (0, 0)
+            for k, j0 in enumerate(starts):
+                g = pipeline.StepGraph(eng, [dev_batches[(j0 + i) % nb] for i in range(spg)], args.ids_input, stream=side,
+                                       lookahead=dev_batches[starts[(k + 1) % len(starts)]], phase=phase, primed=True)
+                multis.append(g)
+                phase = g.next_phase
+            assert phase == (0, 0) and all(g.chained for g in multis)
+        else:
+            multis = [graph_cls(eng, [dev_batches[(j0 + i) % nb] for i in range(spg)], args.ids_input, stream=side)
+                      for j0 in starts]
         singles = [graph_cls(eng, [tb], args.ids_input, stream=side) for tb in dev_batches[:8 if sharded else nb]]
         steps_per_run, run_steps_graph = spg, True
         # multi-step graphs walk the pool forwards from batch 0, one-step graphs (warm-up steps that do not fill a graph, the
@@ -547,6 +563,10 @@ def main():
             for _ in range(n % spg if spg > 1 else n):
                 singles[(len(singles) - 1 - cursor["s"]) % len(singles)].replay()
                 cursor["s"] += 1
+            if chain and n % spg:
+                # the one-step graphs leave no input work behind: hand the chain what its next graph expects (the multi-step
+                # graphs do this for each other; inside the timed region it happens exactly as often as outside)
+                multis[cursor["m"] % len(multis)].prime()
 
         # clocks, caches and the graph executor's first-replay work are out of the way before the official warm-up: every
         # graph is replayed once (untimed; the contract's W warm-up steps and K timed steps follow unchanged)
@@ -612,6 +632,7 @@ def main():
             }[args.config],
             "global_batch": B * world, "ids": args.dist, "input": "pre-hashed ids" if args.ids_input else "raw string tokens (hashed in step)",
             "hip_graph": bool(use_graph), "steps_per_graph": steps_per_run,
+            "chained_graphs": bool(use_graph and run_steps_graph and chain),
             "table_layout": ("row records: %d B = [emb %d f32 | w z n -]" % (4 * eng.rec_stride, eng.emb.shape[1])
                              if getattr(eng, "rec", None) is not None else "separate tables"),
             "pipelined_graph": bool(use_graph and run_steps_graph and (sharded or multis[0].pipelined)),

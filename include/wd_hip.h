@@ -587,6 +587,29 @@ typedef struct wd_tail_layer {
 } wd_tail_layer_t;
 int wd_chain_tail(const wd_tail_layer_t *layers, int32_t nlayers, float *P, float *Pacc, float *Gflat, float inv, float lr,
                   int32_t mode, wd_stream_t stream);
+/* wd_gemm_tn_splitk_group + wd_chain_tail(GRAD | UPDATE | PACK) in ONE launch (single GPU, Adagrad: nothing reduces the
+ * gradients between the two): job j is the job of wd_gemm_tn_splitk_group, and fuse[j] says whose gradient it completes --
+ *   WD_FUSE_KERNEL  a product job = the kernel gradient of layers[layer] (Cpart = its Gpart, nsplit = its nsplit, no appended
+ *                   ones row): the LAST workgroup to finish an output tile sums the tile's partials in split order, takes the
+ *                   Adagrad step and rewrites the packed copies (tile_counters: one zeroed int per output tile; left zero);
+ *   WD_FUSE_BIAS / WD_FUSE_GAMMA / WD_FUSE_BETA  a column-sum job = that vector's gradient (gamma: x inv);
+ *   WD_FUSE_WHOLE   no product: the whole tail of layers[layer] from partials complete before the launch (logits layer);
+ *   WD_FUSE_NONE    the job as it is (e.g. the loss sum).
+ * Same arithmetic, element by element, as the two launches (python/lib/joint.py:233-241). */
+#define WD_FUSE_NONE 0
+#define WD_FUSE_KERNEL 1
+#define WD_FUSE_BIAS 2
+#define WD_FUSE_GAMMA 3
+#define WD_FUSE_BETA 4
+#define WD_FUSE_WHOLE 5
+#define WD_TN_FUSED_MAX_JOBS 16
+#define WD_TN_FUSED_MAX_LAYERS 5
+typedef struct wd_tn_fuse {
+  int32_t kind, layer;
+} wd_tn_fuse_t;
+int wd_gemm_tn_group_tail(const wd_tn_job_t *jobs, const wd_tn_fuse_t *fuse, int32_t njobs, const wd_tail_layer_t *layers,
+                          int32_t nlayers, float *P, float *Pacc, float *Gflat, float inv, float lr, int32_t *tile_counters,
+                          int32_t ncounters, wd_stream_t stream);
 /* Optional (wd_chain_opts_t.input): fuse the input layer into the call (one-id-per-bag batches, the Criteo shape): the kernel
  * then builds its x tile itself -- x[b, out_col_s ..] = emb[emb_off_s + ids[b*S + s]*dim ..] for the slots
  * [slot0, slot0+ngroup) (id < 0: zeros), the numeric columns (wd_dense_fwd), and the wide logit

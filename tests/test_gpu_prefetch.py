@@ -151,3 +151,62 @@ def test_prefetched_input_and_patched_graph_are_bit_identical(kw, B, dist):
     _state_equal(b, c, "7 eager steps, prefetched vs fused input layer")
     _state_equal(a, b, "graph replay (prefetch a step ahead + patch) vs eager launches")
     assert a.global_step == b.global_step
+
+
+@pytest.mark.parametrize("kw,B,dist", [
+    (dict(n_dense=13, n_sparse=26, buckets=5000, dim=16, hidden=(256, 128, 64)), 1024, "zipf"),
+    (dict(n_dense=16, n_sparse=6, buckets=37, dim=8, hidden=(64, 32)), 512, "uniform"),     # every row shared with the next batch
+])
+def test_chained_graphs_are_bit_identical(kw, B, dist):
+    """Graphs chained through lookahead / phase / primed (the next graph's first batch is hashed, bucketed, sorted and gathered
+    by the previous graph, whose last update patches it) == eager launches, bit for bit: a chain walked in order, a chain
+    entered in the middle (the primed graph does its own input work), and a closed cycle replayed twice."""
+    from wide_deep_amd import synth
+    from wide_deep_amd.pipeline import StepGraph, step_eager
+    from wide_deep_amd.plan import criteo_spec
+    spec = criteo_spec(**kw)
+    a, b = _engine(spec, B), _engine(spec, B)
+    assert a.prefetch and b.prefetch
+    hbs = [synth.make_raw_batch(a.plan, B, seed=300 + i, dist=dist, pos_rate=0.3) for i in range(7)]
+    ta, tb_ = [synth.TokenBatch(a.plan, hb) for hb in hbs], [synth.TokenBatch(b.plan, hb) for hb in hbs]
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        step_eager(a, ta[0])
+        step_eager(b, tb_[0])
+    torch.cuda.synchronize()
+    # cycle over batches 1..6: g1 = [1], g2 = [2, 3], g3 = [4, 5, 6]; 6 steps close the (set, buffer) phases
+    g1 = StepGraph(a, ta[1:2], stream=side, lookahead=ta[2], phase=(0, 0), primed=True)
+    g2 = StepGraph(a, ta[2:4], stream=side, lookahead=ta[4], phase=g1.next_phase, primed=True)
+    g3 = StepGraph(a, ta[4:7], stream=side, lookahead=ta[1], phase=g2.next_phase, primed=True)
+    assert g1.chained and g2.chained and g3.chained and g3.next_phase == (0, 0)
+    assert g1.next_phase == (1, 1) and g2.next_phase == (1, 0)
+    order = [1, 2, 3, 4, 5, 6]
+    for g in (g1, g2, g3):
+        g.replay()                                      # g1 primes itself, g2 and g3 find their input work in place
+    assert a._primed is not None and a._primed[0] == id(ta[1])
+    with torch.cuda.stream(side):
+        for i in order:
+            step_eager(b, tb_[i])
+    torch.cuda.synchronize()
+    _state_equal(a, b, "chain walked in order")
+    for g in (g1, g2, g3):                              # the cycle again: g1 now continues from g3's lookahead
+        g.replay()
+    with torch.cuda.stream(side):
+        for i in order:
+            step_eager(b, tb_[i])
+    torch.cuda.synchronize()
+    _state_equal(a, b, "closed cycle, second round")
+    g3.replay()                                         # entered in the middle: g3's input work is not in place (g1 is primed)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):
+        for i in (4, 5, 6):
+            step_eager(b, tb_[i])
+        step_eager(a, ta[0])                            # an eager step invalidates what g3 left for g1
+        step_eager(b, tb_[0])
+    torch.cuda.synchronize()
+    g1.replay()
+    with torch.cuda.stream(side):
+        step_eager(b, tb_[1])
+    torch.cuda.synchronize()
+    _state_equal(a, b, "chain entered in the middle / after an eager step")
+    assert a.global_step == b.global_step

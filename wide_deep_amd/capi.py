@@ -110,6 +110,12 @@ class WdChainLayer(ctypes.Structure):
 
 
 WD_TAIL_GRAD, WD_TAIL_UPDATE, WD_TAIL_PACK = 1, 2, 4
+WD_FUSE_NONE, WD_FUSE_KERNEL, WD_FUSE_BIAS, WD_FUSE_GAMMA, WD_FUSE_BETA, WD_FUSE_WHOLE = 0, 1, 2, 3, 4, 5
+WD_TN_FUSED_MAX_JOBS, WD_TN_FUSED_MAX_LAYERS = 16, 5
+
+
+class WdTnFuse(ctypes.Structure):
+    _fields_ = [("kind", ctypes.c_int32), ("layer", ctypes.c_int32)]
 
 
 class WdTailLayer(ctypes.Structure):
@@ -219,6 +225,7 @@ _PROTOS = {
     "wd_tower_chain_blocks": [I64, I32],
     "wd_tower_chain": [P, I64, I32, P, I32, I32, F32, P, P, P, P, P, I64, P, P, P, P, P, P, P, I64, I32, P, P],
     "wd_chain_tail": [P, I32, P, P, P, F32, F32, I32, P],
+    "wd_gemm_tn_group_tail": [P, P, I32, P, I32, P, P, P, F32, F32, P, I32, P],
     "wd_logits_head_h": [P, I64, I64, P, P, I32, P, P, P, I64, P, P, P, P, P, P, I64, I32, P, P],
     "wd_hgemm_nn": [P, I64, P, I64, P, I32, I32, P, I64, P, I64, I64, I64, I64, P],
     "wd_hgemm_nt": [P, I64, P, I64, I64, I64, I64, P, I64, I32, P, I64, P, I64, P, I64, I32, P],

@@ -26,6 +26,91 @@ constexpr int kXCDs = 8;
 
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// ---- one dense parameter's share of the dense tail (python/lib/joint.py:233-241, tf.train.AdagradOptimizer on the dnn scope):
+// shared by k_chain_tail (mlp_chain.hip) and by the weight-gradient launch that finishes its own tiles (mlp.hip,
+// wd_gemm_tn_group_tail), so that both take the same arithmetic.
+struct TailCtx {
+  float *P, *Pacc, *Gflat;
+  float inv, lr;
+};
+
+// gradient gv of parameter idx is final: store it, take the Adagrad step on (w, a) = (P[idx], Pacc[idx]) as loaded by the
+// caller, and rewrite the two MFMA-packed copies of a hidden-layer kernel element e = k * N + n (e < 0: a vector parameter)
+__device__ __forceinline__ void tail_apply(const wd_tail_layer_t &L, const TailCtx &c, int64_t idx, int64_t e, float gv, float w,
+                                           float a, bool grad, bool upd, bool pack) {
+  if (grad) c.Gflat[idx] = gv;
+  if (upd) {
+    const float gg = grad ? gv : c.Gflat[idx];      // update without grad: the (all-reduced) gradient buffer
+    a = a + gg * gg;
+    c.Pacc[idx] = a;
+    w -= c.lr * gg / sqrtf(a);
+    c.P[idx] = w;
+  }
+  if (pack && e >= 0 && L.Wpk) {
+    const int64_t K = L.K, N = L.N;
+    const int64_t k = e / N, n = e - k * N;
+    if (L.pk_tile == 16) {
+      L.Wpk[((n >> 4) * (K >> 4) + (k >> 4)) * 256 + (((k & 3) << 4) + (n & 15)) * 4 + ((k & 15) >> 2)] = w;
+      if (L.WTpk) L.WTpk[((k >> 4) * (N >> 4) + (n >> 4)) * 256 + (((n & 3) << 4) + (k & 15)) * 4 + ((n & 15) >> 2)] = w;
+    } else {
+      L.Wpk[((n >> 5) * (K >> 3) + (k >> 3)) * 256 + (((k & 1) << 5) + (n & 31)) * 4 + ((k & 7) >> 1)] = w;
+      if (L.WTpk) L.WTpk[((k >> 5) * (N >> 3) + (n >> 3)) * 256 + (((n & 1) << 5) + (k & 31)) * 4 + ((n & 7) >> 1)] = w;
+    }
+  }
+}
+
+// element e of layer L's K*N + 3*N tail elements (kernel | bias | gamma | beta), gradient from the layer's partials / sums
+__device__ __forceinline__ void tail_element(const wd_tail_layer_t &L, const TailCtx &c, int64_t e, int32_t mode) {
+  const int64_t K = L.K, N = L.N;
+  const int64_t nW = K * N;
+  const bool grad = mode & WD_TAIL_GRAD, upd = mode & WD_TAIL_UPDATE, pack = mode & WD_TAIL_PACK;
+  if (e >= nW + 3 * N) return;
+  int64_t idx;
+  float gv = 0.f;
+  if (e < nW) {                       // kernel element (k, n)
+    idx = L.w_off + e;
+    if (grad) {
+      const int64_t stride = (L.db_sum ? K : K + 1) * N;
+      float v[16];
+      for (int32_t z0 = 0; z0 < L.nsplit; z0 += 16) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = z0 + u < L.nsplit ? L.Gpart[(z0 + u) * stride + e] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) gv += v[u];
+      }
+    }
+  } else {
+    const int64_t n = (e - nW) % N;
+    const int which = (int)((e - nW) / N);    // 0 bias, 1 gamma, 2 beta
+    if (which == 0) {
+      idx = L.b_off + n;
+      if (grad) {
+        if (L.db_sum) {
+          gv = L.db_sum[n];
+        } else {                       // partials with an appended bias-gradient row (logits layer: one per row tile)
+          const int64_t stride = (K + 1) * N;
+          float v[16];
+          for (int32_t z0 = 0; z0 < L.nsplit; z0 += 16) {
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = z0 + u < L.nsplit ? L.Gpart[(z0 + u) * stride + K * N + n] : 0.f;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) gv += v[u];
+          }
+        }
+      }
+    } else if (which == 1) {
+      if (L.gamma_off < 0) return;
+      idx = L.gamma_off + n;
+      if (grad) gv = L.dgamma_sum[n] * c.inv;
+    } else {
+      if (L.beta_off < 0) return;
+      idx = L.beta_off + n;
+      if (grad) gv = L.dbeta_sum[n];
+    }
+  }
+  tail_apply(L, c, idx, e < nW ? e : -1, gv, c.P[idx], upd ? c.Pacc[idx] : 0.f, grad, upd, pack);
+}
+
 }  // namespace wd
 
 #define WD_REQUIRE(cond, msg)                 \

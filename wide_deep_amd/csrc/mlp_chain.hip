@@ -783,74 +783,8 @@ __global__ void __launch_bounds__(256) k_chain_tail(TailArgs g) {
   int l = 0;
   while (l + 1 < g.nlayers && (int)blockIdx.x >= g.first[l + 1]) ++l;
   l = uni(l);
-  const wd_tail_layer_t &L = g.layer[l];
-  const int64_t K = L.K, N = L.N;
-  const int64_t e = (int64_t)(blockIdx.x - g.first[l]) * 256 + threadIdx.x;
-  const int64_t nW = K * N;
-  const bool grad = g.mode & WD_TAIL_GRAD, upd = g.mode & WD_TAIL_UPDATE, pack = g.mode & WD_TAIL_PACK;
-  if (e >= nW + 3 * N) return;
-  int64_t idx;
-  float gv = 0.f;
-  if (e < nW) {                       // kernel element (k, n)
-    idx = L.w_off + e;
-    if (grad) {
-      const int64_t stride = (L.db_sum ? K : K + 1) * N;
-      float v[16];
-      for (int32_t z0 = 0; z0 < L.nsplit; z0 += 16) {
-#pragma unroll
-        for (int u = 0; u < 16; ++u) v[u] = z0 + u < L.nsplit ? L.Gpart[(z0 + u) * stride + e] : 0.f;
-#pragma unroll
-        for (int u = 0; u < 16; ++u) gv += v[u];
-      }
-    }
-  } else {
-    const int64_t n = (e - nW) % N;
-    const int which = (int)((e - nW) / N);    // 0 bias, 1 gamma, 2 beta
-    if (which == 0) {
-      idx = L.b_off + n;
-      if (grad) {
-        if (L.db_sum) {
-          gv = L.db_sum[n];
-        } else {                       // partials with an appended bias-gradient row (logits layer: one per row tile)
-          const int64_t stride = (K + 1) * N;
-          float v[16];
-          for (int32_t z0 = 0; z0 < L.nsplit; z0 += 16) {
-#pragma unroll
-            for (int u = 0; u < 16; ++u) v[u] = z0 + u < L.nsplit ? L.Gpart[(z0 + u) * stride + K * N + n] : 0.f;
-#pragma unroll
-            for (int u = 0; u < 16; ++u) gv += v[u];
-          }
-        }
-      }
-    } else if (which == 1) {
-      if (L.gamma_off < 0) return;
-      idx = L.gamma_off + n;
-      if (grad) gv = L.dgamma_sum[n] * g.inv;
-    } else {
-      if (L.beta_off < 0) return;
-      idx = L.beta_off + n;
-      if (grad) gv = L.dbeta_sum[n];
-    }
-  }
-  float w = g.P[idx];
-  if (grad) g.Gflat[idx] = gv;
-  if (upd) {
-    const float gg = grad ? gv : g.Gflat[idx];      // update without grad: the (all-reduced) gradient buffer
-    const float a = g.Pacc[idx] + gg * gg;
-    g.Pacc[idx] = a;
-    w -= g.lr * gg / sqrtf(a);
-    g.P[idx] = w;
-  }
-  if (pack && e < nW && L.Wpk) {
-    const int64_t k = e / N, n = e - k * N;
-    if (L.pk_tile == 16) {
-      L.Wpk[((n >> 4) * (K >> 4) + (k >> 4)) * 256 + (((k & 3) << 4) + (n & 15)) * 4 + ((k & 15) >> 2)] = w;
-      if (L.WTpk) L.WTpk[((k >> 4) * (N >> 4) + (n >> 4)) * 256 + (((n & 3) << 4) + (k & 15)) * 4 + ((n & 15) >> 2)] = w;
-    } else {
-      L.Wpk[((n >> 5) * (K >> 3) + (k >> 3)) * 256 + (((k & 1) << 5) + (n & 31)) * 4 + ((k & 7) >> 1)] = w;
-      if (L.WTpk) L.WTpk[((k >> 5) * (N >> 3) + (n >> 3)) * 256 + (((n & 1) << 5) + (k & 31)) * 4 + ((n & 7) >> 1)] = w;
-    }
-  }
+  const wd::TailCtx c{g.P, g.Pacc, g.Gflat, g.inv, g.lr};
+  wd::tail_element(g.layer[l], c, (int64_t)(blockIdx.x - g.first[l]) * 256 + threadIdx.x, g.mode);
 }
 
 }  // namespace

@@ -89,6 +89,9 @@ class WideDeepEngine:
         self.rec = None
         self.act_id = capi.ACT_IDS["relu" if self.crelu else spec.activation]
         self.global_step = 0
+        self._tail_fused, self._tile_counters = False, None
+        self.fuse_tail = os.environ.get("WD_FUSE_TAIL", "1") != "0"   # dense tail inside the weight-gradient launch
+        self._primed = None             # pipeline.StepGraph: (batch, bucket set, activation buffer, global step) whose input work is in place
         dev = self.device
         f32 = dict(dtype=torch.float32, device=dev)
         i32 = dict(dtype=torch.int32, device=dev)
@@ -533,6 +536,14 @@ class WideDeepEngine:
         call("wd_fold_affine_all", ptr(self.P), ptr(self.layers_dev), self.n_layers, self.max_layer_n, self.inv,
              None if self.chain else ptr(self.loss), 1, ptr(self.G) if zero_g else None, self.G.numel() if zero_g else 0, st)
 
+    def _tail_fusable(self):
+        """The dense tail can ride in the weight-gradient launch: one GPU (nothing reduces the gradients in between), Adagrad,
+        the tail of every step also re-packs (fold at end).  WD_FUSE_TAIL=0: the two launches of round 2."""
+        return (self.chain and self.all_simple and self.default_opts and not self.crelu and self._fold_at_end()
+                and type(self)._reduce_dense_grads is WideDeepEngine._reduce_dense_grads
+                and type(self)._dense_backward is WideDeepEngine._dense_backward
+                and os.environ.get("WD_FUSE_ADAGRAD", "1") != "0" and self.fuse_tail)
+
     def _chain_tail(self, mode, st):
         """wd_chain_tail: gradients from the split-K partials / Adagrad / packed kernel copies, any combination."""
         tw = self.towers[0]
@@ -857,6 +868,29 @@ class WideDeepEngine:
                     spec_jobs.append(dict(A=tw[nm + "_part"][l].data_ptr(), lda=m["N"], B=None, C=tw[nm + "_sum"][l].data_ptr(),
                                           N=m["N"], K=nblk))
             spec_jobs.append(dict(A=self.loss_part.data_ptr(), lda=1, B=None, C=self.loss.data_ptr(), N=1, K=nblk))
+            self._tail_fused = False
+            if self._tail_fusable() and len(spec_jobs) + 1 <= capi.WD_TN_FUSED_MAX_JOBS and L + 1 <= capi.WD_TN_FUSED_MAX_LAYERS:
+                # one launch: every job finishes its own share of the dense tail (wd_gemm_tn_group_tail) -- the last workgroup
+                # of a product's output tile sums, updates and re-packs it; the column-sum jobs update their vectors; the
+                # logits layer (partials from the tower) rides along as extra workgroups
+                kinds = [(capi.WD_FUSE_KERNEL, l) for l in range(L)]
+                for l in range(L):
+                    kinds += [(capi.WD_FUSE_BIAS, l)] + ([(capi.WD_FUSE_GAMMA, l), (capi.WD_FUSE_BETA, l)] if "gamma_off" in metas[l] else [])
+                kinds += [(capi.WD_FUSE_NONE, 0), (capi.WD_FUSE_WHOLE, L)]
+                njobs = len(spec_jobs) + 1
+                jobs, fuse = (capi.WdTnJob * njobs)(), (capi.WdTnFuse * njobs)()
+                for j, d in zip(jobs, spec_jobs):
+                    j.A, j.lda, j.B, j.Cpart, j.N, j.K = d["A"], d["lda"], d["B"], d["C"], d["N"], d["K"]
+                    if d["B"] is not None:
+                        j.ldb, j.M, j.nsplit, j.append_ones = d["ldb"], d["M"], d["nsplit"], 0
+                for f, (kind, layer) in zip(fuse, kinds):
+                    f.kind, f.layer = kind, layer
+                if self._tile_counters is None:
+                    self._tile_counters = torch.zeros(1024, dtype=torch.int32, device=self.device)
+                call("wd_gemm_tn_group_tail", jobs, fuse, njobs, tw["tail_layers"], L + 1, ptr(self.P), ptr(self.Pacc), ptr(self.G),
+                     self.inv, float(self.spec.dnn_opt[1]), ptr(self._tile_counters), self._tile_counters.numel(), st)
+                self._tail_fused = True
+                return
             for i0 in range(0, len(spec_jobs), capi.WD_TN_GROUP_MAX):
                 chunk = spec_jobs[i0: i0 + capi.WD_TN_GROUP_MAX]
                 jobs = (capi.WdTnJob * len(chunk))()
@@ -1133,7 +1167,9 @@ class WideDeepEngine:
                 # single GPU + Adagrad: the dense update rides in the finalize launch (nothing reduces G in between)
                 fused_opt = (self.default_opts and type(self)._reduce_dense_grads is WideDeepEngine._reduce_dense_grads
                              and not self.crelu and os.environ.get("WD_FUSE_ADAGRAD", "1") != "0")
-                if self.chain and fused_opt:
+                if self.chain and fused_opt and self._tail_fused:
+                    self._folded = True     # the products launch has already finished the tail (wd_gemm_tn_group_tail)
+                elif self.chain and fused_opt:
                     # gradients from the partials + Adagrad + the packed kernels of the next step, one launch
                     self._chain_tail(capi.WD_TAIL_GRAD | capi.WD_TAIL_UPDATE | capi.WD_TAIL_PACK, st)
                     self._folded = True
@@ -1364,6 +1400,7 @@ class WideDeepEngine:
             if names[0] in state:
                 self.pow[scope][0] = float(state[names[0]])
                 self.pow[scope][1] = float(state[names[1]])
+        self._primed = None
         if "global_step" in state:
             self.global_step = int(state["global_step"])
         if spec.has_deep and self.chain:

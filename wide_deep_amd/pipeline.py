@@ -54,14 +54,27 @@ class StepGraph:
     """`len(token_batches)` consecutive train steps in one hipGraph.  The engine must have run at least one eager step
     on a side stream before (lazy allocations / module loads are not capturable)."""
 
-    def __init__(self, eng, token_batches, ids_input=False, stream=None, pipelined=None):
+    def __init__(self, eng, token_batches, ids_input=False, stream=None, pipelined=None, lookahead=None, phase=(0, 0),
+                 primed=False):
+        """`lookahead`, `phase`, `primed` chain consecutive graphs of the prefetched capture (engine.prefetch) the way steps are
+        chained inside one: a graph with a `lookahead` batch also hashes, buckets and gathers THAT batch (beside its last
+        tower; its last update patches the rows both share), and the next graph -- captured with `primed=True` on that batch
+        and with the phase `next_phase` of this one -- starts with its tower.  A primed graph replayed in any other situation
+        (`eng._primed` does not name its first batch at the current global step) runs that input work itself first
+        (`prime()`), so a chain can be entered anywhere; results are bit-identical either way."""
         self.eng = eng
         self.n = len(token_batches)
+        self.ids_input = ids_input
+        self.first, self.lookahead, self.phase, self.primed = token_batches[0], lookahead, (phase[0] & 1, phase[1]), bool(primed)
         self.stream = stream or torch.cuda.Stream()
         self.graph = torch.cuda.CUDAGraph()
         if pipelined is None:
             pipelined = os.environ.get("WD_PIPELINE", "1") != "0"
         self.pipelined = bool(pipelined) and all(pipelined_ok(eng, tb) for tb in token_batches) and eng._folded
+        self.chained = self.pipelined and eng.prefetch and (lookahead is None or pipelined_ok(eng, lookahead))
+        if not self.chained:
+            if primed or lookahead is not None or tuple(phase) != (0, 0):
+                raise ValueError("StepGraph: lookahead / phase / primed need the prefetched pipelined capture (engine.prefetch)")
         self.stream.wait_stream(torch.cuda.current_stream())
         gs = eng.global_step            # capturing executes nothing: the counter must not move
         with torch.cuda.graph(self.graph, stream=self.stream):
@@ -184,6 +197,12 @@ class StepGraph:
         s_sp.wait_stream(main)
         keep = self._events = []
         n = len(tbs)
+        seq = list(tbs) + ([self.lookahead] if self.lookahead is not None else [])    # batches whose input work this graph does
+        first = 1 if self.primed else 0                                               # ... from this one on
+        set0, act0 = self.phase
+        na = eng.n_act      # 3 activation buffers: the one batch t+1 is gathered into was last read by the products of step t-2
+        sset = lambda t: (set0 + t) & 1
+        sact = lambda t: (act0 + t) % na
 
         def event(stream):
             ev = torch.cuda.Event()
@@ -191,47 +210,48 @@ class StepGraph:
             keep.append(ev)
             return ev
 
-        hash_ahead = not ids_input
-        ev_hash = []
+        hash_ahead = not ids_input and len(seq) > first
+        ev_hash = {}
         if hash_ahead:
             s_h = eng._side(1)
             s_h.wait_stream(main)
             with torch.cuda.stream(s_h):
-                for tb in tbs:
-                    synth.hash_tokens(eng, tb)
-                    ev_hash.append(event(s_h))
-
-        na = eng.n_act      # 3 activation buffers: the one batch t+1 is gathered into was last read by the products of step t-2
+                for t in range(first, len(seq)):
+                    synth.hash_tokens(eng, seq[t])
+                    ev_hash[t] = event(s_h)
 
         def input_work(t):
             """bucket(t) (+ sort, + which rows of batch t-1 it shares) -> set t & 1, prefetch(t) -> activation buffer t % 3, on the
             sparse branch behind update(t-2): the set's last reader; the buffer's last readers -- tower and products of step
             t-3 -- completed before tower(t-2), which update(t-2) waited for."""
-            bt = tbs[t].batch
+            bt = seq[t].batch
             eng._check_batch(bt)
             if hash_ahead:
                 s_sp.wait_event(ev_hash[t])
             with torch.cuda.stream(s_sp):
-                eng._sparse_bucketize(bt, s_sp.cuda_stream, t & 1, prev=(t - 1) & 1 if t >= 1 else None)
-                eng._prefetch_input(bt, s_sp.cuda_stream, t % na)
+                eng._sparse_bucketize(bt, s_sp.cuda_stream, sset(t), prev=sset(t - 1) if t >= 1 else None)
+                eng._prefetch_input(bt, s_sp.cuda_stream, sact(t))
 
-        input_work(0)
-        ev_upd = event(s_sp)            # x(0) in place
+        ev_upd = None
+        if not self.primed:
+            input_work(0)
+            ev_upd = event(s_sp)        # x(0) in place
         for t, tb in enumerate(tbs):
             bt = tb.batch
-            main.wait_event(ev_upd)                     # update(t-1), with its patch of this step's x
-            if t + 1 < n:
+            if ev_upd is not None:
+                main.wait_event(ev_upd)                 # update(t-1), with its patch of this step's x
+            if t + 1 < len(seq):
                 input_work(t + 1)                       # sparse branch, behind update(t-1): runs beside tower(t)
-            eng._apar, eng._prefetched = t % na, True
+            eng._apar, eng._prefetched = sact(t), True
             eng.forward(bt, need_loss=True)             # the tower launch: x from HBM, wide logit from the weight list
             ev_tower = event(main)
             hold = {}
 
             def update_then_join(t=t, bt=bt, ev_tower=ev_tower, hold=hold):
                 s_sp.wait_event(ev_tower)
-                nxt = ((t + 1) & 1, (t + 1) % na) if t + 1 < n else None
+                nxt = (sset(t + 1), sact(t + 1)) if t + 1 < len(seq) else None
                 with torch.cuda.stream(s_sp):
-                    eng._sparse_backward(bt, s_sp.cuda_stream, bucketized=True, pset=t & 1, patch=nxt)
+                    eng._sparse_backward(bt, s_sp.cuda_stream, bucketized=True, pset=sset(t), patch=nxt)
                     hold["upd"] = event(s_sp)
 
             eng._dense_backward(bt, main.cuda_stream, after_products=update_then_join)
@@ -240,10 +260,33 @@ class StepGraph:
         if hash_ahead:
             main.wait_stream(s_h)
 
+    @property
+    def next_phase(self):
+        """(bucket set, activation buffer) the `lookahead` batch is left in: the phase of the graph that continues the chain."""
+        return ((self.phase[0] + self.n) & 1, (self.phase[1] + self.n) % self.eng.n_act)
+
+    def _token(self, tb, phase):
+        return (id(tb), phase[0], phase[1], self.eng.global_step)
+
+    def prime(self):
+        """The input work of this graph's first batch as eager launches on the current stream (what the previous graph of a
+        chain does through its `lookahead`): ids, sorted buckets (set phase[0]), x and the wide weight list (buffer phase[1])."""
+        eng, tb = self.eng, self.first
+        st = torch.cuda.current_stream().cuda_stream
+        bt = tb.batch if self.ids_input else synth.hash_tokens(eng, tb)
+        eng._check_batch(bt)
+        eng._sparse_bucketize(bt, st, self.phase[0], prev=None)
+        eng._prefetch_input(bt, st, self.phase[1])
+        eng._primed = self._token(tb, self.phase)
+
     def replay(self):
+        eng = self.eng
+        if self.primed and getattr(eng, "_primed", None) != self._token(self.first, self.phase):
+            self.prime()
         self.graph.replay()
-        self.eng.global_step += self._bump
-        return self.eng.loss
+        eng.global_step += self._bump
+        eng._primed = self._token(self.lookahead, self.next_phase) if self.lookahead is not None else None
+        return eng.loss
 
 
 def warm(eng, token_batches, ids_input=False, steps=2):

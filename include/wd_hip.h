@@ -655,7 +655,8 @@ typedef struct wd_chain_opts {
   void *tile_stamps;
   int32_t row_tile;
   int32_t flags;       /* bit 0: row tile 16 without the priority split between the two co-resident workgroups; bit 1: dx stage without
-                          the reduction-split last column tile (A/B switches) */
+                          the reduction-split last column tile; bit 2: plain instead of write-through stores of the HBM outputs
+                          (A/B switches) */
   /* wide logit from a per-occurrence weight list (wd_prefetch_onehot): wide_logit[b] = wide_bias[0] + sum_s wide_vals[b*wide_S + s],
    * slots in order; replaces the wide_logit argument (input must be NULL); also stored to wide_out when that is not NULL */
   const float *wide_vals;

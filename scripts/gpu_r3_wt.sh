@@ -1,0 +1,24 @@
+#!/bin/bash
+# round 3: write-through stores of the tower's HBM outputs (WD_CHAIN_FLAGS=4) against the end-of-kernel L2 write-back;
+# how to cut the driver's 20 timed steps into graphs
+cd "${GRAFT_REPO_ROOT:-/root/repo}"; export TMPDIR=/tmp
+TAG=${1:-r3wt}; OUT=$PWD/gpurun_out/$TAG; mkdir -p $OUT
+timeout 300 python -m pytest tests/test_gpu_fused_tail.py -m gpu -x -q 2>&1 | tail -3
+b() { name=$1; shift; env "$@" timeout 150 python bench.py --no-cpu-baseline --no-pmc ${ARGS:---steps 20 --warmup 5} 2> $OUT/$name.err > $OUT/bench_$name.json; python - $OUT/bench_$name.json $name <<'PY'
+import json, sys
+try:
+    d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+    print("%-28s %.4f ms/step  %s" % (sys.argv[2], d["ms_per_step"], d.get("repeats_ms_per_step")))
+except Exception as e:
+    print(sys.argv[2], "FAILED", e)
+PY
+}
+b default X=1
+b tower_wt WD_CHAIN_FLAGS=4
+ARGS="--steps 200 --warmup 20" b default_200 X=1
+ARGS="--steps 200 --warmup 20" b tower_wt_200 WD_CHAIN_FLAGS=4
+timeout 200 python scripts/bench_graph_launch.py 2> $OUT/launch.err | tee $OUT/graph_launch.txt; tail -2 $OUT/launch.err
+WD_CHAIN_FLAGS=4 timeout 120 rocprofv3 --kernel-trace --output-format csv -d $OUT/prof -o trace -- python bench.py --steps 100 --warmup 10 --repeats 2 --no-cpu-baseline --no-pmc --no-parity > $OUT/prof.log 2>&1
+T=$(find $OUT/prof -name "*kernel_trace*.csv" | head -1)
+python scripts/trace_window.py $T k_tower_chain 45 2 > $OUT/c2_step_timeline_wt.txt; cat $OUT/c2_step_timeline_wt.txt
+rm -rf $OUT/prof

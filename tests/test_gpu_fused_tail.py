@@ -43,7 +43,7 @@ def test_products_launch_that_finishes_the_tail_is_bit_identical(kw, B):
     from wide_deep_amd.pipeline import StepGraph, step_eager
     from wide_deep_amd.plan import criteo_spec
     spec = criteo_spec(**kw)
-    a, b = _engine(spec, B), _engine(spec, B, WD_FUSE_TAIL=0)
+    a, b = _engine(spec, B, WD_FUSE_TAIL=1), _engine(spec, B, WD_FUSE_TAIL=0)
     assert a.chain and b.chain and a._tail_fusable() and not b._tail_fusable()
     hbs = [synth.make_raw_batch(a.plan, B, seed=500 + i, pos_rate=0.3) for i in range(8)]
     ta, tb = [synth.TokenBatch(a.plan, hb) for hb in hbs], [synth.TokenBatch(b.plan, hb) for hb in hbs]

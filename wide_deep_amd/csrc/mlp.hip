@@ -48,6 +48,7 @@ struct GemmArgs {
   int32_t bias_parts;   // bias = sum of `bias_parts` vectors of stride N
   int32_t a_vec, b_vec; // float4 loads legal (ld % 4 == 0 and 16-byte aligned base)
   int32_t tiles_m, tiles_n;
+  int32_t wt;           // TN partials stored write-through (common.h)
 };
 
 __device__ __forceinline__ float act_fwd(float v, int act) {
@@ -127,7 +128,7 @@ struct FuseTile {
   int32_t nsplit;
 };
 
-template <bool A_RC, bool B_RC, int EPI, int BK, bool VEC, bool TAIL = false>
+template <bool A_RC, bool B_RC, int EPI, int BK, bool VEC, bool TAIL = false, bool DEEP = false>
 __device__ __forceinline__ void gemm_body(const GemmArgs &g, const int orig, const int bz, const FuseTile &ft = FuseTile{}) {
   constexpr int LDA = A_RC ? LD_RC : LD_OC;
   constexpr int LDB = B_RC ? LD_RC : LD_OC;
@@ -260,32 +261,9 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &g, const int orig, con
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 
-  float4 ra[NV], rb[NV];
-  bool fast = fast_tile && (kbeg + BK <= kend);
-  if (fast) {
-    load_fast(kbeg, ra, rb);
-    store_fast(As[0], Bs[0], ra, rb);
-  } else {
-    load_a(kbeg, ra);
-    load_b(kbeg, rb);
-    store_a(As[0], kbeg, ra);
-    store_b(Bs[0], kbeg, rb);
-  }
-  __syncthreads();
-
   const int fr = (lane >> 5), fc = (lane & 31);
-  int cur = 0;
-  for (int64_t k0 = kbeg; k0 < kend; k0 += BK) {
-    const bool more = k0 + BK < kend;
-    fast = fast_tile && (k0 + 2 * BK <= kend);  // the slab being prefetched is full
-    if (more) {
-      if (fast) {
-        load_fast(k0 + BK, ra, rb);
-      } else {
-        load_a(k0 + BK, ra);
-        load_b(k0 + BK, rb);
-      }
-    }
+  // one slab of MFMAs from LDS buffer `cur`
+  auto compute = [&](int cur) {
     const float *Ac = As[cur] + fr * LDA + wm * 32 + fc;
     const float *Bc = Bs[cur] + fr * LDB + wn * 32 + fc;
     // software-pipelined fragment reads: the LDS reads of group gi+1 are issued BEFORE the MFMAs of group gi
@@ -313,16 +291,93 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &g, const int orig, con
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[gi & 1][j], fb[gi & 1][j], acc, 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
-    if (more) {
-      if (fast) {
-        store_fast(As[cur ^ 1], Bs[cur ^ 1], ra, rb);
-      } else {
-        store_a(As[cur ^ 1], k0 + BK, ra);
-        store_b(Bs[cur ^ 1], k0 + BK, rb);
-      }
+  };
+
+  const int64_t nslab = (kend - kbeg) / BK;
+  if (DEEP && fast_tile && kend > kbeg && (kend - kbeg) % BK == 0 && nslab >= 2) {
+    // Interior tile, whole slabs (the weight-gradient products of a full batch): the global loads run TWO slabs ahead of the
+    // MFMAs -- slab s+1 waits in registers while slab s+2 is requested, and goes to the other LDS buffer after the MFMAs
+    // of slab s.  One slab of MFMAs (16 per wavefront at BK = 32) is ~0.45 us; an L2 / HBM round trip beside the row update of
+    // the same step is several times that, and with one slab in flight every slab boundary waited for it.
+    struct Slab {
+      float4 a[NV], b[NV];
+    };
+    auto ld = [&](int64_t sl) {
+      Slab x;
+      load_fast(kbeg + sl * BK, x.a, x.b);
+      return x;
+    };
+    auto st = [&](int buf, const Slab &x) { store_fast(As[buf], Bs[buf], x.a, x.b); };
+    st(0, ld(0));
+    Slab r = ld(1), q;
+    __syncthreads();
+    int64_t sl = 0;           // top of the loop: LDS buffer 0 holds slab sl (even), r = slab sl + 1 (requested, maybe in flight)
+    while (sl + 3 < nslab) {
+      q = ld(sl + 2);
+      __builtin_amdgcn_sched_barrier(0);      // (the requests go out BEFORE the MFMAs of this slab, not behind them)
+      compute(0);
+      st(1, r);
+      __syncthreads();
+      r = ld(sl + 3);
+      __builtin_amdgcn_sched_barrier(0);
+      compute(1);
+      st(0, q);
+      __syncthreads();
+      sl += 2;
+    }
+    if (sl + 2 < nslab) {     // three slabs left
+      q = ld(sl + 2);
+      compute(0);
+      st(1, r);
+      __syncthreads();
+      compute(1);
+      st(0, q);
+      __syncthreads();
+      compute(0);
+    } else {                  // two
+      compute(0);
+      st(1, r);
+      __syncthreads();
+      compute(1);
     }
     __syncthreads();
-    cur ^= 1;
+  } else {
+    float4 ra[NV], rb[NV];
+    bool fast = fast_tile && (kbeg + BK <= kend);
+    if (fast) {
+      load_fast(kbeg, ra, rb);
+      store_fast(As[0], Bs[0], ra, rb);
+    } else {
+      load_a(kbeg, ra);
+      load_b(kbeg, rb);
+      store_a(As[0], kbeg, ra);
+      store_b(Bs[0], kbeg, rb);
+    }
+    __syncthreads();
+    int cur = 0;
+    for (int64_t k0 = kbeg; k0 < kend; k0 += BK) {
+      const bool more = k0 + BK < kend;
+      fast = fast_tile && (k0 + 2 * BK <= kend);  // the slab being prefetched is full
+      if (more) {
+        if (fast) {
+          load_fast(k0 + BK, ra, rb);
+        } else {
+          load_a(k0 + BK, ra);
+          load_b(k0 + BK, rb);
+        }
+      }
+      compute(cur);
+      if (more) {
+        if (fast) {
+          store_fast(As[cur ^ 1], Bs[cur ^ 1], ra, rb);
+        } else {
+          store_a(As[cur ^ 1], k0 + BK, ra);
+          store_b(Bs[cur ^ 1], k0 + BK, rb);
+        }
+      }
+      __syncthreads();
+      cur ^= 1;
+    }
   }
 
   // C/D layout of 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
@@ -335,7 +390,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &g, const int orig, con
 #pragma unroll
       for (int rg = 0; rg < 16; ++rg) {
         const int64_t m = m0 + wm * 32 + (rg & 3) + 8 * (rg >> 2) + 4 * fr;
-        if (n_ok && m < g.M) Cz[m * g.ldc + n] = acc[rg];
+        if (n_ok && m < g.M) wd::store1(&Cz[m * g.ldc + n], acc[rg], g.wt);
       }
       return;
     }
@@ -364,6 +419,46 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &g, const int orig, con
     const wd_tail_layer_t &L = ft.L;
     const wd::TailCtx &c = ft.c;
     const int32_t ns = ft.nsplit;
+    auto row_of = [&](int rg) -> int64_t { return m0 + wm * 32 + (rg & 3) + 8 * (rg >> 2) + 4 * fr; };
+    if (ns <= 16) {
+      // this lane's 16 rows in 8 rounds of two; the 32 partial loads + 4 parameter loads of a round are issued TWO rounds
+      // ahead of their use (three register sets): one exposed memory round trip for the tile instead of one per round
+      float v[3][2][16], pw[3][2], pa[3][2];
+      auto issue = [&](int k, int b) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int64_t m = row_of(2 * k + u);
+          const uint32_t o = (uint32_t)((m < g.M ? m : 0) * g.ldc + n);
+          pw[b][u] = c.P[L.w_off + o];
+          pa[b][u] = c.Pacc[L.w_off + o];
+#pragma unroll
+          for (int zz = 0; zz < 16; ++zz) {
+            const float *pz = g.C + (int64_t)(zz < ns ? zz : 0) * g.c_split;      // uniform
+            v[b][u][zz] = __hip_atomic_load(pz + o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+        }
+      };
+      auto consume = [&](int k, int b) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int64_t m = row_of(2 * k + u);
+          if (m >= g.M) continue;
+          float gv = 0.f;
+#pragma unroll
+          for (int zz = 0; zz < 16; ++zz) gv += zz < ns ? v[b][u][zz] : 0.f;
+          const uint32_t o = (uint32_t)(m * g.ldc + n);
+          wd::tail_apply(L, c, L.w_off + o, o, gv, pw[b][u], pa[b][u], true, true, true);
+        }
+      };
+      issue(0, 0);
+      issue(1, 1);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        if (k + 2 < 8) issue(k + 2, (k + 2) % 3);
+        consume(k, k % 3);
+      }
+      return;
+    }
 #pragma unroll 1
     for (int r0 = 0; r0 < 16; r0 += 4) {
       uint32_t off[4];
@@ -371,7 +466,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &g, const int orig, con
       float gv[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const int64_t m = m0 + wm * 32 + u + 8 * (r0 >> 2) + 4 * fr;
+        const int64_t m = row_of(r0 + u);
         ok[u] = m < g.M;
         off[u] = (uint32_t)((ok[u] ? m : 0) * g.ldc + n);
       }
@@ -418,7 +513,8 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &g, const int orig, con
       if (g.accumulate) v += Cz[m * g.ldc + n];
       if (g.act_src) v *= act_bwd(g.act_src[m * g.ld_act + n], g.act);
     }
-    Cz[m * g.ldc + n] = v;
+    if (EPI == 2) wd::store1(&Cz[m * g.ldc + n], v, g.wt);
+    else Cz[m * g.ldc + n] = v;
   }
 }
 
@@ -440,7 +536,7 @@ struct GroupArgs {
   int32_t njobs;
 };
 
-template <int BK, bool VEC>
+template <int BK, bool VEC, bool DEEP = false>
 __global__ void __launch_bounds__(256) k_gemm_tn_group(GroupArgs G) {
   int j = 0;
   while (j + 1 < G.njobs && (int)blockIdx.x >= G.first[j + 1]) ++j;
@@ -470,7 +566,7 @@ __global__ void __launch_bounds__(256) k_gemm_tn_group(GroupArgs G) {
     return;
   }
   const int nwg = g.tiles_m * g.tiles_n;
-  gemm_body<false, false, 2, BK, VEC>(g, rem % nwg, rem / nwg);
+  gemm_body<false, false, 2, BK, VEC, false, DEEP>(g, rem % nwg, rem / nwg);
 }
 
 // wd_gemm_tn_group_tail: the grouped launch that also finishes the dense tail of the step (see FuseTile).
@@ -492,7 +588,7 @@ struct FusedArgs {
 };
 static_assert(sizeof(FusedArgs) <= 4096, "kernel arguments of k_gemm_tn_group_tail");
 
-template <int BK, bool VEC>
+template <int BK, bool VEC, bool DEEP = false>
 __global__ void __launch_bounds__(256) k_gemm_tn_group_tail(FusedArgs G) {
   int j = 0;
   while (j + 1 < G.njobs && (int)blockIdx.x >= G.first[j + 1]) ++j;
@@ -539,7 +635,7 @@ __global__ void __launch_bounds__(256) k_gemm_tn_group_tail(FusedArgs G) {
   }
   const int nwg = g.tiles_m * g.tiles_n;
   const FuseTile ft{G.layer[lyr], kind == WD_FUSE_KERNEL, c, G.counters + G.ctr0[j], G.nsplit[j]};
-  gemm_body<false, false, 2, BK, VEC, true>(g, rem % nwg, rem / nwg, ft);
+  gemm_body<false, false, 2, BK, VEC, true, DEEP>(g, rem % nwg, rem / nwg, ft);
 }
 
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -1272,6 +1368,7 @@ extern "C" int wd_gemm_tn_splitk_group(const wd_tn_job_t *jobs, int32_t njobs, w
     g.tiles_n = (int)wd::ceil_div(g.N, BN);
     g.a_vec = (g.lda % 4 == 0) && aligned16(g.A);
     g.b_vec = (g.ldb % 4 == 0) && aligned16(g.B);
+    g.wt = wd::wt_mask() & WD_WT_PRODUCTS ? 1 : 0;
     vec = vec && g.a_vec && g.b_vec;
     G.first[j] = total;
     G.count[j] = g.tiles_m * g.tiles_n * q.nsplit;
@@ -1286,7 +1383,11 @@ extern "C" int wd_gemm_tn_splitk_group(const wd_tn_job_t *jobs, int32_t njobs, w
     if (vec) hipLaunchKernelGGL((k_gemm_tn_group<kBK, true>), dim3((unsigned)total), dim3(256), 0, wd::as_stream(stream), G);
     else hipLaunchKernelGGL((k_gemm_tn_group<kBK, false>), dim3((unsigned)total), dim3(256), 0, wd::as_stream(stream), G);
   } else {
-    if (vec) hipLaunchKernelGGL((k_gemm_tn_group<32, true>), dim3((unsigned)total), dim3(256), 0, wd::as_stream(stream), G);
+    // WD_TN_DEEP=1: global loads two slabs ahead of the MFMAs (gemm_body DEEP).  The launch gets shorter (48 -> 41 us in the
+    // step) and the step longer: the row update and the dense tail beside / behind it stretch by more (profiles/README.md)
+    static const bool deep = getenv("WD_TN_DEEP") && atoi(getenv("WD_TN_DEEP")) == 1;
+    if (vec && deep) hipLaunchKernelGGL((k_gemm_tn_group<32, true, true>), dim3((unsigned)total), dim3(256), 0, wd::as_stream(stream), G);
+    else if (vec) hipLaunchKernelGGL((k_gemm_tn_group<32, true>), dim3((unsigned)total), dim3(256), 0, wd::as_stream(stream), G);
     else hipLaunchKernelGGL((k_gemm_tn_group<32, false>), dim3((unsigned)total), dim3(256), 0, wd::as_stream(stream), G);
   }
   return wd::check_launch("wd_gemm_tn_splitk_group");
@@ -1343,6 +1444,7 @@ extern "C" int wd_gemm_tn_group_tail(const wd_tn_job_t *jobs, const wd_tn_fuse_t
     g.tiles_n = (int)wd::ceil_div(g.N, BN);
     g.a_vec = (g.lda % 4 == 0) && aligned16(g.A);
     g.b_vec = (g.ldb % 4 == 0) && aligned16(g.B);
+    g.wt = wd::wt_mask() & WD_WT_PRODUCTS ? 1 : 0;
     vec = vec && g.a_vec && g.b_vec;
     G.count[j] = g.tiles_m * g.tiles_n * q.nsplit;
     G.nsplit[j] = q.nsplit;
@@ -1359,7 +1461,9 @@ extern "C" int wd_gemm_tn_group_tail(const wd_tn_job_t *jobs, const wd_tn_fuse_t
   G.first[njobs] = total;
   G.njobs = njobs;
   G.P = P; G.Pacc = Pacc; G.Gflat = Gflat; G.counters = tile_counters; G.inv = inv; G.lr = lr;
-  if (vec) hipLaunchKernelGGL((k_gemm_tn_group_tail<32, true>), dim3((unsigned)total), dim3(256), 0, wd::as_stream(stream), G);
+  static const bool deep = getenv("WD_TN_DEEP") && atoi(getenv("WD_TN_DEEP")) == 1;
+  if (vec && deep) hipLaunchKernelGGL((k_gemm_tn_group_tail<32, true, true>), dim3((unsigned)total), dim3(256), 0, wd::as_stream(stream), G);
+  else if (vec) hipLaunchKernelGGL((k_gemm_tn_group_tail<32, true>), dim3((unsigned)total), dim3(256), 0, wd::as_stream(stream), G);
   else hipLaunchKernelGGL((k_gemm_tn_group_tail<32, false>), dim3((unsigned)total), dim3(256), 0, wd::as_stream(stream), G);
   return wd::check_launch("wd_gemm_tn_group_tail");
 }

@@ -94,6 +94,8 @@ struct ChainArgs {
   float *dx;
   int64_t ld_dx;
   unsigned long long *stamps;   // diagnostics (wd_chain_opts_t.stamps): shader-clock stamps of workgroups 0 and 100
+  int32_t flags_prio;                // wd_chain_opts_t.flags bit 3: s_setprio 3 for every wavefront of the launch
+  int32_t flags_wt;                  // write-through stores of the HBM outputs (WD_WT bit 0; wd_chain_opts_t.flags bit 2 turns it off)
   int32_t flags_nosplit;             // wd_chain_opts_t.flags bit 1: dx stage without the split last tile (A/B switch)
   int32_t prio_split;                // row tile 16: the wavefront in the odd hardware slot of each SIMD runs at priority 3
   unsigned long long *tile_stamps;   // wd_chain_opts_t.tile_stamps: [tile][2] realtime-clock stamps {start, x tile in LDS}
@@ -250,7 +252,11 @@ struct StageAff {
   // the LAST tile is split over the reduction instead: every wavefront multiplies a quarter of the k range, the partial tiles
   // meet in this scratch and are added in wavefront order (fixed summation order)
   float *split_scratch;
+  // HBM outputs (activations, dz, dx) stored at device scope = written through this XCD's L2 while the kernel computes,
+  // instead of staying dirty in it until the end-of-kernel release writes ~45 MB back (common.h; wd_chain_opts_t.flags bit 2: off)
+  int32_t wt;
 };
+__device__ __forceinline__ void gstore(float *p, float v, bool wt) { wd::store1(p, v, wt); }
 template <typename TL, int MODE>
 __device__ __forceinline__ void stage(const float *__restrict__ in, int K, const float *__restrict__ Wpk, int N,
                                       const float *__restrict__ bias, int act,
@@ -296,7 +302,7 @@ __device__ __forceinline__ void stage(const float *__restrict__ in, int K, const
           const int32_t p = af.sc_pos[(b0 + m) * af.sc_S + (n >> af.sc_shift)];
           if (p >= 0) af.sc_out[(int64_t)p * af.sc_RS + (n & (af.sc_dim - 1))] = o;
         }
-      } else if ((FULLR || b0 + m < batch) && n < n_store) g_out[(b0 + m) * ld_g + n] = o;
+      } else if ((FULLR || b0 + m < batch) && n < n_store) gstore(&g_out[(b0 + m) * ld_g + n], o, af.wt);
     }
     if (MODE == 1) {   // this tile's partials of the bias / BN gradients: column sums over its RT rows (rows >= batch are 0)
 #pragma unroll
@@ -380,7 +386,7 @@ __device__ __forceinline__ void stage(const float *__restrict__ in, int K, const
           if (pp >= 0) af.sc_out[(int64_t)pp * af.sc_RS + (n & (af.sc_dim - 1))] = v;
         }
       } else if (n < n_store) {
-        g_out[(b0 + m) * ld_g + n] = v;
+        gstore(&g_out[(b0 + m) * ld_g + n], v, af.wt);
       }
     }
   }
@@ -413,6 +419,9 @@ __global__ void __launch_bounds__(256, RT_ == 16 ? 2 : 1) k_tower_chain(ChainArg
   // lock-step (both gather, both multiply at half rate, both store).  The wavefront in the odd hardware slot gets priority: it
   // runs its matrix phases at full rate and pulls ahead, the other one fills its gaps.
   if (RT == 16 && g.prio_split && (__builtin_amdgcn_s_getreg((4) | (0 << 6) | (3 << 11)) & 1u)) __builtin_amdgcn_s_setprio(3);
+  // (row tile 32, one wavefront per SIMD: priority over the wavefronts of the kernels that run beside the tower -- bucketing,
+  // sort and gather of the next batch; wd_chain_opts_t.flags bit 3)
+  if (g.flags_prio) __builtin_amdgcn_s_setprio(3);
 
   // ---- head inputs: requested now, consumed after the last hidden layer (no exposed latency there) -------------
   const int KL = uni(g.layer[L - 1].N);
@@ -590,6 +599,7 @@ __global__ void __launch_bounds__(256, RT_ == 16 ? 2 : 1) k_tower_chain(ChainArg
     const wd_chain_layer_t &ly = g.layer[l];
     float *out = lds + g.a_off[l];
     StageAff af{};
+    af.wt = g.flags_wt;
     if (l > 0 && g.layer[l - 1].gamma) { af.s_in = lds + g.tab_off[l - 1]; af.t_in = af.s_in + g.layer[l - 1].N; }
     if (ly.gamma) { af.s_out = lds + g.tab_off[l]; af.t_out = af.s_out + ly.N; }
     stage<TL, 0>(in, K, ly.Wpk, ly.N, ly.bias, g.act, nullptr, out, ly.a_out, g.ld_act, ly.N, b0, g.batch, af,
@@ -742,6 +752,7 @@ __global__ void __launch_bounds__(256, RT_ == 16 ? 2 : 1) k_tower_chain(ChainArg
     const wd_chain_layer_t &ly = g.layer[l];
     const wd_chain_layer_t &lp = g.layer[l - 1];
     StageAff af{};
+    af.wt = g.flags_wt;
     if (lp.gamma) { af.s_out = lds + g.tab_off[l - 1]; af.t_out = af.s_out + lp.N; }
     af.db_out = lp.db_part ? lp.db_part + (int64_t)blockIdx.x * lp.N : nullptr;
     af.dg_out = lp.dgamma_part ? lp.dgamma_part + (int64_t)blockIdx.x * lp.N : nullptr;
@@ -754,6 +765,7 @@ __global__ void __launch_bounds__(256, RT_ == 16 ? 2 : 1) k_tower_chain(ChainArg
   if (g.dx && g.dx_cols > 0) {
     const wd_chain_layer_t &ly = g.layer[0];
     StageAff af{};
+    af.wt = g.flags_wt;
     af.sc_pos = g.sc_pos; af.sc_out = g.sc_out; af.sc_S = g.sc_S; af.sc_RS = g.sc_RS; af.sc_dim = g.sc_dim; af.sc_shift = g.sc_shift;
     // (a_0's LDS region is dead since the gradient stage of layer 1 read it for act')
     if (ly.N >= 4 * RT && !(g.flags_nosplit)) af.split_scratch = lds + g.a_off[0];
@@ -914,11 +926,14 @@ extern "C" int wd_tower_chain(const float *x, int64_t ld_act, int32_t K0, const 
   g.wide_logit = wide_logit; g.labels = labels; g.weights = weights; g.batch = batch;
   g.dnn_logit = dnn_logit; g.logit = logit; g.prob = prob; g.dlogit = dlogit; g.loss_sum = loss_sum;
   g.Gpart_logits = Gpart_logits; g.dx = dx; g.ld_dx = ld_dx;
+  g.flags_wt = wd::wt_mask() & WD_WT_TOWER ? 1 : 0;
   if (opts) {
     g.stamps = static_cast<unsigned long long *>(opts->stamps);
     g.tile_stamps = static_cast<unsigned long long *>(opts->tile_stamps);
     g.prio_split = opts->flags & 1 ? 0 : 1;
     g.flags_nosplit = opts->flags & 2 ? 1 : 0;
+    if (opts->flags & 4) g.flags_wt = 0;
+    g.flags_prio = opts->flags & 8 ? 1 : 0;
     g.loss_part = opts->loss_part;
     if (opts->dx_pos) {
       WD_REQUIRE(opts->dx_scatter && opts->dx_S > 0 && opts->dx_rs > opts->dx_dim && opts->dx_dim >= 4 &&

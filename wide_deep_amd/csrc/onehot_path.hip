@@ -182,7 +182,7 @@ __global__ void __launch_bounds__(256)
 k_prefetch_onehot(const float *__restrict__ rec, int32_t rec_stride, const wd_slot_t *__restrict__ rslots, int32_t S,
                   const int32_t *__restrict__ ids, int64_t B, float *__restrict__ x, int64_t ldx, float *__restrict__ wv,
                   const float *__restrict__ dense, int64_t ld_dense, const wd_dense_col_t *__restrict__ cols,
-                  int32_t ncols, int32_t gather_blocks, unsigned long long *__restrict__ span) {
+                  int32_t ncols, int32_t gather_blocks, unsigned long long *__restrict__ span, int32_t wt) {
   const int t = threadIdx.x;
   // diagnostics (bench.py: the duration of this launch AS IT RUNS INSIDE the pipelined step): every workgroup stores the
   // chip-wide realtime clock (100 MHz) at its start and end, span[2 * block], [2 * block + 1] (one min / max word for all of
@@ -238,8 +238,8 @@ k_prefetch_onehot(const float *__restrict__ rec, int32_t rec_stride, const wd_sl
     for (int q = 0; q < BPG; ++q) {
       if (w[q] >= nwork) continue;
       const int64_t b = w[q] / S;
-      *reinterpret_cast<f4 *>(x + b * ldx + col[q] + 4 * lane) = r[q];
-      if (lane == 0) wv[w[q]] = wq[q];
+      wd::store4(reinterpret_cast<float4 *>(x + b * ldx + col[q] + 4 * lane), make_float4(r[q].x, r[q].y, r[q].z, r[q].w), wt);
+      if (lane == 0) wd::store1(&wv[w[q]], wq[q], wt);
     }
   }
   if (span) {
@@ -339,6 +339,7 @@ struct SortArgs {
   int2 *ppatch;
   int32_t long_cap, bag_bits, nb, S;
   int64_t batch;
+  int32_t prio;              // wavefront priority of the two launches (WD_SORT_PRIO; they run beside the tower)
 };
 
 // One bucket, CAP pairs rank-sorted in LDS (2 x CAP x 8 bytes).  false: the bucket is larger (SMALL launch: the caller lists it).
@@ -559,6 +560,7 @@ __global__ void __launch_bounds__(256) k_bucket_sort_small(SortArgs g) {
   __shared__ uint64_t lds_pairs[SMALL_CAP];
   __shared__ uint64_t lds_in[SMALL_CAP];
   __shared__ uint32_t s_kmin[4], s_kmax[4];
+  if (g.prio) __builtin_amdgcn_s_setprio(3);
   const int bkt = blockIdx.x;
   if (!sort_bucket<SMALL_CAP, true, 256>(g, bkt, lds_pairs, lds_in, s_kmin, s_kmax, nullptr) && threadIdx.x == 0)
     g.big_list[atomicAdd(&g.long_list[1], 1)] = bkt;
@@ -571,6 +573,7 @@ __global__ void __launch_bounds__(512) k_bucket_sort_big(SortArgs g) {
   __shared__ uint64_t lds_in[BIG_CAP];
   __shared__ uint32_t s_kmin[8], s_kmax[8];
   __shared__ int32_t s_dom[16];
+  if (g.prio) __builtin_amdgcn_s_setprio(3);
   const int nbig = g.long_list[1];
   for (int q = blockIdx.x; q < nbig; q += BIG_WORKERS) {
     sort_bucket<BIG_CAP, false, 512>(g, g.big_list[q], lds_pairs, lds_in, s_kmin, s_kmax, s_dom);
@@ -591,6 +594,7 @@ struct RowUpd {
   int64_t ldx, nldx, nnz, batch;
   int32_t rec_stride, dim, S, flat_blocks, long_cap;
   float lr_emb, lr_w, l1, l2;
+  int32_t wt;                 // rows / patches stored write-through (common.h)
 };
 
 __device__ __forceinline__ void ftrl_row(float &w, float &z, float &n, float g, float lr, float l1, float l2) {
@@ -632,8 +636,8 @@ k_row_update(RowUpd u) {
     for (int k = l; k < pj.y; k += nl) {
       const int32_t bag2 = (int32_t)(uint32_t)((have_first && k == l) ? first : u.npairs[pj.x + k]);
       float *dst = u.nx + (int64_t)(bag2 / S) * u.nldx + out_col;
-      for (int c = 0; c < LG; ++c) *reinterpret_cast<float4 *>(dst + 4 * c) = make_float4(row[4 * c], row[4 * c + 1], row[4 * c + 2], row[4 * c + 3]);
-      u.nwv[bag2] = wnew;
+      for (int c = 0; c < LG; ++c) wd::store4(reinterpret_cast<float4 *>(dst + 4 * c), make_float4(row[4 * c], row[4 * c + 1], row[4 * c + 2], row[4 * c + 3]), u.wt);
+      wd::store1(&u.nwv[bag2], wnew, u.wt);
     }
   };
   if ((int)blockIdx.x == u.flat_blocks + LONG_WORKERS) {     // (grid: long-segment workers first, flat blocks, this one) bias_weights: g = sum_b dlogit[b] (fixed-shape tree), dense FTRL
@@ -842,12 +846,12 @@ k_row_update(RowUpd u) {
   float4 wn = w;
   if (lane_emb) {
     wn = adagrad_row4(a, w, g, u.lr_emb);
-    *reinterpret_cast<float4 *>(u.accum + off) = a;
-    *reinterpret_cast<float4 *>(u.rec + eoff) = wn;
+    wd::store4(reinterpret_cast<float4 *>(u.accum + off), a, u.wt);
+    wd::store4(reinterpret_cast<float4 *>(u.rec + eoff), wn, u.wt);
   }
   if (gl == 0) {
     ftrl_row(r.x, r.y, r.z, gw, u.lr_w, u.l1, u.l2);
-    *reinterpret_cast<float4 *>(u.rec + (int64_t)key * RS + D) = r;
+    wd::store4(reinterpret_cast<float4 *>(u.rec + (int64_t)key * RS + D), r, u.wt);
   }
   if (pj.y > 0) {     // every lane of the group gets the whole new row (shuffles) and takes every 4th pair of the run
     float row[16];
@@ -902,7 +906,7 @@ extern "C" int wd_prefetch_onehot(const float *rec, int32_t rec_stride, int32_t 
 #define WD_LAUNCH_PF(L)                                                                                                     \
   hipLaunchKernelGGL((k_prefetch_onehot<L, BPG>), dim3((unsigned)(gb + db)), dim3(256), 0, st, rec, rec_stride, rec_slots, \
                      S, ids, batch, x, ldx, wide_vals, dense, ld_dense, dense_cols, ncols, gb,                              \
-                     static_cast<unsigned long long *>(span))
+                     static_cast<unsigned long long *>(span), (int32_t)(wd::wt_mask() & WD_WT_PREFETCH ? 1 : 0))
   if (lanes == 4) WD_LAUNCH_PF(4);
   else if (lanes == 2) WD_LAUNCH_PF(2);
   else WD_LAUNCH_PF(1);
@@ -922,6 +926,8 @@ extern "C" int wd_bucket_sort(const int32_t *bucket_start, uint64_t *pairs, int3
   g.S = S; g.batch = batch;
   g.start = bucket_start; g.pairs = pairs; g.long_list = long_list; g.big_list = big_list; g.pstart = prev_bucket_start;
   g.ppairs = prev_pairs; g.ppatch = reinterpret_cast<int2 *>(prev_patch); g.long_cap = long_capacity; g.nb = nbuckets;
+  static const int sort_prio = getenv("WD_SORT_PRIO") ? atoi(getenv("WD_SORT_PRIO")) : 0;
+  g.prio = sort_prio;
   g.bag_bits = 1;
   while (g.bag_bits < 32 && ((int64_t)1 << g.bag_bits) < nnz) ++g.bag_bits;
   hipStream_t st = wd::as_stream(stream);
@@ -947,6 +953,7 @@ extern "C" int wd_row_update(float *rec, int32_t rec_stride, int32_t dim, float 
   u.dim = dim; u.S = S; u.lr_emb = lr_emb; u.lr_w = lr_wide; u.l1 = l1; u.l2 = l2;
   if (patch) { u.npairs = next->pairs; u.nx = next->x; u.nwv = next->wide_vals; u.nldx = next->ldx; }
   u.flat_blocks = (int32_t)wd::ceil_div(u.nnz * 4, 256);
+  u.wt = wd::wt_mask() & WD_WT_ROW_UPDATE ? 1 : 0;
   hipLaunchKernelGGL(k_row_update, dim3((unsigned)(u.flat_blocks + LONG_WORKERS + 1)), dim3(256), 0, wd::as_stream(stream), u);
   return wd::check_launch("wd_row_update");
 }

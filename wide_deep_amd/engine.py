@@ -90,7 +90,7 @@ class WideDeepEngine:
         self.act_id = capi.ACT_IDS["relu" if self.crelu else spec.activation]
         self.global_step = 0
         self._tail_fused, self._tile_counters = False, None
-        self.fuse_tail = os.environ.get("WD_FUSE_TAIL", "1") != "0"   # dense tail inside the weight-gradient launch
+        self.fuse_tail = os.environ.get("WD_FUSE_TAIL", "0") == "1"   # dense tail inside the weight-gradient launch
         self._primed = None             # pipeline.StepGraph: (batch, bucket set, activation buffer, global step) whose input work is in place
         dev = self.device
         f32 = dict(dtype=torch.float32, device=dev)
@@ -355,11 +355,11 @@ class WideDeepEngine:
             raise capi.WdError("wd_sort_workspace_bytes failed")
         self.sort_ws_bytes = max(qs)
         self.sort_ws = torch.zeros(self.sort_ws_bytes, dtype=torch.uint8, device=dev)
-        # two sets of bucketing scratch: in a pipelined multi-step graph (pipeline.StepGraph) the occurrences of step t+1
-        # are bucketed while the update of step t still reads its own set
+        # three sets of bucketing scratch: in a pipelined multi-step graph (pipeline.StepGraph) the occurrences of step t+1
+        # are bucketed and sorted on a branch of their own while the updates of steps t-1 and t still read their sets
         self._bucket_sets = []
         self.max_slot_buckets = max([((int(sl.num_buckets) + (1 << sh) - 1) >> sh) for sl, sh in zip(plan.slots, shifts)] + [1])
-        for _ in range(2):
+        for _ in range(3):
             self._bucket_sets.append(dict(
                 ticket=torch.zeros(4, **i32), unsorted=False,      # wd_bucket_onehot: last-workgroup ticket; arrival-order pairs
                 sorted=False,                                      # pairs sorted in place by wd_bucket_sort (flat row update)

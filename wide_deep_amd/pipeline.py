@@ -65,7 +65,7 @@ class StepGraph:
         self.eng = eng
         self.n = len(token_batches)
         self.ids_input = ids_input
-        self.first, self.lookahead, self.phase, self.primed = token_batches[0], lookahead, (phase[0] & 1, phase[1]), bool(primed)
+        self.first, self.lookahead, self.phase, self.primed = token_batches[0], lookahead, (phase[0], phase[1]), bool(primed)
         self.stream = stream or torch.cuda.Stream()
         self.graph = torch.cuda.CUDAGraph()
         if pipelined is None:
@@ -178,30 +178,33 @@ class StepGraph:
             main.wait_stream(s_h)
 
     def _capture_prefetched(self, tbs, ids_input):
-        """The pipelined step with the input layer taken out of the tower launch (engine.prefetch).  The sparse branch carries,
-        in stream order,  update(t-1) -> bucket(t+1) -> prefetch(t+1) -> update(t):  while tower(t) runs on the main branch
-        the sparse branch -- idle until dx(t) exists -- buckets batch t+1 (one launch, wd_bucket_onehot) and gathers its rows +
-        wide weights into the OTHER activation buffer (wd_prefetch_onehot); update(t) then stores the rows it rewrites into
-        that buffer again (wd_apply_next_t), so tower(t+1) -- which reads x from HBM -- sees exactly the tables after update(t):
+        """The pipelined step with the input layer taken out of the tower launch (engine.prefetch): everything that needs only
+        the ids of batch t+1 runs beside tower(t), on two branches --
 
-            hash branch    tokens -> ids of every step of the graph, ahead
-            main           tower(t) -> products(t) -> tail(t)                          tower(t) waits for update(t-1)
-            sparse branch  update(t-1) | bucket(t+1) -> prefetch(t+1) | update(t) + patch of x(t+1)
+            ids branch     tokens -> ids of every step (ahead) | bucket(t+1) -> sort(t+1)        released by the end of tail(t-1)
+            sparse branch  update(t-1) | prefetch(t+1) | update(t) + patch of x(t+1)            in stream order
+            main           tower(t) -> products(t) -> tail(t)                                   tower(t) waits for update(t-1)
 
-        No event sits between update(t-1) and tower(t) except the join itself, and the input work needs no edge of its own
-        (edges from the sparse branch into a third one two steps ahead crash hipStreamEndCapture of ROCm 7.2).  Every step's
-        results are bit-identical to the eager launches (gather -> tower -> ...), tests/test_gpu_prefetch.py."""
+        prefetch(t+1) gathers the rows + wide weights of batch t+1 into the next activation buffer (wd_prefetch_onehot) from
+        the tables as update(t-1) left them; update(t) -- which needs the sorted pairs of batches t and t+1 -- then stores the
+        rows it rewrites into that buffer again (wd_apply_next_t), so tower(t+1), which reads x from HBM, sees exactly the
+        tables after update(t).  Edges run main -> ids branch and ids branch -> sparse branch only (edges from the sparse
+        branch into a third one crash hipStreamEndCapture of ROCm 7.2); three scratch sets / activation buffers keep every
+        writer behind the last reader without more.  WD_SORT_BRANCH=0: bucket + sort in stream order on the sparse branch, in
+        front of the gather (the first layout of round 3: 0.1935 against 0.185 ms/step with Zipf ids).  Every step's results are
+        bit-identical to the eager launches (gather -> tower -> ...), tests/test_gpu_prefetch.py."""
         eng = self.eng
         main = torch.cuda.current_stream()
-        s_sp = eng._side(0)
+        s_sp, s_h = eng._side(0), eng._side(1)
         s_sp.wait_stream(main)
+        s_h.wait_stream(main)
         keep = self._events = []
         n = len(tbs)
         seq = list(tbs) + ([self.lookahead] if self.lookahead is not None else [])    # batches whose input work this graph does
         first = 1 if self.primed else 0                                               # ... from this one on
         set0, act0 = self.phase
-        na = eng.n_act      # 3 activation buffers: the one batch t+1 is gathered into was last read by the products of step t-2
-        sset = lambda t: (set0 + t) & 1
+        na, ns = eng.n_act, len(eng._bucket_sets)
+        sset = lambda t: (set0 + t) % ns
         sact = lambda t: (act0 + t) % na
 
         def event(stream):
@@ -210,60 +213,86 @@ class StepGraph:
             keep.append(ev)
             return ev
 
-        hash_ahead = not ids_input and len(seq) > first
-        ev_hash = {}
-        if hash_ahead:
-            s_h = eng._side(1)
-            s_h.wait_stream(main)
+        # ---- ids branch: tokens -> ids of every batch, back to back at the head of the graph; then, batch by batch,
+        # ids -> sorted (row, bag) pairs + the shared-row list of the batch before (sort_work below)
+        ev_ids, ev_sort, ev_tail, ev_twr = {}, {}, {}, {}
+        sort_branch = os.environ.get("WD_SORT_BRANCH", "0") == "1"
+        if not ids_input:
             with torch.cuda.stream(s_h):
                 for t in range(first, len(seq)):
                     synth.hash_tokens(eng, seq[t])
-                    ev_hash[t] = event(s_h)
+                    ev_ids[t] = event(s_h)
 
-        def input_work(t):
-            """bucket(t) (+ sort, + which rows of batch t-1 it shares) -> set t & 1, prefetch(t) -> activation buffer t % 3, on the
-            sparse branch behind update(t-2): the set's last reader; the buffer's last readers -- tower and products of step
-            t-3 -- completed before tower(t-2), which update(t-2) waited for."""
+        def sort_work(t):
+            """bucket(t) + sort(t) -> scratch set t % 3 (+ which rows batch t-1 shares with batch t), on the ids branch.  The
+            set's last reader, update(t-3), completed before tower(t-2) started; released by the end of tail(t-2), the work runs
+            beside tower(t-1) -- and beside the gather of the same batch instead of in front of it (with skewed ids the sort of
+            the head rows' buckets takes 80 us: in stream order in front of the gather it delayed update(t-1) by 30)."""
             bt = seq[t].batch
             eng._check_batch(bt)
-            if hash_ahead:
-                s_sp.wait_event(ev_hash[t])
+            s_b = s_h if sort_branch else s_sp
+            gate = ev_twr if os.environ.get("WD_SORT_GATE", "tail") == "tower" else ev_tail
+            if sort_branch and t - 2 in gate:
+                s_h.wait_event(gate[t - 2])
+            if not sort_branch and t in ev_ids:
+                s_sp.wait_event(ev_ids[t])
+            with torch.cuda.stream(s_b):
+                eng._sparse_bucketize(bt, s_b.cuda_stream, sset(t), prev=sset(t - 1) if t >= 1 else None)
+                ev_sort[t] = event(s_b)
+
+        def gather_work(t):
+            """prefetch(t) -> activation buffer t % 3 + wide weight list, on the sparse branch behind update(t-2) (stream order):
+            the buffer's last readers -- tower and products of step t-3 -- completed before tower(t-2), which update(t-2)
+            waited for."""
+            bt = seq[t].batch
+            if t in ev_ids:
+                s_sp.wait_event(ev_ids[t])
             with torch.cuda.stream(s_sp):
-                eng._sparse_bucketize(bt, s_sp.cuda_stream, sset(t), prev=sset(t - 1) if t >= 1 else None)
                 eng._prefetch_input(bt, s_sp.cuda_stream, sact(t))
 
         ev_upd = None
         if not self.primed:
-            input_work(0)
+            sort_work(0)
+            gather_work(0)
             ev_upd = event(s_sp)        # x(0) in place
         for t, tb in enumerate(tbs):
             bt = tb.batch
             if ev_upd is not None:
                 main.wait_event(ev_upd)                 # update(t-1), with its patch of this step's x
-            if t + 1 < len(seq):
-                input_work(t + 1)                       # sparse branch, behind update(t-1): runs beside tower(t)
+            if t + 1 < len(seq) and not sort_branch:
+                sort_work(t + 1)
+                gather_work(t + 1)
             eng._apar, eng._prefetched = sact(t), True
             eng.forward(bt, need_loss=True)             # the tower launch: x from HBM, wide logit from the weight list
-            ev_tower = event(main)
+            ev_tower = ev_twr[t] = event(main)
+            if t + 1 < len(seq) and sort_branch:
+                # (captured BEHIND the tower: the graph runtime keeps the first-captured successor of tail(t-1) on the main
+                # branch's hardware queue -- captured in front of the tower, bucket + sort ran between tail and tower)
+                sort_work(t + 1)                        # ids branch, released by tail(t-1): beside tower(t)
+                gather_work(t + 1)                      # sparse branch, behind update(t-1): beside tower(t)
             hold = {}
 
             def update_then_join(t=t, bt=bt, ev_tower=ev_tower, hold=hold):
                 s_sp.wait_event(ev_tower)
                 nxt = (sset(t + 1), sact(t + 1)) if t + 1 < len(seq) else None
+                if sort_branch and t in ev_sort:
+                    s_sp.wait_event(ev_sort[t])         # (a primed graph's step 0: sorted by the previous graph)
+                if sort_branch and nxt is not None:
+                    s_sp.wait_event(ev_sort[t + 1])     # the shared-row list of this batch
                 with torch.cuda.stream(s_sp):
                     eng._sparse_backward(bt, s_sp.cuda_stream, bucketized=True, pset=sset(t), patch=nxt)
                     hold["upd"] = event(s_sp)
 
             eng._dense_backward(bt, main.cuda_stream, after_products=update_then_join)
+            ev_tail[t] = event(main)
             ev_upd = hold["upd"]
         main.wait_stream(s_sp)
-        if hash_ahead:
-            main.wait_stream(s_h)
+        main.wait_stream(s_h)
 
     @property
     def next_phase(self):
         """(bucket set, activation buffer) the `lookahead` batch is left in: the phase of the graph that continues the chain."""
-        return ((self.phase[0] + self.n) & 1, (self.phase[1] + self.n) % self.eng.n_act)
+        return ((self.phase[0] + self.n) % len(self.eng._bucket_sets), (self.phase[1] + self.n) % self.eng.n_act)
 
     def _token(self, tb, phase):
         return (id(tb), phase[0], phase[1], self.eng.global_step)

@@ -463,11 +463,21 @@ def main():
         B = args.batch // world
     if sharded:
         from wide_deep_amd.dist import ShardedWideDeepEngine
+        # distinct (slot, id) pairs of this rank's first batch: what the exchange segments are sized from when the engine sends
+        # every distinct row once (sender-side unique; WD_SHARD_DEDUP=auto turns it on below 80 % distinct)
+        from wide_deep_amd.plan import FeaturePlan
+        uniq = None
+        if mean_len == 1 and os.environ.get("WD_SHARD_DEDUP", "auto") != "0":
+            gp = FeaturePlan(spec)
+            r0 = synth.make_raw_batch(gp, B, seed=20260925 + 1000 * rank, mean_len=1, dist=args.dist)["raw"].reshape(B, -1)
+            uniq = sum(len(np.unique(r0[:, j])) for j in range(r0.shape[1]))
+        dedup_expected = uniq is not None and (uniq < 0.8 * B * 26 or os.environ.get("WD_SHARD_DEDUP") == "1")
         eng = ShardedWideDeepEngine(spec, max_batch=B, max_nnz=B * 26 * (2 * mean_len + 2), seed=0,
-                                    expected_nnz=B * 26 * mean_len,
+                                    expected_nnz=B * 26 * mean_len, expected_unique=uniq,
                                     # per-peer segment capacity over the uniform expectation: Zipf(1.05) sends ~8 % of all
-                                    # occurrences to the owner of the hottest row (id % world), 1.6x the mean at 8 ranks
-                                    slack=1.3 if args.dist == "uniform" else 2.5)
+                                    # occurrences to the owner of the hottest row (id % world), 1.6x the mean at 8 ranks --
+                                    # but only one REQUEST when the row travels once
+                                    slack=1.3 if (args.dist == "uniform" or dedup_expected) else 2.5)
     else:
         eng = WideDeepEngine(spec, max_batch=B, max_nnz=B * 26 * (2 * mean_len + 2), seed=0, tower_dtype=tower_dtype)
     plan = getattr(eng, "hash_plan", eng.plan)    # sharded: batches live in the GLOBAL id space
@@ -644,7 +654,7 @@ def main():
         RS, cap, W = eng.RS, eng.cap, world
         out["config"]["exchange"] = {
             "graph": eng._graph_mode() if use_graph else "eager",
-            "segment_capacity": cap, "check_overflow": overflow,
+            "segment_capacity": cap, "check_overflow": overflow, "sender_side_unique": bool(getattr(eng, "dedup", False)),
             "payload_bytes_per_rank_per_step": {"A_rows_int32": 4 * W * cap, "B_records_f32": 4 * W * cap * RS,
                                                 "C_gradients_f32": 4 * W * cap * RS, "D_dense_allreduce_f32": 4 * eng.G.numel()},
             "owner_table_layout": "row records" if eng.rec is not None else "separate tables"}

@@ -22,6 +22,11 @@ def _free_port():
 def _spec(kind):
     from wide_deep_amd.plan import criteo_spec
     kind = kind.rstrip("4")                      # "<kind>4" = the same model on four ranks
+    if kind.endswith("_dedup"):                  # sender-side unique: vocabularies small enough that most rows repeat in a batch
+        s, ml = _spec(kind[: -len("_dedup")])    # (slot 2: three rows -> more than 32 occurrences each, the long-row path)
+        for sl, v in zip(s.slots, (300, 40, 3)):
+            sl.num_buckets = v
+        return s, ml
     if kind == "mixed":         # every embedding column its own width (the reference's default rule), ragged vocabularies
         s = criteo_spec(n_dense=2, n_sparse=5, buckets=101, dim=16, hidden=(24, 12))
         for sl, d, v in zip(s.slots, (8, 16, 32, 16, 4), (101, 57, 300, 23, 11)):
@@ -69,14 +74,18 @@ def _worker(rank, world, port, kind, q):
         if kind == "chain_pack":          # the tower kernel writes the gradient-exchange records itself (dist._chain_scatter)
             os.environ["WD_SHARD_PACK"] = "tower"
         B_loc, steps = (48 if world == 2 else 24), 3
+        dedup = "_dedup" in kind
+        if dedup:
+            B_loc = 160 if world == 2 else 120
         ref = WideDeepEngine(spec, max_batch=B_loc * world, seed=11)
         full0 = ref.export_state()
-        sh = ShardedWideDeepEngine(spec, max_batch=B_loc, seed=11)
+        sh = ShardedWideDeepEngine(spec, max_batch=B_loc, seed=11, dedup=True if dedup else None)
         sh.import_full_state(full0)
         bs = _batches(ref.plan, kind, steps, B_loc, world)
         if kind.startswith("chain"):
             assert sh.chain and ref.chain
             assert sh._scatter_ok() == (kind == "chain_pack")
+        assert sh.dedup == dedup
         if kind.startswith("mixed"):
             assert sh.mixed_dims and sh.dim == 32 and sh.emb.numel() >= sh.n_emb_rows * 32
         if kind.startswith("indicator"):
@@ -89,7 +98,7 @@ def _worker(rank, world, port, kind, q):
                     "raw": np.concatenate([h["raw"] for h in hbs]), "dense": None if hbs[0]["dense"] is None else np.concatenate([h["dense"] for h in hbs], 0),
                     "labels": np.concatenate([h["labels"] for h in hbs])}
             ref.train_step(synth.to_device_ids(ref.plan, glob))
-            if kind == "chain_graph":
+            if kind.startswith("chain_graph"):
                 # graph segments between the collectives: capture once on fixed buffers, refresh their contents per step
                 nb = synth.to_device_ids(sh.global_plan, hbs[rank])
                 if replay is None:
@@ -109,6 +118,13 @@ def _worker(rank, world, port, kind, q):
             torch.cuda.synchronize()
             assert_close(sh.logit[:B_loc], ref.logit[rank * B_loc:(rank + 1) * B_loc], 1e-4, 1e-5, "logits step %d" % st)
             sh.check_overflow()
+            if dedup:
+                # every distinct (slot, id) of this rank's batch was requested exactly once
+                assert any(xs["unique"] for xs in sh._xsets), "the sender-side unique path did not run"
+                ids = synth.to_device_ids(sh.global_plan, hbs[rank]).ids.view(B_loc, -1).cpu().numpy()
+                want = sum(len(np.unique(ids[:, j])) for j in range(ids.shape[1]))
+                got = int(sh.peer_counts.sum().item()) if kind != "chain_graph_dedup" else want
+                assert got == want, "requests %d, distinct rows %d" % (got, want)
         full1, exp = sh.export_full_state(), ref.export_state()
         for k, v in exp.items():
             if k == "global_step":
@@ -169,7 +185,7 @@ def test_exchange_overflow_is_reported():
 
 
 @pytest.mark.parametrize("kind", ["onehot", "multihot", "wideonly", "deeponly", "chain", "chain_graph", "chain_pack", "mixed", "indicator",
-                                  "onehot4", "chain4", "mixed4", "indicator4"])
+                                  "onehot4", "chain4", "mixed4", "indicator4", "chain_dedup", "chain_graph_dedup", "chain_dedup4"])
 def test_sharded_world2_equals_single_engine(kind):
     """world 2, and (kinds ending in 4) world 4: four owners per table, three peers per all-to-all"""
     world = 4 if kind.endswith("4") else 2
@@ -218,14 +234,22 @@ def _fullsize_worker(rank, world, port, kind, q):
         from wide_deep_amd.engine import WideDeepEngine
         from wide_deep_amd.plan import criteo_spec
         from tests.helpers import assert_close
-        cfg, idist = kind.split("_")
+        cfg, idist = kind.split("_")[:2]
+        dedup = kind.endswith("_dedup")
         buckets = 1_000_000 if cfg == "c2" else 3_846_154
         spec = criteo_spec(n_dense=13, n_sparse=26, buckets=buckets, dim=16, hidden=(256, 128, 64), mode="simple")
         B_loc, steps = 4096, 3
         ref = WideDeepEngine(spec, max_batch=B_loc * world, seed=3)
+        uniq = None
+        if dedup:       # segments sized from the distinct rows of a batch (what bench.py does from its first batch)
+            r0 = synth.make_raw_batch(ref.plan, B_loc, seed=7000 + rank, mean_len=1, dist=idist)["raw"].reshape(B_loc, -1) % buckets
+            uniq = sum(len(np.unique(r0[:, j])) for j in range(r0.shape[1]))
         sh = ShardedWideDeepEngine(spec, max_batch=B_loc, max_nnz=B_loc * 26 * 4, seed=3, expected_nnz=B_loc * 26,
-                                   slack=1.3 if idist == "uniform" else 2.5)
+                                   slack=1.3 if (idist == "uniform" or dedup) else 2.5, expected_unique=uniq,
+                                   dedup=True if dedup else False)
         assert sh.chain and ref.chain and sh.rec is not None and ref.rec is not None
+        if dedup:
+            assert sh.dedup and sh.cap < 0.75 * B_loc * 26 / world * 1.3, "segments are not sized from the distinct rows"
         S = ref.plan.S
         for st in range(steps):
             hbs = [synth.make_raw_batch(ref.plan, B_loc, seed=7000 + 10 * st + r, mean_len=1, dist=idist) for r in range(world)]
@@ -269,7 +293,7 @@ def _fullsize_worker(rank, world, port, kind, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("kind", ["c2_uniform", "c2_zipf", "c3_uniform"])
+@pytest.mark.parametrize("kind", ["c2_uniform", "c2_zipf", "c3_uniform", "c2_zipf_dedup"])
 def test_sharded_world2_at_baseline_size(kind):
     """BASELINE configs[1] / configs[2] shape through the sharded engine: world 2 on one GPU (gloo staging), 4096 examples per
     rank, uniform and Zipf(1.05) ids, segment overflow checked, against the full-size single engine on the 8192-example

@@ -225,6 +225,8 @@ _PROTOS = {
     "wd_tower_chain_blocks": [I64, I32],
     "wd_tower_chain": [P, I64, I32, P, I32, I32, F32, P, P, P, P, P, I64, P, P, P, P, P, P, P, I64, I32, P, P],
     "wd_chain_tail": [P, I32, P, P, P, F32, F32, I32, P],
+    "wd_route_unique": [P, I64, I32, I32, P, P, P, P, P, P],
+    "wd_row_grad_presum": [P, I32, I64, P, I64, P, I32, P, P, I32, P, P, I32, P],
     "wd_gemm_tn_group_tail": [P, P, I32, P, I32, P, P, P, F32, F32, P, I32, P],
     "wd_logits_head_h": [P, I64, I64, P, P, I32, P, P, P, I64, P, P, P, P, P, P, I64, I32, P, P],
     "wd_hgemm_nn": [P, I64, P, I64, P, I32, I32, P, I64, P, I64, I64, I64, I64, P],

@@ -202,6 +202,90 @@ k_grad_pack(const wd_slot_t *__restrict__ slots, int32_t S, const int32_t *__res
   }
 }
 
+
+// ---- sender-side unique (wd_route_unique): one request per DISTINCT (owner, local row) of the batch ---------------------------
+// Input: the batch's occurrences sorted on (key, occurrence) -- wd_bucket_onehot + wd_bucket_sort with requester-side slot
+// descriptors whose row space is  key = W * local_row_base(slot) + id,  so that  owner = key % W  and  local row = key / W
+// with no table lookup.  A position whose predecessor holds another key starts a row ("head"): heads get the next entry of
+// their owner's segment in sorted order (deterministic: wave votes ordered through LDS, chunk prefixes from k_route_scan), every
+// other occurrence of the row points at the same entry.  With skewed ids a batch asks for less than half as many rows as it has
+// occurrences (Zipf(1.05), 8192 x 26: 46 %), and sends one pre-summed gradient per row (wd_row_grad_presum).
+__device__ __forceinline__ uint32_t uq_key(uint64_t p) { return (uint32_t)(p >> 32); }
+
+template <bool SCATTER>
+__global__ void __launch_bounds__(256)
+k_route_unique(const uint64_t *__restrict__ pairs, int64_t n, int64_t per_chunk, int32_t W, int32_t cap,
+               int32_t *__restrict__ cntm, int32_t *__restrict__ send_rows, int32_t *__restrict__ pos) {
+  __shared__ int32_t wcount[4][MAX_W];
+  __shared__ int32_t running[MAX_W];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  if (!SCATTER) {   // count pass: every workgroup also clears its share of the send segments (unused entries = row -1)
+    const int64_t m = (int64_t)W * cap;
+    const int64_t per = (m + gridDim.x - 1) / gridDim.x;
+    const int64_t i1 = ((int64_t)blockIdx.x + 1) * per < m ? ((int64_t)blockIdx.x + 1) * per : m;
+    for (int64_t i = (int64_t)blockIdx.x * per + t; i < i1; i += 256) send_rows[i] = -1;
+  }
+  if (t < MAX_W) running[t] = (SCATTER && t < W) ? cntm[(int64_t)blockIdx.x * W + t] : 0;
+  __syncthreads();
+  const int64_t i0 = (int64_t)blockIdx.x * per_chunk;
+  const int64_t i1 = i0 + per_chunk < n ? i0 + per_chunk : n;
+  for (int64_t base = i0; base < i1; base += 256) {
+    const int64_t i = base + t;
+    bool head = false;
+    uint64_t pr = 0;
+    if (i < i1) {
+      pr = pairs[i];
+      head = i == 0 || uq_key(pairs[i - 1]) != uq_key(pr);
+    }
+    const uint32_t key = uq_key(pr);
+    const int32_t o = head ? (int32_t)(key % (uint32_t)W) : -1;
+    int32_t my_rank = 0;
+    for (int w = 0; w < W; ++w) {
+      const unsigned long long m = __ballot(o == w);
+      if (o == w) my_rank = __popcll(m & ((1ull << lane) - 1ull));
+      if (lane == 0) wcount[wave][w] = __popcll(m);
+    }
+    __syncthreads();
+    if (SCATTER && head) {
+      int32_t before = running[o];
+      for (int w2 = 0; w2 < wave; ++w2) before += wcount[w2][o];
+      const int32_t p = before + my_rank;   // index inside the owner's segment
+      const int32_t occ = (int32_t)(uint32_t)pr;
+      if (p < cap) {
+        send_rows[(int64_t)o * cap + p] = (int32_t)(key / (uint32_t)W);
+        pos[occ] = o * cap + p;
+      } else {
+        pos[occ] = -1;
+      }
+    }
+    __syncthreads();
+    if (t < W) running[t] += wcount[0][t] + wcount[1][t] + wcount[2][t] + wcount[3][t];
+    __syncthreads();
+  }
+  if (!SCATTER && t < W) cntm[(int64_t)blockIdx.x * W + t] = running[t];
+}
+
+// every occurrence that is not the first of its row: the entry of the row's head (first position holding the key: lower bound)
+__global__ void __launch_bounds__(256)
+k_route_unique_fill(const uint64_t *__restrict__ pairs, int64_t n, int32_t *__restrict__ pos) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n || i == 0) return;
+  const uint64_t pr = pairs[i];
+  const uint32_t key = uq_key(pr);
+  if (uq_key(pairs[i - 1]) != key) return;      // a head: done by the scatter pass
+  int64_t lo = 0, hi = i - 1;                    // first index in [0, i - 1] holding `key` (pairs[i - 1] does)
+  // galloping backwards first: most rows have a handful of occurrences
+  int64_t step = 1;
+  while (i - 1 - step >= 0 && uq_key(pairs[i - 1 - step]) == key) step <<= 1;
+  lo = i - 1 - step >= 0 ? i - 1 - step + 1 : 0;
+  hi = i - 1 - (step >> 1);
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (uq_key(pairs[mid]) == key) hi = mid; else lo = mid + 1;
+  }
+  pos[(int32_t)(uint32_t)pr] = pos[(int32_t)(uint32_t)pairs[lo]];
+}
+
 }  // namespace
 
 extern "C" int32_t wd_route_chunks(void) { return MAX_CHUNKS; }
@@ -224,6 +308,27 @@ extern "C" int wd_route_build(const wd_slot_t *local_slots, int32_t S, int32_t w
     hipLaunchKernelGGL((k_route<true>), dim3(nchunks), dim3(256), 0, st, local_slots, S, world, ids, bag_offs, nbags,
                        bags_per_chunk, cap, workspace, send_rows, pos);
   return wd::check_launch("wd_route_build");
+}
+
+
+extern "C" int wd_route_unique(const uint64_t *sorted_pairs, int64_t n, int32_t world, int32_t cap, int32_t *send_rows,
+                               int32_t *pos, int32_t *workspace, int32_t *peer_counts, int32_t *overflow, wd_stream_t stream) {
+  WD_REQUIRE(sorted_pairs && send_rows && pos && workspace && peer_counts && overflow, "null pointer");
+  WD_REQUIRE(world >= 1 && world <= MAX_W && cap > 0 && n >= 0 && n < ((int64_t)1 << 31), "bad geometry");
+  hipStream_t st = wd::as_stream(stream);
+  const int64_t per_chunk = n > 0 ? wd::ceil_div(wd::ceil_div(n, MAX_CHUNKS), 256) * 256 : 256;
+  const int nchunks = n > 0 ? (int)wd::ceil_div(n, per_chunk) : 0;
+  if (nchunks > 0)
+    hipLaunchKernelGGL((k_route_unique<false>), dim3(nchunks), dim3(256), 0, st, sorted_pairs, n, per_chunk, world, cap,
+                       workspace, send_rows, pos);
+  hipLaunchKernelGGL(k_route_scan, dim3(1), dim3(1024), 0, st, workspace, nchunks, world, cap, send_rows, overflow,
+                     peer_counts);
+  if (nchunks > 0) {
+    hipLaunchKernelGGL((k_route_unique<true>), dim3(nchunks), dim3(256), 0, st, sorted_pairs, n, per_chunk, world, cap,
+                       workspace, send_rows, pos);
+    hipLaunchKernelGGL(k_route_unique_fill, dim3((unsigned)wd::ceil_div(n, (int64_t)256)), dim3(256), 0, st, sorted_pairs, n, pos);
+  }
+  return wd::check_launch("wd_route_unique");
 }
 
 extern "C" int wd_owner_gather(const float *emb, int64_t n_emb_rows, int32_t dim, const float *wide,

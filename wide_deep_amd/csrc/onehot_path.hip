@@ -595,6 +595,11 @@ struct RowUpd {
   int32_t rec_stride, dim, S, flat_blocks, long_cap;
   float lr_emb, lr_w, l1, l2;
   int32_t wt;                 // rows / patches stored write-through (common.h)
+  // emit mode (wd_row_grad_presum, sharded engine: sender-side unique): the summed gradient of a row is not applied but
+  // written as ONE record [dim floats | dlogit sum | ..] at emit_out[emit_pos[first occurrence] * emit_rs]
+  float *emit_out;
+  const int32_t *emit_pos;
+  int32_t emit_rs;
 };
 
 __device__ __forceinline__ void ftrl_row(float &w, float &z, float &n, float g, float lr, float l1, float l2) {
@@ -712,7 +717,10 @@ k_row_update(RowUpd u) {
         }
         __syncthreads();
       }
-      if (gidx == 0 && c < LG) {
+      const int32_t eslot = u.emit_out ? u.emit_pos[(int32_t)(uint32_t)p0] : -1;
+      if (u.emit_out) {
+        if (gidx == 0 && c < LG && eslot >= 0) *reinterpret_cast<float4 *>(u.emit_out + (int64_t)eslot * u.emit_rs + 4 * c) = red[t];
+      } else if (gidx == 0 && c < LG) {
         g = red[t];
         const float gg[4] = {g.x, g.y, g.z, g.w};
         for (int k2 = 0; k2 < 4; ++k2) {
@@ -743,14 +751,16 @@ k_row_update(RowUpd u) {
         if (t < st) redw[t] += redw[t + st];
         __syncthreads();
       }
-      if (t == 0) {
+      if (u.emit_out) {
+        if (t == 0 && eslot >= 0) u.emit_out[(int64_t)eslot * u.emit_rs + D] = redw[0];
+      } else if (t == 0) {
         float4 r = *reinterpret_cast<float4 *>(u.rec + eoff + D);
         ftrl_row(r.x, r.y, r.z, redw[0], u.lr_w, u.l1, u.l2);
         *reinterpret_cast<float4 *>(u.rec + eoff + D) = r;
         new_row[16] = r.x;
       }
       __syncthreads();
-      if (pj.y > 0) patch_run(pj, t, 256, new_row, new_row[16], out_col, 0, false);      // the whole workgroup over the run
+      if (!u.emit_out && pj.y > 0) patch_run(pj, t, 256, new_row, new_row[16], out_col, 0, false);      // the whole workgroup over the run
       __syncthreads();
     }
     return;
@@ -790,11 +800,13 @@ k_row_update(RowUpd u) {
   float4 a = make_float4(0.f, 0.f, 0.f, 0.f), w = a, r = a;
   uint64_t tgt0 = 0;
   if (gl < pj.y) tgt0 = u.npairs[pj.x + gl];       // the lane's first patch target: in flight with the row
-  if (lane_emb) {
+  const bool emit = u.emit_out != nullptr;
+  const int32_t eslot = emit ? u.emit_pos[bag0] : -1;
+  if (lane_emb && !emit) {
     a = *reinterpret_cast<float4 *>(u.accum + off);
     w = *reinterpret_cast<float4 *>(u.rec + eoff);
   }
-  if (gl == 0) r = *reinterpret_cast<float4 *>(u.rec + (int64_t)key * RS + D);
+  if (gl == 0 && !emit) r = *reinterpret_cast<float4 *>(u.rec + (int64_t)key * RS + D);
   float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
   float gw = 0.f;
   const float scale = 1.0f;                  // one id per bag: the mean of one
@@ -843,6 +855,13 @@ k_row_update(RowUpd u) {
         }
     }
   }
+  if (emit) {
+    if (eslot >= 0) {
+      if (lane_emb) *reinterpret_cast<float4 *>(u.emit_out + (int64_t)eslot * u.emit_rs + 4 * gl) = g;
+      if (gl == 0) u.emit_out[(int64_t)eslot * u.emit_rs + D] = gw;
+    }
+    return;
+  }
   float4 wn = w;
   if (lane_emb) {
     wn = adagrad_row4(a, w, g, u.lr_emb);
@@ -867,6 +886,23 @@ k_row_update(RowUpd u) {
 }
 
 }  // namespace
+
+extern "C" int wd_row_grad_presum(const wd_slot_t *slots, int32_t S, int64_t batch, const float *dx, int64_t ldx,
+                                  const float *dlogit, int32_t dim, const uint64_t *pairs, const int32_t *long_list,
+                                  int32_t long_capacity, const int32_t *pos, float *out, int32_t row_stride, wd_stream_t stream) {
+  if (batch <= 0) return WD_OK;
+  WD_REQUIRE(slots && dx && dlogit && pairs && long_list && pos && out, "null pointer");
+  WD_REQUIRE(S > 0 && S <= 128 && (dim == 4 || dim == 8 || dim == 16) && row_stride >= dim + 1 && row_stride % 4 == 0,
+             "record = [dim | dlogit ..], dim in {4, 8, 16}, row_stride % 4 == 0, S <= 128");
+  WD_REQUIRE(ldx % 4 == 0, "ldx % 4 == 0");
+  RowUpd u{};
+  u.slots = slots; u.dx = dx; u.dlogit = dlogit; u.pairs = pairs; u.long_list = long_list; u.long_cap = long_capacity;
+  u.ldx = ldx; u.nnz = batch * S; u.batch = batch; u.rec_stride = row_stride; u.dim = dim; u.S = S;
+  u.emit_out = out; u.emit_pos = pos; u.emit_rs = row_stride;
+  u.flat_blocks = (int32_t)wd::ceil_div(u.nnz * 4, 256);
+  hipLaunchKernelGGL(k_row_update, dim3((unsigned)(u.flat_blocks + LONG_WORKERS + 1)), dim3(256), 0, wd::as_stream(stream), u);
+  return wd::check_launch("wd_row_grad_presum");
+}
 
 extern "C" int wd_bucket_onehot(const wd_slot_t *slots, int32_t S, const int32_t *ids, int32_t ids_slot_major, int64_t batch,
                                 int32_t *bucket_start, uint64_t *pairs, int32_t nbuckets, int32_t max_slot_buckets,

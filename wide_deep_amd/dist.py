@@ -171,7 +171,7 @@ class ShardedWideDeepEngine(WideDeepEngine):
     """
 
     def __init__(self, spec: ModelSpec, max_batch=8192, max_nnz=None, device="cuda", seed=0, group=None, slack=1.5,
-                 expected_nnz=None):
+                 expected_nnz=None, expected_unique=None, dedup=None):
         if not dist.is_initialized():
             raise RuntimeError("ShardedWideDeepEngine needs torch.distributed to be initialised")
         self.group = group
@@ -193,7 +193,17 @@ class ShardedWideDeepEngine(WideDeepEngine):
         W = self.world
         # entries per peer segment: the all-to-alls always move FULL segments, so size them from the occurrences a
         # batch really has (expected_nnz), not from the worst case the buffers could hold
-        self.cap = ((int(math.ceil(int(expected_nnz or mn) / W * slack)) + 63) // 64) * 64
+        # Sender-side unique (one id per bag, row records): a batch asks its owners for every DISTINCT row once and sends one
+        # pre-summed gradient per row -- the segments are then sized from the distinct rows a batch holds (expected_unique).
+        # dedup: True / False, or None = WD_SHARD_DEDUP (1 / 0 / auto: on when the first batch holds < 80 % distinct rows -- with
+        # uniform ids over 1M-row tables 99.6 % are distinct and the requester-side sort would buy nothing).
+        if dedup is None:
+            env = os.environ.get("WD_SHARD_DEDUP", "auto")
+            dedup = True if env == "1" else False if env == "0" else (
+                expected_unique is not None and expected_unique < 0.8 * int(expected_nnz or mn))
+        self.dedup = bool(dedup)
+        need = int(expected_unique) if (self.dedup and expected_unique) else int(expected_nnz or mn)
+        self.cap = ((int(math.ceil(need / W * slack)) + 63) // 64) * 64
         # the all-to-alls move [W][cap] on every rank: a rank that sized its segments from a different first batch would
         # hang or corrupt the exchange -- agree on the largest
         capt = torch.tensor([self.cap], dtype=torch.int64)
@@ -241,6 +251,9 @@ class ShardedWideDeepEngine(WideDeepEngine):
                             route_ws=torch.zeros(int(call("wd_route_chunks")) * W, **i32),
                             peer_counts=torch.zeros(W, **i32)) for _ in range(2)]
         self._pset = 0
+        self._rq = None
+        if self.dedup:
+            self._setup_dedup()
         self._skip_exchange = False
         self.overflow = torch.zeros(1, **i32)
         self.fwd_send = torch.zeros(self.n_req * self.RS, **f32)
@@ -374,7 +387,8 @@ class ShardedWideDeepEngine(WideDeepEngine):
         lp = self.plan
         D = self.dim
         return (self.spec.has_wide and self.n_emb_slots == lp.S and D >= 4 and D & (D - 1) == 0 and not self.mixed_dims
-                and all(lp.out_col[i] == i * D for i in range(lp.S)) and os.environ.get("WD_SHARD_PACK", "kernel") == "tower")
+                and all(lp.out_col[i] == i * D for i in range(lp.S)) and os.environ.get("WD_SHARD_PACK", "kernel") == "tower"
+                and not self.dedup)
 
     def _chain_scatter(self, opts, bt, on):
         self._packed_by_tower = bool(on and self._scatter_ok())
@@ -382,8 +396,54 @@ class ShardedWideDeepEngine(WideDeepEngine):
             opts.dx_pos, opts.dx_scatter = ptr(self.pos), ptr(self.bwd_send)
             opts.dx_S, opts.dx_rs, opts.dx_dim = self.plan.S, self.RS, self.dim
 
+    def _setup_dedup(self):
+        """Requester-side state of the sender-side unique: slot descriptors over the key space  W * local_row_base(slot) + id
+        (owner = key % W, local row = key / W), their row-range bucket geometry, and sort scratch per routing set."""
+        lp, gp, W, dev = self.plan, self.global_plan, self.world, self.device
+        S = lp.S
+        vs = [int(s.num_buckets) for s in gp.slots]                      # ids of slot s: [0, V_s) in the GLOBAL space
+        if S > 128 or W * int(lp.total_rows) >= (1 << 32):
+            self.dedup = False
+            return
+        shifts, bases, nb = bucket_geometry(vs, self.max_batch, int(call("wd_bucket_max")),
+                                            float(os.environ.get("WD_BUCKET_TARGET", "64")))
+        arr = (capi.WdSlot * S)()
+        for i, sl in enumerate(lp.slots):
+            is_emb = bool(sl.deep == "embedding" and self.spec.has_deep)
+            arr[i].emb_off, arr[i].row_base = 0, W * int(lp.row_base[i])
+            arr[i].num_buckets, arr[i].dim, arr[i].out_col = vs[i], int(sl.dim) if is_emb else 0, lp.out_col[i]
+            arr[i].kind, arr[i].wide = capi.SLOT_EMBEDDING if is_emb else capi.SLOT_NONE, 1 if sl.wide else 0
+            arr[i].bucket_shift, arr[i].bucket_base = shifts[i], bases[i]
+        i32 = dict(dtype=torch.int32, device=dev)
+        n = self.max_batch * S
+        self._rq = dict(slots=torch.from_numpy(np.frombuffer(bytes(arr), dtype=np.uint8).copy()).to(dev), nb=nb,
+                        max_slot_buckets=max([((v + (1 << sh) - 1) >> sh) for v, sh in zip(vs, shifts)] + [1]),
+                        long_cap=n // 32 + 2)
+        for xs in self._xsets:
+            xs.update(rq_start=torch.zeros(2 * nb + 2, **i32), rq_pairs=torch.zeros(n, dtype=torch.int64, device=dev),
+                      rq_long=torch.zeros(2 * (n // 32 + 2) + 2, **i32), rq_big=torch.zeros(nb, **i32), unique=False)
+
+    def _dedup_ok(self, bt):
+        lp = self.plan
+        return (self.dedup and self._rq is not None and bt.one_hot and bt.nnz == bt.B * lp.S and self.rec is not None
+                and self.dim in (4, 8, 16) and self.n_emb_slots == lp.S and self.spec.has_wide and self.spec.has_deep)
+
     def _route(self, bt: DeviceBatch, st):
         """A, requester side: every occurrence -> (owner segment, position); needs the ids only."""
+        xs = self._xsets[self._pset]
+        xs["unique"] = False
+        if self._dedup_ok(bt):
+            # sort the batch's occurrences on (key, occurrence), then one segment entry per distinct key
+            rq, S = self._rq, self.plan.S
+            cols = bt.ids_cols is not None
+            call("wd_bucket_onehot", ptr(rq["slots"]), S, ptr(bt.ids_cols if cols else bt.ids), 1 if cols else 0, bt.B,
+                 ptr(xs["rq_start"]), ptr(xs["rq_pairs"]), rq["nb"], rq["max_slot_buckets"], None, ptr(xs["rq_long"]), st)
+            call("wd_bucket_sort", ptr(xs["rq_start"]), ptr(xs["rq_pairs"]), rq["nb"], ptr(xs["rq_long"]), rq["long_cap"],
+                 ptr(xs["rq_big"]), bt.B, S, None, None, None, st)
+            call("wd_route_unique", ptr(xs["rq_pairs"]), bt.B * S, self.world, self.cap, ptr(self.send_rows), ptr(self.pos),
+                 ptr(self.route_ws), ptr(self.peer_counts), ptr(self.overflow), st)
+            xs["unique"] = True
+            return
         call("wd_route_build", ptr(self.slots_dev), self.plan.S, self.world, ptr(bt.ids), ptr(bt.bag_offs), bt.B, self.cap,
              ptr(self.send_rows), ptr(self.pos), ptr(self.route_ws), ptr(self.peer_counts), ptr(self.overflow), st)
 
@@ -462,6 +522,12 @@ class ShardedWideDeepEngine(WideDeepEngine):
             tw0 = self.towers[0]
             tl0 = tw0["layout"]
             dx_ptr, ld = tw0["dact"].data_ptr() + 4 * tl0.seg_start[0], tl0.ld
+        xs = self._xsets[self._pset]
+        if xs.get("unique"):
+            # one record per distinct row: the sum over the row's occurrences in this batch (sorted pairs of _route)
+            call("wd_row_grad_presum", ptr(self._rq["slots"]), lp.S, bt.B, dx_ptr, ld, ptr(self.dlogit), self.dim,
+                 ptr(xs["rq_pairs"]), ptr(xs["rq_long"]), self._rq["long_cap"], ptr(self.pos), ptr(self.bwd_send), self.RS, st)
+            return
         call("wd_grad_pack", ptr(self.slots_dev), lp.S, ptr(bt.bag_offs), ptr(self.pos), bt.B, dx_ptr, ld,
              ptr(self.dlogit) if spec.has_wide else None, self.dim, self.RS, ptr(self.bwd_send), st)
 

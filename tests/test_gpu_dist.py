@@ -301,6 +301,85 @@ def test_sharded_world2_at_baseline_size(kind):
     _run(_fullsize_worker, kind)
 
 
+# ---- the multi-step graph with CAPTURED collectives (dist.ShardedStepGraph: RCCL backend) on a one-rank group -----------------
+def _graph_rccl_worker(rank, world, port, kind, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["WD_SHARD_DEDUP"] = "1" if kind == "dedup" else "0"
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    msg = "ok"
+    try:
+        from wide_deep_amd import synth
+        from wide_deep_amd.dist import ShardedStepGraph, ShardedWideDeepEngine
+        from wide_deep_amd.engine import WideDeepEngine
+        from wide_deep_amd.pipeline import step_eager
+        from wide_deep_amd.plan import criteo_spec
+        from tests.helpers import assert_close
+        B, steps = 1024, 5
+        spec = criteo_spec(n_dense=16, n_sparse=5, buckets=5000, dim=16, hidden=(64, 32))     # K0 = 96
+        ref = WideDeepEngine(spec, max_batch=B, seed=9)
+        a = ShardedWideDeepEngine(spec, max_batch=B, seed=9, slack=2.0)      # replayed as one graph, collectives captured
+        b = ShardedWideDeepEngine(spec, max_batch=B, seed=9, slack=2.0)      # the same steps as eager launches + collectives
+        assert a._graph_mode() == "full" and a.chain and a.rec is not None and a.dedup == (kind == "dedup")
+        full0 = ref.export_state()
+        a.import_full_state(full0)
+        b.import_full_state(full0)
+        hbs = [synth.make_raw_batch(ref.plan, B, seed=40 + i, dist="zipf", pos_rate=0.3) for i in range(steps)]
+        ta = [synth.TokenBatch(a.hash_plan, hb) for hb in hbs]
+        tb = [synth.TokenBatch(b.hash_plan, hb) for hb in hbs]
+        tr = [synth.TokenBatch(ref.plan, hb) for hb in hbs]
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):
+            for e, t in ((a, ta), (b, tb), (ref, tr)):
+                step_eager(e, t[0])
+        torch.cuda.synchronize()
+        g = ShardedStepGraph(a, ta[1:], stream=side)
+        g.replay()
+        with torch.cuda.stream(side):
+            for i in range(1, steps):
+                step_eager(b, tb[i])
+                step_eager(ref, tr[i])
+        torch.cuda.synchronize()
+        a.check_overflow()
+        b.check_overflow()
+        for name in ("rec", "emb_acc", "P", "Pacc", "bias", "logit"):
+            x, y = getattr(a, name), getattr(b, name)
+            assert torch.equal(x, y), "graph replay vs eager sharded steps: %s differs (max |d| %.3g)" % (name, float((x - y).abs().max()))
+        assert_close(a.logit[:B], ref.logit[:B], 1e-4, 1e-5, "logits against the single engine")
+        fa, fr = a.export_full_state(), ref.export_state()
+        for k, v in fr.items():
+            if k != "global_step":
+                assert_close(fa[k], v, 2e-4, 1e-5, k)
+        assert a.global_step == ref.global_step
+    except Exception as e:  # pragma: no cover
+        import traceback
+        msg = "FAIL: %s\n%s" % (e, traceback.format_exc())
+    q.put((rank, msg))
+    q.close()
+    q.join_thread()
+    os._exit(0)        # (destroy_process_group() can hang behind captured collectives: bench.py's guarded teardown)
+
+
+@pytest.mark.parametrize("kind", ["plain", "dedup"])
+def test_sharded_step_graph_with_captured_collectives_one_rank(kind):
+    """dist.ShardedStepGraph on a one-rank RCCL group (what one GPU can run of the RCCL path): four steps replayed as ONE
+    graph with the all-to-alls / all-reduce captured == the same steps as eager launches, bit for bit, and == the single
+    engine within the sharded tolerance; with and without the sender-side unique."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_graph_rccl_worker, args=(0, 1, _free_port(), kind, q))
+    p.start()
+    try:
+        rank, msg = q.get(timeout=300)
+    finally:
+        p.join(30)
+        if p.is_alive():
+            p.kill()
+    assert msg == "ok", msg
+
+
 # ---- python train.py under torch.distributed: the Estimator-shaped object on the sharded engine -----------------------
 def _write_conf(dst):
     """A conf directory the sharded engine accepts: the repo conf restricted to hash_bucket + continuous features, one

@@ -296,7 +296,9 @@ def tower_roofline(eng, bt, iters=100):
             "avg_launch_us": round(ms * 1e3, 2),
             "note": "the kernel as launched in the step (%s): forward of all hidden layers + logits + head + "
                     "input-gradient chain down to dx; exact fp32 MFMA; flops of the products only"
-                    % ("input layer fused: gather phase included in the duration" if fuse else "x from HBM")}
+                    % ("x gathered by wd_prefetch_onehot a step ahead: the kernel reads x from HBM and sums the wide weight list"
+                       if (fuse and getattr(eng, "prefetch", False)) else
+                       "input layer fused: gather phase included in the duration" if fuse else "x from HBM")}
 
 
 def cpu_baseline(eng, host_batches, steps, B):

@@ -11,7 +11,7 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "wide_deep_amd", "csrc")
-HOT = ["k_tower_chain", "k_gemm_tn_group", "k_bucket_update", "k_bucket_hist", "k_bucket_scatter", "k_bucket_colscan",
+HOT = ["k_tower_chain", "k_gemm_tn_group", "k_row_update", "k_prefetch_onehot", "k_bucket_onehot", "k_bucket_sort_small", "k_bucket_sort_big", "k_route_unique", "k_bucket_update", "k_bucket_hist", "k_bucket_scatter", "k_bucket_colscan",
        "k_embag_fwd_range", "k_input_layer", "k_hash_bucket", "k_fold_affine_all", "k_mlp_finalize_all", "k_hgemm", "k_gemm<"]
 FILES = ["hash", "embag", "sparse_fused", "mlp", "mlp_half", "mlp_chain"]
 

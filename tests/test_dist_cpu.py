@@ -231,3 +231,28 @@ def test_estimator_world2_gloo_lines_checkpoints_and_resume(tmp_path):
         p.join(60)
     for rank, msg in res:
         assert msg == "ok", "rank %d: %s" % (rank, msg)
+
+
+def test_unique_key_space_encodes_owner_and_local_row():
+    """Sender-side unique: key = world * local_row_base(slot) + id  must give  key % world = owner  and  key // world = the
+    owner's local row for every id of every slot, slots must not overlap, for ragged vocabularies and every world size."""
+    import numpy as np
+    from wide_deep_amd.dist import local_spec, unique_key_space
+    from wide_deep_amd.plan import FeaturePlan, criteo_spec
+    spec = criteo_spec(n_dense=2, n_sparse=6, buckets=101, dim=16, hidden=(32, 16))
+    for sl, v in zip(spec.slots, (101, 57, 300, 23, 1, 4096)):
+        sl.num_buckets = v
+    gp = FeaturePlan(spec)
+    for W in (1, 2, 3, 4, 8, 16):
+        lp = FeaturePlan(local_spec(spec, W))
+        ks = unique_key_space(gp, lp, W)
+        hi = 0
+        for i, (base, V) in enumerate(ks):
+            assert V == int(gp.slots[i].num_buckets) and base >= hi, "slot %d starts inside the previous slot's keys" % i
+            ids = np.arange(V, dtype=np.int64)
+            key = base + ids
+            assert np.array_equal(key % W, ids % W), "owner"
+            assert np.array_equal(key // W, lp.row_base[i] + ids // W), "local row on the owner"
+            assert (ids // W).max() < int(lp.slots[i].num_buckets), "local row inside the owner's share of the slot"
+            hi = int(key.max()) + 1
+        assert hi <= W * int(lp.total_rows)

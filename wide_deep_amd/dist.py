@@ -161,6 +161,15 @@ def local_spec(spec: ModelSpec, world):
 # ---------------------------------------------------------------------------------------------
 # HIP engine
 # ---------------------------------------------------------------------------------------------
+def unique_key_space(global_plan, local_plan, world):
+    """Key space of the sender-side unique (requester side): per slot (row_base, ids) with  key = row_base + id  for an id of the
+    GLOBAL space [0, V_s), laid out so that  key % world = id % world = the owner  and  key // world = the owner's local row
+    (local_row_base(slot) + id // world): row_base = world * local_row_base(slot).  A slot's keys end before the next slot's
+    begin because every rank holds ceil(V_s / world) rows of it."""
+    W = int(world)
+    return [(W * int(local_plan.row_base[i]), int(s.num_buckets)) for i, s in enumerate(global_plan.slots)]
+
+
 class ShardedWideDeepEngine(WideDeepEngine):
     """WideDeepEngine whose tables hold rows id % world == rank; batches are this rank's examples.
 
@@ -401,7 +410,8 @@ class ShardedWideDeepEngine(WideDeepEngine):
         (owner = key % W, local row = key / W), their row-range bucket geometry, and sort scratch per routing set."""
         lp, gp, W, dev = self.plan, self.global_plan, self.world, self.device
         S = lp.S
-        vs = [int(s.num_buckets) for s in gp.slots]                      # ids of slot s: [0, V_s) in the GLOBAL space
+        ks = unique_key_space(gp, lp, W)
+        vs = [v for _, v in ks]                                          # ids of slot s: [0, V_s) in the GLOBAL space
         if S > 128 or W * int(lp.total_rows) >= (1 << 32):
             self.dedup = False
             return
@@ -410,7 +420,7 @@ class ShardedWideDeepEngine(WideDeepEngine):
         arr = (capi.WdSlot * S)()
         for i, sl in enumerate(lp.slots):
             is_emb = bool(sl.deep == "embedding" and self.spec.has_deep)
-            arr[i].emb_off, arr[i].row_base = 0, W * int(lp.row_base[i])
+            arr[i].emb_off, arr[i].row_base = 0, ks[i][0]
             arr[i].num_buckets, arr[i].dim, arr[i].out_col = vs[i], int(sl.dim) if is_emb else 0, lp.out_col[i]
             arr[i].kind, arr[i].wide = capi.SLOT_EMBEDDING if is_emb else capi.SLOT_NONE, 1 if sl.wide else 0
             arr[i].bucket_shift, arr[i].bucket_base = shifts[i], bases[i]

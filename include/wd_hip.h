@@ -404,21 +404,6 @@ int wd_adam_untouched(float *emb, float *emb_m, float *emb_v, float *wide, const
                       const wd_opt_t *wide_opt, wd_stream_t stream);
 int wd_adam_tick(float *pow, float beta1, float beta2, wd_stream_t stream);
 
-/* Sender-side unique of the row exchange (sharded engine, one id per bag): ONE request per distinct (owner, local row) of the
- * batch instead of one per occurrence.  sorted_pairs = the batch's (key << 32 | occurrence) pairs sorted ascending
- * (wd_bucket_onehot + wd_bucket_sort with requester-side slot descriptors: key = world * local_row_base(slot) + id, so that
- * owner = key % world and local row = key / world).  Fills the [world][cap] request segments (unused entries -1) with the
- * distinct rows in key order, pos[occurrence] = entry of the occurrence's row (-1: segment overflow), peer_counts and the
- * overflow flag like wd_route_build.  workspace: wd_route_chunks() * world ints. */
-int wd_route_unique(const uint64_t *sorted_pairs, int64_t n, int32_t world, int32_t cap, int32_t *send_rows, int32_t *pos,
-                    int32_t *workspace, int32_t *peer_counts, int32_t *overflow, wd_stream_t stream);
-/* ... and the gradient records that go with it: out[pos[first occurrence of a row] * row_stride + ..] = [sum of dx[b, col_s ..]
- * over the row's occurrences (ascending bag order) | sum of dlogit[b]] -- wd_grad_pack + the owner's per-row sum of the
- * requester's share, done before the wire (python/lib/joint.py:233-262: the gradient of a row is the sum over its
- * occurrences).  long_list as written by wd_bucket_sort. */
-int wd_row_grad_presum(const wd_slot_t *slots, int32_t S, int64_t batch, const float *dx, int64_t ldx, const float *dlogit,
-                       int32_t dim, const uint64_t *pairs, const int32_t *long_list, int32_t long_capacity, const int32_t *pos,
-                       float *out, int32_t row_stride, wd_stream_t stream);
 /* ---- multi-GPU exchange (replaces the PS-partitioned variables of python/lib/joint.py:140-143, train.py:202-225):
  * rows are sharded owner = id % world, local row = row_base_local[slot] + id / world.  All exchange buffers have
  * `world` equal segments of `cap` entries so that the all-to-all split sizes are static (no host sync).
@@ -440,6 +425,21 @@ int wd_owner_gather(const float *emb, int64_t n_emb_rows, int32_t dim, const flo
                     float *out, int32_t row_stride, wd_stream_t stream);
 int wd_owner_gather_rec(const float *rec, int32_t rec_stride, int32_t dim, const int32_t *rows, int64_t n, float *out,
                         int32_t row_stride, wd_stream_t stream);
+/* Sender-side unique of the row exchange (sharded engine, one id per bag): ONE request per distinct (owner, local row) of the
+ * batch instead of one per occurrence.  sorted_pairs = the batch's (key << 32 | occurrence) pairs sorted ascending
+ * (wd_bucket_onehot + wd_bucket_sort with requester-side slot descriptors: key = world * local_row_base(slot) + id, so that
+ * owner = key % world and local row = key / world).  Fills the [world][cap] request segments (unused entries -1) with the
+ * distinct rows in key order, pos[occurrence] = entry of the occurrence's row (-1: segment overflow), peer_counts and the
+ * overflow flag like wd_route_build.  workspace: wd_route_chunks() * world ints. */
+int wd_route_unique(const uint64_t *sorted_pairs, int64_t n, int32_t world, int32_t cap, int32_t *send_rows, int32_t *pos,
+                    int32_t *workspace, int32_t *peer_counts, int32_t *overflow, wd_stream_t stream);
+/* ... and the gradient records that go with it: out[pos[first occurrence of a row] * row_stride + ..] = [sum of dx[b, col_s ..]
+ * over the row's occurrences (ascending bag order) | sum of dlogit[b]] -- wd_grad_pack + the owner's per-row sum of the
+ * requester's share, done before the wire (python/lib/joint.py:233-262: the gradient of a row is the sum over its
+ * occurrences).  long_list as written by wd_bucket_sort. */
+int wd_row_grad_presum(const wd_slot_t *slots, int32_t S, int64_t batch, const float *dx, int64_t ldx, const float *dlogit,
+                       int32_t dim, const uint64_t *pairs, const int32_t *long_list, int32_t long_capacity, const int32_t *pos,
+                       float *out, int32_t row_stride, wd_stream_t stream);
 int wd_grad_pack(const wd_slot_t *slots, int32_t S, const int32_t *bag_offs, const int32_t *pos, int64_t batch,
                  const float *dx, int64_t ldx, const float *dlogit, int32_t dim, int32_t row_stride, float *out,
                  wd_stream_t stream);

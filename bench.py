@@ -513,20 +513,10 @@ def main():
         # RCCL backend: the collectives are captured with the kernels -> multi-step pipelined graphs like the single-GPU path
         from wide_deep_amd.dist import ShardedStepGraph
         graph_cls = ShardedStepGraph
-    if use_graph and sharded and graph_cls is pipeline.StepGraph:
-        # sharded step: hipGraph segments between the collectives (dist._Segments); every rank captures in lock-step
-        try:
-            # (one eager warm-up step in front of the first capture only: the batches share every buffer shape)
-            replays = [eng.capture_train_step(tb.batch, warmup=1 if i == 0 else 0,
-                                              pre=None if args.ids_input else (lambda tb=tb: synth.hash_tokens(eng, tb)))
-                       for i, tb in enumerate(dev_batches)]
-            run = lambda i: replays[i % len(replays)]()
-        except Exception as e:      # capture refused by the runtime: the eager step is the same work, launch by launch
-            print("bench: graph segments unavailable (%s); running the sharded step eagerly" % (e,), file=sys.stderr)
-            torch.cuda.synchronize()
-            use_graph = False
-            run = lambda i: step_eager(dev_batches[i % len(dev_batches)])
-    elif use_graph:
+    multis = []
+    def build_multi_step_graphs():
+        """Multi-step hipGraphs over windows of the resident pool (pipeline.StepGraph on one GPU, dist.ShardedStepGraph with the
+        collectives captured on the RCCL backend); returns (run_steps, steps per graph, chained, the multi-step graphs)."""
         side = pipeline.warm(eng, dev_batches, args.ids_input)
         # One hipGraph holds `spg` consecutive steps (each the full step on its own resident batch): the 10-30 us between two
         # graph launches is paid once per `spg` steps.  spg = the largest divisor of --steps up to --steps-per-graph (default
@@ -562,7 +552,6 @@ def main():
             multis = [graph_cls(eng, [dev_batches[(j0 + i) % nb] for i in range(spg)], args.ids_input, stream=side)
                       for j0 in starts]
         singles = [graph_cls(eng, [tb], args.ids_input, stream=side) for tb in dev_batches[:8 if sharded else nb]]
-        steps_per_run, run_steps_graph = spg, True
         # multi-step graphs walk the pool forwards from batch 0, one-step graphs (warm-up steps that do not fill a graph, the
         # remainder of an odd step count) backwards from its end: a short run (the driver's 20 steps after 5 warm-up steps)
         # does not time batches whose rows the warm-up has just pulled into the Infinity Cache
@@ -586,6 +575,43 @@ def main():
             for gph in multis + (singles[:4] if rep == 0 else []):
                 gph.replay()
         torch.cuda.synchronize()
+        return run_steps, spg, chain, multis
+
+    if use_graph and graph_cls is not pipeline.StepGraph:
+        # captured collectives: if ANY rank's runtime refuses the capture, every rank falls back to graph segments between
+        # ordinary collectives (the ranks must keep issuing the same collectives in the same order)
+        ok, err = 1, None
+        try:
+            run_steps, steps_per_run, chain, multis = build_multi_step_graphs()
+            run_steps_graph = True
+        except Exception as e:
+            ok, err = 0, e
+        if world > 1:
+            flag = torch.tensor([ok], device="cuda", dtype=torch.int32)
+            torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
+            ok = int(flag.item())
+        if not ok:
+            print("bench: multi-step graphs with captured collectives unavailable (%s); graph segments between the collectives"
+                  % (err if err is not None else "refused on another rank"), file=sys.stderr)
+            torch.cuda.synchronize()
+            os.environ["WD_DIST_GRAPH"] = "segments"
+            graph_cls, run_steps, run_steps_graph, steps_per_run, chain, multis = pipeline.StepGraph, None, False, 1, False, []
+    if use_graph and sharded and graph_cls is pipeline.StepGraph:
+        # sharded step: hipGraph segments between the collectives (dist._Segments); every rank captures in lock-step
+        try:
+            # (one eager warm-up step in front of the first capture only: the batches share every buffer shape)
+            replays = [eng.capture_train_step(tb.batch, warmup=1 if i == 0 else 0,
+                                              pre=None if args.ids_input else (lambda tb=tb: synth.hash_tokens(eng, tb)))
+                       for i, tb in enumerate(dev_batches)]
+            run = lambda i: replays[i % len(replays)]()
+        except Exception as e:      # capture refused by the runtime: the eager step is the same work, launch by launch
+            print("bench: graph segments unavailable (%s); running the sharded step eagerly" % (e,), file=sys.stderr)
+            torch.cuda.synchronize()
+            use_graph = False
+            run = lambda i: step_eager(dev_batches[i % len(dev_batches)])
+    elif use_graph and graph_cls is pipeline.StepGraph:
+        run_steps, steps_per_run, chain, multis = build_multi_step_graphs()
+        run_steps_graph = True
     else:
         run = lambda i: step_eager(dev_batches[i % len(dev_batches)])
     if run_steps is None:

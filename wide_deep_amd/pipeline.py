@@ -52,7 +52,10 @@ def pipelined_ok(eng, tb):
 
 class StepGraph:
     """`len(token_batches)` consecutive train steps in one hipGraph.  The engine must have run at least one eager step
-    on a side stream before (lazy allocations / module loads are not capturable)."""
+    on a side stream before (lazy allocations / module loads are not capturable; that step also leaves the packed kernel
+    copies current -- `eng._folded` -- without which the capture is the plain stream-order one, `self.pipelined` False).
+    A captured step bakes in "the packed copies are current": `import_state` re-packs them itself; anything else that writes
+    the dense parameters behind the engine's back must call `eng._chain_tail(WD_TAIL_PACK)` before the next replay."""
 
     def __init__(self, eng, token_batches, ids_input=False, stream=None, pipelined=None, lookahead=None, phase=(0, 0),
                  primed=False):

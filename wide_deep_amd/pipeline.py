@@ -182,20 +182,23 @@ class StepGraph:
 
     def _capture_prefetched(self, tbs, ids_input):
         """The pipelined step with the input layer taken out of the tower launch (engine.prefetch): everything that needs only
-        the ids of batch t+1 runs beside tower(t), on two branches --
+        the ids of batch t+1 runs beside tower(t).  The sparse branch carries, in stream order,
 
-            ids branch     tokens -> ids of every step (ahead) | bucket(t+1) -> sort(t+1)        released by the end of tail(t-1)
-            sparse branch  update(t-1) | prefetch(t+1) | update(t) + patch of x(t+1)            in stream order
-            main           tower(t) -> products(t) -> tail(t)                                   tower(t) waits for update(t-1)
+            hash branch    tokens -> ids of every step of the graph, ahead
+            sparse branch  update(t-1) | bucket(t+1) -> sort(t+1) -> prefetch(t+1) | update(t) + patch of x(t+1)
+            main           tower(t) -> products(t) -> tail(t)                          tower(t) waits for update(t-1)
 
         prefetch(t+1) gathers the rows + wide weights of batch t+1 into the next activation buffer (wd_prefetch_onehot) from
         the tables as update(t-1) left them; update(t) -- which needs the sorted pairs of batches t and t+1 -- then stores the
         rows it rewrites into that buffer again (wd_apply_next_t), so tower(t+1), which reads x from HBM, sees exactly the
-        tables after update(t).  Edges run main -> ids branch and ids branch -> sparse branch only (edges from the sparse
-        branch into a third one crash hipStreamEndCapture of ROCm 7.2); three scratch sets / activation buffers keep every
-        writer behind the last reader without more.  WD_SORT_BRANCH=0: bucket + sort in stream order on the sparse branch, in
-        front of the gather (the first layout of round 3: 0.1935 against 0.185 ms/step with Zipf ids).  Every step's results are
-        bit-identical to the eager launches (gather -> tower -> ...), tests/test_gpu_prefetch.py."""
+        tables after update(t).  No event sits between update(t-1) and tower(t) except the join itself; three scratch sets /
+        activation buffers keep every writer behind the last reader.
+        WD_SORT_BRANCH=1 (experiment, off): bucket + sort on the hash branch, released by the end of tail(t-1) (WD_SORT_GATE=tower:
+        of tower(t-1)), so that with skewed ids the 80 us of sort do not sit in front of the gather.  ROCm 7.2's graph executor
+        does not keep a captured stream on a hardware queue of its own, though: depending on capture order and gate it ran the
+        third branch on the main queue (between tail and tower), on the update's queue, or in front of the gather again -- 0.166-0.227
+        against 0.158-0.160 ms per step.  Every step's results are bit-identical to the eager launches
+        (gather -> tower -> ...) in every layout, tests/test_gpu_prefetch.py."""
         eng = self.eng
         main = torch.cuda.current_stream()
         s_sp, s_h = eng._side(0), eng._side(1)

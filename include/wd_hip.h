@@ -655,7 +655,7 @@ typedef struct wd_chain_input {
  *   loss_part  store each row tile's loss to loss_part[tile] (wd_tower_chain_blocks(batch, row_tile) floats, plain stores) instead of
  *              adding it atomically to loss_sum -- the caller sums them in tile order (a column-sum job of
  *              wd_gemm_tn_splitk_group): a reproducible loss that needs no zeroed accumulator
- *   stamps     diagnostics: device uint64[64]; workgroups 0 and 100 write shader-clock stamps (start, x tile in LDS, after
+ *   stamps     diagnostics: device uint64[192]; workgroups 0 and 100 write shader-clock stamps (start, x tile in LDS, after
  *              each forward layer, head, after each gradient stage, end) to [0..31] / [32..63]
  *   row_tile   examples per workgroup: 0 or 32 -> v_mfma_f32_32x32x2_f32, one workgroup per CU; 16 -> v_mfma_f32_16x16x4_f32,
  *              half the LDS, two workgroups per CU (one computes while the other gathers / stores / waits at a barrier).
@@ -670,8 +670,9 @@ typedef struct wd_chain_opts {
   void *tile_stamps;
   int32_t row_tile;
   int32_t flags;       /* bit 0: row tile 16 without the priority split between the two co-resident workgroups; bit 1: dx stage without
-                          the reduction-split last column tile; bit 2: plain instead of write-through stores of the HBM outputs
-                          (A/B switches) */
+                          the reduction-split last column tile; bit 2: plain instead of write-through stores of the HBM outputs;
+                          bit 3: s_setprio 3 for the launch's wavefronts; bit 4: row tile 32 on the one-wavefront-per-SIMD kernel
+                          (csrc/mlp_chain.hip) instead of the two-wavefronts-per-SIMD one (csrc/mlp_chain8.hip) (A/B switches) */
   /* wide logit from a per-occurrence weight list (wd_prefetch_onehot): wide_logit[b] = wide_bias[0] + sum_s wide_vals[b*wide_S + s],
    * slots in order; replaces the wide_logit argument (input must be NULL); also stored to wide_out when that is not NULL */
   const float *wide_vals;

@@ -50,7 +50,7 @@ print("chain B=%d hidden=%s: %s %.1f us | x from HBM + given wide logit: full %.
                                        if eng.prefetch else "with fused input layer", fused, full, nodx, fwd, fl_f / 1e9))
 
 
-stamps = torch.zeros(64, dtype=torch.int64, device="cuda")
+stamps = torch.zeros(64 + 128, dtype=torch.int64, device="cuda")
 eng._chain_stamps = stamps.data_ptr()
 eng._tower_chain(tw, bt, B, st, True, fuse)
 torch.cuda.synchronize()
@@ -62,6 +62,18 @@ for wg, off in ((0, 0), (100, 32)):
 v = stamps[16:32].cpu().tolist()
 print("wg0 wave0 F0: mma %d, epilogue x2 %d | dx pair 1: mma %d, epilogue %d; pair 2: mma %d, epilogue %d" % (
     v[1] - v[0], v[2] - v[1], v[5] - v[4], v[6] - v[5], v[8] - v[7], v[9] - v[8]))
+
+
+# two-wavefronts-per-SIMD kernel: per-stage stamps of workgroup 0's wavefronts 0 and 4 (mlp_chain8.hip stage8)
+sv = stamps[64:192].cpu().view(8, 2, 8)
+if int(sv.abs().sum()):
+    snames = ["F%d" % l for l in range(len(hidden))] + ["B%d" % l for l in range(len(hidden) - 1, 0, -1)] + ["dx"]
+    for si, nm in enumerate(snames):
+        for wi, wv_ in enumerate((0, 4)):
+            v = sv[si, wi].tolist()
+            if v[0]:
+                print("  %s wave %d: first unit mma %d, ring complete +%d, to epilogue/barrier +%d, epilogue +%d, rest of stage + end barrier +%d"
+                      % (nm, wv_, v[1] - v[0], v[2] - v[1], v[3] - v[2], v[4] - v[3], v[5] - v[4]))
 
 
 # in-step gather span from the per-tile realtime stamps (100 MHz): max(x tile ready) - min(start) over all workgroups

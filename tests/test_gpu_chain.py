@@ -11,11 +11,14 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=[16, 32])
+@pytest.fixture(autouse=True, params=[(32, 0), (32, 16), (16, 0)], ids=["rt32-8waves", "rt32-4waves", "rt16"])
 def row_tile(request, monkeypatch):
-    """every test of this file runs on both row tiles of the kernel (wd_chain_opts_t.row_tile; engine: WD_CHAIN_RT)"""
-    monkeypatch.setenv("WD_CHAIN_RT", str(request.param))
-    return request.param
+    """every test of this file runs on the three forms of the kernel: row tile 32 with two wavefronts per SIMD (csrc/mlp_chain8.hip,
+    the default), row tile 32 with one (csrc/mlp_chain.hip; wd_chain_opts_t.flags bit 4, engine: WD_CHAIN_FLAGS=16) and row tile
+    16 (wd_chain_opts_t.row_tile; engine: WD_CHAIN_RT)"""
+    monkeypatch.setenv("WD_CHAIN_RT", str(request.param[0]))
+    monkeypatch.setenv("WD_CHAIN_FLAGS", str(request.param[1]))
+    return request.param[0]
 
 
 def _engines(spec, max_batch, seed=5):

@@ -39,10 +39,11 @@
 //     back-to-back fp32 MFMAs consume, so the waves sat in s_waitcnt 54 % of the time.)  A register ring keeps 7-11
 //     groups (> 1 us of MFMAs) in flight.
 //   * exact fp32 (v_mfma_f32_32x32x2_f32 == an fmaf chain), same numerics class as the per-layer GEMMs.
-#include "common.h"
+#include "mlp_chain.h"
 #include <type_traits>
 
 namespace {
+using namespace wd_chain;
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef float floatx4v __attribute__((ext_vector_type(4)));
@@ -55,7 +56,6 @@ typedef float floatx4a __attribute__((ext_vector_type(4)));
 #ifndef WD_CHAIN_RING16
 #define WD_CHAIN_RING16 4
 #endif
-constexpr int MAXL = WD_CHAIN_MAX_LAYERS;
 
 // Geometry of a row tile.  One MFMA covers RT rows x RT columns x KS reduction rows; a "group" is the GK = 4 KS reduction
 // rows that ONE 16-byte weight load per lane feeds (four MFMA steps).
@@ -72,77 +72,6 @@ template <> struct Tile<16> {
   static __device__ __forceinline__ acc_t mfma(float a, float b, acc_t c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
   static __device__ __forceinline__ int row_of(int r, int h) { return r + 4 * h; }
 };
-
-struct ChainArgs {
-  wd_chain_layer_t layer[MAXL];
-  int32_t a_off[MAXL];   // LDS float offsets of a_l and dz_l
-  int32_t dz_off[MAXL];
-  int32_t tab_off[MAXL]; // LDS float offset of layer l's BN affine table: s_l[N_l] (= gamma inv) then t_l[N_l] (= beta)
-  float inv;             // 1 / sqrt(1 + eps): the inference-mode BN of SURVEY App. C.1
-  int32_t L;
-  int32_t act;
-  int32_t K0;            // width of x
-  int32_t dx_cols;       // gradient columns of x wanted (multiple of 32, <= round32(K0)); 0: none
-  int32_t train;
-  const float *x;        // [batch][ld_act]
-  int64_t ld_act;
-  const float *w_logits; // [K_L]
-  const float *b_logits; // [1]
-  const float *wide_logit, *labels, *weights;
-  int64_t batch;
-  float *dnn_logit, *logit, *prob, *dlogit, *loss_sum, *Gpart_logits;
-  float *dx;
-  int64_t ld_dx;
-  unsigned long long *stamps;   // diagnostics (wd_chain_opts_t.stamps): shader-clock stamps of workgroups 0 and 100
-  int32_t flags_prio;                // wd_chain_opts_t.flags bit 3: s_setprio 3 for every wavefront of the launch
-  int32_t flags_wt;                  // write-through stores of the HBM outputs (WD_WT bit 0; wd_chain_opts_t.flags bit 2 turns it off)
-  int32_t flags_nosplit;             // wd_chain_opts_t.flags bit 1: dx stage without the split last tile (A/B switch)
-  int32_t prio_split;                // row tile 16: the wavefront in the odd hardware slot of each SIMD runs at priority 3
-  unsigned long long *tile_stamps;   // wd_chain_opts_t.tile_stamps: [tile][2] realtime-clock stamps {start, x tile in LDS}
-  wd_chain_input_t in;          // in.emb != NULL: the x tile is built here (input layer fused), wd_chain_opts_t.input
-  float *loss_part;             // != NULL: this tile's loss is stored to loss_part[tile] (no atomic on loss_sum)
-  const int32_t *sc_pos;        // wd_chain_opts_t.dx_pos: scatter dx / dlogit into per-occurrence records instead of dx[batch][ld]
-  float *sc_out;
-  int32_t sc_S, sc_RS, sc_dim, sc_shift;
-  const float *wv;              // wd_chain_opts_t.wide_vals: per-occurrence wide weights [batch][wv_S] (x from HBM)
-  const float *wv_bias;
-  float *wv_out;
-  int32_t wv_S;
-};
-
-__device__ __forceinline__ float act_fwd(float v, int act) {
-  switch (act) {
-    case WD_ACT_RELU: return fmaxf(v, 0.f);
-    case WD_ACT_SIGMOID: return 1.0f / (1.0f + expf(-v));
-    case WD_ACT_TANH: return tanhf(v);
-    case WD_ACT_RELU6: return fminf(fmaxf(v, 0.f), 6.f);
-    case WD_ACT_LEAKY_RELU: return v > 0.f ? v : 0.2f * v;
-    case WD_ACT_ELU: return v > 0.f ? v : expm1f(v);
-    case WD_ACT_SELU: return v > 0.f ? 1.0507009873554805f * v : 1.0507009873554805f * 1.6732632423543772f * expm1f(v);
-    case WD_ACT_SOFTPLUS: return v > 20.f ? v : log1pf(expf(v));
-    case WD_ACT_SOFTSIGN: return v / (1.0f + fabsf(v));
-    default: return v;
-  }
-}
-
-__device__ __forceinline__ float act_bwd(float a, int act) {  // derivative through the activation OUTPUT a
-  switch (act) {
-    case WD_ACT_RELU: return a > 0.f ? 1.f : 0.f;
-    case WD_ACT_SIGMOID: return a * (1.f - a);
-    case WD_ACT_TANH: return 1.f - a * a;
-    case WD_ACT_RELU6: return (a > 0.f && a < 6.f) ? 1.f : 0.f;
-    case WD_ACT_LEAKY_RELU: return a > 0.f ? 1.f : 0.2f;
-    case WD_ACT_ELU: return a > 0.f ? 1.f : a + 1.f;
-    case WD_ACT_SELU: return a > 0.f ? 1.0507009873554805f : a + 1.0507009873554805f * 1.6732632423543772f;
-    case WD_ACT_SOFTPLUS: return 1.f - expf(-a);
-    case WD_ACT_SOFTSIGN: { float t = 1.f - fabsf(a); return t * t; }
-    default: return 1.f;
-  }
-}
-
-// Values that are the same in every lane but that the compiler cannot prove uniform (descriptor fields selected by a
-// loop index): pin them to SGPRs, otherwise the reduction loops get exec-masked branches and vmcnt(0) joins.
-__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
 // acc[t] += in[32 x K] . B[K x 32-column tile t]  for NT tiles `tstride` float4 apart in the packed operand.
 // inA / WB already carry the lane's (lane%32, lane/32).
@@ -955,6 +884,12 @@ extern "C" int wd_tower_chain(const float *x, int64_t ld_act, int32_t K0, const 
       WD_REQUIRE((int64_t)rt * g.in.S * 4 <= (int64_t)N[0] * (rt + 1) * 4 && rt * g.in.S <= 1024,
                  "input fusion: row_tile x S ids must fit the scratch region ((row_tile + 1) x N_0 floats) and be <= 1024");
     }
+  }
+  // two wavefronts per SIMD (mlp_chain8.hip) wherever that kernel takes the call; WD_CHAIN_WAVES=4 / flags bit 4: this file's
+  static const bool waves8 = !(getenv("WD_CHAIN_WAVES") && atoi(getenv("WD_CHAIN_WAVES")) == 4);
+  if (rt == 32 && waves8 && !g.sc_pos && !(opts && (opts->flags & 16))) {
+    const int rc = wd::chain8_launch(g, stream);
+    if (rc <= 0) return rc;
   }
   return rt == 16 ? launch_chain<16>(g, bytes, stream) : launch_chain<32>(g, bytes, stream);
 }

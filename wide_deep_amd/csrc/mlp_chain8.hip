@@ -113,7 +113,7 @@ __device__ __forceinline__ void mma_unit(const float *__restrict__ inA, gw_t Wl,
   // Wl / Wn: UNIFORM pointers (scalar registers); the lane offset is added at the load
 #ifndef WD_CHAIN8_EXP
 #define WD_CHAIN8_EXP 0   // diagnostics (scripts/build_chain8_exp.sh), bits: 1 no MFMAs, 2 no weight loads in the loop, 4 A fragments
-#endif                    // read once, 8 no HBM stores in the epilogues, 16 two accumulators alternate (no dependent MFMA chain)
+#endif                    // read once, 8 no HBM stores in the epilogues, 16 two accumulators alternate (no dependent MFMA chain), 32 no ring_complete
   float fa[2][4], fs[2][4], ft[2][4];
   floatx16 acc2;
   if (WD_CHAIN8_EXP & 16) {
@@ -379,7 +379,7 @@ __device__ __forceinline__ void stage8(const Args8 &A, int s, const float *__res
     }
     // on every path, before any store of the epilogue: the next unit's first groups have arrived (see mma_unit)
     if (ph == ph0) dstamp(1);
-    if (nx.KG > 0) ring_complete(fb);
+    if (nx.KG > 0 && !(WD_CHAIN8_EXP & 32)) ring_complete(fb);
     if (ph == ph0) dstamp(2);
     const int ns = uni(A.ph[ph].ns), l2 = uni(A.ph[ph].ntp_log2);
     if (ns > 1) {
@@ -468,7 +468,7 @@ __global__ void __launch_bounds__(NTHR, 2) k_tower_chain8(Args8 A) {
     }
   }
 
-  float *s_wide = red;   // [RT] wide logit of the tile's examples (gather mode); `red` is free until the head
+  float *s_wide = red2;  // [RT] wide logit of the tile's examples; `red2` is free until the gradient of the last hidden layer
   float wv[2] = {0.f, 0.f};   // this lane's wide weights, in flight from here (or from the tile gather) to the head
   if (g.wv) {
     // prefetched input layer: the tile's RT x S wide weights are one contiguous run of the per-occurrence list -- requested here,
@@ -641,20 +641,27 @@ __global__ void __launch_bounds__(NTHR, 2) k_tower_chain8(Args8 A) {
       for (int u = 0; u < 2; ++u)
         if (t + NTHR * u < nbag) regx[t + NTHR * u] = wv[u];
       lds_barrier();
-      if (t < RT) {
+      // 8 lanes per example: lane j adds the slots j, j + 8, ... in ascending order, the 8 partial sums meet in a fixed tree
+      // (one wavefront used to walk all S slots of an example serially while the other 480 lanes waited)
+      if (t < 8 * RT) {
+        const int e = t >> 3, j = t & 7;
         float acc = 0.f;
-        for (int sidx = 0; sidx < S; ++sidx) acc += regx[t * S + sidx];
+        for (int sidx = j; sidx < S; sidx += 8) acc += regx[e * S + sidx];
+        acc += __shfl_xor(acc, 1, 64);
+        acc += __shfl_xor(acc, 2, 64);
+        acc += __shfl_xor(acc, 4, 64);
         acc += wbias[0];
-        s_wide[t] = acc;
-        if (wout && b0 + t < g.batch) wout[b0 + t] = acc;
+        if (j == 0) {
+          s_wide[e] = acc;
+          if (wout && b0 + e < g.batch) wout[b0 + e] = acc;
+        }
       }
     }
     float d = 0.f;
     for (int n = part; n < K; n += PARTS) d += __fadd_rn(__fmul_rn(in[n * P + m], sL[n]), tL[n]) * swl[n];
-    const float h_wide_lds = (wlist && t < RT) ? s_wide[t] : 0.f;   // read before `red` is reused below
-    lds_barrier();
     red[part * RT + m] = d;
     lds_barrier();
+    const float h_wide_lds = (wlist && t < RT) ? s_wide[t] : 0.f;
     if (t < RT) {
       float dn = 0.f;
 #pragma unroll

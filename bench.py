@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--force-sharded", action="store_true",
                     help="diagnostics: run the row-sharded engine even with one rank (one-rank RCCL group)")
     ap.add_argument("--cpu-steps", type=int, default=50)
+    ap.add_argument("--cpu-only", action="store_true",
+                    help="print only the cpu_baseline object of the workload (what an N > 1 run launches as a child of rank 0)")
     ap.add_argument("--ids-input", action="store_true", help="feed pre-hashed ids (skips the hash kernel)")
     ap.add_argument("--repeats", type=int, default=5,
                     help="the K timed steps are measured this many times back to back (each bracketed by barrier + synchronize); "
@@ -174,7 +176,7 @@ def gather_kernel_roofline(eng, batches, args, iters=200):
                      "batches take it (or k_input_layer) inside the step")}
 
 
-def gather_instep_roofline(eng, dev_batches, step_eager, steps=16):
+def gather_instep_roofline(eng, dev_batches, step_eager, steps=16, runner=None, span=None):
     """The gather AS IT RUNS IN THE STEP.  One-id-per-bag batches (C2 / C3): the input layer is the first phase of
     k_tower_chain; every workgroup stores the chip-wide realtime clock (100 MHz) at its start and when its x tile is complete
     (wd_chain_opts_t.tile_stamps), and the phase's duration is  max(tile complete) - min(start)  over all workgroups of a
@@ -185,33 +187,22 @@ def gather_instep_roofline(eng, dev_batches, step_eager, steps=16):
     (dim, gs), = list(eng.group_slots.items())[:1]
     alg = gather_alg_bytes(plan, bt0, dim, gs.numel())
     side = torch.cuda.Stream()
-    if getattr(eng, "prefetch", False) and eng._chain_input_ok(bt0):
+    if span is not None and runner is not None and runner.multis:
         # the input layer is its own launch (wd_prefetch_onehot), issued one step ahead beside the tower of the previous batch:
-        # every workgroup stores the chip-wide realtime clock (100 MHz) at its start and end (per activation buffer);
-        # a 3-step pipelined hipGraph (as timed) runs the launches of steps 1 and 2 beside towers 0 and 1
-        from wide_deep_amd import pipeline
-        nblk = eng.prefetch_blocks(bt0.B)
-        span = torch.zeros(eng.n_act, nblk, 2, dtype=torch.int64, device="cuda")
-        eng._prefetch_span = span.data_ptr()
+        # every workgroup stores the chip-wide realtime clock (100 MHz) at its start and, once its stores have completed, at its
+        # end (per activation buffer).  Measured on THE GRAPHS THAT WERE TIMED (pipeline.StepRunner, captured with the stamp
+        # buffer attached): after a replay the buffer holds the stamps of the last launch into each activation buffer
         durs = []
-        try:
-            nb = len(dev_batches)
-            graphs = [pipeline.StepGraph(eng, [dev_batches[(j + i) % nb] for i in range(3)], stream=side)
-                      for j in range(0, min(nb, 12), 3)]
-            for i in range(steps + 2):
-                graphs[i % len(graphs)].replay()
-                torch.cuda.synchronize()
-                v = span.cpu()
-                if i >= 2:
-                    durs += [float(v[p, :, 1].max() - v[p, :, 0].min()) / 100.0 for p in (1, 2)]
-            del graphs
-        finally:
-            eng._prefetch_span = None
+        for i in range(steps):
+            runner.run(runner.spg)
+            torch.cuda.synchronize()
+            v = span.cpu()
+            durs += [float(v[p, :, 1].max() - v[p, :, 0].min()) / 100.0 for p in range(v.shape[0])]
         us = sum(durs) / len(durs)
         kernel = "k_prefetch_onehot<%d, 1> (the input layer of batch t+1, launched beside the tower of batch t)" % (dim // 4)
-        how = ("realtime-clock stamps of the launch's workgroups, first start -> last end, for the two overlapped launches of a "
-               "3-step pipelined hipGraph replay (as timed), mean of %d launches (min %.2f, max %.2f us)"
-               % (len(durs), min(durs), max(durs)))
+        how = ("realtime-clock stamps of the launch's workgroups, first start -> last end (stores completed), in the chained "
+               "%d-step hipGraphs the timed region replays, mean of %d launches (min %.2f, max %.2f us)"
+               % (runner.spg, len(durs), min(durs), max(durs)))
     elif getattr(eng, "chain", False) and eng._chain_input_ok(bt0):
         # the steps run exactly as in the timed region: a (pipelined) hipGraph of 4 train steps on 4 resident batches, captured
         # with the stamp buffer attached; after each replay the buffer holds the stamps of the graph's LAST step
@@ -358,8 +349,27 @@ def cpu_baseline(eng, host_batches, steps, B):
             "kind": "port", "one_thread": runs[1], "all_cores": runs[ncpu], "runs": list(runs.values()),
             "sample": "%d steps x batch %d of the same synthetic workload (token hashing + full train step) per thread "
                       "count; CPU oracle = C/OpenMP sparse ops (columns side by side) + torch-CPU fp32 tower; TensorFlow "
-                      "(the reference's runtime) is not installable in this image" % (steps, B),
+                      "(the reference's runtime) is not installable in this image.  `value` is the BEST thread count (%d "
+                      "threads); the port does not scale past it: all %d host cores give %.0f examples/s (%.2f x), one thread %.0f"
+                      % (steps, B, best["threads"], ncpu, runs[ncpu]["examples_per_sec"],
+                         runs[ncpu]["examples_per_sec"] / best["examples_per_sec"], runs[1]["examples_per_sec"]),
             "seconds": best["seconds"]}
+
+
+def cpu_baseline_sharded(spec, args, B):
+    """N > 1: the CPU port timed on rank 0's host on the per-rank workload (batch B of the global model), from a child process
+    that owns no GPU state of this run: `python bench.py --cpu-only`.  The figure is per-process examples/sec of ONE host, as
+    at N = 1 -- the reference's CPU path does not get faster with more GPUs."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-only", "--config", args.config, "--dist", args.dist, "--batch", str(B),
+           "--cpu-steps", str(min(args.cpu_steps, 20))]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")
+           and not k.startswith("TORCHELASTIC") and not k.startswith("WD_FAULT")}
+    try:
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+        return json.loads(r.stdout.strip().splitlines()[-1])
+    except Exception as e:
+        return {"value": None, "error": str(e)[:200]}
 
 
 def parity_check(eng, spec, tb, hb, step_eager):
@@ -395,6 +405,55 @@ def parity_check(eng, spec, tb, hb, step_eager):
             "oracle": "oracle/ CPU restatement on the rows this batch touches (tests/helpers.CompactOracle)"}
 
 
+def parity_check_sharded(eng, spec, tb, hb, step_eager, rank):
+    """N > 1 (COLLECTIVE: every rank calls it, rank 0 gets the object): one eager sharded step on every rank's batch 0 BEFORE
+    anything is timed; rank 0's LOCAL examples against the CPU oracle -- hashed (global) ids bit-exact, logits and the local
+    loss sum of the step's forward.  The oracle's tables hold the rows rank 0's batch touches, fetched from their owners by
+    plain indexing + a reduce (tests/helpers.ShardedCompactOracle), not through the engine's exchange kernels; the dense
+    parameters are the replicated ones.  (The backward / update of N ranks against one GPU on the global batch:
+    tests/test_gpu_dist.py, world 2 and 4.)"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle import oracle as O
+    from tests.helpers import ShardedCompactOracle
+    from wide_deep_amd import synth
+    plan = eng.hash_plan
+    bt = synth.hash_tokens(eng, tb)
+    torch.cuda.synchronize()
+    ids, offs = bt.ids.cpu().numpy()[: bt.nnz].copy(), bt.bag_offs.cpu().numpy()
+    ids_ok = None
+    if rank == 0:
+        data, toffs = synth.pack_decimal_tokens(hb["raw"])
+        nb = np.asarray([s.num_buckets for s in plan.slots], dtype=np.uint64)
+        slot_of = np.repeat(np.tile(np.arange(plan.S), hb["B"]), hb["lens"].reshape(-1))
+        want = (O.fingerprint64_batch(data, toffs.astype(np.int64)) % nb[slot_of]).astype(np.int64)
+        ids_ok = bool(np.array_equal(ids.astype(np.int64), want))
+    co = ShardedCompactOracle(eng, [(ids, offs, hb["B"])], dst=0)
+    w = None
+    if spec.use_weight_column:
+        w = np.where(hb["labels"] > 0, spec.pos_weight, spec.neg_weight).astype(np.float32)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        step_eager(tb)
+    torch.cuda.synchronize()
+    if rank != 0:
+        return None
+    B = hb["B"]
+    oloss, ologits = co.ora.train_step(co.batch(ids, offs, B, hb["dense"], hb["labels"], w))
+    d = (eng.logit[:B].cpu() - ologits).abs()
+    rel = d / (1.0 + ologits.abs())
+    # the local loss sum from the logits the engine produced (the engine's own `loss` may already be the all-reduced one)
+    x = eng.logit[:B].cpu().double()
+    y = torch.as_tensor(hb["labels"], dtype=torch.float64)
+    ww = torch.as_tensor(w, dtype=torch.float64) if w is not None else torch.ones(B, dtype=torch.float64)
+    loss = float((ww * (x.clamp_min(0) - x * y + torch.log1p(torch.exp(-x.abs())))).sum())
+    return {"batch": 0, "rank": 0, "world": eng.world, "what": "rank 0's local examples of one eager sharded step (forward)",
+            "hash_ids_bit_exact": ids_ok, "loss_local": round(loss, 4), "oracle_loss_local": round(float(oloss), 4),
+            "max_abs_dlogit": float("%.3g" % float(d.max())), "max_rel_dlogit": float("%.3g" % float(rel.max())),
+            "tolerance": "|dlogit| <= 2e-4 + 2e-4 |logit| (tests/test_gpu_fullsize.py)",
+            "oracle": "oracle/ CPU restatement on the rows rank 0's batch touches, fetched from their owners by indexing + "
+                      "reduce (tests/helpers.ShardedCompactOracle)"}
+
+
 def self_launch(n):
     """`python bench.py --gpus N` without a launcher: re-exec the same command line as N ranks of ONE node
     (python -m torch.distributed.run, rendezvous on 127.0.0.1 and a free port) and wait for them."""
@@ -406,15 +465,41 @@ def self_launch(n):
         raise SystemExit("bench.py --gpus %d: this node has %d GPU(s); RCCL needs one device per rank "
                          "(WD_DIST_BACKEND=gloo stages the collectives through the host with ranks sharing a GPU: "
                          "a functional check, not a measurement)" % (n, have))
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    env.setdefault("OMP_NUM_THREADS", "8")
-    raise SystemExit(subprocess.call(cmd, env=env))
+    def launch(extra_env):
+        with socket.socket() as s2:
+            s2.bind(("127.0.0.1", 0))
+            p = s2.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr",
+               "127.0.0.1", "--master-port", str(p), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("OMP_NUM_THREADS", "8")
+        env.update(extra_env)
+        return subprocess.call(cmd, env=env)
+
+    rc = launch({})
+    if rc != 0 and "WD_DIST_GRAPH" not in os.environ:
+        # The ranks died (capturing RCCL collectives into a hipGraph SEGFAULTS hipStreamEndCapture of ROCm 7.2 when one of its
+        # capture rules is broken -- DESIGN.md section 6 -- and a signal cannot be caught in-process) or left with an error:
+        # once more with hipGraph segments between ORDINARY collectives, so that the run still ends with a measured line
+        # (`config.exchange.graph_fallback` records why)
+        print("bench: the %d ranks ended with status %d; retrying with WD_DIST_GRAPH=segments" % (n, rc), file=sys.stderr, flush=True)
+        rc = launch({"WD_DIST_GRAPH": "segments", "WD_BENCH_GRAPH_FALLBACK": "first attempt (collectives captured into the "
+                     "step graphs) ended with status %d" % rc})
+    raise SystemExit(rc)
+
+
+def cpu_only(args):
+    """`cpu_baseline` of the workload and nothing else (one JSON line): a single-GPU engine supplies the model's initial state,
+    the oracle is timed on the host."""
+    from wide_deep_amd import synth
+    from wide_deep_amd.engine import WideDeepEngine
+    torch.cuda.set_device(0)
+    spec, mean_len = make_spec(args.config)
+    B = args.batch
+    eng = WideDeepEngine(spec, max_batch=B, max_nnz=B * 26 * (2 * mean_len + 2), seed=0)
+    hbs = [synth.make_raw_batch(eng.plan, B, seed=20260925 + i, mean_len=mean_len, dist=args.dist) for i in range(4)]
+    print(json.dumps(cpu_baseline(eng, hbs, args.cpu_steps, B)), flush=True)
 
 
 def main():
@@ -425,6 +510,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.cpu_only:
+        return cpu_only(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # bare `python bench.py --gpus N`: become the launcher -- one rank per GPU through torch.distributed.run on a free
         # local port; rank 0 prints the one JSON line, this process forwards the ranks' exit status
@@ -503,8 +590,10 @@ def main():
         return pipeline.step_eager(eng, tb, args.ids_input)
 
     parity = None
-    if world == 1 and not sharded and not args.no_parity:
+    if not sharded and not args.no_parity:
         parity = parity_check(eng, spec, dev_batches[0], host_batches[0], step_eager)
+    elif sharded and not args.no_parity:
+        parity = parity_check_sharded(eng, spec, dev_batches[0], host_batches[0], step_eager, rank)      # collective
 
     use_graph = not args.no_graph
     steps_per_run, run_steps, run_steps_graph, chain = 1, None, False, False
@@ -513,84 +602,43 @@ def main():
         # RCCL backend: the collectives are captured with the kernels -> multi-step pipelined graphs like the single-GPU path
         from wide_deep_amd.dist import ShardedStepGraph
         graph_cls = ShardedStepGraph
-    multis = []
-    def build_multi_step_graphs():
-        """Multi-step hipGraphs over windows of the resident pool (pipeline.StepGraph on one GPU, dist.ShardedStepGraph with the
-        collectives captured on the RCCL backend); returns (run_steps, steps per graph, chained, the multi-step graphs)."""
-        side = pipeline.warm(eng, dev_batches, args.ids_input)
-        # One hipGraph holds `spg` consecutive steps (each the full step on its own resident batch): the 10-30 us between two
-        # graph launches is paid once per `spg` steps.  spg = the largest divisor of --steps up to --steps-per-graph (default
-        # 32, but at least two graphs for the timed region: the driver's 20 timed steps are two replays of 10); other step counts finish on one-step graphs.  A window of spg
-        # consecutive batches of the resident pool (wrapping around) per multi-step graph.
-        nb = len(dev_batches)
-        cap = max(1, min(args.steps_per_graph, nb))
-        spg = max(d for d in range(1, cap + 1) if args.steps % d == 0)
-        if spg == args.steps and args.steps >= 16:
-            # the timed steps would be ONE graph launch: its launch latency (a few hundred nodes on four streams) is then fully
-            # exposed.  Two graphs: the second is launched while the first runs (measured at --steps 20: 0.184 against 0.187 ms)
-            spg = max(d for d in range(1, args.steps // 2 + 1) if args.steps % d == 0 and d <= cap)
-        chain = (spg > 1 and graph_cls is pipeline.StepGraph and eng.prefetch and os.environ.get("WD_GRAPH_CHAIN", "1") != "0"
-                 and all(pipeline.pipelined_ok(eng, tb) for tb in dev_batches))
-        starts, j = [], 0
-        while spg > 1 and (len(starts) < 6 if chain else (j not in starts and len(starts) < 8)):
-            starts.append(j)
-            j = (j + spg) % nb
-        if chain:
-            # consecutive multi-step graphs are chained like the steps inside one: a graph also does the input work (hash,
-            # buckets, sort, gather) of the NEXT graph's first batch beside its last tower, and its last row update patches the
-            # rows both share; the next graph starts with its tower (pipeline.StepGraph: lookahead / phase / primed).  Without
-            # it every graph starts with ~80 us of serial input work, 10 us per step at the driver's 2 x 10 steps.  Six
-            # graphs close the cycle of (bucket set, activation buffer) phases for any spg: 6 * spg = 0 mod 2 and mod 3.
-            multis, phase = [], (0, 0)
-            for k, j0 in enumerate(starts):
-                g = pipeline.StepGraph(eng, [dev_batches[(j0 + i) % nb] for i in range(spg)], args.ids_input, stream=side,
-                                       lookahead=dev_batches[starts[(k + 1) % len(starts)]], phase=phase, primed=True)
-                multis.append(g)
-                phase = g.next_phase
-            assert phase == (0, 0) and all(g.chained for g in multis)
-        else:
-            multis = [graph_cls(eng, [dev_batches[(j0 + i) % nb] for i in range(spg)], args.ids_input, stream=side)
-                      for j0 in starts]
-        singles = [graph_cls(eng, [tb], args.ids_input, stream=side) for tb in dev_batches[:8 if sharded else nb]]
-        # multi-step graphs walk the pool forwards from batch 0, one-step graphs (warm-up steps that do not fill a graph, the
-        # remainder of an odd step count) backwards from its end: a short run (the driver's 20 steps after 5 warm-up steps)
-        # does not time batches whose rows the warm-up has just pulled into the Infinity Cache
-        cursor = {"m": 0, "s": 0}
+    multis, runner = [], None
+    if sharded and os.environ.get("WD_FAULT_CAPTURE_RANK") == str(rank) and "WD_BENCH_GRAPH_FALLBACK" not in os.environ:
+        # test hook (tests/test_gpu_dist.py): this rank dies the way a refused capture does -- by signal, uncatchable
+        import signal
+        sys.stderr.write("bench: fault injection: rank %d dies at graph capture\n" % rank)
+        sys.stderr.flush()
+        os.kill(os.getpid(), signal.SIGSEGV)
+    span = None
+    if use_graph and not sharded and getattr(eng, "prefetch", False) and eng._chain_input_ok(dev_batches[0].batch):
+        # diagnostics that ride in the timed graphs: start / end stamps of every workgroup of wd_prefetch_onehot (two 8-byte
+        # stores per workgroup), read after the timed region for `roofline`
+        span = torch.zeros(eng.n_act, eng.prefetch_blocks(B), 2, dtype=torch.int64, device="cuda")
+        eng._prefetch_span = span.data_ptr()
 
-        def run_steps(n):
-            for _ in range(n // spg if spg > 1 else 0):
-                multis[cursor["m"] % len(multis)].replay()
-                cursor["m"] += 1
-            for _ in range(n % spg if spg > 1 else n):
-                singles[(len(singles) - 1 - cursor["s"]) % len(singles)].replay()
-                cursor["s"] += 1
-            if chain and n % spg:
-                # the one-step graphs leave no input work behind: hand the chain what its next graph expects (the multi-step
-                # graphs do this for each other; inside the timed region it happens exactly as often as outside)
-                multis[cursor["m"] % len(multis)].prime()
-
-        # clocks, caches and the graph executor's first-replay work are out of the way before the official warm-up: every
-        # graph is replayed once (untimed; the contract's W warm-up steps and K timed steps follow unchanged)
-        for rep in range(3):        # (three rounds: the first replay of a graph also pays its one-time upload, the clocks ramp)
-            for gph in multis + (singles[:4] if rep == 0 else []):
-                gph.replay()
-        torch.cuda.synchronize()
-        return run_steps, spg, chain, multis
+    def build_runner():
+        """pipeline.StepRunner: the multi-step (chained) hipGraphs over windows of the resident pool -- the object that is timed,
+        and the one tests/test_gpu_fullsize.py replays against the oracle.  Captures only; warm_up() replays."""
+        return pipeline.StepRunner(eng, dev_batches, args.steps, args.steps_per_graph, args.ids_input, graph_cls,
+                                   n_singles=8 if sharded else None)
 
     if use_graph and graph_cls is not pipeline.StepGraph:
         # captured collectives: if ANY rank's runtime refuses the capture, every rank falls back to graph segments between
         # ordinary collectives (the ranks must keep issuing the same collectives in the same order)
         ok, err = 1, None
         try:
-            run_steps, steps_per_run, chain, multis = build_multi_step_graphs()
-            run_steps_graph = True
+            runner = build_runner()          # captures only: nothing has been replayed when the ranks compare notes
         except Exception as e:
             ok, err = 0, e
         if world > 1:
             flag = torch.tensor([ok], device="cuda", dtype=torch.int32)
             torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
             ok = int(flag.item())
-        if not ok:
+        if ok:
+            runner.warm_up()
+            run_steps, steps_per_run, chain, multis, run_steps_graph = runner.run, runner.spg, runner.chain, runner.multis, True
+        else:
+            runner = None
             print("bench: multi-step graphs with captured collectives unavailable (%s); graph segments between the collectives"
                   % (err if err is not None else "refused on another rank"), file=sys.stderr)
             torch.cuda.synchronize()
@@ -610,8 +658,9 @@ def main():
             use_graph = False
             run = lambda i: step_eager(dev_batches[i % len(dev_batches)])
     elif use_graph and graph_cls is pipeline.StepGraph:
-        run_steps, steps_per_run, chain, multis = build_multi_step_graphs()
-        run_steps_graph = True
+        runner = build_runner()
+        runner.warm_up()
+        run_steps, steps_per_run, chain, multis, run_steps_graph = runner.run, runner.spg, runner.chain, runner.multis, True
     else:
         run = lambda i: step_eager(dev_batches[i % len(dev_batches)])
     if run_steps is None:
@@ -686,6 +735,31 @@ def main():
             "payload_bytes_per_rank_per_step": {"A_rows_int32": 4 * W * cap, "B_records_f32": 4 * W * cap * RS,
                                                 "C_gradients_f32": 4 * W * cap * RS, "D_dense_allreduce_f32": 4 * eng.G.numel()},
             "owner_table_layout": "row records" if eng.rec is not None else "separate tables"}
+        if os.environ.get("WD_BENCH_GRAPH_FALLBACK"):
+            out["config"]["exchange"]["graph_fallback"] = os.environ["WD_BENCH_GRAPH_FALLBACK"]
+        # every collective of the step alone, against the xGMI peak (collective: all ranks measure, rank 0 reports)
+        XGMI_PEAK_GBS = 7 * 153.6           # MI355X: 7 links x 153.6 GB/s per direction to the 7 peers
+        legs = eng.measure_exchange()
+        nreq = int((eng.recv_rows >= 0).sum().item())      # requests this rank answered in the last step
+        out["config"]["exchange"]["collectives_alone"] = {
+            k: {"us": round(us, 2), "wire_bytes_per_rank": int(nb), "achieved_GBps": round(nb / us / 1e3, 1),
+                "frac_of_xgmi_peak": round(nb / us / 1e3 / XGMI_PEAK_GBS, 4)}
+            for k, (us, nb) in legs.items() if k != "owner_gather_kernel"}
+        out["config"]["exchange"]["xgmi_peak_GBps_per_gpu"] = XGMI_PEAK_GBS
+        out["config"]["exchange"]["note"] = ("each collective issued alone, 20 calls between two stream events, full static "
+                                             "segments; backend %s%s" % (backend, "" if world > 1 else
+                                                                         " (one rank: RCCL's local copies, no link)"))
+        us_g = legs["owner_gather_kernel"][0]
+        D_ = eng.dim
+        alg = nreq * (D_ * 4 + 4) + nreq * eng.RS * 4      # SURVEY 8(d) per request: row read + id, record written back
+        out["roofline_sharded_gather"] = {
+            "bound": "hbm", "kernel": "wd_owner_gather_rec (this rank's share of the embedding gather: one %d-byte record per "
+                                      "received request)" % (4 * eng.rec_stride) if eng.rec is not None else "wd_owner_gather",
+            "achieved": round(alg / us_g / 1e3, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(alg / us_g / 1e3 / HBM_PEAK_GBS, 4), "traffic": None, "algorithmic_bytes_per_launch": int(alg),
+            "avg_launch_us": round(us_g, 2), "requests": nreq,
+            "note": "rank 0, the launch alone on the request list of the last step (HIP events, 20 launches); segments are "
+                    "static, so the launch also walks the unused (-1) entries"}
     if rank == 0:
         out["parity"] = parity
         if world == 1:
@@ -694,7 +768,7 @@ def main():
                 synth.hash_tokens(eng, tb)
             torch.cuda.synchronize()
             if not sharded and eng.spec.has_deep and eng.group_slots:
-                out["roofline"] = gather_instep_roofline(eng, dev_batches, step_eager)
+                out["roofline"] = gather_instep_roofline(eng, dev_batches, step_eager, runner=runner, span=span)
             out["roofline_gather_kernel"] = gather_kernel_roofline(eng, [tb.batch for tb in dev_batches], args)
             if "roofline" not in out:
                 out["roofline"] = out["roofline_gather_kernel"]
@@ -704,6 +778,13 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(eng, host_batches, args.cpu_steps, B)
             else:
                 out["cpu_baseline"] = None
+        else:
+            out["roofline"] = out["roofline_sharded_gather"]
+            out["cpu_baseline"] = None
+            if not args.no_cpu_baseline:
+                # the same CPU port on the same per-rank workload (a single-GPU-shaped oracle of the global model over the rows
+                # rank 0's batches touch would be the same arithmetic): a bounded sample, rank 0's host cores while the peers idle
+                out["cpu_baseline"] = cpu_baseline_sharded(spec, args, B)
         print(json.dumps(out), flush=True)
     if sharded:
         # graphs that hold captured RCCL nodes go first; the teardown itself runs on a helper thread -- on ROCm 7.2 / RCCL 2.26

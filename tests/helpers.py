@@ -263,3 +263,84 @@ class CompactOracle:
             if len(self.uniq[si]):
                 m[self.plan.row_base[si] + self._idx(si)] = True
         return m
+
+
+class ShardedCompactOracle(CompactOracle):
+    """CompactOracle over a ROW-SHARDED engine (wide_deep_amd.dist.ShardedWideDeepEngine): the sampled rows of the global
+    tables are fetched from their owners -- global id g of a slot lives on rank g % world as that rank's local row g // world
+    -- by plain torch indexing + one reduce(SUM) to rank `dst` per buffer, i.e. NOT through the engine's exchange kernels.
+    COLLECTIVE: every rank constructs it (and calls resync()) with the batches of rank `dst`; only `dst` ends up with an oracle
+    (`self.ora`), whose forward (logits, loss of dst's local examples) is what bench.py's N > 1 parity object compares.
+    The batches hold GLOBAL ids (hashed against eng.hash_plan)."""
+
+    def __init__(self, eng, batches, dst=0):
+        import torch.distributed as dist
+        self._dist, self.dst = dist, dst
+        self.world, self.rank = eng.world, eng.rank
+        payload = [batches if eng.rank == dst else None]
+        dist.broadcast_object_list(payload, src=dst, group=eng.group)
+        self.local_plan = eng.plan
+        # (CompactOracle.__init__ reads eng.plan: the GLOBAL plan here)
+        self.eng = eng
+        plan = eng.global_plan
+        S = plan.S
+        per_slot = [[] for _ in range(S)]
+        for ids, offs, B in payload[0]:
+            csr = slot_csr(plan, ids, offs, B)
+            for si, sl in enumerate(plan.slots):
+                per_slot[si].append(csr[sl.name][0])
+        self.plan = plan
+        self.uniq = []
+        for si in range(S):
+            u = np.unique(np.concatenate(per_slot[si])) if per_slot[si] else np.zeros(0, np.int64)
+            self.uniq.append(u[u >= 0])
+        self.ora = None
+        self.resync()
+
+    def _fetch(self, rows_of_owner, width):
+        """rows [n, width] of the sampled ids of one slot: every rank fills the ids it owns, reduce(SUM) to dst"""
+        dist, eng = self._dist, self.eng
+        out = rows_of_owner
+        if dist.get_backend(eng.group) == "gloo":
+            t = out.cpu()
+            dist.reduce(t, dst=self.dst, op=dist.ReduceOp.SUM, group=eng.group)
+            return t
+        dist.reduce(out, dst=self.dst, op=dist.ReduceOp.SUM, group=eng.group)
+        return out.cpu()
+
+    def _owned(self, si):
+        g = torch.as_tensor(self.uniq[si], dtype=torch.int64, device=self.eng.device)
+        mine = (g % self.world) == self.rank
+        return g, mine, (g // self.world)[mine]
+
+    def _emb_rows(self, buf, si):
+        s = self.plan.slots[si]
+        if len(self.uniq[si]) == 0:
+            return torch.zeros(1, s.dim)
+        g, mine, loc = self._owned(si)
+        out = torch.zeros(len(g), s.dim, dtype=torch.float32, device=self.eng.device)
+        out[mine] = self.eng._emb_view(buf, si)[loc].float()
+        return self._fetch(out, s.dim).clone()
+
+    def _wide_rows(self, si):
+        if len(self.uniq[si]) == 0:
+            return torch.zeros(1, 4)
+        g, mine, loc = self._owned(si)
+        out = torch.zeros(len(g), 4, dtype=torch.float32, device=self.eng.device)
+        out[mine] = self.eng.wide[self.local_plan.row_base[si] + loc].float()
+        return self._fetch(out, 4).clone()
+
+    def resync(self):
+        if self.rank == self.dst:
+            return super().resync()
+        # the other ranks serve the same sequence of fetches that CompactOracle.resync() issues on dst
+        eng, spec, plan = self.eng, self.eng.spec, self.plan
+        dsa, dsb = O.SLOT_NAMES[spec.dnn_opt[0]] if spec.has_deep else (None, None)
+        lsa, lsb = O.SLOT_NAMES[spec.lin_opt[0]] if spec.has_wide else (None, None)
+        for si, s in enumerate(plan.slots):
+            if spec.has_deep and s.deep == "embedding":
+                for buf, suf in ((eng.emb, ""), (eng.emb_a, dsa), (eng.emb_acc, dsb)):
+                    if suf is not None:
+                        self._emb_rows(buf, si)
+            if spec.has_wide and s.wide:
+                self._wide_rows(si)

@@ -150,6 +150,71 @@ def test_c2_full_size_bench_path_matches_oracle(dist):
     assert eng.chain and eng._fused_input_layer       # the path bench.py times: one-launch tower, input layer fused
 
 
+@pytest.mark.parametrize("dist", ["uniform", "zipf"])
+def test_c2_the_graphs_bench_times_are_bit_identical_to_eager_steps_that_match_the_oracle(dist):
+    """The OBJECT bench.py times -- pipeline.StepRunner at the driver's arguments (--steps 20: chained, primed 10-step hipGraphs
+    with a look-ahead batch, six of them closing the cycle of bucket-set / activation-buffer phases) -- replayed for two full
+    cycles (120 steps) on a twin engine, against the same steps as eager launches: bit-identical after every cycle.  The
+    first eager steps are checked against the re-synchronised oracle like every step of the tests above."""
+    from tests.helpers import CompactOracle, assert_close
+    from wide_deep_amd import synth
+    from wide_deep_amd.engine import WideDeepEngine
+    from wide_deep_amd.pipeline import StepRunner, step_eager
+    spec, B, nb, tol = _c2(), 8192, 16, FP32_TOL
+    mk = lambda: WideDeepEngine(spec, max_batch=B, max_nnz=B * 26 * 4, seed=0)
+    eng, twin = mk(), mk()
+    hbs = [synth.make_raw_batch(eng.plan, B, seed=20260925 + i, mean_len=1, dist=dist) for i in range(nb)]
+    tbs = [synth.TokenBatch(eng.plan, hb) for hb in hbs]
+    tbs2 = [synth.TokenBatch(twin.plan, hb) for hb in hbs]
+    dev_ids = _hash_and_check(eng, tbs, hbs)
+    co = CompactOracle(eng, dev_ids)
+    side = torch.cuda.Stream()
+
+    def eager(i, check):
+        if check:
+            co.resync()
+        with torch.cuda.stream(side):
+            loss = step_eager(eng, tbs[i])
+        torch.cuda.synchronize()
+        if check:
+            ids, offs, _ = dev_ids[i]
+            oloss, ologits = co.ora.train_step(co.batch(ids, offs, B, hbs[i]["dense"], hbs[i]["labels"], None))
+            assert_close(eng.logit[:B], ologits, tol["l_rtol"], tol["l_atol"], "logits of batch %d" % i)
+            assert abs(float(loss) - oloss) <= tol["loss_rtol"] * max(1.0, abs(oloss)), (i, float(loss), oloss)
+            co.assert_state_matches(tol["p_rtol"], tol["p_atol"], kink=tol["kink"], slot_kink=tol["slot_kink"])
+
+    runner = StepRunner(twin, tbs2, steps=20)        # (its warm() runs batches 0 and 1 eagerly on the twin)
+    assert twin.chain and twin.prefetch and runner.chain and runner.spg == 10 and len(runner.multis) == 6
+    assert all(g.chained and g.primed and g.lookahead is not None for g in runner.multis)
+    eager(0, True)
+    eager(1, True)
+    _bit_identical(eng, twin)
+    checked = 0
+    for cycle in range(2):
+        for k in range(len(runner.multis)):
+            order = [tbs2.index(tb) for tb in runner.next_batches(tbs2)]
+            for i in order:
+                eager(i, checked < 3)
+                checked += 1
+            runner.run(runner.spg)
+        torch.cuda.synchronize()
+        _bit_identical(eng, twin)
+    # the driver's own call pattern: 5 warm-up steps (one-step graphs + re-priming of the chain), then 20 timed ones
+    twin2_steps = 5
+    for n in (twin2_steps, 20):
+        m0, s0 = runner.cursor["m"], runner.cursor["s"]
+        order = []
+        for r in range(n // runner.spg):
+            j0 = runner.starts[(m0 + r) % len(runner.multis)]
+            order += [(j0 + i) % nb for i in range(runner.spg)]
+        order += [(len(runner.singles) - 1 - (s0 + r)) % len(runner.singles) for r in range(n % runner.spg)]
+        for i in order:
+            eager(i, False)
+        runner.run(n)
+        torch.cuda.synchronize()
+        _bit_identical(eng, twin)
+
+
 def test_c3_100m_row_table_one_gpu_matches_oracle():
     eng = _fullsize(_c2(buckets=3_846_154), 8192, 1, "uniform", n_steps=3, n_graph=2)
     assert eng.plan.total_rows == 26 * 3_846_154

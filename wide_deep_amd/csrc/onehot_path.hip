@@ -184,6 +184,10 @@ k_prefetch_onehot(const float *__restrict__ rec, int32_t rec_stride, const wd_sl
                   const float *__restrict__ dense, int64_t ld_dense, const wd_dense_col_t *__restrict__ cols,
                   int32_t ncols, int32_t gather_blocks, unsigned long long *__restrict__ span, int32_t wt) {
   const int t = threadIdx.x;
+  // Issue priority over the tower's wavefronts (WD_PREFETCH_PRIO=0: off).  The launch runs beside the tower of the previous
+  // batch, whose two wavefronts per SIMD issue an MFMA / LDS stream without gaps; a handful of loads per wavefront here only
+  // need to get OUT: 26 -> 13 us for the launch inside the step, the step itself unchanged (profiles/r4_gather_instep.txt)
+  if (wt & 2) __builtin_amdgcn_s_setprio(3);
   // diagnostics (bench.py: the duration of this launch AS IT RUNS INSIDE the pipelined step): every workgroup stores the
   // chip-wide realtime clock (100 MHz) at its start and end, span[2 * block], [2 * block + 1] (one min / max word for all of
   // them -- 7500 same-address atomics -- stretched the launch from 11 to 86 us)
@@ -238,12 +242,13 @@ k_prefetch_onehot(const float *__restrict__ rec, int32_t rec_stride, const wd_sl
     for (int q = 0; q < BPG; ++q) {
       if (w[q] >= nwork) continue;
       const int64_t b = w[q] / S;
-      wd::store4(reinterpret_cast<float4 *>(x + b * ldx + col[q] + 4 * lane), make_float4(r[q].x, r[q].y, r[q].z, r[q].w), wt);
-      if (lane == 0) wd::store1(&wv[w[q]], wq[q], wt);
+      wd::store4(reinterpret_cast<float4 *>(x + b * ldx + col[q] + 4 * lane), make_float4(r[q].x, r[q].y, r[q].z, r[q].w), wt & 1);
+      if (lane == 0) wd::store1(&wv[w[q]], wq[q], wt & 1);
     }
   }
   if (span) {
-    __syncthreads();       // (every lane's stores are issued; the stamp is a lower bound on their completion by one store latency)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the end stamp is taken when this workgroup's stores have completed
+    __syncthreads();
     if (t == 0) span[2 * blockIdx.x + 1] = (unsigned long long)wall_clock64();
   }
 }
@@ -918,9 +923,21 @@ extern "C" int wd_bucket_onehot(const wd_slot_t *slots, int32_t S, const int32_t
   return wd::check_launch("wd_bucket_onehot");
 }
 
+// bags per lane group (independent id -> record chains per lane): 1 gives the most wavefronts -- best when the launch has the
+// chip to itself --, 2 / 4 put more requests in flight per wavefront, which is what counts beside the tower of the previous
+// batch, where only a few wavefront slots per SIMD are free (WD_PREFETCH_BPG; profiles/r4_gather_instep.txt)
+static int prefetch_bpg() {
+  static const int v = [] {
+    const char *e = getenv("WD_PREFETCH_BPG");
+    const int b = e ? atoi(e) : 1;
+    return (b == 2 || b == 4) ? b : 1;
+  }();
+  return v;
+}
+
 extern "C" int64_t wd_prefetch_onehot_blocks(int64_t batch, int32_t S, int32_t dim, int32_t ncols) {
   if (batch <= 0 || S <= 0 || dim <= 0) return 0;
-  return wd::ceil_div(batch * S * (dim / 4), 256) + (ncols > 0 ? wd::ceil_div(batch * ncols, 256) : 0);
+  return wd::ceil_div(wd::ceil_div(batch * S, (int64_t)prefetch_bpg()) * (dim / 4), 256) + (ncols > 0 ? wd::ceil_div(batch * ncols, 256) : 0);
 }
 
 extern "C" int wd_prefetch_onehot(const float *rec, int32_t rec_stride, int32_t dim, const wd_slot_t *rec_slots, int32_t S,
@@ -934,19 +951,27 @@ extern "C" int wd_prefetch_onehot(const float *rec, int32_t rec_stride, int32_t 
   WD_REQUIRE(ldx % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0, "x must be 16-byte aligned with ldx % 4 == 0");
   WD_REQUIRE(ncols == 0 || (dense && dense_cols), "numeric columns need dense + descriptors");
   hipStream_t st = wd::as_stream(stream);
-  constexpr int BPG = 1;
+  const int bpg = prefetch_bpg();
+  static const int prio = (getenv("WD_PREFETCH_PRIO") && atoi(getenv("WD_PREFETCH_PRIO")) == 0) ? 0 : 2;
   const int lanes = dim / 4;
-  const int64_t groups = wd::ceil_div(batch * S, BPG);
+  const int64_t groups = wd::ceil_div(batch * S, (int64_t)bpg);
   const int gb = (int)wd::ceil_div(groups * lanes, 256);
   const int db = ncols > 0 ? (int)wd::ceil_div(batch * ncols, 256) : 0;
-#define WD_LAUNCH_PF(L)                                                                                                     \
+#define WD_LAUNCH_PF2(L, BPG)                                                                                               \
   hipLaunchKernelGGL((k_prefetch_onehot<L, BPG>), dim3((unsigned)(gb + db)), dim3(256), 0, st, rec, rec_stride, rec_slots, \
                      S, ids, batch, x, ldx, wide_vals, dense, ld_dense, dense_cols, ncols, gb,                              \
-                     static_cast<unsigned long long *>(span), (int32_t)(wd::wt_mask() & WD_WT_PREFETCH ? 1 : 0))
+                     static_cast<unsigned long long *>(span), (int32_t)((wd::wt_mask() & WD_WT_PREFETCH ? 1 : 0) | prio))
+#define WD_LAUNCH_PF(L)                    \
+  do {                                     \
+    if (bpg == 4) WD_LAUNCH_PF2(L, 4);     \
+    else if (bpg == 2) WD_LAUNCH_PF2(L, 2); \
+    else WD_LAUNCH_PF2(L, 1);              \
+  } while (0)
   if (lanes == 4) WD_LAUNCH_PF(4);
   else if (lanes == 2) WD_LAUNCH_PF(2);
   else WD_LAUNCH_PF(1);
 #undef WD_LAUNCH_PF
+#undef WD_LAUNCH_PF2
   return wd::check_launch("wd_prefetch_onehot");
 }
 
@@ -962,7 +987,7 @@ extern "C" int wd_bucket_sort(const int32_t *bucket_start, uint64_t *pairs, int3
   g.S = S; g.batch = batch;
   g.start = bucket_start; g.pairs = pairs; g.long_list = long_list; g.big_list = big_list; g.pstart = prev_bucket_start;
   g.ppairs = prev_pairs; g.ppatch = reinterpret_cast<int2 *>(prev_patch); g.long_cap = long_capacity; g.nb = nbuckets;
-  static const int sort_prio = getenv("WD_SORT_PRIO") ? atoi(getenv("WD_SORT_PRIO")) : 0;
+  static const int sort_prio = getenv("WD_SORT_PRIO") ? atoi(getenv("WD_SORT_PRIO")) : 1;
   g.prio = sort_prio;
   g.bag_bits = 1;
   while (g.bag_bits < 32 && ((int64_t)1 << g.bag_bits) < nnz) ++g.bag_bits;

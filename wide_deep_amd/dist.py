@@ -210,8 +210,18 @@ class ShardedWideDeepEngine(WideDeepEngine):
             env = os.environ.get("WD_SHARD_DEDUP", "auto")
             dedup = True if env == "1" else False if env == "0" else (
                 expected_unique is not None and expected_unique < 0.8 * int(expected_nnz or mn))
-        self.dedup = bool(dedup)
-        need = int(expected_unique) if (self.dedup and expected_unique) else int(expected_nnz or mn)
+        # ... and only where the unique path is GUARANTEED to be taken: a batch routed per occurrence into segments sized for its
+        # distinct rows would lose occurrences until the next check_overflow().  Everything static is decided here, before the
+        # segments are sized (record-shaped model -- engine.py's rule --, key space below 2^32, at most 128 slots); what is left
+        # to the batch (one id per bag) makes _route raise instead of falling back.
+        dset = sorted(dims)
+        static_ok = (spec.has_deep and spec.has_wide and len(dset) == 1 and dset[0] in (4, 8, 16) and 0 < S <= 128
+                     and all(s.deep == "embedding" and s.wide for s in gp.slots)
+                     and os.environ.get("WD_ROW_RECORDS", "1") != "0"
+                     and W * sum(shard_rows(int(s.num_buckets), W) for s in gp.slots) < (1 << 32))
+        self.dedup = bool(dedup) and static_ok
+        self._cap_from_unique = bool(self.dedup and expected_unique)
+        need = int(expected_unique) if self._cap_from_unique else int(expected_nnz or mn)
         self.cap = ((int(math.ceil(need / W * slack)) + 63) // 64) * 64
         # the all-to-alls move [W][cap] on every rank: a rank that sized its segments from a different first batch would
         # hang or corrupt the exchange -- agree on the largest
@@ -412,7 +422,9 @@ class ShardedWideDeepEngine(WideDeepEngine):
         S = lp.S
         ks = unique_key_space(gp, lp, W)
         vs = [v for _, v in ks]                                          # ids of slot s: [0, V_s) in the GLOBAL space
-        if S > 128 or W * int(lp.total_rows) >= (1 << 32):
+        if S > 128 or W * int(lp.total_rows) >= (1 << 32) or self.rec is None:
+            if self._cap_from_unique:      # (cannot happen: __init__ checks the same conditions before it sizes the segments)
+                raise RuntimeError("sharded engine: segments sized for distinct rows, but the unique path is not available")
             self.dedup = False
             return
         shifts, bases, nb = bucket_geometry(vs, self.max_batch, int(call("wd_bucket_max")),
@@ -442,10 +454,14 @@ class ShardedWideDeepEngine(WideDeepEngine):
         """A, requester side: every occurrence -> (owner segment, position); needs the ids only."""
         xs = self._xsets[self._pset]
         xs["unique"] = False
+        if self._cap_from_unique and not self._dedup_ok(bt):
+            raise ValueError("sharded engine: the exchange segments were sized for the DISTINCT rows of a batch "
+                             "(expected_unique), which needs one id per bag in every batch; build the engine with dedup=False "
+                             "(or WD_SHARD_DEDUP=0) for multi-hot batches")
         if self._dedup_ok(bt):
             # sort the batch's occurrences on (key, occurrence), then one segment entry per distinct key
             rq, S = self._rq, self.plan.S
-            cols = bt.ids_cols is not None
+            cols = bt.ids_cols is not None and bt.ids_cols_valid
             call("wd_bucket_onehot", ptr(rq["slots"]), S, ptr(bt.ids_cols if cols else bt.ids), 1 if cols else 0, bt.B,
                  ptr(xs["rq_start"]), ptr(xs["rq_pairs"]), rq["nb"], rq["max_slot_buckets"], None, ptr(xs["rq_long"]), st)
             call("wd_bucket_sort", ptr(xs["rq_start"]), ptr(xs["rq_pairs"]), rq["nb"], ptr(xs["rq_long"]), rq["long_cap"],
@@ -470,6 +486,11 @@ class ShardedWideDeepEngine(WideDeepEngine):
 
     def _owner_gather(self, st):
         """B: owners read the requested rows (+ wide weight) and send them back."""
+        self._owner_gather_kernel(st)
+        self._collective(lambda: _a2a(self.fwd_recv, self.fwd_send, None, None, self.group))
+
+    def _owner_gather_kernel(self, st):
+        """the owner-side gather alone (this rank's share of the embedding gather: one record per received request)"""
         spec = self.spec
         has_emb = self.n_emb_slots > 0
         if self.rec is not None:
@@ -478,7 +499,36 @@ class ShardedWideDeepEngine(WideDeepEngine):
         else:
             call("wd_owner_gather", ptr(self.emb) if has_emb else None, self.n_emb_rows, self.dim,
                  ptr(self.wide) if spec.has_wide else None, ptr(self.recv_rows), self.n_req, ptr(self.fwd_send), self.RS, st)
-        self._collective(lambda: _a2a(self.fwd_recv, self.fwd_send, None, None, self.group))
+
+    def measure_exchange(self, iters=20):
+        """Diagnostics (bench.py, after the timed region; collective -- every rank calls it): each collective of a step issued
+        alone on the buffers of the last step, `iters` times back to back between two stream events, and the owner-side gather
+        kernel the same way.  Returns {name: (microseconds per call, bytes this rank puts on the wire per call)}; with W ranks
+        (W - 1) / W of an all-to-all's payload leaves the GPU, an all-reduce of n bytes moves 2 (W - 1) / W n."""
+        W, RS, cap = self.world, self.RS, self.cap
+        wire = (W - 1) / W if W > 1 else 1.0       # (one rank: RCCL's local copies, reported against the same payload)
+        st = torch.cuda.current_stream().cuda_stream
+        legs = [("A_rows_int32", lambda: _a2a(self.recv_rows, self.send_rows, None, None, self.group), 4 * W * cap * wire),
+                ("B_records_f32", lambda: _a2a(self.fwd_recv, self.fwd_send, None, None, self.group), 4 * W * cap * RS * wire),
+                ("C_gradients_f32", lambda: _a2a(self.bwd_recv, self.bwd_send, None, None, self.group), 4 * W * cap * RS * wire),
+                ("D_dense_allreduce_f32", lambda: _all_reduce_sum(self._gdiag, self.group),
+                 4 * self.G.numel() * (2 * wire if W > 1 else 1.0)),
+                ("owner_gather_kernel", lambda: self._owner_gather_kernel(st), 0)]
+        self._gdiag = torch.zeros_like(self.G)      # (a scratch copy: the gradient buffer itself stays what the step left)
+        out = {}
+        for name, fn, nbytes in legs:
+            fn()
+            torch.cuda.synchronize()
+            dist.barrier(group=self.group)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(iters):
+                fn()
+            e1.record()
+            e1.synchronize()
+            out[name] = (e0.elapsed_time(e1) / iters * 1e3, nbytes)
+        del self._gdiag
+        return out
 
     def _sparse_exchange(self, bt: DeviceBatch, st):
         if self._skip_exchange:      # ShardedStepGraph has already issued route / A / B of this step on its own branches

@@ -35,6 +35,8 @@ class DeviceBatch:
         self.weights = weights      # float32 [B] or None
         self.nnz = int(nnz if nnz is not None else ids.numel())
         self.ids_cols = None        # optional slot-major copy of a one-id-per-bag batch: ids_cols[s * B + b] (wd_hash_bucket_cols)
+        self.ids_cols_valid = False   # set by whoever fills ids_cols together with ids (synth.hash_tokens); a caller that writes
+                                      # `ids` itself leaves it False and the bucketing reads `ids`
 
 
 def _stream():
@@ -718,6 +720,9 @@ class WideDeepEngine:
         fuse_in = self._chain_input_ok(bt)
         if fuse_in and self.prefetch:
             if not self._prefetched:            # (pipeline.StepGraph gathers a step ahead and patches: nothing to do here)
+                # an eager forward (evaluate / predict / an eager step between two chained graph replays) gathers into the
+                # activation buffer a primed graph may be counting on: whatever was primed is gone
+                self._primed = None
                 self._prefetch_input(bt, st, self._apar)
         elif fuse_in:
             self._sparse_exchange(bt, st)       # rows that have to travel first (sharded engine); nothing on one GPU
@@ -1027,12 +1032,13 @@ class WideDeepEngine:
         """Phase 1 of the sparse backward (ids only): occurrences -> row-range buckets (scratch set `pset`).  Flat row update:
         + the sort of every bucket; prev = scratch set of the batch stepped BEFORE this one (pipelined graph): its patch list
         (rows this batch reads too) is filled as well."""
+        self._primed = None      # the scratch set is rewritten: a primed graph's token is void (StepGraph.prime() sets it again behind this call)
         plan = self.plan
         self._check_batch(bt)
         bs = self._bucket_sets[pset]
         if self._bucket_onehot_ok(bt):
             # one id per bag: every slot owns B occurrences -> one launch, no count matrix (csrc/onehot_path.hip)
-            cols = bt.ids_cols is not None
+            cols = bt.ids_cols is not None and bt.ids_cols_valid
             flat = self.flat_update and self.prefetch
             call("wd_bucket_onehot", ptr(self.slots_dev), plan.S, ptr(bt.ids_cols if cols else bt.ids), 1 if cols else 0, bt.B,
                  ptr(bs["start"]), ptr(bs["pairs"]), self.n_buckets, self.max_slot_buckets,

@@ -64,7 +64,10 @@ class StepGraph:
         tower; its last update patches the rows both share), and the next graph -- captured with `primed=True` on that batch
         and with the phase `next_phase` of this one -- starts with its tower.  A primed graph replayed in any other situation
         (`eng._primed` does not name its first batch at the current global step) runs that input work itself first
-        (`prime()`), so a chain can be entered anywhere; results are bit-identical either way."""
+        (`prime()`), so a chain can be entered anywhere; results are bit-identical either way.  The token is void after anything
+        that rewrites a bucket set or an activation buffer outside a replay (an eager `forward()` / train step: the engine
+        clears it).  It names the look-ahead batch by identity: a TokenBatch that is refilled IN PLACE between the replay that
+        gathered it and the replay that trains on it must be re-primed by the caller (`eng._primed = None`)."""
         self.eng = eng
         self.n = len(token_batches)
         self.ids_input = ids_input
@@ -334,3 +337,84 @@ def warm(eng, token_batches, ids_input=False, steps=2):
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
     return side
+
+
+class StepRunner:
+    """What `bench.py` times: `steps` consecutive train steps as replays of multi-step hipGraphs over windows of the resident
+    batch pool, plus one-step graphs for what does not fill a multi-step graph (warm-up steps, the remainder of an odd count).
+
+    One hipGraph holds `spg` consecutive steps (each the full step on its own resident batch): the 10-30 us between two graph
+    launches is paid once per `spg` steps.  spg = the largest divisor of `steps` up to `steps_per_graph` -- but at least two
+    graphs for the timed region (the second is launched while the first runs; the driver's 20 timed steps are two replays of
+    10).  On the prefetched single-GPU capture consecutive graphs are CHAINED like the steps inside one (StepGraph lookahead /
+    phase / primed): a graph also does the input work (hash, buckets, sort, gather) of the next graph's first batch beside its
+    last tower; six graphs close the cycle of (bucket set, activation buffer) phases for any spg (6 spg = 0 mod 2 and mod 3).
+
+    `graph_cls` is StepGraph or dist.ShardedStepGraph (collectives captured).  Construction only CAPTURES; `warm_up()` replays
+    every graph (untimed) -- with captured collectives the caller agrees across the ranks between the two that every capture
+    succeeded, so that no rank replays collectives its peers never issue.  tests/test_gpu_fullsize.py builds the same object."""
+
+    def __init__(self, eng, dev_batches, steps, steps_per_graph=32, ids_input=False, graph_cls=None, n_singles=None, stream=None):
+        graph_cls = graph_cls or StepGraph
+        self.eng, self.ids_input = eng, ids_input
+        self.side = stream or warm(eng, dev_batches, ids_input)
+        nb = len(dev_batches)
+        cap = max(1, min(steps_per_graph, nb))
+        spg = max(d for d in range(1, cap + 1) if steps % d == 0)
+        if spg == steps and steps >= 16:
+            spg = max(d for d in range(1, steps // 2 + 1) if steps % d == 0 and d <= cap)
+        self.spg = spg
+        self.chain = (spg > 1 and graph_cls is StepGraph and bool(getattr(eng, "prefetch", False))
+                      and os.environ.get("WD_GRAPH_CHAIN", "1") != "0" and all(pipelined_ok(eng, tb) for tb in dev_batches))
+        starts, j = [], 0
+        while spg > 1 and (len(starts) < 6 if self.chain else (j not in starts and len(starts) < 8)):
+            starts.append(j)
+            j = (j + spg) % nb
+        self.starts = starts
+        if self.chain:
+            self.multis, phase = [], (0, 0)
+            for k, j0 in enumerate(starts):
+                g = StepGraph(eng, [dev_batches[(j0 + i) % nb] for i in range(spg)], ids_input, stream=self.side,
+                              lookahead=dev_batches[starts[(k + 1) % len(starts)]], phase=phase, primed=True)
+                self.multis.append(g)
+                phase = g.next_phase
+            assert phase == (0, 0) and all(g.chained for g in self.multis)
+        else:
+            self.multis = [graph_cls(eng, [dev_batches[(j0 + i) % nb] for i in range(spg)], ids_input, stream=self.side)
+                           for j0 in starts]
+        self.singles = [graph_cls(eng, [tb], ids_input, stream=self.side) for tb in dev_batches[:n_singles or nb]]
+        # multi-step graphs walk the pool forwards from batch 0, one-step graphs backwards from its end: a short run (the
+        # driver's 20 steps after 5 warm-up steps) does not time batches whose rows the warm-up has just pulled into the
+        # Infinity Cache
+        self.cursor = {"m": 0, "s": 0}
+
+    @property
+    def pipelined(self):
+        g = (self.multis or self.singles)[0]
+        return bool(getattr(g, "pipelined", True))
+
+    def warm_up(self, rounds=3):
+        """clocks, caches and the graph executor's first-replay work out of the way: every graph is replayed (untimed; the
+        first replay of a graph also pays its one-time upload)"""
+        for rep in range(rounds):
+            for g in self.multis + (self.singles[:4] if rep == 0 else []):
+                g.replay()
+        torch.cuda.synchronize()
+
+    def run(self, n):
+        spg = self.spg
+        for _ in range(n // spg if spg > 1 else 0):
+            self.multis[self.cursor["m"] % len(self.multis)].replay()
+            self.cursor["m"] += 1
+        for _ in range(n % spg if spg > 1 else n):
+            self.singles[(len(self.singles) - 1 - self.cursor["s"]) % len(self.singles)].replay()
+            self.cursor["s"] += 1
+        if self.chain and n % spg:
+            # the one-step graphs leave no input work behind: hand the chain what its next graph expects (the multi-step
+            # graphs do this for each other; inside a timed region it happens exactly as often as outside)
+            self.multis[self.cursor["m"] % len(self.multis)].prime()
+
+    def next_batches(self, dev_batches):
+        """the resident batches the next multi-step replay will train on, in order (for the tests' eager twin)"""
+        j0 = self.starts[self.cursor["m"] % len(self.multis)]
+        return [dev_batches[(j0 + i) % len(dev_batches)] for i in range(self.spg)]

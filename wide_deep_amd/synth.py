@@ -111,6 +111,7 @@ def hash_tokens(engine, tb: TokenBatch):
     if tb.batch.ids_cols is not None and tb.ntok == tb.B * plan.S:
         call("wd_hash_bucket_cols", ptr(tb.bytes), ptr(tb.tok_offs), tb.ntok, ptr(slots_dev), plan.S, ptr(tb.ids),
              ptr(tb.batch.ids_cols), st)
+        tb.batch.ids_cols_valid = True
         return tb.batch
     call("wd_hash_bucket", ptr(tb.bytes), ptr(tb.tok_offs), tb.ntok, None if tb.one_per_bag else ptr(tb.bag_offs),
          tb.B * plan.S, ptr(slots_dev), plan.S, ptr(tb.ids), st)

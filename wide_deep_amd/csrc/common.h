@@ -12,6 +12,16 @@
 #define WD_WT_PREFETCH 8
 #define WD_WT_DEFAULT 1
 
+// Small latency-bound kernels that run BESIDE a long MFMA kernel (hash, routing, bucketing, exchange packing, pooling: a few loads
+// per wavefront) raise their issue priority: the tower's wavefronts (two per SIMD, an MFMA / LDS stream without gaps) otherwise
+// keep them waiting at the instruction arbiter -- the input-layer launch of the step went 26 -> 13 us that way, the tower did not
+// notice (profiles/r4_gather_instep.txt).  -DWD_NO_SIDE_PRIO builds without it (A/B).
+#ifdef WD_NO_SIDE_PRIO
+#define WD_SIDE_PRIO() do { } while (0)
+#else
+#define WD_SIDE_PRIO() __builtin_amdgcn_s_setprio(2)
+#endif
+
 namespace wd {
 
 void set_error(const char *fmt, ...);

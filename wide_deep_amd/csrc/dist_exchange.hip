@@ -32,6 +32,7 @@ k_route(const wd_slot_t *__restrict__ slots, int32_t S, int32_t W, const int32_t
         const int32_t *__restrict__ bag_offs, int64_t nbags, int64_t bags_per_chunk, int32_t cap,
         int32_t *__restrict__ cntm /* [chunks][W] counts (pass 1) / exclusive chunk prefixes (pass 3) */,
         int32_t *__restrict__ send_rows, int32_t *__restrict__ pos) {
+  WD_SIDE_PRIO();
   __shared__ int32_t wcount[4][MAX_W];
   __shared__ int32_t running[MAX_W];
   __shared__ int32_t any_left;
@@ -100,6 +101,7 @@ k_route(const wd_slot_t *__restrict__ slots, int32_t S, int32_t W, const int32_t
 __global__ void __launch_bounds__(1024)
 k_route_scan(int32_t *__restrict__ cntm, int32_t nchunks, int32_t W, int32_t cap, int32_t *__restrict__ send_rows,
              int32_t *__restrict__ overflow, int32_t *__restrict__ peer_counts) {
+  WD_SIDE_PRIO();
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;   // wavefront w = owner w (W <= MAX_W = 16 wavefronts)
   if (w < W) {
     int32_t run = 0;
@@ -137,6 +139,7 @@ k_fill_i32(int32_t *__restrict__ p, int32_t v, int64_t n) {
 __global__ void __launch_bounds__(256)
 k_owner_gather(const float *__restrict__ emb, int64_t n_emb_rows, int32_t D, const float *__restrict__ wide,
                const int32_t *__restrict__ rows, int64_t n, float *__restrict__ out, int32_t RS) {
+  WD_SIDE_PRIO();
   const int64_t r = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 2;
   const int lane = threadIdx.x & 3;
   if (r >= n) return;
@@ -155,6 +158,7 @@ k_owner_gather(const float *__restrict__ emb, int64_t n_emb_rows, int32_t D, con
 __global__ void __launch_bounds__(256)
 k_owner_gather_rec(const float *__restrict__ rec, int32_t rec_stride, int32_t nvec, const int32_t *__restrict__ rows,
                    int64_t n, float *__restrict__ out, int32_t RS) {
+  WD_SIDE_PRIO();
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int64_t r = i / nvec;
   const int c = (int)(i - r * nvec);
@@ -173,6 +177,7 @@ __global__ void __launch_bounds__(256)
 k_grad_pack(const wd_slot_t *__restrict__ slots, int32_t S, const int32_t *__restrict__ bag_offs,
             const int32_t *__restrict__ pos, int64_t nbags, const float *__restrict__ dx, int64_t ldx,
             const float *__restrict__ dlogit, int32_t D, int32_t RS, float *__restrict__ out) {
+  WD_SIDE_PRIO();
   const int64_t bag = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 2;
   const int lane = threadIdx.x & 3;
   if (bag >= nbags) return;
@@ -216,6 +221,7 @@ template <bool SCATTER>
 __global__ void __launch_bounds__(256)
 k_route_unique(const uint64_t *__restrict__ pairs, int64_t n, int64_t per_chunk, int32_t W, int32_t cap,
                int32_t *__restrict__ cntm, int32_t *__restrict__ send_rows, int32_t *__restrict__ pos) {
+  WD_SIDE_PRIO();
   __shared__ int32_t wcount[4][MAX_W];
   __shared__ int32_t running[MAX_W];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -268,6 +274,7 @@ k_route_unique(const uint64_t *__restrict__ pairs, int64_t n, int64_t per_chunk,
 // every occurrence that is not the first of its row: the entry of the row's head (first position holding the key: lower bound)
 __global__ void __launch_bounds__(256)
 k_route_unique_fill(const uint64_t *__restrict__ pairs, int64_t n, int32_t *__restrict__ pos) {
+  WD_SIDE_PRIO();
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n || i == 0) return;
   const uint64_t pr = pairs[i];

@@ -20,6 +20,7 @@ __global__ void __launch_bounds__(256)
 k_embag_fwd(const float *__restrict__ emb, const wd_slot_t *__restrict__ slots, int32_t S,
             const int32_t *__restrict__ group_slots, int32_t ngroup, const int32_t *__restrict__ ids,
             const int32_t *__restrict__ bag_offs, int64_t nwork, float *__restrict__ x, int64_t ldx, int64_t RS4) {
+  WD_SIDE_PRIO();
   // RS4: row stride in float4 units (LANES for a dense table; larger for rows received through the exchange)
   constexpr int D = LANES * 4;
   const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -332,6 +333,7 @@ __global__ void __launch_bounds__(256)
 k_wide_fwd(const float *__restrict__ wide, const float *__restrict__ bias, const wd_slot_t *__restrict__ slots,
            int32_t S, const int32_t *__restrict__ ids, const int32_t *__restrict__ bag_offs, int64_t batch,
            int32_t stride, float *__restrict__ out) {
+  WD_SIDE_PRIO();
   wide_body(wide, bias, slots, S, ids, bag_offs, batch, stride, out, blockIdx.x);
 }
 

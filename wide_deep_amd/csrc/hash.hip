@@ -171,6 +171,7 @@ __global__ void k_hash_bucket(const uint8_t *__restrict__ bytes, const int32_t *
                               const int32_t *__restrict__ token_bag_offs, int64_t nbags,
                               const wd_slot_t *__restrict__ slots, int32_t S, int32_t *__restrict__ out_ids,
                               int32_t *__restrict__ out_cols) {
+  WD_SIDE_PRIO();
   int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= ntok) return;
   int32_t o0 = tok_offs[t], o1 = tok_offs[t + 1];

@@ -49,6 +49,7 @@ struct GemmArgs {
   int32_t a_vec, b_vec; // float4 loads legal (ld % 4 == 0 and 16-byte aligned base)
   int32_t tiles_m, tiles_n;
   int32_t wt;           // TN partials stored write-through (common.h)
+  int32_t prio;         // wavefront priorities (WD_TN_PRIO, experiment): 0 the odd hardware slot at 2, 1 every wavefront at 3, 2 none
 };
 
 __device__ __forceinline__ float act_fwd(float v, int act) {
@@ -143,7 +144,13 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &g, const int orig, con
   // lock-step (both in their MFMA phase at half rate, then both in their load/LDS-store phase with the pipe idle:
   // measured 46 % MFMA busy).  Give the wave in the odd hardware slot priority: it runs its MFMA phase at full
   // rate while the other one stores / waits, and vice versa.
-  if (__builtin_amdgcn_s_getreg((4) | (0 << 6) | (3 << 11)) & 1u) __builtin_amdgcn_s_setprio(2);  // HW_ID.WAVE_ID
+  static_assert(true, "");
+  {
+    // WD_TN_PRIO (experiment, read on the host: GemmArgs.prio): 1 = every wavefront of the products at priority 3 (over the row
+    // update beside them), 2 = none raised
+    if (g.prio == 1) __builtin_amdgcn_s_setprio(3);
+    else if (g.prio == 0 && (__builtin_amdgcn_s_getreg((4) | (0 << 6) | (3 << 11)) & 1u)) __builtin_amdgcn_s_setprio(2);  // HW_ID.WAVE_ID
+  }
 
   // XCD-aware tile mapping: hardware places block i on XCD i % 8; give each XCD a contiguous run of
   // tiles (n fastest) so the N-tiles sharing an A panel hit the same L2.  Bijective for any grid.
@@ -1369,6 +1376,8 @@ extern "C" int wd_gemm_tn_splitk_group(const wd_tn_job_t *jobs, int32_t njobs, w
     g.a_vec = (g.lda % 4 == 0) && aligned16(g.A);
     g.b_vec = (g.ldb % 4 == 0) && aligned16(g.B);
     g.wt = wd::wt_mask() & WD_WT_PRODUCTS ? 1 : 0;
+    static const int tn_prio = getenv("WD_TN_PRIO") ? atoi(getenv("WD_TN_PRIO")) : 0;
+    g.prio = tn_prio;
     vec = vec && g.a_vec && g.b_vec;
     G.first[j] = total;
     G.count[j] = g.tiles_m * g.tiles_n * q.nsplit;
@@ -1445,6 +1454,8 @@ extern "C" int wd_gemm_tn_group_tail(const wd_tn_job_t *jobs, const wd_tn_fuse_t
     g.a_vec = (g.lda % 4 == 0) && aligned16(g.A);
     g.b_vec = (g.ldb % 4 == 0) && aligned16(g.B);
     g.wt = wd::wt_mask() & WD_WT_PRODUCTS ? 1 : 0;
+    static const int tn_prio = getenv("WD_TN_PRIO") ? atoi(getenv("WD_TN_PRIO")) : 0;
+    g.prio = tn_prio;
     vec = vec && g.a_vec && g.b_vec;
     G.count[j] = g.tiles_m * g.tiles_n * q.nsplit;
     G.nsplit[j] = q.nsplit;

@@ -48,6 +48,7 @@ __global__ void __launch_bounds__(512)
 k_bucket_onehot(const wd_slot_t *__restrict__ slots, int32_t S, const int32_t *__restrict__ ids, int64_t sb, int64_t ss,
                 int64_t B, int32_t nb, int32_t *__restrict__ start, uint64_t *__restrict__ pairs,
                 int32_t *__restrict__ ticket, int32_t *__restrict__ zero_word) {
+  WD_SIDE_PRIO();
   extern __shared__ int32_t lds_i[];
   __shared__ int32_t wsum[8];
   __shared__ int32_t is_last;
@@ -628,6 +629,7 @@ __device__ __forceinline__ float4 adagrad_row4(float4 &a, float4 w, float4 g, fl
 
 __global__ void __launch_bounds__(256)
 k_row_update(RowUpd u) {
+  if (u.wt & 2) __builtin_amdgcn_s_setprio(3);     // WD_UPDATE_PRIO=1 (experiment): issue priority beside the weight-gradient products
   constexpr int MAXS = 128;
   __shared__ int64_t s_acc_off[MAXS];     // accumulator offset of the slot's first row, minus row_base * dim
   __shared__ int32_t s_col[MAXS];
@@ -646,8 +648,8 @@ k_row_update(RowUpd u) {
     for (int k = l; k < pj.y; k += nl) {
       const int32_t bag2 = (int32_t)(uint32_t)((have_first && k == l) ? first : u.npairs[pj.x + k]);
       float *dst = u.nx + (int64_t)(bag2 / S) * u.nldx + out_col;
-      for (int c = 0; c < LG; ++c) wd::store4(reinterpret_cast<float4 *>(dst + 4 * c), make_float4(row[4 * c], row[4 * c + 1], row[4 * c + 2], row[4 * c + 3]), u.wt);
-      wd::store1(&u.nwv[bag2], wnew, u.wt);
+      for (int c = 0; c < LG; ++c) wd::store4(reinterpret_cast<float4 *>(dst + 4 * c), make_float4(row[4 * c], row[4 * c + 1], row[4 * c + 2], row[4 * c + 3]), u.wt & 1);
+      wd::store1(&u.nwv[bag2], wnew, u.wt & 1);
     }
   };
   if ((int)blockIdx.x == u.flat_blocks + LONG_WORKERS) {     // (grid: long-segment workers first, flat blocks, this one) bias_weights: g = sum_b dlogit[b] (fixed-shape tree), dense FTRL
@@ -870,12 +872,12 @@ k_row_update(RowUpd u) {
   float4 wn = w;
   if (lane_emb) {
     wn = adagrad_row4(a, w, g, u.lr_emb);
-    wd::store4(reinterpret_cast<float4 *>(u.accum + off), a, u.wt);
-    wd::store4(reinterpret_cast<float4 *>(u.rec + eoff), wn, u.wt);
+    wd::store4(reinterpret_cast<float4 *>(u.accum + off), a, u.wt & 1);
+    wd::store4(reinterpret_cast<float4 *>(u.rec + eoff), wn, u.wt & 1);
   }
   if (gl == 0) {
     ftrl_row(r.x, r.y, r.z, gw, u.lr_w, u.l1, u.l2);
-    wd::store4(reinterpret_cast<float4 *>(u.rec + (int64_t)key * RS + D), r, u.wt);
+    wd::store4(reinterpret_cast<float4 *>(u.rec + (int64_t)key * RS + D), r, u.wt & 1);
   }
   if (pj.y > 0) {     // every lane of the group gets the whole new row (shuffles) and takes every 4th pair of the run
     float row[16];
@@ -1014,7 +1016,8 @@ extern "C" int wd_row_update(float *rec, int32_t rec_stride, int32_t dim, float 
   u.dim = dim; u.S = S; u.lr_emb = lr_emb; u.lr_w = lr_wide; u.l1 = l1; u.l2 = l2;
   if (patch) { u.npairs = next->pairs; u.nx = next->x; u.nwv = next->wide_vals; u.nldx = next->ldx; }
   u.flat_blocks = (int32_t)wd::ceil_div(u.nnz * 4, 256);
-  u.wt = wd::wt_mask() & WD_WT_ROW_UPDATE ? 1 : 0;
+  static const int upd_prio = (getenv("WD_UPDATE_PRIO") && atoi(getenv("WD_UPDATE_PRIO"))) ? 2 : 0;
+  u.wt = (wd::wt_mask() & WD_WT_ROW_UPDATE ? 1 : 0) | upd_prio;
   hipLaunchKernelGGL(k_row_update, dim3((unsigned)(u.flat_blocks + LONG_WORKERS + 1)), dim3(256), 0, wd::as_stream(stream), u);
   return wd::check_launch("wd_row_update");
 }

@@ -48,6 +48,7 @@ __global__ void __launch_bounds__(256)
 k_bucket_hist(const wd_slot_t *__restrict__ slots, int32_t S, const int32_t *__restrict__ ids,
               const int32_t *__restrict__ bag_offs, int64_t nbags, int64_t bags_per_chunk, int32_t nb,
               int32_t *__restrict__ cntm, int32_t *__restrict__ rank) {
+  WD_SIDE_PRIO();
   __shared__ int32_t hist[MAX_NB];
   __shared__ int32_t has_stable, any_left;
   const int t = threadIdx.x;
@@ -125,6 +126,7 @@ k_bucket_hist(const wd_slot_t *__restrict__ slots, int32_t S, const int32_t *__r
 __global__ void __launch_bounds__(256)
 k_bucket_colscan(const int32_t *__restrict__ cntm, int32_t *__restrict__ cpre, int32_t nchunks, int32_t nb,
                  int32_t *__restrict__ total) {
+  WD_SIDE_PRIO();
   const int b = blockIdx.x * 256 + threadIdx.x;
   if (b >= nb) return;
   int32_t run = 0;
@@ -147,6 +149,7 @@ k_bucket_scatter(const wd_slot_t *__restrict__ slots, int32_t S, const int32_t *
                  const int32_t *__restrict__ bag_offs, int64_t nbags, int64_t bags_per_chunk,
                  int32_t nb, const int32_t *__restrict__ total, const int32_t *__restrict__ cntm,
                  const int32_t *__restrict__ rank, int32_t *__restrict__ start, uint64_t *__restrict__ pairs) {
+  WD_SIDE_PRIO();
   __shared__ int32_t sstart[MAX_NB];
   __shared__ int32_t wsum[4];
   // exclusive scan of total[0..nb): thread t owns E consecutive counters

@@ -772,6 +772,14 @@ def main():
             out["roofline_gather_kernel"] = gather_kernel_roofline(eng, [tb.batch for tb in dev_batches], args)
             if "roofline" not in out:
                 out["roofline"] = out["roofline_gather_kernel"]
+            elif out["roofline"].get("traffic") is None and out["roofline_gather_kernel"].get("traffic") is not None and span is not None:
+                # the in-step launch IS this launch (same kernel, same arguments, the same resident batches): its HBM traffic is
+                # what the PMC passes measured for it -- counter collection serialises kernels, so the bytes can only be taken
+                # with the launch alone; what the overlap changes is its duration, not what it moves
+                out["roofline"]["traffic"] = out["roofline_gather_kernel"]["traffic"]
+                out["roofline"]["traffic_source"] = ("the same launch under rocprofv3 --pmc (roofline_gather_kernel.traffic_source): "
+                                                     "counter passes serialise kernels, so the bytes are those of the launch "
+                                                     "alone; inside the step only its duration differs")
             if not sharded:
                 out["roofline_tower"] = tower_roofline(eng, dev_batches[0].batch)
             if not args.no_cpu_baseline:

@@ -42,6 +42,9 @@ extern "C" {
 typedef void *wd_stream_t; /* hipStream_t */
 
 const char *wd_last_error(void);
+/* sha256 (hex) over the sources the library was built from (csrc/build.sh); the Python loader compares it with the sources it
+ * finds next to itself and refuses a stale binary. */
+const char *wd_build_stamp(void);
 int wd_abi_version(void);
 
 /* Per-slot descriptor (device array of S entries, built once by the host). */

@@ -76,3 +76,18 @@ def test_missing_extension_and_bad_arguments_fail_loudly(monkeypatch):
     with pytest.raises(capi.WdError, match="needs slot"):
         capi.call("wd_opt_dense", 64, None, None, 64, 8, ctypes.byref(o), None)
     assert b"needs slot" in capi.load().wd_last_error()
+
+
+def test_a_library_built_from_other_sources_is_refused(monkeypatch):
+    """csrc/build.sh embeds a sha256 of the sources (wd_build_stamp); capi.load() recomputes it from the tree and refuses a
+    binary that does not match -- the prebuilt .so travels with the tree, a stale one must not load silently."""
+    import pytest
+    from wide_deep_amd import capi
+    lib = ctypes.CDLL(capi.LIB_PATH)
+    lib.wd_build_stamp.restype = ctypes.c_char_p
+    assert lib.wd_build_stamp().decode() == capi.source_stamp()
+    monkeypatch.setattr(capi, "_lib", None)
+    monkeypatch.delenv("WD_HIP_LIB", raising=False)
+    monkeypatch.setattr(capi, "source_stamp", lambda: "0" * 64)
+    with pytest.raises(capi.WdError, match="stale HIP library"):
+        capi.load()

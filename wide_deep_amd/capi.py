@@ -164,6 +164,7 @@ I32, I64, U64, F32, SZ = ctypes.c_int32, ctypes.c_int64, ctypes.c_uint64, ctypes
 # name -> argtypes; every function returns int status unless listed in _RESTYPES
 _PROTOS = {
     "wd_abi_version": [],
+    "wd_build_stamp": [],
     "wd_fingerprint64": [P, P, I64, P, P],
     "wd_hash_bucket": [P, P, I64, P, I64, P, I32, P, P],
     "wd_emit_hash_slot": [P, P, I64, U64, P, I32, I32, P, P],
@@ -246,7 +247,7 @@ _PROTOS = {
     "wd_diag_gather_modes": [P, I64, P, I64, I32, P, P],
     "wd_diag_access": [P, P, P, I32, P, I64, I32, I32, P, P],
 }
-_RESTYPES = {"wd_prefetch_onehot_blocks": I64, "wd_feat_offsets_workspace_bytes": I64, "wd_sort_workspace_bytes": SZ, "wd_logits_head_blocks": I64, "wd_tower_chain_lds_bytes": I64, "wd_tower_chain_blocks": I64, "wd_bucket_max": I32, "wd_bucket_chunks": I32, "wd_route_chunks": I32}
+_RESTYPES = {"wd_build_stamp": ctypes.c_char_p, "wd_prefetch_onehot_blocks": I64, "wd_feat_offsets_workspace_bytes": I64, "wd_sort_workspace_bytes": SZ, "wd_logits_head_blocks": I64, "wd_tower_chain_lds_bytes": I64, "wd_tower_chain_blocks": I64, "wd_bucket_max": I32, "wd_bucket_chunks": I32, "wd_route_chunks": I32}
 
 EXPORTED_SYMBOLS = sorted(list(_PROTOS) + ["wd_last_error"])
 
@@ -255,6 +256,26 @@ _lib = None
 
 class WdError(RuntimeError):
     pass
+
+
+def source_stamp():
+    """sha256 over csrc/*.hip, csrc/*.h and include/wd_hip.h in name order -- what csrc/build.sh embeds as wd_build_stamp().
+    None when the sources are not there (an installed library without its tree)."""
+    import glob
+    import hashlib
+    csrc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+    names = sorted([os.path.basename(f) for f in glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.h"))]
+                   + ["../../include/wd_hip.h"])
+    if len(names) < 3:
+        return None
+    h = hashlib.sha256()
+    try:
+        for n in names:
+            with open(os.path.join(csrc, n), "rb") as f:
+                h.update(f.read())
+    except OSError:
+        return None
+    return h.hexdigest()
 
 
 def load():
@@ -270,6 +291,17 @@ def load():
     lib = ctypes.CDLL(path)
     lib.wd_last_error.restype = ctypes.c_char_p
     lib.wd_last_error.argtypes = []
+    if "WD_HIP_LIB" not in os.environ:
+        # the prebuilt library ships with the tree (gpurun copies it): it must have been built from THESE sources
+        want = source_stamp()
+        try:
+            lib.wd_build_stamp.restype = ctypes.c_char_p
+            got = lib.wd_build_stamp().decode()
+        except AttributeError:
+            got = "(none: built before the stamp existed)"
+        if want is not None and got != want:
+            raise WdError("stale HIP library %s: built from sources with stamp %s, the tree has %s -- run "
+                          "`python -c 'import __graft_entry__ as g; g.build()'` (wide_deep_amd/csrc/build.sh)" % (path, got[:16], want[:16]))
     for name, argtypes in _PROTOS.items():
         fn = getattr(lib, name)
         fn.argtypes = argtypes

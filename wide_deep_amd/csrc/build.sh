@@ -14,7 +14,12 @@ for f in common hash embag sparse_update sparse_fused onehot_path dist_exchange 
   fi
 done
 for p in $pids; do wait $p; done
-hipcc --offload-arch=gfx950 -shared -fPIC "$HERE"/_obj/common.o "$HERE"/_obj/hash.o "$HERE"/_obj/embag.o \
+# source stamp: sha256 over the sources this library is built from (sorted by name; capi.load() recomputes it and refuses a
+# library that was built from other sources -- the prebuilt .so travels to the GPU box, a stale one would otherwise load silently)
+STAMP=$(cd "$HERE" && cat $(ls *.hip *.h ../../include/wd_hip.h | LC_ALL=C sort) | sha256sum | cut -c1-64)
+printf 'extern "C" const char *wd_build_stamp(void) { return "%s"; }\n' "$STAMP" > "$HERE/_obj/build_stamp.cpp"
+g++ -O1 -fPIC -c "$HERE/_obj/build_stamp.cpp" -o "$HERE/_obj/build_stamp.o"
+hipcc --offload-arch=gfx950 -shared -fPIC "$HERE"/_obj/build_stamp.o "$HERE"/_obj/common.o "$HERE"/_obj/hash.o "$HERE"/_obj/embag.o \
       "$HERE"/_obj/sparse_update.o "$HERE"/_obj/sparse_fused.o "$HERE"/_obj/onehot_path.o "$HERE"/_obj/dist_exchange.o "$HERE"/_obj/mlp.o "$HERE"/_obj/mlp_half.o "$HERE"/_obj/mlp_chain.o "$HERE"/_obj/mlp_chain8.o -o "$OUT/libwd_hip.so"
 echo "built $OUT/libwd_hip.so"
 # host-side TSV ingest (plain C, no GPU code)

@@ -556,7 +556,8 @@ int wd_logits_head(const float *a, int64_t ld_a, int64_t K, const float *wf, con
 /* ---- whole `simple` tower in one launch (csrc/mlp_chain.hip) -------------------------------------------------------
  * python/lib/dnn.py:92-141 (dense -> activation -> BN per hidden layer; BN = the inference affine of SURVEY App. C.1, applied
  * as written -- nothing is folded), dnn.py:226-232 (logits), python/lib/joint.py:216-222, 264-269 (joint logit, sigmoid CE) for
- * one row tile (wd_chain_opts_t.row_tile: 32 or 16 examples) per workgroup, with s_l = gamma_l inv, t_l = beta_l:
+ * one row tile of 32 examples per workgroup (csrc/mlp_chain8.hip: 512 lanes, two wavefronts per SIMD), with s_l = gamma_l inv,
+ * t_l = beta_l:
  *   a_l = act(bn_{l-1} W_l + b_l),  bn_l = s_l a_l + t_l  (bn_{-1} = x),  dnn_logit = bn_{L-1} . w_logits + b, head as
  *   wd_logits_head, and with labels  d(bn_{L-1}) = dlogit w_logits^T,  dz_l = d(bn_l) s_l act'(a_l),  d(bn_{l-1}) = dz_l W_l^T,
  *   dx = dz_0 W_0^T.
@@ -581,9 +582,8 @@ typedef struct wd_chain_layer {
   int32_t K, N;
 } wd_chain_layer_t;
 /* A packed operand B [R reduction rows][C columns] (Wpk: R = K, C = N; WTpk = pack(W^T): R = N, C = K) is stored as
- *   row tile 32:  pk[((c/32) * (R/8)  + r/8)  * 256 + ((r%2) * 32 + c%32) * 4 + (r%8)/2 ]  =  B[r][c]
- *   row tile 16:  pk[((c/16) * (R/16) + r/16) * 256 + ((r%4) * 16 + c%16) * 4 + (r%16)/4]  =  B[r][c]
- * i.e. one 16-byte load per lane feeds four consecutive v_mfma_f32_32x32x2_f32 (v_mfma_f32_16x16x4_f32) steps of a tile.
+ *   pk[((c/32) * (R/8)  + r/8)  * 256 + ((r%2) * 32 + c%32) * 4 + (r%8)/2 ]  =  B[r][c]
+ * i.e. one 16-byte load per lane feeds four consecutive v_mfma_f32_32x32x2_f32 steps of a 32-column tile.
  *
  * wd_chain_tail -- the dense tail of a step on the one-launch tower (python/lib/joint.py:233-241: Adagrad on the dnn scope).
  * Nothing is folded, so every dense parameter is on its own: per parameter the split-K partials of its gradient are summed in
@@ -601,33 +601,10 @@ typedef struct wd_tail_layer {
   const float *db_sum;       /* [N] or NULL (then the partials carry the bias-gradient row K) */
   const float *dgamma_sum, *dbeta_sum;   /* [N] (when gamma_off / beta_off >= 0) */
   float *Wpk, *WTpk;         /* NULL: not packed (the logits layer) */
-  int32_t nsplit, pk_tile;
+  int32_t nsplit, pk_tile;   /* pk_tile: 32 (the only packing) */
 } wd_tail_layer_t;
 int wd_chain_tail(const wd_tail_layer_t *layers, int32_t nlayers, float *P, float *Pacc, float *Gflat, float inv, float lr,
                   int32_t mode, wd_stream_t stream);
-/* wd_gemm_tn_splitk_group + wd_chain_tail(GRAD | UPDATE | PACK) in ONE launch (single GPU, Adagrad: nothing reduces the
- * gradients between the two): job j is the job of wd_gemm_tn_splitk_group, and fuse[j] says whose gradient it completes --
- *   WD_FUSE_KERNEL  a product job = the kernel gradient of layers[layer] (Cpart = its Gpart, nsplit = its nsplit, no appended
- *                   ones row): the LAST workgroup to finish an output tile sums the tile's partials in split order, takes the
- *                   Adagrad step and rewrites the packed copies (tile_counters: one zeroed int per output tile; left zero);
- *   WD_FUSE_BIAS / WD_FUSE_GAMMA / WD_FUSE_BETA  a column-sum job = that vector's gradient (gamma: x inv);
- *   WD_FUSE_WHOLE   no product: the whole tail of layers[layer] from partials complete before the launch (logits layer);
- *   WD_FUSE_NONE    the job as it is (e.g. the loss sum).
- * Same arithmetic, element by element, as the two launches (python/lib/joint.py:233-241). */
-#define WD_FUSE_NONE 0
-#define WD_FUSE_KERNEL 1
-#define WD_FUSE_BIAS 2
-#define WD_FUSE_GAMMA 3
-#define WD_FUSE_BETA 4
-#define WD_FUSE_WHOLE 5
-#define WD_TN_FUSED_MAX_JOBS 16
-#define WD_TN_FUSED_MAX_LAYERS 5
-typedef struct wd_tn_fuse {
-  int32_t kind, layer;
-} wd_tn_fuse_t;
-int wd_gemm_tn_group_tail(const wd_tn_job_t *jobs, const wd_tn_fuse_t *fuse, int32_t njobs, const wd_tail_layer_t *layers,
-                          int32_t nlayers, float *P, float *Pacc, float *Gflat, float inv, float lr, int32_t *tile_counters,
-                          int32_t ncounters, wd_stream_t stream);
 /* Optional (wd_chain_opts_t.input): fuse the input layer into the call (one-id-per-bag batches, the Criteo shape): the kernel
  * then builds its x tile itself -- x[b, out_col_s ..] = emb[emb_off_s + ids[b*S + s]*dim ..] for the slots
  * [slot0, slot0+ngroup) (id < 0: zeros), the numeric columns (wd_dense_fwd), and the wide logit
@@ -660,9 +637,7 @@ typedef struct wd_chain_input {
  *              wd_gemm_tn_splitk_group): a reproducible loss that needs no zeroed accumulator
  *   stamps     diagnostics: device uint64[192]; workgroups 0 and 100 write shader-clock stamps (start, x tile in LDS, after
  *              each forward layer, head, after each gradient stage, end) to [0..31] / [32..63]
- *   row_tile   examples per workgroup: 0 or 32 -> v_mfma_f32_32x32x2_f32, one workgroup per CU; 16 -> v_mfma_f32_16x16x4_f32,
- *              half the LDS, two workgroups per CU (one computes while the other gathers / stores / waits at a barrier).
- *              Wpk / WTpk must be packed for the same tile (wd_tail_layer_t.pk_tile); every width a multiple of it
+ *   row_tile   examples per workgroup: 0 or 32 (v_mfma_f32_32x32x2_f32; the 16-row variant of rounds 1-3 is gone)
  *   tile_stamps diagnostics: device uint64[2 * wd_tower_chain_blocks]: every workgroup stores the constant-rate realtime
  *              clock (100 MHz, chip-wide) at its start and when its x tile is complete in LDS -- bench.py derives the
  *              in-step gather span from them */
@@ -672,23 +647,14 @@ typedef struct wd_chain_opts {
   void *stamps;
   void *tile_stamps;
   int32_t row_tile;
-  int32_t flags;       /* bit 0: row tile 16 without the priority split between the two co-resident workgroups; bit 1: dx stage without
-                          the reduction-split last column tile; bit 2: plain instead of write-through stores of the HBM outputs;
-                          bit 3: s_setprio 3 for the launch's wavefronts; bit 4: row tile 32 on the one-wavefront-per-SIMD kernel
-                          (csrc/mlp_chain.hip) instead of the two-wavefronts-per-SIMD one (csrc/mlp_chain8.hip) (A/B switches) */
+  int32_t flags;       /* A/B switches -- bit 2: plain instead of write-through stores of the HBM outputs; bit 3: s_setprio 3 for
+                          the launch's wavefronts */
   /* wide logit from a per-occurrence weight list (wd_prefetch_onehot): wide_logit[b] = wide_bias[0] + sum_s wide_vals[b*wide_S + s],
    * slots in order; replaces the wide_logit argument (input must be NULL); also stored to wide_out when that is not NULL */
   const float *wide_vals;
   const float *wide_bias;
   float *wide_out;
   int32_t wide_S, pad_;
-  /* gradients straight into the per-occurrence records of the row exchange (sharded engine; one id per bag, the embedding columns
-   * of slot s at x columns [s * dx_dim, (s + 1) * dx_dim)): dx[b, s * dx_dim + c] goes to dx_scatter[dx_pos[b * dx_S + s] * dx_rs + c]
-   * and dlogit[b] to dx_scatter[dx_pos[b * dx_S + s] * dx_rs + dx_dim] for every s (dx_pos < 0: dropped) -- what wd_grad_pack does
-   * in a launch of its own; the dx argument is then only a switch (its buffer is not written). */
-  const int32_t *dx_pos;
-  float *dx_scatter;
-  int32_t dx_S, dx_rs, dx_dim, pad2_;
 } wd_chain_opts_t;
 int64_t wd_tower_chain_lds_bytes(int32_t K0, const int32_t *N, int32_t L, int32_t row_tile);   /* -1: unsupported shape */
 int64_t wd_tower_chain_blocks(int64_t batch, int32_t row_tile);   /* ceil(batch / row_tile) */

@@ -44,7 +44,6 @@ tw["dx_cols"] = 0
 nodx = timeit(lambda: eng._tower_chain(tw, bt, B, st, True))
 tw["dx_cols"] = dxc
 fwd = timeit(lambda: eng._tower_chain(tw, bt, B, st, False))
-print("row tile %d (WD_CHAIN_RT)" % eng.chain_rt)
 print("chain B=%d hidden=%s: %s %.1f us | x from HBM + given wide logit: full %.1f us, no dx %.1f us, forward only %.1f us "
       "(forward GEMM flops %.2f G)" % (B, hidden, "as launched in the step (x from HBM, wide logit from the prefetched weight list)"
                                        if eng.prefetch else "with fused input layer", fused, full, nodx, fwd, fl_f / 1e9))
@@ -59,10 +58,6 @@ names = ["x tile"] + ["F%d" % l for l in range(len(hidden))] + ["head"] + ["B%d"
 for wg, off in ((0, 0), (100, 32)):
     v = stamps[off: off + len(names) + 1].cpu().tolist()
     print("workgroup %d cycles: " % wg + ", ".join("%s %d" % (n, v[i + 1] - v[i]) for i, n in enumerate(names)) + ", total %d" % (v[len(names)] - v[0]))
-v = stamps[16:32].cpu().tolist()
-print("wg0 wave0 F0: mma %d, epilogue x2 %d | dx pair 1: mma %d, epilogue %d; pair 2: mma %d, epilogue %d" % (
-    v[1] - v[0], v[2] - v[1], v[5] - v[4], v[6] - v[5], v[8] - v[7], v[9] - v[8]))
-
 
 # two-wavefronts-per-SIMD kernel: per-stage stamps of workgroup 0's wavefronts 0 and 4 (mlp_chain8.hip stage8)
 sv = stamps[64:192].cpu().view(8, 2, 8)

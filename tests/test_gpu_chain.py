@@ -1,5 +1,7 @@
-"""GPU: the one-launch tower (wd_tower_chain, csrc/mlp_chain.hip) against the CPU oracle and against the per-layer GEMM
-launches it replaces (same engine with WD_CHAIN=0).
+"""GPU: the one-launch tower (wd_tower_chain, csrc/mlp_chain8.hip) against the CPU oracle and against the per-layer GEMM
+launches it replaces (same engine with WD_CHAIN=0).  The parametrised shapes cover the kernel's phase kinds: whole phases of 8
+column tiles, reduction-split phases (4 x 2, 2 x 4, 1 x 8 slices), units shorter than the weight ring and of lengths that are
+no multiple of it, a ragged last row tile, a non-ReLU activation.
 
 Tolerances: as tests/test_gpu_step.py (fp32 summation order is the only difference: MFMA k-order of a 32-row tile vs the
 64x64 tiles of the GEMMs vs BLAS)."""
@@ -11,16 +13,6 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=[(32, 0), (32, 16), (16, 0)], ids=["rt32-8waves", "rt32-4waves", "rt16"])
-def row_tile(request, monkeypatch):
-    """every test of this file runs on the three forms of the kernel: row tile 32 with two wavefronts per SIMD (csrc/mlp_chain8.hip,
-    the default), row tile 32 with one (csrc/mlp_chain.hip; wd_chain_opts_t.flags bit 4, engine: WD_CHAIN_FLAGS=16) and row tile
-    16 (wd_chain_opts_t.row_tile; engine: WD_CHAIN_RT)"""
-    monkeypatch.setenv("WD_CHAIN_RT", str(request.param[0]))
-    monkeypatch.setenv("WD_CHAIN_FLAGS", str(request.param[1]))
-    return request.param[0]
-
-
 def _engines(spec, max_batch, seed=5):
     from wide_deep_amd.engine import WideDeepEngine
     chain = WideDeepEngine(spec, max_batch=max_batch, seed=seed)
@@ -29,7 +21,7 @@ def _engines(spec, max_batch, seed=5):
         layered = WideDeepEngine(spec, max_batch=max_batch, seed=seed)
     finally:
         del os.environ["WD_CHAIN"]
-    assert chain.chain and not layered.chain and chain.chain_rt == int(os.environ["WD_CHAIN_RT"])
+    assert chain.chain and not layered.chain and chain.chain_rt == 32
     return chain, layered
 
 

@@ -45,7 +45,7 @@ def _spec(kind):
         return criteo_spec(n_dense=0, n_sparse=6, buckets=97, dim=16, hidden=(8,), model_type="wide"), 2
     if kind == "deeponly":
         return criteo_spec(n_dense=2, n_sparse=3, buckets=50, dim=32, hidden=(16,), model_type="deep"), 4
-    if kind in ("chain", "chain_graph", "chain_pack"):   # one-launch tower (widths % 32 == 0): gradient exchange overlapped with the dense branch
+    if kind in ("chain", "chain_graph"):   # one-launch tower (widths % 32 == 0): gradient exchange overlapped with the dense branch
         return criteo_spec(n_dense=16, n_sparse=3, buckets=300, dim=16, hidden=(64, 32)), 1
     return criteo_spec(n_dense=3, n_sparse=5, buckets=300, dim=16, hidden=(32, 16)), 1
 
@@ -71,8 +71,6 @@ def _worker(rank, world, port, kind, q):
         from wide_deep_amd.engine import WideDeepEngine
         from tests.helpers import assert_close
         spec, _ = _spec(kind)
-        if kind == "chain_pack":          # the tower kernel writes the gradient-exchange records itself (dist._chain_scatter)
-            os.environ["WD_SHARD_PACK"] = "tower"
         B_loc, steps = (48 if world == 2 else 24), 3
         dedup = "_dedup" in kind
         if dedup:
@@ -84,7 +82,6 @@ def _worker(rank, world, port, kind, q):
         bs = _batches(ref.plan, kind, steps, B_loc, world)
         if kind.startswith("chain"):
             assert sh.chain and ref.chain
-            assert sh._scatter_ok() == (kind == "chain_pack")
         assert sh.dedup == dedup
         if kind.startswith("mixed"):
             assert sh.mixed_dims and sh.dim == 32 and sh.emb.numel() >= sh.n_emb_rows * 32
@@ -184,7 +181,7 @@ def test_exchange_overflow_is_reported():
     _run(_overflow_worker, "onehot")
 
 
-@pytest.mark.parametrize("kind", ["onehot", "multihot", "wideonly", "deeponly", "chain", "chain_graph", "chain_pack", "mixed", "indicator",
+@pytest.mark.parametrize("kind", ["onehot", "multihot", "wideonly", "deeponly", "chain", "chain_graph", "mixed", "indicator",
                                   "onehot4", "chain4", "mixed4", "indicator4", "chain_dedup", "chain_graph_dedup", "chain_dedup4"])
 def test_sharded_world2_equals_single_engine(kind):
     """world 2, and (kinds ending in 4) world 4: four owners per table, three peers per all-to-all"""

@@ -82,9 +82,7 @@ class WdChainOpts(ctypes.Structure):
     _fields_ = [("input", ctypes.c_void_p), ("loss_part", ctypes.c_void_p), ("stamps", ctypes.c_void_p),
                 ("tile_stamps", ctypes.c_void_p), ("row_tile", ctypes.c_int32), ("flags", ctypes.c_int32),
                 ("wide_vals", ctypes.c_void_p), ("wide_bias", ctypes.c_void_p), ("wide_out", ctypes.c_void_p),
-                ("wide_S", ctypes.c_int32), ("pad_", ctypes.c_int32),
-                ("dx_pos", ctypes.c_void_p), ("dx_scatter", ctypes.c_void_p), ("dx_S", ctypes.c_int32),
-                ("dx_rs", ctypes.c_int32), ("dx_dim", ctypes.c_int32), ("pad2_", ctypes.c_int32)]
+                ("wide_S", ctypes.c_int32), ("pad_", ctypes.c_int32)]
 
 
 class WdApplyNext(ctypes.Structure):
@@ -110,12 +108,6 @@ class WdChainLayer(ctypes.Structure):
 
 
 WD_TAIL_GRAD, WD_TAIL_UPDATE, WD_TAIL_PACK = 1, 2, 4
-WD_FUSE_NONE, WD_FUSE_KERNEL, WD_FUSE_BIAS, WD_FUSE_GAMMA, WD_FUSE_BETA, WD_FUSE_WHOLE = 0, 1, 2, 3, 4, 5
-WD_TN_FUSED_MAX_JOBS, WD_TN_FUSED_MAX_LAYERS = 16, 5
-
-
-class WdTnFuse(ctypes.Structure):
-    _fields_ = [("kind", ctypes.c_int32), ("layer", ctypes.c_int32)]
 
 
 class WdTailLayer(ctypes.Structure):
@@ -228,7 +220,6 @@ _PROTOS = {
     "wd_chain_tail": [P, I32, P, P, P, F32, F32, I32, P],
     "wd_route_unique": [P, I64, I32, I32, P, P, P, P, P, P],
     "wd_row_grad_presum": [P, I32, I64, P, I64, P, I32, P, P, I32, P, P, I32, P],
-    "wd_gemm_tn_group_tail": [P, P, I32, P, I32, P, P, P, F32, F32, P, I32, P],
     "wd_logits_head_h": [P, I64, I64, P, P, I32, P, P, P, I64, P, P, P, P, P, P, I64, I32, P, P],
     "wd_hgemm_nn": [P, I64, P, I64, P, I32, I32, P, I64, P, I64, I64, I64, I64, P],
     "wd_hgemm_nt": [P, I64, P, I64, I64, I64, I64, P, I64, I32, P, I64, P, I64, P, I64, I32, P],

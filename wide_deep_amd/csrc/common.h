@@ -66,9 +66,8 @@ inline int wt_mask() {
   return m;
 }
 
-// ---- one dense parameter's share of the dense tail (python/lib/joint.py:233-241, tf.train.AdagradOptimizer on the dnn scope):
-// shared by k_chain_tail (mlp_chain.hip) and by the weight-gradient launch that finishes its own tiles (mlp.hip,
-// wd_gemm_tn_group_tail), so that both take the same arithmetic.
+// ---- one dense parameter's share of the dense tail (python/lib/joint.py:233-241, tf.train.AdagradOptimizer on the dnn scope),
+// k_chain_tail (mlp_chain.hip).
 struct TailCtx {
   float *P, *Pacc, *Gflat;
   float inv, lr;
@@ -89,13 +88,8 @@ __device__ __forceinline__ void tail_apply(const wd_tail_layer_t &L, const TailC
   if (pack && e >= 0 && L.Wpk) {
     const int64_t K = L.K, N = L.N;
     const int64_t k = e / N, n = e - k * N;
-    if (L.pk_tile == 16) {
-      L.Wpk[((n >> 4) * (K >> 4) + (k >> 4)) * 256 + (((k & 3) << 4) + (n & 15)) * 4 + ((k & 15) >> 2)] = w;
-      if (L.WTpk) L.WTpk[((k >> 4) * (N >> 4) + (n >> 4)) * 256 + (((n & 3) << 4) + (k & 15)) * 4 + ((n & 15) >> 2)] = w;
-    } else {
-      L.Wpk[((n >> 5) * (K >> 3) + (k >> 3)) * 256 + (((k & 1) << 5) + (n & 31)) * 4 + ((k & 7) >> 1)] = w;
-      if (L.WTpk) L.WTpk[((k >> 5) * (N >> 3) + (n >> 3)) * 256 + (((n & 1) << 5) + (k & 31)) * 4 + ((n & 7) >> 1)] = w;
-    }
+    L.Wpk[((n >> 5) * (K >> 3) + (k >> 3)) * 256 + (((k & 1) << 5) + (n & 31)) * 4 + ((k & 7) >> 1)] = w;
+    if (L.WTpk) L.WTpk[((k >> 5) * (N >> 3) + (n >> 3)) * 256 + (((n & 1) << 5) + (k & 31)) * 4 + ((n & 7) >> 1)] = w;
   }
 }
 

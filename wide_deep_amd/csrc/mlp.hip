@@ -49,7 +49,6 @@ struct GemmArgs {
   int32_t a_vec, b_vec; // float4 loads legal (ld % 4 == 0 and 16-byte aligned base)
   int32_t tiles_m, tiles_n;
   int32_t wt;           // TN partials stored write-through (common.h)
-  int32_t prio;         // wavefront priorities (WD_TN_PRIO, experiment): 0 the odd hardware slot at 2, 1 every wavefront at 3, 2 none
 };
 
 __device__ __forceinline__ float act_fwd(float v, int act) {
@@ -117,20 +116,8 @@ __device__ __forceinline__ float4 mask4(float4 v, int64_t row, int64_t col, int6
 // before the BK/2 MFMAs of slab i and land in the other LDS buffer afterwards -> ONE barrier per slab and
 // NV = BK/16 independent 16-byte loads per operand per lane in flight (the BK=16 single-stage version paid
 // one full HBM/L2 latency per 8 MFMAs).
-// What the workgroup that completes an output tile of a split-K weight-gradient product does with it (TAIL = true,
-// wd_gemm_tn_group_tail): the tile's partials are final when the LAST of its nsplit workgroups arrives -- that one sums them
-// in split order (the order wd_chain_tail uses), takes the Adagrad step and rewrites the packed copies of its 64 x 64 kernel
-// elements.  The step's dense chain is then tower -> products instead of tower -> products -> tail (15 us + a kernel boundary).
-struct FuseTile {
-  wd_tail_layer_t L;    // (by value: the address of a kernel argument would force the whole argument block into scratch)
-  bool on;              // false: a product job of the group that finishes nothing
-  wd::TailCtx c;
-  int32_t *counter;     // one per output tile of the job; zero between launches
-  int32_t nsplit;
-};
-
-template <bool A_RC, bool B_RC, int EPI, int BK, bool VEC, bool TAIL = false, bool DEEP = false>
-__device__ __forceinline__ void gemm_body(const GemmArgs &g, const int orig, const int bz, const FuseTile &ft = FuseTile{}) {
+template <bool A_RC, bool B_RC, int EPI, int BK, bool VEC>
+__device__ __forceinline__ void gemm_body(const GemmArgs &g, const int orig, const int bz) {
   constexpr int LDA = A_RC ? LD_RC : LD_OC;
   constexpr int LDB = B_RC ? LD_RC : LD_OC;
   constexpr int NV = BK / 16;  // float4 per lane per operand per slab
@@ -144,13 +131,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &g, const int orig, con
   // lock-step (both in their MFMA phase at half rate, then both in their load/LDS-store phase with the pipe idle:
   // measured 46 % MFMA busy).  Give the wave in the odd hardware slot priority: it runs its MFMA phase at full
   // rate while the other one stores / waits, and vice versa.
-  static_assert(true, "");
-  {
-    // WD_TN_PRIO (experiment, read on the host: GemmArgs.prio): 1 = every wavefront of the products at priority 3 (over the row
-    // update beside them), 2 = none raised
-    if (g.prio == 1) __builtin_amdgcn_s_setprio(3);
-    else if (g.prio == 0 && (__builtin_amdgcn_s_getreg((4) | (0 << 6) | (3 << 11)) & 1u)) __builtin_amdgcn_s_setprio(2);  // HW_ID.WAVE_ID
-  }
+  if (__builtin_amdgcn_s_getreg((4) | (0 << 6) | (3 << 11)) & 1u) __builtin_amdgcn_s_setprio(2);  // HW_ID.WAVE_ID
 
   // XCD-aware tile mapping: hardware places block i on XCD i % 8; give each XCD a contiguous run of
   // tiles (n fastest) so the N-tiles sharing an A panel hit the same L2.  Bijective for any grid.
@@ -300,55 +281,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &g, const int orig, con
     }
   };
 
-  const int64_t nslab = (kend - kbeg) / BK;
-  if (DEEP && fast_tile && kend > kbeg && (kend - kbeg) % BK == 0 && nslab >= 2) {
-    // Interior tile, whole slabs (the weight-gradient products of a full batch): the global loads run TWO slabs ahead of the
-    // MFMAs -- slab s+1 waits in registers while slab s+2 is requested, and goes to the other LDS buffer after the MFMAs
-    // of slab s.  One slab of MFMAs (16 per wavefront at BK = 32) is ~0.45 us; an L2 / HBM round trip beside the row update of
-    // the same step is several times that, and with one slab in flight every slab boundary waited for it.
-    struct Slab {
-      float4 a[NV], b[NV];
-    };
-    auto ld = [&](int64_t sl) {
-      Slab x;
-      load_fast(kbeg + sl * BK, x.a, x.b);
-      return x;
-    };
-    auto st = [&](int buf, const Slab &x) { store_fast(As[buf], Bs[buf], x.a, x.b); };
-    st(0, ld(0));
-    Slab r = ld(1), q;
-    __syncthreads();
-    int64_t sl = 0;           // top of the loop: LDS buffer 0 holds slab sl (even), r = slab sl + 1 (requested, maybe in flight)
-    while (sl + 3 < nslab) {
-      q = ld(sl + 2);
-      __builtin_amdgcn_sched_barrier(0);      // (the requests go out BEFORE the MFMAs of this slab, not behind them)
-      compute(0);
-      st(1, r);
-      __syncthreads();
-      r = ld(sl + 3);
-      __builtin_amdgcn_sched_barrier(0);
-      compute(1);
-      st(0, q);
-      __syncthreads();
-      sl += 2;
-    }
-    if (sl + 2 < nslab) {     // three slabs left
-      q = ld(sl + 2);
-      compute(0);
-      st(1, r);
-      __syncthreads();
-      compute(1);
-      st(0, q);
-      __syncthreads();
-      compute(0);
-    } else {                  // two
-      compute(0);
-      st(1, r);
-      __syncthreads();
-      compute(1);
-    }
-    __syncthreads();
-  } else {
+  {
     float4 ra[NV], rb[NV];
     bool fast = fast_tile && (kbeg + BK <= kend);
     if (fast) {
@@ -389,120 +322,6 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &g, const int orig, con
 
   // C/D layout of 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
   const int64_t n = n0 + wn * 32 + fc;
-  if constexpr (TAIL) {
-    static_assert(EPI == 2, "the fused tail belongs to the split-K weight-gradient product");
-    const bool n_ok = n < g.N;
-    float *Cz = g.C + (int64_t)bz * g.c_split;
-    if (!ft.on) {       // a product job of the group that finishes nothing: plain partial stores
-#pragma unroll
-      for (int rg = 0; rg < 16; ++rg) {
-        const int64_t m = m0 + wm * 32 + (rg & 3) + 8 * (rg >> 2) + 4 * fr;
-        if (n_ok && m < g.M) wd::store1(&Cz[m * g.ldc + n], acc[rg], g.wt);
-      }
-      return;
-    }
-    // (1) this split's partial tile, stored at DEVICE scope (write-through: the workgroup that sums the tile may sit on
-    //     another XCD, whose L2 is not coherent with ours; a __threadfence() instead would write back this XCD's whole L2)
-#pragma unroll
-    for (int rg = 0; rg < 16; ++rg) {
-      const int64_t m = m0 + wm * 32 + (rg & 3) + 8 * (rg >> 2) + 4 * fr;
-      if (n_ok && m < g.M) __hip_atomic_store(&Cz[m * g.ldc + n], acc[rg], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_s_waitcnt(0);        // every store of this wavefront has been acknowledged
-    __syncthreads();
-    int32_t *flag = reinterpret_cast<int32_t *>(&As[0][0]);     // (the slab loop ended with a barrier: the LDS tiles are dead)
-    if (t == 0) {
-      int32_t *ctr = ft.counter + vid;
-      const bool last = __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ft.nsplit - 1;
-      if (last) __hip_atomic_store(ctr, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // ready for the next launch
-      *flag = last;
-    }
-    __syncthreads();
-    if (!*flag || !n_ok) return;
-    // (2) the last workgroup of the tile: gradient = sum of the nsplit partials in split order (device-scope loads: past this
-    //     CU's L1 and this XCD's L2), four rows x 16 splits in flight per lane; addresses = uniform split base + 32-bit lane
-    //     offset (one VGPR per row, not two per load)
-    const wd_tail_layer_t &L = ft.L;
-    const wd::TailCtx &c = ft.c;
-    const int32_t ns = ft.nsplit;
-    auto row_of = [&](int rg) -> int64_t { return m0 + wm * 32 + (rg & 3) + 8 * (rg >> 2) + 4 * fr; };
-    if (ns <= 16) {
-      // this lane's 16 rows in 8 rounds of two; the 32 partial loads + 4 parameter loads of a round are issued TWO rounds
-      // ahead of their use (three register sets): one exposed memory round trip for the tile instead of one per round
-      float v[3][2][16], pw[3][2], pa[3][2];
-      auto issue = [&](int k, int b) {
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const int64_t m = row_of(2 * k + u);
-          const uint32_t o = (uint32_t)((m < g.M ? m : 0) * g.ldc + n);
-          pw[b][u] = c.P[L.w_off + o];
-          pa[b][u] = c.Pacc[L.w_off + o];
-#pragma unroll
-          for (int zz = 0; zz < 16; ++zz) {
-            const float *pz = g.C + (int64_t)(zz < ns ? zz : 0) * g.c_split;      // uniform
-            v[b][u][zz] = __hip_atomic_load(pz + o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          }
-        }
-      };
-      auto consume = [&](int k, int b) {
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const int64_t m = row_of(2 * k + u);
-          if (m >= g.M) continue;
-          float gv = 0.f;
-#pragma unroll
-          for (int zz = 0; zz < 16; ++zz) gv += zz < ns ? v[b][u][zz] : 0.f;
-          const uint32_t o = (uint32_t)(m * g.ldc + n);
-          wd::tail_apply(L, c, L.w_off + o, o, gv, pw[b][u], pa[b][u], true, true, true);
-        }
-      };
-      issue(0, 0);
-      issue(1, 1);
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        if (k + 2 < 8) issue(k + 2, (k + 2) % 3);
-        consume(k, k % 3);
-      }
-      return;
-    }
-#pragma unroll 1
-    for (int r0 = 0; r0 < 16; r0 += 4) {
-      uint32_t off[4];
-      bool ok[4];
-      float gv[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int64_t m = row_of(r0 + u);
-        ok[u] = m < g.M;
-        off[u] = (uint32_t)((ok[u] ? m : 0) * g.ldc + n);
-      }
-#pragma unroll 1
-      for (int32_t z0 = 0; z0 < ns; z0 += 16) {
-        float v[4][16];
-#pragma unroll
-        for (int zz = 0; zz < 16; ++zz) {
-          const float *pz = g.C + (int64_t)(z0 + zz < ns ? z0 + zz : 0) * g.c_split;      // uniform
-#pragma unroll
-          for (int u = 0; u < 4; ++u) v[u][zz] = __hip_atomic_load(pz + off[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-          for (int zz = 0; zz < 16; ++zz) gv[u] += z0 + zz < ns ? v[u][zz] : 0.f;
-      }
-      float w[4], a[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        w[u] = c.P[L.w_off + off[u]];
-        a[u] = c.Pacc[L.w_off + off[u]];
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-        if (ok[u]) wd::tail_apply(L, c, L.w_off + off[u], off[u], gv[u], w[u], a[u], true, true, true);
-    }
-    return;
-  }
   if (n >= g.N) return;
   float *Cz = g.C + (EPI == 2 ? (int64_t)bz * g.c_split : 0);
   float bv = 0.f;
@@ -543,7 +362,7 @@ struct GroupArgs {
   int32_t njobs;
 };
 
-template <int BK, bool VEC, bool DEEP = false>
+template <int BK, bool VEC>
 __global__ void __launch_bounds__(256) k_gemm_tn_group(GroupArgs G) {
   int j = 0;
   while (j + 1 < G.njobs && (int)blockIdx.x >= G.first[j + 1]) ++j;
@@ -573,77 +392,9 @@ __global__ void __launch_bounds__(256) k_gemm_tn_group(GroupArgs G) {
     return;
   }
   const int nwg = g.tiles_m * g.tiles_n;
-  gemm_body<false, false, 2, BK, VEC, false, DEEP>(g, rem % nwg, rem / nwg);
+  gemm_body<false, false, 2, BK, VEC>(g, rem % nwg, rem / nwg);
 }
 
-// wd_gemm_tn_group_tail: the grouped launch that also finishes the dense tail of the step (see FuseTile).
-constexpr int MAX_FUSED_JOBS = 16, MAX_FUSED_LAYERS = 5;
-struct FusedArgs {
-  GemmArgs job[MAX_FUSED_JOBS];
-  wd_tail_layer_t layer[MAX_FUSED_LAYERS];
-  int32_t first[MAX_FUSED_JOBS + 1];
-  int32_t count[MAX_FUSED_JOBS];
-  int32_t ctr0[MAX_FUSED_JOBS];     // first tile counter of a product job
-  int32_t nsplit[MAX_FUSED_JOBS];
-  int8_t kind[MAX_FUSED_JOBS];      // WD_FUSE_*
-  int8_t lyr[MAX_FUSED_JOBS];       // layer the job's gradient belongs to
-  int8_t colsum[MAX_FUSED_JOBS];
-  int32_t njobs;
-  float *P, *Pacc, *Gflat;
-  int32_t *counters;
-  float inv, lr;
-};
-static_assert(sizeof(FusedArgs) <= 4096, "kernel arguments of k_gemm_tn_group_tail");
-
-template <int BK, bool VEC, bool DEEP = false>
-__global__ void __launch_bounds__(256) k_gemm_tn_group_tail(FusedArgs G) {
-  int j = 0;
-  while (j + 1 < G.njobs && (int)blockIdx.x >= G.first[j + 1]) ++j;
-  j = __builtin_amdgcn_readfirstlane(j);
-  const GemmArgs &g = G.job[j];
-  const int rem = blockIdx.x - G.first[j];
-  if (rem >= G.count[j]) return;   // padding of the job's range
-  const int kind = G.kind[j], lyr = G.lyr[j];
-  const wd::TailCtx c{G.P, G.Pacc, G.Gflat, G.inv, G.lr};
-  if (kind == WD_FUSE_WHOLE) {     // a layer whose partials were complete before the launch (logits layer: from the tower)
-    const wd_tail_layer_t L = G.layer[lyr];
-    wd::tail_element(L, c, (int64_t)rem * 256 + threadIdx.x, WD_TAIL_GRAD | WD_TAIL_UPDATE | WD_TAIL_PACK);
-    return;
-  }
-  if (G.colsum[j]) {               // as in k_gemm_tn_group; the finished sum is a bias / gamma / beta gradient
-    __shared__ float part[4][64];
-    const int cc = threadIdx.x & 63, q = threadIdx.x >> 6;
-    const int64_t n = (int64_t)rem * 64 + cc;
-    float acc = 0.f;
-    if (n < g.N) {
-      for (int64_t k0 = q; k0 < g.K; k0 += 32) {
-        float v[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = k0 + 4 * u < g.K ? g.A[(k0 + 4 * u) * g.lda + n] : 0.f;
-#pragma unroll
-        for (int u = 0; u < 8; ++u) acc += v[u];
-      }
-    }
-    part[q][cc] = acc;
-    __syncthreads();
-    if (q == 0 && n < g.N) {
-      const float sum = part[0][cc] + part[1][cc] + part[2][cc] + part[3][cc];
-      g.C[n] = sum;
-      if (kind != WD_FUSE_NONE) {
-        const wd_tail_layer_t L = G.layer[lyr];
-        const int64_t off = kind == WD_FUSE_BIAS ? L.b_off : kind == WD_FUSE_GAMMA ? L.gamma_off : L.beta_off;
-        if (off >= 0) {
-          const float gv = kind == WD_FUSE_GAMMA ? sum * c.inv : sum;
-          wd::tail_apply(L, c, off + n, -1, gv, c.P[off + n], c.Pacc[off + n], true, true, false);
-        }
-      }
-    }
-    return;
-  }
-  const int nwg = g.tiles_m * g.tiles_n;
-  const FuseTile ft{G.layer[lyr], kind == WD_FUSE_KERNEL, c, G.counters + G.ctr0[j], G.nsplit[j]};
-  gemm_body<false, false, 2, BK, VEC, true, DEEP>(g, rem % nwg, rem / nwg, ft);
-}
 
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
@@ -1376,8 +1127,6 @@ extern "C" int wd_gemm_tn_splitk_group(const wd_tn_job_t *jobs, int32_t njobs, w
     g.a_vec = (g.lda % 4 == 0) && aligned16(g.A);
     g.b_vec = (g.ldb % 4 == 0) && aligned16(g.B);
     g.wt = wd::wt_mask() & WD_WT_PRODUCTS ? 1 : 0;
-    static const int tn_prio = getenv("WD_TN_PRIO") ? atoi(getenv("WD_TN_PRIO")) : 0;
-    g.prio = tn_prio;
     vec = vec && g.a_vec && g.b_vec;
     G.first[j] = total;
     G.count[j] = g.tiles_m * g.tiles_n * q.nsplit;
@@ -1392,92 +1141,12 @@ extern "C" int wd_gemm_tn_splitk_group(const wd_tn_job_t *jobs, int32_t njobs, w
     if (vec) hipLaunchKernelGGL((k_gemm_tn_group<kBK, true>), dim3((unsigned)total), dim3(256), 0, wd::as_stream(stream), G);
     else hipLaunchKernelGGL((k_gemm_tn_group<kBK, false>), dim3((unsigned)total), dim3(256), 0, wd::as_stream(stream), G);
   } else {
-    // WD_TN_DEEP=1: global loads two slabs ahead of the MFMAs (gemm_body DEEP).  The launch gets shorter (48 -> 41 us in the
-    // step) and the step longer: the row update and the dense tail beside / behind it stretch by more (profiles/README.md)
-    static const bool deep = getenv("WD_TN_DEEP") && atoi(getenv("WD_TN_DEEP")) == 1;
-    if (vec && deep) hipLaunchKernelGGL((k_gemm_tn_group<32, true, true>), dim3((unsigned)total), dim3(256), 0, wd::as_stream(stream), G);
-    else if (vec) hipLaunchKernelGGL((k_gemm_tn_group<32, true>), dim3((unsigned)total), dim3(256), 0, wd::as_stream(stream), G);
+    if (vec) hipLaunchKernelGGL((k_gemm_tn_group<32, true>), dim3((unsigned)total), dim3(256), 0, wd::as_stream(stream), G);
     else hipLaunchKernelGGL((k_gemm_tn_group<32, false>), dim3((unsigned)total), dim3(256), 0, wd::as_stream(stream), G);
   }
   return wd::check_launch("wd_gemm_tn_splitk_group");
 }
 
-extern "C" int wd_gemm_tn_group_tail(const wd_tn_job_t *jobs, const wd_tn_fuse_t *fuse, int32_t njobs,
-                                     const wd_tail_layer_t *layers, int32_t nlayers, float *P, float *Pacc, float *Gflat,
-                                     float inv, float lr, int32_t *tile_counters, int32_t ncounters, wd_stream_t stream) {
-  if (njobs <= 0) return WD_OK;
-  WD_REQUIRE(jobs && fuse && layers && P && Pacc && Gflat && tile_counters, "null pointer");
-  WD_REQUIRE(njobs <= MAX_FUSED_JOBS, "njobs <= WD_TN_FUSED_MAX_JOBS");
-  WD_REQUIRE(nlayers >= 1 && nlayers <= MAX_FUSED_LAYERS, "1 <= nlayers <= WD_TN_FUSED_MAX_LAYERS");
-  FusedArgs G{};
-  for (int l = 0; l < nlayers; ++l) G.layer[l] = layers[l];
-  bool vec = true;
-  int total = 0, ctr = 0;
-  for (int j = 0; j < njobs; ++j) {
-    const wd_tn_job_t &q = jobs[j];
-    const wd_tn_fuse_t &f = fuse[j];
-    GemmArgs &g = G.job[j];
-    WD_REQUIRE(f.kind >= WD_FUSE_NONE && f.kind <= WD_FUSE_WHOLE, "wd_tn_fuse_t.kind");
-    WD_REQUIRE(f.kind == WD_FUSE_NONE || (f.layer >= 0 && f.layer < nlayers), "wd_tn_fuse_t.layer");
-    G.kind[j] = (int8_t)f.kind;
-    G.lyr[j] = (int8_t)(f.kind == WD_FUSE_NONE ? 0 : f.layer);
-    G.first[j] = total;
-    if (f.kind == WD_FUSE_WHOLE) {
-      const wd_tail_layer_t &L = layers[f.layer];
-      WD_REQUIRE(L.K > 0 && L.N > 0 && L.Gpart, "whole-layer tail: shape and partials");
-      G.count[j] = (int)wd::ceil_div(L.K * L.N + 3 * L.N, (int64_t)256);
-      total += (G.count[j] + 7) / 8 * 8;
-      continue;
-    }
-    if (!q.B) {    // column sums
-      WD_REQUIRE(q.A && q.Cpart && q.N > 0 && q.K > 0, "column-sum job: A, Cpart, N, K");
-      WD_REQUIRE(f.kind == WD_FUSE_NONE || f.kind == WD_FUSE_BIAS || f.kind == WD_FUSE_GAMMA || f.kind == WD_FUSE_BETA,
-                 "a column-sum job finishes a bias / gamma / beta gradient");
-      WD_REQUIRE(f.kind == WD_FUSE_NONE || q.N == layers[f.layer].N, "column-sum job: N of its layer");
-      g.A = q.A; g.C = q.Cpart; g.lda = q.lda; g.N = q.N; g.K = q.K;
-      G.colsum[j] = 1;
-      G.count[j] = (int)wd::ceil_div(q.N, 64);
-      total += (G.count[j] + 7) / 8 * 8;
-      continue;
-    }
-    WD_REQUIRE(q.A && q.B && q.Cpart, "null pointer");
-    WD_REQUIRE(q.M > 0 && q.N > 0 && q.K > 0 && q.nsplit > 0, "M, N, K, nsplit must be > 0");
-    WD_REQUIRE(f.kind == WD_FUSE_NONE || f.kind == WD_FUSE_KERNEL, "a product job finishes a kernel gradient");
-    const int64_t Mo = q.append_ones ? q.M + 1 : q.M;
-    g.A = q.A; g.B = q.B; g.C = q.Cpart; g.lda = q.lda; g.ldb = q.ldb; g.ldc = q.N;
-    g.M = Mo; g.N = q.N; g.K = q.K;
-    g.kchunk = wd::ceil_div(wd::ceil_div(q.K, q.nsplit), kBK) * kBK;
-    g.c_split = Mo * q.N;
-    g.ones_row = q.append_ones ? q.M : -1;
-    g.tiles_m = (int)wd::ceil_div(g.M, BM);
-    g.tiles_n = (int)wd::ceil_div(g.N, BN);
-    g.a_vec = (g.lda % 4 == 0) && aligned16(g.A);
-    g.b_vec = (g.ldb % 4 == 0) && aligned16(g.B);
-    g.wt = wd::wt_mask() & WD_WT_PRODUCTS ? 1 : 0;
-    static const int tn_prio = getenv("WD_TN_PRIO") ? atoi(getenv("WD_TN_PRIO")) : 0;
-    g.prio = tn_prio;
-    vec = vec && g.a_vec && g.b_vec;
-    G.count[j] = g.tiles_m * g.tiles_n * q.nsplit;
-    G.nsplit[j] = q.nsplit;
-    if (f.kind == WD_FUSE_KERNEL) {
-      const wd_tail_layer_t &L = layers[f.layer];
-      WD_REQUIRE(!q.append_ones && q.M == L.K && q.N == L.N && q.Cpart == L.Gpart && q.nsplit == L.nsplit && L.db_sum,
-                 "fused kernel job: [K x N] product into the layer's partials, bias gradient from a column-sum job");
-      G.ctr0[j] = ctr;
-      ctr += g.tiles_m * g.tiles_n;
-    }
-    total += (G.count[j] + 7) / 8 * 8;
-  }
-  WD_REQUIRE(ctr <= ncounters, "tile_counters: one per output tile of the fused product jobs");
-  G.first[njobs] = total;
-  G.njobs = njobs;
-  G.P = P; G.Pacc = Pacc; G.Gflat = Gflat; G.counters = tile_counters; G.inv = inv; G.lr = lr;
-  static const bool deep = getenv("WD_TN_DEEP") && atoi(getenv("WD_TN_DEEP")) == 1;
-  if (vec && deep) hipLaunchKernelGGL((k_gemm_tn_group_tail<32, true, true>), dim3((unsigned)total), dim3(256), 0, wd::as_stream(stream), G);
-  else if (vec) hipLaunchKernelGGL((k_gemm_tn_group_tail<32, true>), dim3((unsigned)total), dim3(256), 0, wd::as_stream(stream), G);
-  else hipLaunchKernelGGL((k_gemm_tn_group_tail<32, false>), dim3((unsigned)total), dim3(256), 0, wd::as_stream(stream), G);
-  return wd::check_launch("wd_gemm_tn_group_tail");
-}
 
 extern "C" int wd_fold_affine(const float *P, int64_t w_off, int64_t b_off, const int32_t *gamma_idx,
                               const int32_t *beta_idx, float inv, float *Wf, float *bf, float *s, float *t, int64_t K,

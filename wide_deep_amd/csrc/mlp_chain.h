@@ -1,6 +1,6 @@
-// wide_deep_amd/csrc/mlp_chain.h -- what the two one-launch tower kernels share (mlp_chain.hip: one wavefront per SIMD, the
-// round-1..3 kernel; mlp_chain8.hip: two wavefronts per SIMD, round 4): the launch arguments, the activation functions
-// (python/lib/utils/model_util.py:28-55 activation_fn) and small helpers.  Internal to csrc/.
+// wide_deep_amd/csrc/mlp_chain.h -- shared by the one-launch tower's entry point (mlp_chain.hip) and its kernel (mlp_chain8.hip):
+// the launch arguments, the activation functions (python/lib/utils/model_util.py:28-55 activation_fn) and small helpers.
+// Internal to csrc/.
 #pragma once
 #include "common.h"
 
@@ -31,14 +31,9 @@ struct ChainArgs {
   unsigned long long *stamps;   // diagnostics (wd_chain_opts_t.stamps): shader-clock stamps of workgroups 0 and 100
   int32_t flags_prio;                // wd_chain_opts_t.flags bit 3: s_setprio 3 for every wavefront of the launch
   int32_t flags_wt;                  // write-through stores of the HBM outputs (WD_WT bit 0; wd_chain_opts_t.flags bit 2 turns it off)
-  int32_t flags_nosplit;             // wd_chain_opts_t.flags bit 1: dx stage without the split last tile (A/B switch)
-  int32_t prio_split;                // row tile 16: the wavefront in the odd hardware slot of each SIMD runs at priority 3
   unsigned long long *tile_stamps;   // wd_chain_opts_t.tile_stamps: [tile][2] realtime-clock stamps {start, x tile in LDS}
   wd_chain_input_t in;          // in.emb != NULL: the x tile is built here (input layer fused), wd_chain_opts_t.input
   float *loss_part;             // != NULL: this tile's loss is stored to loss_part[tile] (no atomic on loss_sum)
-  const int32_t *sc_pos;        // wd_chain_opts_t.dx_pos: scatter dx / dlogit into per-occurrence records instead of dx[batch][ld]
-  float *sc_out;
-  int32_t sc_S, sc_RS, sc_dim, sc_shift;
   const float *wv;              // wd_chain_opts_t.wide_vals: per-occurrence wide weights [batch][wv_S] (x from HBM)
   const float *wv_bias;
   float *wv_out;
@@ -83,7 +78,7 @@ __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlan
 }  // namespace wd_chain
 
 namespace wd {
-// the two-wavefronts-per-SIMD kernel (mlp_chain8.hip): LDS bytes of its layout (-1: the shape does not fit), and the launch
+// the kernel (mlp_chain8.hip): LDS bytes of its layout (-1: the shape does not fit), and the launch (> 0: call not supported)
 int64_t chain8_lds_bytes(int32_t K0, const int32_t *N, int32_t L, int32_t dx_cols);
 int chain8_launch(const wd_chain::ChainArgs &g, wd_stream_t stream);
 }  // namespace wd

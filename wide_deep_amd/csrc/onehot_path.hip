@@ -629,7 +629,6 @@ __device__ __forceinline__ float4 adagrad_row4(float4 &a, float4 w, float4 g, fl
 
 __global__ void __launch_bounds__(256)
 k_row_update(RowUpd u) {
-  if (u.wt & 2) __builtin_amdgcn_s_setprio(3);     // WD_UPDATE_PRIO=1 (experiment): issue priority beside the weight-gradient products
   constexpr int MAXS = 128;
   __shared__ int64_t s_acc_off[MAXS];     // accumulator offset of the slot's first row, minus row_base * dim
   __shared__ int32_t s_col[MAXS];
@@ -648,8 +647,8 @@ k_row_update(RowUpd u) {
     for (int k = l; k < pj.y; k += nl) {
       const int32_t bag2 = (int32_t)(uint32_t)((have_first && k == l) ? first : u.npairs[pj.x + k]);
       float *dst = u.nx + (int64_t)(bag2 / S) * u.nldx + out_col;
-      for (int c = 0; c < LG; ++c) wd::store4(reinterpret_cast<float4 *>(dst + 4 * c), make_float4(row[4 * c], row[4 * c + 1], row[4 * c + 2], row[4 * c + 3]), u.wt & 1);
-      wd::store1(&u.nwv[bag2], wnew, u.wt & 1);
+      for (int c = 0; c < LG; ++c) wd::store4(reinterpret_cast<float4 *>(dst + 4 * c), make_float4(row[4 * c], row[4 * c + 1], row[4 * c + 2], row[4 * c + 3]), u.wt);
+      wd::store1(&u.nwv[bag2], wnew, u.wt);
     }
   };
   if ((int)blockIdx.x == u.flat_blocks + LONG_WORKERS) {     // (grid: long-segment workers first, flat blocks, this one) bias_weights: g = sum_b dlogit[b] (fixed-shape tree), dense FTRL
@@ -872,12 +871,12 @@ k_row_update(RowUpd u) {
   float4 wn = w;
   if (lane_emb) {
     wn = adagrad_row4(a, w, g, u.lr_emb);
-    wd::store4(reinterpret_cast<float4 *>(u.accum + off), a, u.wt & 1);
-    wd::store4(reinterpret_cast<float4 *>(u.rec + eoff), wn, u.wt & 1);
+    wd::store4(reinterpret_cast<float4 *>(u.accum + off), a, u.wt);
+    wd::store4(reinterpret_cast<float4 *>(u.rec + eoff), wn, u.wt);
   }
   if (gl == 0) {
     ftrl_row(r.x, r.y, r.z, gw, u.lr_w, u.l1, u.l2);
-    wd::store4(reinterpret_cast<float4 *>(u.rec + (int64_t)key * RS + D), r, u.wt & 1);
+    wd::store4(reinterpret_cast<float4 *>(u.rec + (int64_t)key * RS + D), r, u.wt);
   }
   if (pj.y > 0) {     // every lane of the group gets the whole new row (shuffles) and takes every 4th pair of the run
     float row[16];
@@ -925,21 +924,9 @@ extern "C" int wd_bucket_onehot(const wd_slot_t *slots, int32_t S, const int32_t
   return wd::check_launch("wd_bucket_onehot");
 }
 
-// bags per lane group (independent id -> record chains per lane): 1 gives the most wavefronts -- best when the launch has the
-// chip to itself --, 2 / 4 put more requests in flight per wavefront, which is what counts beside the tower of the previous
-// batch, where only a few wavefront slots per SIMD are free (WD_PREFETCH_BPG; profiles/r4_gather_instep.txt)
-static int prefetch_bpg() {
-  static const int v = [] {
-    const char *e = getenv("WD_PREFETCH_BPG");
-    const int b = e ? atoi(e) : 1;
-    return (b == 2 || b == 4) ? b : 1;
-  }();
-  return v;
-}
-
 extern "C" int64_t wd_prefetch_onehot_blocks(int64_t batch, int32_t S, int32_t dim, int32_t ncols) {
   if (batch <= 0 || S <= 0 || dim <= 0) return 0;
-  return wd::ceil_div(wd::ceil_div(batch * S, (int64_t)prefetch_bpg()) * (dim / 4), 256) + (ncols > 0 ? wd::ceil_div(batch * ncols, 256) : 0);
+  return wd::ceil_div(batch * S * (dim / 4), 256) + (ncols > 0 ? wd::ceil_div(batch * ncols, 256) : 0);
 }
 
 extern "C" int wd_prefetch_onehot(const float *rec, int32_t rec_stride, int32_t dim, const wd_slot_t *rec_slots, int32_t S,
@@ -953,27 +940,21 @@ extern "C" int wd_prefetch_onehot(const float *rec, int32_t rec_stride, int32_t 
   WD_REQUIRE(ldx % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0, "x must be 16-byte aligned with ldx % 4 == 0");
   WD_REQUIRE(ncols == 0 || (dense && dense_cols), "numeric columns need dense + descriptors");
   hipStream_t st = wd::as_stream(stream);
-  const int bpg = prefetch_bpg();
+  constexpr int BPG = 1;     // bags per lane group: 2 / 4 (more requests per wavefront, fewer wavefronts) are slower alone AND
+                             // beside the tower (profiles/r4_gather_instep.txt)
   static const int prio = (getenv("WD_PREFETCH_PRIO") && atoi(getenv("WD_PREFETCH_PRIO")) == 0) ? 0 : 2;
   const int lanes = dim / 4;
-  const int64_t groups = wd::ceil_div(batch * S, (int64_t)bpg);
+  const int64_t groups = wd::ceil_div(batch * S, BPG);
   const int gb = (int)wd::ceil_div(groups * lanes, 256);
   const int db = ncols > 0 ? (int)wd::ceil_div(batch * ncols, 256) : 0;
-#define WD_LAUNCH_PF2(L, BPG)                                                                                               \
+#define WD_LAUNCH_PF(L)                                                                                                     \
   hipLaunchKernelGGL((k_prefetch_onehot<L, BPG>), dim3((unsigned)(gb + db)), dim3(256), 0, st, rec, rec_stride, rec_slots, \
                      S, ids, batch, x, ldx, wide_vals, dense, ld_dense, dense_cols, ncols, gb,                              \
                      static_cast<unsigned long long *>(span), (int32_t)((wd::wt_mask() & WD_WT_PREFETCH ? 1 : 0) | prio))
-#define WD_LAUNCH_PF(L)                    \
-  do {                                     \
-    if (bpg == 4) WD_LAUNCH_PF2(L, 4);     \
-    else if (bpg == 2) WD_LAUNCH_PF2(L, 2); \
-    else WD_LAUNCH_PF2(L, 1);              \
-  } while (0)
   if (lanes == 4) WD_LAUNCH_PF(4);
   else if (lanes == 2) WD_LAUNCH_PF(2);
   else WD_LAUNCH_PF(1);
 #undef WD_LAUNCH_PF
-#undef WD_LAUNCH_PF2
   return wd::check_launch("wd_prefetch_onehot");
 }
 
@@ -1016,8 +997,7 @@ extern "C" int wd_row_update(float *rec, int32_t rec_stride, int32_t dim, float 
   u.dim = dim; u.S = S; u.lr_emb = lr_emb; u.lr_w = lr_wide; u.l1 = l1; u.l2 = l2;
   if (patch) { u.npairs = next->pairs; u.nx = next->x; u.nwv = next->wide_vals; u.nldx = next->ldx; }
   u.flat_blocks = (int32_t)wd::ceil_div(u.nnz * 4, 256);
-  static const int upd_prio = (getenv("WD_UPDATE_PRIO") && atoi(getenv("WD_UPDATE_PRIO"))) ? 2 : 0;
-  u.wt = (wd::wt_mask() & WD_WT_ROW_UPDATE ? 1 : 0) | upd_prio;
+  u.wt = wd::wt_mask() & WD_WT_ROW_UPDATE ? 1 : 0;
   hipLaunchKernelGGL(k_row_update, dim3((unsigned)(u.flat_blocks + LONG_WORKERS + 1)), dim3(256), 0, wd::as_stream(stream), u);
   return wd::check_launch("wd_row_update");
 }

@@ -398,23 +398,6 @@ class ShardedWideDeepEngine(WideDeepEngine):
             ci.wide, ci.wide_in_row = ptr(self.fwd_recv), 1
         return ci
 
-    def _scatter_ok(self):
-        """The tower kernel can pack the gradient exchange itself: every slot an embedding + wide column of ONE power-of-two
-        width, the embedding columns of slot s at x columns [s * D, (s + 1) * D).  Opt-in (WD_SHARD_PACK=tower): it saves the
-        wd_grad_pack launch (10 us + a kernel boundary in front of C) but the scattered stores and the 16 position loads per lane
-        lengthen the tower's dx stage by as much -- 0.296 against 0.289 ms per step on a one-rank RCCL group (round 3)."""
-        lp = self.plan
-        D = self.dim
-        return (self.spec.has_wide and self.n_emb_slots == lp.S and D >= 4 and D & (D - 1) == 0 and not self.mixed_dims
-                and all(lp.out_col[i] == i * D for i in range(lp.S)) and os.environ.get("WD_SHARD_PACK", "kernel") == "tower"
-                and not self.dedup)
-
-    def _chain_scatter(self, opts, bt, on):
-        self._packed_by_tower = bool(on and self._scatter_ok())
-        if self._packed_by_tower:
-            opts.dx_pos, opts.dx_scatter = ptr(self.pos), ptr(self.bwd_send)
-            opts.dx_S, opts.dx_rs, opts.dx_dim = self.plan.S, self.RS, self.dim
-
     def _setup_dedup(self):
         """Requester-side state of the sender-side unique: slot descriptors over the key space  W * local_row_base(slot) + id
         (owner = key % W, local row = key / W), their row-range bucket geometry, and sort scratch per routing set."""
@@ -573,9 +556,6 @@ class ShardedWideDeepEngine(WideDeepEngine):
         """C: per-occurrence gradients to the owners.  Issued asynchronously: RCCL moves them while this stream goes on
         with the dense branch; `_owner_update` waits for them."""
         lp, spec = self.plan, self.spec
-        if getattr(self, "_packed_by_tower", False):      # the tower kernel of this step wrote the records itself
-            self._packed_by_tower = False
-            return
         has_emb = self.n_emb_slots > 0
         dx_ptr, ld = None, 0
         if has_emb:

@@ -91,8 +91,6 @@ class WideDeepEngine:
         self.rec = None
         self.act_id = capi.ACT_IDS["relu" if self.crelu else spec.activation]
         self.global_step = 0
-        self._tail_fused, self._tile_counters = False, None
-        self.fuse_tail = os.environ.get("WD_FUSE_TAIL", "0") == "1"   # dense tail inside the weight-gradient launch
         self._primed = None             # pipeline.StepGraph: (batch, bucket set, activation buffer, global step) whose input work is in place
         dev = self.device
         f32 = dict(dtype=torch.float32, device=dev)
@@ -413,20 +411,14 @@ class WideDeepEngine:
             return
         tw = self.towers[0]
         tl, metas, L = tw["layout"], tw["metas"], tw["L"]
-        self.chain_rt = 32
+        self.chain_rt = 32           # examples per workgroup of the one-launch tower (csrc/mlp_chain8.hip)
         if tl.mode != "simple" or L < 1 or L > capi.WD_CHAIN_MAX_LAYERS or tl.in_start[0] % 4 or tl.ld % 4:
             return
         dims = [int(metas[l]["N"]) for l in range(L)]
         K0 = int(metas[0]["K"])
-        # row tile: 32 examples per workgroup (one workgroup per CU at batch 8192), or WD_CHAIN_RT=16 (two per CU: same kernel
-        # time alone -- both stream the same 1.2 MB of weights per tile from L2 and are bound there, profiles/r2c_tower_ablation.txt -- but
-        # slower in the step: 0.200 against 0.187 ms, the second wavefront per SIMD is what the bucketing branch used to get)
-        rt = int(os.environ.get("WD_CHAIN_RT", "32"))
-        if rt not in (16, 32):
-            raise ValueError("WD_CHAIN_RT must be 16 or 32")
+        rt = 32
         if int(call("wd_tower_chain_lds_bytes", K0, (ctypes.c_int32 * L)(*dims), L, rt)) <= 0:
             return
-        self.chain_rt = rt
         dev, B = self.device, self.max_batch
         f32 = dict(dtype=torch.float32, device=dev)
         # the kernels in MFMA-fragment order, forward and transposed (wd_chain_layer_t.Wpk / WTpk: written by wd_chain_tail)
@@ -538,27 +530,6 @@ class WideDeepEngine:
         call("wd_fold_affine_all", ptr(self.P), ptr(self.layers_dev), self.n_layers, self.max_layer_n, self.inv,
              None if self.chain else ptr(self.loss), 1, ptr(self.G) if zero_g else None, self.G.numel() if zero_g else 0, st)
 
-    def _tail_fusable(self):
-        """The dense tail can ride in the weight-gradient launch: one GPU (nothing reduces the gradients in between), Adagrad,
-        the tail of every step also re-packs (fold at end).  WD_FUSE_TAIL=0: the two launches of round 2."""
-        return (self.chain and self.all_simple and self.default_opts and not self.crelu and self._fold_at_end()
-                and type(self)._reduce_dense_grads is WideDeepEngine._reduce_dense_grads
-                and type(self)._dense_backward is WideDeepEngine._dense_backward
-                and os.environ.get("WD_FUSE_ADAGRAD", "1") != "0" and self.fuse_tail)
-
-    def _chain_tail(self, mode, st):
-        """wd_chain_tail: gradients from the split-K partials / Adagrad / packed kernel copies, any combination."""
-        tw = self.towers[0]
-        call("wd_chain_tail", tw["tail_layers"], tw["L"] + 1, ptr(self.P), ptr(self.Pacc), ptr(self.G), self.inv,
-             float(self.spec.dnn_opt[1]), mode, st)
-
-    def _fold_at_end(self):
-        """The fold of step t+1 depends on nothing but the dense update of step t: launched right behind it, it runs beside
-        the sparse update instead of at the head of the next step (profiles/r2d_timeline_before_pipelining.txt: 9 us + a kernel boundary)."""
-        return (self.chain and type(self)._reduce_dense_grads is WideDeepEngine._reduce_dense_grads
-                and type(self).backward_and_update is WideDeepEngine.backward_and_update
-                and os.environ.get("WD_FOLD_AT_END", "1") == "1")
-
     def _chain_input_ok(self, bt):
         """The one-launch tower can build its x tile itself (input layer fused, wd_chain_opts_t.input): one id per bag,
         one embedding group, no indicator columns -- the Criteo shape.  WD_CHAIN_INPUT=0 keeps wd_input_layer_fwd."""
@@ -607,7 +578,6 @@ class WideDeepEngine:
             opts.input = ctypes.addressof(ci)
         if pf and self.spec.has_wide:
             opts.wide_vals, opts.wide_bias, opts.wide_out, opts.wide_S = ptr(self.wv[p]), ptr(self.bias), ptr(self.wide_logit), self.plan.S
-        self._chain_scatter(opts, bt, fuse_in and train)
         if train:
             opts.loss_part = ptr(self.loss_part)
         opts.stamps = self._chain_stamps
@@ -622,9 +592,6 @@ class WideDeepEngine:
              ptr(tw["Gpart"][L]) if train else None,
              tw["dact"].data_ptr() + 4 * tl.in_start[0] if need_dx else None, tl.ld, tw["dx_cols"] if need_dx else 0,
              ctypes.byref(opts), st)
-
-    def _chain_scatter(self, opts, bt, on):
-        """Hook (dist.py): let the tower kernel write dx / dlogit straight into the records of the gradient exchange."""
 
     def dropout_masks(self, B):
         """Host copy of the keep masks the NEXT train step will use: [tower][layer] -> float32 [B, N] of 0 / 1 (the
@@ -873,29 +840,6 @@ class WideDeepEngine:
                     spec_jobs.append(dict(A=tw[nm + "_part"][l].data_ptr(), lda=m["N"], B=None, C=tw[nm + "_sum"][l].data_ptr(),
                                           N=m["N"], K=nblk))
             spec_jobs.append(dict(A=self.loss_part.data_ptr(), lda=1, B=None, C=self.loss.data_ptr(), N=1, K=nblk))
-            self._tail_fused = False
-            if self._tail_fusable() and len(spec_jobs) + 1 <= capi.WD_TN_FUSED_MAX_JOBS and L + 1 <= capi.WD_TN_FUSED_MAX_LAYERS:
-                # one launch: every job finishes its own share of the dense tail (wd_gemm_tn_group_tail) -- the last workgroup
-                # of a product's output tile sums, updates and re-packs it; the column-sum jobs update their vectors; the
-                # logits layer (partials from the tower) rides along as extra workgroups
-                kinds = [(capi.WD_FUSE_KERNEL, l) for l in range(L)]
-                for l in range(L):
-                    kinds += [(capi.WD_FUSE_BIAS, l)] + ([(capi.WD_FUSE_GAMMA, l), (capi.WD_FUSE_BETA, l)] if "gamma_off" in metas[l] else [])
-                kinds += [(capi.WD_FUSE_NONE, 0), (capi.WD_FUSE_WHOLE, L)]
-                njobs = len(spec_jobs) + 1
-                jobs, fuse = (capi.WdTnJob * njobs)(), (capi.WdTnFuse * njobs)()
-                for j, d in zip(jobs, spec_jobs):
-                    j.A, j.lda, j.B, j.Cpart, j.N, j.K = d["A"], d["lda"], d["B"], d["C"], d["N"], d["K"]
-                    if d["B"] is not None:
-                        j.ldb, j.M, j.nsplit, j.append_ones = d["ldb"], d["M"], d["nsplit"], 0
-                for f, (kind, layer) in zip(fuse, kinds):
-                    f.kind, f.layer = kind, layer
-                if self._tile_counters is None:
-                    self._tile_counters = torch.zeros(1024, dtype=torch.int32, device=self.device)
-                call("wd_gemm_tn_group_tail", jobs, fuse, njobs, tw["tail_layers"], L + 1, ptr(self.P), ptr(self.Pacc), ptr(self.G),
-                     self.inv, float(self.spec.dnn_opt[1]), ptr(self._tile_counters), self._tile_counters.numel(), st)
-                self._tail_fused = True
-                return
             for i0 in range(0, len(spec_jobs), capi.WD_TN_GROUP_MAX):
                 chunk = spec_jobs[i0: i0 + capi.WD_TN_GROUP_MAX]
                 jobs = (capi.WdTnJob * len(chunk))()
@@ -1173,9 +1117,7 @@ class WideDeepEngine:
                 # single GPU + Adagrad: the dense update rides in the finalize launch (nothing reduces G in between)
                 fused_opt = (self.default_opts and type(self)._reduce_dense_grads is WideDeepEngine._reduce_dense_grads
                              and not self.crelu and os.environ.get("WD_FUSE_ADAGRAD", "1") != "0")
-                if self.chain and fused_opt and self._tail_fused:
-                    self._folded = True     # the products launch has already finished the tail (wd_gemm_tn_group_tail)
-                elif self.chain and fused_opt:
+                if self.chain and fused_opt:
                     # gradients from the partials + Adagrad + the packed kernels of the next step, one launch
                     self._chain_tail(capi.WD_TAIL_GRAD | capi.WD_TAIL_UPDATE | capi.WD_TAIL_PACK, st)
                     self._folded = True

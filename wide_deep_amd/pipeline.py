@@ -196,11 +196,9 @@ class StepGraph:
         rows it rewrites into that buffer again (wd_apply_next_t), so tower(t+1), which reads x from HBM, sees exactly the
         tables after update(t).  No event sits between update(t-1) and tower(t) except the join itself; three scratch sets /
         activation buffers keep every writer behind the last reader.
-        WD_SORT_BRANCH=1 (experiment, off): bucket + sort on the hash branch, released by the end of tail(t-1) (WD_SORT_GATE=tower:
-        of tower(t-1)), so that with skewed ids the 80 us of sort do not sit in front of the gather.  ROCm 7.2's graph executor
-        does not keep a captured stream on a hardware queue of its own, though: depending on capture order and gate it ran the
-        third branch on the main queue (between tail and tower), on the update's queue, or in front of the gather again -- 0.166-0.227
-        against 0.158-0.160 ms per step.  Every step's results are bit-identical to the eager launches
+        (A third graph branch for bucket + sort -- for skewed ids, whose sort is the long pole of the sparse branch -- was tried in
+        round 3 and removed in round 4: ROCm 7.2's graph executor does not keep a captured stream on a hardware queue of its own,
+        profiles/README.md.)  Every step's results are bit-identical to the eager launches
         (gather -> tower -> ...) in every layout, tests/test_gpu_prefetch.py."""
         eng = self.eng
         main = torch.cuda.current_stream()
@@ -225,7 +223,6 @@ class StepGraph:
         # ---- ids branch: tokens -> ids of every batch, back to back at the head of the graph; then, batch by batch,
         # ids -> sorted (row, bag) pairs + the shared-row list of the batch before (sort_work below)
         ev_ids, ev_sort, ev_tail, ev_twr = {}, {}, {}, {}
-        sort_branch = os.environ.get("WD_SORT_BRANCH", "0") == "1"
         if not ids_input:
             with torch.cuda.stream(s_h):
                 for t in range(first, len(seq)):
@@ -239,15 +236,11 @@ class StepGraph:
             the head rows' buckets takes 80 us: in stream order in front of the gather it delayed update(t-1) by 30)."""
             bt = seq[t].batch
             eng._check_batch(bt)
-            s_b = s_h if sort_branch else s_sp
-            gate = ev_twr if os.environ.get("WD_SORT_GATE", "tail") == "tower" else ev_tail
-            if sort_branch and t - 2 in gate:
-                s_h.wait_event(gate[t - 2])
-            if not sort_branch and t in ev_ids:
+            if t in ev_ids:
                 s_sp.wait_event(ev_ids[t])
-            with torch.cuda.stream(s_b):
-                eng._sparse_bucketize(bt, s_b.cuda_stream, sset(t), prev=sset(t - 1) if t >= 1 else None)
-                ev_sort[t] = event(s_b)
+            with torch.cuda.stream(s_sp):
+                eng._sparse_bucketize(bt, s_sp.cuda_stream, sset(t), prev=sset(t - 1) if t >= 1 else None)
+                ev_sort[t] = event(s_sp)
 
         def gather_work(t):
             """prefetch(t) -> activation buffer t % 3 + wide weight list, on the sparse branch behind update(t-2) (stream order):
@@ -268,26 +261,17 @@ class StepGraph:
             bt = tb.batch
             if ev_upd is not None:
                 main.wait_event(ev_upd)                 # update(t-1), with its patch of this step's x
-            if t + 1 < len(seq) and not sort_branch:
+            if t + 1 < len(seq):
                 sort_work(t + 1)
                 gather_work(t + 1)
             eng._apar, eng._prefetched = sact(t), True
             eng.forward(bt, need_loss=True)             # the tower launch: x from HBM, wide logit from the weight list
             ev_tower = ev_twr[t] = event(main)
-            if t + 1 < len(seq) and sort_branch:
-                # (captured BEHIND the tower: the graph runtime keeps the first-captured successor of tail(t-1) on the main
-                # branch's hardware queue -- captured in front of the tower, bucket + sort ran between tail and tower)
-                sort_work(t + 1)                        # ids branch, released by tail(t-1): beside tower(t)
-                gather_work(t + 1)                      # sparse branch, behind update(t-1): beside tower(t)
             hold = {}
 
             def update_then_join(t=t, bt=bt, ev_tower=ev_tower, hold=hold):
                 s_sp.wait_event(ev_tower)
                 nxt = (sset(t + 1), sact(t + 1)) if t + 1 < len(seq) else None
-                if sort_branch and t in ev_sort:
-                    s_sp.wait_event(ev_sort[t])         # (a primed graph's step 0: sorted by the previous graph)
-                if sort_branch and nxt is not None:
-                    s_sp.wait_event(ev_sort[t + 1])     # the shared-row list of this batch
                 with torch.cuda.stream(s_sp):
                     eng._sparse_backward(bt, s_sp.cuda_stream, bucketized=True, pset=sset(t), patch=nxt)
                     hold["upd"] = event(s_sp)

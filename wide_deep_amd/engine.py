@@ -530,6 +530,19 @@ class WideDeepEngine:
         call("wd_fold_affine_all", ptr(self.P), ptr(self.layers_dev), self.n_layers, self.max_layer_n, self.inv,
              None if self.chain else ptr(self.loss), 1, ptr(self.G) if zero_g else None, self.G.numel() if zero_g else 0, st)
 
+    def _chain_tail(self, mode, st):
+        """wd_chain_tail: gradients from the split-K partials / Adagrad / packed kernel copies, any combination."""
+        tw = self.towers[0]
+        call("wd_chain_tail", tw["tail_layers"], tw["L"] + 1, ptr(self.P), ptr(self.Pacc), ptr(self.G), self.inv,
+             float(self.spec.dnn_opt[1]), mode, st)
+
+    def _fold_at_end(self):
+        """The fold of step t+1 depends on nothing but the dense update of step t: launched right behind it, it runs beside
+        the sparse update instead of at the head of the next step (profiles/r2d_timeline_before_pipelining.txt: 9 us + a kernel boundary)."""
+        return (self.chain and type(self)._reduce_dense_grads is WideDeepEngine._reduce_dense_grads
+                and type(self).backward_and_update is WideDeepEngine.backward_and_update
+                and os.environ.get("WD_FOLD_AT_END", "1") == "1")
+
     def _chain_input_ok(self, bt):
         """The one-launch tower can build its x tile itself (input layer fused, wd_chain_opts_t.input): one id per bag,
         one embedding group, no indicator columns -- the Criteo shape.  WD_CHAIN_INPUT=0 keeps wd_input_layer_fwd."""

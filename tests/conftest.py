@@ -20,3 +20,17 @@ def pytest_collection_modifyitems(config, items):
     for it in items:
         if "gpu" in it.keywords:
             it.add_marker(skip)
+
+
+@pytest.fixture(autouse=True)
+def _release_gpu_objects(request):
+    """GPU tests build engines (GBs of tables) and hipGraphs whose Python owners sit in reference cycles (closures of the
+    capture): collect them when the test ends instead of whenever the cycle collector gets to it -- graph executables and their
+    kernel-argument pools otherwise pile up across the ~170 tests of one process."""
+    yield
+    if "gpu" in request.keywords:
+        import gc
+        import torch
+        gc.collect()
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()

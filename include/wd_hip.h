@@ -366,7 +366,8 @@ int wd_sparse_bwd_fused(float *emb, float *emb_accum, float *wide, float *bias_w
  *   Adagrad  b = accumulator                b += g^2; var -= lr g / sqrt(b)
  *   Ftrl     a = linear, b = accumulator    (as wd_wide_bwd_ftrl; p0 = l1, p1 = l2; p2 = learning_rate_power <= 0: the TF default
  *            -0.5 takes sqrt(accumulator), anything else accumulator^(-p2), FtrlCompute's general branch -- set it
- *            explicitly, a zeroed struct means a FIXED learning rate)
+ *            explicitly, a zeroed struct means a FIXED learning rate; p3 = l2_shrinkage_regularization_strength: the linear
+ *            slot moves by g + 2 p3 var, the accumulator by the plain g^2 -- TF's FtrlCompute with shrinkage)
  *   RMSProp  a = rms (init 1), b = momentum a += (g^2 - a)(1 - p0); b = p1 b + lr g / sqrt(a + p2); var -= b
  *            (p0 = decay, p1 = momentum, p2 = epsilon; centered = False)
  *   RMSProp centered (WD_OPT_RMSPROP_CENTERED, TF ApplyCenteredRMSProp / SparseApplyCenteredRMSProp): third slot
@@ -390,7 +391,7 @@ typedef struct wd_opt {
   int32_t kind;
   float lr;
   float p0, p1, p2;
-  int32_t pad_;
+  float p3;                 /* Ftrl: l2_shrinkage_regularization_strength (0: none) */
   const float *pow;
   float *slot_c;            /* centered RMSProp: mean-gradient slot of the variable this call updates; else NULL */
 } wd_opt_t;

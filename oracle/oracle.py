@@ -277,11 +277,24 @@ def slot_names(opt):
     return SLOT_NAMES[opt[0]] + (None,)
 
 
-def _ftrl_general(w, z, n, g, lr, l1, l2, lr_power):
-    """FtrlCompute with lr_power != -0.5 on torch tensors (elementwise, fp32)."""
+def _ftrl_shrink(opt):
+    return float(opt[6]) if (opt[0] == "Ftrl" and len(opt) > 6) else 0.0
+
+
+def _ftrl_is_general(opt):
+    """an Ftrl tuple that leaves the default kernel: learning_rate_power != -0.5 or l2_shrinkage != 0"""
+    return opt[0] == "Ftrl" and ((len(opt) > 5 and opt[5] != -0.5) or _ftrl_shrink(opt) != 0.0)
+
+
+def _ftrl_general(w, z, n, g, lr, l1, l2, lr_power, l2_shrink=0.0):
+    """FtrlCompute (TF training_ops.cc) with lr_power != -0.5 and / or l2_shrinkage on torch tensors (elementwise, fp32): the
+    linear slot takes g + 2 l2_shrinkage var, the accumulator the plain g^2 (pinned by ftrl_test.testFtrlWithL1_L2_L2Shrinkage)."""
     n_new = n + g * g
-    pn = torch.pow(n_new, -lr_power)
-    z_new = z + g - (pn - torch.pow(n, -lr_power)) / lr * w
+    if lr_power == -0.5:
+        pn, po = torch.sqrt(n_new), torch.sqrt(n)
+    else:
+        pn, po = torch.pow(n_new, -lr_power), torch.pow(n, -lr_power)
+    z_new = z + (g + 2.0 * l2_shrink * w) - (pn - po) / lr * w
     quad = pn / lr + 2.0 * l2
     w_new = torch.where(z_new.abs() > l1, (torch.sign(z_new) * l1 - z_new) / quad, torch.zeros_like(w))
     return w_new, z_new, n_new
@@ -295,8 +308,9 @@ def opt_apply_dense(opt, state, nm, g, pow_):
         w -= opt[1] * g
     elif kind == "Adagrad":
         adagrad_dense(w, state[nm + sb], g, opt[1])
-    elif kind == "Ftrl" and len(opt) > 5 and opt[5] != -0.5:
-        wn, zn, nn = _ftrl_general(w, state[nm + sa], state[nm + sb], g.reshape(w.shape), opt[1], opt[2], opt[3], opt[5])
+    elif _ftrl_is_general(opt):
+        wn, zn, nn = _ftrl_general(w, state[nm + sa], state[nm + sb], g.reshape(w.shape), opt[1], opt[2], opt[3], opt[5],
+                                   _ftrl_shrink(opt))
         w.copy_(wn); state[nm + sa].copy_(zn); state[nm + sb].copy_(nn)
     elif kind == "Ftrl":
         ftrl_dense(w, state[nm + sa], state[nm + sb], g, opt[1], opt[2], opt[3])
@@ -336,9 +350,9 @@ def opt_apply_rows(opt, state, nm, uniq, rg, pow_):
         w2[idx] -= opt[1] * rg
     elif kind == "Adagrad":
         adagrad_rows(w2, state[nm + sb].reshape(w2.shape), uniq, rg, opt[1])
-    elif kind == "Ftrl" and len(opt) > 5 and opt[5] != -0.5:
+    elif _ftrl_is_general(opt):
         z_t, n_t = state[nm + sa].reshape(w2.shape), state[nm + sb].reshape(w2.shape)
-        wn, zn, nn = _ftrl_general(w2[idx], z_t[idx], n_t[idx], rg, opt[1], opt[2], opt[3], opt[5])
+        wn, zn, nn = _ftrl_general(w2[idx], z_t[idx], n_t[idx], rg, opt[1], opt[2], opt[3], opt[5], _ftrl_shrink(opt))
         w2[idx] = wn
         z_t[idx] = zn
         n_t[idx] = nn

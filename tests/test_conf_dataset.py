@@ -257,8 +257,11 @@ def test_every_reference_optimizer_name_and_constructor_parses():
     assert opt_tuple(*parse_optimizer("tf.train.FtrlOptimizer(0.1, learning_rate_power=-0.5)", 0.05)) == ("Ftrl", 0.1, 0.0, 0.0, 0.1)
     with pytest.raises(ValueError, match="needs to be negative or zero"):       # tf.train.FtrlOptimizer.__init__
         opt_tuple(*parse_optimizer("tf.train.FtrlOptimizer(0.1, learning_rate_power=0.5)", 0.05))
-    with pytest.raises(NotImplementedError):
-        opt_tuple(*parse_optimizer("tf.train.FtrlOptimizer(0.1, l2_shrinkage_regularization_strength=0.1)", 0.05))
+    # l2_shrinkage_regularization_strength (round 4; the reference's eval'd constructor accepts it, model_util.py:97-101)
+    assert opt_tuple(*parse_optimizer("tf.train.FtrlOptimizer(0.1, l2_shrinkage_regularization_strength=0.1)", 0.05)) == (
+        "Ftrl", 0.1, 0.0, 0.0, 0.1, -0.5, 0.1)
+    with pytest.raises(ValueError, match="needs to be positive or zero"):       # tf.train.FtrlOptimizer.__init__
+        opt_tuple(*parse_optimizer("tf.train.FtrlOptimizer(0.1, l2_shrinkage_regularization_strength=-0.1)", 0.05))
 
 
 def test_prefetch_keeps_order_content_errors_and_stops_early():

@@ -16,6 +16,8 @@ RMSPROP_MOM = ("RMSProp", 0.01, 0.8, 0.5, 1e-6)
 ADAM = ("Adam", 0.01, 0.9, 0.999, 1e-8)
 FTRL_POW = ("Ftrl", 0.1, 0.5, 1.0, 0.1, -0.7)                  # learning_rate_power != -0.5: FtrlCompute's general branch
 FTRL_POW_DNN = ("Ftrl", 0.05, 0.001, 0.01, 0.1, -0.3)
+FTRL_SHRINK = ("Ftrl", 0.1, 0.5, 1.0, 0.1, -0.5, 0.05)         # l2_shrinkage_regularization_strength (round 4)
+FTRL_SHRINK_POW_DNN = ("Ftrl", 0.05, 0.001, 0.01, 0.1, -0.3, 0.02)
 RMSPROP_CENTERED = ("RMSProp", 0.01, 0.9, 0.0, 1e-6, True)     # ApplyCenteredRMSProp: third slot (mean gradient)
 RMSPROP_CENTERED_MOM = ("RMSProp", 0.01, 0.8, 0.5, 1e-6, True)
 
@@ -31,7 +33,8 @@ def _spec(dnn, lin, **kw):
 
 @pytest.mark.parametrize("dnn,lin", [(SGD, SGD), (RMSPROP, ADAGRAD), (ADAM, ADAM), (FTRL_DNN, RMSPROP_MOM), (ADAGRAD, ADAM),
                                      (RMSPROP_MOM, FTRL), (ADAM, FTRL), (ADAGRAD, FTRL_POW), (RMSPROP_CENTERED, FTRL_POW),
-                                     (FTRL_POW_DNN, RMSPROP_CENTERED_MOM), (RMSPROP_CENTERED_MOM, RMSPROP_CENTERED)])
+                                     (FTRL_POW_DNN, RMSPROP_CENTERED_MOM), (RMSPROP_CENTERED_MOM, RMSPROP_CENTERED),
+                                     (ADAGRAD, FTRL_SHRINK), (FTRL_SHRINK_POW_DNN, FTRL_SHRINK)])
 def test_train_steps_match_oracle(dnn, lin):
     from tests.test_gpu_step import _run
     eng, ora = _run(_spec(dnn, lin), B=96, steps=4)
@@ -133,7 +136,7 @@ def test_centered_rmsprop_slot_names_and_ftrl_power_zero_is_sgd():
     w2 = torch.zeros(n, device="cuda")
     of, os_ = capi.WdOpt(), capi.WdOpt()
     of.kind, of.lr = capi.WD_OPT_KINDS["Ftrl"], 3.0
-    of.p0, of.p1, of.p2 = opt_params(("Ftrl", 3.0, 0.0, 0.0, 0.1, 0.0))
+    of.p0, of.p1, of.p2, of.p3 = opt_params(("Ftrl", 3.0, 0.0, 0.0, 0.1, 0.0))
     os_.kind, os_.lr = capi.WD_OPT_KINDS["SGD"], 3.0
     for _ in range(3):
         gr = torch.randn(n, device="cuda", generator=g) * 0.1

@@ -19,7 +19,7 @@ def _opt_dense(opt, var, grad, steps, each_step=None):
     import ctypes
     o = capi.WdOpt()
     o.kind, o.lr = capi.WD_OPT_KINDS[opt[0]], float(opt[1])
-    o.p0, o.p1, o.p2 = opt_params(opt)
+    o.p0, o.p1, o.p2, o.p3 = opt_params(opt)
     ia, ib = opt_slot_init(opt)
     w = torch.tensor(var, dtype=torch.float32, device="cuda")
     a = torch.full_like(w, 0.0 if ia is None else ia)
@@ -44,7 +44,8 @@ def test_dense_adagrad_and_ftrl_kernels_match_tf_optimizer_tests():
         np.testing.assert_allclose(_opt_dense(("Adagrad", a["lr"], a["init"]), c["var"], c["grad"], a["steps"]), c["expect"], rtol=3e-6)
     for f in G["ftrl"]:
         for c in f["cases"]:
-            got = _opt_dense(("Ftrl", f["lr"], f["l1"], f["l2"], f["init"]), c["var"], c["grad"], f["steps"])
+            opt = ("Ftrl", f["lr"], f["l1"], f["l2"], f["init"]) + ((-0.5, f["l2_shrinkage"]) if "l2_shrinkage" in f else ())
+            got = _opt_dense(opt, c["var"], c["grad"], f["steps"])
             np.testing.assert_allclose(got, c["expect"], rtol=3e-6)
 
 

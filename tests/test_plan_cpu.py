@@ -76,11 +76,12 @@ def test_optimizer_slot_tables_are_consistent():
         a, b = opt_slot_init(o)
         sa, sb = OPT_SLOT_NAMES[o[0]]
         assert (a is None) == (sa is None) and (b is None) == (sb is None)
-        assert len(opt_params(o)) == 3
+        assert len(opt_params(o)) == 4
     assert opt_slot_init(opts[1]) == (None, 0.1) and opt_slot_init(opts[2]) == (0.0, 0.2)
     assert opt_slot_init(opts[3]) == (1.0, 0.0)                       # rms slot starts at ones
-    assert opt_params(opts[2]) == (0.5, 1.0, -0.5) and opt_params(opts[4]) == (0.9, 0.999, 1e-8)
-    assert opt_params(("Ftrl", 0.1, 0.5, 1.0, 0.2, -0.7)) == (0.5, 1.0, -0.7)          # p2 = learning_rate_power
+    assert opt_params(opts[2]) == (0.5, 1.0, -0.5, 0.0) and opt_params(opts[4]) == (0.9, 0.999, 1e-8, 0.0)
+    assert opt_params(("Ftrl", 0.1, 0.5, 1.0, 0.2, -0.7)) == (0.5, 1.0, -0.7, 0.0)     # p2 = learning_rate_power
+    assert opt_params(("Ftrl", 0.1, 0.5, 1.0, 0.2, -0.5, 0.25)) == (0.5, 1.0, -0.5, 0.25)   # p3 = l2_shrinkage_regularization_strength
     # RMSPropOptimizer._create_slots: rms, [mg,] momentum -> /RMSProp, [/RMSProp_1,] /RMSProp_1 or _2
     assert opt_slot_names(opts[3]) == ("/RMSProp", "/RMSProp_1", None)
     assert opt_slot_names(opts[3] + (True,)) == ("/RMSProp", "/RMSProp_2", "/RMSProp_1")

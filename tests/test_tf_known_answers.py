@@ -37,7 +37,8 @@ def test_adagrad_and_ftrl_formulas_match_tf_optimizer_tests():
             np.testing.assert_allclose(got, c["expect"], rtol=2e-6)
         for f in G["ftrl"]:
             for c in f["cases"]:
-                got = _run(("Ftrl", f["lr"], f["l1"], f["l2"], f["init"]), c["var"], c["grad"], f["steps"], rows)
+                opt = ("Ftrl", f["lr"], f["l1"], f["l2"], f["init"]) + ((-0.5, f["l2_shrinkage"]) if "l2_shrinkage" in f else ())
+                got = _run(opt, c["var"], c["grad"], f["steps"], rows)
                 np.testing.assert_allclose(got, c["expect"], rtol=2e-6)
 
 

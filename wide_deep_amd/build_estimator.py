@@ -75,7 +75,8 @@ def opt_tuple(name, kw):
     """(name, kwargs) -> the optimizer tuple of plan.ModelSpec / the oracle, with the tf.train constructor defaults:
        ("SGD", lr) ("Adagrad", lr, initial_accumulator_value) ("Ftrl", lr, l1, l2, initial_accumulator_value)
        ("RMSProp", lr, decay, momentum, epsilon) ("Adam", lr, beta1, beta2, epsilon)
-    Non-default variants append one element: ("Ftrl", ..., learning_rate_power) when it is not -0.5,
+    Non-default variants append elements: ("Ftrl", ..., learning_rate_power) when it is not -0.5, ("Ftrl", ..., learning_rate_power,
+    l2_shrinkage_regularization_strength) when the shrinkage is not 0,
     ("RMSProp", ..., True) for centered=True."""
     lr = float(kw["learning_rate"])
     if name == "SGD":
@@ -83,13 +84,16 @@ def opt_tuple(name, kw):
     if name == "Adagrad":
         return ("Adagrad", lr, float(kw.get("initial_accumulator_value", 0.1)))
     if name == "Ftrl":
-        if float(kw.get("l2_shrinkage_regularization_strength", 0.0)) != 0.0:
-            raise NotImplementedError("FtrlOptimizer: l2_shrinkage_regularization_strength is not implemented")
+        shrink = float(kw.get("l2_shrinkage_regularization_strength", 0.0))
+        if shrink < 0.0:        # tf.train.FtrlOptimizer.__init__
+            raise ValueError("l2_shrinkage_regularization_strength %f needs to be positive or zero" % shrink)
         lr_power = float(kw.get("learning_rate_power", -0.5))
         if lr_power > 0.0:      # tf.train.FtrlOptimizer.__init__
             raise ValueError("learning_rate_power %f needs to be negative or zero" % lr_power)
         base = ("Ftrl", lr, float(kw.get("l1_regularization_strength", 0.0)),
                 float(kw.get("l2_regularization_strength", 0.0)), float(kw.get("initial_accumulator_value", 0.1)))
+        if shrink != 0.0:
+            return base + (lr_power, shrink)
         return base if lr_power == -0.5 else base + (lr_power,)
     if name == "RMSProp":
         base = ("RMSProp", lr, float(kw.get("decay", 0.9)), float(kw.get("momentum", 0.0)), float(kw.get("epsilon", 1e-10)))

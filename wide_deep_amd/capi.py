@@ -62,7 +62,7 @@ WD_OPT_RMSPROP_CENTERED = 6
 
 class WdOpt(ctypes.Structure):
     _fields_ = [("kind", ctypes.c_int32), ("lr", ctypes.c_float), ("p0", ctypes.c_float), ("p1", ctypes.c_float),
-                ("p2", ctypes.c_float), ("pad_", ctypes.c_int32), ("pow", ctypes.c_void_p), ("slot_c", ctypes.c_void_p)]
+                ("p2", ctypes.c_float), ("p3", ctypes.c_float), ("pow", ctypes.c_void_p), ("slot_c", ctypes.c_void_p)]
 
 
 class WdChainInput(ctypes.Structure):

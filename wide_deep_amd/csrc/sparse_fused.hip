@@ -248,7 +248,7 @@ __device__ __forceinline__ float4 adagrad4(float4 &a, float4 w, float4 g, float 
 // RMSProp a = rms, b = momentum (centered: c = mean gradient); Adam a = m, b = v.
 struct OptK {
   int32_t kind;
-  float lr, p0, p1, p2;
+  float lr, p0, p1, p2, p3;
   float b1p, b2p;   // Adam: beta1^t, beta2^t of this step
 };
 
@@ -256,11 +256,15 @@ __device__ __forceinline__ void ftrl_update(float &w, float &z, float &n, float 
 
 // FtrlOptimizer with learning_rate_power != -0.5 (TF training_ops.cc FtrlCompute, general branch): accum^(-lr_power) in
 // place of sqrt(accum)
+// l2_shrink != 0 (FtrlOptimizer(l2_shrinkage_regularization_strength=...)): the LINEAR slot accumulates the gradient of the
+// shrinkage-penalised loss, g + 2 l2_shrink var, the ACCUMULATOR the plain g^2 (TF training_ops.cc FtrlCompute; the constants of
+// ftrl_test.testFtrlWithL1_L2_L2Shrinkage pin exactly this form: tests/golden/kat_tf_fp32.json)
 __device__ __forceinline__ void ftrl_update_pow(float &w, float &z, float &n, float g, float lr, float l1, float l2,
-                                                float lr_power) {
+                                                float lr_power, float l2_shrink) {
   const float n_new = n + g * g;
-  const float pn = powf(n_new, -lr_power);
-  z += g - (pn - powf(n, -lr_power)) / lr * w;
+  const float pn = lr_power == -0.5f ? sqrtf(n_new) : powf(n_new, -lr_power);
+  const float po = lr_power == -0.5f ? sqrtf(n) : powf(n, -lr_power);
+  z += (g + 2.0f * l2_shrink * w) - (pn - po) / lr * w;
   const float quad = pn / lr + 2.0f * l2;
   const float sgn = z > 0.f ? 1.f : (z < 0.f ? -1.f : 0.f);
   const float pre = (sgn * l1 - z) / quad;
@@ -278,8 +282,8 @@ __device__ __forceinline__ void opt_step(const OptK &o, float &w, float &a, floa
       w -= o.lr * g / sqrtf(b);
       break;
     case WD_OPT_FTRL:      // p2 = learning_rate_power (TF default -0.5; 0 = fixed learning rate)
-      if (o.p2 == -0.5f) ftrl_update(w, a, b, g, o.lr, o.p0, o.p1);
-      else ftrl_update_pow(w, a, b, g, o.lr, o.p0, o.p1, o.p2);
+      if (o.p2 == -0.5f && o.p3 == 0.0f) ftrl_update(w, a, b, g, o.lr, o.p0, o.p1);
+      else ftrl_update_pow(w, a, b, g, o.lr, o.p0, o.p1, o.p2, o.p3);
       break;
     case WD_OPT_RMSPROP_CENTERED:   // ApplyCenteredRMSProp: + mg += (g - mg)(1 - decay); denominator sqrt(ms - mg^2 + eps)
       a += (g * g - a) * (1.0f - o.p0);
@@ -884,7 +888,7 @@ extern "C" int wd_sparse_apply_rec(float *rec, int32_t rec_stride, int32_t dim, 
 static OptK to_optk(const wd_opt_t *o) {
   OptK k{};
   if (o) {
-    k.kind = o->kind; k.lr = o->lr; k.p0 = o->p0; k.p1 = o->p1; k.p2 = o->p2;
+    k.kind = o->kind; k.lr = o->lr; k.p0 = o->p0; k.p1 = o->p1; k.p2 = o->p2; k.p3 = o->p3;
     k.b1p = o->p0; k.b2p = o->p1;   // Adam without a power buffer: first step
   }
   return k;

@@ -18,7 +18,7 @@ import torch
 
 from . import capi
 from .capi import call, ptr
-from .plan import (BN_EPS, FeaturePlan, ModelSpec, OPT_SLOT_ODD, adam_pow_names, bucket_geometry, ftrl_lr_power, opt_params,
+from .plan import (BN_EPS, FeaturePlan, ModelSpec, OPT_SLOT_ODD, adam_pow_names, bucket_geometry, ftrl_l2_shrinkage, ftrl_lr_power, opt_params,
                    opt_slot_init, opt_slot_names, rmsprop_centered)
 
 
@@ -60,7 +60,8 @@ class WideDeepEngine:
         # the reference's defaults (conf/model.yaml: Adagrad on the dnn scope, Ftrl on the linear scope) take the
         # specialised kernels; any other tf.train optimizer of model_util.py:84-90 the generic ones (wd_opt_t)
         self.default_opts = ((not spec.has_deep or spec.dnn_opt[0] == "Adagrad") and
-                             (not spec.has_wide or (spec.lin_opt[0] == "Ftrl" and ftrl_lr_power(spec.lin_opt) == -0.5)))
+                             (not spec.has_wide or (spec.lin_opt[0] == "Ftrl" and ftrl_lr_power(spec.lin_opt) == -0.5
+                                                    and ftrl_l2_shrinkage(spec.lin_opt) == 0.0)))
         if tower_dtype not in ("fp32", "fp16"):
             raise ValueError("tower_dtype must be 'fp32' (exact fp32 MFMA) or 'fp16' (half operands, fp32 accumulate)")
         self.half = tower_dtype == "fp16"     # BASELINE configs[4]: fp16 MFMA dense path, fp32 embeddings
@@ -192,7 +193,7 @@ class WideDeepEngine:
                 o.kind = capi.WD_OPT_RMSPROP_CENTERED
                 if scope == "dnn":
                     o.slot_c = self.emb_c.data_ptr()
-            o.p0, o.p1, o.p2 = opt_params(opt)
+            o.p0, o.p1, o.p2, o.p3 = opt_params(opt)
             if opt[0] == "Adam":
                 self.pow[scope] = torch.tensor([opt[2], opt[3]], **f32)
                 o.pow = self.pow[scope].data_ptr()

@@ -398,8 +398,13 @@ OPT_SLOT_NAMES = {"SGD": (None, None), "Adagrad": (None, "/Adagrad"), "Ftrl": ("
 
 
 def ftrl_lr_power(opt):
-    """learning_rate_power of an Ftrl tuple ("Ftrl", lr, l1, l2, init[, lr_power]); TF default -0.5."""
+    """learning_rate_power of an Ftrl tuple ("Ftrl", lr, l1, l2, init[, lr_power[, l2_shrinkage]]); TF default -0.5."""
     return float(opt[5]) if len(opt) > 5 else -0.5
+
+
+def ftrl_l2_shrinkage(opt):
+    """l2_shrinkage_regularization_strength of an Ftrl tuple (TF default 0: the 7th element exists only when it is not)."""
+    return float(opt[6]) if (opt[0] == "Ftrl" and len(opt) > 6) else 0.0
 
 
 def rmsprop_centered(opt):
@@ -440,13 +445,13 @@ def opt_slot_init(opt):
 
 
 def opt_params(opt):
-    """(p0, p1, p2) of wd_opt_t."""
+    """(p0, p1, p2, p3) of wd_opt_t."""
     kind = opt[0]
     if kind == "Ftrl":
-        return float(opt[2]), float(opt[3]), ftrl_lr_power(opt)
+        return float(opt[2]), float(opt[3]), ftrl_lr_power(opt), ftrl_l2_shrinkage(opt)
     if kind in ("RMSProp", "Adam"):
-        return float(opt[2]), float(opt[3]), float(opt[4])
-    return 0.0, 0.0, 0.0
+        return float(opt[2]), float(opt[3]), float(opt[4]), 0.0
+    return 0.0, 0.0, 0.0, 0.0
 
 
 def adam_pow_names(dnn_opt, lin_opt, has_deep, has_wide):

@@ -327,3 +327,32 @@ def test_input_fn_mirrors_the_reference_test_input_fn(tmp_path):
             assert abs(float(b.floats[key][0]) - (0.0 if raw == b"-" else float(raw))) < 1e-6, key
     assert set(b.cat) | set(b.ints) | set(b.floats) == set(c.get_feature_name("used"))   # unused fields are dropped
     assert b.labels.tolist() == [1.0 if line.split(b"\t")[0] == b"1" else 0.0] and not b.labels[0]
+
+
+def test_lr_decay_is_opt_in_and_follows_exponential_decay(tmp_path):
+    """The reference builds tf.train.exponential_decay over a tf.Variable(0) that nothing increments (python/lib/joint.py:145-154):
+    its learning rates never move, and neither do ours by default.  `lr_decay: true` in train.yaml (an extension) decays the
+    scopes whose optimizer is given by NAME over TF's global step: lr_0 * decay_rate ** (global_step / (num_examples / batch_size))."""
+    import shutil
+    import yaml
+    spec = BE.build_model_spec(Config(), "wide_deep")
+    assert spec.lr_decay is None and spec.decayed_lr("dnn", 3000) == 0.05 and spec.decayed_lr("linear", 3000) == 0.1
+    base = tmp_path / "conf"
+    shutil.copytree(conf_dir(), base)
+    tr = yaml.safe_load(open(base / "train.yaml"))
+    tr["train"]["lr_decay"] = True
+    yaml.safe_dump(tr, open(base / "train.yaml", "w"))
+    conf = Config(base_dir=str(base))
+    spec = BE.build_model_spec(conf, "wide_deep")
+    steps = conf.train["num_examples"] / conf.train["batch_size"]
+    # dnn_optimizer: 'Adagrad' (a name: takes the model_fn's rate) decays at dnn_decay_rate 0.8; linear_optimizer is a constructor
+    # string with its own learning rate: untouched
+    assert spec.lr_decay == {"dnn": (0.8, steps)}
+    for gs in (0, 3, 300, 4711):
+        assert abs(spec.decayed_lr("dnn", gs) - 0.05 * 0.8 ** (gs / steps)) < 1e-12
+        assert spec.decayed_lr("linear", gs) == 0.1
+    m = yaml.safe_load(open(base / "model.yaml"))
+    m["linear_optimizer"], m["linear_decay_rate"], m["dnn_decay_rate"] = "Ftrl", 0.5, 1
+    yaml.safe_dump(m, open(base / "model.yaml", "w"))
+    spec = BE.build_model_spec(Config(base_dir=str(base)), "wide_deep")
+    assert spec.lr_decay == {"linear": (0.5, steps)} and spec.lin_opt[0] == "Ftrl"

@@ -162,3 +162,36 @@ def test_checkpoint_round_trip_restores_slots(tmp_path):
     sa, sb = a.export_state(), b.export_state()
     for k in sa:
         assert torch.equal(sa[k], sb[k]), k
+
+
+def test_learning_rates_set_per_step_train_like_the_oracle_with_the_same_rates():
+    """engine.set_learning_rates (what Estimator.train calls before every step under the opt-in `lr_decay`): the launches that
+    follow use the new rates -- default optimizers (specialised kernels) and generic ones (wd_opt_t) -- like an oracle whose
+    optimizer tuples carry the same per-step rates."""
+    from wide_deep_amd import synth
+    from wide_deep_amd.engine import WideDeepEngine
+    from tests.helpers import oracle_batch, oracle_from_engine, assert_close
+    from tests.test_gpu_step import L_RTOL, L_ATOL, P_RTOL, P_ATOL
+    for dnn, lin, kw in ((ADAGRAD, FTRL, {}), (RMSPROP_MOM, FTRL_SHRINK, {}), (ADAGRAD, FTRL, dict(hidden=(64, 32), n_dense=16, n_sparse=3))):
+        spec = _spec(dnn, lin, **kw)
+        spec.lr_decay = {"dnn": (0.5, 4.0), "linear": (0.8, 4.0)}
+        eng = WideDeepEngine(spec, max_batch=128, seed=3)
+        ora = oracle_from_engine(eng)
+        B = 96
+        for step in range(4):
+            gs = eng.global_step
+            ld, ll = dnn[1] * 0.5 ** (gs / 4.0), lin[1] * 0.8 ** (gs / 4.0)
+            eng.set_learning_rates(dnn=ld, linear=ll)
+            ora.dnn_opt = (dnn[0], ld) + tuple(dnn[2:])
+            ora.lin_opt = (lin[0], ll) + tuple(lin[2:])
+            hb = synth.make_raw_batch(eng.plan, B, seed=200 + step, pos_rate=0.3)
+            bt = synth.to_device_ids(eng.plan, hb)
+            loss = eng.train_step(bt)
+            torch.cuda.synchronize()
+            oloss, ologits = ora.train_step(oracle_batch(eng.plan, bt.ids.cpu().numpy(), bt.bag_offs.cpu().numpy(), B, hb["dense"], hb["labels"]))
+            assert_close(eng.logit[:B], ologits, L_RTOL, L_ATOL, "logits step %d" % step)
+        assert eng.global_step == 12 and abs(eng.spec.dnn_opt[1] - dnn[1] * 0.5 ** (9 / 4.0)) < 1e-9
+        st = eng.export_state()
+        for k, v in ora.state.items():
+            if k != "global_step" and "moving_" not in k:
+                assert_close(st[k], v.detach(), P_RTOL, P_ATOL, k)

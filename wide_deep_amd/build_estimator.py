@@ -162,6 +162,16 @@ def build_model_spec(conf=None, model_type=None):
         towers = [TowerSpec([int(h) for h in hidden], _mode_name(mode))]
     dnn_name, dnn_kw = parse_optimizer(model["dnn_optimizer"], model.get("dnn_initial_learning_rate") or 0.05)
     lin_name, lin_kw = parse_optimizer(model["linear_optimizer"], model.get("linear_initial_learning_rate") or 0.05)
+    # learning-rate decay done the way the reference's comment describes it (python/lib/joint.py:65-66, 145-154), behind a flag:
+    # the reference itself never decays (quirk C.2).  Only optimizers given by name take the model_fn's learning rate.
+    lr_decay = None
+    if train.get("lr_decay"):
+        steps = float(train["num_examples"]) / float(train["batch_size"])       # decay_steps is a float (joint.py:78)
+        lr_decay = {}
+        for scope, key, rk in (("dnn", "dnn_optimizer", "dnn_decay_rate"), ("linear", "linear_optimizer", "linear_decay_rate")):
+            rate = model.get(rk) or 1
+            if str(model[key]).strip() in _OPT_NAMES and float(rate) != 1.0:
+                lr_decay[scope] = (float(rate), steps)
     # weight column is switched on when EITHER weight is set (build_estimator.py:43-46) ...
     use_w = train["pos_sample_loss_weight"] is not None or train["neg_sample_loss_weight"] is not None
     return ModelSpec(model_type=model_type, slots=slots, dense_cols=dense, towers=towers,
@@ -169,7 +179,7 @@ def build_model_spec(conf=None, model_type=None):
                      batch_norm=bool(model.get("dnn_batch_normalization")), dropout=model.get("dnn_dropout") or None,
                      dnn_opt=opt_tuple(dnn_name, dnn_kw), lin_opt=opt_tuple(lin_name, lin_kw),
                      use_weight_column=use_w, pos_weight=float(train["pos_sample_loss_weight"] or 1.0),
-                     neg_weight=float(train["neg_sample_loss_weight"] or 1.0))
+                     neg_weight=float(train["neg_sample_loss_weight"] or 1.0), lr_decay=lr_decay or None)
 
 
 def _mode_name(m):

@@ -155,7 +155,8 @@ def local_spec(spec: ModelSpec, world):
     return ModelSpec(model_type=spec.model_type, slots=slots, dense_cols=list(spec.dense_cols),
                      towers=list(spec.towers), activation=spec.activation, batch_norm=spec.batch_norm,
                      dropout=spec.dropout, dnn_opt=spec.dnn_opt, lin_opt=spec.lin_opt,
-                     use_weight_column=spec.use_weight_column, pos_weight=spec.pos_weight, neg_weight=spec.neg_weight)
+                     use_weight_column=spec.use_weight_column, pos_weight=spec.pos_weight, neg_weight=spec.neg_weight,
+                     lr_decay=spec.lr_decay)
 
 
 # ---------------------------------------------------------------------------------------------

@@ -531,6 +531,20 @@ class WideDeepEngine:
         call("wd_fold_affine_all", ptr(self.P), ptr(self.layers_dev), self.n_layers, self.max_layer_n, self.inv,
              None if self.chain else ptr(self.loss), 1, ptr(self.G) if zero_g else None, self.G.numel() if zero_g else 0, st)
 
+    def set_learning_rates(self, dnn=None, linear=None):
+        """Learning rates of the two scopes for the launches that follow (eager steps read them at launch time; a captured
+        graph has them baked in).  Estimator.train calls this before every step when spec.lr_decay is set."""
+        spec = self.spec
+        if dnn is not None and spec.has_deep:
+            spec.dnn_opt = (spec.dnn_opt[0], float(dnn)) + tuple(spec.dnn_opt[2:])
+            for k in ("dnn", "dnn_dense"):
+                if k in self.opt_c:
+                    self.opt_c[k].lr = float(dnn)
+        if linear is not None and spec.has_wide:
+            spec.lin_opt = (spec.lin_opt[0], float(linear)) + tuple(spec.lin_opt[2:])
+            if "linear" in self.opt_c:
+                self.opt_c["linear"].lr = float(linear)
+
     def _chain_tail(self, mode, st):
         """wd_chain_tail: gradients from the split-K partials / Adagrad / packed kernel copies, any combination."""
         tw = self.towers[0]

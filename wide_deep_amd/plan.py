@@ -97,6 +97,22 @@ class ModelSpec:
     use_weight_column: bool = False
     pos_weight: float = 1.0
     neg_weight: float = 1.0
+    # Learning-rate decay, OFF (None) by default -- the reference's exponential_decay runs over a fresh tf.Variable(0) that
+    # nothing increments, so its learning rates never move (python/lib/joint.py:145-154).  Opt-in
+    # (train.yaml `lr_decay: true`, build_estimator.build_model_spec): {"dnn": (decay_rate, decay_steps), "linear": (...)} for
+    # the scopes whose optimizer is given by NAME (those take the model_fn's learning rate; a constructor string keeps its own,
+    # python/lib/utils/model_util.py:84-105):  lr_t = lr_0 * decay_rate ** (global_step / decay_steps)  over TF's global step.
+    lr_decay: Optional[dict] = None
+
+    def decayed_lr(self, scope, global_step):
+        """learning rate of `scope` ("dnn" | "linear") at TF global step `global_step` (tf.train.exponential_decay, staircase=False)"""
+        opt = self.dnn_opt if scope == "dnn" else self.lin_opt
+        lr0 = float(self._lr0[scope]) if getattr(self, "_lr0", None) else float(opt[1])
+        sch = (self.lr_decay or {}).get(scope)
+        if not sch:
+            return lr0
+        rate, steps = sch
+        return lr0 * float(rate) ** (float(global_step) / float(steps))
 
     @property
     def has_deep(self):

@@ -194,10 +194,13 @@ class Columns(object):
 
     def towers(self):
         hidden, mode = self.model["dnn_hidden_units"], self.model["dnn_connected_mode"]
-        if hidden and isinstance(hidden[0], (list, tuple)):
-            modes = mode if isinstance(mode, (list, tuple)) else [mode] * len(hidden)
-            return [(list(h), m) for h, m in zip(hidden, modes)]
-        return [(list(hidden), mode)]
+        # python/lib/dnn.py:253-258: a 1-D hidden list is one DNN; one mode (a name, or a connection list whose first item
+        # has three characters like '0-1') serves every DNN
+        if not (hidden and isinstance(hidden[0], (list, tuple))):
+            hidden = [hidden]
+        if isinstance(mode, str) or (isinstance(mode[0], str) and len(mode[0]) == 3):
+            mode = [mode] * len(hidden)
+        return [(list(h), m) for h, m in zip(hidden, mode)]
 
     def optimizers(self):
         """(dnn_opt, lin_opt) tuples for OracleWideDeep from model.yaml (python/lib/utils/model_util.py:62-105;

@@ -426,12 +426,38 @@ ACTIVATIONS = {
 }
 
 
+def connection_map(mode):
+    """python/lib/dnn.py:195-205: ['0-1', '0-3', '1-2'] (or '0-1,0-3,1-2', or (i, j) pairs) -> {j: [i, ...]}.  The reference
+    line `connected_mapping[j] = connected_mapping[j].append(i)` (dnn.py:203) stores None for a second edge into j and
+    `connected_mapping[layer_id + 1]` (dnn.py:220) raises KeyError for a layer nothing connects to: this is
+    what the docstring (dnn.py:65-66) says the list means -- every edge kept, unconnected layers read their predecessor.
+    (Under Python 2, which `map(...)` being subscripted-by-unpacking at dnn.py:196-199 assumes, the comprehension at :220 also
+    rebinds `net` to the last collected tensor, so the layer's own output would be dropped; the branch cannot have been run.)
+    No golden vector exists for this mode: parity is pinned by construction only -- the chain list 0-1, 1-2, ... must
+    reproduce `dense` (same concat, same order) and the result must equal torch autograd of this function."""
+    if isinstance(mode, str):
+        mode = [p for p in mode.replace(" ", "").split(",") if p]
+    cm = {}
+    for e in mode:
+        i, j = (int(v) for v in (e.split("-") if isinstance(e, str) else e))
+        if i not in cm.setdefault(j, []):
+            cm[j].append(i)
+    return cm
+
+
+def is_connection_list(mode):
+    return not isinstance(mode, str) or (len(mode) >= 3 and mode.replace(" ", "").replace(",", "").replace("-", "").isdigit())
+
+
 def tower_forward(x, tw, mode, act, batch_norm, dropout=None, masks=None):
     """python/lib/dnn.py:92-234 for one tower.  tw: dict with lists 'kernel','bias','gamma','beta' (hidden
     layers) and 'logits_kernel','logits_bias'.  BN is the inference-mode affine of SURVEY App. C.1.
     dropout (rate) + masks (per layer [B, N] of 0 / 1, the keep decisions): tf.layers.dropout in TRAIN mode, between
     the activation and BN (dnn.py:111-114): x / keep_prob * keep.  The random draw itself is the caller's."""
     f = ACTIVATIONS[act]
+    cmap = None
+    if is_connection_list(mode):
+        cmap, mode = connection_map(mode), "list"
     inv = 1.0 / float(np.sqrt(np.float32(1.0) + np.float32(BN_EPS)))
     input_layer = x
     net = x
@@ -454,6 +480,9 @@ def tower_forward(x, tw, mode, act, batch_norm, dropout=None, masks=None):
             net = torch.cat(coll, dim=1)
         elif mode == "resnet":
             net = torch.cat([h, coll[l]], dim=1)
+            coll.append(net)
+        elif mode == "list":    # dnn.py:218-223: [net_collections[idx] for idx in the mapping, in index order] + [this layer]
+            net = torch.cat([coll[i] for i in range(len(coll)) if i in cmap.get(l + 1, ())] + [h], dim=1)
             coll.append(net)
         else:
             raise ValueError(mode)

@@ -356,3 +356,27 @@ def test_lr_decay_is_opt_in_and_follows_exponential_decay(tmp_path):
     yaml.safe_dump(m, open(base / "model.yaml", "w"))
     spec = BE.build_model_spec(Config(base_dir=str(base)), "wide_deep")
     assert spec.lr_decay == {"linear": (0.5, steps)} and spec.lin_opt[0] == "Ftrl"
+
+
+def test_connection_list_from_model_yaml(tmp_path):
+    """dnn_connected_mode as a connection list (python/lib/dnn.py:65-66).  The conf reader only lets a string through
+    (python/lib/read_conf.py:183-197), so from model.yaml the list is written '0-1,0-3'; a YAML list is rejected there exactly as
+    the reference rejects it, while the API (TowerSpec / tower_specs) takes the list form."""
+    import shutil
+    import yaml
+    base = tmp_path / "conf"
+    shutil.copytree(conf_dir(), base)
+    m = yaml.safe_load(open(base / "model.yaml"))
+    L = len(m["dnn_hidden_units"])
+    m["dnn_connected_mode"] = "0-1, 0-%d,1-2" % L
+    yaml.safe_dump(m, open(base / "model.yaml", "w"))
+    spec = BE.build_model_spec(Config(base_dir=str(base)), "wide_deep")
+    assert spec.towers[0].mode == ((0, 1), (0, L), (1, 2))
+    assert OC.Columns(str(base)).towers() == [(list(m["dnn_hidden_units"]), m["dnn_connected_mode"])]
+    from wide_deep_amd.plan import FeaturePlan
+    tl = FeaturePlan(spec).towers[0]
+    assert tl.mode == "list" and [tl.canon(s) for s in tl.in_segs[L]] == [0, L] and [tl.canon(s) for s in tl.in_segs[2]] == [0, 1, 2]
+    m["dnn_connected_mode"] = ["0-1", "0-2"]
+    yaml.safe_dump(m, open(base / "model.yaml", "w"))
+    with pytest.raises(ValueError, match="String type is required"):
+        Config(base_dir=str(base)).model

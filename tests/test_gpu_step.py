@@ -61,6 +61,31 @@ def test_first_dense_depths(hidden):
     _run(_spec(mode="first_dense", hidden=hidden))
 
 
+@pytest.mark.parametrize("conn,hidden", [((("0-1"), ("0-3"), ("1-2")), (32, 16, 8)), ("0-2", (16, 8)), ("0-1,1-2,2-3", (16, 8, 12)),
+                                         ([(0, 3), (1, 3), (2, 3)], (8, 4, 12)), (["0-1", "0-2", "1-2", "0-4", "2-4"], (16, 8, 8, 4))])
+def test_connection_list_train_steps_match_oracle(conn, hidden):
+    """Connection lists (python/lib/dnn.py:65-66, 195-224): layer j reads [net_i, i -> j ascending | h_{j-1}] with net_i such a
+    concat itself -- windows of copies, gradients of a repeated segment summed back into it."""
+    eng, _ = _run(_spec(mode=conn, hidden=hidden))
+    assert eng.towers[0]["layout"].mode == "list" and not eng.chain
+
+
+def test_connection_list_chain_equals_dense_and_survives_dropout_and_two_towers():
+    from wide_deep_amd.plan import TowerSpec
+    a, _ = _run(_spec(mode="dense", hidden=(16, 8, 8)))
+    b, _ = _run(_spec(mode="0-1,1-2,2-3", hidden=(16, 8, 8)))
+    sa, sb = a.export_state(), b.export_state()          # same seed, same concat order -> the same model
+    for k in sa:
+        if k != "global_step":
+            assert torch.allclose(sa[k], sb[k], rtol=1e-5, atol=1e-6), k
+    s = _spec(mode=["0-1", "0-2"], hidden=(16, 8))
+    s.dropout, s.activation = 0.25, "tanh"
+    _run(s)
+    s = _spec(mode="simple", hidden=(16, 8))
+    s.towers = [TowerSpec([16, 8], ((0, 2),)), TowerSpec([8, 8, 4], ((0, 1), (1, 3))), TowerSpec([12], "simple")]
+    _run(s, mean_len=3, dist="zipf")
+
+
 @pytest.mark.parametrize("mode,rate,act", [("simple", 0.3, "relu"), ("resnet", 0.1, "tanh"), ("first_dense", 0.5, "relu"),
                                            ("dense", 0.2, "sigmoid")])
 def test_dropout_train_steps_match_oracle(mode, rate, act):

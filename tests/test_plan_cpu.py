@@ -100,3 +100,57 @@ def test_deep_input_is_padded_for_aligned_windows():
         assert plan.tf_deep_dim == c and plan.deep_dim >= c and plan.deep_dim % 4 == 0
         assert plan.deep_dim % 64 == 0 or c <= 128
         assert len(set(plan.tf_input_perm.tolist())) == c and int(plan.tf_input_perm.max()) < plan.deep_dim
+
+
+@pytest.mark.parametrize("conn,hidden", [(["0-1", "0-3", "1-2"], (16, 8, 8)), ("0-1,1-2,2-3", (16, 8, 4)), (["0-2"], (8, 8)),
+                                         ([(0, 3), (1, 3), (2, 3)], (8, 4, 12)), (["1-2", "1-2"], (8, 8))])
+def test_connection_list_windows(conn, hidden):
+    """python/lib/dnn.py:195-224 (as documented at :65-66): layer j reads [net_i for every i -> j, ascending | h_{j-1}], each
+    net_i itself such a concat; every window is contiguous, ends in its own segment, and repeats the others as copies."""
+    from wide_deep_amd.plan import parse_connections
+    deep = 20
+    tl = TowerLayout(deep, hidden, conn)
+    L = len(hidden)
+    assert tl.mode == "list" and tl.connections == parse_connections(conn, L)
+    into = {}
+    for i, j in tl.connections:
+        into.setdefault(j, []).append(i)
+    flat = [[0]]
+    for l in range(1, L + 1):
+        flat.append([s for i in sorted(into.get(l, [])) for s in flat[i]] + [l])
+    spans = sorted((tl.seg_start[j], tl.seg_start[j] + tl.seg_width[j]) for j in range(len(tl.seg_width)))
+    for (a0, a1), (b0, b1) in zip(spans, spans[1:]):
+        assert a1 <= b0, "segments overlap"
+    for l in range(L + 1):
+        segs = tl.in_segs[l]
+        assert [tl.canon(j) for j in segs] == flat[l] and segs[-1] == l
+        assert all(j > L for j in segs[:-1])                                   # everything but the tail is a copy
+        assert sum(tl.seg_width[j] for j in segs) == tl.in_K[l] and tl.in_start[l] % 4 == 0
+        assert all(seg >= 0 for seg, _ in tl.window_cols(l))
+    assert sorted(tl.x_copies) == sorted(cs for cs, src in tl.copies.items() if src == 0)
+    for l in range(1, L + 1):
+        assert all(tl.seg_width[cs] == hidden[l - 1] for cs in tl.copies_of(l))
+
+
+def test_connection_list_errors_and_chain_list_is_dense():
+    from wide_deep_amd.build_estimator import tower_specs
+    from wide_deep_amd.plan import is_connection_list
+    for bad in (["1-0"], ["0-4"], ["2-2"], ["a-b"], ["0-1-2"]):
+        with pytest.raises(ValueError):
+            TowerLayout(16, (8, 8, 8), bad)
+    with pytest.raises(ValueError):
+        TowerLayout(16, (8, 8), "densenet")
+    assert not is_connection_list("simple") and is_connection_list("0-1, 1-2") and is_connection_list(["0-1"])
+    # python/lib/dnn.py:253-258: one mode for every DNN when it is a name or a list of 'i-j' items, else one per DNN
+    t = tower_specs([[8, 8], [8, 4, 4]], ["0-1", "0-2"])
+    assert [x.mode for x in t] == [((0, 1), (0, 2)), ((0, 1), (0, 2))]
+    t = tower_specs([[8, 8], [8, 4, 4]], ["simple", ["0-1", "1-3"]])
+    assert [x.mode for x in t] == ["simple", ((0, 1), (1, 3))]
+    assert tower_specs([8, 4], "0-1,0-2")[0].mode == ((0, 1), (0, 2)) and tower_specs([8, 4], "resnet")[0].mode == "resnet"
+    # kernel rows: the chain list concatenates exactly what `dense` does, in the same order
+    a = FeaturePlan(criteo_spec(n_dense=3, n_sparse=2, buckets=10, dim=8, hidden=(8, 4, 4), mode="dense"))
+    b = FeaturePlan(criteo_spec(n_dense=3, n_sparse=2, buckets=10, dim=8, hidden=(8, 4, 4), mode=((0, 1), (1, 2), (2, 3))))
+    for l in range(4):
+        ra, rb = a.tf_rows_of_layer(0, l), b.tf_rows_of_layer(0, l)
+        ca, cb = a.towers[0].window_cols(l), b.towers[0].window_cols(l)
+        assert [(a.towers[0].canon(ca[r][0]), ca[r][1]) for r in ra] == [(b.towers[0].canon(cb[r][0]), cb[r][1]) for r in rb]

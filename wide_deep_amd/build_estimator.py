@@ -155,11 +155,7 @@ def build_model_spec(conf=None, model_type=None):
                              dim=int(global_dim or embedding_dim(size)) if is_deep else 0, cross_keys=keys))
 
     hidden, mode = model["dnn_hidden_units"], model["dnn_connected_mode"]
-    if hidden and isinstance(hidden[0], (list, tuple)):     # multi-DNN  (python/lib/dnn.py:237-275)
-        modes = mode if isinstance(mode, (list, tuple)) else [mode] * len(hidden)
-        towers = [TowerSpec([int(h) for h in hs], _mode_name(m)) for hs, m in zip(hidden, modes)]
-    else:
-        towers = [TowerSpec([int(h) for h in hidden], _mode_name(mode))]
+    towers = tower_specs(hidden, mode)
     dnn_name, dnn_kw = parse_optimizer(model["dnn_optimizer"], model.get("dnn_initial_learning_rate") or 0.05)
     lin_name, lin_kw = parse_optimizer(model["linear_optimizer"], model.get("linear_initial_learning_rate") or 0.05)
     # learning-rate decay done the way the reference's comment describes it (python/lib/joint.py:65-66, 145-154), behind a flag:
@@ -182,10 +178,23 @@ def build_model_spec(conf=None, model_type=None):
                      neg_weight=float(train["neg_sample_loss_weight"] or 1.0), lr_decay=lr_decay or None)
 
 
-def _mode_name(m):
-    # connected modes: names as in python/lib/dnn.py:74-81; a 0/1 connection matrix ("arbitrary") is not supported
-    if not isinstance(m, str):
-        raise NotImplementedError("arbitrary dnn connection matrices (python/lib/dnn.py:195-224) are not implemented")
+def tower_specs(hidden, mode):
+    """dnn_hidden_units / dnn_connected_mode -> one TowerSpec per DNN (python/lib/dnn.py:237-258): a 1-D hidden list is one
+    tower; ONE mode -- a name, or a connection list, recognised as the reference does by a first item of three characters
+    ('0-1') -- serves every tower, anything else is one mode per tower."""
+    multi = bool(hidden) and isinstance(hidden[0], (list, tuple))
+    hidden = [list(h) for h in hidden] if multi else [list(hidden)]
+    one = isinstance(mode, str) or (len(mode) > 0 and isinstance(mode[0], str) and len(mode[0]) == 3)
+    modes = [mode] * len(hidden) if one else list(mode)
+    return [TowerSpec([int(h) for h in hs], _mode_name(m, len(hs))) for hs, m in zip(hidden, modes)]
+
+
+def _mode_name(m, n_hidden):
+    """Connected mode of one tower: a name of python/lib/dnn.py:58-66 or a connection list ['0-1', '0-3', '1-2'] (also as one
+    string '0-1,0-3,1-2': the conf reader only lets strings through) -> tuple of (i, j) pairs."""
+    from .plan import is_connection_list, parse_connections
+    if is_connection_list(m):
+        return parse_connections(m, n_hidden)
     return {"normal": "simple"}.get(m, m)
 
 

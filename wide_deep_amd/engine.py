@@ -259,8 +259,9 @@ class WideDeepEngine:
                 if self.half:
                     if len(plan.towers) != 1:
                         raise NotImplementedError("tower_dtype='fp16': one tower")
-                    if tl.mode == "first_dense":
-                        raise NotImplementedError("tower_dtype='fp16': connected_mode first_dense runs on the fp32 tower")
+                    if tl.copies:
+                        raise NotImplementedError("tower_dtype='fp16': connected_mode first_dense / connection lists run on "
+                                                  "the fp32 tower")
                     f16 = dict(dtype=torch.float16, device=dev)
                     r8 = lambda v: (v + 7) // 8 * 8
 
@@ -742,7 +743,7 @@ class WideDeepEngine:
                     w0 = tl.seg_width[0]
                     tw["act"][:B, tl.seg_start[xs]: tl.seg_start[xs] + w0].copy_(
                         tw["act"][:B, tl.seg_start[0]: tl.seg_start[0] + w0])
-                if train and tl.mode == "first_dense":
+                if train and tl.copies:
                     tw["dact"][:B].zero_()   # windows are accumulated into; the logits window does not cover them all
                 if not self.chain:
                     self._tower_hidden_forward(tw, B, st, train)
@@ -797,6 +798,8 @@ class WideDeepEngine:
                  self.act_id, c_ptr, tl.ld, B, N, K, st)
             if train and self.dropout:     # tf.layers.dropout(net, rate, training=True): TRAIN mode only, before BN
                 call("wd_dropout_fwd", c_ptr, tl.ld, B, N, self.dropout, ptr(self.drop_seed), self._drop_layer(tw, l), st)
+            for cs in tl.copies_of(l + 1):  # connection list: later windows repeat this layer's output (dnn.py:218-221)
+                act[:B, tl.seg_start[cs]: tl.seg_start[cs] + N].copy_(act[:B, tl.seg_start[l + 1]: tl.seg_start[l + 1] + N])
 
     def _tower_hidden_forward_h(self, tw, B, st):
         """fp16-input tower: x (fp32, from the gather) -> half + transposed half; every layer writes both copies."""
@@ -910,6 +913,8 @@ class WideDeepEngine:
             else:
                 seg = tl.seg_start[l + 1]
                 dz_ptr, lddz = tw["dz"][0].data_ptr(), N
+                for cs in tl.copies_of(l + 1):          # connection list: the gradient of a segment = sum over its copies
+                    dact[:B, seg: seg + N].add_(dact[:B, tl.seg_start[cs]: tl.seg_start[cs] + N])
                 if tn_done is not None:
                     main.wait_event(tn_done)            # the previous layer's TN still reads dz[0]
                 if self.dropout:

@@ -14,6 +14,7 @@ tf.feature_column objects:
     exchanged with the reference's checkpoint naming.
 """
 import math
+import re
 from dataclasses import dataclass, field
 from typing import List, Optional
 
@@ -78,7 +79,33 @@ class DenseCol:
 @dataclass
 class TowerSpec:
     hidden_units: List[int]
-    mode: str = "simple"
+    mode: object = "simple"     # a name, or a connection list: tuple of (i, j) layer pairs (python/lib/dnn.py:195-224)
+
+
+def parse_connections(mode, n_hidden):
+    """`['0-1', '0-3', '1-2']` (python/lib/dnn.py:65-66, 195-205) -> sorted tuple of (i, j): layer j also reads what
+    layer i read ... index 0 = the input layer, L = len(hidden_units); "smaller index first".  Accepts a list / tuple of
+    'i-j' strings or (i, j) pairs, or ONE string 'i-j,i-j' (the conf reader only lets a string through, read_conf.py:183)."""
+    if isinstance(mode, str):
+        mode = [p for p in mode.replace(" ", "").split(",") if p]
+    pairs = set()
+    for e in mode:
+        try:
+            i, j = (int(v) for v in (e.split("-") if isinstance(e, str) else e))
+        except (TypeError, ValueError):
+            raise ValueError("Invalid connected_mode entry `%s`: expected 'i-j'" % (e,))
+        if not 0 <= i < j <= n_hidden:
+            raise ValueError("Invalid connection `%s-%s`: need 0 <= i < j <= len(hidden_units) = %d (index 0 is the input "
+                             "layer, smaller index first)" % (i, j, n_hidden))
+        pairs.add((i, j))
+    return tuple(sorted(pairs))
+
+
+def is_connection_list(mode):
+    """A connection list rather than a mode name: a sequence, or a string made of 'i-j' items."""
+    if isinstance(mode, str):
+        return bool(re.fullmatch(r"\s*\d+\s*-\s*\d+\s*(,\s*\d+\s*-\s*\d+\s*)*,?\s*", mode))
+    return isinstance(mode, (list, tuple))
 
 
 @dataclass
@@ -136,19 +163,53 @@ class TowerLayout:
       dense       [seg0 | seg1 | ... | seg_l]          (python/lib/dnn.py:155-173)
       resnet      [seg_l | seg_{l-1} | ... | seg0]     (python/lib/dnn.py:175-193, concat not add: quirk C.8)
       last_dense  hidden layers as simple, logits over [seg0 | ... | seg_L]  (python/lib/dnn.py:135-153)
+      connection list ((i, j) pairs, mode "list"): net_j = [net_i for every i -> j, ascending | h_{j-1}]  (python/lib/dnn.py:
+                  195-224) where net_i is itself such a concat; a window holds COPIES of the segments it repeats (filled
+                  when the source layer is done, their gradients added back to the source) and ends in its own segment.
     """
 
     def __init__(self, deep_dim, hidden, mode):
-        if mode not in ("simple", "dense", "resnet", "last_dense", "first_dense"):
-            raise ValueError("connected_mode `%s` is not supported by the gfx950 engine yet "
-                             "(supported: simple, first_dense, last_dense, dense, resnet)" % (mode,))
-        self.mode = mode
         self.hidden = list(hidden)
         widths = [deep_dim] + self.hidden
         L = len(self.hidden)
-        self.x_copies = []          # first_dense: extra segments (index > L) that hold a copy of segment 0
+        self.connections = None
+        if is_connection_list(mode):
+            self.connections = parse_connections(mode, L)
+            mode = "list" if self.connections else "simple"    # no edge: every layer reads its predecessor only
+        if mode not in ("simple", "dense", "resnet", "last_dense", "first_dense", "list"):
+            raise ValueError("Invalid connected_mode: `%s` (simple, first_dense, last_dense, dense, resnet, or a connection "
+                             "list like ['0-1', '0-3', '1-2'])" % (mode,))
+        self.mode = mode
+        self.copies = {}            # extra segment (index > L) -> the segment whose values it repeats
+        self.x_copies = []          # ... those of segment 0 (first_dense, connection lists): filled behind the input layer
         xseg_of = {}                # first_dense: layer l >= 1 -> the x segment inside its window
-        if mode in ("dense", "last_dense"):
+        win = None                  # connection list: segments of each layer's window, in concat order
+        if mode == "list":
+            if any(w % 4 for w in widths):
+                raise ValueError("connection lists: hidden widths and the deep input width must be multiples of 4 "
+                                 "(16-byte aligned windows); got %s / %d" % (self.hidden, deep_dim))
+            into = {}
+            for i, j in self.connections:
+                into.setdefault(j, []).append(i)
+            flat = [[0]]            # net_l as a list of source segments (with multiplicity)
+            for l in range(1, L + 1):
+                flat.append([s for i in sorted(into.get(l, [])) for s in flat[i]] + [l])
+            starts, win, c = [0] * (L + 1), [[0]], deep_dim
+            for l in range(1, L + 1):
+                w = []
+                for src in flat[l][:-1]:
+                    cs = len(widths)
+                    widths.append(widths[src])
+                    starts.append(c)
+                    c += widths[src]
+                    self.copies[cs] = src
+                    w.append(cs)
+                starts[l] = c
+                c += widths[l]
+                win.append(w + [l])
+            self.x_copies = [cs for cs, src in self.copies.items() if src == 0]
+            total = c
+        elif mode in ("dense", "last_dense"):
             starts, c = [], 0
             for w in widths:
                 starts.append(c)
@@ -183,6 +244,7 @@ class TowerLayout:
                     widths.append(deep_dim)
                     starts.append(c)
                     self.x_copies.append(xs)
+                    self.copies[xs] = 0
                 c += deep_dim
                 xseg_of[2 * g + 1] = xs
                 if 2 * g + 2 <= L:                          # consumer 2g+2 exists; its h_{2g+1} is segment 2g+2
@@ -206,7 +268,9 @@ class TowerLayout:
         self.in_start, self.in_K, self.in_segs = [], [], []
         for l in range(L + 1):
             is_logits = l == L
-            if mode == "simple" or (mode == "last_dense" and not is_logits):
+            if mode == "list":
+                segs = win[l]
+            elif mode == "simple" or (mode == "last_dense" and not is_logits):
                 segs = [l]
             elif mode == "first_dense":
                 segs = [0] if l == 0 else [l, xseg_of[l]]   # TF order: [h_{l-1} | x]
@@ -222,8 +286,12 @@ class TowerLayout:
             self.in_segs.append(segs)
 
     def canon(self, seg):
-        """Segment whose values `seg` holds: copies of the deep input (first_dense) are segment 0."""
-        return 0 if seg in self.x_copies else seg
+        """Segment whose values `seg` holds (copies: first_dense's of the deep input, a connection list's of anything)."""
+        return self.copies.get(seg, seg)
+
+    def copies_of(self, seg):
+        """Copy segments of hidden segment `seg`, in buffer order."""
+        return [cs for cs, src in self.copies.items() if src == seg]
 
     def window_cols(self, l):
         """For layer l: list of (segment, unit) for every column of its input window, -1 segment for pad."""
@@ -370,8 +438,8 @@ class FeaturePlan:
         s0 = tl.in_start[l]
         if tl.mode in ("simple",) or (tl.mode == "last_dense" and l < len(tl.hidden)):
             order = [l]
-        elif tl.mode == "first_dense":
-            order = list(tl.in_segs[l])                    # [h_{l-1}, x] in the reference's concat order
+        elif tl.mode in ("first_dense", "list"):
+            order = list(tl.in_segs[l])                    # [h_{l-1}, x] / [net_i ... | h_{l-1}]: the reference's concat order
         elif tl.mode in ("dense", "last_dense"):
             order = list(range(0, l + 1))
         else:

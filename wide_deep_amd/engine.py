@@ -382,7 +382,11 @@ class WideDeepEngine:
         # tower at C5 gains 4 % from the TN branch.  Defaults follow the measurements; WD_OVERLAP=none|bucket|tn|both.
         # With the one-launch tower (wd_tower_chain: one wavefront per SIMD for ~75 us, 118 KB of LDS) the bucketing
         # kernels co-reside on the same CUs: 0.2425 -> 0.232 ms/step at C2, so that branch is on by default there.
-        mode = os.environ.get("WD_OVERLAP", "tn" if self.half else ("bucket" if getattr(self, "chain", False) else "none"))
+        # Per-layer towers on big ragged batches (C4: 1.06 M occurrences, bucketing 84 us; C5): both branches, 0.7414 -> 0.7157
+        # and 1.0227 -> 1.0121 ms/step (profiles/r4_overlap_c4_c5.txt); small batches keep one stream.
+        big = self.max_batch * max(1, self.plan.S) >= (1 << 16)
+        mode = os.environ.get("WD_OVERLAP", "bucket" if getattr(self, "chain", False) else
+                              ("both" if big else ("tn" if self.half else "none")))
         self.overlap_bucket = mode in ("both", "bucket")
         self.overlap_tn = mode in ("both", "tn")
         self._sides = None
@@ -743,7 +747,7 @@ class WideDeepEngine:
                     w0 = tl.seg_width[0]
                     tw["act"][:B, tl.seg_start[xs]: tl.seg_start[xs] + w0].copy_(
                         tw["act"][:B, tl.seg_start[0]: tl.seg_start[0] + w0])
-                if train and tl.copies:
+                if train and tl.mode in ("first_dense", "list"):
                     tw["dact"][:B].zero_()   # windows are accumulated into; the logits window does not cover them all
                 if not self.chain:
                     self._tower_hidden_forward(tw, B, st, train)

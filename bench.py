@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--force-sharded", action="store_true",
                     help="diagnostics: run the row-sharded engine even with one rank (one-rank RCCL group)")
     ap.add_argument("--cpu-steps", type=int, default=50)
+    ap.add_argument("--probe-capture", action="store_true",
+                    help="(internal) child of a rank: capture and replay a small sharded step graph with the collectives in it")
     ap.add_argument("--cpu-only", action="store_true",
                     help="print only the cpu_baseline object of the workload (what an N > 1 run launches as a child of rank 0)")
     ap.add_argument("--ids-input", action="store_true", help="feed pre-hashed ids (skips the hash kernel)")
@@ -492,6 +494,76 @@ def self_launch(n):
     raise SystemExit(rc)
 
 
+def probe_capture_child():
+    """`bench.py --probe-capture` (started by probe_captured_collectives, one child per rank, on a rendezvous of their own):
+    a small C2-shaped model through exactly what the timed region of an N > 1 run is made of -- dist.ShardedStepGraph, the
+    all-to-alls and the all-reduce captured into multi-step hipGraphs, built by pipeline.StepRunner -- captured, replayed,
+    segment overflow checked.  Leaves with os._exit: 0 = it works on this node."""
+    import datetime
+    import torch.distributed as dist
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dev = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", device_id=torch.device("cuda", dev), timeout=datetime.timedelta(minutes=2))
+    from wide_deep_amd import pipeline, synth
+    from wide_deep_amd.dist import ShardedStepGraph, ShardedWideDeepEngine
+    from wide_deep_amd.plan import criteo_spec
+    B = 1024
+    spec = criteo_spec(n_dense=13, n_sparse=26, buckets=20000, dim=16, hidden=(256, 128, 64))
+    eng = ShardedWideDeepEngine(spec, max_batch=B, seed=0, slack=2.0)
+    tbs = [synth.TokenBatch(eng.hash_plan, synth.make_raw_batch(eng.hash_plan, B, seed=77 + 100 * rank + i)) for i in range(4)]
+    if not (eng._graph_mode() == "full" and eng.chain and eng._chain_input_ok(tbs[0].batch)):
+        print("probe: this model does not take the captured-collectives path", flush=True)
+        os._exit(3)
+    if os.environ.get("WD_FAULT_CAPTURE_RANK") == str(rank):     # test hook: die the way a refused capture does
+        import signal
+        os.kill(os.getpid(), signal.SIGSEGV)
+    runner = pipeline.StepRunner(eng, tbs, 4, 2, False, ShardedStepGraph, n_singles=2)
+    runner.warm_up(1)
+    runner.run(5)
+    torch.cuda.synchronize()
+    eng.check_overflow()
+    ok = bool(torch.isfinite(eng.loss).all())
+    print("probe ok" if ok else "probe: loss is not finite", flush=True)
+    os._exit(0 if ok else 4)       # (no destroy_process_group: it can hang behind captured collectives)
+
+
+def probe_captured_collectives(rank, world, limit=240):
+    """Can this node capture RCCL collectives into hipGraphs?  Tried in a CHILD process per rank before anything is built.
+    hipStreamEndCapture of ROCm 7.2 answers a broken capture rule with SIGSEGV: under
+    `python -m torch.distributed.run` -- how the driver starts an N > 1 run; self_launch() can retry, that launcher cannot --
+    one rank dying takes the job with it and no line is printed.  The children rendezvous on a port of their own; every rank
+    waits for its child (a hang counts as a failure after `limit` seconds), the ranks agree (MIN), and on a failure the run
+    uses hipGraph segments between ordinary collectives.  Returns None (captured collectives work) or why not."""
+    import socket
+    import subprocess
+    port = torch.zeros(1, dtype=torch.int32, device="cuda")
+    if rank == 0:
+        with socket.socket() as s2:
+            s2.bind(("127.0.0.1", 0))
+            port[0] = s2.getsockname()[1]
+    if world > 1:
+        torch.distributed.all_reduce(port)
+    env = {k: v for k, v in os.environ.items() if not k.startswith("TORCHELASTIC_")}     # rank 0's child hosts the store
+    env["MASTER_PORT"] = str(int(port.item()))
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    why = None
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--probe-capture"], env=env, timeout=limit,
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+        if r.returncode != 0 or b"probe ok" not in r.stdout:
+            tail = r.stdout.decode("utf-8", "replace").strip().splitlines()[-1:] or [""]
+            why = "status %d (%s)" % (r.returncode, tail[0][:120])
+    except subprocess.TimeoutExpired:
+        why = "no answer in %d s" % limit
+    flag = torch.tensor([0 if why else 1], dtype=torch.int32, device="cuda")
+    if world > 1:
+        torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
+    if int(flag.item()):
+        return None
+    return "probe of captured collectives failed on %s" % ("this rank: " + why if why else "another rank")
+
+
 def cpu_only(args):
     """`cpu_baseline` of the workload and nothing else (one JSON line): a single-GPU engine supplies the model's initial state,
     the oracle is timed on the host."""
@@ -515,6 +587,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.cpu_only:
         return cpu_only(args)
+    if args.probe_capture:
+        return probe_capture_child()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # bare `python bench.py --gpus N`: become the launcher -- one rank per GPU through torch.distributed.run on a free
         # local port; rank 0 prints the one JSON line, this process forwards the ranks' exit status
@@ -542,6 +616,13 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index), timeout=limit)
         else:
             dist.init_process_group(backend, timeout=limit)
+        if (backend == "nccl" and not args.no_graph and "WD_DIST_GRAPH" not in os.environ and args.config in ("c2", "c3")
+                and (world > 1 or os.environ.get("WD_BENCH_PROBE") == "1") and os.environ.get("WD_BENCH_PROBE") != "0"):
+            why = probe_captured_collectives(rank, world)
+            if why:
+                print("bench: %s; hipGraph segments between ordinary collectives" % why, file=sys.stderr, flush=True)
+                os.environ["WD_DIST_GRAPH"] = "segments"
+                os.environ.setdefault("WD_BENCH_GRAPH_FALLBACK", why)
 
     from wide_deep_amd import pipeline, synth
     from wide_deep_amd.engine import WideDeepEngine

@@ -56,6 +56,9 @@ class StandInEngine(object):
     def export_state(self):
         return {"w": self.w.clone(), "global_step": torch.tensor(self.global_step)}
 
+    def state_shapes(self):
+        return {"w": tuple(self.w.shape), "global_step": ()}
+
     def import_state(self, st):
         self.w.copy_(st["w"])
         self.global_step = int(st["global_step"])

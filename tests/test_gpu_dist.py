@@ -504,3 +504,36 @@ def test_bench_two_ranks_prints_a_creditable_line_even_when_a_rank_dies_at_captu
     assert p["hash_ids_bit_exact"] is True and p["world"] == 2
     assert p["max_abs_dlogit"] <= 2e-4 + 2e-4 * 20 and abs(p["loss_local"] - p["oracle_loss_local"]) <= 1e-3 * abs(p["oracle_loss_local"])
     assert d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["kind"] == "port"
+
+
+@pytest.mark.parametrize("fault", [False, True])
+def test_bench_under_the_drivers_launcher_probes_captured_collectives_first(fault):
+    """`python -m torch.distributed.run ... bench.py --gpus N` is how the driver starts an N > 1 run: no launcher of ours that could
+    retry, and a rank dying inside hipStreamEndCapture would end the job without a line.  bench.py therefore tries the capture
+    of RCCL collectives in a child process per rank first (a one-rank RCCL group here: WD_BENCH_PROBE=1 switches the probe on
+    for world 1).  Probe fine -> multi-step graphs with the collectives in them; probe child killed by a signal -> the ranks
+    themselves never touch that capture, run graph segments between ordinary collectives and say so in the line."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WD_BENCH_PROBE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WD_DIST_GRAPH", "WD_DIST_BACKEND", "WD_FAULT_CAPTURE_RANK", "WD_BENCH_GRAPH_FALLBACK"):
+        env.pop(k, None)
+    if fault:
+        env["WD_FAULT_CAPTURE_RANK"] = "0"
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+                        "127.0.0.1", "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "1",
+                        "--force-sharded", "--steps", "4", "--warmup", "1", "--pool", "4", "--repeats", "1", "--batch", "2048",
+                        "--no-cpu-baseline", "--no-pmc"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    ex = d["config"]["exchange"]
+    assert d["value"] > 0 and ex["check_overflow"] == "clean" and d["parity"]["hash_ids_bit_exact"] is True
+    if fault:
+        assert "probe of captured collectives failed" in r.stderr and "probe of captured collectives failed" in ex["graph_fallback"]
+        assert ex["graph"] == "segments"
+    else:
+        assert "graph_fallback" not in ex and ex["graph"] == "full"

@@ -36,6 +36,7 @@ def _run(spec, B=96, steps=3, mean_len=1, weights=False, dist="uniform", max_bat
         assert_close(eng.logit[:B], ologits, L_RTOL, L_ATOL, "logits step %d" % step)
         assert abs(float(loss) - oloss) <= 1e-3 * max(1.0, abs(oloss)), (float(loss), oloss)
     st = eng.export_state()
+    assert eng.state_shapes() == {k: tuple(v.shape) for k, v in st.items()}      # what a restore checks a checkpoint against
     for k, v in ora.state.items():
         if k == "global_step" or "moving_" in k:
             continue

@@ -1288,6 +1288,43 @@ class WideDeepEngine:
         opt = self.spec.dnn_opt if scope == "dnn" else self.spec.lin_opt
         return opt_slot_names(opt)
 
+    def state_shapes(self):
+        """{TF variable name: shape} of what export_state() returns -- from the plan alone, nothing is copied off the device
+        (estimator._check_tf_state: a restore must not stage a second host copy of every table just to learn the names)."""
+        plan, spec = self.plan, self.spec
+        out = {}
+        if spec.has_deep:
+            sufs = [""] + [x for x in self._slot_bufs("dnn") if x is not None]
+            for i, s in enumerate(plan.slots):
+                if plan.emb_off[i] >= 0:
+                    for suf in sufs:
+                        out["dnn/input_from_feature_columns/input_layer/%s/embedding_weights%s" % (s.deep_name, suf)] = (
+                            int(s.num_buckets), int(s.dim))
+            for ti, tw in enumerate(self.towers):
+                for l, m in enumerate(tw["metas"]):
+                    scope = "dnn/dnn_%d/" % (ti + 1) + ("hiddenlayer_%d/" % l if l < tw["L"] else "logits/")
+                    for suf in sufs:
+                        out[scope + "kernel" + suf] = (len(plan.tf_rows_of_layer(ti, l)), int(m["N_tf"]))
+                        out[scope + "bias" + suf] = (int(m["N_tf"]),)
+                        if "gamma_off" in m:
+                            out[scope + "batch_normalization/gamma" + suf] = (int(m["N"]),)
+                            out[scope + "batch_normalization/beta" + suf] = (int(m["N"]),)
+                    if "gamma_off" in m:
+                        out[scope + "batch_normalization/moving_mean"] = (int(m["N"]),)
+                        out[scope + "batch_normalization/moving_variance"] = (int(m["N"]),)
+        if spec.has_wide:
+            sufs = [""] + [x for x in self._slot_bufs("linear") if x is not None]
+            for s in plan.slots:
+                if s.wide:
+                    for suf in sufs:
+                        out["linear/linear_model/%s/weights%s" % (s.name, suf)] = (int(s.num_buckets), 1)
+            for suf in sufs:
+                out["linear/linear_model/bias_weights" + suf] = (1,)
+        for scope, names in self.pow_names.items():
+            out[names[0]], out[names[1]] = (), ()
+        out["global_step"] = ()
+        return out
+
     def export_state(self, tables=True):
         """TF-named variables (+ optimizer slots).  tables=False: dense-tower parameters, bias and counters only (the
         embedding / wide tables of a 100M-row model are tens of GB; tests/helpers.compact_oracle samples their rows)."""

@@ -161,8 +161,7 @@ class WideAndDeepClassifier(object):
                 rows["dnn/input_from_feature_columns/input_layer/%s/embedding_weights" % sl.deep_name] = int(sl.num_buckets)
                 rows["linear/linear_model/%s/weights" % sl.name] = int(sl.num_buckets)
             want = {}
-            for k, v in self._engine.export_state().items():
-                shape = tuple(v.shape)
+            for k, shape in self._engine.state_shapes().items():
                 base = k
                 for suf in ("/Adagrad", "/Ftrl_1", "/Ftrl"):
                     if base.endswith(suf):
@@ -171,7 +170,7 @@ class WideAndDeepClassifier(object):
                     shape = (rows[base],) + shape[1:]
                 want[k] = shape
         else:
-            want = {k: tuple(v.shape) for k, v in self._engine.export_state().items()}
+            want = self._engine.state_shapes()
         skip = lambda k: k == "global_step" or k.endswith("/moving_mean") or k.endswith("/moving_variance")
         missing = sorted(k for k in want if k not in state and not skip(k))
         if missing:

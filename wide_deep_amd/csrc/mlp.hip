@@ -116,7 +116,7 @@ __device__ __forceinline__ float4 mask4(float4 v, int64_t row, int64_t col, int6
 // before the BK/2 MFMAs of slab i and land in the other LDS buffer afterwards -> ONE barrier per slab and
 // NV = BK/16 independent 16-byte loads per operand per lane in flight (the BK=16 single-stage version paid
 // one full HBM/L2 latency per 8 MFMAs).
-template <bool A_RC, bool B_RC, int EPI, int BK, bool VEC>
+template <bool A_RC, bool B_RC, int EPI, int BK, bool VEC, bool XCD_REMAP = true>
 __device__ __forceinline__ void gemm_body(const GemmArgs &g, const int orig, const int bz) {
   constexpr int LDA = A_RC ? LD_RC : LD_OC;
   constexpr int LDB = B_RC ? LD_RC : LD_OC;
@@ -135,10 +135,13 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &g, const int orig, con
 
   // XCD-aware tile mapping: hardware places block i on XCD i % 8; give each XCD a contiguous run of
   // tiles (n fastest) so the N-tiles sharing an A panel hit the same L2.  Bijective for any grid.
-  const int nwg = g.tiles_m * g.tiles_n;
-  const int q = nwg / wd::kXCDs, r = nwg % wd::kXCDs;
-  const int xcd = orig % wd::kXCDs, loc = orig / wd::kXCDs;
-  const int vid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+  int vid = orig;       // !XCD_REMAP: the caller has placed the tile (k_gemm_tn_group: a whole split per XCD)
+  if (XCD_REMAP) {
+    const int nwg = g.tiles_m * g.tiles_n;
+    const int q = nwg / wd::kXCDs, r = nwg % wd::kXCDs;
+    const int xcd = orig % wd::kXCDs, loc = orig / wd::kXCDs;
+    vid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+  }
   const int64_t m0 = (int64_t)(vid / g.tiles_n) * BM;
   const int64_t n0 = (int64_t)(vid % g.tiles_n) * BN;
 
@@ -357,9 +360,11 @@ struct GroupArgs {
   GemmArgs job[MAX_TN_JOBS];
   int32_t first[MAX_TN_JOBS + 1];   // first flat workgroup id of job j (multiple of 8: keeps the XCD-aware tile order
                                     // of the body valid); [njobs] = grid size
-  int32_t count[MAX_TN_JOBS];       // workgroups of job j (tiles x splits)
+  int32_t count[MAX_TN_JOBS];       // workgroups of job j (tiles x splits; split_xcd: tiles x 8 x ceil(splits / 8))
   int32_t colsum[MAX_TN_JOBS];      // job j is a column-sum job (B == NULL)
+  int32_t nsplit[MAX_TN_JOBS];
   int32_t njobs;
+  int32_t split_xcd;                // all tiles of a split on ONE XCD (split z -> XCD z % 8)
 };
 
 template <int BK, bool VEC>
@@ -392,6 +397,16 @@ __global__ void __launch_bounds__(256) k_gemm_tn_group(GroupArgs G) {
     return;
   }
   const int nwg = g.tiles_m * g.tiles_n;
+  if (G.split_xcd) {
+    // Every tile of a split reads the same kchunk rows of A and B: with the whole split on one XCD (hardware: workgroup i
+    // runs on XCD i % 8, and a job's range starts at a multiple of 8) its L2 fetches each panel once -- 1.4 MB per split of
+    // C2's first layer -- instead of once per XCD that holds some of its tiles.
+    const int xcd = rem % wd::kXCDs, loc = rem / wd::kXCDs;
+    const int bz = xcd + wd::kXCDs * (loc / nwg);
+    if (bz >= G.nsplit[j]) return;
+    gemm_body<false, false, 2, BK, VEC, false>(g, loc % nwg, bz);
+    return;
+  }
   gemm_body<false, false, 2, BK, VEC>(g, rem % nwg, rem / nwg);
 }
 
@@ -1102,6 +1117,7 @@ extern "C" int wd_gemm_tn_splitk_group(const wd_tn_job_t *jobs, int32_t njobs, w
   GroupArgs G{};
   bool vec = true;
   int total = 0;
+  const int split_xcd = 1;   // measured on one box, alternating: 0.1696 / 0.1717 / 0.1690 (tiles spread) vs 0.1686 / 0.1699 / 0.1669 ms/step
   for (int j = 0; j < njobs; ++j) {
     const wd_tn_job_t &q = jobs[j];
     GemmArgs &g = G.job[j];
@@ -1129,9 +1145,11 @@ extern "C" int wd_gemm_tn_splitk_group(const wd_tn_job_t *jobs, int32_t njobs, w
     g.wt = wd::wt_mask() & WD_WT_PRODUCTS ? 1 : 0;
     vec = vec && g.a_vec && g.b_vec;
     G.first[j] = total;
-    G.count[j] = g.tiles_m * g.tiles_n * q.nsplit;
+    G.nsplit[j] = q.nsplit;
+    G.count[j] = g.tiles_m * g.tiles_n * (split_xcd ? wd::kXCDs * (int)wd::ceil_div(q.nsplit, wd::kXCDs) : q.nsplit);
     total += (G.count[j] + 7) / 8 * 8;
   }
+  G.split_xcd = split_xcd;
   G.first[njobs] = total;
   G.njobs = njobs;
   // 32-deep slabs: 35 KB of LDS per workgroup instead of 70 -- the sparse update that runs beside this launch keeps

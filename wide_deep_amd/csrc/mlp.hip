@@ -376,19 +376,19 @@ __global__ void __launch_bounds__(256) k_gemm_tn_group(GroupArgs G) {
   const int rem = blockIdx.x - G.first[j];
   if (rem >= G.count[j]) return;   // padding of the job's range
   if (G.colsum[j]) {
-    // C[n] = sum_k A[k][n]: 64 columns per workgroup, 4 row groups (k = q, q+4, ..) with 8 independent loads in flight
+    // C[n] = sum_k A[k][n]: 64 columns per workgroup, 4 row groups (k = q, q+4, ..) with 16 independent loads in flight
     // each, combined in group order -- a fixed summation order, and no chain of exposed load latencies
     __shared__ float part[4][64];
     const int c = threadIdx.x & 63, q = threadIdx.x >> 6;
     const int64_t n = (int64_t)rem * 64 + c;
     float acc = 0.f;
     if (n < g.N) {
-      for (int64_t k0 = q; k0 < g.K; k0 += 32) {
-        float v[8];
+      for (int64_t k0 = q; k0 < g.K; k0 += 64) {
+        float v[16];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = k0 + 4 * u < g.K ? g.A[(k0 + 4 * u) * g.lda + n] : 0.f;
+        for (int u = 0; u < 16; ++u) v[u] = k0 + 4 * u < g.K ? g.A[(k0 + 4 * u) * g.lda + n] : 0.f;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) acc += v[u];
+        for (int u = 0; u < 16; ++u) acc += v[u];
       }
     }
     part[q][c] = acc;

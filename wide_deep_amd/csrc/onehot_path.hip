@@ -651,10 +651,19 @@ k_row_update(RowUpd u) {
       wd::store1(&u.nwv[bag2], wnew, u.wt);
     }
   };
-  if ((int)blockIdx.x == u.flat_blocks + LONG_WORKERS) {     // (grid: long-segment workers first, flat blocks, this one) bias_weights: g = sum_b dlogit[b] (fixed-shape tree), dense FTRL
+  if ((int)blockIdx.x == LONG_WORKERS) {     // (grid: long-segment workers, this one, flat blocks) bias_weights: g = sum_b dlogit[b] (fixed-shape tree), dense FTRL
+    // One workgroup, batch / 256 values per lane: eight loads in flight per trip (one load -> wait -> add per value was 32
+    // dependent round trips at batch 8192, in the LAST workgroup of the grid -- the tail of the whole launch).  Same order of adds.
     if (!u.bias) return;
     float acc = 0.f;
-    for (int64_t i = t; i < u.batch; i += 256) acc += u.dlogit[i];
+    for (int64_t i0 = t; i0 < u.batch; i0 += 256 * 8) {
+      float v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = i0 + 256 * k < u.batch ? u.dlogit[i0 + 256 * k] : 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        if (i0 + 256 * k < u.batch) acc += v[k];
+    }
     redw[t] = acc;
     __syncthreads();
     for (int st = 128; st >= 1; st >>= 1) {
@@ -773,7 +782,7 @@ k_row_update(RowUpd u) {
   }
   // ---- flat part: 4 lanes per sorted position ------------------------------------------------------------------------
   const int gl = t & 3;
-  const int64_t i = (((int64_t)blockIdx.x - LONG_WORKERS) * 256 + t) >> 2;
+  const int64_t i = (((int64_t)blockIdx.x - LONG_WORKERS - 1) * 256 + t) >> 2;
   uint64_t pr = 0, prv = ~0ull, nxt = ~0ull, far = ~0ull;
   int2 pj = make_int2(-1, 0);
   if (i < u.nnz) {

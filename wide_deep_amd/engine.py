@@ -442,6 +442,10 @@ class WideDeepEngine:
         ns = ntile
         tw["nsplit"][L] = ns
         tw["Gpart"][L] = torch.zeros(ns * (metas[L]["K"] + 1) * metas[L]["N"], **f32)
+        # ... summed over the tiles by a column-sum job of the grouped weight-gradient launch: the dense tail reads ONE value per
+        # element of the logits layer (summing the 256 per-tile partials itself was 16 dependent round trips of its 65 lanes --
+        # the long pole of the launch that sits between the products and the next tower)
+        tw["Glog_sum"] = torch.zeros((metas[L]["K"] + 1) * metas[L]["N"], **f32)
         pbase = self.P.data_ptr()
         carr = (capi.WdChainLayer * L)()
         tarr = (capi.WdTailLayer * (L + 1))()
@@ -452,6 +456,7 @@ class WideDeepEngine:
             t.beta_off = m["beta_off"] if "beta_off" in m else -1
             t.Gpart, t.nsplit, t.pk_tile = tw["Gpart"][l].data_ptr(), tw["nsplit"][l], rt
             if l == L:
+                t.Gpart, t.nsplit = tw["Glog_sum"].data_ptr(), 1
                 continue
             bn = "gamma_off" in m
             t.db_sum = tw["db_sum"][l].data_ptr()
@@ -863,18 +868,23 @@ class WideDeepEngine:
             # (split-K products) and the sums of the per-tile partials of the bias / BN gradients and of the loss
             # (column-sum jobs), all in grouped launches of at most WD_TN_GROUP_MAX jobs
             nblk = int(call("wd_tower_chain_blocks", B, self.chain_rt))
-            spec_jobs = []
+            spec_jobs, prod_jobs = [], []
             for l in range(L):    # largest product first: its workgroups start while the small ones fill the gaps
                 m = metas[l]
-                spec_jobs.append(dict(A=act.data_ptr() + 4 * tl.in_start[l], lda=tl.ld, B=tw["dzl"][l].data_ptr(), ldb=m["N"],
+                prod_jobs.append(dict(A=act.data_ptr() + 4 * tl.in_start[l], lda=tl.ld, B=tw["dzl"][l].data_ptr(), ldb=m["N"],
                                       C=tw["Gpart"][l].data_ptr(), M=m["K"], N=m["N"], K=B, nsplit=tw["nsplit"][l]))
+            # the column-sum jobs go FIRST: a handful of workgroups, each a chain of dependent round trips over the row tiles --
+            # at the end of the grid they would start last and finish after the products
             for l in range(L):
                 m = metas[l]
                 names = ("db", "dg", "dbeta") if "gamma_off" in m else ("db",)
                 for nm in names:
                     spec_jobs.append(dict(A=tw[nm + "_part"][l].data_ptr(), lda=m["N"], B=None, C=tw[nm + "_sum"][l].data_ptr(),
                                           N=m["N"], K=nblk))
+            nl = (metas[L]["K"] + 1) * metas[L]["N"]
+            spec_jobs.append(dict(A=tw["Gpart"][L].data_ptr(), lda=nl, B=None, C=tw["Glog_sum"].data_ptr(), N=nl, K=nblk))
             spec_jobs.append(dict(A=self.loss_part.data_ptr(), lda=1, B=None, C=self.loss.data_ptr(), N=1, K=nblk))
+            spec_jobs += prod_jobs
             for i0 in range(0, len(spec_jobs), capi.WD_TN_GROUP_MAX):
                 chunk = spec_jobs[i0: i0 + capi.WD_TN_GROUP_MAX]
                 jobs = (capi.WdTnJob * len(chunk))()

@@ -395,10 +395,21 @@ k_bce_loss_sum(const float *__restrict__ logit, const float *__restrict__ labels
                int64_t batch, float *__restrict__ loss_sum) {
   __shared__ float part[1024];
   float l = 0.f;
-  for (int64_t i = threadIdx.x; i < batch; i += 1024) {
-    const float x = logit[i], y = labels[i];
-    const float w = weights ? weights[i] : 1.0f;
-    l += w * (fmaxf(x, 0.f) - x * y + log1pf(expf(-fabsf(x))));
+  // eight examples per lane and trip, their loads in flight together (one example per trip was a chain of batch / 1024
+  // dependent round trips in a one-workgroup launch that sits on the step's critical path); the adds keep their order
+  for (int64_t i0 = threadIdx.x; i0 < batch; i0 += 8 * 1024) {
+    float x[8], y[8], w[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int64_t i = i0 + 1024 * k;
+      const bool live = i < batch;
+      x[k] = live ? logit[i] : 0.f;
+      y[k] = live ? labels[i] : 0.f;
+      w[k] = (live && weights) ? weights[i] : 1.0f;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      if (i0 + 1024 * k < batch) l += w[k] * (fmaxf(x[k], 0.f) - x[k] * y[k] + log1pf(expf(-fabsf(x[k]))));
   }
   part[threadIdx.x] = l;
   __syncthreads();

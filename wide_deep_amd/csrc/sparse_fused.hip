@@ -408,7 +408,14 @@ k_bucket_update(UpdArgs u, const int32_t *__restrict__ start, uint64_t *__restri
   if ((int)blockIdx.x == u.nb) {  // bias_weights: g = sum_b dlogit[b] (fixed-shape tree), dense FTRL
     if (!u.bias) return;
     float acc = 0.f;
-    for (int64_t i = t; i < u.batch; i += 256) acc += u.dlogit[i * u.ld_dlogit];
+    for (int64_t i0 = t; i0 < u.batch; i0 += 8 * 256) {      // eight loads in flight per trip, same order of adds
+      float v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = i0 + 256 * k < u.batch ? u.dlogit[(i0 + 256 * k) * u.ld_dlogit] : 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        if (i0 + 256 * k < u.batch) acc += v[k];
+    }
     redw[t] = acc;
     __syncthreads();
     for (int st = 128; st >= 1; st >>= 1) {

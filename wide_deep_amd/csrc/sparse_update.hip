@@ -136,7 +136,14 @@ __global__ void __launch_bounds__(1024) k_bias_ftrl(float *__restrict__ bias, co
                                                     int64_t batch, float lr, float l1, float l2) {
   __shared__ float red[16];
   float acc = 0.f;
-  for (int64_t i = threadIdx.x; i < batch; i += blockDim.x) acc += dlogit[i];
+  for (int64_t i0 = threadIdx.x; i0 < batch; i0 += 8 * (int64_t)blockDim.x) {      // eight loads in flight, same order of adds
+    float v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = i0 + k * (int64_t)blockDim.x < batch ? dlogit[i0 + k * (int64_t)blockDim.x] : 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      if (i0 + k * (int64_t)blockDim.x < batch) acc += v[k];
+  }
   for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
   __syncthreads();

@@ -120,19 +120,18 @@ k_embag_fwd_range(const float *__restrict__ emb, const wd_slot_t *__restrict__ s
 #pragma unroll
   for (int q = 0; q < BPG; ++q) {
     const float4 *__restrict__ tab = reinterpret_cast<const float4 *>(emb + s_emb_off[g[q]]);
-    int32_t j = j0[q] + 1;
-    for (; j + 4 <= j1[q]; j += 4) {   // multi-hot tail: 4 independent row reads in flight
-      const int32_t i0 = ids[j], i1 = ids[j + 1], i2 = ids[j + 2], i3 = ids[j + 3];
-      const float4 r0 = tab[(int64_t)i0 * LANES + lane], r1 = tab[(int64_t)i1 * LANES + lane];
-      const float4 r2 = tab[(int64_t)i2 * LANES + lane], r3 = tab[(int64_t)i3 * LANES + lane];
-      acc[q].x += r0.x; acc[q].y += r0.y; acc[q].z += r0.z; acc[q].w += r0.w;
-      acc[q].x += r1.x; acc[q].y += r1.y; acc[q].z += r1.z; acc[q].w += r1.w;
-      acc[q].x += r2.x; acc[q].y += r2.y; acc[q].z += r2.z; acc[q].w += r2.w;
-      acc[q].x += r3.x; acc[q].y += r3.y; acc[q].z += r3.z; acc[q].w += r3.w;
-    }
-    for (; j < j1[q]; ++j) {
-      const float4 r = tab[(int64_t)ids[j] * LANES + lane];
-      acc[q].x += r.x; acc[q].y += r.y; acc[q].z += r.z; acc[q].w += r.w;
+    // multi-hot tail: the ids of up to eight more occurrences in ONE round of loads, then their rows in one round, added in
+    // bag order (groups of four + a one-by-one remainder made a bag of 7 a chain of 9 dependent round trips)
+    for (int32_t j = j0[q] + 1; j < j1[q]; j += 8) {
+      int32_t iv[8];
+      float4 rv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) iv[u] = j + u < j1[q] ? ids[j + u] : 0;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) rv[u] = j + u < j1[q] ? tab[(int64_t)iv[u] * LANES + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (j + u < j1[q]) { acc[q].x += rv[u].x; acc[q].y += rv[u].y; acc[q].z += rv[u].z; acc[q].w += rv[u].w; }
     }
     const int32_t n = j1[q] - j0[q];
     if (n > 1) {  // combiner='mean'
@@ -205,19 +204,18 @@ __device__ __forceinline__ void embag_range_body(const float *__restrict__ emb, 
 #pragma unroll
   for (int q = 0; q < BPG; ++q) {
     const float4 *__restrict__ tab = reinterpret_cast<const float4 *>(emb + s_emb_off[g[q]]);
-    int32_t j = j0[q] + 1;
-    for (; j + 4 <= j1[q]; j += 4) {   // multi-hot tail: 4 independent row reads in flight
-      const int32_t i0 = ids[j], i1 = ids[j + 1], i2 = ids[j + 2], i3 = ids[j + 3];
-      const float4 r0 = tab[(int64_t)i0 * LANES + lane], r1 = tab[(int64_t)i1 * LANES + lane];
-      const float4 r2 = tab[(int64_t)i2 * LANES + lane], r3 = tab[(int64_t)i3 * LANES + lane];
-      acc[q].x += r0.x; acc[q].y += r0.y; acc[q].z += r0.z; acc[q].w += r0.w;
-      acc[q].x += r1.x; acc[q].y += r1.y; acc[q].z += r1.z; acc[q].w += r1.w;
-      acc[q].x += r2.x; acc[q].y += r2.y; acc[q].z += r2.z; acc[q].w += r2.w;
-      acc[q].x += r3.x; acc[q].y += r3.y; acc[q].z += r3.z; acc[q].w += r3.w;
-    }
-    for (; j < j1[q]; ++j) {
-      const float4 r = tab[(int64_t)ids[j] * LANES + lane];
-      acc[q].x += r.x; acc[q].y += r.y; acc[q].z += r.z; acc[q].w += r.w;
+    // multi-hot tail: the ids of up to eight more occurrences in ONE round of loads, then their rows in one round, added in
+    // bag order (groups of four + a one-by-one remainder made a bag of 7 a chain of 9 dependent round trips)
+    for (int32_t j = j0[q] + 1; j < j1[q]; j += 8) {
+      int32_t iv[8];
+      float4 rv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) iv[u] = j + u < j1[q] ? ids[j + u] : 0;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) rv[u] = j + u < j1[q] ? tab[(int64_t)iv[u] * LANES + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (j + u < j1[q]) { acc[q].x += rv[u].x; acc[q].y += rv[u].y; acc[q].z += rv[u].z; acc[q].w += rv[u].w; }
     }
     const int32_t n = j1[q] - j0[q];
     if (n > 1) {  // combiner='mean'
@@ -316,9 +314,16 @@ __device__ __forceinline__ void wide_body(const float *__restrict__ wide, const 
       if (!sl.wide) continue;
       const int64_t bag = b * S + s;
       const int32_t j0 = bag_offs[bag], j1 = bag_offs[bag + 1];
-      for (int32_t j = j0; j < j1; ++j) {
-        const int32_t id = ids[j];
-        if (id >= 0) acc += wide[(sl.row_base + id) * stride];   // id < 0: dropped exchange entry
+      for (int32_t j = j0; j < j1; j += 8) {      // eight ids, then their eight weights, each in one round of loads; adds in bag order
+        int32_t iv[8];
+        float wv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) iv[u] = j + u < j1 ? ids[j + u] : -1;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) wv[u] = iv[u] >= 0 ? wide[(sl.row_base + iv[u]) * stride] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (iv[u] >= 0) acc += wv[u];   // id < 0: dropped exchange entry
       }
     }
   }

@@ -202,6 +202,58 @@ def test_gemm_variants_match_torch_fp32():
             assert_close(G[K], dZ.double().sum(0), 1e-5, 2e-4, "TN ones row")
 
 
+@pytest.mark.parametrize("stream", ["1", "0"])
+def test_grouped_weight_gradient_products_streamed_and_tiled(stream):
+    """wd_gemm_tn_splitk_group in a process of its own with WD_TN_STREAM set (the library reads it once): see _tn_group_check."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", "import sys; sys.path.insert(0, %r); from tests.test_gpu_kernels import _tn_group_check; "
+                        "_tn_group_check(); print('TN-GROUP-OK')" % root], capture_output=True, text=True, timeout=600, cwd=root,
+                       env=dict(os.environ, WD_TN_STREAM=stream))
+    assert r.returncode == 0 and "TN-GROUP-OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+
+
+def _tn_group_check():
+    """wd_gemm_tn_splitk_group: the register-streamed kernel (csrc/mlp_tn.hip) on operands it can read as MFMA fragments -- even row
+    strides, odd widths, ragged last tiles, batches that are not a multiple of 16 or of 2, more splits than sets -- against fp64
+    torch, with column-sum jobs in the same launch, and the LDS-tiled kernel on what the streamed one refuses (odd strides)."""
+    import ctypes
+    from wide_deep_amd import capi
+    from wide_deep_amd.capi import call, ptr
+    from tests.helpers import assert_close
+    st = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator(device="cuda"); g.manual_seed(5)
+    cases = [   # (batch, [(K_l, N_l, lda, nsplit)])
+        (8192, [(429, 256, 896, 13), (256, 128, 896, 13), (128, 64, 896, 13)]),
+        (1000, [(77, 96, 80, 3), (64, 32, 64, 5)]),
+        (999, [(45, 34, 46, 2)]),              # odd batch, odd width (reads column 45 of its last pair), N not a tile multiple
+        (37, [(64, 64, 64, 4)]),               # two full sets + a masked one; splits without a set
+        (400, [(130, 66, 131, 4)]),            # odd stride: the LDS-tiled kernel
+    ]
+    for B, layers in cases:
+        jobs = (capi.WdTnJob * (len(layers) + 1))()
+        keep, exp = [], []
+        cs_src = torch.randn(B, 70, device="cuda", generator=g)
+        cs_out = torch.zeros(70, device="cuda")
+        jobs[0].A, jobs[0].lda, jobs[0].B, jobs[0].Cpart, jobs[0].N, jobs[0].K = ptr(cs_src), 70, None, ptr(cs_out), 70, B
+        for j, (K, N, lda, ns) in enumerate(layers):
+            A = torch.randn(B, lda, device="cuda", generator=g)
+            dZ = torch.randn(B, N, device="cuda", generator=g)
+            Gp = torch.full((ns, K, N), float("nan"), device="cuda")
+            q = jobs[j + 1]
+            q.A, q.lda, q.B, q.ldb, q.Cpart, q.M, q.N, q.K, q.nsplit, q.append_ones = ptr(A), lda, ptr(dZ), N, ptr(Gp), K, N, B, ns, 0
+            keep.append((A, dZ, Gp))
+            exp.append(A[:, :K].double().t() @ dZ.double())
+        call("wd_gemm_tn_splitk_group", jobs, len(layers) + 1, st)
+        torch.cuda.synchronize()
+        for (A, dZ, Gp), e, (K, N, lda, ns) in zip(keep, exp, layers):
+            assert not bool(torch.isnan(Gp).any()), "every partial of every split is written (B %d, layer %s)" % (B, (K, N))
+            assert_close(Gp.double().sum(0), e, 1e-5, 3e-4 * (B / 1000.0) ** 0.5, "TN group B %d layer %s" % (B, (K, N, lda, ns)))
+        assert_close(cs_out, cs_src.double().sum(0), 1e-5, 1e-4, "column-sum job beside the products")
+
+
 def test_a_identity_asymmetric_b_detects_transposes():
     from wide_deep_amd.capi import call, ptr
     st = torch.cuda.current_stream().cuda_stream

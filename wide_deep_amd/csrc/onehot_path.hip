@@ -1007,6 +1007,7 @@ extern "C" int wd_row_update(float *rec, int32_t rec_stride, int32_t dim, float 
   if (patch) { u.npairs = next->pairs; u.nx = next->x; u.nwv = next->wide_vals; u.nldx = next->ldx; }
   u.flat_blocks = (int32_t)wd::ceil_div(u.nnz * 4, 256);
   u.wt = wd::wt_mask() & WD_WT_ROW_UPDATE ? 1 : 0;
-  hipLaunchKernelGGL(k_row_update, dim3((unsigned)(u.flat_blocks + LONG_WORKERS + 1)), dim3(256), 0, wd::as_stream(stream), u);
+  static const int pad_lds = getenv("WD_UPD_LDS") ? atoi(getenv("WD_UPD_LDS")) : 0;   // diagnostics: extra LDS bytes = fewer workgroups per CU
+  hipLaunchKernelGGL(k_row_update, dim3((unsigned)(u.flat_blocks + LONG_WORKERS + 1)), dim3(256), (size_t)pad_lds, wd::as_stream(stream), u);
   return wd::check_launch("wd_row_update");
 }

@@ -116,3 +116,55 @@ def hash_tokens(engine, tb: TokenBatch):
     call("wd_hash_bucket", ptr(tb.bytes), ptr(tb.tok_offs), tb.ntok, None if tb.one_per_bag else ptr(tb.bag_offs),
          tb.B * plan.S, ptr(slots_dev), plan.S, ptr(tb.ids), st)
     return tb.batch
+
+
+def make_parsed_batch(plan, B, seed=20260925, mean_len=1, dist="uniform", pos_rate=0.03, weights=None):
+    """A synthetic batch in the form dataset.input_fn hands to the Featurizer (dataset.RawBatch: packed string tokens per
+    feature, float features, labels) -- for models whose columns need more than one hash per token: crossed columns over
+    multi-valued string features (BASELINE configs[3]; python/lib/build_estimator.py:138-155).  The string features are the
+    hash slots' (one decimal token per occurrence, lengths 1 + Poisson(mean_len - 1)); crosses read the same tokens.
+    Returns (RawBatch, hb) with hb = {"lens" [B, n_features], "raw" per feature, "dense", "labels"} for the oracle."""
+    from .dataset import PackedTokens, RawBatch
+    rng = np.random.default_rng(seed)
+    feats = []
+    for s in plan.slots:
+        if s.kind == "hash" and s.feature not in feats:
+            feats.append(s.feature)
+    nb = {s.feature: int(s.num_buckets) for s in plan.slots if s.kind == "hash"}
+    F = len(feats)
+    lens = bag_lengths(rng, B, F, mean_len)                        # [B, F]
+    toks, per_feat, base = [], [], 0
+    raw_of = {}
+    perm = None
+    for j, f in enumerate(feats):
+        n = int(lens[:, j].sum())
+        if dist == "uniform":
+            raw = (rng.random(n) * nb[f]).astype(np.int64)
+        elif dist == "zipf":
+            ranks = zipf_ranks(rng, n, nb[f])
+            if perm is None or len(perm) != nb[f]:
+                perm = np.random.default_rng(12345).permutation(nb[f])
+            raw = perm[ranks]
+        else:
+            raise ValueError(dist)
+        raw_of[f] = raw
+        ex = np.zeros(B + 1, dtype=np.int32)
+        np.cumsum(lens[:, j], out=ex[1:])
+        toks.append(raw)
+        per_feat.append((f, base, n, ex))
+        base += n
+    allraw = np.concatenate(toks) if toks else np.zeros(0, np.int64)
+    data, toffs = pack_decimal_tokens(allraw)
+    # the Featurizer's buffers end in one empty token (the '' a missing value parses to) and a NUL byte
+    tok_offs = np.concatenate([toffs, toffs[-1:]]).astype(np.int32)
+    tok_bytes = np.concatenate([data, np.zeros(1, np.uint8)])
+    cat = {f: PackedTokens(tok_bytes, tok_offs, b0, n, ex) for f, b0, n, ex in per_feat}
+    nd = len(plan.dense_cols)
+    dense = rng.standard_normal((B, nd)).astype(np.float32) if nd else None
+    floats = {d.feature: np.ascontiguousarray(dense[:, i]) for i, d in enumerate(plan.dense_cols)}
+    labels = (rng.random(B) < pos_rate).astype(np.float32)
+    w = None
+    if weights is not None:
+        w = np.where(labels > 0, np.float32(weights[0]), np.float32(weights[1])).astype(np.float32)
+    raw = RawBatch(B, cat, {}, floats, labels, w, tok_bytes, tok_offs)
+    return raw, {"B": B, "features": feats, "lens": lens, "raw": raw_of, "dense": dense, "labels": labels, "weights": w}

@@ -364,7 +364,6 @@ struct GroupArgs {
   int32_t colsum[MAX_TN_JOBS];      // job j is a column-sum job (B == NULL)
   int32_t nsplit[MAX_TN_JOBS];
   int32_t njobs;
-  int32_t split_xcd;                // all tiles of a split on ONE XCD (split z -> XCD z % 8)
 };
 
 template <int BK, bool VEC>
@@ -397,17 +396,15 @@ __global__ void __launch_bounds__(256) k_gemm_tn_group(GroupArgs G) {
     return;
   }
   const int nwg = g.tiles_m * g.tiles_n;
-  if (G.split_xcd) {
-    // Every tile of a split reads the same kchunk rows of A and B: with the whole split on one XCD (hardware: workgroup i
-    // runs on XCD i % 8, and a job's range starts at a multiple of 8) its L2 fetches each panel once -- 1.4 MB per split of
-    // C2's first layer -- instead of once per XCD that holds some of its tiles.
-    const int xcd = rem % wd::kXCDs, loc = rem / wd::kXCDs;
-    const int bz = xcd + wd::kXCDs * (loc / nwg);
-    if (bz >= G.nsplit[j]) return;
-    gemm_body<false, false, 2, BK, VEC, false>(g, loc % nwg, bz);
-    return;
-  }
-  gemm_body<false, false, 2, BK, VEC>(g, rem % nwg, rem / nwg);
+  // Every tile of a split reads the same kchunk rows of A and B: with the whole split on one XCD (hardware: workgroup i runs on
+  // XCD i % 8, and a job's range starts at a multiple of 8) its L2 fetches each panel once -- 1.4 MB per split of C2's first
+  // layer -- instead of once per XCD that holds some of its tiles.  (ONE instantiation of the body: a second one -- the tiles of
+  // a split spread over the XCDs, measured 1 % slower and switched off since round 4 -- carried its own static LDS slabs, 70 KB
+  // per workgroup where the kernel uses 35: two workgroups per CU instead of four, and 19 KB left for the row update beside it.)
+  const int xcd = rem % wd::kXCDs, loc = rem / wd::kXCDs;
+  const int bz = xcd + wd::kXCDs * (loc / nwg);
+  if (bz >= G.nsplit[j]) return;
+  gemm_body<false, false, 2, BK, VEC, false>(g, loc % nwg, bz);
 }
 
 
@@ -1121,7 +1118,7 @@ extern "C" int wd_gemm_tn_splitk_group(const wd_tn_job_t *jobs, int32_t njobs, w
   GroupArgs G{};
   bool vec = true;
   int total = 0;
-  const int split_xcd = 1;   // measured on one box, alternating: 0.1696 / 0.1717 / 0.1690 (tiles spread) vs 0.1686 / 0.1699 / 0.1669 ms/step
+  const int split_xcd = 1;   // all tiles of a split on ONE XCD (split z -> XCD z % 8); measured on one box, alternating: 0.1696 / 0.1717 / 0.1690 (tiles spread) vs 0.1686 / 0.1699 / 0.1669 ms/step
   for (int j = 0; j < njobs; ++j) {
     const wd_tn_job_t &q = jobs[j];
     GemmArgs &g = G.job[j];
@@ -1153,18 +1150,18 @@ extern "C" int wd_gemm_tn_splitk_group(const wd_tn_job_t *jobs, int32_t njobs, w
     G.count[j] = g.tiles_m * g.tiles_n * (split_xcd ? wd::kXCDs * (int)wd::ceil_div(q.nsplit, wd::kXCDs) : q.nsplit);
     total += (G.count[j] + 7) / 8 * 8;
   }
-  G.split_xcd = split_xcd;
   G.first[njobs] = total;
   G.njobs = njobs;
   // 32-deep slabs: 35 KB of LDS per workgroup instead of 70 -- the sparse update that runs beside this launch keeps
   // workgroups resident on the same CUs (WD_TN_BK=64 for the deeper slabs)
   static const bool bk64 = getenv("WD_TN_BK") && atoi(getenv("WD_TN_BK")) == 64;   // (16-deep slabs measured no better)
+  static const size_t pad = getenv("WD_TN_LDS") ? (size_t)atoi(getenv("WD_TN_LDS")) : 0;   // diagnostics: extra LDS bytes per workgroup (34816 = the 70 KB of rounds 2-4)
   if (bk64) {
     if (vec) hipLaunchKernelGGL((k_gemm_tn_group<kBK, true>), dim3((unsigned)total), dim3(256), 0, wd::as_stream(stream), G);
     else hipLaunchKernelGGL((k_gemm_tn_group<kBK, false>), dim3((unsigned)total), dim3(256), 0, wd::as_stream(stream), G);
   } else {
-    if (vec) hipLaunchKernelGGL((k_gemm_tn_group<32, true>), dim3((unsigned)total), dim3(256), 0, wd::as_stream(stream), G);
-    else hipLaunchKernelGGL((k_gemm_tn_group<32, false>), dim3((unsigned)total), dim3(256), 0, wd::as_stream(stream), G);
+    if (vec) hipLaunchKernelGGL((k_gemm_tn_group<32, true>), dim3((unsigned)total), dim3(256), pad, wd::as_stream(stream), G);
+    else hipLaunchKernelGGL((k_gemm_tn_group<32, false>), dim3((unsigned)total), dim3(256), pad, wd::as_stream(stream), G);
   }
   return wd::check_launch("wd_gemm_tn_splitk_group");
 }

@@ -437,6 +437,9 @@ __global__ void __launch_bounds__(NTHR, 2) k_tower_chain8(Args8 A) {
     ++nstamp;
   };
   stamp();
+  // (the same two workgroups also stamp the 100 MHz realtime clock at their start and end, [28] / [29] and [60] / [61]: cycle
+  // stamps over realtime = the shader clock this launch really ran at, scripts/sclk_probe.py)
+  if (g.stamps && (blockIdx.x == 0 || blockIdx.x == 100) && t == 0) g.stamps[(blockIdx.x ? 32 : 0) + 28] = wall_clock64();
   if (g.tile_stamps && t == 0) g.tile_stamps[2 * blockIdx.x] = wall_clock64();
   if (g.flags_prio) __builtin_amdgcn_s_setprio(3);
 
@@ -787,6 +790,10 @@ __global__ void __launch_bounds__(NTHR, 2) k_tower_chain8(Args8 A) {
     stage8<2>(A, s, lds + g.dz_off[0], nullptr, nullptr, g.dx, g.ld_dx, g.K0, nullptr, 0, af, fb, lds, b0, g.batch, true);
   }
   stamp();
+  if (g.stamps && (blockIdx.x == 0 || blockIdx.x == 100) && t == 0) {
+    g.stamps[(blockIdx.x ? 32 : 0) + 29] = wall_clock64();
+    g.stamps[(blockIdx.x ? 32 : 0) + 27] = (unsigned long long)(nstamp - 1);     // index of the last cycle stamp
+  }
 }
 
 // LDS layout: [x | dz_{L-1} .. dz_0 aliasing x] [a_0] [a_1] ... [BN + bias tables]   (rows of 33 floats)

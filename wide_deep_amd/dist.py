@@ -25,7 +25,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-from . import capi
+from . import capi, hipgraph
 from .capi import call, ptr
 from .engine import DeviceBatch, WideDeepEngine, _stream
 from .plan import CatSlot, FeaturePlan, ModelSpec, bucket_geometry
@@ -67,7 +67,7 @@ class _Segments:
         self.g = None
 
     def begin(self):
-        self.g = torch.cuda.CUDAGraph()
+        self.g = hipgraph.new_graph()
         # thread_local: the process group's watchdog thread polls events while we capture
         self.g.capture_begin(pool=self.pool, capture_error_mode="thread_local")
         self.mark = capi.NCALLS
@@ -710,7 +710,7 @@ class ShardedWideDeepEngine(WideDeepEngine):
             self._quiesce()
         bump = 3 if self.spec.model_type == "wide_deep" else 2
         if self._graph_mode() == "full":
-            graph = torch.cuda.CUDAGraph()
+            graph = hipgraph.new_graph()
             gs = self.global_step
             with torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local"):
                 if pre:
@@ -820,7 +820,7 @@ class ShardedStepGraph:
             raise capi.WdError("ShardedStepGraph: run one eager train step first (packed kernels, lazy allocations)")
         self.eng, self.n = eng, len(token_batches)
         self.stream = stream or torch.cuda.Stream()
-        self.graph = torch.cuda.CUDAGraph()
+        self.graph = hipgraph.new_graph()
         self._events = []
         self.stream.wait_stream(torch.cuda.current_stream())
         eng._quiesce()

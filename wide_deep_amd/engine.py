@@ -16,7 +16,7 @@ import os
 import numpy as np
 import torch
 
-from . import capi
+from . import capi, hipgraph
 from .capi import call, ptr
 from .plan import (BN_EPS, FeaturePlan, ModelSpec, OPT_SLOT_ODD, adam_pow_names, bucket_geometry, ftrl_l2_shrinkage, ftrl_lr_power, opt_params,
                    opt_slot_init, opt_slot_names, rmsprop_centered)
@@ -1280,7 +1280,7 @@ class WideDeepEngine:
                 self.train_step(bt)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        graph = torch.cuda.CUDAGraph()
+        graph = hipgraph.new_graph()
         with torch.cuda.graph(graph, stream=side):
             self.train_step(bt)
         self._graph = graph

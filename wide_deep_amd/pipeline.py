@@ -31,7 +31,7 @@ import os
 
 import torch
 
-from . import synth
+from . import hipgraph, synth
 from .engine import WideDeepEngine
 
 
@@ -73,7 +73,7 @@ class StepGraph:
         self.ids_input = ids_input
         self.first, self.lookahead, self.phase, self.primed = token_batches[0], lookahead, (phase[0], phase[1]), bool(primed)
         self.stream = stream or torch.cuda.Stream()
-        self.graph = torch.cuda.CUDAGraph()
+        self.graph = hipgraph.new_graph()
         if pipelined is None:
             pipelined = os.environ.get("WD_PIPELINE", "1") != "0"
         self.pipelined = bool(pipelined) and all(pipelined_ok(eng, tb) for tb in token_batches) and eng._folded
@@ -252,6 +252,13 @@ class StepGraph:
             with torch.cuda.stream(s_sp):
                 eng._prefetch_input(bt, s_sp.cuda_stream, sact(t))
 
+        # diagnostics (timing only, results are garbage): WD_DIAG_SKIP=sort,gather,update leaves those launches out of a REPLAYED
+        # step -- after the first batch of the graph, so that every buffer holds something -- to price what each costs the tower
+        skip = set(filter(None, os.environ.get("WD_DIAG_SKIP", "").split(",")))
+        if skip:
+            sort0, gather0 = sort_work, gather_work
+            sort_work = lambda t: sort0(t) if (t <= 1 or "sort" not in skip) else None
+            gather_work = lambda t: gather0(t) if (t <= 1 or "gather" not in skip) else None
         ev_upd = None
         if not self.primed:
             sort_work(0)

@@ -34,7 +34,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=8192, help="examples per GPU per step")
-    ap.add_argument("--config", default="c2", choices=["c2", "c3", "c4", "c5"])
+    ap.add_argument("--config", default="c2", choices=["c2", "c3", "c4", "c4-nocross", "c5"])
     ap.add_argument("--dist", default="uniform", choices=["uniform", "zipf"])
     ap.add_argument("--pool", type=int, default=32, help="distinct resident batches cycled through")
     ap.add_argument("--no-graph", action="store_true", help="launch kernels eagerly instead of hipGraph replay")
@@ -64,6 +64,9 @@ def parse():
     return ap.parse_args()
 
 
+C4_CROSSES = ((0, 1), (2, 3, 4))
+
+
 def make_spec(cfg):
     from wide_deep_amd.plan import criteo_spec
     if cfg == "c2":
@@ -79,9 +82,12 @@ def make_spec(cfg):
         # --tower-dtype fp32 runs the same shape on the exact-fp32 MFMA tower
         return criteo_spec(n_dense=13, n_sparse=26, buckets=1_000_000, dim=64, hidden=(1024, 512, 256, 128),
                            mode="dense", model_type="deep"), 1
-    # configs[3] shape on one GPU: multi-hot (avg 5 ids/slot), ResDnn, weight column
+    # BASELINE.json configs[3] on one GPU: multi-hot (avg 5 ids/slot), ResDnn, weight column -- and, "c4", its 200-bucket
+    # crossed columns over 2 and 3 slots ("200-bucket crosses over 2-3 slots each"; python/lib/build_estimator.py:
+    # 138-155; embedding_dim(200) = 4, so the deep input mixes two embedding widths).  "c4-nocross" = the workload rounds 1-4
+    # ran under the name c4
     return criteo_spec(n_dense=13, n_sparse=26, buckets=1_000_000, dim=16, hidden=(256, 128, 64), mode="resnet",
-                       use_weight_column=True), 5
+                       use_weight_column=True, crosses=C4_CROSSES if cfg == "c4" else (), cross_buckets=200), 5
 
 
 def event_time_ms(fn, iters):
@@ -109,7 +115,7 @@ def pmc_traffic(args, bt, plan):
     import csv, glob, shutil, subprocess, tempfile
     if shutil.which("rocprofv3") is None:
         return None, "rocprofv3 not on PATH"
-    env = dict(os.environ, GATHER_ITERS="20", GATHER_POOL="8", GATHER_CONFIG=args.config, GATHER_BATCH=str(args.batch),
+    env = dict(os.environ, GATHER_ITERS="20", GATHER_POOL="8", GATHER_CONFIG="c4-nocross" if args.config == "c4" else args.config, GATHER_BATCH=str(args.batch),
                GATHER_DIST=args.dist, TMPDIR="/tmp")
     raw, calib = {}, {}
     for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -313,16 +319,22 @@ def cpu_baseline(eng, host_batches, steps, B):
     # tokens packed ahead of the timed region, exactly as the GPU path receives them (resident, packed)
     packed = {}
     for hb in host_batches:
+        if "features" in hb:
+            continue
         data, offs = synth.pack_decimal_tokens(hb["raw"])
         packed[id(hb)] = (data, offs.astype(np.int64))
 
     def one(hb):
-        lens = hb["lens"]
-        slot_of = np.repeat(np.tile(np.arange(S), hb["B"]), lens.reshape(-1))
-        data, offs = packed[id(hb)]
-        fp = O.fingerprint64_batch(data, offs)
-        ids = (fp % np.asarray(nb, dtype=np.uint64)[slot_of]).astype(np.int64)
-        bag_offs = synth.offsets_from_lens(lens)
+        if "features" in hb:      # parsed batch (crossed columns): fingerprints + SparseCross of the oracle, then the step
+            from tests.helpers import parsed_batch_ids
+            ids, bag_offs = parsed_batch_ids(plan, hb)
+        else:
+            lens = hb["lens"]
+            slot_of = np.repeat(np.tile(np.arange(S), hb["B"]), lens.reshape(-1))
+            data, offs = packed[id(hb)]
+            fp = O.fingerprint64_batch(data, offs)
+            ids = (fp % np.asarray(nb, dtype=np.uint64)[slot_of]).astype(np.int64)
+            bag_offs = synth.offsets_from_lens(lens)
         w = None
         if eng.spec.use_weight_column:
             w = np.where(hb["labels"] > 0, eng.spec.pos_weight, eng.spec.neg_weight).astype(np.float32)
@@ -388,11 +400,16 @@ def parity_check(eng, spec, tb, hb, step_eager):
     bt = synth.hash_tokens(eng, tb)
     torch.cuda.synchronize()
     ids, offs = bt.ids.cpu().numpy()[: bt.nnz].copy(), bt.bag_offs.cpu().numpy()
-    data, toffs = synth.pack_decimal_tokens(hb["raw"])
-    nb = np.asarray([s.num_buckets for s in plan.slots], dtype=np.uint64)
-    slot_of = np.repeat(np.tile(np.arange(plan.S), hb["B"]), hb["lens"].reshape(-1))
-    want = (O.fingerprint64_batch(data, toffs.astype(np.int64)) % nb[slot_of]).astype(np.int64)
-    ids_ok = bool(np.array_equal(ids.astype(np.int64), want))
+    if "features" in hb:       # the device featurizer's ids (hash slots + crossed columns) against the oracle's
+        from tests.helpers import parsed_batch_ids
+        want, woffs = parsed_batch_ids(plan, hb)
+        ids_ok = bool(np.array_equal(offs[: len(woffs)], woffs) and np.array_equal(ids.astype(np.int64), want))
+    else:
+        data, toffs = synth.pack_decimal_tokens(hb["raw"])
+        nb = np.asarray([s.num_buckets for s in plan.slots], dtype=np.uint64)
+        slot_of = np.repeat(np.tile(np.arange(plan.S), hb["B"]), hb["lens"].reshape(-1))
+        want = (O.fingerprint64_batch(data, toffs.astype(np.int64)) % nb[slot_of]).astype(np.int64)
+        ids_ok = bool(np.array_equal(ids.astype(np.int64), want))
     co = CompactOracle(eng, [(ids, offs, hb["B"])])
     w = None
     if spec.use_weight_column:
@@ -573,7 +590,11 @@ def cpu_only(args):
     spec, mean_len = make_spec(args.config)
     B = args.batch
     eng = WideDeepEngine(spec, max_batch=B, max_nnz=B * 26 * (2 * mean_len + 2), seed=0)
-    hbs = [synth.make_raw_batch(eng.plan, B, seed=20260925 + i, mean_len=mean_len, dist=args.dist) for i in range(4)]
+    if any(s.kind == "cross" for s in spec.slots):
+        hbs = [synth.make_parsed_batch(eng.plan, B, seed=20260925 + i, mean_len=mean_len, dist=args.dist,
+                                       weights=(spec.pos_weight, spec.neg_weight))[1] for i in range(4)]
+    else:
+        hbs = [synth.make_raw_batch(eng.plan, B, seed=20260925 + i, mean_len=mean_len, dist=args.dist) for i in range(4)]
     print(json.dumps(cpu_baseline(eng, hbs, args.cpu_steps, B)), flush=True)
 
 
@@ -628,6 +649,9 @@ def main():
     from wide_deep_amd.engine import WideDeepEngine
 
     spec, mean_len = make_spec(args.config)
+    featurized = any(s.kind == "cross" for s in spec.slots)
+    if featurized and sharded:
+        raise SystemExit("bench.py --config c4 (crossed columns) runs on one GPU; --config c4-nocross takes --gpus N")
     tower_dtype = args.tower_dtype or ("fp16" if args.config == "c5" else "fp32")
     B = args.batch
     if args.scaling == "strong":
@@ -654,13 +678,33 @@ def main():
                                     # n = 213 k that is 26.6 k +- 152, so 1.1 leaves 17 sigma (round 3 shipped 1.3: 15 % more
                                     # bytes in every all-to-all and in the owner-side kernels that walk the padding)
                                     slack=args.slack if args.slack else (1.1 if args.dist == "uniform" else 1.2 if dedup_expected else 2.5))
+    elif featurized:
+        # crossed columns (BASELINE configs[3]): the batches go through the product's device featurizer (features.Featurizer:
+        # fingerprints, hash buckets, SparseCross) BEFORE the timed region -- its one host wait for the id count keeps it out of
+        # a hipGraph -- and the step is timed on the resident ids
+        from wide_deep_amd.features import Featurizer
+        from wide_deep_amd.plan import FeaturePlan
+        gp = FeaturePlan(spec)
+        parsed = [synth.make_parsed_batch(gp, B, seed=20260925 + 1000 * rank + i, mean_len=mean_len, dist=args.dist,
+                                          weights=(spec.pos_weight, spec.neg_weight) if spec.use_weight_column else None)
+                  for i in range(args.pool)]
+        eng = WideDeepEngine(spec, max_batch=B, max_nnz=int(1.02 * max(hb["nnz"] for _, hb in parsed)) + 1024, seed=0,
+                             tower_dtype=tower_dtype)
+        args.ids_input = True
     else:
         eng = WideDeepEngine(spec, max_batch=B, max_nnz=B * 26 * (2 * mean_len + 2), seed=0, tower_dtype=tower_dtype)
     plan = getattr(eng, "hash_plan", eng.plan)    # sharded: batches live in the GLOBAL id space
 
     # resident batch pool (raw tokens in HBM); distinct seeds per rank
     host_batches, dev_batches = [], []
-    for i in range(args.pool):
+    if featurized:
+        fz = Featurizer(eng, cross_padding="ragged")
+        for i, (raw, hb) in enumerate(parsed):
+            if i < 4:
+                host_batches.append(hb)
+            dev_batches.append(synth.FeaturizedBatch(fz.to_device(raw), hb))
+        del parsed
+    for i in range(0 if featurized else args.pool):
         hb = synth.make_raw_batch(plan, B, seed=20260925 + 1000 * rank + i, mean_len=mean_len, dist=args.dist)
         w = None
         if spec.use_weight_column:
@@ -668,7 +712,7 @@ def main():
         if i < 4:
             host_batches.append(hb)
         dev_batches.append(synth.TokenBatch(plan, hb, weights=w))
-    if args.ids_input:
+    if args.ids_input and not featurized:
         for tb in dev_batches:
             synth.hash_tokens(eng, tb)
     torch.cuda.synchronize()
@@ -799,12 +843,16 @@ def main():
                       "emb_dim 16, Dnn [256,128,64] BN+ReLU, wide FTRL + deep Adagrad, batch %d per GPU" % B,
                 "c3": "BASELINE configs[2] (C3) table: C2 with ONE 100M-row table (26 x 3,846,154 rows) on %d GPU(s), "
                       "batch %d per GPU" % (world, B),
-                "c4": "BASELINE configs[3] shape (C4) on %d GPU(s): multi-hot avg %d ids/slot, ResDnn, weight column"
-                      % (world, mean_len),
+                "c4": "BASELINE configs[3] (C4) on one GPU: multi-hot avg %d ids/slot (1 + Poisson(4), <= 32), 26 slots x 1M buckets + "
+                      "200-bucket crossed columns over slots (0,1) and (2,3,4) (ragged products: ~25 and ~125 ids per example), "
+                      "ResDnn [256,128,64], weight column 0.99 / 0.01, batch %d" % (mean_len, B),
+                "c4-nocross": "BASELINE configs[3] shape WITHOUT its crossed columns (the workload rounds 1-4 reported as C4) on %d "
+                              "GPU(s): multi-hot avg %d ids/slot, ResDnn, weight column" % (world, mean_len),
                 "c5": "BASELINE configs[4] (C5): deep-only DenseDnn [1024,512,256,128], emb_dim 64, %s tower, batch %d"
                       % (tower_dtype, B),
             }[args.config],
-            "global_batch": B * world, "ids": args.dist, "input": "pre-hashed ids" if args.ids_input else "raw string tokens (hashed in step)",
+            "global_batch": B * world, "ids": args.dist, "input": ("ids resident: produced before the timed region by the device featurizer (hash buckets + crossed columns)"
+                                                               if featurized else "pre-hashed ids" if args.ids_input else "raw string tokens (hashed in step)"),
             "hip_graph": bool(use_graph), "steps_per_graph": steps_per_run,
             "chained_graphs": bool(use_graph and run_steps_graph and chain),
             "table_layout": ("row records: %d B = [emb %d f32 | w z n -]" % (4 * eng.rec_stride, eng.emb.shape[1])

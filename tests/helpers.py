@@ -344,3 +344,41 @@ class ShardedCompactOracle(CompactOracle):
                         self._emb_rows(buf, si)
             if spec.has_wide and s.wide:
                 self._wide_rows(si)
+
+
+def parsed_batch_ids(plan, hb, cross_padding="ragged"):
+    """The oracle's ids of a synthetic parsed batch (wide_deep_amd.synth.make_parsed_batch): Fingerprint64 % buckets of every
+    token of the hash slots, SparseCross over the key features' fingerprints for the crossed slots (last key fastest, default
+    hash_key; python/lib/build_estimator.py:138-155), as ONE example-major bag CSR in the plan's slot order.
+    Returns (ids int64 [nnz], bag_offs int32 [B * S + 1])."""
+    from wide_deep_amd import synth
+    assert cross_padding == "ragged", "synthetic batches have no padded [B, Lmax] form (quirk C.16 is a property of the TSV path)"
+    B, feats = hb["B"], hb["features"]
+    fp, ex = {}, {}
+    for j, f in enumerate(feats):
+        data, toffs = synth.pack_decimal_tokens(hb["raw"][f])
+        fp[f] = O.fingerprint64_batch(data, toffs.astype(np.int64))
+        e = np.zeros(B + 1, dtype=np.int32)
+        np.cumsum(hb["lens"][:, j], out=e[1:])
+        ex[f] = e
+    per = []
+    for s in plan.slots:
+        if s.kind == "hash":
+            per.append(((fp[s.feature] % np.uint64(s.num_buckets)).astype(np.int64), ex[s.feature]))
+        elif s.kind == "cross":
+            assert all(k.kind == "string" for k in s.cross_keys)
+            ids, offs = O.cross_hash([(fp[k.feature], ex[k.feature]) for k in s.cross_keys], s.num_buckets)
+            per.append((ids.astype(np.int64), offs))
+        else:
+            raise NotImplementedError(s.kind)
+    S = plan.S
+    lens = np.stack([np.diff(o) for _, o in per], axis=1).astype(np.int64)          # [B, S]
+    bag_offs = np.zeros(B * S + 1, dtype=np.int64)
+    np.cumsum(lens.reshape(-1), out=bag_offs[1:])
+    out = np.zeros(int(bag_offs[-1]), dtype=np.int64)
+    for si, (ids, offs) in enumerate(per):
+        n = np.diff(offs).astype(np.int64)
+        b_of = np.repeat(np.arange(B), n)
+        within = np.arange(len(ids)) - np.repeat(offs[:-1].astype(np.int64), n)
+        out[bag_offs[b_of * S + si] + within] = ids
+    return out, bag_offs.astype(np.int32)

@@ -81,7 +81,33 @@ def _bit_identical(a, b):
     assert torch.equal(a.logit, b.logit) and torch.equal(a.loss, b.loss)
 
 
-def _fullsize(spec, B, mean_len, dist, n_steps, n_graph, tower_dtype="fp32", tol=FP32_TOL, seed=20260925):
+def _featurized(mk, spec, B, mean_len, dist, n_steps, seed):
+    """(engine, host batches, FeaturizedBatch list, [(ids, offs, B)]): synthetic parsed batches through features.Featurizer, the
+    device's ids checked bit-exact against the oracle's (tests/helpers.parsed_batch_ids)."""
+    from tests.helpers import parsed_batch_ids
+    from wide_deep_amd import synth
+    from wide_deep_amd.features import Featurizer
+    from wide_deep_amd.plan import FeaturePlan
+    gp = FeaturePlan(spec)
+    w = (spec.pos_weight, spec.neg_weight) if spec.use_weight_column else None
+    parsed = [synth.make_parsed_batch(gp, B, seed=seed + i, mean_len=mean_len, dist=dist, weights=w) for i in range(n_steps)]
+    eng = mk(int(1.02 * max(hb["nnz"] for _, hb in parsed)) + 1024)
+    fz = Featurizer(eng, cross_padding="ragged")
+    tbs, dev_ids = [], []
+    for raw, hb in parsed:
+        bt = fz.to_device(raw)
+        torch.cuda.synchronize()
+        ids, offs = bt.ids.cpu().numpy()[: bt.nnz].copy(), bt.bag_offs.cpu().numpy()
+        want, woffs = parsed_batch_ids(eng.plan, hb)
+        assert bt.nnz == hb["nnz"] == len(want)
+        assert np.array_equal(offs[: len(woffs)], woffs), "bag offsets differ from the oracle"
+        assert np.array_equal(ids.astype(np.int64), want), "featurizer ids (hash slots + crossed columns) differ from the oracle"
+        tbs.append(synth.FeaturizedBatch(bt, hb))
+        dev_ids.append((ids, offs, B))
+    return eng, [hb for _, hb in parsed], tbs, dev_ids
+
+
+def _fullsize(spec, B, mean_len, dist, n_steps, n_graph, tower_dtype="fp32", tol=FP32_TOL, seed=20260925, featurize=False):
     """n_steps eager steps on engine A, each against the re-synchronised oracle; engine B (same seed = same initial state)
     runs step 0 eagerly and the other steps as hipGraphs of n_graph steps -- the replay bench.py times -- and must end
     bit-identical to A."""
@@ -90,11 +116,18 @@ def _fullsize(spec, B, mean_len, dist, n_steps, n_graph, tower_dtype="fp32", tol
     from wide_deep_amd.engine import WideDeepEngine
     from wide_deep_amd.pipeline import StepGraph, step_eager
     S = len(spec.slots)
-    mk = lambda: WideDeepEngine(spec, max_batch=B, max_nnz=B * S * (2 * mean_len + 2), seed=0, tower_dtype=tower_dtype)
-    eng = mk()
-    hbs = [synth.make_raw_batch(eng.plan, B, seed=seed + i, mean_len=mean_len, dist=dist) for i in range(n_steps)]
-    tbs = [synth.TokenBatch(eng.plan, hb, weights=_weights(spec, hb)) for hb in hbs]
-    dev_ids = _hash_and_check(eng, tbs, hbs)
+    if featurize:
+        mkn = lambda nnz: WideDeepEngine(spec, max_batch=B, max_nnz=nnz, seed=0, tower_dtype=tower_dtype)
+        eng, hbs, tbs, dev_ids = _featurized(mkn, spec, B, mean_len, dist, n_steps, seed)
+        mk = lambda: mkn(eng.max_nnz)
+        step_eager_ = lambda e, tb: step_eager(e, tb, True)
+    else:
+        mk = lambda: WideDeepEngine(spec, max_batch=B, max_nnz=B * S * (2 * mean_len + 2), seed=0, tower_dtype=tower_dtype)
+        eng = mk()
+        hbs = [synth.make_raw_batch(eng.plan, B, seed=seed + i, mean_len=mean_len, dist=dist) for i in range(n_steps)]
+        tbs = [synth.TokenBatch(eng.plan, hb, weights=_weights(spec, hb)) for hb in hbs]
+        dev_ids = _hash_and_check(eng, tbs, hbs)
+        step_eager_ = step_eager
     co = CompactOracle(eng, dev_ids)
     touched = co.touched_mask()
     emb0 = eng.emb.clone() if eng.emb is not None else None
@@ -104,7 +137,7 @@ def _fullsize(spec, B, mean_len, dist, n_steps, n_graph, tower_dtype="fp32", tol
     for i in range(n_steps):
         co.resync()
         with torch.cuda.stream(side):
-            loss = step_eager(eng, tbs[i])
+            loss = step_eager_(eng, tbs[i])
         torch.cuda.synchronize()
         ids, offs, _ = dev_ids[i]
         ob = co.batch(ids, offs, B, hbs[i]["dense"], hbs[i]["labels"], _weights(spec, hbs[i]))
@@ -127,11 +160,12 @@ def _fullsize(spec, B, mean_len, dist, n_steps, n_graph, tower_dtype="fp32", tol
     del emb0, wide0, co, free
     # ---- the replay bench.py times: n_graph steps per hipGraph, each on its own batch, on a twin engine ----------------
     twin = mk()
-    tbs2 = [synth.TokenBatch(twin.plan, hb, weights=_weights(spec, hb)) for hb in hbs]
+    # (featurized batches are inputs only: the twin trains on the same resident ids)
+    tbs2 = tbs if featurize else [synth.TokenBatch(twin.plan, hb, weights=_weights(spec, hb)) for hb in hbs]
     with torch.cuda.stream(side):
-        step_eager(twin, tbs2[0])
+        step_eager_(twin, tbs2[0])
     torch.cuda.synchronize()
-    graphs = [StepGraph(twin, tbs2[j: j + n_graph], stream=side) for j in range(1, n_steps, n_graph)]
+    graphs = [StepGraph(twin, tbs2[j: j + n_graph], ids_input=featurize, stream=side) for j in range(1, n_steps, n_graph)]
     for g in graphs:
         g.replay()
     torch.cuda.synchronize()
@@ -230,10 +264,26 @@ def test_c3_100m_row_table_one_gpu_matches_oracle():
 
 
 def test_c4_full_size_multi_hot_resnet_weights_matches_oracle():
+    """configs[3] WITHOUT its crossed columns (what rounds 1-4 ran as C4): raw tokens hashed in the step."""
     from wide_deep_amd.plan import criteo_spec
     spec = criteo_spec(n_dense=13, n_sparse=26, buckets=1_000_000, dim=16, hidden=(256, 128, 64), mode="resnet",
                        use_weight_column=True)
     _fullsize(spec, 8192, 5, "zipf", n_steps=3, n_graph=2)
+
+
+def test_c4_full_size_with_crossed_columns_matches_oracle():
+    """BASELINE configs[3] as stated, at size: batch 8192, 26 multi-hot slots (mean 5) x 1M buckets + two 200-bucket crossed
+    columns over 2 and 3 of the slots (python/lib/build_estimator.py:138-155; ~25 and ~125 cross ids per example, 2.3 M ids per
+    batch), ResDnn, weight column.  The batch goes through the product's device featurizer (features.Featurizer: Fingerprint64,
+    hash buckets, SparseCross with the last key fastest) -- ids and bag offsets BIT-EXACT against the oracle's fingerprints and
+    cross hash -- then every step against the re-synchronised oracle, then the hipGraph replay against the eager twin."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    spec, mean_len = bench.make_spec("c4")
+    assert sorted(s.num_buckets for s in spec.slots if s.kind == "cross") == [200, 200]
+    eng = _fullsize(spec, 8192, mean_len, "uniform", n_steps=3, n_graph=2, featurize=True)
+    assert len(eng.plan.emb_groups) == 2      # embedding_dim(200) = 4 beside the slots' 16
 
 
 def test_c5_full_size_fp16_tower_matches_oracle():

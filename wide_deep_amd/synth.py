@@ -103,8 +103,18 @@ class TokenBatch:
             self.batch.ids_cols = torch.zeros(max(self.ntok, 1), dtype=torch.int32, device=device)
 
 
-def hash_tokens(engine, tb: TokenBatch):
+class FeaturizedBatch:
+    """A synthetic batch whose ids the Featurizer has already produced (features.Featurizer.to_device on a make_parsed_batch
+    batch: hash slots AND crossed columns) -- stands where a TokenBatch stands (`.batch`), with nothing left to hash."""
+
+    def __init__(self, batch, host):
+        self.batch, self.B, self.host = batch, batch.B, host
+
+
+def hash_tokens(engine, tb):
     """tokens -> ids on the device (wd_hash_bucket): a4 of SURVEY section 8."""
+    if isinstance(tb, FeaturizedBatch):
+        return tb.batch
     plan = getattr(engine, "hash_plan", engine.plan)            # sharded engines hash in the global id space
     slots_dev = getattr(engine, "hash_slots_dev", engine.slots_dev)
     st = torch.cuda.current_stream().cuda_stream
@@ -167,4 +177,11 @@ def make_parsed_batch(plan, B, seed=20260925, mean_len=1, dist="uniform", pos_ra
     if weights is not None:
         w = np.where(labels > 0, np.float32(weights[0]), np.float32(weights[1])).astype(np.float32)
     raw = RawBatch(B, cat, {}, floats, labels, w, tok_bytes, tok_offs)
-    return raw, {"B": B, "features": feats, "lens": lens, "raw": raw_of, "dense": dense, "labels": labels, "weights": w}
+    nnz = 0          # ids the Featurizer will emit (ragged crosses: the product of the key features' counts per example)
+    col = {f: j for j, f in enumerate(feats)}
+    for s in plan.slots:
+        if s.kind == "hash":
+            nnz += int(lens[:, col[s.feature]].sum())
+        elif s.kind == "cross":
+            nnz += int(np.prod(np.stack([lens[:, col[k.feature]] for k in s.cross_keys], axis=1), axis=1).sum())
+    return raw, {"B": B, "features": feats, "lens": lens, "raw": raw_of, "dense": dense, "labels": labels, "weights": w, "nnz": nnz}

@@ -51,7 +51,7 @@ def parse():
     ap.add_argument("--cpu-only", action="store_true",
                     help="print only the cpu_baseline object of the workload (what an N > 1 run launches as a child of rank 0)")
     ap.add_argument("--ids-input", action="store_true", help="feed pre-hashed ids (skips the hash kernel)")
-    ap.add_argument("--repeats", type=int, default=5,
+    ap.add_argument("--repeats", type=int, default=9,
                     help="the K timed steps are measured this many times back to back (each bracketed by barrier + synchronize); "
                          "`value` is the median, all of them are printed in `repeats_ms_per_step`")
     ap.add_argument("--slack", type=float, default=0.0,
@@ -835,6 +835,7 @@ def main():
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
         "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
         "repeats_ms_per_step": [round(r / args.steps * 1e3, 4) for r in reps],
+        "ms_per_step_min_median_max": [round(x / args.steps * 1e3, 4) for x in (min(reps), elapsed, max(reps))],
         "dtype": "f32" if tower_dtype == "fp32" else "f16 tower operands, f32 accumulate / embeddings / optimizer state",
         "data": "synthetic",
         "config": {

@@ -9,7 +9,7 @@ a dense [n][16] matrix (the contract's bytes: n * 64 read + n * 4 ids + n * 64 w
   batches  1 .. 16 per launch
 
 HIP events over back-to-back launches on fresh id sets; GC_ONLY="<layout>,<order>,<batches>,<mode>" runs one cell (for rocprofv3
---pmc passes: scripts/gpu_r4_gather_pmc.sh)."""
+--pmc passes: profiles/run_scripts/gpu_r4_gather_pmc.sh)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

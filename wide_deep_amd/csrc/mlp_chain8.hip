@@ -112,7 +112,7 @@ __device__ __forceinline__ void mma_unit(const float *__restrict__ inA, gw_t Wl,
                                          const float *__restrict__ sA, const float *__restrict__ tA, int lane) {
   // Wl / Wn: UNIFORM pointers (scalar registers); the lane offset is added at the load
 #ifndef WD_CHAIN8_EXP
-#define WD_CHAIN8_EXP 0   // diagnostics (scripts/build_chain8_exp.sh), bits: 1 no MFMAs, 2 no weight loads in the loop, 4 A fragments
+#define WD_CHAIN8_EXP 0   // diagnostics (profiles/run_scripts/build_chain8_exp.sh), bits: 1 no MFMAs, 2 no weight loads in the loop, 4 A fragments
 #endif                    // read once, 8 no HBM stores in the epilogues, 16 two accumulators alternate (no dependent MFMA chain), 32 no ring_complete
   float fa[2][4], fs[2][4], ft[2][4];
   floatx16 acc2;

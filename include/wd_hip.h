@@ -60,8 +60,12 @@ typedef struct wd_slot {
    * rows get bucket_shift 0 (ONE row per bucket: its occurrences need no sort), big tables ~64 occurrences a bucket. */
   int32_t bucket_shift;
   int32_t bucket_base;
-  int32_t pad_;
+  int32_t flags;       /* WD_SLOT_F_*; 0 in the tables every entry point but the ones named there takes */
 } wd_slot_t;
+
+/* wd_slot_t.flags bit 0: the column is handled by wd_small_tables_fwd / _bwd (csrc/small_tables.hip); wd_wide_fwd and
+ * wd_sparse_bucketize treat its bags as empty when they are handed a slot table that carries the flag. */
+#define WD_SLOT_F_SMALL 1
 
 #define WD_SLOT_NONE 0      /* wide-only categorical column (bucketized, cross with is_deep=0) */
 #define WD_SLOT_EMBEDDING 1 /* embedding_column(combiner='mean')   build_estimator.py:90-97,157 */
@@ -743,6 +747,27 @@ int wd_diag_access(float *const *base, const int64_t *stride_bytes, const int32_
 
 /* misc plumbing */
 int wd_fill_f32(float *p, float v, int64_t n, wd_stream_t stream);
+
+/* ---- a7 / a8 / a12 for categorical columns whose whole table fits in LDS and whose bags are long: crossed columns over
+ * multi-valued keys (python/lib/build_estimator.py:138-155: a bag holds the product of its keys' counts), their
+ * embedding_column(combiner='mean') and linear_model weight, Adagrad / Ftrl with IndexedSlices semantics (joint.py:224-262).
+ * small_idx[nsmall]: slot numbers (device); max_rows / max_dim over those slots, max_rows * (max_dim + 2) <=
+ * WD_SMALL_MAX_FLOATS, max_dim <= 16.  Separate tables only (emb flat, wide [rows][4] = {w, z, n, -}).
+ *   wd_small_tables_fwd: x[b][out_col ..] = mean of the bag's rows; wide_logit[b] += sum of the bag's wide weights -- call it
+ *     BEHIND wd_wide_fwd on the same stream (that launch writes bias + the other columns).
+ *   wd_small_tables_bwd: per slot, count x (dx / len | dlogit) summed per row in ascending example order (integer histograms in
+ *     LDS, no sort, no float atomics), then Adagrad (embedding rows) / Ftrl ({w, z, n}) on the rows the batch holds.
+ *     ws: wd_small_tables_ws_floats(nsmall, max_rows, max_dim, max_batch) floats. */
+#define WD_SMALL_MAX_FLOATS 8192
+#define WD_SMALL_BAGS_PER_SLICE 64
+int64_t wd_small_tables_ws_floats(int32_t nsmall, int32_t max_rows, int32_t max_dim, int64_t max_batch);
+int wd_small_tables_fwd(const float *emb, const float *wide, const wd_slot_t *slots, int32_t S, const int32_t *small_idx,
+                        int32_t nsmall, int32_t max_rows, int32_t max_dim, const int32_t *ids, const int32_t *bag_offs,
+                        int64_t batch, float *x, int64_t ldx, float *wide_logit, wd_stream_t stream);
+int wd_small_tables_bwd(float *emb, float *emb_accum, float *wide_wzn, const wd_slot_t *slots, int32_t S,
+                        const int32_t *small_idx, int32_t nsmall, int32_t max_rows, int32_t max_dim, const int32_t *ids,
+                        const int32_t *bag_offs, int64_t batch, const float *dx, int64_t ldx, const float *dlogit, float lr_emb,
+                        float lr_wide, float l1, float l2, float *ws, int64_t ws_floats, wd_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -105,3 +105,48 @@ def test_c4_shape_through_conf_path_matches_oracle(tmp_path, monkeypatch, paddin
         assert_close(eng.logit[: raw.B], ologits, 2e-4, 2e-5, "logits step %d" % step)
         assert abs(loss - oloss) <= 2e-4 * max(1.0, abs(oloss)), (step, loss, oloss)
     assert k == len(lines)
+
+
+@pytest.mark.parametrize("dims", [(16, 4), (8, 8)])
+def test_small_table_path_trains_like_the_general_path_and_the_oracle(monkeypatch, dims):
+    """Crossed columns (200 / 37 buckets over 2 and 3 multi-hot slots, one of them wide-only) through csrc/small_tables.hip
+    (tables in LDS, bags counted, no sort) against the SAME model on the general bucketed path (WD_SMALL_TABLES=0) and against
+    the oracle: three steps, empty bags, a bag longer than a workgroup, batch not a multiple of the slice / workgroup sizes."""
+    from tests.helpers import assert_close, oracle_batch, oracle_from_engine, parsed_batch_ids
+    from wide_deep_amd import synth
+    from wide_deep_amd.engine import WideDeepEngine
+    from wide_deep_amd.features import Featurizer
+    from wide_deep_amd.plan import CatSlot, CrossKey, FeaturePlan, criteo_spec
+    B = 203
+    spec = criteo_spec(n_dense=3, n_sparse=5, buckets=5000, dim=dims[0], hidden=(32, 16), mode="resnet", crosses=((0, 1), (2, 3, 4)),
+                       cross_buckets=200, use_weight_column=True)
+    for s in spec.slots:
+        if s.kind == "cross":
+            s.dim = dims[1]
+    spec.slots.append(CatSlot(name="C01_X_C04", kind="cross", num_buckets=37, deep=None, dim=0, wide=True,
+                              cross_keys=[CrossKey("C04", "string"), CrossKey("C01", "string")]))
+    gp = FeaturePlan(spec)
+    parsed = [synth.make_parsed_batch(gp, B, seed=50 + i, mean_len=4, weights=(0.99, 0.01), pos_rate=0.3) for i in range(3)]
+    nnz = max(hb["nnz"] for _, hb in parsed) + 64
+    monkeypatch.setenv("WD_SMALL_TABLES", "0")
+    gen = WideDeepEngine(spec, max_batch=256, max_nnz=nnz, seed=4)
+    monkeypatch.setenv("WD_SMALL_TABLES", "cross")
+    eng = WideDeepEngine(spec, max_batch=256, max_nnz=nnz, seed=4)
+    assert not gen.small_idx and len(eng.small_idx) == 3 and eng.rec is None
+    ora = oracle_from_engine(eng)
+    fz, fzg = Featurizer(eng, cross_padding="ragged"), Featurizer(gen, cross_padding="ragged")
+    for step, (raw, hb) in enumerate(parsed):
+        bt, btg = fz.to_device(raw), fzg.to_device(raw)
+        assert not bt.one_hot and eng._small_on(bt)
+        ids, offs = parsed_batch_ids(eng.plan, hb)
+        assert np.array_equal(bt.ids.cpu().numpy()[: bt.nnz].astype(np.int64), ids)
+        loss, lossg = float(eng.train_step(bt)), float(gen.train_step(btg))
+        torch.cuda.synchronize()
+        oloss, ologits = ora.train_step(oracle_batch(eng.plan, ids, offs, B, hb["dense"], hb["labels"], hb["weights"]))
+        assert_close(eng.logit[:B], ologits, 2e-4, 2e-5, "logits vs oracle, step %d" % step)
+        assert_close(eng.logit[:B], gen.logit[:B], 2e-4, 2e-5, "logits vs the general path, step %d" % step)
+        assert abs(loss - oloss) <= 2e-4 * max(1.0, abs(oloss)) and abs(loss - lossg) <= 2e-4 * max(1.0, abs(lossg))
+    a, g = eng.export_state(), gen.export_state()
+    for k in a:
+        if a[k].dtype.is_floating_point:
+            assert_close(a[k], g[k], 5e-4, 1e-5, "state %s vs the general path" % k)

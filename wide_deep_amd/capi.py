@@ -16,6 +16,8 @@ WD_MAX_CROSS_KEYS = 8
 WD_FOLD_PARTS = 16
 
 SLOT_NONE, SLOT_EMBEDDING, SLOT_INDICATOR = 0, 1, 2
+SLOT_F_SMALL = 1              # wd_slot_t.flags (include/wd_hip.h)
+SMALL_MAX_FLOATS = 8192       # WD_SMALL_MAX_FLOATS
 
 ACT_IDS = {
     None: 0, "none": 0, "relu": 1, "sigmoid": 2, "tanh": 3, "relu6": 4, "leaky_relu": 5, "elu": 6, "selu": 7,
@@ -34,7 +36,7 @@ class WdSlot(ctypes.Structure):
         ("wide", ctypes.c_int32),
         ("bucket_shift", ctypes.c_int32),
         ("bucket_base", ctypes.c_int32),
-        ("pad_", ctypes.c_int32),
+        ("flags", ctypes.c_int32),
     ]
 
 
@@ -173,6 +175,9 @@ _PROTOS = {
     "wd_indicator_fwd": [P, I32, P, I32, P, P, I64, P, I64, P],
     "wd_dense_fwd": [P, I64, P, I32, I64, P, I64, P],
     "wd_wide_fwd": [P, I32, P, P, I32, P, P, I64, P, P],
+    "wd_small_tables_ws_floats": [I32, I32, I32, I64],
+    "wd_small_tables_fwd": [P, P, P, I32, P, I32, I32, I32, P, P, I64, P, I64, P, P],
+    "wd_small_tables_bwd": [P, P, P, P, I32, P, I32, I32, I32, P, P, I64, P, I64, P, F32, F32, F32, F32, P, I64, P],
     "wd_bce_sum_fwd_bwd": [P, P, P, P, I64, P, P, P, P, P],
     "wd_bce_loss_sum": [P, P, P, I64, P, P],
     "wd_sort_workspace_bytes": [I64, I32],
@@ -238,7 +243,7 @@ _PROTOS = {
     "wd_diag_gather_modes": [P, I64, P, I64, I32, P, P],
     "wd_diag_access": [P, P, P, I32, P, I64, I32, I32, P, P],
 }
-_RESTYPES = {"wd_build_stamp": ctypes.c_char_p, "wd_prefetch_onehot_blocks": I64, "wd_feat_offsets_workspace_bytes": I64, "wd_sort_workspace_bytes": SZ, "wd_logits_head_blocks": I64, "wd_tower_chain_lds_bytes": I64, "wd_tower_chain_blocks": I64, "wd_bucket_max": I32, "wd_bucket_chunks": I32, "wd_route_chunks": I32}
+_RESTYPES = {"wd_build_stamp": ctypes.c_char_p, "wd_prefetch_onehot_blocks": I64, "wd_feat_offsets_workspace_bytes": I64, "wd_sort_workspace_bytes": SZ, "wd_logits_head_blocks": I64, "wd_tower_chain_lds_bytes": I64, "wd_tower_chain_blocks": I64, "wd_bucket_max": I32, "wd_bucket_chunks": I32, "wd_route_chunks": I32, "wd_small_tables_ws_floats": I64}
 
 EXPORTED_SYMBOLS = sorted(list(_PROTOS) + ["wd_last_error"])
 

@@ -311,7 +311,7 @@ __device__ __forceinline__ void wide_body(const float *__restrict__ wide, const 
   if (b < batch) {
     for (int32_t s = lane; s < S; s += 16) {
       const wd_slot_t sl = slots[s];
-      if (!sl.wide) continue;
+      if (!sl.wide || (sl.flags & WD_SLOT_F_SMALL)) continue;     // (small tables: wd_small_tables_fwd adds their share)
       const int64_t bag = b * S + s;
       const int32_t j0 = bag_offs[bag], j1 = bag_offs[bag + 1];
       for (int32_t j = j0; j < j1; j += 8) {      // eight ids, then their eight weights, each in one round of loads; adds in bag order

@@ -1,0 +1,279 @@
+// wide_deep_amd/csrc/small_tables.hip -- categorical columns whose whole table fits in LDS and whose bags are LONG: the crossed
+// columns of python/lib/build_estimator.py:138-155 (tf.feature_column.crossed_column over multi-valued keys: a bag holds the
+// PRODUCT of its keys' counts -- ~25 / ~125 ids per example for BASELINE configs[3]'s crosses over 2 / 3 slots of mean 5 -- hashed
+// into a few hundred buckets), their embedding_column (combiner='mean', dnn.py:83-90 input_layer) and linear_model weight
+// (linear.py:29-36), with the reference's optimizers on them (joint.py:224-262: Adagrad on the dnn scope, Ftrl on linear; sparse
+// IndexedSlices semantics: a row moves once per step, by the sum of its occurrences' gradients, only if the batch holds it).
+//
+// The general path (sparse_fused.hip) sorts occurrences into row-range buckets; a 200-row table that a batch hits 1.2 M times is
+// its worst case -- every row a "long segment" of ~5 k occurrences, and the order-stable histogram of one-row buckets walks the
+// longest bag of every 256 in lock-step: 1.9 of the 2.0 ms of a configs[3] step (profiles/r5_c4_crosses_kernel_stats_before.md).
+// Here the table never leaves the CU:
+//   k_small_fwd    a workgroup takes 32 examples; per small slot it loads the table (+ wide weights) into LDS, then one
+//                  wavefront per bag: lanes stride over the ids, add rows from LDS, meet in a fixed shuffle tree; mean -> x,
+//                  wide sum -> added to the wide logit once per example (slot order, no atomics).
+//   k_small_bwd    (slice of the batch, slot) per workgroup, bags in ascending order: the bag's ids are COUNTED into an LDS
+//                  histogram (integer atomics: exact, order-free), then the owner thread of every row adds
+//                  count x (dx / len | dlogit) to its partial sums in LDS -- a fixed order of float adds, no sort, no float atomic;
+//                  one barrier per bag (histograms double-buffered).  Partials + hit counts go to HBM per slice.
+//   k_small_apply  per slot: partials summed in slice order, Adagrad on the embedding rows / Ftrl on {w, z, n} of the rows
+//                  the batch touched.
+#include "common.h"
+
+namespace {
+
+constexpr int SM_MAX_DIM = 16;
+constexpr int SM_EX_PER_WG = 32;      // forward: examples per workgroup (8 per wavefront)
+
+struct SmallArgs {
+  const wd_slot_t *slots;
+  const int32_t *small_idx;   // [nsmall] slot numbers
+  int32_t nsmall, S;
+  const int32_t *ids, *bag_offs;
+  int64_t batch;
+  // forward
+  const float *emb, *wide;
+  float *x;
+  int64_t ldx;
+  float *wide_logit;
+  // backward
+  const float *dx, *dlogit;
+  float *part;                // [nsmall][nslice][part_rows][D_max + 2]  (g_0 .. g_{D-1}, g_wide, count)
+  int32_t nslice, part_rows, part_w;
+  int64_t bags_per_slice;
+  // apply
+  float *emb_w, *emb_acc, *wide_w;
+  float lr_emb, lr_w, l1, l2;
+};
+
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+__device__ __forceinline__ float wave_sum(float v) {     // fixed-shape tree over the 64 lanes
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+  return v;
+}
+
+__global__ void __launch_bounds__(256) k_small_fwd(SmallArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];     // table [R][D] then wide weights [R]
+  const int t = threadIdx.x, lane = t & 63, wave = uni(t >> 6);
+  const int64_t b0 = (int64_t)blockIdx.x * SM_EX_PER_WG + wave * (SM_EX_PER_WG / 4);
+  float wsum[SM_EX_PER_WG / 4];
+#pragma unroll
+  for (int e = 0; e < SM_EX_PER_WG / 4; ++e) wsum[e] = 0.f;
+  bool any_wide = false;
+  for (int k = 0; k < a.nsmall; ++k) {
+    const int s = uni(a.small_idx[k]);
+    const wd_slot_t sl = a.slots[s];
+    const int R = uni(sl.num_buckets), D = uni(sl.dim);
+    float *T = lds, *W = lds + (int64_t)R * D;
+    __syncthreads();                         // the previous slot's table is no longer read
+    if (D > 0)
+      for (int i = t; i < R * D; i += 256) T[i] = a.emb[sl.emb_off + i];
+    if (sl.wide)
+      for (int i = t; i < R; i += 256) W[i] = a.wide[(sl.row_base + i) * 4];
+    __syncthreads();
+    any_wide = any_wide || sl.wide;
+#pragma unroll
+    for (int e = 0; e < SM_EX_PER_WG / 4; ++e) {
+      const int64_t b = b0 + e;
+      if (b >= a.batch) break;
+      const int64_t bag = b * a.S + s;
+      const int32_t j0 = a.bag_offs[bag], j1 = a.bag_offs[bag + 1];
+      float acc[SM_MAX_DIM];
+#pragma unroll
+      for (int d = 0; d < SM_MAX_DIM; ++d) acc[d] = 0.f;
+      float ws = 0.f, cnt = 0.f;
+      for (int32_t j = j0 + lane; j < j1; j += 64) {
+        const int32_t id = a.ids[j];
+        if (id < 0) continue;
+        cnt += 1.f;
+        if (sl.wide) ws += W[id];
+#pragma unroll
+        for (int d = 0; d < SM_MAX_DIM; ++d)
+          if (d < D) acc[d] += T[id * D + d];
+      }
+      cnt = wave_sum(cnt);
+      if (sl.wide) wsum[e] += wave_sum(ws);
+      if (D > 0 && sl.out_col >= 0) {
+#pragma unroll
+        for (int d = 0; d < SM_MAX_DIM; ++d) {
+          if (d < D) {
+            float v = wave_sum(acc[d]);
+            if (cnt > 1.f) v = v / cnt;              // combiner='mean' (an empty bag stays the zero vector)
+            if (lane == 0) a.x[b * a.ldx + sl.out_col + d] = v;
+          }
+        }
+      }
+    }
+  }
+  if (any_wide && a.wide_logit && lane == 0) {
+#pragma unroll
+    for (int e = 0; e < SM_EX_PER_WG / 4; ++e)
+      if (b0 + e < a.batch) a.wide_logit[b0 + e] += wsum[e];      // behind wd_wide_fwd (bias + the other columns) in stream order
+  }
+}
+
+__global__ void __launch_bounds__(256) k_small_bwd(SmallArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int t = threadIdx.x;
+  const int k = blockIdx.y, c = blockIdx.x;
+  const int s = uni(a.small_idx[k]);
+  const wd_slot_t sl = a.slots[s];
+  const int R = uni(sl.num_buckets), D = uni(sl.dim);
+  const int PW = D + 2;                                   // partial record: g_0 .. g_{D-1}, g_wide, count
+  float *part = lds;                                      // [R][PW]
+  int32_t *cnt = reinterpret_cast<int32_t *>(lds + (int64_t)R * PW);   // [2][R]
+  float *gb = reinterpret_cast<float *>(cnt + 2 * R);     // [2][SM_MAX_DIM + 1]: the bag's dx / len and dlogit
+  for (int i = t; i < R * PW; i += 256) part[i] = 0.f;
+  for (int i = t; i < 2 * R; i += 256) cnt[i] = 0;
+  __syncthreads();
+  const int64_t e0 = (int64_t)c * a.bags_per_slice;
+  const int64_t e1 = e0 + a.bags_per_slice < a.batch ? e0 + a.bags_per_slice : a.batch;
+  int p = 0;
+  for (int64_t b = e0; b < e1; ++b, p ^= 1) {
+    const int64_t bag = b * a.S + s;
+    const int32_t j0 = a.bag_offs[bag], j1 = a.bag_offs[bag + 1];
+    const int32_t len = j1 - j0;
+    int32_t *cp = cnt + p * R;
+    float *gp = gb + p * (SM_MAX_DIM + 1);
+    // ---- count the bag's ids (exact, whatever order the atomics land in); stage its gradient --------------------------------
+    for (int32_t j = j0 + t; j < j1; j += 256) {
+      const int32_t id = a.ids[j];
+      if (id >= 0) atomicAdd(&cp[id], 1);
+    }
+    if (t < D) {
+      const float scale = len > 1 ? 1.0f / (float)len : 1.0f;      // mean combiner: every occurrence carries dx / len
+      gp[t] = (a.dx && sl.out_col >= 0) ? a.dx[b * a.ldx + sl.out_col + t] * scale : 0.f;
+    }
+    if (t == D) gp[D] = (sl.wide && a.dlogit) ? a.dlogit[b] : 0.f;
+    __syncthreads();
+    // ---- every row's owner adds count x gradient to the row's partial sums (bags in ascending order: a fixed order of adds) ---
+    for (int r = t; r < R; r += 256) {
+      const int32_t n = cp[r];
+      if (n == 0) continue;
+      cp[r] = 0;                                  // this histogram is counted into again two bags from now
+      const float fn = (float)n;
+      float *pr = part + (int64_t)r * PW;
+      for (int d = 0; d < D; ++d) pr[d] += fn * gp[d];
+      pr[D] += fn * gp[D];
+      pr[D + 1] += fn;
+    }
+    // (no second barrier: the next bag counts into the OTHER histogram and stages into the other gradient slot; a thread
+    // can be at most one barrier ahead of another)
+  }
+  __syncthreads();
+  float *out = a.part + ((int64_t)k * a.nslice + c) * a.part_rows * a.part_w;
+  for (int i = t; i < R * PW; i += 256) {
+    const int r = i / PW, d = i - r * PW;
+    out[(int64_t)r * a.part_w + d] = part[i];
+  }
+}
+
+__device__ __forceinline__ void ftrl1(float &w, float &z, float &n, float g, float lr, float l1, float l2) {
+  const float n_new = n + g * g;
+  z += g - (sqrtf(n_new) - sqrtf(n)) / lr * w;
+  const float quad = sqrtf(n_new) / lr + 2.0f * l2;
+  const float sgn = z > 0.f ? 1.f : (z < 0.f ? -1.f : 0.f);
+  const float pre = (sgn * l1 - z) / quad;
+  w = fabsf(z) > l1 ? pre : 0.f;
+  n = n_new;
+}
+
+// one thread per (row, element): element d < D = embedding column d (Adagrad), d == D = the wide weight (Ftrl)
+__global__ void __launch_bounds__(256) k_small_apply(SmallArgs a) {
+  const int k = blockIdx.y;
+  const int s = uni(a.small_idx[k]);
+  const wd_slot_t sl = a.slots[s];
+  const int R = sl.num_buckets, D = sl.dim;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= R * (D + 1)) return;
+  const int r = i / (D + 1), d = i - r * (D + 1);
+  const float *p = a.part + (int64_t)k * a.nslice * a.part_rows * a.part_w + (int64_t)r * a.part_w;
+  const int64_t st = (int64_t)a.part_rows * a.part_w;
+  float g = 0.f, hits = 0.f;
+  for (int c0 = 0; c0 < a.nslice; c0 += 8) {        // eight slices per round of loads, added in slice order
+    float v[8], h[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const bool live = c0 + u < a.nslice;
+      v[u] = live ? p[(c0 + u) * st + d] : 0.f;
+      h[u] = live ? p[(c0 + u) * st + D + 1] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { g += v[u]; hits += h[u]; }
+  }
+  if (hits == 0.f) return;                          // the batch does not hold this row: it does not move
+  if (d < D) {
+    if (!a.emb_w || sl.out_col < 0) return;
+    const int64_t o = sl.emb_off + (int64_t)r * D + d;
+    const float acc = a.emb_acc[o] + g * g;
+    a.emb_acc[o] = acc;
+    a.emb_w[o] -= a.lr_emb * g / sqrtf(acc);
+  } else if (sl.wide && a.wide_w) {
+    float4 q = *reinterpret_cast<float4 *>(a.wide_w + (sl.row_base + r) * 4);
+    ftrl1(q.x, q.y, q.z, g, a.lr_w, a.l1, a.l2);
+    *reinterpret_cast<float4 *>(a.wide_w + (sl.row_base + r) * 4) = q;
+  }
+}
+
+}  // namespace
+
+extern "C" int64_t wd_small_tables_ws_floats(int32_t nsmall, int32_t max_rows, int32_t max_dim, int64_t max_batch) {
+  if (nsmall <= 0) return 0;
+  const int64_t nslice = wd::ceil_div(max_batch, (int64_t)WD_SMALL_BAGS_PER_SLICE);
+  return (int64_t)nsmall * nslice * max_rows * (max_dim + 2);
+}
+
+static int small_check(const wd_slot_t *slots, const int32_t *small_idx, int32_t nsmall, int32_t max_rows, int32_t max_dim) {
+  WD_REQUIRE(slots && small_idx && nsmall > 0, "null pointer / no slots");
+  WD_REQUIRE(max_rows > 0 && max_dim >= 0 && max_dim <= SM_MAX_DIM, "max_rows > 0, 0 <= max_dim <= 16");
+  WD_REQUIRE((int64_t)max_rows * (max_dim + 2) <= WD_SMALL_MAX_FLOATS, "rows x (dim + 2) must fit WD_SMALL_MAX_FLOATS");
+  return WD_OK;
+}
+
+extern "C" int wd_small_tables_fwd(const float *emb, const float *wide, const wd_slot_t *slots, int32_t S,
+                                   const int32_t *small_idx, int32_t nsmall, int32_t max_rows, int32_t max_dim,
+                                   const int32_t *ids, const int32_t *bag_offs, int64_t batch, float *x, int64_t ldx,
+                                   float *wide_logit, wd_stream_t stream) {
+  if (batch <= 0 || nsmall <= 0) return WD_OK;
+  const int rc = small_check(slots, small_idx, nsmall, max_rows, max_dim);
+  if (rc != WD_OK) return rc;
+  WD_REQUIRE(ids && bag_offs, "null pointer");
+  WD_REQUIRE(!(max_dim > 0) || (emb && x), "embedded columns need the table and x");
+  SmallArgs a{};
+  a.slots = slots; a.small_idx = small_idx; a.nsmall = nsmall; a.S = S; a.ids = ids; a.bag_offs = bag_offs; a.batch = batch;
+  a.emb = emb; a.wide = wide; a.x = x; a.ldx = ldx; a.wide_logit = wide_logit;
+  const size_t lds = (size_t)max_rows * (max_dim + 1) * 4;
+  hipLaunchKernelGGL(k_small_fwd, dim3((unsigned)wd::ceil_div(batch, (int64_t)SM_EX_PER_WG)), dim3(256), lds,
+                     wd::as_stream(stream), a);
+  return wd::check_launch("wd_small_tables_fwd");
+}
+
+extern "C" int wd_small_tables_bwd(float *emb, float *emb_accum, float *wide_wzn, const wd_slot_t *slots, int32_t S,
+                                   const int32_t *small_idx, int32_t nsmall, int32_t max_rows, int32_t max_dim,
+                                   const int32_t *ids, const int32_t *bag_offs, int64_t batch, const float *dx, int64_t ldx,
+                                   const float *dlogit, float lr_emb, float lr_wide, float l1, float l2, float *ws,
+                                   int64_t ws_floats, wd_stream_t stream) {
+  if (batch <= 0 || nsmall <= 0) return WD_OK;
+  const int rc = small_check(slots, small_idx, nsmall, max_rows, max_dim);
+  if (rc != WD_OK) return rc;
+  WD_REQUIRE(ids && bag_offs && ws, "null pointer");
+  WD_REQUIRE(!emb || (emb_accum && dx), "embedding update needs accum and dx");
+  WD_REQUIRE(!wide_wzn || dlogit, "wide update needs dlogit");
+  SmallArgs a{};
+  a.slots = slots; a.small_idx = small_idx; a.nsmall = nsmall; a.S = S; a.ids = ids; a.bag_offs = bag_offs; a.batch = batch;
+  a.dx = emb ? dx : nullptr; a.ldx = ldx; a.dlogit = wide_wzn ? dlogit : nullptr;
+  a.bags_per_slice = WD_SMALL_BAGS_PER_SLICE;
+  a.nslice = (int32_t)wd::ceil_div(batch, a.bags_per_slice);
+  a.part = ws; a.part_rows = max_rows; a.part_w = max_dim + 2;
+  WD_REQUIRE((int64_t)nsmall * a.nslice * max_rows * (max_dim + 2) <= ws_floats, "workspace too small (wd_small_tables_ws_floats)");
+  a.emb_w = emb; a.emb_acc = emb_accum; a.wide_w = wide_wzn;
+  a.lr_emb = lr_emb; a.lr_w = lr_wide; a.l1 = l1; a.l2 = l2;
+  const size_t lds = (size_t)max_rows * (max_dim + 2) * 4 + (size_t)2 * max_rows * 4 + (size_t)2 * (SM_MAX_DIM + 1) * 4;
+  hipStream_t st = wd::as_stream(stream);
+  hipLaunchKernelGGL(k_small_bwd, dim3((unsigned)a.nslice, (unsigned)nsmall), dim3(256), lds, st, a);
+  hipLaunchKernelGGL(k_small_apply, dim3((unsigned)wd::ceil_div((int64_t)max_rows * (max_dim + 1), (int64_t)256), (unsigned)nsmall),
+                     dim3(256), 0, st, a);
+  return wd::check_launch("wd_small_tables_bwd");
+}

@@ -56,13 +56,14 @@ k_bucket_hist(const wd_slot_t *__restrict__ slots, int32_t S, const int32_t *__r
   for (int i = t; i < nb; i += 256) hist[i] = 0;
   __syncthreads();
   for (int i = t; i < S; i += 256)
-    if (slots[i].bucket_shift == 0) has_stable = 1;
+    if (slots[i].bucket_shift == 0 && !(slots[i].flags & WD_SLOT_F_SMALL)) has_stable = 1;
   __syncthreads();
   const int64_t b0 = (int64_t)blockIdx.x * bags_per_chunk;
   const int64_t b1 = b0 + bags_per_chunk < nbags ? b0 + bags_per_chunk : nbags;
   if (!has_stable) {
     for (int64_t bag = b0 + t; bag < b1; bag += 256) {
       const wd_slot_t sl = slots[bag % S];
+      if (sl.flags & WD_SLOT_F_SMALL) continue;      // csrc/small_tables.hip updates this column
       const int32_t j0 = bag_offs[bag], j1 = bag_offs[bag + 1];
       for (int32_t j = j0; j < j1; ++j) {
         const int32_t id = ids[j];
@@ -79,7 +80,7 @@ k_bucket_hist(const wd_slot_t *__restrict__ slots, int32_t S, const int32_t *__r
       if (bag < b1) {
         const wd_slot_t sl = slots[bag % S];
         j0 = bag_offs[bag];
-        j1 = bag_offs[bag + 1];
+        j1 = (sl.flags & WD_SLOT_F_SMALL) ? j0 : bag_offs[bag + 1];      // (csrc/small_tables.hip updates that column)
         bshift = sl.bucket_shift;
         bbase = sl.bucket_base;
       }
@@ -214,6 +215,7 @@ k_bucket_scatter(const wd_slot_t *__restrict__ slots, int32_t S, const int32_t *
   const int64_t b1 = b0 + bags_per_chunk < nbags ? b0 + bags_per_chunk : nbags;
   for (int64_t bag = b0 + t; bag < b1; bag += 256) {
     const wd_slot_t sl = slots[bag % S];
+    if (sl.flags & WD_SLOT_F_SMALL) continue;
     const int32_t j0 = bag_offs[bag], j1 = bag_offs[bag + 1];
     for (int32_t j = j0; j < j1; ++j) {
       const int32_t id = ids[j];

@@ -121,6 +121,34 @@ class WideDeepEngine:
         raw = np.frombuffer(bytes(arr), dtype=np.uint8).copy()
         self.slots_dev = torch.from_numpy(raw).to(dev)
         self.group_slots = {d: torch.tensor(v, **i32) for d, v in plan.emb_groups.items()}
+        # Small tables with long bags (csrc/small_tables.hip): crossed columns (python/lib/build_estimator.py:138-155 -- a bag holds
+        # the PRODUCT of its keys' counts, hashed into a few hundred buckets) whose table + one partial record per row fit in
+        # LDS.  Multi-hot batches take them out of the general path (wd_wide_fwd / the embedding-bag groups / the bucketed
+        # update skip a slot whose descriptor carries WD_SLOT_F_SMALL) and through wd_small_tables_fwd / _bwd.  Separate tables,
+        # the reference's default optimizers, one GPU.  WD_SMALL_TABLES=0: off; =all: every column that fits, crossed or not.
+        self.small_idx = []
+        mode = os.environ.get("WD_SMALL_TABLES", "cross")
+        if mode != "0" and type(self) is WideDeepEngine:
+            for i, s in enumerate(plan.slots):
+                d = int(arr[i].dim)
+                if ((s.kind == "cross" or mode == "all") and arr[i].kind != capi.SLOT_INDICATOR and (d > 0 or arr[i].wide)
+                        and d <= 16 and int(s.num_buckets) * (d + 2) <= capi.SMALL_MAX_FLOATS):
+                    self.small_idx.append(i)
+        self.slots_small_dev = self.small_idx_dev = self.small_ws = None
+        if self.small_idx:
+            for i in self.small_idx:
+                arr[i].flags = capi.SLOT_F_SMALL
+            self.slots_small_dev = torch.from_numpy(np.frombuffer(bytes(arr), dtype=np.uint8).copy()).to(dev)
+            for i in self.small_idx:
+                arr[i].flags = 0
+            self.small_idx_dev = torch.tensor(self.small_idx, **i32)
+            self.small_ws = None      # partial sums of wd_small_tables_bwd, allocated by the first (eager) step that needs them
+            self.small_rows = max(int(plan.slots[i].num_buckets) for i in self.small_idx)
+            self.small_dim = max(int(arr[i].dim) for i in self.small_idx)
+            # embedding-bag groups without the small columns (a group may lose its contiguity: the slot-list kernel takes it)
+            self.group_lists_big = {d: [i for i in v if i not in self.small_idx] for d, v in plan.emb_groups.items()
+                                    if any(i not in self.small_idx for i in v)}
+            self.group_slots_big = {d: torch.tensor(v, **i32) for d, v in self.group_lists_big.items()}
         self.ind_slots_dev = torch.tensor(plan.ind_slots, **i32) if plan.ind_slots else None
         if plan.dense_cols:
             darr = (capi.WdDenseCol * len(plan.dense_cols))()
@@ -684,7 +712,7 @@ class WideDeepEngine:
         """Input layer (embedding bags, indicators, numeric columns) into tower 0's x, and the wide logit."""
         plan, spec = self.plan, self.spec
         B, S = bt.B, plan.S
-        if spec.has_deep and self._fused_input_layer and self.rec is None:
+        if spec.has_deep and self._fused_input_layer and self.rec is None and not self._small_on(bt):
             # one launch: embedding bags + wide sum + numeric columns
             tw0 = self.towers[0]
             (dim, sl), = plan.emb_groups.items()
@@ -695,12 +723,14 @@ class WideDeepEngine:
                  ptr(self.wide) if spec.has_wide else None, ptr(self.bias) if spec.has_wide else None,
                  ptr(self.wide_logit) if spec.has_wide else None, st)
             return
+        small = self._small_on(bt)
+        slots_dev = self.slots_small_dev if small else self.slots_dev
         if spec.has_deep:
             tw0 = self.towers[0]
             ld = tw0["layout"].ld
             xp = self._x_ptr(tw0)
-            for dim, gs in self.group_slots.items():
-                self.embag_fwd(dim, gs, bt, xp, ld, st)
+            for dim, gs in (self.group_slots_big if small else self.group_slots).items():
+                self.embag_fwd(dim, gs, bt, xp, ld, st, sub=small)
             if self.ind_slots_dev is not None:
                 call("wd_indicator_fwd", ptr(self.slots_dev), S, ptr(self.ind_slots_dev), self.ind_slots_dev.numel(),
                      ptr(bt.ids), ptr(bt.bag_offs), B, xp, ld, st)
@@ -708,13 +738,24 @@ class WideDeepEngine:
                 call("wd_dense_fwd", ptr(bt.dense), bt.dense.stride(0), ptr(self.dense_cols_dev),
                      len(plan.dense_cols), B, xp, ld, st)
         if spec.has_wide:
-            call("wd_wide_fwd", ptr(self.wide), self.rec_stride or 4, ptr(self.bias), ptr(self.slots_dev), S, ptr(bt.ids),
+            call("wd_wide_fwd", ptr(self.wide), self.rec_stride or 4, ptr(self.bias), ptr(slots_dev), S, ptr(bt.ids),
                  ptr(bt.bag_offs), B, ptr(self.wide_logit), st)
+        if small:
+            call("wd_small_tables_fwd", ptr(self.emb) if spec.has_deep else None, ptr(self.wide) if spec.has_wide else None,
+                 ptr(self.slots_dev), S, ptr(self.small_idx_dev), len(self.small_idx), self.small_rows, self.small_dim,
+                 ptr(bt.ids), ptr(bt.bag_offs), B, self._x_ptr(self.towers[0]) if spec.has_deep else None,
+                 self.towers[0]["layout"].ld if spec.has_deep else 0, ptr(self.wide_logit) if spec.has_wide else None, st)
 
-    def embag_fwd(self, dim, gs, bt, xp, ld, st):
-        """Embedding-bag gather of one dim group into x (the kernel bench.py reports the HBM roofline of)."""
+    def _small_on(self, bt):
+        """This batch's small-table columns go through csrc/small_tables.hip: multi-hot batches on separate tables with the
+        reference's default optimizers (one-id-per-bag batches keep the one-launch bucketing, whose bags cannot be long)."""
+        return bool(self.small_idx) and not bt.one_hot and self.rec is None and self.default_opts
+
+    def embag_fwd(self, dim, gs, bt, xp, ld, st, sub=False):
+        """Embedding-bag gather of one dim group into x (the kernel bench.py reports the HBM roofline of).  sub: `gs` is the
+        group without its small-table columns."""
         plan = self.plan
-        sl = plan.emb_groups[dim]
+        sl = self.group_lists_big[dim] if sub else plan.emb_groups[dim]
         contiguous = sl == list(range(sl[0], sl[0] + len(sl)))
         if self.rec is not None:
             call("wd_embag_fwd_strided", ptr(self.rec), self.rec_stride, ptr(self.rslots_dev), plan.S, ptr(gs), gs.numel(),
@@ -1051,7 +1092,7 @@ class WideDeepEngine:
                      (bs["long_list"].numel() - 2) // 2, ptr(bs["big_list"]), bt.B, plan.S, ptr(bp["start"]) if bp else None, ptr(bp["pairs"]) if bp else None, ptr(bp["patch"]) if bp else None, st)
             return
         bs["unsorted"] = bs["sorted"] = False
-        call("wd_sparse_bucketize", ptr(self.slots_dev), plan.S, ptr(bt.ids), ptr(bt.bag_offs), bt.B, bt.nnz,
+        call("wd_sparse_bucketize", ptr(self.slots_small_dev if self._small_on(bt) else self.slots_dev), plan.S, ptr(bt.ids), ptr(bt.bag_offs), bt.B, bt.nnz,
              ptr(bs["cnt"]), ptr(bs["start"]), ptr(bs["rank"]), ptr(bs["pairs"]), self.n_buckets, st)
 
     def _bucket_onehot_ok(self, bt):
@@ -1108,6 +1149,15 @@ class WideDeepEngine:
             return
         if self.default_opts:
             lr, l1, l2 = (spec.lin_opt[1], spec.lin_opt[2], spec.lin_opt[3]) if spec.has_wide else (0.0, 0.0, 0.0)
+            if self._small_on(bt):      # the crossed columns' tables: counted in LDS, no sort (the bucketing above skipped them)
+                if self.small_ws is None:
+                    n = int(call("wd_small_tables_ws_floats", len(self.small_idx), self.small_rows, self.small_dim, self.max_batch))
+                    self.small_ws = torch.zeros(max(n, 1), dtype=torch.float32, device=self.device)
+                call("wd_small_tables_bwd", ptr(self.emb) if has_emb else None, ptr(self.emb_acc) if has_emb else None,
+                     ptr(self.wide) if spec.has_wide else None, ptr(self.slots_dev), plan.S, ptr(self.small_idx_dev),
+                     len(self.small_idx), self.small_rows, self.small_dim, ptr(bt.ids), ptr(bt.bag_offs), bt.B, dx_ptr, ld,
+                     ptr(self.dlogit), float(spec.dnn_opt[1]) if spec.has_deep else 0.0, float(lr), float(l1), float(l2),
+                     ptr(self.small_ws), self.small_ws.numel(), st)
             call("wd_sparse_apply", ptr(self.emb) if has_emb else None, ptr(self.emb_acc) if has_emb else None,
                  ptr(self.wide), ptr(self.bias), ptr(self.slots_dev), plan.S, ptr(bt.bag_offs), bt.B, dx_ptr, ld,
                  ptr(self.dlogit), 1, float(spec.dnn_opt[1]) if spec.has_deep else 0.0, float(lr), float(l1), float(l2),

@@ -154,3 +154,27 @@ def test_connection_list_errors_and_chain_list_is_dense():
         ra, rb = a.tf_rows_of_layer(0, l), b.tf_rows_of_layer(0, l)
         ca, cb = a.towers[0].window_cols(l), b.towers[0].window_cols(l)
         assert [(a.towers[0].canon(ca[r][0]), ca[r][1]) for r in ra] == [(b.towers[0].canon(cb[r][0]), cb[r][1]) for r in rb]
+
+
+def test_tower_specs_refuse_mode_lists_that_do_not_match_the_towers():
+    """build_estimator.tower_specs: a silent zip() used to drop towers (or modes) -- an empty dnn_connected_mode gave a deep model
+    without a tower; a connection list with items longer than three characters ('0-10') was taken for one mode per tower."""
+    import pytest
+    from wide_deep_amd.build_estimator import tower_specs
+    assert [t.mode for t in tower_specs([[8, 4], [6]], ["simple", "resnet"])] == ["simple", "resnet"]
+    assert len(tower_specs([[8, 4], [6]], "dense")) == 2
+    with pytest.raises(ValueError):
+        tower_specs([8, 4], [])
+    with pytest.raises(ValueError):
+        tower_specs([[8, 4], [6]], ["simple"])
+    hidden = [4] * 12
+    t, = tower_specs(hidden, ["0-10", "1-3"])           # ONE tower: a list of 'i-j' items is its connection list whatever their length
+    assert (0, 10) in t.mode and (1, 3) in t.mode
+
+
+def test_decayed_lr_starts_from_the_initial_rate_it_is_given():
+    from wide_deep_amd.plan import criteo_spec
+    spec = criteo_spec(n_dense=1, n_sparse=1, buckets=10, dim=4, hidden=(4,))
+    spec.lr_decay = {"dnn": (0.5, 10.0)}
+    spec.dnn_opt = ("Adagrad", 0.0125, 0.1)      # what an engine's own copy holds after a few decayed steps
+    assert abs(spec.decayed_lr("dnn", 20, lr0=0.05) - 0.0125) < 1e-12 and spec.decayed_lr("linear", 20, lr0=0.1) == 0.1

@@ -76,7 +76,10 @@ def opt_tuple(name, kw):
        ("SGD", lr) ("Adagrad", lr, initial_accumulator_value) ("Ftrl", lr, l1, l2, initial_accumulator_value)
        ("RMSProp", lr, decay, momentum, epsilon) ("Adam", lr, beta1, beta2, epsilon)
     Non-default variants append elements: ("Ftrl", ..., learning_rate_power) when it is not -0.5, ("Ftrl", ..., learning_rate_power,
-    l2_shrinkage_regularization_strength) when the shrinkage is not 0,
+    l2_shrinkage_regularization_strength) when the shrinkage is not 0 -- applied in the form TensorFlow >= 1.13 computes and
+    its ftrl_test pins ([-0.22578995, -0.44345796] ...): the linear slot takes g + 2 shrinkage var, the accumulator the PLAIN
+    g^2.  (The reference only asks for tensorflow >= 1.4; earlier 1.x releases are recalled to square the shrunk gradient into
+    the accumulator -- not verifiable here, no TF.  The newer semantics are matched on purpose),
     ("RMSProp", ..., True) for centered=True."""
     lr = float(kw["learning_rate"])
     if name == "SGD":
@@ -162,7 +165,9 @@ def build_model_spec(conf=None, model_type=None):
     # the reference itself never decays (quirk C.2).  Only optimizers given by name take the model_fn's learning rate.
     lr_decay = None
     if train.get("lr_decay"):
-        steps = float(train["num_examples"]) / float(train["batch_size"])       # decay_steps is a float (joint.py:78)
+        # decay_steps (python/lib/joint.py:78 `_num_examples / _batch_size`): the reference is Python 2 (`map(int, ...)` unpacked,
+        # print statements), where `/` on two ints floors
+        steps = float(max(int(train["num_examples"]) // int(train["batch_size"]), 1))
         lr_decay = {}
         for scope, key, rk in (("dnn", "dnn_optimizer", "dnn_decay_rate"), ("linear", "linear_optimizer", "linear_decay_rate")):
             rate = model.get(rk) or 1
@@ -184,8 +189,16 @@ def tower_specs(hidden, mode):
     ('0-1') -- serves every tower, anything else is one mode per tower."""
     multi = bool(hidden) and isinstance(hidden[0], (list, tuple))
     hidden = [list(h) for h in hidden] if multi else [list(hidden)]
-    one = isinstance(mode, str) or (len(mode) > 0 and isinstance(mode[0], str) and len(mode[0]) == 3)
+    from .plan import is_connection_list
+    if not isinstance(mode, str) and len(mode) == 0:
+        raise ValueError("dnn_connected_mode is empty")
+    # one connection list for a single tower whatever the length of its items ('0-10'); for several towers the reference's
+    # three-character test (python/lib/dnn.py:253-258) decides between "one list for all" and "one mode per tower"
+    one = (isinstance(mode, str) or (len(mode) > 0 and isinstance(mode[0], str) and len(mode[0]) == 3)
+           or (not multi and is_connection_list(mode)))
     modes = [mode] * len(hidden) if one else list(mode)
+    if len(modes) != len(hidden):
+        raise ValueError("dnn_connected_mode lists %d modes for %d DNNs (dnn_hidden_units)" % (len(modes), len(hidden)))
     return [TowerSpec([int(h) for h in hs], _mode_name(m, len(hs))) for hs, m in zip(hidden, modes)]
 
 

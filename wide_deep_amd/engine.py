@@ -49,6 +49,11 @@ class WideDeepEngine:
         if not torch.cuda.is_available():
             raise capi.WdError("WideDeepEngine needs a GPU (MI355X / gfx950); there is no CPU fallback")
         capi.load()
+        # the engine's OWN copy of the spec: set_learning_rates rewrites the optimizer tuples the launches read their rates from,
+        # and a second engine built from the caller's spec must still see the initial ones
+        import dataclasses
+        spec = dataclasses.replace(spec)
+        self.lr0 = {"dnn": float(spec.dnn_opt[1]) if spec.has_deep else None, "linear": float(spec.lin_opt[1]) if spec.has_wide else None}
         self.dropout = float(spec.dropout) if (spec.dropout and spec.has_deep) else 0.0
         if not 0.0 <= self.dropout < 1.0:
             raise ValueError("dnn_dropout must be in [0, 1), got %r" % (spec.dropout,))
@@ -581,7 +586,9 @@ class WideDeepEngine:
 
     def set_learning_rates(self, dnn=None, linear=None):
         """Learning rates of the two scopes for the launches that follow (eager steps read them at launch time; a captured
-        graph has them baked in).  Estimator.train calls this before every step when spec.lr_decay is set."""
+        graph has them baked in: capturing with spec.lr_decay set warns).  Estimator.train calls this before every step when
+        spec.lr_decay is set, with rates decayed from self.lr0 -- the initial ones; self.spec (the engine's own copy) carries the
+        current ones."""
         spec = self.spec
         if dnn is not None and spec.has_deep:
             spec.dnn_opt = (spec.dnn_opt[0], float(dnn)) + tuple(spec.dnn_opt[2:])
@@ -1323,6 +1330,10 @@ class WideDeepEngine:
     def capture_train_step(self, bt: DeviceBatch, warmup=2):
         """Capture forward+backward+updates on `bt`'s buffers into a hipGraph; returns a replay callable.
         The caller refreshes the contents of bt's tensors in place between replays."""
+        if self.spec.lr_decay:
+            import warnings
+            warnings.warn("capture_train_step: the model decays its learning rates (train.yaml lr_decay); a captured step keeps the "
+                          "rates of the capture")
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):

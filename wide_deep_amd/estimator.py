@@ -235,10 +235,10 @@ class WideAndDeepClassifier(object):
                 if max_steps is not None and self._engine.global_step >= max_steps:
                     break
             if self._engine.spec.lr_decay:      # opt-in (train.yaml lr_decay: true): exponential decay over TF's global step
-                sp, gs = self._engine.spec, self._engine.global_step
-                if getattr(sp, "_lr0", None) is None:
-                    sp._lr0 = {"dnn": float(sp.dnn_opt[1]), "linear": float(sp.lin_opt[1])}
-                self._engine.set_learning_rates(dnn=sp.decayed_lr("dnn", gs), linear=sp.decayed_lr("linear", gs))
+                eng = self._engine
+                sp, gs = eng.spec, eng.global_step
+                eng.set_learning_rates(dnn=sp.decayed_lr("dnn", gs, eng.lr0["dnn"]) if sp.has_deep else None,
+                                       linear=sp.decayed_lr("linear", gs, eng.lr0["linear"]) if sp.has_wide else None)
             loss = self._engine.train_step(bt)
             n += 1
             seen += bt.B

@@ -69,6 +69,10 @@ class StepGraph:
         clears it).  It names the look-ahead batch by identity: a TokenBatch that is refilled IN PLACE between the replay that
         gathered it and the replay that trains on it must be re-primed by the caller (`eng._primed = None`)."""
         self.eng = eng
+        if eng.spec.lr_decay:
+            import warnings
+            warnings.warn("StepGraph: the model decays its learning rates (train.yaml lr_decay), a captured step has the rates of the "
+                          "capture baked in -- replays will not decay")
         self.n = len(token_batches)
         self.ids_input = ids_input
         self.first, self.lookahead, self.phase, self.primed = token_batches[0], lookahead, (phase[0], phase[1]), bool(primed)

@@ -128,13 +128,17 @@ class ModelSpec:
     # nothing increments, so its learning rates never move (python/lib/joint.py:145-154).  Opt-in
     # (train.yaml `lr_decay: true`, build_estimator.build_model_spec): {"dnn": (decay_rate, decay_steps), "linear": (...)} for
     # the scopes whose optimizer is given by NAME (those take the model_fn's learning rate; a constructor string keeps its own,
-    # python/lib/utils/model_util.py:84-105):  lr_t = lr_0 * decay_rate ** (global_step / decay_steps)  over TF's global step.
+    # python/lib/utils/model_util.py:84-105):  lr_t = lr_0 * decay_rate ** (global_step / decay_steps)  over TF's global step --
+    # which advances 3 per train step in wide_deep mode (2 otherwise; quirk C.4): with decay_steps = num_examples // batch_size
+    # (python/lib/joint.py:78 under the reference's Python 2: integer division) a rate has decayed by `decay_rate` after a THIRD
+    # of an epoch, not after one as the reference's comment has it.
     lr_decay: Optional[dict] = None
 
-    def decayed_lr(self, scope, global_step):
-        """learning rate of `scope` ("dnn" | "linear") at TF global step `global_step` (tf.train.exponential_decay, staircase=False)"""
+    def decayed_lr(self, scope, global_step, lr0=None):
+        """learning rate of `scope` ("dnn" | "linear") at TF global step `global_step` (tf.train.exponential_decay, staircase=False);
+        lr0: the scope's INITIAL rate (WideDeepEngine.lr0 -- an engine's own spec carries the current rate, not the initial one)"""
         opt = self.dnn_opt if scope == "dnn" else self.lin_opt
-        lr0 = float(self._lr0[scope]) if getattr(self, "_lr0", None) else float(opt[1])
+        lr0 = float(opt[1]) if lr0 is None else float(lr0)
         sch = (self.lr_decay or {}).get(scope)
         if not sch:
             return lr0

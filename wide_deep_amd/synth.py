@@ -123,6 +123,7 @@ def hash_tokens(engine, tb):
              ptr(tb.batch.ids_cols), st)
         tb.batch.ids_cols_valid = True
         return tb.batch
+    tb.batch.ids_cols_valid = False      # this entry point writes the example-major ids only: a slot-major copy is stale now
     call("wd_hash_bucket", ptr(tb.bytes), ptr(tb.tok_offs), tb.ntok, None if tb.one_per_bag else ptr(tb.bag_offs),
          tb.B * plan.S, ptr(slots_dev), plan.S, ptr(tb.ids), st)
     return tb.batch

@@ -108,43 +108,57 @@ def gather_alg_bytes(plan, bt, dim, nslots):
 
 def pmc_traffic(args, bt, plan):
     """HBM traffic of the stand-alone gather kernel, measured BY THIS RUN: two child passes of the same kernel on the same
-    workload under `rocprofv3 --kernel-trace --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes, as the microarch guide
-    prescribes; counter CSVs parsed here, nothing read from a committed file).  The 256 MiB copy in the same pass calibrates
-    the counters: on gfx950 FETCH_SIZE tallies a 128-byte streaming request at 64 bytes (the copy reads back 1/2), the 64-byte
-    row requests count in full -> traffic = FETCH + WRITE + half of the streamed id / offset bytes.  None on any failure."""
+    workload under `rocprofv3 --kernel-trace --pmc` (separate passes, as the microarch guide prescribes), with the L2 -> fabric
+    REQUEST counters by size instead of the derived FETCH_SIZE / WRITE_SIZE:
+        bytes = 128 RDREQ_128B + 64 RDREQ_64B + 32 RDREQ_32B + 64 WRREQ_64B + 32 (WRREQ - WRREQ_64B).
+    Why (profiles/r5_gather_counter_calibration_pass{1,2}.txt, calibration on the gather's own access pattern): FETCH_SIZE is
+    RDREQ x 64 B, but on gfx950 a read request is a whole 128-byte line -- a 256 MiB streaming copy issues exactly 2^21 of them, all
+    in RDREQ_128B -- and a random row costs ONE such request whether 64 or 128 bytes of its record are needed (1.03 per row either
+    way; RDREQ_64B ~ 0).  Rounds 1-4 took FETCH_SIZE at face value for the random rows (x 1.0) and reported 1.04 x the algorithmic
+    bytes; the rows really move 128 B each.  The 256 MiB copy of the same pass is the check: it must read back x 1.000 and write
+    x 1.000 by this formula.  None on any failure."""
     import csv, glob, shutil, subprocess, tempfile
     if shutil.which("rocprofv3") is None:
         return None, "rocprofv3 not on PATH"
-    env = dict(os.environ, GATHER_ITERS="20", GATHER_POOL="8", GATHER_CONFIG="c4-nocross" if args.config == "c4" else args.config, GATHER_BATCH=str(args.batch),
-               GATHER_DIST=args.dist, TMPDIR="/tmp")
-    raw, calib = {}, {}
-    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+    env = dict(os.environ, GATHER_ITERS="20", GATHER_POOL="8", GATHER_CONFIG="c4-nocross" if args.config == "c4" else args.config,
+               GATHER_BATCH=str(args.batch), GATHER_DIST=args.dist, TMPDIR="/tmp")
+    passes = (("TCC_EA0_RDREQ_128B_sum", "TCC_EA0_RDREQ_64B_sum", "TCC_EA0_RDREQ_32B_sum"), ("TCC_EA0_WRREQ_sum", "TCC_EA0_WRREQ_64B_sum"))
+    val, cal = {}, {}
+    for ctrs in passes:
         d = tempfile.mkdtemp(prefix="wd_pmc_", dir="/tmp")
         try:
-            subprocess.run(["rocprofv3", "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "pmc", "--",
+            subprocess.run(["rocprofv3", "--kernel-trace", "--pmc"] + list(ctrs) + ["--output-format", "csv", "-d", d, "-o", "pmc", "--",
                             sys.executable, os.path.join(ROOT, "scripts", "bench_gather.py")], env=env, cwd="/tmp",
                            stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240, check=True)
             f = glob.glob(d + "/**/*counter_collection.csv", recursive=True)
-            g, c = [], []
+            g, c = {k: [] for k in ctrs}, {k: [] for k in ctrs}
             for r in csv.DictReader(open(f[0])):
-                if r["Counter_Name"] != ctr:
+                if r["Counter_Name"] not in g:
                     continue
                 if "k_embag_fwd" in r["Kernel_Name"] or "k_prefetch_onehot" in r["Kernel_Name"]:
-                    g.append(float(r["Counter_Value"]))
+                    g[r["Counter_Name"]].append(float(r["Counter_Value"]))
                 elif "copy" in r["Kernel_Name"].lower():
-                    c.append(float(r["Counter_Value"]))
-            raw[ctr] = sum(g[-20:]) / len(g[-20:]) * 1024.0        # KiB per launch -> bytes
-            calib[ctr] = max(c) * 1024.0 / float(1 << 28) if c else None    # reported / known bytes of the 256 MiB copy
+                    c[r["Counter_Name"]].append(float(r["Counter_Value"]))
+            for k in ctrs:
+                val[k] = sum(g[k][-20:]) / len(g[k][-20:])          # requests per launch
+                cal[k] = max(c[k]) if c[k] else None                 # requests of the 256 MiB copy
         except Exception as e:
-            return None, "PMC pass %s failed: %s" % (ctr, str(e)[:120])
+            return None, "PMC pass %s failed: %s" % ("+".join(ctrs), str(e)[:120])
         finally:
             shutil.rmtree(d, ignore_errors=True)
-    streamed = bt.nnz * 4 + (bt.B * plan.S + 1) * 4
-    traffic = int(raw["FETCH_SIZE"] + raw["WRITE_SIZE"] + 0.5 * streamed)
-    return traffic, ("measured by this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE child passes of the kernel; raw "
-                     "%d + %d B per launch, + half of the %d streamed id/offset bytes (calibration copy of 256 MiB in the "
-                     "same passes reads back x%.3f / writes x%.3f)" % (int(raw["FETCH_SIZE"]), int(raw["WRITE_SIZE"]), streamed,
-                                                                      calib["FETCH_SIZE"] or -1, calib["WRITE_SIZE"] or -1))
+    rd = 128 * val["TCC_EA0_RDREQ_128B_sum"] + 64 * val["TCC_EA0_RDREQ_64B_sum"] + 32 * val["TCC_EA0_RDREQ_32B_sum"]
+    wr = 64 * val["TCC_EA0_WRREQ_64B_sum"] + 32 * (val["TCC_EA0_WRREQ_sum"] - val["TCC_EA0_WRREQ_64B_sum"])
+    chk = ""
+    if all(v is not None for v in cal.values()):
+        crd = 128 * cal["TCC_EA0_RDREQ_128B_sum"] + 64 * cal["TCC_EA0_RDREQ_64B_sum"] + 32 * cal["TCC_EA0_RDREQ_32B_sum"]
+        cwr = 64 * cal["TCC_EA0_WRREQ_64B_sum"] + 32 * (cal["TCC_EA0_WRREQ_sum"] - cal["TCC_EA0_WRREQ_64B_sum"])
+        chk = "; the 256 MiB copy of the same passes reads back x%.3f / writes x%.3f by the same formula" % (crd / float(1 << 28), cwr / float(1 << 28))
+    nrow = max(bt.nnz, 1)
+    return int(rd + wr), ("measured by this run: rocprofv3 --pmc passes of the kernel alone, L2 -> fabric requests by size: reads "
+                          "%.0f x 128 B + %.0f x 64 B + %.0f x 32 B = %d B (%.2f requests of 128 B per gathered row: a random row costs a "
+                          "whole 128-byte line), writes %d B%s" % (val["TCC_EA0_RDREQ_128B_sum"], val["TCC_EA0_RDREQ_64B_sum"],
+                                                                  val["TCC_EA0_RDREQ_32B_sum"], int(rd), val["TCC_EA0_RDREQ_128B_sum"] / nrow,
+                                                                  int(wr), chk))
 
 
 def gather_kernel_roofline(eng, batches, args, iters=200):

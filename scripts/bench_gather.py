@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Embedding-gather kernel alone on the C2 workload (run on the GPU box): HIP-event timing, and -- under
-`rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` -- its HBM traffic next to a streaming copy of KNOWN size that
+`rocprofv3 --pmc` request counters by size (bench.py pmc_traffic; profiles/r5_gather_counter_calibration.md) -- its HBM traffic next to a streaming copy of KNOWN size that
 calibrates the counters (MI355X_MICROARCH.md: FETCH_SIZE under-reports wide coalesced reads by 2x on gfx950)."""
 import os, sys, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -930,6 +930,13 @@ def main():
                 out["roofline"]["traffic_source"] = ("the same launch under rocprofv3 --pmc (roofline_gather_kernel.traffic_source): "
                                                      "counter passes serialise kernels, so the bytes are those of the launch "
                                                      "alone; inside the step only its duration differs")
+            for key in ("roofline", "roofline_gather_kernel"):
+                r = out.get(key)
+                if r and r.get("traffic") and r.get("avg_launch_us"):
+                    # what the launch really moves (128-byte lines, request counters) over its duration: the contract's `frac` is
+                    # this figure x algorithmic bytes / traffic
+                    r["moved_GBps"] = round(r["traffic"] / r["avg_launch_us"] / 1e3, 1)
+                    r["moved_frac_of_peak"] = round(r["traffic"] / r["avg_launch_us"] / 1e3 / HBM_PEAK_GBS, 4)
             if not sharded:
                 out["roofline_tower"] = tower_roofline(eng, dev_batches[0].batch)
             if not args.no_cpu_baseline:

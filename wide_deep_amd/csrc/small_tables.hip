@@ -9,13 +9,14 @@
 // its worst case -- every row a "long segment" of ~5 k occurrences, and the order-stable histogram of one-row buckets walks the
 // longest bag of every 256 in lock-step: 1.9 of the 2.0 ms of a configs[3] step (profiles/r5_c4_crosses_kernel_stats_before.md).
 // Here the table never leaves the CU:
-//   k_small_fwd    a workgroup takes 32 examples; per small slot it loads the table (+ wide weights) into LDS, then one
+//   k_small_fwd    a workgroup takes 8 examples; per small slot it loads the table (+ wide weights) into LDS, then one
 //                  wavefront per bag: lanes stride over the ids, add rows from LDS, meet in a fixed shuffle tree; mean -> x,
 //                  wide sum -> added to the wide logit once per example (slot order, no atomics).
 //   k_small_bwd    (slice of the batch, slot) per workgroup, bags in ascending order: the bag's ids are COUNTED into an LDS
 //                  histogram (integer atomics: exact, order-free), then the owner thread of every row adds
 //                  count x (dx / len | dlogit) to its partial sums in LDS -- a fixed order of float adds, no sort, no float atomic;
-//                  one barrier per bag (histograms double-buffered).  Partials + hit counts go to HBM per slice.
+//                  one barrier per bag (histograms double-buffered); the slice's bag bounds and gradients are staged in one
+//                  round of loads, the ids of four bags ride in a register ring.  Partials + hit counts go to HBM per slice.
 //   k_small_apply  per slot: partials summed in slice order, Adagrad on the embedding rows / Ftrl on {w, z, n} of the rows
 //                  the batch touched.
 #include "common.h"
@@ -23,7 +24,9 @@
 namespace {
 
 constexpr int SM_MAX_DIM = 16;
-constexpr int SM_EX_PER_WG = 32;      // forward: examples per workgroup (8 per wavefront)
+constexpr int SM_SLICE = WD_SMALL_BAGS_PER_SLICE;
+constexpr int SM_EX_PER_WG = 8;       // forward: examples per workgroup (2 per wavefront: a bag is a chain of two round trips --
+                                      // offsets, ids -- that 4 k wavefronts hide better than 1 k with eight bags each)
 
 struct SmallArgs {
   const wd_slot_t *slots;
@@ -124,43 +127,77 @@ __global__ void __launch_bounds__(256) k_small_bwd(SmallArgs a) {
   const int PW = D + 2;                                   // partial record: g_0 .. g_{D-1}, g_wide, count
   float *part = lds;                                      // [R][PW]
   int32_t *cnt = reinterpret_cast<int32_t *>(lds + (int64_t)R * PW);   // [2][R]
-  float *gb = reinterpret_cast<float *>(cnt + 2 * R);     // [2][SM_MAX_DIM + 1]: the bag's dx / len and dlogit
   for (int i = t; i < R * PW; i += 256) part[i] = 0.f;
   for (int i = t; i < 2 * R; i += 256) cnt[i] = 0;
   __syncthreads();
   const int64_t e0 = (int64_t)c * a.bags_per_slice;
   const int64_t e1 = e0 + a.bags_per_slice < a.batch ? e0 + a.bags_per_slice : a.batch;
+  const int nbag = (int)(e1 - e0);
+  // the slice's bag bounds and gradients in ONE round of loads (a bag's own chain offsets -> ids -> count would be two round
+  // trips per bag, 64 times in a row: 84 us for a launch that moves 10 MB)
+  int32_t *lo = cnt + 2 * R, *hi = lo + SM_SLICE;            // [SM_SLICE] each: ids [lo, hi) of the slice's q-th bag
+  float *gs = reinterpret_cast<float *>(hi + SM_SLICE);      // [SM_SLICE][SM_MAX_DIM + 1]: its dx and dlogit
+  for (int i = t; i < nbag; i += 256) {
+    lo[i] = a.bag_offs[(e0 + i) * a.S + s];
+    hi[i] = a.bag_offs[(e0 + i) * a.S + s + 1];
+  }
+  for (int i = t; i < nbag * (D + 1); i += 256) {
+    const int q = i / (D + 1), d = i - q * (D + 1);
+    float v;
+    if (d < D) v = (a.dx && sl.out_col >= 0) ? a.dx[(e0 + q) * a.ldx + sl.out_col + d] : 0.f;
+    else v = (sl.wide && a.dlogit) ? a.dlogit[e0 + q] : 0.f;
+    gs[q * (SM_MAX_DIM + 1) + d] = v;
+  }
+  __syncthreads();
+  // ids: a ring of four bags in flight (two ids per lane each; what a bag holds beyond 512 ids is loaded when it is counted)
+  int32_t idr[4][2];
+  auto lens_of = [&](int q, int32_t &j0, int32_t &j1) {
+    j0 = 0; j1 = 0;
+    if (q < nbag) { j0 = lo[q]; j1 = hi[q]; }
+  };
+  auto load_ids = [&](int q, int32_t (&r)[2]) {
+    int32_t j0, j1;
+    lens_of(q, j0, j1);
+    r[0] = j0 + t < j1 ? a.ids[j0 + t] : -1;
+    r[1] = j0 + t + 256 < j1 ? a.ids[j0 + t + 256] : -1;
+  };
+#pragma unroll
+  for (int q = 0; q < 4; ++q) load_ids(q, idr[q]);
   int p = 0;
-  for (int64_t b = e0; b < e1; ++b, p ^= 1) {
-    const int64_t bag = b * a.S + s;
-    const int32_t j0 = a.bag_offs[bag], j1 = a.bag_offs[bag + 1];
+  auto one_bag = [&](int q, int32_t (&r)[2]) {
+    if (q >= nbag) return;
+    int32_t j0, j1;
+    lens_of(q, j0, j1);
     const int32_t len = j1 - j0;
     int32_t *cp = cnt + p * R;
-    float *gp = gb + p * (SM_MAX_DIM + 1);
-    // ---- count the bag's ids (exact, whatever order the atomics land in); stage its gradient --------------------------------
-    for (int32_t j = j0 + t; j < j1; j += 256) {
+    if (r[0] >= 0) atomicAdd(&cp[r[0]], 1);
+    if (r[1] >= 0) atomicAdd(&cp[r[1]], 1);
+    for (int32_t j = j0 + 512 + t; j < j1; j += 256) {
       const int32_t id = a.ids[j];
       if (id >= 0) atomicAdd(&cp[id], 1);
     }
-    if (t < D) {
-      const float scale = len > 1 ? 1.0f / (float)len : 1.0f;      // mean combiner: every occurrence carries dx / len
-      gp[t] = (a.dx && sl.out_col >= 0) ? a.dx[b * a.ldx + sl.out_col + t] * scale : 0.f;
-    }
-    if (t == D) gp[D] = (sl.wide && a.dlogit) ? a.dlogit[b] : 0.f;
+    load_ids(q + 4, r);                                   // this slot of the ring: the bag four ahead
     __syncthreads();
-    // ---- every row's owner adds count x gradient to the row's partial sums (bags in ascending order: a fixed order of adds) ---
-    for (int r = t; r < R; r += 256) {
-      const int32_t n = cp[r];
+    const float scale = len > 1 ? 1.0f / (float)len : 1.0f;      // mean combiner: every occurrence carries dx / len
+    const float *gp = gs + q * (SM_MAX_DIM + 1);
+    for (int rr = t; rr < R; rr += 256) {
+      const int32_t n = cp[rr];
       if (n == 0) continue;
-      cp[r] = 0;                                  // this histogram is counted into again two bags from now
+      cp[rr] = 0;                                 // this histogram is counted into again two bags from now
       const float fn = (float)n;
-      float *pr = part + (int64_t)r * PW;
-      for (int d = 0; d < D; ++d) pr[d] += fn * gp[d];
+      float *pr = part + (int64_t)rr * PW;
+      for (int d = 0; d < D; ++d) pr[d] += fn * (gp[d] * scale);
       pr[D] += fn * gp[D];
       pr[D + 1] += fn;
     }
-    // (no second barrier: the next bag counts into the OTHER histogram and stages into the other gradient slot; a thread
-    // can be at most one barrier ahead of another)
+    p ^= 1;
+    // (no second barrier: the next bag counts into the OTHER histogram; a thread can be at most one barrier ahead of another)
+  };
+  for (int q0 = 0; q0 < nbag; q0 += 4) {
+    one_bag(q0 + 0, idr[0]);
+    one_bag(q0 + 1, idr[1]);
+    one_bag(q0 + 2, idr[2]);
+    one_bag(q0 + 3, idr[3]);
   }
   __syncthreads();
   float *out = a.part + ((int64_t)k * a.nslice + c) * a.part_rows * a.part_w;
@@ -192,16 +229,17 @@ __global__ void __launch_bounds__(256) k_small_apply(SmallArgs a) {
   const float *p = a.part + (int64_t)k * a.nslice * a.part_rows * a.part_w + (int64_t)r * a.part_w;
   const int64_t st = (int64_t)a.part_rows * a.part_w;
   float g = 0.f, hits = 0.f;
-  for (int c0 = 0; c0 < a.nslice; c0 += 8) {        // eight slices per round of loads, added in slice order
-    float v[8], h[8];
+  constexpr int RND = 32;                            // slices per round of loads, added in slice order (128 slices: 4 round trips)
+  for (int c0 = 0; c0 < a.nslice; c0 += RND) {
+    float v[RND], h[RND];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
+    for (int u = 0; u < RND; ++u) {
       const bool live = c0 + u < a.nslice;
       v[u] = live ? p[(c0 + u) * st + d] : 0.f;
       h[u] = live ? p[(c0 + u) * st + D + 1] : 0.f;
     }
 #pragma unroll
-    for (int u = 0; u < 8; ++u) { g += v[u]; hits += h[u]; }
+    for (int u = 0; u < RND; ++u) { g += v[u]; hits += h[u]; }
   }
   if (hits == 0.f) return;                          // the batch does not hold this row: it does not move
   if (d < D) {
@@ -270,7 +308,8 @@ extern "C" int wd_small_tables_bwd(float *emb, float *emb_accum, float *wide_wzn
   WD_REQUIRE((int64_t)nsmall * a.nslice * max_rows * (max_dim + 2) <= ws_floats, "workspace too small (wd_small_tables_ws_floats)");
   a.emb_w = emb; a.emb_acc = emb_accum; a.wide_w = wide_wzn;
   a.lr_emb = lr_emb; a.lr_w = lr_wide; a.l1 = l1; a.l2 = l2;
-  const size_t lds = (size_t)max_rows * (max_dim + 2) * 4 + (size_t)2 * max_rows * 4 + (size_t)2 * (SM_MAX_DIM + 1) * 4;
+  const size_t lds = (size_t)max_rows * (max_dim + 2) * 4 + (size_t)2 * max_rows * 4 + (size_t)2 * SM_SLICE * 4 +
+                     (size_t)SM_SLICE * (SM_MAX_DIM + 1) * 4;
   hipStream_t st = wd::as_stream(stream);
   hipLaunchKernelGGL(k_small_bwd, dim3((unsigned)a.nslice, (unsigned)nsmall), dim3(256), lds, st, a);
   hipLaunchKernelGGL(k_small_apply, dim3((unsigned)wd::ceil_div((int64_t)max_rows * (max_dim + 1), (int64_t)256), (unsigned)nsmall),

@@ -18,12 +18,16 @@ tbs = [synth.TokenBatch(eng.plan, synth.make_raw_batch(eng.plan, B, seed=2026092
 stamps = torch.zeros(64 + 128, dtype=torch.int64, device="cuda")
 
 
+NAMES = ["x tile", "F0", "F1", "F2", "head", "B2", "B1", "dx"]
+
+
 def report(tag):
     v = stamps.cpu().tolist()
     for wg, o in ((0, 0), (100, 32)):
         last = int(v[o + 27])
         cyc, rt = v[o + last] - v[o], (v[o + 29] - v[o + 28]) / 100.0
-        print("%-34s workgroup %3d: %7d cycles in %6.2f us = %.0f MHz" % (tag, wg, cyc, rt, cyc / max(rt, 1e-9)))
+        stages = ", ".join("%s %d" % (NAMES[i] if i < len(NAMES) else "s%d" % i, v[o + i + 1] - v[o + i]) for i in range(last))
+        print("%-34s workgroup %3d: %7d cycles in %6.2f us = %.0f MHz | %s" % (tag, wg, cyc, rt, cyc / max(rt, 1e-9), stages))
 
 
 side = pipeline.warm(eng, tbs)
@@ -43,7 +47,7 @@ report("tower alone, 200th back to back")
 # in the step: the chained multi-step graphs bench.py times, captured with the stamp buffer attached
 runner = pipeline.StepRunner(eng, tbs, steps=20, stream=side)
 runner.warm_up()
-for rep in range(4):
+for rep in range(3):
     runner.run(20)
     torch.cuda.synchronize()
     report("tower in the step (replay %d)" % rep)

@@ -263,6 +263,11 @@ class StepGraph:
             sort0, gather0 = sort_work, gather_work
             sort_work = lambda t: sort0(t) if (t <= 1 or "sort" not in skip) else None
             gather_work = lambda t: gather0(t) if (t <= 1 or "gather" not in skip) else None
+        # order of the two side jobs beside tower(t).  gather (default, round 5): the gather of batch t+1 first -- it meets the tower's
+        # x tile (both read HBM: the x tile 17 k -> 29 k cycles) and leaves the head and B2 alone (21 k -> 13 k, 12 k -> 10 k): tower
+        # -1 %, step -1.2 %, and the gather itself 12.8 -> 11.5 us in the step (roofline 0.28 -> 0.31).  WD_PIPE_SIDE=sort: rounds
+        # 3-4, sort first (the gather then lands on the narrow stages and the head).  profiles/r5_tower_stage_cycles_in_step.txt
+        gather_first = os.environ.get("WD_PIPE_SIDE", "gather") == "gather"
         ev_upd = None
         if not self.primed:
             sort_work(0)
@@ -273,8 +278,12 @@ class StepGraph:
             if ev_upd is not None:
                 main.wait_event(ev_upd)                 # update(t-1), with its patch of this step's x
             if t + 1 < len(seq):
-                sort_work(t + 1)
-                gather_work(t + 1)
+                if gather_first:
+                    gather_work(t + 1)
+                    sort_work(t + 1)
+                else:
+                    sort_work(t + 1)
+                    gather_work(t + 1)
             eng._apar, eng._prefetched = sact(t), True
             eng.forward(bt, need_loss=True)             # the tower launch: x from HBM, wide logit from the weight list
             ev_tower = ev_twr[t] = event(main)

@@ -267,6 +267,8 @@ class StepGraph:
         # x tile (both read HBM: the x tile 17 k -> 29 k cycles) and leaves the head and B2 alone (21 k -> 13 k, 12 k -> 10 k): tower
         # -1 %, step -1.2 %, and the gather itself 12.8 -> 11.5 us in the step (roofline 0.28 -> 0.31).  WD_PIPE_SIDE=sort: rounds
         # 3-4, sort first (the gather then lands on the narrow stages and the head).  profiles/r5_tower_stage_cycles_in_step.txt
+        # (bucketing first, then the gather, then the sort -- the gather under F0 instead of the x tile -- gives the x tile its 17-24 k
+        # cycles back and takes 52-59 k for F0: the tower's 188-190 k cycles do not move, the step is 2 % slower)
         gather_first = os.environ.get("WD_PIPE_SIDE", "gather") == "gather"
         ev_upd = None
         if not self.primed:

@@ -607,6 +607,13 @@ typedef struct wd_tail_layer {
   const float *dgamma_sum, *dbeta_sum;   /* [N] (when gamma_off / beta_off >= 0) */
   float *Wpk, *WTpk;         /* NULL: not packed (the logits layer) */
   int32_t nsplit, pk_tile;   /* pk_tile: 32 (the only packing) */
+  /* concatenating towers (wd_chain_windows_t): the segments of this layer's window, in window order -- rows
+   * [seg_k0[q], seg_k0[q] + seg_w[q]) of the kernel go to the pull operand seg_wt[q] of that segment (reduction length
+   * seg_kred[q]), kernel column n to its reduction row seg_red0[q] + n.  nseg = 0: WTpk = pack(W^T). */
+  int32_t nseg, pad_;
+  int32_t seg_k0[WD_CHAIN_MAX_LAYERS + 1], seg_w[WD_CHAIN_MAX_LAYERS + 1], seg_red0[WD_CHAIN_MAX_LAYERS + 1],
+      seg_kred[WD_CHAIN_MAX_LAYERS + 1];
+  float *seg_wt[WD_CHAIN_MAX_LAYERS + 1];
 } wd_tail_layer_t;
 int wd_chain_tail(const wd_tail_layer_t *layers, int32_t nlayers, float *P, float *Pacc, float *Gflat, float inv, float lr,
                   int32_t mode, wd_stream_t stream);
@@ -646,6 +653,24 @@ typedef struct wd_chain_input {
  *   tile_stamps diagnostics: device uint64[2 * wd_tower_chain_blocks]: every workgroup stores the constant-rate realtime
  *              clock (100 MHz, chip-wide) at its start and when its x tile is complete in LDS -- bench.py derives the
  *              in-step gather span from them */
+/* Concatenating towers in the one launch (python/lib/dnn.py:155-193: dnn_connected_mode 'dense' -- every layer reads
+ * [x | h_0 | .. | h_{l-1}] -- and 'resnet' -- [h_{l-1} | .. | h_0 | x], a concat, not an add: SURVEY App. C.8).  The activation row
+ * holds every segment once, in an order that makes each layer's input ONE contiguous column window; the row tile in LDS mirrors
+ * the row.  seg_col[0] = first column of x, seg_col[l + 1] = of hidden layer l's output; layer l reads layers[l].K columns from
+ * in_col[l] on, the logits layer k_logits columns from in_col[L] on (w_logits: that many weights, in window order);
+ * layers[l].Wpk = pack(W_l) with its K = the window width.  layers[l].WTpk = the PULL operand of segment l (x for l = 0, else
+ * the output of hidden layer l - 1): pack(B) with B[r][c] = W_j[row of column c of the segment in layer j's window][n],
+ * r = (N_l + .. + N_{j-1}) + n over the consumers j = l .. L-1 -- the gradient of a segment is one product over
+ * [dz_l | .. | dz_{L-1}], plus dlogit x the segment's logits weights (added in the epilogue).  wd_chain_tail writes these
+ * operands from wd_tail_layer_t.seg_*.  Needs N_0 + .. + N_{L-1} <= K0 (the dz tiles take the x region once x is dead), every
+ * width a multiple of 32, x / wide_logit given (no fused input layer, no wide_vals). */
+typedef struct wd_chain_windows {
+  int32_t seg_col[WD_CHAIN_MAX_LAYERS + 1];
+  int32_t in_col[WD_CHAIN_MAX_LAYERS + 1];
+  int32_t k_logits;
+  int32_t cols;          /* columns of the row tile: >= the end of every segment, multiple of 32 */
+} wd_chain_windows_t;
+
 typedef struct wd_chain_opts {
   const wd_chain_input_t *input;
   float *loss_part;
@@ -660,8 +685,10 @@ typedef struct wd_chain_opts {
   const float *wide_bias;
   float *wide_out;
   int32_t wide_S, pad_;
+  const wd_chain_windows_t *windows;   /* NULL: every layer reads its predecessor only ('simple') */
 } wd_chain_opts_t;
 int64_t wd_tower_chain_lds_bytes(int32_t K0, const int32_t *N, int32_t L, int32_t row_tile);   /* -1: unsupported shape */
+int64_t wd_tower_chain_windows_lds_bytes(const wd_chain_windows_t *windows, int32_t K0, const int32_t *N, int32_t L);
 int64_t wd_tower_chain_blocks(int64_t batch, int32_t row_tile);   /* ceil(batch / row_tile) */
 int wd_tower_chain(const float *x, int64_t ld_act, int32_t K0, const wd_chain_layer_t *layers, int32_t L, int32_t act,
                    float inv, const float *w_logits, const float *b_logits, const float *wide_logit,

@@ -110,3 +110,54 @@ def test_chain_unsupported_shapes_fall_back_to_layer_launches():
     assert not WideDeepEngine(criteo_spec(n_dense=3, n_sparse=5, buckets=50, dim=16, hidden=(32, 16, 8)), max_batch=64).chain
     assert not WideDeepEngine(criteo_spec(n_dense=8, n_sparse=3, buckets=50, dim=8, hidden=(64, 32), mode="dense"),
                               max_batch=64).chain
+
+
+@pytest.mark.parametrize("mode,B,kw", [
+    ("resnet", 100, dict(n_dense=16, n_sparse=3, buckets=500, dim=16, hidden=(32, 32))),                   # K0 = 64 = sum of the widths
+    ("dense", 70, dict(n_dense=16, n_sparse=7, buckets=300, dim=16, hidden=(64, 32, 32))),                 # K0 = 128
+    ("resnet", 257, dict(n_dense=13, n_sparse=26, buckets=2000, dim=16, hidden=(256, 128, 64))),           # BASELINE configs[3] tower
+    ("dense", 96, dict(n_dense=13, n_sparse=26, buckets=2000, dim=16, hidden=(256, 128, 64), activation="tanh")),
+    ("resnet", 64, dict(n_dense=0, n_sparse=6, buckets=100, dim=16, hidden=(96,))),                        # one hidden layer
+])
+def test_concatenating_towers_in_the_one_launch_match_per_layer_launches_and_the_oracle(mode, B, kw):
+    """dnn_connected_mode 'resnet' / 'dense' (python/lib/dnn.py:155-193: every layer reads the concat of what came before) in the
+    one-launch tower -- row tile mirroring the activation row, pull over [dz_l | .. | dz_{L-1}] + the logits layer's rank-1 term,
+    concatenated packed operands written by wd_chain_tail -- against the per-layer launches (WD_CHAIN=0) and the oracle's
+    autograd, multi-hot bags, three steps."""
+    from wide_deep_amd import synth
+    from wide_deep_amd.plan import criteo_spec
+    from tests.helpers import assert_close, oracle_batch, oracle_from_engine
+    kw = dict(kw)
+    activation = kw.pop("activation", None)
+    spec = criteo_spec(mode=mode, **kw)
+    if activation:
+        spec.activation = activation
+    a, b = _engines(spec, max_batch=B + 7)
+    assert a.towers[0]["windows"] is not None and not a.prefetch
+    ora = oracle_from_engine(a)
+    for step in range(3):
+        hb = synth.make_raw_batch(a.plan, B, seed=60 + step, pos_rate=0.3, mean_len=2)
+        bta, btb = synth.to_device_ids(a.plan, hb), synth.to_device_ids(b.plan, hb)
+        la, lb = a.train_step(bta), b.train_step(btb)
+        torch.cuda.synchronize()
+        oloss, ologits = ora.train_step(oracle_batch(a.plan, bta.ids.cpu().numpy(), bta.bag_offs.cpu().numpy(), B, hb["dense"], hb["labels"]))
+        assert_close(a.logit[:B], b.logit[:B], 2e-5, 2e-5, "logits vs per-layer, step %d" % step)
+        assert_close(a.logit[:B], ologits, 2e-4, 2e-5, "logits vs oracle, step %d" % step)
+        assert_close(a.dlogit[:B], b.dlogit[:B], 1e-5, 1e-6, "dlogit")
+        assert abs(float(la) - float(lb)) <= 1e-5 * max(1.0, abs(float(lb))) and abs(float(la) - oloss) <= 2e-4 * max(1.0, abs(oloss))
+        assert_close(a.G, b.G, 2e-4, 2e-6, "dense gradient step %d" % step)
+        dxa = a.towers[0]["dact"][:B, a.towers[0]["layout"].seg_start[0]: a.towers[0]["layout"].seg_start[0] + a.towers[0]["dx_cols"]]
+        dxb = b.towers[0]["dact"][:B, b.towers[0]["layout"].seg_start[0]: b.towers[0]["layout"].seg_start[0] + a.towers[0]["dx_cols"]]
+        assert_close(dxa, dxb, 2e-4, 2e-6, "dx step %d" % step)
+    sa, sb = a.export_state(), b.export_state()
+    for k in sb:
+        assert_close(sa[k], sb[k], 2e-4, 2e-6, k)
+    for k, v in ora.state.items():
+        if k != "global_step" and "moving_" not in k:
+            assert_close(sa[k], v.detach(), 5e-4, 1e-5, "vs oracle: " + k)
+    hb = synth.make_raw_batch(a.plan, B, seed=77, mean_len=2)
+    bta, btb = synth.to_device_ids(a.plan, hb), synth.to_device_ids(b.plan, hb)
+    bta.labels = btb.labels = None
+    a.forward(bta, need_loss=False); b.forward(btb, need_loss=False)
+    torch.cuda.synchronize()
+    assert_close(a.logit[:B], b.logit[:B], 2e-5, 2e-5, "predict logits")

@@ -84,7 +84,12 @@ class WdChainOpts(ctypes.Structure):
     _fields_ = [("input", ctypes.c_void_p), ("loss_part", ctypes.c_void_p), ("stamps", ctypes.c_void_p),
                 ("tile_stamps", ctypes.c_void_p), ("row_tile", ctypes.c_int32), ("flags", ctypes.c_int32),
                 ("wide_vals", ctypes.c_void_p), ("wide_bias", ctypes.c_void_p), ("wide_out", ctypes.c_void_p),
-                ("wide_S", ctypes.c_int32), ("pad_", ctypes.c_int32)]
+                ("wide_S", ctypes.c_int32), ("pad_", ctypes.c_int32), ("windows", ctypes.c_void_p)]
+
+
+class WdChainWindows(ctypes.Structure):
+    _fields_ = [("seg_col", ctypes.c_int32 * (WD_CHAIN_MAX_LAYERS + 1)), ("in_col", ctypes.c_int32 * (WD_CHAIN_MAX_LAYERS + 1)),
+                ("k_logits", ctypes.c_int32), ("cols", ctypes.c_int32)]
 
 
 class WdApplyNext(ctypes.Structure):
@@ -118,6 +123,10 @@ class WdTailLayer(ctypes.Structure):
         ("K", ctypes.c_int64), ("N", ctypes.c_int64), ("Gpart", ctypes.c_void_p), ("db_sum", ctypes.c_void_p),
         ("dgamma_sum", ctypes.c_void_p), ("dbeta_sum", ctypes.c_void_p), ("Wpk", ctypes.c_void_p), ("WTpk", ctypes.c_void_p),
         ("nsplit", ctypes.c_int32), ("pk_tile", ctypes.c_int32),
+        ("nseg", ctypes.c_int32), ("pad_", ctypes.c_int32),
+        ("seg_k0", ctypes.c_int32 * (WD_CHAIN_MAX_LAYERS + 1)), ("seg_w", ctypes.c_int32 * (WD_CHAIN_MAX_LAYERS + 1)),
+        ("seg_red0", ctypes.c_int32 * (WD_CHAIN_MAX_LAYERS + 1)), ("seg_kred", ctypes.c_int32 * (WD_CHAIN_MAX_LAYERS + 1)),
+        ("seg_wt", ctypes.c_void_p * (WD_CHAIN_MAX_LAYERS + 1)),
     ]
 
 
@@ -220,6 +229,7 @@ _PROTOS = {
     "wd_adam_untouched": [P, P, P, P, P, I32, I64, I64, P, P, P, P],
     "wd_adam_tick": [P, F32, F32, P],
     "wd_tower_chain_lds_bytes": [I32, P, I32, I32],
+    "wd_tower_chain_windows_lds_bytes": [P, I32, P, I32],
     "wd_tower_chain_blocks": [I64, I32],
     "wd_tower_chain": [P, I64, I32, P, I32, I32, F32, P, P, P, P, P, I64, P, P, P, P, P, P, P, I64, I32, P, P],
     "wd_chain_tail": [P, I32, P, P, P, F32, F32, I32, P],
@@ -243,7 +253,7 @@ _PROTOS = {
     "wd_diag_gather_modes": [P, I64, P, I64, I32, P, P],
     "wd_diag_access": [P, P, P, I32, P, I64, I32, I32, P, P],
 }
-_RESTYPES = {"wd_build_stamp": ctypes.c_char_p, "wd_prefetch_onehot_blocks": I64, "wd_feat_offsets_workspace_bytes": I64, "wd_sort_workspace_bytes": SZ, "wd_logits_head_blocks": I64, "wd_tower_chain_lds_bytes": I64, "wd_tower_chain_blocks": I64, "wd_bucket_max": I32, "wd_bucket_chunks": I32, "wd_route_chunks": I32, "wd_small_tables_ws_floats": I64}
+_RESTYPES = {"wd_build_stamp": ctypes.c_char_p, "wd_prefetch_onehot_blocks": I64, "wd_feat_offsets_workspace_bytes": I64, "wd_sort_workspace_bytes": SZ, "wd_logits_head_blocks": I64, "wd_tower_chain_lds_bytes": I64, "wd_tower_chain_windows_lds_bytes": I64, "wd_tower_chain_blocks": I64, "wd_bucket_max": I32, "wd_bucket_chunks": I32, "wd_route_chunks": I32, "wd_small_tables_ws_floats": I64}
 
 EXPORTED_SYMBOLS = sorted(list(_PROTOS) + ["wd_last_error"])
 

@@ -89,7 +89,21 @@ __device__ __forceinline__ void tail_apply(const wd_tail_layer_t &L, const TailC
     const int64_t K = L.K, N = L.N;
     const int64_t k = e / N, n = e - k * N;
     L.Wpk[((n >> 5) * (K >> 3) + (k >> 3)) * 256 + (((k & 1) << 5) + (n & 31)) * 4 + ((k & 7) >> 1)] = w;
-    if (L.WTpk) L.WTpk[((k >> 5) * (N >> 3) + (n >> 3)) * 256 + (((n & 1) << 5) + (k & 31)) * 4 + ((n & 7) >> 1)] = w;
+    if (L.nseg > 0) {
+      // concatenating tower: row k of the kernel belongs to one segment of the layer's window; the element goes to that
+      // segment's pull operand B[r][c], c = the row's column inside the segment, r = this layer's first reduction row there + n
+      for (int q = 0; q < L.nseg; ++q) {
+        const int64_t u = k - L.seg_k0[q];
+        if (u < 0 || u >= L.seg_w[q]) continue;
+        if (L.seg_wt[q]) {
+          const int64_t r = L.seg_red0[q] + n, R = L.seg_kred[q];
+          L.seg_wt[q][((u >> 5) * (R >> 3) + (r >> 3)) * 256 + (((r & 1) << 5) + (u & 31)) * 4 + ((r & 7) >> 1)] = w;
+        }
+        break;
+      }
+    } else if (L.WTpk) {
+      L.WTpk[((k >> 5) * (N >> 3) + (n >> 3)) * 256 + (((n & 1) << 5) + (k & 31)) * 4 + ((n & 7) >> 1)] = w;
+    }
   }
 }
 

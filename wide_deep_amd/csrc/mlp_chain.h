@@ -38,6 +38,15 @@ struct ChainArgs {
   const float *wv_bias;
   float *wv_out;
   int32_t wv_S;
+  // concatenating towers (wd_chain_windows_t): the row tile mirrors the activation row
+  int32_t win;                  // 0: every layer reads its predecessor only
+  int32_t x_off;                // LDS float offset of the x region (simple: 0)
+  int32_t in_off[MAXL + 1];     // LDS float offset of layer l's input window ([L]: the logits layer)
+  int32_t in_col[MAXL + 1];     // ... its first column (index into the column-wise affine tables)
+  int32_t seg_col[MAXL + 1];    // first column of segment s (0: x, l + 1: hidden layer l's output)
+  int32_t KL;                   // inputs of the logits layer
+  int32_t sall_off, tall_off;   // LDS float offsets of the column-wise BN affine of the whole row (x: 1 / 0)
+  int32_t cols;
 };
 
 __device__ __forceinline__ float act_fwd(float v, int act) {
@@ -80,5 +89,6 @@ __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlan
 namespace wd {
 // the kernel (mlp_chain8.hip): LDS bytes of its layout (-1: the shape does not fit), and the launch (> 0: call not supported)
 int64_t chain8_lds_bytes(int32_t K0, const int32_t *N, int32_t L, int32_t dx_cols);
+int64_t chain8_windows_lds_bytes(const wd_chain_windows_t *w, int32_t K0, const int32_t *N, int32_t L);
 int chain8_launch(const wd_chain::ChainArgs &g, wd_stream_t stream);
 }  // namespace wd

@@ -81,6 +81,11 @@ static int check_chain_input(const wd_chain_input_t *in) {
   return WD_OK;
 }
 
+extern "C" int64_t wd_tower_chain_windows_lds_bytes(const wd_chain_windows_t *windows, int32_t K0, const int32_t *N, int32_t L) {
+  if (!windows || !N) return -1;
+  return wd::chain8_windows_lds_bytes(windows, K0, N, L);
+}
+
 extern "C" int64_t wd_tower_chain_blocks(int64_t batch, int32_t row_tile) {
   return wd::ceil_div(batch, (int64_t)(row_tile ? row_tile : 32));
 }
@@ -104,11 +109,22 @@ extern "C" int wd_tower_chain(const float *x, int64_t ld_act, int32_t K0, const 
     N[l] = layers[l].N;
     WD_REQUIRE(layers[l].Wpk && layers[l].a_out, "layer pointers");
     WD_REQUIRE(!layers[l].gamma == !layers[l].beta, "BN needs both gamma and beta");
-    WD_REQUIRE(layers[l].K == (l == 0 ? K0 : layers[l - 1].N), "layer K must equal the previous width");
+    WD_REQUIRE((opts && opts->windows) || layers[l].K == (l == 0 ? K0 : layers[l - 1].N), "layer K must equal the previous width");
     if (labels) WD_REQUIRE(layers[l].dz_out && (l == 0 ? (!dx || layers[l].WTpk) : layers[l].WTpk != nullptr), "training needs dz_out / WTpk");
   }
-  WD_REQUIRE(wd::chain8_lds_bytes(K0, N, L, 0) > 0,
-             "unsupported tower shape (widths must be multiples of 32 and the row tile must fit the LDS; see wd_tower_chain_lds_bytes)");
+  const wd_chain_windows_t *win = opts ? opts->windows : nullptr;
+  if (win) {
+    WD_REQUIRE(!opts->input && !opts->wide_vals, "windows: x and the wide logit are given (no fused input layer, no wide_vals)");
+    WD_REQUIRE(wd::chain8_windows_lds_bytes(win, K0, N, L) > 0,
+               "unsupported concatenating tower (widths / columns multiples of 32, sum of the hidden widths <= K0, k_logits <= 1024, "
+               "the row tile must fit the LDS; see wd_tower_chain_windows_lds_bytes)");
+    WD_REQUIRE(layers[0].K == K0, "windows: the first layer reads x");
+    for (int l = 0; l < L; ++l)
+      WD_REQUIRE(layers[l].K > 0 && layers[l].K % 8 == 0 && win->in_col[l] + layers[l].K <= win->cols, "windows: a layer's window lies inside the row");
+  } else {
+    WD_REQUIRE(wd::chain8_lds_bytes(K0, N, L, 0) > 0,
+               "unsupported tower shape (widths must be multiples of 32 and the row tile must fit the LDS; see wd_tower_chain_lds_bytes)");
+  }
   const int dxc = dx ? round_up(dx_cols, rt) : 0;
   WD_REQUIRE(dxc <= K0, "dx_cols must be <= K0");
   g.L = L; g.act = act; g.inv = inv; g.K0 = K0; g.dx_cols = dxc;
@@ -118,6 +134,10 @@ extern "C" int wd_tower_chain(const float *x, int64_t ld_act, int32_t K0, const 
   g.dnn_logit = dnn_logit; g.logit = logit; g.prob = prob; g.dlogit = dlogit; g.loss_sum = loss_sum;
   g.Gpart_logits = Gpart_logits; g.dx = dx; g.ld_dx = ld_dx;
   g.flags_wt = wd::wt_mask() & WD_WT_TOWER ? 1 : 0;
+  if (win) {
+    g.win = 1; g.KL = win->k_logits; g.cols = win->cols;
+    for (int l = 0; l <= L; ++l) { g.seg_col[l] = win->seg_col[l]; g.in_col[l] = win->in_col[l]; }
+  }
   if (opts) {
     g.stamps = static_cast<unsigned long long *>(opts->stamps);
     g.tile_stamps = static_cast<unsigned long long *>(opts->tile_stamps);

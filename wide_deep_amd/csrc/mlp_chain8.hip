@@ -210,6 +210,9 @@ struct Aff8 {
   const float *s_out, *t_out;   // LDS tables of the OUTPUT layer's BN affine or NULL
   float *db_out, *dg_out, *dbeta_out;   // MODE 1: this row tile's column-sum partials [N] (HBM) or NULL
   int32_t wt;                   // HBM outputs stored at device scope (write-through), common.h
+  // concatenating towers, MODE 1 / 2: the logits layer reads this segment too -- acc[m][n] += dl[m] * wl[n] (dl: the tile's
+  // dlogit, wl: the segment's logits weights); NULL: the segment has one consumer (simple towers)
+  const float *dl, *wl;
 };
 
 // MODE 1: the wavefront's own tile, as its epilogue left it in LDS, row by row to HBM -- 8 lanes x 16 bytes per example row
@@ -243,6 +246,7 @@ __device__ __forceinline__ void epilogue8(const floatx16 &acc, int n0, float bv,
     }
     if (MODE == 1) {
       const float a = a_prev[n * P + m];
+      if (af.wl) v += af.dl[m] * af.wl[n];
       bsum += v;
       gsum += v * a;
       v = v * sv * act_bwd(a, a_id);
@@ -298,7 +302,7 @@ __device__ __forceinline__ void epilogue8t(const floatx16 &acc, int n0, int act,
         out[(nb + i) * P + c] = v;
         o[i] = __fadd_rn(__fmul_rn(v, ss[i]), tt[i]);
       } else {
-        o[i] = v;
+        o[i] = (MODE == 2 && af.wl) ? v + af.dl[c] * af.wl[nb + i] : v;
       }
     }
     if ((WD_CHAIN8_EXP & 8) || !row_ok) continue;
@@ -422,14 +426,14 @@ __global__ void __launch_bounds__(NTHR, 2) k_tower_chain8(Args8 A) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   __shared__ float sdl[RT];
   __shared__ float red[NTHR], red2[NTHR], red3[NTHR];
-  __shared__ float swl[512];   // logits-layer kernel
+  __shared__ float swl[1024];  // logits-layer kernel (concatenating towers: the whole row)
   __shared__ int64_t s_eoff[WD_CHAIN_MAX_SLOTS], s_rbase[WD_CHAIN_MAX_SLOTS];   // fused input layer: slot descriptors
   __shared__ int32_t s_ocol[WD_CHAIN_MAX_SLOTS];
   const int t = threadIdx.x;
   const int lane = t & 63, wave = uni(t >> 6);
   const int64_t b0 = (int64_t)blockIdx.x * RT;
   const int L = uni(g.L);
-  float *regx = lds;  // x, later the dz_l
+  float *regx = lds + uni(g.x_off);  // x; the dz_l take this region once x is dead
   int nstamp = 0;
   auto stamp = [&]() {
     if (g.stamps && (blockIdx.x == 0 || blockIdx.x == 100) && t == 0)
@@ -451,7 +455,7 @@ __global__ void __launch_bounds__(NTHR, 2) k_tower_chain8(Args8 A) {
   }
 
   // ---- head inputs: requested now, consumed after the last hidden layer (no exposed latency there) -------------
-  const int KL = uni(g.layer[L - 1].N);
+  const int KL = g.win ? uni(g.KL) : uni(g.layer[L - 1].N);
   for (int n = t; n < KL; n += NTHR) swl[n] = g.w_logits[n];
   float h_wide = 0.f, h_y = 0.f, h_w = 1.0f, h_bias = 0.f;
   if (t < RT && b0 + t < g.batch) {
@@ -468,6 +472,23 @@ __global__ void __launch_bounds__(NTHR, 2) k_tower_chain8(Args8 A) {
       tab[n] = ly.gamma ? ly.gamma[n] * g.inv : 1.0f;
       tab[ly.N + n] = ly.beta ? ly.beta[n] : 0.0f;
       tab[2 * ly.N + n] = ly.bias ? ly.bias[n] : 0.0f;
+    }
+  }
+
+  if (g.win) {
+    // concatenating towers: the BN affine of the WHOLE row, column by column (x: the identity) -- a layer's input window spans
+    // several segments, its fragment reads index these tables by column
+    float *sall = lds + g.sall_off, *tall = lds + g.tall_off;
+    for (int c = t; c < g.cols; c += NTHR) { sall[c] = 1.0f; tall[c] = 0.0f; }
+    lds_barrier();
+    for (int l = 0; l < L; ++l) {
+      const wd_chain_layer_t &ly = g.layer[l];
+      if (!ly.gamma) continue;
+      const int c0 = g.seg_col[l + 1];
+      for (int n = t; n < ly.N; n += NTHR) {
+        sall[c0 + n] = ly.gamma[n] * g.inv;
+        tall[c0 + n] = ly.beta[n];
+      }
     }
   }
 
@@ -620,7 +641,12 @@ __global__ void __launch_bounds__(NTHR, 2) k_tower_chain8(Args8 A) {
     float *out = lds + g.a_off[l];
     Aff8 af{};
     af.wt = g.flags_wt;
-    if (l > 0 && g.layer[l - 1].gamma) { af.s_in = lds + g.tab_off[l - 1]; af.t_in = af.s_in + g.layer[l - 1].N; }
+    if (g.win) {
+      in = lds + g.in_off[l];       // the layer's window of the row tile ([h_{l-1} | .. | x] or [x | .. | h_{l-1}])
+      if (l > 0) { af.s_in = lds + g.sall_off + g.in_col[l]; af.t_in = lds + g.tall_off + g.in_col[l]; }
+    } else if (l > 0 && g.layer[l - 1].gamma) {
+      af.s_in = lds + g.tab_off[l - 1]; af.t_in = af.s_in + g.layer[l - 1].N;
+    }
     if (ly.gamma) { af.s_out = lds + g.tab_off[l]; af.t_out = af.s_out + ly.N; }
     stage8<0>(A, l, in, out, nullptr, ly.a_out, g.ld_act, ly.N, ly.bias ? lds + g.tab_off[l] + 2 * ly.N : nullptr, g.act, af, fb, lds,
               b0, g.batch, false);
@@ -630,9 +656,18 @@ __global__ void __launch_bounds__(NTHR, 2) k_tower_chain8(Args8 A) {
   }
 
   // ---- logits layer + head (in = a_{L-1} [K][P]) ------------------------------------------------------------
+  if (g.win) {     // the logits layer reads its window of the row tile
+    in = lds + g.in_off[L];
+    K = KL;
+  }
+  const float *sL_ = g.win ? lds + g.sall_off + g.in_col[L] : lds + g.tab_off[L - 1];
+  const float *tL_ = g.win ? lds + g.tall_off + g.in_col[L] : sL_ + K;
+  // the last hidden layer inside that window: its activations, logits weights and affine (simple: the window IS that layer)
+  const int NL = uni(g.layer[L - 1].N), woffL = g.win ? uni(g.seg_col[L] - g.in_col[L]) : 0;
+  const float *aL = g.win ? lds + g.a_off[L - 1] : in;
   {
     const int m = t % RT, part = t / RT;
-    const float *sL = lds + g.tab_off[L - 1], *tL = sL + K;     // affine of the last hidden layer (identity without BN)
+    const float *sL = sL_, *tL = tL_;     // affine of the logits layer's inputs (identity without BN / for x)
     const bool wlist = (g.in.emb && g.in.wide) || g.wv;      // wide weights of the tile's occurrences in the wv registers
     if (wlist) {
       // the wide weights requested with the tile have long arrived: registers -> LDS (the x region is dead since the first
@@ -704,54 +739,9 @@ __global__ void __launch_bounds__(NTHR, 2) k_tower_chain8(Args8 A) {
     float *dz = lds + g.dz_off[L - 1];
     const wd_chain_layer_t &ll = g.layer[L - 1];
     float *gdz = ll.dz_out;
-    const float *sL = lds + g.tab_off[L - 1], *tL = sL + K;
+    const float *sL = sL_, *tL = tL_;
     float *Gp = g.Gpart_logits ? g.Gpart_logits + (int64_t)blockIdx.x * (K + 1) : nullptr;
-    const int KT = K < NTHR ? K : NTHR;   // lanes along n: coalesced HBM rows, conflict-free LDS
-    const int MQ = NTHR / KT;             // K < 512: several example groups in parallel
-    const int nq = t % KT, mq = t / KT;
-    float *dbp = ll.db_part ? ll.db_part + (int64_t)blockIdx.x * K : nullptr;
-    float *dgp = ll.dgamma_part ? ll.dgamma_part + (int64_t)blockIdx.x * K : nullptr;
-    float *dtp = ll.dbeta_part ? ll.dbeta_part + (int64_t)blockIdx.x * K : nullptr;
-    if (mq < MQ) {
-      for (int n = nq; n < K; n += KT) {
-        const float w = swl[n], sv = sL[n];
-        float csum = 0.f, gsum = 0.f, bsum = 0.f;
-        for (int m = mq; m < RT; m += MQ) {
-          const float a = in[n * P + m];
-          const float dbn = sdl[m] * w;
-          bsum += dbn;
-          gsum += dbn * a;
-          const float v = dbn * sv * act_bwd(a, g.act);
-          dz[n * P + m] = v;
-          if (b0 + m < g.batch) wd::store1(&gdz[(b0 + m) * K + n], v, g.flags_wt);
-          csum += v;
-        }
-        if (MQ == 1) {
-          if (dbp) dbp[n] = csum;
-          if (dgp) dgp[n] = gsum;
-          if (dtp) dtp[n] = bsum;
-        } else {     // K < 512: MQ * KT <= 512 partial sums each, combined below in group order
-          red[mq * KT + n] = csum;
-          red2[mq * KT + n] = gsum;
-          red3[mq * KT + n] = bsum;
-        }
-      }
-    }
-    if (MQ > 1) {
-      lds_barrier();
-      if (t < K) {
-        float v = red[t], u = red2[t], x = red3[t];
-        for (int j = 1; j < MQ; ++j) {
-          v += red[j * KT + t];
-          u += red2[j * KT + t];
-          x += red3[j * KT + t];
-        }
-        if (dbp) dbp[t] = v;
-        if (dgp) dgp[t] = u;
-        if (dtp) dtp[t] = x;
-      }
-    }
-    if (Gp) {     // logits kernel gradient: its input is bn_{L-1}
+    auto logits_kernel_gradient = [&]() {     // its input is the logits layer's window of bn values (simple: bn_{L-1})
       for (int n = t; n < K; n += NTHR) {
         float gw = 0.f;
 #pragma unroll 8
@@ -763,7 +753,58 @@ __global__ void __launch_bounds__(NTHR, 2) k_tower_chain8(Args8 A) {
         for (int m = 0; m < RT; ++m) v += sdl[m];
         Gp[K] = v;
       }
+    };
+    if (g.win && Gp) {     // the window holds x, and the dz tiles below take x's region: read it first
+      logits_kernel_gradient();
+      lds_barrier();
     }
+    const float *wl = swl + woffL, *sLs = sL + woffL;      // the last hidden layer's share of the logits layer
+    const int KT = NL < NTHR ? NL : NTHR;   // lanes along n: coalesced HBM rows, conflict-free LDS
+    const int MQ = NTHR / KT;               // N_{L-1} < 512: several example groups in parallel
+    const int nq = t % KT, mq = t / KT;
+    float *dbp = ll.db_part ? ll.db_part + (int64_t)blockIdx.x * NL : nullptr;
+    float *dgp = ll.dgamma_part ? ll.dgamma_part + (int64_t)blockIdx.x * NL : nullptr;
+    float *dtp = ll.dbeta_part ? ll.dbeta_part + (int64_t)blockIdx.x * NL : nullptr;
+    if (mq < MQ) {
+      for (int n = nq; n < NL; n += KT) {
+        const float w = wl[n], sv = sLs[n];
+        float csum = 0.f, gsum = 0.f, bsum = 0.f;
+        for (int m = mq; m < RT; m += MQ) {
+          const float a = aL[n * P + m];
+          const float dbn = sdl[m] * w;
+          bsum += dbn;
+          gsum += dbn * a;
+          const float v = dbn * sv * act_bwd(a, g.act);
+          dz[n * P + m] = v;
+          if (b0 + m < g.batch) wd::store1(&gdz[(b0 + m) * NL + n], v, g.flags_wt);
+          csum += v;
+        }
+        if (MQ == 1) {
+          if (dbp) dbp[n] = csum;
+          if (dgp) dgp[n] = gsum;
+          if (dtp) dtp[n] = bsum;
+        } else {     // N_{L-1} < 512: MQ * KT <= 512 partial sums each, combined below in group order
+          red[mq * KT + n] = csum;
+          red2[mq * KT + n] = gsum;
+          red3[mq * KT + n] = bsum;
+        }
+      }
+    }
+    if (MQ > 1) {
+      lds_barrier();
+      if (t < NL) {
+        float v = red[t], u = red2[t], x = red3[t];
+        for (int j = 1; j < MQ; ++j) {
+          v += red[j * KT + t];
+          u += red2[j * KT + t];
+          x += red3[j * KT + t];
+        }
+        if (dbp) dbp[t] = v;
+        if (dgp) dgp[t] = u;
+        if (dtp) dtp[t] = x;
+      }
+    }
+    if (Gp && !g.win) logits_kernel_gradient();
   }
   lds_barrier();
   stamp();
@@ -780,6 +821,7 @@ __global__ void __launch_bounds__(NTHR, 2) k_tower_chain8(Args8 A) {
     af.db_out = lp.db_part ? lp.db_part + (int64_t)blockIdx.x * lp.N : nullptr;
     af.dg_out = lp.dgamma_part ? lp.dgamma_part + (int64_t)blockIdx.x * lp.N : nullptr;
     af.dbeta_out = lp.dbeta_part ? lp.dbeta_part + (int64_t)blockIdx.x * lp.N : nullptr;
+    if (g.win) { af.dl = sdl; af.wl = swl + (g.seg_col[l] - g.in_col[L]); }      // + dlogit x the logits weights of this segment
     stage8<1>(A, s, lds + g.dz_off[l], lds + g.dz_off[l - 1], lds + g.a_off[l - 1], lp.dz_out, lp.N, lp.N, nullptr, g.act, af, fb,
               lds, b0, g.batch, l == 1 && !want_dx);
     stamp();
@@ -787,6 +829,7 @@ __global__ void __launch_bounds__(NTHR, 2) k_tower_chain8(Args8 A) {
   if (want_dx) {
     Aff8 af{};
     af.wt = g.flags_wt;
+    if (g.win) { af.dl = sdl; af.wl = swl + (g.seg_col[0] - g.in_col[L]); }
     stage8<2>(A, s, lds + g.dz_off[0], nullptr, nullptr, g.dx, g.ld_dx, g.K0, nullptr, 0, af, fb, lds, b0, g.batch, true);
   }
   stamp();
@@ -824,6 +867,43 @@ int64_t layout8(int32_t K0, const int32_t *N, int32_t L, int32_t *a_off, int32_t
   if (sum_n_out) *sum_n_out = sum_n;
   const int64_t bytes = off * 4;
   return bytes <= 148 * 1024 ? bytes : -1;   // 160 KB per workgroup minus the kernel's static arrays (~11 KB)
+}
+
+// Concatenating towers: the row tile mirrors the activation row (cols columns of P floats; segment s at seg_col[s]); the dz
+// tiles take x's region once x is dead, in ASCENDING layer order -- the gradient of segment l is one product over the suffix
+// [dz_l | .. | dz_{L-1}] --; behind the tile the per-layer tables (s, t, bias) and the column-wise affine of the whole row.
+int64_t layout8w(const wd_chain_windows_t &w, int32_t K0, const int32_t *N, int32_t L, int32_t *a_off, int32_t *dz_off,
+                 int32_t *tab_off, int32_t *x_off, int32_t *sall_off, int32_t *tall_off) {
+  if (L < 1 || L > MAXL || K0 <= 0 || K0 % RT || w.cols <= 0 || w.cols % RT || w.k_logits <= 0 || w.k_logits > 1024) return -1;
+  int64_t sum_n = 0;
+  for (int l = 0; l < L; ++l) {
+    if (N[l] <= 0 || N[l] % RT || N[l] > 512) return -1;
+    if (w.seg_col[l + 1] < 0 || w.seg_col[l + 1] % RT || w.seg_col[l + 1] + N[l] > w.cols) return -1;
+    sum_n += N[l];
+  }
+  if (w.seg_col[0] < 0 || w.seg_col[0] % RT || w.seg_col[0] + K0 > w.cols || sum_n > K0) return -1;
+  for (int l = 0; l <= L; ++l)
+    if (w.in_col[l] < 0 || w.in_col[l] % 8) return -1;
+  if (w.in_col[L] + w.k_logits > w.cols) return -1;
+  for (int l = 0; l < L; ++l)
+    if (a_off) a_off[l] = (int32_t)((int64_t)w.seg_col[l + 1] * P);
+  if (x_off) *x_off = (int32_t)((int64_t)w.seg_col[0] * P);
+  int64_t off = (int64_t)w.seg_col[0] * P;
+  for (int l = 0; l < L; ++l) {
+    if (dz_off) dz_off[l] = (int32_t)off;
+    off += (int64_t)N[l] * P;
+  }
+  off = (int64_t)w.cols * P;
+  for (int l = 0; l < L; ++l) {
+    if (tab_off) tab_off[l] = (int32_t)off;
+    off += 3 * (int64_t)N[l];
+  }
+  if (sall_off) *sall_off = (int32_t)off;
+  off += w.cols;
+  if (tall_off) *tall_off = (int32_t)off;
+  off += w.cols;
+  const int64_t bytes = off * 4;
+  return bytes <= 148 * 1024 ? bytes : -1;
 }
 
 // the phases of one stage: 8 column tiles x 1 slice while 8 are left, then 4 x 2, 2 x 4, 1 x 8 for what remains.  The partial
@@ -873,6 +953,23 @@ int64_t chain8_lds_bytes(int32_t K0, const int32_t *N, int32_t L, int32_t dx_col
   return layout8(K0, N, L, nullptr, nullptr, nullptr, nullptr, nullptr);
 }
 
+int64_t chain8_windows_lds_bytes(const wd_chain_windows_t *w, int32_t K0, const int32_t *N, int32_t L) {
+  return layout8w(*w, K0, N, L, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+}
+
+// adjacent dead regions as one (the scratch of a split phase wants SCR_SLOTS tiles in a row)
+static int merge_regions(Region *r, int n) {
+  for (int i = 1; i < n; ++i)
+    for (int j = i; j > 0 && r[j].off < r[j - 1].off; --j) { const Region q = r[j]; r[j] = r[j - 1]; r[j - 1] = q; }
+  int m = 0;
+  for (int i = 0; i < n; ++i) {
+    if (r[i].size <= 0) continue;
+    if (m > 0 && r[m - 1].off + r[m - 1].size == r[i].off) r[m - 1].size += r[i].size;
+    else r[m++] = r[i];
+  }
+  return m;
+}
+
 int chain8_launch(const ChainArgs &g0, wd_stream_t stream) {
   Args8 A{};
   A.g = g0;
@@ -881,15 +978,59 @@ int chain8_launch(const ChainArgs &g0, wd_stream_t stream) {
   int32_t N[MAXL];
   for (int l = 0; l < L; ++l) N[l] = g.layer[l].N;
   int64_t regx = 0, sum_n = 0;
-  const int64_t bytes = layout8(g.K0, N, L, g.a_off, g.dz_off, g.tab_off, &regx, &sum_n);
+  int64_t bytes;
+  if (g.win) {
+    wd_chain_windows_t w{};
+    for (int l = 0; l <= L; ++l) { w.seg_col[l] = g.seg_col[l]; w.in_col[l] = g.in_col[l]; }
+    w.k_logits = g.KL; w.cols = g.cols;
+    bytes = layout8w(w, g.K0, N, L, g.a_off, g.dz_off, g.tab_off, &g.x_off, &g.sall_off, &g.tall_off);
+    for (int l = 0; l <= L; ++l) g.in_off[l] = (int32_t)((int64_t)g.in_col[l] * P);
+  } else {
+    bytes = layout8(g.K0, N, L, g.a_off, g.dz_off, g.tab_off, &regx, &sum_n);
+  }
   if (bytes <= 0) return 1;    // > 0: this kernel does not take the shape -- the caller falls back
   // 16-byte stores of the activations, dz and dx
   auto al16 = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
   if (g.ld_act % 4 || (g.dx && (g.ld_dx % 4 || !al16(g.dx)))) return 1;
   for (int l = 0; l < L; ++l)
     if (!al16(g.layer[l].a_out) || (g.train && !al16(g.layer[l].dz_out))) return 1;
-  const int64_t a_end = g.a_off[L - 1] + (int64_t)N[L - 1] * P, dz_end = g.dz_off[0] + (int64_t)N[0] * P;
   int nph = 0, s = 0;
+  int nph_fwd = 0;
+  if (g.win) {
+    // F_l reads its window (x stays alive through the whole forward): only the outputs of LATER layers are dead
+    for (int l = 0; l < L; ++l) {
+      Region fr[MAXL];
+      int nf = 0;
+      for (int j = l + 1; j < L; ++j) fr[nf++] = Region{g.a_off[j], (int64_t)N[j] * P};
+      nf = merge_regions(fr, nf);
+      if (g.layer[l].K <= 0 || g.layer[l].K % GK) return 1;
+      if (!add_stage(A, nph, s, g.layer[l].Wpk, g.layer[l].K, N[l], fr, nf)) return 1;
+    }
+    nph_fwd = nph;
+    if (g.train) {
+      // the stage that produces dz_{l-1} reads [dz_l | .. | dz_{L-1}] and a_{l-1}: a_l .. a_{L-1} are dead, and so is what the x
+      // region holds below dz_{l-1}
+      int64_t kred = 0;
+      for (int l = L - 1; l >= 1; --l) {
+        kred += N[l];
+        Region fr[MAXL + 1];
+        int nf = 0;
+        for (int j = l; j < L; ++j) fr[nf++] = Region{g.a_off[j], (int64_t)N[j] * P};
+        if (l >= 2) fr[nf++] = Region{g.x_off, (int64_t)g.dz_off[l - 1] - g.x_off};
+        nf = merge_regions(fr, nf);
+        if (!add_stage(A, nph, s, g.layer[l].WTpk, (int)kred, N[l - 1], fr, nf)) return 1;
+      }
+      if (g.dx && g.dx_cols > 0) {
+        kred += N[0];
+        Region fr[MAXL];
+        int nf = 0;
+        for (int j = 0; j < L; ++j) fr[nf++] = Region{g.a_off[j], (int64_t)N[j] * P};
+        nf = merge_regions(fr, nf);
+        if (!add_stage(A, nph, s, g.layer[0].WTpk, (int)kred, g.dx_cols, fr, nf)) return 1;
+      }
+    }
+  } else {
+  const int64_t a_end = g.a_off[L - 1] + (int64_t)N[L - 1] * P, dz_end = g.dz_off[0] + (int64_t)N[0] * P;
   for (int l = 0; l < L; ++l) {
     // F_l reads x (l = 0) or a_{l-1} and writes a_l: the x region is dead from F_1 on, a_{l+1} .. are not written yet
     Region fr[2];
@@ -898,7 +1039,7 @@ int chain8_launch(const ChainArgs &g0, wd_stream_t stream) {
     if (l + 1 < L) fr[nf++] = Region{g.a_off[l + 1], a_end - g.a_off[l + 1]};
     if (!add_stage(A, nph, s, g.layer[l].Wpk, l == 0 ? g.K0 : N[l - 1], N[l], fr, nf)) return 1;
   }
-  const int nph_fwd = nph;
+  nph_fwd = nph;
   if (g.train) {
     for (int l = L - 1; l >= 1; --l) {
       // B_l reads dz_l and a_{l-1}, writes dz_{l-1}: dz_{L-1} .. dz_{l+1} and a_l .. a_{L-1} are dead, dz_{l-2} .. dz_0 (and
@@ -920,6 +1061,7 @@ int chain8_launch(const ChainArgs &g0, wd_stream_t stream) {
       fr[nf++] = Region{g.a_off[0], a_end - g.a_off[0]};
       if (!add_stage(A, nph, s, g.layer[0].WTpk, N[0], g.dx_cols, fr, nf)) return 1;
     }
+  }
   }
   A.ph_first[s] = nph;
   A.nph = g.train ? nph : nph_fwd;

@@ -451,18 +451,35 @@ class WideDeepEngine:
         tw = self.towers[0]
         tl, metas, L = tw["layout"], tw["metas"], tw["L"]
         self.chain_rt = 32           # examples per workgroup of the one-launch tower (csrc/mlp_chain8.hip)
-        if tl.mode != "simple" or L < 1 or L > capi.WD_CHAIN_MAX_LAYERS or tl.in_start[0] % 4 or tl.ld % 4:
+        # concatenating towers (python/lib/dnn.py:155-193: 'dense', 'resnet') take the same launch: the row tile in LDS mirrors the
+        # activation row, whose segment order already makes every layer's input one contiguous window (plan.TowerLayout)
+        windows = (tl.mode in ("dense", "resnet") and not tl.copies and type(self) is WideDeepEngine
+                   and os.environ.get("WD_CHAIN_WINDOWS", "1") != "0")
+        if (tl.mode != "simple" and not windows) or L < 1 or L > capi.WD_CHAIN_MAX_LAYERS or tl.in_start[0] % 4 or tl.ld % 4:
             return
         dims = [int(metas[l]["N"]) for l in range(L)]
         K0 = int(metas[0]["K"])
         rt = 32
-        if int(call("wd_tower_chain_lds_bytes", K0, (ctypes.c_int32 * L)(*dims), L, rt)) <= 0:
+        tw["windows"] = None
+        if windows:
+            w = capi.WdChainWindows()
+            for sg in range(L + 1):
+                w.seg_col[sg], w.in_col[sg] = int(tl.seg_start[sg]), int(tl.in_start[sg])
+            w.k_logits, w.cols = int(metas[L]["K"]), (int(tl.ld) + 31) // 32 * 32
+            if int(call("wd_tower_chain_windows_lds_bytes", ctypes.byref(w), K0, (ctypes.c_int32 * L)(*dims), L)) <= 0:
+                return
+            tw["windows"] = w
+        elif int(call("wd_tower_chain_lds_bytes", K0, (ctypes.c_int32 * L)(*dims), L, rt)) <= 0:
             return
         dev, B = self.device, self.max_batch
         f32 = dict(dtype=torch.float32, device=dev)
         # the kernels in MFMA-fragment order, forward and transposed (wd_chain_layer_t.Wpk / WTpk: written by wd_chain_tail)
         tw["Wpk"] = [torch.zeros(metas[l]["N"] * metas[l]["K"], **f32) for l in range(L)]
-        tw["WTpk"] = [torch.zeros(metas[l]["N"] * metas[l]["K"], **f32) for l in range(L)]
+        if windows:
+            # the PULL operand of segment l (x for l = 0, else hidden layer l - 1's output): [N_l + .. + N_{L-1}] x [segment width]
+            tw["WTpk"] = [torch.zeros(sum(dims[l:]) * int(tl.seg_width[l]), **f32) for l in range(L)]
+        else:
+            tw["WTpk"] = [torch.zeros(metas[l]["N"] * metas[l]["K"], **f32) for l in range(L)]
         tw["dzl"] = [torch.zeros(B * metas[l]["N"], **f32) for l in range(L)]
         # bias / BN gradients: per-row-tile column sums from the tower kernel (dz; d(bn) * a; d(bn)), reduced by column-sum jobs
         # of the grouped weight-gradient launch -- the products need no appended ones row (449 = 7 x 64 + 1 rows cost an 8th
@@ -505,6 +522,15 @@ class WideDeepEngine:
             t.db_sum = tw["db_sum"][l].data_ptr()
             t.dgamma_sum, t.dbeta_sum = (tw["dg_sum"][l].data_ptr(), tw["dbeta_sum"][l].data_ptr()) if bn else (None, None)
             t.Wpk, t.WTpk = tw["Wpk"][l].data_ptr(), tw["WTpk"][l].data_ptr()
+            if windows:      # rows of this layer's kernel by segment of its window -> that segment's pull operand
+                segs = list(tl.in_segs[l])
+                t.nseg = len(segs)
+                for q, sg in enumerate(segs):
+                    t.seg_k0[q] = int(tl.seg_start[sg] - tl.in_start[l])
+                    t.seg_w[q] = int(tl.seg_width[sg])
+                    t.seg_red0[q] = sum(dims[sg:l])          # the dz tiles lie in ascending layer order from dz_sg on
+                    t.seg_kred[q] = sum(dims[sg:])
+                    t.seg_wt[q] = tw["WTpk"][sg].data_ptr()
             c = carr[l]
             c.Wpk, c.WTpk, c.bias = tw["Wpk"][l].data_ptr(), tw["WTpk"][l].data_ptr(), pbase + 4 * m["b_off"]
             c.gamma, c.beta = (pbase + 4 * m["gamma_off"], pbase + 4 * m["beta_off"]) if bn else (None, None)
@@ -532,7 +558,7 @@ class WideDeepEngine:
         that update (wd_apply_next_t).  WD_INPUT_AHEAD=0: the tower kernel gathers its own x tile (wd_chain_input_t)."""
         self._apar = 0                 # activation buffer / wide-weight list the current step uses
         self._prefetched = False       # pipeline.StepGraph: x / wv of the batch forward() is called with are already in place
-        self.prefetch = bool(self.spec.has_deep and self.chain and self.rec is not None and type(self) is WideDeepEngine
+        self.prefetch = bool(self.spec.has_deep and self.chain and self.towers[0].get("windows") is None and self.rec is not None and type(self) is WideDeepEngine
                              and self._fused_input_layer and os.environ.get("WD_INPUT_AHEAD", "1") != "0")
         if not self.prefetch:
             return
@@ -618,6 +644,8 @@ class WideDeepEngine:
         one embedding group, no indicator columns -- the Criteo shape.  WD_CHAIN_INPUT=0 keeps wd_input_layer_fwd."""
         if not (self.spec.has_deep and self.chain and self._fused_input_layer and bt.one_hot):
             return False
+        if self.towers[0].get("windows") is not None:      # concatenating towers read x (and the wide logit) from HBM
+            return False
         if os.environ.get("WD_CHAIN_INPUT", "1") == "0":
             return False
         (dim, sl), = self.plan.emb_groups.items()
@@ -667,6 +695,8 @@ class WideDeepEngine:
         opts.tile_stamps = self._chain_tile_stamps
         opts.row_tile = self.chain_rt
         opts.flags = int(os.environ.get("WD_CHAIN_FLAGS", "0"))
+        if tw.get("windows") is not None:
+            opts.windows = ctypes.addressof(tw["windows"])
         call("wd_tower_chain", tw["acts"][p].data_ptr() + 4 * tl.in_start[0], tl.ld, int(metas[0]["K"]), tw["chain_layers_p"][p], L,
              self.act_id, self.inv, self.P.data_ptr() + 4 * metas[L]["w_off"], self.P.data_ptr() + 4 * metas[L]["b_off"],
              None if fuse_in else ptr(self.wide_logit),
@@ -1225,7 +1255,7 @@ class WideDeepEngine:
             if after_products is not None:
                 after_products()
             fused_opt = False
-            if self.all_simple:
+            if self.all_simple or self.chain:
                 if not head_done:
                     raise NotImplementedError("multi-tower + all-layer finalize")  # guarded in __init__
                 # single GPU + Adagrad: the dense update rides in the finalize launch (nothing reduces G in between)

@@ -12,7 +12,7 @@ from wide_deep_amd.plan import criteo_spec
 B = int(os.environ.get("CHAIN_B", "8192"))
 iters = int(os.environ.get("CHAIN_ITERS", "50"))
 hidden = tuple(int(v) for v in os.environ.get("CHAIN_HIDDEN", "256,128,64").split(","))
-spec = criteo_spec(buckets=1000, hidden=hidden)
+spec = criteo_spec(buckets=1000, hidden=hidden, mode=os.environ.get("CHAIN_MODE", "simple"))
 eng = WideDeepEngine(spec, max_batch=B, seed=1)
 assert eng.chain
 hb = synth.make_raw_batch(eng.plan, B, seed=3, pos_rate=0.3)

@@ -145,7 +145,9 @@ def test_concatenating_towers_in_the_one_launch_match_per_layer_launches_and_the
         assert_close(a.logit[:B], ologits, 2e-4, 2e-5, "logits vs oracle, step %d" % step)
         assert_close(a.dlogit[:B], b.dlogit[:B], 1e-5, 1e-6, "dlogit")
         assert abs(float(la) - float(lb)) <= 1e-5 * max(1.0, abs(float(lb))) and abs(float(la) - oloss) <= 2e-4 * max(1.0, abs(oloss))
-        assert_close(a.G, b.G, 2e-4, 2e-6, "dense gradient step %d" % step)
+        # step 0 starts from identical parameters; afterwards the two summation orders have been through Adagrad's g / sqrt(acc),
+        # which turns a rounding-level difference of a near-zero gradient into a difference of the parameter
+        assert_close(a.G, b.G, 2e-4, 2e-6 if step == 0 else 5e-5, "dense gradient step %d" % step)
         dxa = a.towers[0]["dact"][:B, a.towers[0]["layout"].seg_start[0]: a.towers[0]["layout"].seg_start[0] + a.towers[0]["dx_cols"]]
         dxb = b.towers[0]["dact"][:B, b.towers[0]["layout"].seg_start[0]: b.towers[0]["layout"].seg_start[0] + a.towers[0]["dx_cols"]]
         assert_close(dxa, dxb, 2e-4, 2e-6, "dx step %d" % step)

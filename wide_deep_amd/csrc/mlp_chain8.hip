@@ -31,6 +31,8 @@ constexpr int NWAVE = 8, NTHR = 512, RT = 32, P = 33, DW = 8, GK = 8, KS = 2, NA
 constexpr int MAXPH = 48;      // phases of one launch
 constexpr int SCR_SLOTS = 7;   // partial tiles of a phase that are not the owner's: (slices - 1) x tiles <= 7
 constexpr int SLOT = NACC * 64;
+// dynamic LDS a launch may ask for: 160 KB per workgroup minus the kernel's static arrays (12,928 B, scripts/kernel_resources.py)
+constexpr int64_t DYN_LDS_MAX = 147 * 1024;
 
 struct Phase8 {
   const float *Wpk;   // packed operand of the stage (wd_chain_layer_t.Wpk / WTpk)
@@ -866,7 +868,7 @@ int64_t layout8(int32_t K0, const int32_t *N, int32_t L, int32_t *a_off, int32_t
   if (regx_floats) *regx_floats = regx;
   if (sum_n_out) *sum_n_out = sum_n;
   const int64_t bytes = off * 4;
-  return bytes <= 148 * 1024 ? bytes : -1;   // 160 KB per workgroup minus the kernel's static arrays (~11 KB)
+  return bytes <= DYN_LDS_MAX ? bytes : -1;
 }
 
 // Concatenating towers: the row tile mirrors the activation row (cols columns of P floats; segment s at seg_col[s]); the dz
@@ -903,7 +905,7 @@ int64_t layout8w(const wd_chain_windows_t &w, int32_t K0, const int32_t *N, int3
   if (tall_off) *tall_off = (int32_t)off;
   off += w.cols;
   const int64_t bytes = off * 4;
-  return bytes <= 148 * 1024 ? bytes : -1;
+  return bytes <= DYN_LDS_MAX ? bytes : -1;
 }
 
 // the phases of one stage: 8 column tiles x 1 slice while 8 are left, then 4 x 2, 2 x 4, 1 x 8 for what remains.  The partial
@@ -915,10 +917,13 @@ bool add_stage(Args8 &A, int &nph, int &s, const float *Wpk, int K, int ncols, c
   const int64_t want = (int64_t)SCR_SLOTS * SLOT;
   int ia = -1, ib = -1;     // largest region for the scratch; a second one in what is left of it or in another region
   for (int i = 0; i < nfree; ++i)
-    if (free[i].size >= want && (ia < 0 || free[i].size > free[ia].size)) ia = i;
+    if (free[i].size >= SLOT && (ia < 0 || free[i].size > free[ia].size)) ia = i;
+  // partial tiles the scratch can hold (a phase of 2^l2 tiles in ns slices needs (ns - 1) 2^l2): a stage with less dead LDS than
+  // the seven a full split wants -- the forward of a concatenating tower, whose x stays alive -- splits less
+  const int slots = ia >= 0 ? (int)(free[ia].size / SLOT < SCR_SLOTS ? free[ia].size / SLOT : SCR_SLOTS) : 0;
   A.scr_off[s] = ia >= 0 ? (int32_t)free[ia].off : -1;
   A.alt_off[s] = -1;
-  if (ia >= 0) {
+  if (ia >= 0 && slots == SCR_SLOTS) {
     if (free[ia].size >= 2 * want) A.alt_off[s] = (int32_t)(free[ia].off + want);
     else
       for (int i = 0; i < nfree; ++i)
@@ -935,7 +940,7 @@ bool add_stage(Args8 &A, int &nph, int &s, const float *Wpk, int K, int ncols, c
     else if (rem >= 2) { l2 = 1; ns = 4; }
     else { l2 = 0; ns = 8; }
     while (ns > 1 && KG % ns) ns >>= 1;
-    if (ia < 0) ns = 1;
+    while (ns > 1 && ((ns - 1) << l2) > slots) ns >>= 1;
     if (nph >= MAXPH) return false;
     A.ph[nph++] = Phase8{Wpk, KG, t0, l2, ns, KG / ns};
     t0 += 1 << l2;
@@ -979,12 +984,21 @@ int chain8_launch(const ChainArgs &g0, wd_stream_t stream) {
   for (int l = 0; l < L; ++l) N[l] = g.layer[l].N;
   int64_t regx = 0, sum_n = 0;
   int64_t bytes;
+  Region win_scr{0, 0};
   if (g.win) {
     wd_chain_windows_t w{};
     for (int l = 0; l <= L; ++l) { w.seg_col[l] = g.seg_col[l]; w.in_col[l] = g.in_col[l]; }
     w.k_logits = g.KL; w.cols = g.cols;
     bytes = layout8w(w, g.K0, N, L, g.a_off, g.dz_off, g.tab_off, &g.x_off, &g.sall_off, &g.tall_off);
     for (int l = 0; l <= L; ++l) g.in_off[l] = (int32_t)((int64_t)g.in_col[l] * P);
+    if (bytes > 0) {
+      // x stays alive through the forward, so its stages have (almost) no dead region for the partial tiles of a split phase:
+      // what the LDS has left behind the tables is theirs (C4: 5 slots -- F1 runs 4 tiles x 2 slices instead of 4 x 1 with four
+      // wavefronts idle, F2 2 x 2 instead of 2 x 1)
+      const int64_t spare = (DYN_LDS_MAX - bytes) / ((int64_t)SLOT * 4);
+      win_scr = Region{bytes / 4, (spare < SCR_SLOTS ? spare : SCR_SLOTS) * SLOT};
+      bytes += win_scr.size * 4;
+    }
   } else {
     bytes = layout8(g.K0, N, L, g.a_off, g.dz_off, g.tab_off, &regx, &sum_n);
   }
@@ -999,10 +1013,15 @@ int chain8_launch(const ChainArgs &g0, wd_stream_t stream) {
   if (g.win) {
     // F_l reads its window (x stays alive through the whole forward): only the outputs of LATER layers are dead
     for (int l = 0; l < L; ++l) {
-      Region fr[MAXL];
+      Region fr[MAXL + 1];
       int nf = 0;
       for (int j = l + 1; j < L; ++j) fr[nf++] = Region{g.a_off[j], (int64_t)N[j] * P};
       nf = merge_regions(fr, nf);
+      if (win_scr.size > 0) {      // the dedicated scratch, unless a dead region is larger
+        bool larger = false;
+        for (int i = 0; i < nf; ++i) larger = larger || fr[i].size >= win_scr.size;
+        if (!larger) { fr[0] = win_scr; nf = 1; }
+      }
       if (g.layer[l].K <= 0 || g.layer[l].K % GK) return 1;
       if (!add_stage(A, nph, s, g.layer[l].Wpk, g.layer[l].K, N[l], fr, nf)) return 1;
     }

@@ -35,7 +35,8 @@ constexpr int MAX_NB = 8192;    // buckets (LDS scan array of K2)
 
 constexpr int RANK_MAX = 512;   // buckets up to this size are rank-sorted (O(m^2 / 256) per lane, 2 barriers)
 constexpr int MAX_SLOTS_LDS = 96;  // slot descriptors cached in LDS by k_bucket_update (more slots: read from HBM)
-constexpr int MAX_CHUNKS = 128; // workgroups of K1 / K2 (rows of the count matrix)
+constexpr int MAX_CHUNKS = 512; // workgroups of K1 / K2 (rows of the count matrix); 128 until round 5: configs[3]'s 1.06 M occurrences
+                                // were 8.3 k per workgroup, one bag after the other per lane -- histogram 35 us, scatter 49 us alone
 
 // chunk c = bags [c*bags_per_chunk, (c+1)*bags_per_chunk); rank = position of an occurrence among the chunk's
 // occurrences of the same bucket.
@@ -122,27 +123,39 @@ k_bucket_hist(const wd_slot_t *__restrict__ slots, int32_t S, const int32_t *__r
   for (int i = t; i < nb; i += 256) row[i] = hist[i];
 }
 
-// thread per bucket: cpre[c][b] = sum_{c' < c} cntm[c'][b];  total[b] = column sum.  Out of place and 32 loads
-// deep: the in-place version was one dependent L2 round trip per chunk (30 us for 104 chunks).
-__global__ void __launch_bounds__(256)
+// cpre[c][b] = sum_{c' < c} cntm[c'][b];  total[b] = column sum.  A workgroup takes 64 buckets x G groups of 32 chunks
+// (G = ceil(nchunks / 32) <= 16 wavefronts): every count is loaded in ONE round of 32 loads per lane, the groups' sums meet in
+// LDS.  (Round 1: thread per bucket, in place -- one dependent L2 round trip per chunk, 30 us for 104 chunks; rounds 2-4: thread
+// per bucket, 32 loads deep -- one round per 32 chunks, 13 us for 128 chunks.)
+constexpr int SCAN_DEPTH = 32;
+constexpr int SCAN_GROUPS = MAX_CHUNKS / SCAN_DEPTH;
+__global__ void __launch_bounds__(64 * SCAN_GROUPS)
 k_bucket_colscan(const int32_t *__restrict__ cntm, int32_t *__restrict__ cpre, int32_t nchunks, int32_t nb,
                  int32_t *__restrict__ total) {
   WD_SIDE_PRIO();
-  const int b = blockIdx.x * 256 + threadIdx.x;
-  if (b >= nb) return;
+  __shared__ int32_t gsum[SCAN_GROUPS][64];
+  const int lane = threadIdx.x & 63, g = threadIdx.x >> 6, G = blockDim.x >> 6;
+  const int b = blockIdx.x * 64 + lane;
+  const int c0 = g * SCAN_DEPTH;
+  int32_t v[SCAN_DEPTH];
+#pragma unroll
+  for (int q = 0; q < SCAN_DEPTH; ++q) v[q] = (b < nb && c0 + q < nchunks) ? cntm[(int64_t)(c0 + q) * nb + b] : 0;
   int32_t run = 0;
-  constexpr int DEPTH = 32;   // loads in flight per lane
-  for (int c0 = 0; c0 < nchunks; c0 += DEPTH) {
-    int32_t v[DEPTH];
 #pragma unroll
-    for (int q = 0; q < DEPTH; ++q) v[q] = c0 + q < nchunks ? cntm[(int64_t)(c0 + q) * nb + b] : 0;
-#pragma unroll
-    for (int q = 0; q < DEPTH; ++q) {
-      if (c0 + q < nchunks) cpre[(int64_t)(c0 + q) * nb + b] = run;
-      run += v[q];
-    }
+  for (int q = 0; q < SCAN_DEPTH; ++q) {
+    const int32_t x = v[q];
+    v[q] = run;
+    run += x;
   }
-  total[b] = run;
+  gsum[g][lane] = run;
+  __syncthreads();
+  int32_t base = 0;
+  for (int h = 0; h < g; ++h) base += gsum[h][lane];
+  if (b >= nb) return;
+#pragma unroll
+  for (int q = 0; q < SCAN_DEPTH; ++q)
+    if (c0 + q < nchunks) cpre[(int64_t)(c0 + q) * nb + b] = base + v[q];
+  if (g == G - 1) total[b] = base + run;
 }
 
 __global__ void __launch_bounds__(256)
@@ -831,7 +844,8 @@ extern "C" int wd_sparse_bucketize(const wd_slot_t *slots, int32_t S, const int3
     hipLaunchKernelGGL(k_bucket_hist, dim3(nchunks), dim3(256), 0, st, slots, S, ids, bag_offs, nbags, bags_per_chunk,
                        nbuckets, bucket_cnt, rank);
   }
-  hipLaunchKernelGGL(k_bucket_colscan, dim3((unsigned)wd::ceil_div(nbuckets, 256)), dim3(256), 0, st, bucket_cnt,
+  const int groups = nchunks > 0 ? (nchunks + SCAN_DEPTH - 1) / SCAN_DEPTH : 1;
+  hipLaunchKernelGGL(k_bucket_colscan, dim3((unsigned)wd::ceil_div(nbuckets, 64)), dim3(64 * groups), 0, st, bucket_cnt,
                      cpre, nchunks, nbuckets, total);
   hipLaunchKernelGGL(k_bucket_scatter, dim3(nchunks > 0 ? nchunks : 1), dim3(256), 0, st, slots, S, ids, bag_offs,
                      nchunks > 0 ? nbags : (int64_t)0, bags_per_chunk, nbuckets, total, cpre, rank, bucket_start, pairs);

@@ -1139,8 +1139,30 @@ class WideDeepEngine:
     def _has_sparse_update(self):
         return (bool(self.group_slots) if self.spec.has_deep else False) or self.spec.has_wide
 
-    def _sparse_backward(self, bt: DeviceBatch, st, bucketized=False, pset=0, patch=None):
-        """Scatter-add of the row gradients + fused Adagrad (embedding rows) / FTRL (wide rows, bias)."""
+    def _small_backward(self, bt: DeviceBatch, st):
+        """The crossed columns' tables (csrc/small_tables.hip): counted in LDS, no sort -- the bucketing skipped them, the big
+        tables' update skips them; needs dx / dlogit only."""
+        if not self._small_on(bt):
+            return
+        plan, spec = self.plan, self.spec
+        has_emb = bool(self.group_slots) if spec.has_deep else False
+        dx_ptr, ld = None, 0
+        if has_emb:
+            tw0 = self.towers[0]
+            dx_ptr, ld = tw0["dact"].data_ptr() + 4 * tw0["layout"].seg_start[0], tw0["layout"].ld
+        lr, l1, l2 = (spec.lin_opt[1], spec.lin_opt[2], spec.lin_opt[3]) if spec.has_wide else (0.0, 0.0, 0.0)
+        if self.small_ws is None:
+            n = int(call("wd_small_tables_ws_floats", len(self.small_idx), self.small_rows, self.small_dim, self.max_batch))
+            self.small_ws = torch.zeros(max(n, 1), dtype=torch.float32, device=self.device)
+        call("wd_small_tables_bwd", ptr(self.emb) if has_emb else None, ptr(self.emb_acc) if has_emb else None,
+             ptr(self.wide) if spec.has_wide else None, ptr(self.slots_dev), plan.S, ptr(self.small_idx_dev),
+             len(self.small_idx), self.small_rows, self.small_dim, ptr(bt.ids), ptr(bt.bag_offs), bt.B, dx_ptr, ld,
+             ptr(self.dlogit), float(spec.dnn_opt[1]) if spec.has_deep else 0.0, float(lr), float(l1), float(l2),
+             ptr(self.small_ws), self.small_ws.numel(), st)
+
+    def _sparse_backward(self, bt: DeviceBatch, st, bucketized=False, pset=0, patch=None, small=True):
+        """Scatter-add of the row gradients + fused Adagrad (embedding rows) / FTRL (wide rows, bias).  small=False: the caller
+        launches the small tables' update itself (_small_backward, on another stream)."""
         plan, spec = self.plan, self.spec
         has_emb = bool(self.group_slots) if spec.has_deep else False
         if not (has_emb or spec.has_wide):
@@ -1186,15 +1208,8 @@ class WideDeepEngine:
             return
         if self.default_opts:
             lr, l1, l2 = (spec.lin_opt[1], spec.lin_opt[2], spec.lin_opt[3]) if spec.has_wide else (0.0, 0.0, 0.0)
-            if self._small_on(bt):      # the crossed columns' tables: counted in LDS, no sort (the bucketing above skipped them)
-                if self.small_ws is None:
-                    n = int(call("wd_small_tables_ws_floats", len(self.small_idx), self.small_rows, self.small_dim, self.max_batch))
-                    self.small_ws = torch.zeros(max(n, 1), dtype=torch.float32, device=self.device)
-                call("wd_small_tables_bwd", ptr(self.emb) if has_emb else None, ptr(self.emb_acc) if has_emb else None,
-                     ptr(self.wide) if spec.has_wide else None, ptr(self.slots_dev), plan.S, ptr(self.small_idx_dev),
-                     len(self.small_idx), self.small_rows, self.small_dim, ptr(bt.ids), ptr(bt.bag_offs), bt.B, dx_ptr, ld,
-                     ptr(self.dlogit), float(spec.dnn_opt[1]) if spec.has_deep else 0.0, float(lr), float(l1), float(l2),
-                     ptr(self.small_ws), self.small_ws.numel(), st)
+            if small:
+                self._small_backward(bt, st)
             call("wd_sparse_apply", ptr(self.emb) if has_emb else None, ptr(self.emb_acc) if has_emb else None,
                  ptr(self.wide), ptr(self.bias), ptr(self.slots_dev), plan.S, ptr(bt.bag_offs), bt.B, dx_ptr, ld,
                  ptr(self.dlogit), 1, float(spec.dnn_opt[1]) if spec.has_deep else 0.0, float(lr), float(l1), float(l2),
@@ -1325,7 +1340,10 @@ class WideDeepEngine:
         if sparse_side:
             side = self._side(0)
             side.wait_event(ev_fwd)
-            self._sparse_backward(bt, side.cuda_stream, bucketized=True)
+            self._sparse_backward(bt, side.cuda_stream, bucketized=True, small=False)
+            # the small tables' update behind the dense tail on this stream, which otherwise idles until the big tables' update
+            # (configs[3]: 200 us) is done: the two touch different rows
+            self._small_backward(bt, st)
             torch.cuda.current_stream().wait_stream(side)
         elif bucketized:
             torch.cuda.current_stream().wait_stream(self._side(0))

@@ -658,7 +658,7 @@ class ShardedWideDeepEngine(WideDeepEngine):
             call("wd_adagrad_dense", ptr(self.P), ptr(self.Pacc), ptr(self.G), self.P.numel(), float(self.spec.dnn_opt[1]), st)
         self._bias_update(bt, st)
 
-    def backward_and_update(self, bt: DeviceBatch, bucketized=False):
+    def backward_and_update(self, bt: DeviceBatch, bucketized=False, pset=0, lookahead=None):
         """With the one-launch tower dx exists when forward() returns: the gradient exchange starts first and overlaps
         with the dense branch (weight-gradient GEMMs, all-reduce, dense tail)."""
         spec, st = self.spec, _stream()

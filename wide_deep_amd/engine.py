@@ -1323,7 +1323,7 @@ class WideDeepEngine:
                 self._fold(False, st)
                 self._folded = True
 
-    def backward_and_update(self, bt: DeviceBatch, bucketized=False):
+    def backward_and_update(self, bt: DeviceBatch, bucketized=False, pset=0, lookahead=None):
         spec, st = self.spec, _stream()
         B = bt.B
         has_emb = bool(self.group_slots) if spec.has_deep else False
@@ -1340,14 +1340,22 @@ class WideDeepEngine:
         if sparse_side:
             side = self._side(0)
             side.wait_event(ev_fwd)
-            self._sparse_backward(bt, side.cuda_stream, bucketized=True, small=False)
+            self._sparse_backward(bt, side.cuda_stream, bucketized=True, pset=pset, small=False)
             # the small tables' update behind the dense tail on this stream, which otherwise idles until the big tables' update
             # (configs[3]: 200 us) is done: the two touch different rows
             self._small_backward(bt, st)
+            if lookahead is not None:
+                # ... and the bucketing of the next batch (ids only; its scratch set was last read by the update before this
+                # one).  Beside the next tower instead -- where plain stream order puts it -- its histogram / scatter workgroups
+                # (32 KB of LDS) find no CU the tower's workgroup has left room on, and the row update waits for them:
+                # profiles/r5_c4_nocross_step_timeline_before.txt, scatter 8 -> 212 us, update from 218
+                self._sparse_bucketize(lookahead[0], st, lookahead[1])
             torch.cuda.current_stream().wait_stream(side)
+        elif lookahead is not None:
+            raise ValueError("train_step(lookahead=): needs the update on the side stream (lookahead_ok)")
         elif bucketized:
             torch.cuda.current_stream().wait_stream(self._side(0))
-            self._sparse_backward(bt, st, bucketized=True)
+            self._sparse_backward(bt, st, bucketized=True, pset=pset)
         else:
             self._sparse_backward(bt, st)
         if self.dropout:
@@ -1356,18 +1364,31 @@ class WideDeepEngine:
             o = spec.dnn_opt if scope == "dnn" else spec.lin_opt
             call("wd_adam_tick", ptr(pw), float(o[2]), float(o[3]), st)
 
-    def train_step(self, bt: DeviceBatch):
-        """One step of python/lib/joint.py:224-262: forward, batch-SUM loss, both optimizers."""
+    def lookahead_ok(self, bt):
+        """train_step(pset=, lookahead=): the ragged bucketing of the NEXT batch inside this step (one-launch tower, the update on
+        the side stream)."""
+        # (not with small tables: their update already runs there, and the bucketing on top of it costs the row update more than
+        # it saves -- configs[3] with its crosses 0.524 -> 0.541 ms/step, without them 0.505 -> 0.495)
+        return bool(type(self) is WideDeepEngine and getattr(self, "chain", False) and self.overlap_bucket and self._has_sparse_update()
+                    and not self._bucket_onehot_ok(bt) and not self._small_on(bt) and os.environ.get("WD_SPARSE_SIDE", "1") == "1")
+
+    def train_step(self, bt: DeviceBatch, pset=None, lookahead=None):
+        """One step of python/lib/joint.py:224-262: forward, batch-SUM loss, both optimizers.
+        pset: this batch's occurrences are already bucketed, in scratch set `pset` (by the previous step's `lookahead`);
+        lookahead = (next batch, scratch set): bucket that batch's occurrences behind this step's dense tail, while the row update
+        runs on the side stream -- pipeline.StepGraph, for batches `lookahead_ok`."""
         if bt.labels is None:
             raise ValueError("train_step needs labels")
         bucketized = False
-        if self.overlap_bucket and self._overlap_ok() and self._has_sparse_update():
+        if pset is not None:
+            bucketized = True
+        elif self.overlap_bucket and self._overlap_ok() and self._has_sparse_update():
             main, side = torch.cuda.current_stream(), self._side(0)
             side.wait_stream(main)                       # the ids were produced on the main stream
             self._sparse_bucketize(bt, side.cuda_stream)
             bucketized = True
         self.forward(bt, need_loss=True)
-        self.backward_and_update(bt, bucketized=bucketized)
+        self.backward_and_update(bt, bucketized=bucketized, pset=pset or 0, lookahead=lookahead)
         # the reference bumps global_step once per minimize() plus the explicit assign_add (quirk C.4)
         self.global_step += 3 if self.spec.model_type == "wide_deep" else 2
         return self.loss

@@ -50,7 +50,10 @@ rm -rf $OUT/prof
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o trace -- python bench.py --config c4 --steps 30 --warmup 5 --pool 8 --repeats 1 $B --no-parity > $OUT/prof_c4.log 2>&1
 find $OUT/prof -name "*kernel_stats*.csv" | head -1 | xargs -I{} cp {} $OUT/c4_kernel_stats.csv
 python scripts/summarize_stats.py $OUT/c4_kernel_stats.csv 35 > $OUT/c4_kernel_stats.md; head -14 $OUT/c4_kernel_stats.md
+T=$(find $OUT/prof -name "*kernel_trace*.csv" | head -1)
+python scripts/trace_window.py $T k_tower_chain 20 1 > $OUT/c4_step_timeline.txt; cat $OUT/c4_step_timeline.txt
 rm -rf $OUT/prof
 # the tower alone: stage cycles
 timeout 200 python scripts/bench_chain.py > $OUT/tower_chain8_stage_cycles.txt 2>&1; grep "^chain B\|^workgroup 0" $OUT/tower_chain8_stage_cycles.txt
+CHAIN_MODE=resnet timeout 200 python scripts/bench_chain.py > $OUT/tower_chain8_resnet_stage_cycles.txt 2>&1; grep "^chain B\|^workgroup 0" $OUT/tower_chain8_resnet_stage_cycles.txt
 tail -n 5 $OUT/bench.err

@@ -101,9 +101,17 @@ def event_time_ms(fn, iters):
     return e0.elapsed_time(e1) / iters
 
 
-def gather_alg_bytes(plan, bt, dim, nslots):
-    """SURVEY 8(d) contract: nnz*D*4 (row reads) + nnz*4 (ids) + (B*S+1)*4 (offsets) + B*S*D*4 (pooled write)."""
-    return bt.nnz * dim * 4 + bt.nnz * 4 + (bt.B * plan.S + 1) * 4 + bt.B * nslots * dim * 4
+def gather_alg_bytes(plan, bt, dim, nslots, whole_layer=False):
+    """SURVEY 8(d) contract: nnz*D*4 (row reads) + nnz*4 (ids) + (B*S+1)*4 (offsets) + B*S*D*4 (pooled write).
+    whole_layer (models with several embedding widths, BASELINE configs[3] with its crossed columns): every embedded column
+    with ITS width and ITS ids (a crossed column's 25-125 ids per bag read 16-byte rows, not the 64-byte rows of the hash slots)."""
+    if not whole_layer or len(plan.emb_groups) <= 1:
+        return bt.nnz * dim * 4 + bt.nnz * 4 + (bt.B * plan.S + 1) * 4 + bt.B * nslots * dim * 4
+    offs = bt.bag_offs[: bt.B * plan.S + 1].to(torch.int64).cpu()
+    lens = (offs[1:] - offs[:-1]).reshape(bt.B, plan.S).sum(dim=0)
+    rows = sum(int(lens[i]) * int(d) * 4 for d, sl in plan.emb_groups.items() for i in sl)
+    pooled = sum(bt.B * len(sl) * int(d) * 4 for d, sl in plan.emb_groups.items())
+    return rows + bt.nnz * 4 + (bt.B * plan.S + 1) * 4 + pooled
 
 
 def pmc_traffic(args, bt, plan):
@@ -210,7 +218,7 @@ def gather_instep_roofline(eng, dev_batches, step_eager, steps=16, runner=None, 
     plan = eng.plan
     bt0 = dev_batches[0].batch
     (dim, gs), = list(eng.group_slots.items())[:1]
-    alg = gather_alg_bytes(plan, bt0, dim, gs.numel())
+    alg = gather_alg_bytes(plan, bt0, dim, gs.numel(), whole_layer=True)
     side = torch.cuda.Stream()
     if span is not None and runner is not None and runner.multis:
         # the input layer is its own launch (wd_prefetch_onehot), issued one step ahead beside the tower of the previous batch:
@@ -263,8 +271,12 @@ def gather_instep_roofline(eng, dev_batches, step_eager, steps=16, runner=None, 
                 eng._sparse_forward(bts[i % len(bts)], st)
             side.synchronize()
             us = event_time_ms(lambda i: eng._sparse_forward(bts[i % len(bts)], st), 100) * 1e3
-        kernel = "k_input_layer<%d, 2, %s>" % (dim // 4, "true" if bt0.one_hot else "false")
-        how = "HIP events around the launch (its own launch in the step), 100 launches over the resident pool"
+        fused = eng.spec.has_deep and eng._fused_input_layer and eng.rec is None and not eng._small_on(bt0)
+        kernel = ("k_input_layer<%d, 2, %s>" % (dim // 4, "true" if bt0.one_hot else "false") if fused else
+                  "the input layer as the step launches it: %s + k_wide_fwd + k_dense_fwd%s"
+                  % ("k_embag_fwd<%d> on row records" % (dim // 4) if eng.rec is not None else "k_embag_fwd_range per embedding width",
+                     " + k_small_fwd (crossed columns, tables in LDS)" if eng._small_on(bt0) else ""))
+        how = "HIP events around the launch%s (in the step as timed here), 100 times over the resident pool" % ("" if fused else "es")
     gbs = alg / us / 1e3
     return {"bound": "hbm", "kernel": kernel, "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,

@@ -836,7 +836,13 @@ extern "C" int wd_sparse_bucketize(const wd_slot_t *slots, int32_t S, const int3
   hipStream_t st = wd::as_stream(stream);
   const int64_t nbags = batch * S;
   // bucket_cnt layout: [MAX_CHUNKS][nbuckets] counts, [MAX_CHUNKS][nbuckets] chunk prefixes, total[nbuckets]
-  int64_t bags_per_chunk = wd::ceil_div(wd::ceil_div(nbags, MAX_CHUNKS), 256) * 256;
+  // ~2 k occurrences per chunk, 128 to MAX_CHUNKS chunks: a chunk's fixed cost (its LDS counters, its row of the count matrix,
+  // the scan of the totals in K2) is paid per chunk and bucket -- one id per bag (the sharded owner's request list, 213 k
+  // occurrences) stays at 128 chunks, configs[3]'s 1.06 M occurrences take all 512.  WD_BUCKET_CHUNKS overrides (A/B runs)
+  static const int chunk_env = getenv("WD_BUCKET_CHUNKS") ? atoi(getenv("WD_BUCKET_CHUNKS")) : 0;
+  int64_t want = chunk_env > 0 ? chunk_env : wd::ceil_div(nnz, (int64_t)2048);
+  want = want < 128 ? 128 : (want > MAX_CHUNKS ? MAX_CHUNKS : want);
+  int64_t bags_per_chunk = wd::ceil_div(wd::ceil_div(nbags, want), 256) * 256;
   const int nchunks = nnz > 0 ? (int)wd::ceil_div(nbags, bags_per_chunk) : 0;
   int32_t *cpre = bucket_cnt + (int64_t)MAX_CHUNKS * nbuckets;
   int32_t *total = cpre + (int64_t)MAX_CHUNKS * nbuckets;

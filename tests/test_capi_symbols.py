@@ -91,3 +91,35 @@ def test_a_library_built_from_other_sources_is_refused(monkeypatch):
     monkeypatch.setattr(capi, "source_stamp", lambda: "0" * 64)
     with pytest.raises(capi.WdError, match="stale HIP library"):
         capi.load()
+
+
+def test_tower_lds_sizing_is_host_arithmetic_and_knows_the_launch_limit():
+    """wd_tower_chain_lds_bytes / wd_tower_chain_windows_lds_bytes (host-side arithmetic, no launch): BASELINE's tower shapes fit a
+    workgroup's dynamic LDS (147 KB: 160 KB minus the kernel's static arrays), shapes that do not are refused with -1 -- the engine
+    falls back to per-layer launches on that answer, so a layout between the limit and 160 KB must never be reported as fitting."""
+    from wide_deep_amd import capi
+    from wide_deep_amd.plan import TowerLayout
+    lib = capi.load()
+    lim = 147 * 1024
+    arr = lambda v: (ctypes.c_int32 * len(v))(*v)
+    # C2 / C3: `simple`, x = 26 x 16 + 13 numeric columns (rounded to 32) -> 256-128-64
+    b = int(lib.wd_tower_chain_lds_bytes(448, arr([256, 128, 64]), 3, 32))
+    assert 0 < b <= lim
+    assert int(lib.wd_tower_chain_lds_bytes(448, arr([256, 128, 64]), 3, 16)) == -1           # row tile 32 only
+    assert int(lib.wd_tower_chain_lds_bytes(4096, arr([1024, 512]), 2, 32)) == -1             # a row tile that cannot fit
+    # configs[3]: `resnet` over the same widths -- every layer reads one contiguous window of the activation row
+    for mode in ("resnet", "dense"):
+        tl = TowerLayout(448, [256, 128, 64], mode)
+        w = capi.WdChainWindows()
+        for sg in range(4):
+            w.seg_col[sg], w.in_col[sg] = int(tl.seg_start[sg]), int(tl.in_start[sg])
+        w.k_logits, w.cols = int(tl.in_K[3]), (int(tl.ld) + 31) // 32 * 32
+        bw = int(lib.wd_tower_chain_windows_lds_bytes(ctypes.byref(w), 448, arr([256, 128, 64]), 3))
+        assert 0 < bw <= lim, (mode, bw)
+    # a concatenating tower whose row does not fit
+    tl = TowerLayout(2048, [1024, 512, 256], "resnet")
+    w = capi.WdChainWindows()
+    for sg in range(4):
+        w.seg_col[sg], w.in_col[sg] = int(tl.seg_start[sg]), int(tl.in_start[sg])
+    w.k_logits, w.cols = int(tl.in_K[3]), (int(tl.ld) + 31) // 32 * 32
+    assert int(lib.wd_tower_chain_windows_lds_bytes(ctypes.byref(w), 2048, arr([1024, 512, 256]), 3)) == -1

@@ -103,15 +103,18 @@ def event_time_ms(fn, iters):
 
 def gather_alg_bytes(plan, bt, dim, nslots, whole_layer=False):
     """SURVEY 8(d) contract: nnz*D*4 (row reads) + nnz*4 (ids) + (B*S+1)*4 (offsets) + B*S*D*4 (pooled write).
-    whole_layer (models with several embedding widths, BASELINE configs[3] with its crossed columns): every embedded column
-    with ITS width and ITS ids (a crossed column's 25-125 ids per bag read 16-byte rows, not the 64-byte rows of the hash slots)."""
+    whole_layer (models with several embedding widths, BASELINE configs[3] with its crossed columns): "all" = every embedded
+    column with ITS width and ITS ids (a crossed column's 25-125 ids per bag read 16-byte rows, not the 64-byte rows of the hash
+    slots); True = the columns of width `dim` only (the embedding-bag launch of that width)."""
     if not whole_layer or len(plan.emb_groups) <= 1:
         return bt.nnz * dim * 4 + bt.nnz * 4 + (bt.B * plan.S + 1) * 4 + bt.B * nslots * dim * 4
     offs = bt.bag_offs[: bt.B * plan.S + 1].to(torch.int64).cpu()
     lens = (offs[1:] - offs[:-1]).reshape(bt.B, plan.S).sum(dim=0)
-    rows = sum(int(lens[i]) * int(d) * 4 for d, sl in plan.emb_groups.items() for i in sl)
-    pooled = sum(bt.B * len(sl) * int(d) * 4 for d, sl in plan.emb_groups.items())
-    return rows + bt.nnz * 4 + (bt.B * plan.S + 1) * 4 + pooled
+    groups = plan.emb_groups.items() if whole_layer == "all" else [(dim, plan.emb_groups[dim])]      # one launch = one width
+    rows = sum(int(lens[i]) * int(d) * 4 for d, sl in groups for i in sl)
+    ids = sum(int(lens[i]) for d, sl in groups for i in sl) * 4
+    pooled = sum(bt.B * len(sl) * int(d) * 4 for d, sl in groups)
+    return rows + ids + (bt.B * plan.S + 1) * 4 + pooled
 
 
 def pmc_traffic(args, bt, plan):
@@ -192,7 +195,7 @@ def gather_kernel_roofline(eng, batches, args, iters=200):
     torch.cuda.synchronize()
     ms = event_time_ms(run, iters)
     bt = batches[0]
-    alg = gather_alg_bytes(plan, bt, dim, gs.numel())
+    alg = gather_alg_bytes(plan, bt, dim, gs.numel(), whole_layer=True)
     gbs = alg / (ms * 1e-3) / 1e9
     traffic, src = (None, "skipped (--no-pmc)") if args.no_pmc else pmc_traffic(args, bt, plan)
     kname = ("k_prefetch_onehot<%d, 1> on %d-byte row records" % (dim // 4, 4 * eng.rec_stride) if pf
@@ -218,7 +221,7 @@ def gather_instep_roofline(eng, dev_batches, step_eager, steps=16, runner=None, 
     plan = eng.plan
     bt0 = dev_batches[0].batch
     (dim, gs), = list(eng.group_slots.items())[:1]
-    alg = gather_alg_bytes(plan, bt0, dim, gs.numel(), whole_layer=True)
+    alg = gather_alg_bytes(plan, bt0, dim, gs.numel(), whole_layer="all")
     side = torch.cuda.Stream()
     if span is not None and runner is not None and runner.multis:
         # the input layer is its own launch (wd_prefetch_onehot), issued one step ahead beside the tower of the previous batch:

@@ -178,3 +178,27 @@ def test_decayed_lr_starts_from_the_initial_rate_it_is_given():
     spec.lr_decay = {"dnn": (0.5, 10.0)}
     spec.dnn_opt = ("Adagrad", 0.0125, 0.1)      # what an engine's own copy holds after a few decayed steps
     assert abs(spec.decayed_lr("dnn", 20, lr0=0.05) - 0.0125) < 1e-12 and spec.decayed_lr("linear", 20, lr0=0.1) == 0.1
+
+
+def test_bench_gather_contract_bytes_by_column_width():
+    """bench.py's SURVEY 8(d) gather contract for models with several embedding widths (configs[3] with its crossed columns): every
+    column priced at its own row width and its own ids -- by hand on a 2-example, 3-column batch."""
+    import importlib.util
+    import os
+    import types
+    import torch
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("wd_bench_module", os.path.join(root, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    B = 2
+    lens = torch.tensor([[1, 2, 5], [3, 0, 7]])
+    offs = torch.cat([torch.zeros(1, dtype=torch.int64), lens.reshape(-1).cumsum(0)]).to(torch.int32)
+    bt = types.SimpleNamespace(B=B, nnz=int(lens.sum()), bag_offs=offs)
+    mixed = types.SimpleNamespace(S=3, emb_groups={16: [0, 1], 4: [2]})
+    offsets = (B * 3 + 1) * 4
+    assert b.gather_alg_bytes(mixed, bt, 16, 2, whole_layer="all") == (6 * 64 + 12 * 16) + 18 * 4 + offsets + (B * 2 * 64 + B * 16)
+    assert b.gather_alg_bytes(mixed, bt, 16, 2, whole_layer=True) == 6 * 64 + 6 * 4 + offsets + B * 2 * 64     # the width-16 launch alone
+    one = types.SimpleNamespace(S=3, emb_groups={16: [0, 1, 2]})
+    for mode in (False, True, "all"):      # one width: the plain formula
+        assert b.gather_alg_bytes(one, bt, 16, 3, whole_layer=mode) == 18 * 64 + 18 * 4 + offsets + B * 3 * 64

@@ -993,7 +993,7 @@ int chain8_launch(const ChainArgs &g0, wd_stream_t stream) {
     for (int l = 0; l <= L; ++l) g.in_off[l] = (int32_t)((int64_t)g.in_col[l] * P);
     if (bytes > 0) {
       // x stays alive through the forward, so its stages have (almost) no dead region for the partial tiles of a split phase:
-      // what the LDS has left behind the tables is theirs (C4: 5 slots -- F1 runs 4 tiles x 2 slices instead of 4 x 1 with four
+      // what the LDS has left behind the tables is theirs (configs[3]: 4 slots -- F1 runs 4 tiles x 2 slices instead of 4 x 1 with four
       // wavefronts idle, F2 2 x 2 instead of 2 x 1)
       const int64_t spare = (DYN_LDS_MAX - bytes) / ((int64_t)SLOT * 4);
       win_scr = Region{bytes / 4, (spare < SCR_SLOTS ? spare : SCR_SLOTS) * SLOT};

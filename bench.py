@@ -337,7 +337,7 @@ def cpu_baseline(eng, host_batches, steps, B):
     here) timed on this box's host cores over `steps` batches of the same workload, hashing included."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from oracle import oracle as O
-    from tests.helpers import oracle_batch, oracle_from_engine
+    from oracle.harness import oracle_batch, oracle_from_engine
     from wide_deep_amd import synth
     ncpu = os.cpu_count() or 1
     ora = oracle_from_engine(eng)
@@ -355,7 +355,7 @@ def cpu_baseline(eng, host_batches, steps, B):
 
     def one(hb):
         if "features" in hb:      # parsed batch (crossed columns): fingerprints + SparseCross of the oracle, then the step
-            from tests.helpers import parsed_batch_ids
+            from oracle.harness import parsed_batch_ids
             ids, bag_offs = parsed_batch_ids(plan, hb)
         else:
             lens = hb["lens"]
@@ -420,17 +420,17 @@ def cpu_baseline_sharded(spec, args, B):
 
 def parity_check(eng, spec, tb, hb, step_eager):
     """One eager step on batch 0 BEFORE anything is timed, against the CPU oracle (the checker; sampled-row tables,
-    tests/helpers.CompactOracle): hashed ids bit-exact, loss and max |logit - oracle logit| of the step."""
+    oracle/harness.CompactOracle): hashed ids bit-exact, loss and max |logit - oracle logit| of the step."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from oracle import oracle as O
-    from tests.helpers import CompactOracle
+    from oracle.harness import CompactOracle
     from wide_deep_amd import synth
     plan = eng.plan
     bt = synth.hash_tokens(eng, tb)
     torch.cuda.synchronize()
     ids, offs = bt.ids.cpu().numpy()[: bt.nnz].copy(), bt.bag_offs.cpu().numpy()
     if "features" in hb:       # the device featurizer's ids (hash slots + crossed columns) against the oracle's
-        from tests.helpers import parsed_batch_ids
+        from oracle.harness import parsed_batch_ids
         want, woffs = parsed_batch_ids(plan, hb)
         ids_ok = bool(np.array_equal(offs[: len(woffs)], woffs) and np.array_equal(ids.astype(np.int64), want))
     else:
@@ -453,19 +453,19 @@ def parity_check(eng, spec, tb, hb, step_eager):
     return {"batch": 0, "hash_ids_bit_exact": ids_ok, "loss": round(loss, 4), "oracle_loss": round(float(oloss), 4),
             "max_abs_dlogit": float("%.3g" % float(d.max())), "max_rel_dlogit": float("%.3g" % float(rel.max())),
             "tolerance": "fp32 tower: |dlogit| <= 2e-4 + 2e-4 |logit| (tests/test_gpu_fullsize.py); fp16-operand tower 3e-2 + 2e-2 |logit|",
-            "oracle": "oracle/ CPU restatement on the rows this batch touches (tests/helpers.CompactOracle)"}
+            "oracle": "oracle/ CPU restatement on the rows this batch touches (oracle/harness.CompactOracle)"}
 
 
 def parity_check_sharded(eng, spec, tb, hb, step_eager, rank):
     """N > 1 (COLLECTIVE: every rank calls it, rank 0 gets the object): one eager sharded step on every rank's batch 0 BEFORE
     anything is timed; rank 0's LOCAL examples against the CPU oracle -- hashed (global) ids bit-exact, logits and the local
     loss sum of the step's forward.  The oracle's tables hold the rows rank 0's batch touches, fetched from their owners by
-    plain indexing + a reduce (tests/helpers.ShardedCompactOracle), not through the engine's exchange kernels; the dense
+    plain indexing + a reduce (oracle/harness.ShardedCompactOracle), not through the engine's exchange kernels; the dense
     parameters are the replicated ones.  (The backward / update of N ranks against one GPU on the global batch:
     tests/test_gpu_dist.py, world 2 and 4.)"""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from oracle import oracle as O
-    from tests.helpers import ShardedCompactOracle
+    from oracle.harness import ShardedCompactOracle
     from wide_deep_amd import synth
     plan = eng.hash_plan
     bt = synth.hash_tokens(eng, tb)
@@ -502,7 +502,7 @@ def parity_check_sharded(eng, spec, tb, hb, step_eager, rank):
             "max_abs_dlogit": float("%.3g" % float(d.max())), "max_rel_dlogit": float("%.3g" % float(rel.max())),
             "tolerance": "|dlogit| <= 2e-4 + 2e-4 |logit| (tests/test_gpu_fullsize.py)",
             "oracle": "oracle/ CPU restatement on the rows rank 0's batch touches, fetched from their owners by indexing + "
-                      "reduce (tests/helpers.ShardedCompactOracle)"}
+                      "reduce (oracle/harness.ShardedCompactOracle)"}
 
 
 def self_launch(n):

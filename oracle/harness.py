@@ -1,0 +1,386 @@
+"""Checker harness (test infrastructure, like everything under oracle/): engine batch / state -> oracle batch / model, the sampled-rows
+oracle of the full-size tests, the oracle-side ids of synthetic parsed batches.  Imported by tests/ (as tests.helpers),
+bench.py's `parity` / `cpu_baseline` legs and __graft_entry__.smoke() only -- never by the product path."""
+import os
+
+import numpy as np
+import torch
+
+from oracle import oracle as O
+
+
+def slot_csr(plan, ids, bag_offs, B):
+    """example-major bag CSR -> {slot name: (ids int64, offs int32[B+1])} (one CSR per column, like TF)."""
+    S = plan.S
+    ids = np.asarray(ids)
+    offs = np.asarray(bag_offs).astype(np.int64)
+    lens = np.diff(offs).reshape(B, S)
+    starts = offs[:-1].reshape(B, S)
+    out = {}
+    for si, s in enumerate(plan.slots):
+        l = lens[:, si]
+        o = np.zeros(B + 1, dtype=np.int32)
+        np.cumsum(l, out=o[1:])
+        if (l == 1).all():
+            v = ids[starts[:, si]]
+        else:
+            idx = np.repeat(starts[:, si] - o[:-1], l) + np.arange(int(o[-1]))
+            v = ids[idx]
+        out[s.name] = (v.astype(np.int64), o)
+    return out
+
+
+def oracle_batch(plan, ids, bag_offs, B, dense, labels, weights=None):
+    bt = {"ids": slot_csr(plan, ids, bag_offs, B), "dense": {}, "labels": np.asarray(labels, dtype=np.float32),
+          "weights": None if weights is None else np.asarray(weights, dtype=np.float32)}
+    for j, d in enumerate(plan.dense_cols):
+        v = np.asarray(dense)[:, j].astype(np.float32)
+        if d.kind == 1:
+            v = (v - np.float32(d.p0)) / (np.float32(d.p1) - np.float32(d.p0))
+        elif d.kind == 2:
+            v = (v - np.float32(d.p0)) / np.float32(d.p1)
+        elif d.kind == 3:
+            v = np.log(v)
+        bt["dense"][d.name] = v.astype(np.float32)
+    return bt
+
+
+def oracle_from_engine(eng):
+    spec, plan = eng.spec, eng.plan
+    deep_cols, wide_cols = [], []
+    for s in plan.slots:
+        if spec.has_deep and s.deep == "embedding":
+            deep_cols.append({"name": s.deep_name, "kind": "embedding", "key": s.name, "num_buckets": s.num_buckets, "dim": s.dim})
+        elif spec.has_deep and s.deep == "indicator":
+            deep_cols.append({"name": s.deep_name, "kind": "indicator", "key": s.name, "num_buckets": s.num_buckets, "dim": 0})
+        if spec.has_wide and s.wide:
+            wide_cols.append({"name": s.name, "key": s.name, "num_buckets": s.num_buckets})
+    for d in plan.dense_cols:
+        deep_cols.append({"name": d.name, "kind": "numeric", "key": d.name, "num_buckets": 0, "dim": 1})
+    state = {k: v.clone().float() if v.dtype != torch.int64 else v for k, v in eng.export_state().items()}
+    towers = [(t.hidden_units, t.mode) for t in spec.towers]
+    return O.OracleWideDeep(spec.model_type, deep_cols, wide_cols, towers, state, act=spec.activation,
+                            batch_norm=spec.batch_norm, dnn_opt=spec.dnn_opt, lin_opt=spec.lin_opt,
+                            dropout=spec.dropout or None)
+
+
+def max_rel_err(a, b, floor=1e-6):
+    a = torch.as_tensor(a).double().reshape(-1)
+    b = torch.as_tensor(b).double().reshape(-1)
+    return float(((a - b).abs() / (b.abs().clamp_min(floor) + 0)).max()) if a.numel() else 0.0
+
+
+def assert_close(a, b, rtol, atol, what=""):
+    a = torch.as_tensor(a).double().reshape(-1).cpu()
+    b = torch.as_tensor(b).double().reshape(-1).cpu()
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    err = (a - b).abs()
+    tol = atol + rtol * b.abs()
+    bad = err > tol
+    assert not bool(bad.any()), "%s: %d/%d out of tolerance, max abs err %.3e (rtol %g atol %g)" % (
+        what, int(bad.sum()), a.numel(), float(err.max()), rtol, atol)
+
+
+# ---- published Fingerprint64 known answers that cover EVERY length branch ---------------------------------------------
+# Guava's FarmHashFingerprint64Test (Hashing.farmHashFingerprint64() == farmhashna::Hash64 == TF's Fingerprint64):
+#   testReallySimpleFingerprints: "test" -> 8581389452482819506, "test"*8 -> -4196240717365766262, "test"*64 -> 3500507768004279527
+#   testMultipleLengths: 3200 chained fingerprints of prefixes 0..3200 bytes long fold to 0x7a1d67c50ec7e167
+# BigQuery FARM_FINGERPRINT documentation example: "1footrue" -> -1541654101129638711, "2applefalse" -> 2794438866806483259,
+#   "3true" -> -4880158226897771312
+GUAVA_SIMPLE = [(b"test", 8581389452482819506), (b"test" * 8, -4196240717365766262 + (1 << 64)),
+                (b"test" * 64, 3500507768004279527)]
+BIGQUERY_DOC = [(b"1footrue", -1541654101129638711 + (1 << 64)), (b"2applefalse", 2794438866806483259),
+                (b"3true", -4880158226897771312 + (1 << 64))]
+GUAVA_MULTIPLE_LENGTHS = 0x7a1d67c50ec7e167
+
+
+def guava_multiple_lengths(fp, record=None):
+    """The chain of Guava's testMultipleLengths over a fingerprint function `fp(bytes) -> uint64`; every message hashed is
+    appended to `record` (so a device kernel can hash the same 3200 messages in one launch and the chain be replayed)."""
+    M = (1 << 64) - 1
+
+    def step(h, msg):
+        if record is not None:
+            record.append(msg)
+        h ^= fp(msg)
+        h ^= h >> 41
+        h = (h * 949921979) & M
+        return h, ord("a") + ((h & 0xfffff) % 26)
+
+    iterations = 800
+    buf, n, h = bytearray(iterations * 4), 0, 0
+    for i in range(iterations):
+        for ln in (lambda: i, lambda: i * i % n, lambda: i * i * i % n, lambda: n):
+            h, c = step(h, bytes(buf[: ln()]))
+            buf[n] = c
+            n += 1
+        x0, x1, x2, x3 = buf[n - 1], buf[n - 2], buf[n - 3], buf[n // 2]
+        buf[((x0 << 16) + (x1 << 8) + x2) % n] ^= x3
+        buf[((x1 << 16) + (x2 << 8) + x3) % n] ^= i % 256
+    return h
+
+
+# ---- full-size parity: an oracle over the SAMPLED rows a set of batches touches -------------------------------------------
+class CompactOracle:
+    """OracleWideDeep whose tables hold only the rows that `batches` touch (ids remapped to their rank among the touched
+    rows of the slot -- np.unique keeps them in ascending order, so every per-row summation order of the oracle is the one it
+    would use on the full table).  Lets the full-size configurations (26 x 1M rows, the 100M-row table) be stepped against the
+    CPU oracle in seconds: nothing of size O(table) crosses PCIe.  batches: list of (ids int32[nnz], bag_offs int32[B*S+1], B)
+    as numpy arrays (the ids the DEVICE produced)."""
+
+    def __init__(self, eng, batches):
+        spec, plan = eng.spec, eng.plan
+        self.eng, self.plan = eng, plan
+        S = plan.S
+        self.uniq = []
+        per_slot = [[] for _ in range(S)]
+        for ids, offs, B in batches:
+            csr = slot_csr(plan, ids, offs, B)
+            for si, s in enumerate(plan.slots):
+                per_slot[si].append(csr[s.name][0])
+        for si in range(S):
+            u = np.unique(np.concatenate(per_slot[si])) if per_slot[si] else np.zeros(0, np.int64)
+            self.uniq.append(u[u >= 0])
+        self.ora = None
+        self.resync()
+
+    def resync(self):
+        """(Re)load the oracle's state from the engine: dense parameters + the sampled table rows + every optimizer slot.
+        Called before a step it makes the comparison a ONE-step comparison from identical state -- the training dynamics of
+        the reference (batch-SUM loss, Adagrad lr 0.05 on accumulators that start at 0.1) amplify fp32 summation-order
+        differences from step to step, which is a property of the model and not of either implementation."""
+        eng, spec, plan = self.eng, self.eng.spec, self.plan
+        state = {k: (v.clone().float() if v.dtype != torch.int64 else v) for k, v in eng.export_state(tables=False).items()}
+        deep_cols, wide_cols = [], []
+        dsa, dsb = O.SLOT_NAMES[spec.dnn_opt[0]] if spec.has_deep else (None, None)
+        lsa, lsb = O.SLOT_NAMES[spec.lin_opt[0]] if spec.has_wide else (None, None)
+        for si, s in enumerate(plan.slots):
+            nb = max(len(self.uniq[si]), 1)
+            if spec.has_deep and s.deep == "embedding":
+                col = {"name": s.deep_name, "kind": "embedding", "key": s.name, "num_buckets": nb, "dim": s.dim}
+                deep_cols.append(col)
+                nm = O.OracleWideDeep.emb_name(col)
+                for buf, suf in ((eng.emb, ""), (eng.emb_a, dsa), (eng.emb_acc, dsb)):
+                    if suf is not None:
+                        state[nm + suf] = self._emb_rows(buf, si)
+            elif spec.has_deep and s.deep == "indicator":
+                raise NotImplementedError("CompactOracle: indicator columns index the full vocabulary")
+            if spec.has_wide and s.wide:
+                col = {"name": s.name, "key": s.name, "num_buckets": nb}
+                wide_cols.append(col)
+                nm = O.OracleWideDeep.wide_name(col)
+                blk = self._wide_rows(si)
+                for c, suf in ((0, ""), (1, lsa), (2, lsb)):
+                    if suf is not None:
+                        state[nm + suf] = blk[:, c:c + 1].clone()
+        for d in plan.dense_cols:
+            deep_cols.append({"name": d.name, "kind": "numeric", "key": d.name, "num_buckets": 0, "dim": 1})
+        towers = [(t.hidden_units, t.mode) for t in spec.towers]
+        self.ora = O.OracleWideDeep(spec.model_type, deep_cols, wide_cols, towers, state, act=spec.activation,
+                                    batch_norm=spec.batch_norm, dnn_opt=spec.dnn_opt, lin_opt=spec.lin_opt,
+                                    dropout=spec.dropout or None)
+
+    def _idx(self, si):
+        return torch.as_tensor(self.uniq[si], dtype=torch.int64, device=self.eng.device)
+
+    def _emb_rows(self, buf, si):
+        s = self.plan.slots[si]
+        v = self.eng._emb_view(buf, si)           # [num_buckets, dim] view in either table layout
+        if len(self.uniq[si]) == 0:
+            return torch.zeros(1, s.dim)
+        return v[self._idx(si)].cpu().clone()
+
+    def _wide_rows(self, si):
+        r0 = self.plan.row_base[si]
+        if len(self.uniq[si]) == 0:
+            return torch.zeros(1, 4)
+        return self.eng.wide[r0 + self._idx(si)].cpu().clone()
+
+    def batch(self, ids, bag_offs, B, dense, labels, weights=None):
+        """oracle batch of device ids (remapped to the compact tables)."""
+        ob = oracle_batch(self.plan, ids, bag_offs, B, dense, labels, weights)
+        for si, s in enumerate(self.plan.slots):
+            v, o = ob["ids"][s.name]
+            r = np.searchsorted(self.uniq[si], v)
+            assert len(v) == 0 or np.array_equal(self.uniq[si][np.minimum(r, len(self.uniq[si]) - 1)], v), "id outside the sample"
+            ob["ids"][s.name] = (r.astype(np.int64), o)
+        return ob
+
+    def assert_state_matches(self, rtol, atol, kink=None, slot_kink=None):
+        """every touched table row (+ optimizer slots) and every dense parameter of the engine against the oracle.
+        kink = (max_fraction, rtol2, atol2): up to that fraction of a tensor's elements may miss (rtol, atol) as long as they
+        meet (rtol2, atol2) -- a ReLU pre-activation that rounds to +0 in one summation order and to -0 / -eps in the other
+        flips act' for ONE (example, unit): that unit's kernel column, the example's 26 embedding rows and (by one
+        example's worth) everything below move by a discrete amount (seen ~once per 10 steps at batch 8192)."""
+        eng, spec, ora = self.eng, self.eng.spec, self.ora
+
+        def close(a, b, what, kink=kink):
+            if slot_kink is not None and what.rsplit("/", 1)[-1] in ("Adagrad", "Ftrl", "Ftrl_1", "RMSProp", "RMSProp_1", "Adam", "Adam_1"):
+                kink = slot_kink            # optimizer slots (sums of squared gradients) under their own bound
+            if kink is None:
+                return assert_close(a, b, rtol, atol, what)
+            a = torch.as_tensor(a).double().reshape(-1).cpu()
+            b = torch.as_tensor(b).double().reshape(-1).cpu()
+            err = (a - b).abs()
+            bad = err > atol + rtol * b.abs()
+            frac, r2, a2 = kink
+            if os.environ.get("WD_PARITY_VERBOSE") == "1" and a.numel():
+                print("  %-70s n %9d  outside base tol %8d (%.4f%%)  max abs err %.3e  rel L2 %.3e" % (
+                    what[-70:], a.numel(), int(bad.sum()), 100.0 * float(bad.sum()) / a.numel(), float(err.max()),
+                    float(err.norm() / b.norm().clamp_min(1e-30))), flush=True)
+            assert int(bad.sum()) <= frac * a.numel() + 1, "%s: %d/%d outside (rtol %g, atol %g)" % (
+                what, int(bad.sum()), a.numel(), rtol, atol)
+            assert not bool((err > a2 + r2 * b.abs()).any()), "%s: max abs err %.3e outside the kink bound (rtol %g, atol %g)" % (
+                what, float(err.max()), r2, a2)
+
+        st = eng.export_state(tables=False)
+        for k, v in st.items():
+            if k == "global_step" or "moving_" in k:
+                continue
+            close(v, ora.state[k].detach(), k)
+        dsa, dsb = O.SLOT_NAMES[spec.dnn_opt[0]] if spec.has_deep else (None, None)
+        lsa, lsb = O.SLOT_NAMES[spec.lin_opt[0]] if spec.has_wide else (None, None)
+        for c in ora.deep_cols:
+            if c["kind"] != "embedding":
+                continue
+            si = [i for i, s in enumerate(self.plan.slots) if s.name == c["key"]][0]
+            nm = ora.emb_name(c)
+            for buf, suf in ((eng.emb, ""), (eng.emb_a, dsa), (eng.emb_acc, dsb)):
+                if suf is not None and len(self.uniq[si]):
+                    close(self._emb_rows(buf, si), ora.state[nm + suf], nm + suf)
+        for c in ora.wide_cols:
+            si = [i for i, s in enumerate(self.plan.slots) if s.name == c["key"]][0]
+            if not len(self.uniq[si]):
+                continue
+            blk = self._wide_rows(si)
+            nm = ora.wide_name(c)
+            for col, suf in ((0, ""), (1, lsa), (2, lsb)):
+                if suf is not None:
+                    close(blk[:, col:col + 1], ora.state[nm + suf], nm + suf)
+
+    def touched_mask(self):
+        """bool [total_rows] on the device: rows of the fused row space any sampled batch touches."""
+        m = torch.zeros(max(self.plan.total_rows, 1), dtype=torch.bool, device=self.eng.device)
+        for si in range(self.plan.S):
+            if len(self.uniq[si]):
+                m[self.plan.row_base[si] + self._idx(si)] = True
+        return m
+
+
+class ShardedCompactOracle(CompactOracle):
+    """CompactOracle over a ROW-SHARDED engine (wide_deep_amd.dist.ShardedWideDeepEngine): the sampled rows of the global
+    tables are fetched from their owners -- global id g of a slot lives on rank g % world as that rank's local row g // world
+    -- by plain torch indexing + one reduce(SUM) to rank `dst` per buffer, i.e. NOT through the engine's exchange kernels.
+    COLLECTIVE: every rank constructs it (and calls resync()) with the batches of rank `dst`; only `dst` ends up with an oracle
+    (`self.ora`), whose forward (logits, loss of dst's local examples) is what bench.py's N > 1 parity object compares.
+    The batches hold GLOBAL ids (hashed against eng.hash_plan)."""
+
+    def __init__(self, eng, batches, dst=0):
+        import torch.distributed as dist
+        self._dist, self.dst = dist, dst
+        self.world, self.rank = eng.world, eng.rank
+        payload = [batches if eng.rank == dst else None]
+        dist.broadcast_object_list(payload, src=dst, group=eng.group)
+        self.local_plan = eng.plan
+        # (CompactOracle.__init__ reads eng.plan: the GLOBAL plan here)
+        self.eng = eng
+        plan = eng.global_plan
+        S = plan.S
+        per_slot = [[] for _ in range(S)]
+        for ids, offs, B in payload[0]:
+            csr = slot_csr(plan, ids, offs, B)
+            for si, sl in enumerate(plan.slots):
+                per_slot[si].append(csr[sl.name][0])
+        self.plan = plan
+        self.uniq = []
+        for si in range(S):
+            u = np.unique(np.concatenate(per_slot[si])) if per_slot[si] else np.zeros(0, np.int64)
+            self.uniq.append(u[u >= 0])
+        self.ora = None
+        self.resync()
+
+    def _fetch(self, rows_of_owner, width):
+        """rows [n, width] of the sampled ids of one slot: every rank fills the ids it owns, reduce(SUM) to dst"""
+        dist, eng = self._dist, self.eng
+        out = rows_of_owner
+        if dist.get_backend(eng.group) == "gloo":
+            t = out.cpu()
+            dist.reduce(t, dst=self.dst, op=dist.ReduceOp.SUM, group=eng.group)
+            return t
+        dist.reduce(out, dst=self.dst, op=dist.ReduceOp.SUM, group=eng.group)
+        return out.cpu()
+
+    def _owned(self, si):
+        g = torch.as_tensor(self.uniq[si], dtype=torch.int64, device=self.eng.device)
+        mine = (g % self.world) == self.rank
+        return g, mine, (g // self.world)[mine]
+
+    def _emb_rows(self, buf, si):
+        s = self.plan.slots[si]
+        if len(self.uniq[si]) == 0:
+            return torch.zeros(1, s.dim)
+        g, mine, loc = self._owned(si)
+        out = torch.zeros(len(g), s.dim, dtype=torch.float32, device=self.eng.device)
+        out[mine] = self.eng._emb_view(buf, si)[loc].float()
+        return self._fetch(out, s.dim).clone()
+
+    def _wide_rows(self, si):
+        if len(self.uniq[si]) == 0:
+            return torch.zeros(1, 4)
+        g, mine, loc = self._owned(si)
+        out = torch.zeros(len(g), 4, dtype=torch.float32, device=self.eng.device)
+        out[mine] = self.eng.wide[self.local_plan.row_base[si] + loc].float()
+        return self._fetch(out, 4).clone()
+
+    def resync(self):
+        if self.rank == self.dst:
+            return super().resync()
+        # the other ranks serve the same sequence of fetches that CompactOracle.resync() issues on dst
+        eng, spec, plan = self.eng, self.eng.spec, self.plan
+        dsa, dsb = O.SLOT_NAMES[spec.dnn_opt[0]] if spec.has_deep else (None, None)
+        lsa, lsb = O.SLOT_NAMES[spec.lin_opt[0]] if spec.has_wide else (None, None)
+        for si, s in enumerate(plan.slots):
+            if spec.has_deep and s.deep == "embedding":
+                for buf, suf in ((eng.emb, ""), (eng.emb_a, dsa), (eng.emb_acc, dsb)):
+                    if suf is not None:
+                        self._emb_rows(buf, si)
+            if spec.has_wide and s.wide:
+                self._wide_rows(si)
+
+
+def parsed_batch_ids(plan, hb, cross_padding="ragged"):
+    """The oracle's ids of a synthetic parsed batch (wide_deep_amd.synth.make_parsed_batch): Fingerprint64 % buckets of every
+    token of the hash slots, SparseCross over the key features' fingerprints for the crossed slots (last key fastest, default
+    hash_key; python/lib/build_estimator.py:138-155), as ONE example-major bag CSR in the plan's slot order.
+    Returns (ids int64 [nnz], bag_offs int32 [B * S + 1])."""
+    from wide_deep_amd import synth
+    assert cross_padding == "ragged", "synthetic batches have no padded [B, Lmax] form (quirk C.16 is a property of the TSV path)"
+    B, feats = hb["B"], hb["features"]
+    fp, ex = {}, {}
+    for j, f in enumerate(feats):
+        data, toffs = synth.pack_decimal_tokens(hb["raw"][f])
+        fp[f] = O.fingerprint64_batch(data, toffs.astype(np.int64))
+        e = np.zeros(B + 1, dtype=np.int32)
+        np.cumsum(hb["lens"][:, j], out=e[1:])
+        ex[f] = e
+    per = []
+    for s in plan.slots:
+        if s.kind == "hash":
+            per.append(((fp[s.feature] % np.uint64(s.num_buckets)).astype(np.int64), ex[s.feature]))
+        elif s.kind == "cross":
+            assert all(k.kind == "string" for k in s.cross_keys)
+            ids, offs = O.cross_hash([(fp[k.feature], ex[k.feature]) for k in s.cross_keys], s.num_buckets)
+            per.append((ids.astype(np.int64), offs))
+        else:
+            raise NotImplementedError(s.kind)
+    S = plan.S
+    lens = np.stack([np.diff(o) for _, o in per], axis=1).astype(np.int64)          # [B, S]
+    bag_offs = np.zeros(B * S + 1, dtype=np.int64)
+    np.cumsum(lens.reshape(-1), out=bag_offs[1:])
+    out = np.zeros(int(bag_offs[-1]), dtype=np.int64)
+    for si, (ids, offs) in enumerate(per):
+        n = np.diff(offs).astype(np.int64)
+        b_of = np.repeat(np.arange(B), n)
+        within = np.arange(len(ids)) - np.repeat(offs[:-1].astype(np.int64), n)
+        out[bag_offs[b_of * S + si] + within] = ids
+    return out, bag_offs.astype(np.int32)

@@ -332,7 +332,7 @@ def test_input_fn_mirrors_the_reference_test_input_fn(tmp_path):
 def test_lr_decay_is_opt_in_and_follows_exponential_decay(tmp_path):
     """The reference builds tf.train.exponential_decay over a tf.Variable(0) that nothing increments (python/lib/joint.py:145-154):
     its learning rates never move, and neither do ours by default.  `lr_decay: true` in train.yaml (an extension) decays the
-    scopes whose optimizer is given by NAME over TF's global step: lr_0 * decay_rate ** (global_step / (num_examples // batch_size))."""
+    scopes whose optimizer is given by NAME over TF's global step: lr_0 * decay_rate ** (global_step / (num_examples / batch_size))."""
     import shutil
     import yaml
     spec = BE.build_model_spec(Config(), "wide_deep")
@@ -344,9 +344,9 @@ def test_lr_decay_is_opt_in_and_follows_exponential_decay(tmp_path):
     yaml.safe_dump(tr, open(base / "train.yaml", "w"))
     conf = Config(base_dir=str(base))
     spec = BE.build_model_spec(conf, "wide_deep")
-    # python/lib/joint.py:78 `_num_examples / _batch_size` under the reference's Python 2: integer (floor) division
-    steps = float(conf.train["num_examples"] // conf.train["batch_size"])
-    assert steps == int(steps) and conf.train["num_examples"] % conf.train["batch_size"] != 0      # (the floor matters for the shipped conf)
+    # python/lib/joint.py:78 `_num_examples / _batch_size` with joint.py:25's `from __future__ import division`: a float
+    steps = conf.train["num_examples"] / conf.train["batch_size"]
+    assert steps != int(steps)      # (true vs floor division matters for the shipped conf)
     # dnn_optimizer: 'Adagrad' (a name: takes the model_fn's rate) decays at dnn_decay_rate 0.8; linear_optimizer is a constructor
     # string with its own learning rate: untouched
     assert spec.lr_decay == {"dnn": (0.8, steps)}

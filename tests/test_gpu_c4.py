@@ -150,3 +150,49 @@ def test_small_table_path_trains_like_the_general_path_and_the_oracle(monkeypatc
     for k in a:
         if a[k].dtype.is_floating_point:
             assert_close(a[k], g[k], 5e-4, 1e-5, "state %s vs the general path" % k)
+
+
+def test_small_tables_are_admitted_against_their_joint_maxima(monkeypatch):
+    """The small-table kernels size LDS and workspace by (longest table) x (widest embedding + 2) over ALL admitted columns:
+    a 3900-row wide-only cross (alone: 7800 floats; its backward asks for 32 + 31 + 5 KB of dynamic LDS -- beyond the 64 KB a
+    launch gets without the attribute) and a 1000-row cross of width 4 (alone: 6000) fit one by one and not together
+    (3900 x 6 = 23400 > 8192).  The first is admitted, the second stays on the general path, and the step matches the model
+    with every column on the general path and the oracle."""
+    from tests.helpers import assert_close, oracle_batch, oracle_from_engine, parsed_batch_ids
+    from wide_deep_amd import capi, synth
+    from wide_deep_amd.engine import WideDeepEngine
+    from wide_deep_amd.features import Featurizer
+    from wide_deep_amd.plan import CatSlot, CrossKey, FeaturePlan, criteo_spec
+    B = 131
+    spec = criteo_spec(n_dense=2, n_sparse=4, buckets=3000, dim=8, hidden=(32, 16), mode="simple", crosses=((0, 1),),
+                       cross_buckets=1000)
+    for s in spec.slots:
+        if s.kind == "cross":
+            s.dim = 4
+    spec.slots.insert(4, CatSlot(name="C02_X_C03", kind="cross", num_buckets=3900, deep=None, dim=0, wide=True,
+                                 cross_keys=[CrossKey("C02", "string"), CrossKey("C03", "string")]))
+    gp = FeaturePlan(spec)
+    kinds = [(s.kind, s.num_buckets) for s in gp.slots]
+    parsed = [synth.make_parsed_batch(gp, B, seed=70 + i, mean_len=3, pos_rate=0.3) for i in range(2)]
+    nnz = max(hb["nnz"] for _, hb in parsed) + 64
+    monkeypatch.setenv("WD_SMALL_TABLES", "0")
+    gen = WideDeepEngine(spec, max_batch=256, max_nnz=nnz, seed=4)
+    monkeypatch.setenv("WD_SMALL_TABLES", "cross")
+    eng = WideDeepEngine(spec, max_batch=256, max_nnz=nnz, seed=4)
+    adm = [kinds[i] for i in eng.small_idx]
+    assert len(adm) == 1 and adm[0][0] == "cross", (kinds, eng.small_idx)
+    assert eng.small_rows * (eng.small_dim + 2) <= capi.SMALL_MAX_FLOATS
+    ora = oracle_from_engine(eng)
+    fz, fzg = Featurizer(eng, cross_padding="ragged"), Featurizer(gen, cross_padding="ragged")
+    for step, (raw, hb) in enumerate(parsed):
+        bt, btg = fz.to_device(raw), fzg.to_device(raw)
+        ids, offs = parsed_batch_ids(eng.plan, hb)
+        loss, lossg = float(eng.train_step(bt)), float(gen.train_step(btg))
+        torch.cuda.synchronize()
+        oloss, ologits = ora.train_step(oracle_batch(eng.plan, ids, offs, B, hb["dense"], hb["labels"], hb.get("weights")))
+        assert_close(eng.logit[:B], ologits, 2e-4, 2e-5, "logits vs oracle, step %d" % step)
+        assert_close(eng.logit[:B], gen.logit[:B], 2e-4, 2e-5, "logits vs the general path, step %d" % step)
+    a, g = eng.export_state(), gen.export_state()
+    for k in a:
+        if a[k].dtype.is_floating_point:
+            assert_close(a[k], g[k], 5e-4, 1e-5, "state %s vs the general path" % k)

@@ -165,9 +165,9 @@ def build_model_spec(conf=None, model_type=None):
     # the reference itself never decays (quirk C.2).  Only optimizers given by name take the model_fn's learning rate.
     lr_decay = None
     if train.get("lr_decay"):
-        # decay_steps (python/lib/joint.py:78 `_num_examples / _batch_size`): the reference is Python 2 (`map(int, ...)` unpacked,
-        # print statements), where `/` on two ints floors
-        steps = float(max(int(train["num_examples"]) // int(train["batch_size"]), 1))
+        # decay_steps (python/lib/joint.py:78 `_num_examples / _batch_size`): true division -- joint.py:25 has
+        # `from __future__ import division`, so the quotient is a float under the reference's Python 2 as well
+        steps = float(train["num_examples"]) / float(train["batch_size"])
         lr_decay = {}
         for scope, key, rk in (("dnn", "dnn_optimizer", "dnn_decay_rate"), ("linear", "linear_optimizer", "linear_decay_rate")):
             rate = model.get(rk) or 1

@@ -86,17 +86,18 @@ __global__ void __launch_bounds__(256) k_small_fwd(SmallArgs a) {
       float acc[SM_MAX_DIM];
 #pragma unroll
       for (int d = 0; d < SM_MAX_DIM; ++d) acc[d] = 0.f;
-      float ws = 0.f, cnt = 0.f;
+      float ws = 0.f;
+      // combiner='mean' divides by the bag's length, as wd_embag_fwd and k_small_bwd do (a negative id -- none reaches a bag
+      // of the featurizer -- contributes a zero row but still counts)
+      const float cnt = (float)(j1 - j0);
       for (int32_t j = j0 + lane; j < j1; j += 64) {
         const int32_t id = a.ids[j];
         if (id < 0) continue;
-        cnt += 1.f;
         if (sl.wide) ws += W[id];
 #pragma unroll
         for (int d = 0; d < SM_MAX_DIM; ++d)
           if (d < D) acc[d] += T[id * D + d];
       }
-      cnt = wave_sum(cnt);
       if (sl.wide) wsum[e] += wave_sum(ws);
       if (D > 0 && sl.out_col >= 0) {
 #pragma unroll
@@ -310,6 +311,15 @@ extern "C" int wd_small_tables_bwd(float *emb, float *emb_accum, float *wide_wzn
   a.lr_emb = lr_emb; a.lr_w = lr_wide; a.l1 = l1; a.l2 = l2;
   const size_t lds = (size_t)max_rows * (max_dim + 2) * 4 + (size_t)2 * max_rows * 4 + (size_t)2 * SM_SLICE * 4 +
                      (size_t)SM_SLICE * (SM_MAX_DIM + 1) * 4;
+  // a wide-only table of ~4 k rows asks for 32 KB of partials + 32 KB of histograms + staging: beyond the 64 KB a launch gets
+  // without the attribute (WD_SMALL_MAX_FLOATS bounds it at 32 KB + 64 KB + 4.9 KB)
+  static size_t lds_allowed = 64 * 1024;
+  if (lds > lds_allowed) {
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_small_bwd), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             (int)lds);
+    WD_REQUIRE(e == hipSuccess, "hipFuncSetAttribute(k_small_bwd, dynamic LDS) failed");
+    lds_allowed = lds;
+  }
   hipStream_t st = wd::as_stream(stream);
   hipLaunchKernelGGL(k_small_bwd, dim3((unsigned)a.nslice, (unsigned)nsmall), dim3(256), lds, st, a);
   hipLaunchKernelGGL(k_small_apply, dim3((unsigned)wd::ceil_div((int64_t)max_rows * (max_dim + 1), (int64_t)256), (unsigned)nsmall),

@@ -134,11 +134,17 @@ class WideDeepEngine:
         self.small_idx = []
         mode = os.environ.get("WD_SMALL_TABLES", "cross")
         if mode != "0" and type(self) is WideDeepEngine:
+            # the kernels size their LDS (and the workspace) by the JOINT maxima over the admitted columns -- rows of the
+            # longest table x (widest embedding + 2) -- so a column is admitted only while that product still fits (a 2000-row
+            # wide-only cross and a 1000-row cross of width 4 fit one by one and not together: the later one stays on the
+            # general path)
+            jr = jd = 0
             for i, s in enumerate(plan.slots):
                 d = int(arr[i].dim)
                 if ((s.kind == "cross" or mode == "all") and arr[i].kind != capi.SLOT_INDICATOR and (d > 0 or arr[i].wide)
-                        and d <= 16 and int(s.num_buckets) * (d + 2) <= capi.SMALL_MAX_FLOATS):
+                        and d <= 16 and max(jr, int(s.num_buckets)) * (max(jd, d) + 2) <= capi.SMALL_MAX_FLOATS):
                     self.small_idx.append(i)
+                    jr, jd = max(jr, int(s.num_buckets)), max(jd, d)
         self.slots_small_dev = self.small_idx_dev = self.small_ws = None
         if self.small_idx:
             for i in self.small_idx:

@@ -128,7 +128,10 @@ class StepGraph:
         for t, tb in enumerate(tbs):
             if ev_ids:
                 main.wait_event(ev_ids[t])
-            nxt = (tbs[t + 1].batch, (t + 1) & 1) if t + 1 < len(tbs) else None
+                if t + 1 < len(tbs):
+                    # step t also buckets batch t+1 (behind its dense tail): the graph needs the edge hash(t+1) -> that node
+                    main.wait_event(ev_ids[t + 1])
+            nxt =(tbs[t + 1].batch, (t + 1) & 1) if t + 1 < len(tbs) else None
             eng.train_step(tb.batch, pset=(t & 1) if t >= 1 else None, lookahead=nxt)
         if ev_ids:
             main.wait_stream(s_h)

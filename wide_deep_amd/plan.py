@@ -129,8 +129,8 @@ class ModelSpec:
     # (train.yaml `lr_decay: true`, build_estimator.build_model_spec): {"dnn": (decay_rate, decay_steps), "linear": (...)} for
     # the scopes whose optimizer is given by NAME (those take the model_fn's learning rate; a constructor string keeps its own,
     # python/lib/utils/model_util.py:84-105):  lr_t = lr_0 * decay_rate ** (global_step / decay_steps)  over TF's global step --
-    # which advances 3 per train step in wide_deep mode (2 otherwise; quirk C.4): with decay_steps = num_examples // batch_size
-    # (python/lib/joint.py:78 under the reference's Python 2: integer division) a rate has decayed by `decay_rate` after a THIRD
+    # which advances 3 per train step in wide_deep mode (2 otherwise; quirk C.4): with decay_steps = num_examples / batch_size
+    # (python/lib/joint.py:78; a float: joint.py:25 imports division from __future__) a rate has decayed by `decay_rate` after a THIRD
     # of an epoch, not after one as the reference's comment has it.
     lr_decay: Optional[dict] = None
 

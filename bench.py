@@ -708,9 +708,10 @@ def main():
                                     # bytes in every all-to-all and in the owner-side kernels that walk the padding)
                                     slack=args.slack if args.slack else (1.1 if args.dist == "uniform" else 1.2 if dedup_expected else 2.5))
     elif featurized:
-        # crossed columns (BASELINE configs[3]): the batches go through the product's device featurizer (features.Featurizer:
-        # fingerprints, hash buckets, SparseCross) BEFORE the timed region -- its one host wait for the id count keeps it out of
-        # a hipGraph -- and the step is timed on the resident ids
+        # crossed columns (BASELINE configs[3]): the batches are PARSED batches resident in HBM (token bytes + per-feature example
+        # ranges, what dataset.input_fn hands over) and every step runs the product's device featurizer on its batch
+        # (features.Featurizer.run: fingerprints, bag lengths, bag CSR, hash buckets, SparseCross -- no host wait) like C2's steps
+        # run wd_hash_bucket; --ids-input featurizes before the timed region instead (the line of round 5)
         from wide_deep_amd.features import Featurizer
         from wide_deep_amd.plan import FeaturePlan
         gp = FeaturePlan(spec)
@@ -719,7 +720,6 @@ def main():
                   for i in range(args.pool)]
         eng = WideDeepEngine(spec, max_batch=B, max_nnz=int(1.02 * max(hb["nnz"] for _, hb in parsed)) + 1024, seed=0,
                              tower_dtype=tower_dtype)
-        args.ids_input = True
     else:
         eng = WideDeepEngine(spec, max_batch=B, max_nnz=B * 26 * (2 * mean_len + 2), seed=0, tower_dtype=tower_dtype)
     plan = getattr(eng, "hash_plan", eng.plan)    # sharded: batches live in the GLOBAL id space
@@ -731,7 +731,8 @@ def main():
         for i, (raw, hb) in enumerate(parsed):
             if i < 4:
                 host_batches.append(hb)
-            dev_batches.append(synth.FeaturizedBatch(fz.to_device(raw), hb))
+            dev_batches.append(synth.FeaturizedBatch(fz.to_device(raw), hb) if args.ids_input
+                               else synth.ParsedTokenBatch(fz, raw, hb, ids_capacity=eng.max_nnz))
         del parsed
     for i in range(0 if featurized else args.pool):
         hb = synth.make_raw_batch(plan, B, seed=20260925 + 1000 * rank + i, mean_len=mean_len, dist=args.dist)
@@ -881,8 +882,13 @@ def main():
                 "c5": "BASELINE configs[4] (C5): deep-only DenseDnn [1024,512,256,128], emb_dim 64, %s tower, batch %d"
                       % (tower_dtype, B),
             }[args.config],
-            "global_batch": B * world, "ids": args.dist, "input": ("ids resident: produced before the timed region by the device featurizer (hash buckets + crossed columns)"
-                                                               if featurized else "pre-hashed ids" if args.ids_input else "raw string tokens (hashed in step)"),
+            "global_batch": B * world, "ids": args.dist,
+            "input": ("ids resident: produced before the timed region by the device featurizer (hash buckets + crossed columns)"
+                      if featurized and args.ids_input else
+                      "parsed batch resident (token bytes + example ranges); fingerprints, bag CSR, hash buckets and crossed columns in step"
+                      if featurized else "pre-hashed ids" if args.ids_input else "raw string tokens (hashed in step)"),
+            # machine-readable: is the tokens -> ids work (hash buckets, crossed columns) inside the timed region?
+            "featurize_in_timed_region": not args.ids_input,
             "hip_graph": bool(use_graph), "steps_per_graph": steps_per_run,
             "chained_graphs": bool(use_graph and run_steps_graph and chain),
             "table_layout": ("row records: %d B = [emb %d f32 | w z n -]" % (4 * eng.rec_stride, eng.emb.shape[1])

@@ -170,12 +170,21 @@ typedef struct wd_feat_batch {
 int wd_feat_vocab_lookup(const uint8_t *bytes, const int32_t *tok_offs, int64_t tok_begin, int64_t n,
                          const uint8_t *vocab_bytes, const int32_t *vocab_offs, int32_t nvocab, int32_t *tok_val,
                          wd_stream_t stream);
-int wd_feat_lens(const wd_feat_slot_t *slots_dev, const wd_feat_batch_t *batch, int32_t *lens, wd_stream_t stream);
-int64_t wd_feat_offsets_workspace_bytes(int64_t n);
-int wd_feat_offsets(const int32_t *lens, int64_t n, int32_t *offs, void *workspace, int64_t workspace_bytes,
-                    wd_stream_t stream);
-int wd_feat_emit(const wd_feat_slot_t *slots_dev, const wd_feat_batch_t *batch, const int32_t *bag_offs, int32_t *ids,
+/* lens[b * S + s] = ids column s gives example b; block_stats[2 k], [2 k + 1] = sum of the lengths of pairs [256 k, 256 k + 256)
+ * and "one of them is not 1" (wd_feat_offsets_workspace_bytes(batch * S) bytes). */
+int wd_feat_lens(const wd_feat_slot_t *slots_dev, const wd_feat_batch_t *batch, int32_t *lens, int32_t *block_stats,
                  wd_stream_t stream);
+int64_t wd_feat_offsets_workspace_bytes(int64_t n);
+/* Bag CSR of the n = batch * S bags: offs[0] = 0, offs[i + 1] = lens[0] + ... + lens[i] (offs[n] = ids of the batch -- it stays on
+ * the device).  flags (optional, device int32[2], plain stores -- nothing to zero): flags[0] = offs[n] > ids_capacity,
+ * flags[1] = some bag does not hold exactly one id (the engine's one-id-per-bag fast paths need to know). */
+int wd_feat_offsets(const int32_t *lens, const int32_t *block_stats, int64_t n, int32_t *offs, int64_t ids_capacity, int32_t *flags,
+                    wd_stream_t stream);
+/* ids of every bag, one lane per OUTPUT id (a crossed column's bag is the product of its keys' counts: 25-125 ids per example at
+ * BASELINE configs[3]); the grid is sized by the batch, not by the id count, so the count never has to reach the host:
+ * `ids` holds `ids_capacity` entries, ids beyond it are dropped (wd_feat_offsets raised flags[0]).  At most 1024 categorical columns. */
+int wd_feat_emit(const wd_feat_slot_t *slots_dev, const wd_feat_batch_t *batch, const int32_t *bag_offs, int32_t *ids,
+                 int64_t ids_capacity, wd_stream_t stream);
 
 /* ---- a8: tf.feature_column.input_layer (python/lib/dnn.py:83-90) ---------------------------
  * Fused multi-slot embedding-bag gather: for every slot g in group_slots (all of one dim D):

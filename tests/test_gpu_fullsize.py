@@ -82,8 +82,9 @@ def _bit_identical(a, b):
 
 
 def _featurized(mk, spec, B, mean_len, dist, n_steps, seed):
-    """(engine, host batches, FeaturizedBatch list, [(ids, offs, B)]): synthetic parsed batches through features.Featurizer, the
-    device's ids checked bit-exact against the oracle's (tests/helpers.parsed_batch_ids)."""
+    """(engine, host batches, ParsedTokenBatch list, [(ids, offs, B)]): synthetic parsed batches resident in HBM, featurized by
+    features.Featurizer.run -- the launches every step of the timed path repeats (no host wait) --, the device's ids checked
+    bit-exact against the oracle's (tests/helpers.parsed_batch_ids) and against the sized entry point (Featurizer.to_device)."""
     from tests.helpers import parsed_batch_ids
     from wide_deep_amd import synth
     from wide_deep_amd.features import Featurizer
@@ -94,15 +95,20 @@ def _featurized(mk, spec, B, mean_len, dist, n_steps, seed):
     eng = mk(int(1.02 * max(hb["nnz"] for _, hb in parsed)) + 1024)
     fz = Featurizer(eng, cross_padding="ragged")
     tbs, dev_ids = [], []
-    for raw, hb in parsed:
-        bt = fz.to_device(raw)
+    for k, (raw, hb) in enumerate(parsed):
+        tb = synth.ParsedTokenBatch(fz, raw, hb, ids_capacity=eng.max_nnz)
+        bt = tb.batch
         torch.cuda.synchronize()
         ids, offs = bt.ids.cpu().numpy()[: bt.nnz].copy(), bt.bag_offs.cpu().numpy()
         want, woffs = parsed_batch_ids(eng.plan, hb)
-        assert bt.nnz == hb["nnz"] == len(want)
+        assert bt.nnz == hb["nnz"] == len(want) and not bt.one_hot
         assert np.array_equal(offs[: len(woffs)], woffs), "bag offsets differ from the oracle"
         assert np.array_equal(ids.astype(np.int64), want), "featurizer ids (hash slots + crossed columns) differ from the oracle"
-        tbs.append(synth.FeaturizedBatch(bt, hb))
+        if k == 0:
+            b2 = fz.to_device(raw)
+            assert b2.nnz == bt.nnz and torch.equal(b2.ids[: bt.nnz], bt.ids[: bt.nnz]) and torch.equal(b2.bag_offs, bt.bag_offs)
+        bt.ids.zero_()              # the steps below must produce the ids themselves (hash_tokens -> Featurizer.run)
+        tbs.append(tb)
         dev_ids.append((ids, offs, B))
     return eng, [hb for _, hb in parsed], tbs, dev_ids
 
@@ -120,7 +126,7 @@ def _fullsize(spec, B, mean_len, dist, n_steps, n_graph, tower_dtype="fp32", tol
         mkn = lambda nnz: WideDeepEngine(spec, max_batch=B, max_nnz=nnz, seed=0, tower_dtype=tower_dtype)
         eng, hbs, tbs, dev_ids = _featurized(mkn, spec, B, mean_len, dist, n_steps, seed)
         mk = lambda: mkn(eng.max_nnz)
-        step_eager_ = lambda e, tb: step_eager(e, tb, True)
+        step_eager_ = step_eager        # tokens in: every step (eager and captured) runs the featurizer's launches on its batch
     else:
         mk = lambda: WideDeepEngine(spec, max_batch=B, max_nnz=B * S * (2 * mean_len + 2), seed=0, tower_dtype=tower_dtype)
         eng = mk()
@@ -160,12 +166,15 @@ def _fullsize(spec, B, mean_len, dist, n_steps, n_graph, tower_dtype="fp32", tol
     del emb0, wide0, co, free
     # ---- the replay bench.py times: n_graph steps per hipGraph, each on its own batch, on a twin engine ----------------
     twin = mk()
-    # (featurized batches are inputs only: the twin trains on the same resident ids)
+    # (parsed batches are inputs only: the twin's steps featurize the same resident tokens again)
+    if featurize:
+        for tb in tbs:
+            tb.batch.ids.zero_()
     tbs2 = tbs if featurize else [synth.TokenBatch(twin.plan, hb, weights=_weights(spec, hb)) for hb in hbs]
     with torch.cuda.stream(side):
         step_eager_(twin, tbs2[0])
     torch.cuda.synchronize()
-    graphs = [StepGraph(twin, tbs2[j: j + n_graph], ids_input=featurize, stream=side) for j in range(1, n_steps, n_graph)]
+    graphs = [StepGraph(twin, tbs2[j: j + n_graph], ids_input=False, stream=side) for j in range(1, n_steps, n_graph)]
     for g in graphs:
         g.replay()
     torch.cuda.synchronize()
@@ -274,9 +283,10 @@ def test_c4_full_size_multi_hot_resnet_weights_matches_oracle():
 def test_c4_full_size_with_crossed_columns_matches_oracle():
     """BASELINE configs[3] as stated, at size: batch 8192, 26 multi-hot slots (mean 5) x 1M buckets + two 200-bucket crossed
     columns over 2 and 3 of the slots (python/lib/build_estimator.py:138-155; ~25 and ~125 cross ids per example, 2.3 M ids per
-    batch), ResDnn, weight column.  The batch goes through the product's device featurizer (features.Featurizer: Fingerprint64,
-    hash buckets, SparseCross with the last key fastest) -- ids and bag offsets BIT-EXACT against the oracle's fingerprints and
-    cross hash -- then every step against the re-synchronised oracle, then the hipGraph replay against the eager twin."""
+    batch), ResDnn, weight column.  Every step runs the product's device featurizer on its resident parsed batch
+    (features.Featurizer.run: Fingerprint64, bag CSR, hash buckets, SparseCross with the last key fastest, one lane per id, no
+    host wait) -- ids and bag offsets BIT-EXACT against the oracle's fingerprints and cross hash -- then the train step against
+    the re-synchronised oracle; then the hipGraph replay (featurizer launches captured with the step) against the eager twin."""
     import sys, os
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import bench

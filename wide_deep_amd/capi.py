@@ -174,10 +174,10 @@ _PROTOS = {
     "wd_emit_int_slot": [P, P, I64, P, I32, I32, P, P],
     "wd_cross_hash": [ctypes.POINTER(WdCrossKeys), I64, U64, U64, P, I32, I32, P, P],
     "wd_feat_vocab_lookup": [P, P, I64, I64, P, P, I32, P, P],
-    "wd_feat_lens": [P, ctypes.POINTER(WdFeatBatch), P, P],
+    "wd_feat_lens": [P, ctypes.POINTER(WdFeatBatch), P, P, P],
     "wd_feat_offsets_workspace_bytes": [I64],
-    "wd_feat_offsets": [P, I64, P, P, I64, P],
-    "wd_feat_emit": [P, ctypes.POINTER(WdFeatBatch), P, P, P],
+    "wd_feat_offsets": [P, P, I64, P, I64, P, P],
+    "wd_feat_emit": [P, ctypes.POINTER(WdFeatBatch), P, P, I64, P],
     "wd_embag_fwd": [P, P, I32, P, I32, I32, P, P, I64, P, I64, P],
     "wd_embag_fwd_range": [P, P, I32, I32, I32, I32, P, P, I64, P, I64, P],
     "wd_input_layer_fwd": [P, P, I32, I32, I32, I32, P, P, I32, I64, P, I64, P, I64, P, I32, P, P, P, P],

@@ -96,6 +96,14 @@ class _Stage(object):
         return self.dbuf[off: off + a.nbytes].view(_NP2T[a.dtype])
 
 
+class ParsedDeviceBatch(object):
+    """A parsed batch resident in HBM (the staged buffer of Featurizer._stage: token bytes + offsets, per-feature example
+    ranges, integer / float feature matrices, labels) with the buffers the featurizer's launches fill: fingerprints, vocabulary
+    indices, bag lengths, the bag CSR `bag`, the ids `ids` (capacity `cap`), device flags [overflow, some bag is not one id].
+    `.batch` is the DeviceBatch over them (Featurizer.resident / run / finalize)."""
+    pass
+
+
 class Featurizer(object):
     def __init__(self, engine, cross_padding="tf_dense", mode=None):
         if cross_padding not in ("tf_dense", "ragged"):
@@ -198,18 +206,14 @@ class Featurizer(object):
         # the tables above were uploaded on the caller's stream: one edge, once, so that the featurizer's own stream -- which is
         # deliberately NOT ordered behind the training stream per batch -- never reads them before they have arrived
         self._fs.wait_stream(torch.cuda.current_stream(dev))
-        self._scan_ws = None
 
-    def _to_device_dev(self, raw):
-        plan, eng = self.plan, self.engine
-        B, S = raw.B, plan.S
-        if B > eng.max_batch:
-            raise ValueError("batch (B=%d) exceeds engine capacity (max_batch=%d)" % (B, eng.max_batch))
-        T = len(raw.tok_offs) - 2
+    def _stage(self, raw):
+        """1. the parsed batch, as it is, in one staged buffer + ONE host-to-device copy (on the current stream)"""
+        plan = self.plan
+        B = raw.B
         F = len(self.str_feats)
-        # ---- 1. the parsed batch, as it is, in one staged buffer ------------------------------------------------------------
         stg = _Stage()
-        h_bytes, h_toffs = stg.add(raw.tok_bytes, np.uint8), stg.add(raw.tok_offs, np.int32)
+        h = {"bytes": stg.add(raw.tok_bytes, np.uint8), "toffs": stg.add(raw.tok_offs, np.int32)}
         ex = np.zeros((max(F, 1), B + 1), dtype=np.int32)
         base = np.zeros(max(F, 1), dtype=np.int32)
         lmax = np.zeros(max(F, 1), dtype=np.int32)
@@ -217,7 +221,7 @@ class Featurizer(object):
             pc = raw.cat[f]
             ex[j], base[j] = pc.ex_offs, pc.base
             lmax[j] = int(np.diff(pc.ex_offs).max()) if B else 0
-        h_ex, h_base, h_lmax = stg.add(ex, np.int32), stg.add(base, np.int32), stg.add(lmax, np.int32)
+        h["ex"], h["base"], h["lmax"] = stg.add(ex, np.int32), stg.add(base, np.int32), stg.add(lmax, np.int32)
         ints = (np.stack([np.asarray(raw.ints[f], dtype=np.int64) for f in self.int_feats]) if self.int_feats
                 else np.zeros((1, max(B, 1)), np.int64))
         rows = []
@@ -225,59 +229,128 @@ class Featurizer(object):
             x = np.asarray(raw.floats[f], dtype=np.float32)
             rows.append(np.log(x) if log else x)
         floats = np.stack(rows) if rows else np.zeros((1, max(B, 1)), np.float32)
-        h_ints, h_floats = stg.add(ints, np.int64), stg.add(floats, np.float32)
+        h["ints"], h["floats"] = stg.add(ints, np.int64), stg.add(floats, np.float32)
         nd = len(plan.dense_cols)
-        h_dense = stg.add(np.stack([raw.floats[d.feature] for d in plan.dense_cols], axis=1), np.float32) if nd else None
-        h_lab = stg.add(raw.labels, np.float32) if raw.labels is not None else None
+        h["dense"] = stg.add(np.stack([raw.floats[d.feature] for d in plan.dense_cols], axis=1), np.float32) if nd else None
+        h["lab"] = stg.add(raw.labels, np.float32) if raw.labels is not None else None
         use_w = raw.weights is not None and self.engine.spec.use_weight_column
-        h_wts = stg.add(raw.weights, np.float32) if use_w else None
+        h["wts"] = stg.add(raw.weights, np.float32) if use_w else None
+        stg.upload(self.dev)
+        return stg, h
+
+    def resident(self, raw, ids_capacity=None):
+        """The parsed batch staged into HBM + every buffer the featurizer's launches fill, allocated once: what `run` works on
+        without allocating or waiting (a ParsedDeviceBatch can be featurized inside a captured step, like a synth.TokenBatch is
+        hashed).  ids_capacity: entries of the id array (default: the engine's max_nnz); `pdb.batch.nnz` is that CAPACITY --
+        the engine only uses it as a sizing hint -- until `finalize` reads the real count."""
+        plan, eng = self.plan, self.engine
+        if self.mode != "device":
+            raise ValueError("Featurizer.resident needs mode='device'")
+        B, S = raw.B, plan.S
+        if B > eng.max_batch:
+            raise ValueError("batch (B=%d) exceeds engine capacity (max_batch=%d)" % (B, eng.max_batch))
+        cap = int(ids_capacity) if ids_capacity is not None else int(eng.max_nnz)
+        if cap > eng.max_nnz:
+            raise ValueError("ids_capacity %d exceeds engine capacity (max_nnz=%d)" % (cap, eng.max_nnz))
+        pdb = ParsedDeviceBatch()
+        pdb.B, pdb.T, pdb.raw = B, len(raw.tok_offs) - 2, raw
+        pdb.stg, pdb.h = self._stage(raw)
+        self._alloc_head(pdb)
+        pdb.cap = cap
+        pdb.ids = torch.zeros(max(cap, 1), dtype=torch.int32, device=self.dev)
+        self._make_batch(pdb, nnz=cap, one_hot=False)
+        return pdb
+
+    def _alloc_head(self, pdb):
+        stg, h, B, S, T = pdb.stg, pdb.h, pdb.B, self.plan.S, pdb.T
+        i32 = dict(dtype=torch.int32, device=self.dev)
+        pdb.fp = torch.empty(T + 1, dtype=torch.int64, device=self.dev)
+        pdb.tok_val = torch.empty(max(T, 1), **i32) if self.vocab_dev else None
+        n = B * S
+        pdb.lens = torch.empty(max(n, 1), **i32)
+        pdb.bag = torch.empty(n + 1, **i32)
+        pdb.flags = torch.zeros(2, **i32)          # [0] overflow of the id array, [1] some bag does not hold exactly one id
+        q = pdb.q = capi.WdFeatBatch()
+        q.fp, q.tok_val = pdb.fp.data_ptr(), (pdb.tok_val.data_ptr() if pdb.tok_val is not None else None)
+        q.ex_offs, q.tok_base = stg.ptr(h["ex"]).value, stg.ptr(h["base"]).value
+        q.lmax = stg.ptr(h["lmax"]).value if self.cross_padding == "tf_dense" else None
+        q.ints, q.floats, q.bounds = stg.ptr(h["ints"]).value, stg.ptr(h["floats"]).value, self.bounds_dev.data_ptr()
+        q.batch, q.S, q.empty_index = B, S, T
+        need = int(call("wd_feat_offsets_workspace_bytes", max(n, 1)))
+        pdb.scan_ws = torch.empty(need, dtype=torch.uint8, device=self.dev)   # per-block sums of wd_feat_lens (per batch: two may be in flight)
+
+    def _make_batch(self, pdb, nnz, one_hot):
+        stg, h, B, nd = pdb.stg, pdb.h, pdb.B, len(self.plan.dense_cols)
+        dense = stg.tensor(h["dense"]).view(B, nd) if nd else None
+        labels = stg.tensor(h["lab"]) if h["lab"] is not None else None
+        weights = stg.tensor(h["wts"]) if h["wts"] is not None else None
+        pdb.batch = DeviceBatch(B, pdb.ids, pdb.bag, dense, labels, weights, nnz=nnz, one_hot=one_hot)
+        pdb.batch._keep = [pdb.fp, pdb.tok_val, pdb.lens, stg.dbuf, pdb.flags, pdb.scan_ws]
+        return pdb.batch
+
+    def _run_head(self, pdb, st):
+        """2. fingerprints of every token (+ the trailing ''), vocabulary indices; 3a. lengths -> bag CSR"""
+        plan, stg, h, raw = self.plan, pdb.stg, pdb.h, pdb.raw
+        n = pdb.B * plan.S
+        call("wd_fingerprint64", stg.ptr(h["bytes"]), stg.ptr(h["toffs"]), pdb.T + 1, ptr(pdb.fp), st)
+        for i, (vb, vo, nv) in self.vocab_dev.items():
+            pc = raw.cat[plan.slots[i].feature]
+            call("wd_feat_vocab_lookup", stg.ptr(h["bytes"]), stg.ptr(h["toffs"]), pc.base, pc.n, ptr(vb), ptr(vo), nv,
+                 ptr(pdb.tok_val), st)
+        call("wd_feat_lens", ptr(self.feat_slots_dev), ctypes.byref(pdb.q), ptr(pdb.lens), ptr(pdb.scan_ws), st)
+        call("wd_feat_offsets", ptr(pdb.lens), ptr(pdb.scan_ws), n, ptr(pdb.bag), pdb.cap, ptr(pdb.flags), st)
+
+    def _run_emit(self, pdb, st):
+        """3b. the ids, one lane per id (csrc/hash.hip k_feat_emit_par); grid sized by the batch: no id count needed here"""
+        call("wd_feat_emit", ptr(self.feat_slots_dev), ctypes.byref(pdb.q), ptr(pdb.bag), ptr(pdb.ids), pdb.cap, st)
+
+    def run(self, pdb):
+        """Every launch of the featurizer for a resident batch, on the CURRENT stream: no allocation, no host wait (capturable).
+        Returns pdb.batch (ids / bag offsets rewritten in place)."""
+        st = torch.cuda.current_stream().cuda_stream
+        self._run_head(pdb, st)
+        self._run_emit(pdb, st)
+        return pdb.batch
+
+    def finalize(self, pdb):
+        """One host read (id count, one-id-per-bag, overflow) behind a `run`: makes pdb.batch.nnz / .one_hot exact.  A captured
+        step that replays `run` on the same resident batch keeps them valid (same tokens, same ids)."""
+        stats = torch.cat([pdb.bag[-1:], pdb.flags]).cpu()
+        nnz, over, multi = int(stats[0]), int(stats[1]), int(stats[2])
+        if over or nnz > pdb.cap:
+            raise ValueError("batch (B=%d, nnz=%d) exceeds the id capacity %d" % (pdb.B, nnz, pdb.cap))
+        pdb.batch.nnz, pdb.batch.one_hot = nnz, (not multi) if pdb.B * self.plan.S else True
+        return pdb.batch
+
+    def _to_device_dev(self, raw):
+        plan, eng = self.plan, self.engine
+        B, S = raw.B, plan.S
+        if B > eng.max_batch:
+            raise ValueError("batch (B=%d) exceeds engine capacity (max_batch=%d)" % (B, eng.max_batch))
         cur = torch.cuda.current_stream()
         fs = self._fs       # NOT ordered behind `cur`: nothing here reads what the training stream writes, so the kernels below
+        pdb = ParsedDeviceBatch()
+        pdb.B, pdb.T, pdb.raw = B, len(raw.tok_offs) - 2, raw
         with torch.cuda.stream(fs):     # (and the host's wait for the id count) do not wait for the previous train step
             st = fs.cuda_stream
-            stg.upload(self.dev)
-            i32 = dict(dtype=torch.int32, device=self.dev)
-            # ---- 2. fingerprints of every token (+ the trailing ''), vocabulary indices ------------------------------------
-            fp = torch.empty(T + 1, dtype=torch.int64, device=self.dev)
-            call("wd_fingerprint64", stg.ptr(h_bytes), stg.ptr(h_toffs), T + 1, ptr(fp), st)
-            tok_val = None
-            if self.vocab_dev:
-                tok_val = torch.empty(max(T, 1), **i32)
-                for i, (vb, vo, nv) in self.vocab_dev.items():
-                    pc = raw.cat[plan.slots[i].feature]
-                    call("wd_feat_vocab_lookup", stg.ptr(h_bytes), stg.ptr(h_toffs), pc.base, pc.n, ptr(vb), ptr(vo), nv,
-                         ptr(tok_val), st)
-            # ---- 3. lengths -> bag CSR -> ids ---------------------------------------------------------------------------------
-            q = capi.WdFeatBatch()
-            q.fp, q.tok_val = fp.data_ptr(), (tok_val.data_ptr() if tok_val is not None else None)
-            q.ex_offs, q.tok_base = stg.ptr(h_ex).value, stg.ptr(h_base).value
-            q.lmax = stg.ptr(h_lmax).value if self.cross_padding == "tf_dense" else None
-            q.ints, q.floats, q.bounds = stg.ptr(h_ints).value, stg.ptr(h_floats).value, self.bounds_dev.data_ptr()
-            q.batch, q.S, q.empty_index = B, S, T
-            n = B * S
-            lens = torch.empty(max(n, 1), **i32)
-            bag = torch.empty(n + 1, **i32)
-            call("wd_feat_lens", ptr(self.feat_slots_dev), ctypes.byref(q), ptr(lens), st)
-            need = int(call("wd_feat_offsets_workspace_bytes", max(n, 1)))
-            if self._scan_ws is None or self._scan_ws.numel() < need:
-                self._scan_ws = torch.empty(need, dtype=torch.uint8, device=self.dev)
-            call("wd_feat_offsets", ptr(lens), n, ptr(bag), ptr(self._scan_ws), self._scan_ws.numel(), st)
-            stats = torch.stack([bag[-1].to(torch.int64), (lens[:n] == 1).all().to(torch.int64)]).cpu()   # the one host wait
-            nnz, one_hot = int(stats[0]), bool(stats[1]) if n else True
+            pdb.stg, pdb.h = self._stage(raw)
+            self._alloc_head(pdb)
+            pdb.cap = int(eng.max_nnz)
+            self._run_head(pdb, st)
+            # the one host wait: this entry point sizes the id array exactly and tells the engine whether the batch is
+            # one-id-per-bag (resident() / run() do neither and never wait)
+            stats = torch.cat([pdb.bag[-1:], pdb.flags[1:]]).cpu()
+            nnz, one_hot = int(stats[0]), (not int(stats[1])) if B * S else True
             if nnz > eng.max_nnz:
                 raise ValueError("batch (B=%d, nnz=%d) exceeds engine capacity (max_batch=%d, max_nnz=%d)"
                                  % (B, nnz, eng.max_batch, eng.max_nnz))
-            ids = torch.zeros(max(nnz, 1), **i32)
-            call("wd_feat_emit", ptr(self.feat_slots_dev), ctypes.byref(q), ptr(bag), ptr(ids), st)
-            dense = stg.tensor(h_dense).view(B, nd) if nd else None
-            labels = stg.tensor(h_lab) if h_lab is not None else None
-            weights = stg.tensor(h_wts) if h_wts is not None else None
+            pdb.cap = nnz
+            pdb.ids = torch.zeros(max(nnz, 1), dtype=torch.int32, device=self.dev)
+            self._run_emit(pdb, st)
         cur.wait_stream(fs)
-        for t in (ids, bag, stg.dbuf):            # allocated on the featurizer's stream, consumed on the caller's
+        for t in (pdb.ids, pdb.bag, pdb.stg.dbuf):            # allocated on the featurizer's stream, consumed on the caller's
             t.record_stream(cur)
-        bt = DeviceBatch(B, ids, bag, dense, labels, weights, nnz=nnz, one_hot=one_hot)
-        bt._keep = [fp, tok_val, lens, stg.dbuf]
-        return bt
+        return self._make_batch(pdb, nnz=nnz, one_hot=one_hot)
 
     def _vocab_lookup(self, slot, pc):
         """index in vocabulary_list per token of the feature (-1 = out of vocabulary)"""

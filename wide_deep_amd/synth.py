@@ -111,10 +111,25 @@ class FeaturizedBatch:
         self.batch, self.B, self.host = batch, batch.B, host
 
 
+class ParsedTokenBatch:
+    """A synthetic PARSED batch resident in HBM (features.Featurizer.resident on a make_parsed_batch batch: token bytes, per-feature
+    example ranges, floats, labels) -- stands where a TokenBatch stands: `hash_tokens` runs the whole device featurizer on it
+    (fingerprints -> bag lengths -> bag CSR -> hash-bucket ids AND crossed columns), in the step, with no host wait.
+    Constructed with one eager featurizer run + `finalize`, so that `.batch.nnz` / `.one_hot` are exact for the captures."""
+
+    def __init__(self, featurizer, raw, host, ids_capacity=None):
+        self.fz, self.host, self.B = featurizer, host, raw.B
+        self.pdb = featurizer.resident(raw, ids_capacity)
+        featurizer.run(self.pdb)
+        self.batch = featurizer.finalize(self.pdb)
+
+
 def hash_tokens(engine, tb):
     """tokens -> ids on the device (wd_hash_bucket): a4 of SURVEY section 8."""
     if isinstance(tb, FeaturizedBatch):
         return tb.batch
+    if isinstance(tb, ParsedTokenBatch):     # a4 + a5: hash buckets and crossed columns of a parsed batch (features.Featurizer.run)
+        return tb.fz.run(tb.pdb)
     plan = getattr(engine, "hash_plan", engine.plan)            # sharded engines hash in the global id space
     slots_dev = getattr(engine, "hash_slots_dev", engine.slots_dev)
     st = torch.cuda.current_stream().cuda_stream

@@ -472,7 +472,11 @@ def parity_check_sharded(eng, spec, tb, hb, step_eager, rank):
     torch.cuda.synchronize()
     ids, offs = bt.ids.cpu().numpy()[: bt.nnz].copy(), bt.bag_offs.cpu().numpy()
     ids_ok = None
-    if rank == 0:
+    if rank == 0 and "features" in hb:      # parsed batch: the device featurizer's ids (hash slots + crossed columns)
+        from oracle.harness import parsed_batch_ids
+        want, woffs = parsed_batch_ids(plan, hb)
+        ids_ok = bool(np.array_equal(offs[: len(woffs)], woffs) and np.array_equal(ids.astype(np.int64), want))
+    elif rank == 0:
         data, toffs = synth.pack_decimal_tokens(hb["raw"])
         nb = np.asarray([s.num_buckets for s in plan.slots], dtype=np.uint64)
         slot_of = np.repeat(np.tile(np.arange(plan.S), hb["B"]), hb["lens"].reshape(-1))
@@ -679,14 +683,23 @@ def main():
 
     spec, mean_len = make_spec(args.config)
     featurized = any(s.kind == "cross" for s in spec.slots)
-    if featurized and sharded:
-        raise SystemExit("bench.py --config c4 (crossed columns) runs on one GPU; --config c4-nocross takes --gpus N")
     tower_dtype = args.tower_dtype or ("fp16" if args.config == "c5" else "fp32")
     B = args.batch
     if args.scaling == "strong":
         if args.batch % world:
             raise SystemExit("--scaling strong: --batch %d (global) must be a multiple of the %d ranks" % (args.batch, world))
         B = args.batch // world
+    parsed = None
+    if featurized:
+        # crossed columns (BASELINE configs[3]): the batches are PARSED batches resident in HBM (token bytes + per-feature example
+        # ranges, what dataset.input_fn hands over) and every step runs the product's device featurizer on its batch
+        # (features.Featurizer.run: fingerprints, bag lengths, bag CSR, hash buckets, SparseCross -- no host wait) like C2's steps
+        # run wd_hash_bucket; --ids-input featurizes before the timed region instead (the line of round 5)
+        from wide_deep_amd.plan import FeaturePlan
+        gp = FeaturePlan(spec)
+        parsed = [synth.make_parsed_batch(gp, B, seed=20260925 + 1000 * rank + i, mean_len=mean_len, dist=args.dist,
+                                          weights=(spec.pos_weight, spec.neg_weight) if spec.use_weight_column else None)
+                  for i in range(args.pool)]
     if sharded:
         from wide_deep_amd.dist import ShardedWideDeepEngine
         # distinct (slot, id) pairs of this rank's first batch: what the exchange segments are sized from when the engine sends
@@ -698,7 +711,8 @@ def main():
             r0 = synth.make_raw_batch(gp, B, seed=20260925 + 1000 * rank, mean_len=1, dist=args.dist)["raw"].reshape(B, -1)
             uniq = sum(len(np.unique(r0[:, j])) for j in range(r0.shape[1]))
         dedup_expected = uniq is not None and (uniq < 0.8 * B * 26 or os.environ.get("WD_SHARD_DEDUP") == "1")
-        eng = ShardedWideDeepEngine(spec, max_batch=B, max_nnz=B * 26 * (2 * mean_len + 2), seed=0,
+        eng = ShardedWideDeepEngine(spec, max_batch=B, seed=0,
+                                    max_nnz=(int(1.02 * max(hb["nnz"] for _, hb in parsed)) + 1024) if featurized else B * 26 * (2 * mean_len + 2),
                                     expected_nnz=B * 26 * mean_len, expected_unique=uniq,
                                     # per-peer segment capacity over the uniform expectation: Zipf(1.05) sends ~8 % of all
                                     # occurrences to the owner of the hottest row (id % world), 1.6x the mean at 8 ranks --
@@ -708,16 +722,6 @@ def main():
                                     # bytes in every all-to-all and in the owner-side kernels that walk the padding)
                                     slack=args.slack if args.slack else (1.1 if args.dist == "uniform" else 1.2 if dedup_expected else 2.5))
     elif featurized:
-        # crossed columns (BASELINE configs[3]): the batches are PARSED batches resident in HBM (token bytes + per-feature example
-        # ranges, what dataset.input_fn hands over) and every step runs the product's device featurizer on its batch
-        # (features.Featurizer.run: fingerprints, bag lengths, bag CSR, hash buckets, SparseCross -- no host wait) like C2's steps
-        # run wd_hash_bucket; --ids-input featurizes before the timed region instead (the line of round 5)
-        from wide_deep_amd.features import Featurizer
-        from wide_deep_amd.plan import FeaturePlan
-        gp = FeaturePlan(spec)
-        parsed = [synth.make_parsed_batch(gp, B, seed=20260925 + 1000 * rank + i, mean_len=mean_len, dist=args.dist,
-                                          weights=(spec.pos_weight, spec.neg_weight) if spec.use_weight_column else None)
-                  for i in range(args.pool)]
         eng = WideDeepEngine(spec, max_batch=B, max_nnz=int(1.02 * max(hb["nnz"] for _, hb in parsed)) + 1024, seed=0,
                              tower_dtype=tower_dtype)
     else:
@@ -727,6 +731,7 @@ def main():
     # resident batch pool (raw tokens in HBM); distinct seeds per rank
     host_batches, dev_batches = [], []
     if featurized:
+        from wide_deep_amd.features import Featurizer
         fz = Featurizer(eng, cross_padding="ragged")
         for i, (raw, hb) in enumerate(parsed):
             if i < 4:

@@ -312,6 +312,9 @@ class ShardedCompactOracle(CompactOracle):
 
     def _owned(self, si):
         g = torch.as_tensor(self.uniq[si], dtype=torch.int64, device=self.eng.device)
+        if si in getattr(self.eng, "rep_idx", ()):      # a replicated column (whole on every rank): dst's own copy
+            mine = torch.full_like(g, self.rank == self.dst, dtype=torch.bool)
+            return g, mine, g[mine]
         mine = (g % self.world) == self.rank
         return g, mine, (g // self.world)[mine]
 

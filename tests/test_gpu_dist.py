@@ -39,6 +39,16 @@ def _spec(kind):
         s.slots[5].deep, s.slots[5].dim = None, 0
         s.slots[1].dim = 16
         return s, 2
+    if kind == "crosses":       # configs[3]'s shape: multi-hot slots + small crossed columns (replicated on the ranks) + ResDnn in the one launch
+        from wide_deep_amd.plan import CatSlot, CrossKey
+        s = criteo_spec(n_dense=24, n_sparse=4, buckets=101, dim=16, hidden=(32, 32), mode="resnet", crosses=((0, 1), (1, 2, 3)),
+                        cross_buckets=37)
+        for sl in s.slots:
+            if sl.kind == "cross":
+                sl.dim = 4
+        s.slots.append(CatSlot(name="C00_X_C03", kind="cross", num_buckets=11, deep=None, dim=0, wide=True,
+                               cross_keys=[CrossKey("C00", "string"), CrossKey("C03", "string")]))
+        return s, 3
     if kind == "multihot":
         return criteo_spec(n_dense=2, n_sparse=4, buckets=101, dim=16, hidden=(16, 8), mode="resnet"), 3
     if kind == "wideonly":
@@ -87,6 +97,9 @@ def _worker(rank, world, port, kind, q):
             assert sh.mixed_dims and sh.dim == 32 and sh.emb.numel() >= sh.n_emb_rows * 32
         if kind.startswith("indicator"):
             assert sh.ind_xslots_dev is not None and sh.plan.deep_dim == ref.plan.deep_dim
+        if kind.startswith("crosses"):
+            assert len(sh.rep_idx) == 3 and sh.chain and sh.towers[0].get("windows") is not None and ref.small_idx == sh.rep_idx
+            assert [int(sh.plan.slots[i].num_buckets) for i in sh.rep_idx] == [37, 37, 11]
         replay = None
         for st in range(steps):
             hbs = bs[st]
@@ -181,7 +194,7 @@ def test_exchange_overflow_is_reported():
     _run(_overflow_worker, "onehot")
 
 
-@pytest.mark.parametrize("kind", ["onehot", "multihot", "wideonly", "deeponly", "chain", "chain_graph", "mixed", "indicator",
+@pytest.mark.parametrize("kind", ["onehot", "multihot", "crosses", "crosses4", "wideonly", "deeponly", "chain", "chain_graph", "mixed", "indicator",
                                   "onehot4", "chain4", "mixed4", "indicator4", "chain_dedup", "chain_graph_dedup", "chain_dedup4"])
 def test_sharded_world2_equals_single_engine(kind):
     """world 2, and (kinds ending in 4) world 4: four owners per table, three peers per all-to-all"""
@@ -206,11 +219,14 @@ def _copy_shard(ref, sh):
     W, r = sh.world, sh.rank
     lp, gp = sh.plan, ref.plan
     for i, s in enumerate(gp.slots):
-        n = len(range(r, int(s.num_buckets), W))
-        for name in ("emb", "emb_acc"):
-            sh._emb_view(getattr(sh, name), i)[:n].copy_(ref._emb_view(getattr(ref, name), i)[r::W])
+        whole = i in getattr(sh, "rep_idx", ())        # a replicated column: every rank holds all of it
+        n = int(s.num_buckets) if whole else len(range(r, int(s.num_buckets), W))
+        pick = (lambda t: t) if whole else (lambda t: t[r::W])
+        if gp.emb_off[i] >= 0:
+            for name in ("emb", "emb_acc"):
+                sh._emb_view(getattr(sh, name), i)[:n].copy_(pick(ref._emb_view(getattr(ref, name), i)))
         g0, l0 = gp.row_base[i], lp.row_base[i]
-        sh.wide[l0: l0 + n].copy_(ref.wide[g0: g0 + int(s.num_buckets)][r::W])
+        sh.wide[l0: l0 + n].copy_(pick(ref.wide[g0: g0 + int(s.num_buckets)]))
     for name in ("P", "Pacc", "bias"):
         getattr(sh, name).copy_(getattr(ref, name))
     from wide_deep_amd import capi
@@ -288,6 +304,109 @@ def _fullsize_worker(rank, world, port, kind, q):
         q.put((rank, "FAIL: %s\n%s" % (e, traceback.format_exc())))
     finally:
         dist.destroy_process_group()
+
+
+def _c4_crosses_worker(rank, world, port, kind, q):
+    """BASELINE configs[3] as stated through the sharded engine: 26 multi-hot slots (mean 5) x 1M buckets, two 200-bucket crossed
+    columns over 2 and 3 of them (REPLICATED on the ranks: forward from the local copy, gradient sums all-reduced), ResDnn in the
+    one launch (window tower), weight column; tokens through each engine's own device featurizer."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import sys
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        import bench
+        from wide_deep_amd import synth
+        from wide_deep_amd.dist import ShardedWideDeepEngine
+        from wide_deep_amd.engine import DeviceBatch, WideDeepEngine
+        from wide_deep_amd.features import Featurizer
+        from wide_deep_amd.plan import FeaturePlan
+        from tests.helpers import CompactOracle, assert_close
+        spec, mean_len = bench.make_spec("c4")
+        B_loc, steps = 4096, 2
+        gp = FeaturePlan(spec)
+        w = (spec.pos_weight, spec.neg_weight)
+        parsed = [[synth.make_parsed_batch(gp, B_loc, seed=9000 + 10 * st + r, mean_len=mean_len, weights=w) for r in range(world)]
+                  for st in range(steps)]
+        nnz_loc = max(hb["nnz"] for row in parsed for _, hb in row)
+        ref = WideDeepEngine(spec, max_batch=B_loc * world, max_nnz=int(1.02 * world * nnz_loc) + 1024, seed=3)
+        x_nnz = B_loc * 26 * mean_len                     # occurrences of the EXCHANGED columns per rank
+        sh = ShardedWideDeepEngine(spec, max_batch=B_loc, max_nnz=int(1.02 * nnz_loc) + 1024, seed=3, expected_nnz=x_nnz, slack=1.3)
+        crosses = [i for i, s in enumerate(sh.plan.slots) if s.kind == "cross"]
+        assert sh.rep_idx == crosses and len(crosses) == 2 and ref.small_idx == crosses
+        assert sh.chain and ref.chain and sh.towers[0].get("windows") is not None, "the sharded engine did not take the window tower"
+        assert [int(sh.plan.slots[i].num_buckets) for i in crosses] == [200, 200] and int(sh.plan.slots[0].num_buckets) == 500_000
+        assert sh.cap * world < 1.5 * x_nnz, "exchange segments sized for the crossed columns' occurrences too"
+        fz_ref, fz_sh = Featurizer(ref, cross_padding="ragged"), Featurizer(sh, cross_padding="ragged")
+        S = ref.plan.S
+        for st in range(steps):
+            _copy_shard(ref, sh)
+            parts = [fz_ref.to_device(raw) for raw, _ in parsed[st]]
+            offs, base = [parts[0].bag_offs], parts[0].nnz
+            for p in parts[1:]:
+                offs.append(p.bag_offs[1:] + base)
+                base += p.nnz
+            gbt = DeviceBatch(B_loc * world, torch.cat([p.ids[: p.nnz] for p in parts]), torch.cat(offs),
+                              torch.cat([p.dense for p in parts]), torch.cat([p.labels for p in parts]),
+                              torch.cat([p.weights for p in parts]), nnz=base, one_hot=False)
+            lbt = fz_sh.to_device(parsed[st][rank][0])
+            assert torch.equal(lbt.ids[: lbt.nnz], parts[rank].ids[: lbt.nnz]) and not lbt.one_hot
+            co = None
+            if st == 0 and rank == 0:      # the oracle on the rows the GLOBAL batch touches, from the same state
+                co = CompactOracle(ref, [(gbt.ids.cpu().numpy()[: gbt.nnz].copy(), gbt.bag_offs.cpu().numpy(), gbt.B)])
+            ref.train_step(gbt)
+            sh.train_step(lbt)
+            torch.cuda.synchronize()
+            sh.check_overflow()
+            lg, want = sh.logit[:B_loc], ref.logit[rank * B_loc:(rank + 1) * B_loc]
+            bad = ((lg - want).abs() > 2e-4 + 2e-4 * want.abs()).sum().item()
+            assert bad == 0, "step %d: %d logits out of 2e-4 + 2e-4 |logit| (max |d| %.3g)" % (st, bad, float((lg - want).abs().max()))
+            if co is not None:
+                ids, boffs = gbt.ids.cpu().numpy()[: gbt.nnz], gbt.bag_offs.cpu().numpy()
+                hb = {k: np.concatenate([h[k] for _, h in parsed[st]]) for k in ("dense", "labels", "weights")}
+                _, ologits = co.ora.train_step(co.batch(ids, boffs, gbt.B, hb["dense"], hb["labels"], hb["weights"]))
+                d = (sh.logit[:B_loc].cpu() - ologits[:B_loc]).abs()
+                assert float((d - 2e-4 * ologits[:B_loc].abs()).max()) <= 2e-4, "sharded logits vs the oracle: max |d| %.3g" % float(d.max())
+            # replicated crossed columns: whole and identical to the single engine's on every rank
+            for i in crosses:
+                for name in ("emb", "emb_acc"):
+                    assert_close(sh._emb_view(getattr(sh, name), i), ref._emb_view(getattr(ref, name), i), 5e-4, 1e-5,
+                                 "%s of crossed column %d step %d" % (name, i, st))
+                l0, g0 = sh.plan.row_base[i], ref.plan.row_base[i]
+                assert_close(sh.wide[l0: l0 + 200], ref.wide[g0: g0 + 200], 5e-4, 1e-5, "wide rows of crossed column %d" % i)
+            # exchanged columns: the rows this rank OWNS among the ones the global batch touched
+            bag_of = torch.repeat_interleave(torch.arange(gbt.B * S, device="cuda"), (gbt.bag_offs[1:] - gbt.bag_offs[:-1]).long())
+            for i in (0, 7, 25):
+                mine = torch.unique(gbt.ids[: gbt.nnz][bag_of % S == i].long())
+                mine = mine[mine % world == rank]
+                loc = mine // world
+                for name in ("emb", "emb_acc"):
+                    assert_close(sh._emb_view(getattr(sh, name), i)[loc], ref._emb_view(getattr(ref, name), i)[mine],
+                                 5e-4, 1e-5, "%s slot %d step %d" % (name, i, st))
+                assert_close(sh.wide[sh.plan.row_base[i] + loc], ref.wide[ref.plan.row_base[i] + mine], 5e-4, 1e-5,
+                             "wide slot %d step %d" % (i, st))
+            d = (sh.P - ref.P).abs()
+            out = d > 1e-5 + 5e-4 * ref.P.abs()
+            assert out.float().mean().item() <= 0.005 and not bool((d > 5e-3 + 5e-2 * ref.P.abs()).any()), \
+                "dense parameters step %d: %d entries out of tolerance, max |d| %.3g" % (st, int(out.sum()), float(d.max()))
+            assert_close(sh.bias[:3], ref.bias[:3], 5e-4, 1e-5, "bias_weights step %d" % st)
+        q.put((rank, "ok"))
+    except Exception as e:  # pragma: no cover
+        import traceback
+        q.put((rank, "FAIL: %s\n%s" % (e, traceback.format_exc())))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_world2_at_baseline_size_c4_crosses():
+    """BASELINE configs[3] as stated (multi-hot avg 5 + two 200-bucket crossed columns + ResDnn + weight column) through the
+    sharded engine at size: world 2 on one GPU (gloo staging), 4096 examples per rank, every step from identical state against
+    the full-size single engine on the 8192-example global batch (logits, replicated crossed tables, owned touched rows, dense
+    parameters) and, step 0, against the oracle."""
+    _run(_c4_crosses_worker, "c4_crosses")
 
 
 @pytest.mark.parametrize("kind", ["c2_uniform", "c2_zipf", "c3_uniform", "c2_zipf_dedup"])

@@ -52,9 +52,10 @@ k_route(const wd_slot_t *__restrict__ slots, int32_t S, int32_t W, const int32_t
     int32_t j0 = 0, j1 = 0;
     int64_t rbase = 0;
     if (bag < b1) {
+      const wd_slot_t &sl = slots[bag % S];
       j0 = bag_offs[bag];
-      j1 = bag_offs[bag + 1];
-      rbase = slots[bag % S].row_base;
+      j1 = (sl.flags & WD_SLOT_F_SMALL) ? j0 : bag_offs[bag + 1];     // a replicated column (small_tables.hip): nothing to request
+      rbase = sl.row_base;
     }
     for (int32_t k = 0;; ++k) {
       if (t == 0) any_left = 0;
@@ -184,7 +185,7 @@ k_grad_pack(const wd_slot_t *__restrict__ slots, int32_t S, const int32_t *__res
   const int64_t b = bag / S;
   const wd_slot_t sl = slots[bag - b * S];
   const int32_t j0 = bag_offs[bag], j1 = bag_offs[bag + 1];
-  if (j1 <= j0) return;
+  if (j1 <= j0 || (sl.flags & WD_SLOT_F_SMALL)) return;      // (a replicated column's gradient is all-reduced, not exchanged)
   const bool is_emb = dx && sl.kind == WD_SLOT_EMBEDDING;
   const int dq = is_emb ? (sl.dim >> 2) : 0;
   const float scale = (j1 - j0) > 1 ? 1.0f / (float)(j1 - j0) : 1.0f;

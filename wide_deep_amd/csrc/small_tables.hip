@@ -256,6 +256,57 @@ __global__ void __launch_bounds__(256) k_small_apply(SmallArgs a) {
   }
 }
 
+// ---- the same update in two halves, for tables that are REPLICATED on every rank of a row-sharded model (dist.py: a 200-row
+// crossed column is not worth an all-to-all): k_small_reduce leaves this rank's gradient sums + hit counts per row
+// ([nsmall][part_rows][part_w], partials added in slice order), the ranks all-reduce that buffer, k_small_apply_sum applies it.
+__global__ void __launch_bounds__(256) k_small_reduce(SmallArgs a, float *__restrict__ gsum) {
+  const int k = blockIdx.y;
+  const int s = uni(a.small_idx[k]);
+  const wd_slot_t sl = a.slots[s];
+  const int R = sl.num_buckets, D = sl.dim, PW = D + 2;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= a.part_rows * a.part_w) return;
+  const int r = i / a.part_w, d = i - r * a.part_w;
+  float g = 0.f;
+  if (r < R && d < PW) {
+    const float *p = a.part + (int64_t)k * a.nslice * a.part_rows * a.part_w + (int64_t)r * a.part_w + d;
+    const int64_t st = (int64_t)a.part_rows * a.part_w;
+    constexpr int RND = 32;
+    for (int c0 = 0; c0 < a.nslice; c0 += RND) {
+      float v[RND];
+#pragma unroll
+      for (int u = 0; u < RND; ++u) v[u] = c0 + u < a.nslice ? p[(c0 + u) * st] : 0.f;
+#pragma unroll
+      for (int u = 0; u < RND; ++u) g += v[u];
+    }
+  }
+  gsum[(int64_t)k * a.part_rows * a.part_w + i] = g;       // (rows / columns a narrower table does not have: zeros)
+}
+
+__global__ void __launch_bounds__(256) k_small_apply_sum(SmallArgs a, const float *__restrict__ gsum) {
+  const int k = blockIdx.y;
+  const int s = uni(a.small_idx[k]);
+  const wd_slot_t sl = a.slots[s];
+  const int R = sl.num_buckets, D = sl.dim;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= R * (D + 1)) return;
+  const int r = i / (D + 1), d = i - r * (D + 1);
+  const float *p = gsum + (int64_t)k * a.part_rows * a.part_w + (int64_t)r * a.part_w;
+  const float g = p[d], hits = p[D + 1];
+  if (hits == 0.f) return;                          // no rank's batch holds this row: it does not move
+  if (d < D) {
+    if (!a.emb_w || sl.out_col < 0) return;
+    const int64_t o = sl.emb_off + (int64_t)r * D + d;
+    const float acc = a.emb_acc[o] + g * g;
+    a.emb_acc[o] = acc;
+    a.emb_w[o] -= a.lr_emb * g / sqrtf(acc);
+  } else if (sl.wide && a.wide_w) {
+    float4 q = *reinterpret_cast<float4 *>(a.wide_w + (sl.row_base + r) * 4);
+    ftrl1(q.x, q.y, q.z, g, a.lr_w, a.l1, a.l2);
+    *reinterpret_cast<float4 *>(a.wide_w + (sl.row_base + r) * 4) = q;
+  }
+}
+
 }  // namespace
 
 extern "C" int64_t wd_small_tables_ws_floats(int32_t nsmall, int32_t max_rows, int32_t max_dim, int64_t max_batch) {
@@ -289,18 +340,16 @@ extern "C" int wd_small_tables_fwd(const float *emb, const float *wide, const wd
   return wd::check_launch("wd_small_tables_fwd");
 }
 
-extern "C" int wd_small_tables_bwd(float *emb, float *emb_accum, float *wide_wzn, const wd_slot_t *slots, int32_t S,
-                                   const int32_t *small_idx, int32_t nsmall, int32_t max_rows, int32_t max_dim,
-                                   const int32_t *ids, const int32_t *bag_offs, int64_t batch, const float *dx, int64_t ldx,
-                                   const float *dlogit, float lr_emb, float lr_wide, float l1, float l2, float *ws,
-                                   int64_t ws_floats, wd_stream_t stream) {
-  if (batch <= 0 || nsmall <= 0) return WD_OK;
+static int small_bwd_args(SmallArgs &a, size_t &lds, float *emb, float *emb_accum, float *wide_wzn, const wd_slot_t *slots, int32_t S,
+                          const int32_t *small_idx, int32_t nsmall, int32_t max_rows, int32_t max_dim, const int32_t *ids,
+                          const int32_t *bag_offs, int64_t batch, const float *dx, int64_t ldx, const float *dlogit, float lr_emb,
+                          float lr_wide, float l1, float l2, float *ws, int64_t ws_floats) {
   const int rc = small_check(slots, small_idx, nsmall, max_rows, max_dim);
   if (rc != WD_OK) return rc;
   WD_REQUIRE(ids && bag_offs && ws, "null pointer");
   WD_REQUIRE(!emb || (emb_accum && dx), "embedding update needs accum and dx");
   WD_REQUIRE(!wide_wzn || dlogit, "wide update needs dlogit");
-  SmallArgs a{};
+  a = SmallArgs{};
   a.slots = slots; a.small_idx = small_idx; a.nsmall = nsmall; a.S = S; a.ids = ids; a.bag_offs = bag_offs; a.batch = batch;
   a.dx = emb ? dx : nullptr; a.ldx = ldx; a.dlogit = wide_wzn ? dlogit : nullptr;
   a.bags_per_slice = WD_SMALL_BAGS_PER_SLICE;
@@ -309,8 +358,8 @@ extern "C" int wd_small_tables_bwd(float *emb, float *emb_accum, float *wide_wzn
   WD_REQUIRE((int64_t)nsmall * a.nslice * max_rows * (max_dim + 2) <= ws_floats, "workspace too small (wd_small_tables_ws_floats)");
   a.emb_w = emb; a.emb_acc = emb_accum; a.wide_w = wide_wzn;
   a.lr_emb = lr_emb; a.lr_w = lr_wide; a.l1 = l1; a.l2 = l2;
-  const size_t lds = (size_t)max_rows * (max_dim + 2) * 4 + (size_t)2 * max_rows * 4 + (size_t)2 * SM_SLICE * 4 +
-                     (size_t)SM_SLICE * (SM_MAX_DIM + 1) * 4;
+  lds = (size_t)max_rows * (max_dim + 2) * 4 + (size_t)2 * max_rows * 4 + (size_t)2 * SM_SLICE * 4 +
+        (size_t)SM_SLICE * (SM_MAX_DIM + 1) * 4;
   // a wide-only table of ~4 k rows asks for 32 KB of partials + 32 KB of histograms + staging: beyond the 64 KB a launch gets
   // without the attribute (WD_SMALL_MAX_FLOATS bounds it at 32 KB + 64 KB + 4.9 KB)
   static size_t lds_allowed = 64 * 1024;
@@ -320,9 +369,63 @@ extern "C" int wd_small_tables_bwd(float *emb, float *emb_accum, float *wide_wzn
     WD_REQUIRE(e == hipSuccess, "hipFuncSetAttribute(k_small_bwd, dynamic LDS) failed");
     lds_allowed = lds;
   }
+  return WD_OK;
+}
+
+extern "C" int wd_small_tables_bwd(float *emb, float *emb_accum, float *wide_wzn, const wd_slot_t *slots, int32_t S,
+                                   const int32_t *small_idx, int32_t nsmall, int32_t max_rows, int32_t max_dim,
+                                   const int32_t *ids, const int32_t *bag_offs, int64_t batch, const float *dx, int64_t ldx,
+                                   const float *dlogit, float lr_emb, float lr_wide, float l1, float l2, float *ws,
+                                   int64_t ws_floats, wd_stream_t stream) {
+  if (batch <= 0 || nsmall <= 0) return WD_OK;
+  SmallArgs a;
+  size_t lds;
+  const int rc = small_bwd_args(a, lds, emb, emb_accum, wide_wzn, slots, S, small_idx, nsmall, max_rows, max_dim, ids, bag_offs, batch,
+                                dx, ldx, dlogit, lr_emb, lr_wide, l1, l2, ws, ws_floats);
+  if (rc != WD_OK) return rc;
   hipStream_t st = wd::as_stream(stream);
   hipLaunchKernelGGL(k_small_bwd, dim3((unsigned)a.nslice, (unsigned)nsmall), dim3(256), lds, st, a);
   hipLaunchKernelGGL(k_small_apply, dim3((unsigned)wd::ceil_div((int64_t)max_rows * (max_dim + 1), (int64_t)256), (unsigned)nsmall),
                      dim3(256), 0, st, a);
   return wd::check_launch("wd_small_tables_bwd");
+}
+
+extern "C" int wd_small_tables_grad(const wd_slot_t *slots, int32_t S, const int32_t *small_idx, int32_t nsmall, int32_t max_rows,
+                                    int32_t max_dim, const int32_t *ids, const int32_t *bag_offs, int64_t batch, const float *dx,
+                                    int64_t ldx, const float *dlogit, float *ws, int64_t ws_floats, float *gsum, wd_stream_t stream) {
+  WD_REQUIRE(gsum && nsmall > 0 && batch >= 0, "null pointer / no slots");
+  SmallArgs a;
+  size_t lds;
+  float dummy = 0.f;       // (the two halves carry no tables: non-null markers make the kernel read dx / dlogit)
+  const int rc = small_bwd_args(a, lds, dx ? &dummy : nullptr, dx ? &dummy : nullptr, dlogit ? &dummy : nullptr, slots, S, small_idx,
+                                nsmall, max_rows, max_dim, ids, bag_offs, batch > 0 ? batch : 1, dx, ldx, dlogit, 0.f, 0.f, 0.f, 0.f,
+                                ws, ws_floats);
+  if (rc != WD_OK) return rc;
+  a.emb_w = a.emb_acc = a.wide_w = nullptr;
+  hipStream_t st = wd::as_stream(stream);
+  if (batch <= 0) {        // a rank without examples still takes part in the all-reduce: zeros
+    hipMemsetAsync(gsum, 0, sizeof(float) * (size_t)nsmall * max_rows * (max_dim + 2), st);
+    return wd::check_launch("wd_small_tables_grad");
+  }
+  hipLaunchKernelGGL(k_small_bwd, dim3((unsigned)a.nslice, (unsigned)nsmall), dim3(256), lds, st, a);
+  hipLaunchKernelGGL(k_small_reduce, dim3((unsigned)wd::ceil_div((int64_t)max_rows * (max_dim + 2), (int64_t)256), (unsigned)nsmall),
+                     dim3(256), 0, st, a, gsum);
+  return wd::check_launch("wd_small_tables_grad");
+}
+
+extern "C" int wd_small_tables_apply(float *emb, float *emb_accum, float *wide_wzn, const wd_slot_t *slots, int32_t S,
+                                     const int32_t *small_idx, int32_t nsmall, int32_t max_rows, int32_t max_dim, const float *gsum,
+                                     float lr_emb, float lr_wide, float l1, float l2, wd_stream_t stream) {
+  if (nsmall <= 0) return WD_OK;
+  const int rc = small_check(slots, small_idx, nsmall, max_rows, max_dim);
+  if (rc != WD_OK) return rc;
+  WD_REQUIRE(gsum && (!emb || emb_accum), "null pointer");
+  SmallArgs a{};
+  a.slots = slots; a.small_idx = small_idx; a.nsmall = nsmall; a.S = S;
+  a.part_rows = max_rows; a.part_w = max_dim + 2;
+  a.emb_w = emb; a.emb_acc = emb_accum; a.wide_w = wide_wzn;
+  a.lr_emb = lr_emb; a.lr_w = lr_wide; a.l1 = l1; a.l2 = l2;
+  hipLaunchKernelGGL(k_small_apply_sum, dim3((unsigned)wd::ceil_div((int64_t)max_rows * (max_dim + 1), (int64_t)256), (unsigned)nsmall),
+                     dim3(256), 0, wd::as_stream(stream), a, gsum);
+  return wd::check_launch("wd_small_tables_apply");
 }

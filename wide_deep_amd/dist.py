@@ -28,7 +28,7 @@ import torch.distributed as dist
 from . import capi, hipgraph
 from .capi import call, ptr
 from .engine import DeviceBatch, WideDeepEngine, _stream
-from .plan import CatSlot, FeaturePlan, ModelSpec, bucket_geometry
+from .plan import CatSlot, FeaturePlan, ModelSpec, bucket_geometry, ftrl_l2_shrinkage, ftrl_lr_power, small_table_slots
 
 
 # ---------------------------------------------------------------------------------------------
@@ -143,12 +143,41 @@ def shard_rows(v, world):
     return (int(v) + world - 1) // world
 
 
-def local_spec(spec: ModelSpec, world):
-    """Same model, every categorical column holding only this rank's rows (ceil(V / world))."""
+def replicated_slots(plan, spec, world):
+    """Plan indices of the columns a row-sharded model keeps WHOLE on every rank instead of exchanging their rows: the small
+    tables of csrc/small_tables.hip (crossed columns of a few hundred buckets -- python/lib/build_estimator.py:138-155 -- whose
+    bags hold the product of their keys' counts: configs[3]'s two crosses are 1.2 M of a batch's 2.3 M occurrences for 2 x 200
+    rows).  Forward from the local copy, gradient sums all-reduced, the same update on every rank.  Taken when the embedded ones
+    come behind every exchanged embedded column in the plan's order (the owner's "embedding row = local fused row" needs the
+    exchanged tables first) and the exchanged columns share one embedding width; otherwise every column is exchanged."""
+    import os
+    idx = small_table_slots(plan.slots, spec.has_deep, spec.has_wide, capi.SMALL_MAX_FLOATS, os.environ.get("WD_SMALL_TABLES", "cross"))
+    if not idx or not spec_default_opts(spec):
+        return []
+    emb = [i for i, s in enumerate(plan.slots) if s.deep == "embedding" and spec.has_deep]
+    xemb = [i for i in emb if i not in idx]
+    if xemb and any(i < max(xemb) for i in idx if i in emb):
+        return []
+    if len({int(plan.slots[i].dim) for i in xemb}) > 1:
+        return []
+    return idx
+
+
+def spec_default_opts(spec):
+    """the reference's default optimizer pair (conf/model.yaml): Adagrad on the dnn scope, Ftrl (lr_power -0.5) on the linear one"""
+    return ((not spec.has_deep or spec.dnn_opt[0] == "Adagrad") and
+            (not spec.has_wide or (spec.lin_opt[0] == "Ftrl" and ftrl_lr_power(spec.lin_opt) == -0.5
+                                   and ftrl_l2_shrinkage(spec.lin_opt) == 0.0)))
+
+
+def local_spec(spec: ModelSpec, world, keep=()):
+    """Same model, every categorical column holding only this rank's rows (ceil(V / world)); `keep`: names of the columns that
+    stay whole (replicated_slots)."""
     slots = []
     for s in spec.slots:
         d = CatSlot(**{k: getattr(s, k) for k in s.__dataclass_fields__})
-        d.num_buckets = shard_rows(s.num_buckets, world)
+        if s.name not in keep:
+            d.num_buckets = shard_rows(s.num_buckets, world)
         if s.deep == "indicator":
             d.deep_width = int(s.num_buckets)     # the multi-hot vector of the deep input keeps all V columns
         slots.append(d)
@@ -190,7 +219,11 @@ class ShardedWideDeepEngine(WideDeepEngine):
         self.global_spec = spec
         self.global_plan = FeaturePlan(spec)
         gp = self.global_plan
-        dims = {int(s.dim) for s in gp.slots if s.deep == "embedding"} if spec.has_deep else set()
+        # replicated columns (small tables): whole on every rank, never exchanged
+        self.rep_idx = replicated_slots(gp, spec, self.world)
+        rep_names = {gp.slots[i].name for i in self.rep_idx}
+        dims = ({int(s.dim) for i, s in enumerate(gp.slots) if s.deep == "embedding" and i not in self.rep_idx}
+                if spec.has_deep else set())
         if any(d not in (4, 8, 16, 32, 64, 128) for d in dims):
             raise NotImplementedError("sharded engine: embedding dims must be 4, 8, ..., 128 (got %s)" % sorted(dims))
         # Mixed embedding dims (the reference's default rule, build_estimator.py:57-59, gives every hashed column its own):
@@ -217,7 +250,7 @@ class ShardedWideDeepEngine(WideDeepEngine):
         # to the batch (one id per bag) makes _route raise instead of falling back.
         dset = sorted(dims)
         static_ok = (spec.has_deep and spec.has_wide and len(dset) == 1 and dset[0] in (4, 8, 16) and 0 < S <= 128
-                     and all(s.deep == "embedding" and s.wide for s in gp.slots)
+                     and not self.rep_idx and all(s.deep == "embedding" and s.wide for s in gp.slots)
                      and os.environ.get("WD_ROW_RECORDS", "1") != "0"
                      and W * sum(shard_rows(int(s.num_buckets), W) for s in gp.slots) < (1 << 32))
         self.dedup = bool(dedup) and static_ok
@@ -235,8 +268,9 @@ class ShardedWideDeepEngine(WideDeepEngine):
         # owner side: the received list has n_req entries (padding included) -> capacity of the update workspaces
         # the owner keeps its LOCAL rows as records [emb | w z n - | pad] when the model is record-shaped (engine.py): a request
         # is answered from one 128-byte line, the update touches two lines per row (WD_ROW_RECORDS=0: separate tables)
-        self._records_ok = not self.mixed_dims
-        super().__init__(local_spec(spec, W), max_batch=max_batch, max_nnz=max(mn, self.n_req), device=device,
+        self._records_ok = not self.mixed_dims and not self.rep_idx       # (the small-table kernels take separate tables)
+        self._small_forced = list(self.rep_idx)
+        super().__init__(local_spec(spec, W, keep=rep_names), max_batch=max_batch, max_nnz=max(mn, self.n_req), device=device,
                          seed=seed, expected_nnz=self.n_req, table_seed=int(seed) * 1000003 + 7919 * (self.rank + 1))
         if not self.default_opts:
             raise NotImplementedError("sharded engine: Adagrad (dnn) + Ftrl (linear) only; the other optimizers of "
@@ -250,9 +284,12 @@ class ShardedWideDeepEngine(WideDeepEngine):
         self.dim = max(dims) if dims else 0       # width of the embedding part of an exchanged record
         dev = self.device
         lp = self.plan
-        self.n_emb_slots = lp.n_emb if spec.has_deep else 0
-        # embedding slots come first in the fused row space: embedding row == fused local row (rows padded to self.dim)
+        assert [s.name for s in lp.slots] == [s.name for s in gp.slots]      # bags are indexed by the GLOBAL plan's slot order
+        # EXCHANGED embedding slots come first in the fused row space: embedding row == fused local row (rows padded to self.dim)
+        self.n_emb_slots = (lp.n_emb - sum(1 for i in self.rep_idx if lp.slots[i].deep == "embedding")) if spec.has_deep else 0
         self.n_emb_rows = sum(int(s.num_buckets) for s in lp.slots[: self.n_emb_slots])
+        if self.rep_idx:
+            self._sync_replicas()
         if self.mixed_dims:
             self._pad_tables()
         else:
@@ -297,6 +334,9 @@ class ShardedWideDeepEngine(WideDeepEngine):
                            out_col=lp.out_col[i], kind=capi.SLOT_EMBEDDING if is_emb else capi.SLOT_NONE,
                            wide=1 if (spec.has_wide and s.wide) else 0))
         self.xslots_dev = make_slots(xs)
+        for i in self.rep_idx:           # pooling / wide sum of the received rows skip the replicated columns
+            xs[i]["flags"] = capi.SLOT_F_SMALL
+        self.xslots_small_dev = make_slots(xs) if self.rep_idx else None
         if spec.has_deep and lp.ind_slots:
             self.ind_xslots_dev = make_slots([dict(emb_off=-1, row_base=0, num_buckets=s.ind_width, dim=0,
                                                    out_col=lp.out_col[i], kind=capi.SLOT_INDICATOR, wide=0)
@@ -454,7 +494,7 @@ class ShardedWideDeepEngine(WideDeepEngine):
                  ptr(self.route_ws), ptr(self.peer_counts), ptr(self.overflow), st)
             xs["unique"] = True
             return
-        call("wd_route_build", ptr(self.slots_dev), self.plan.S, self.world, ptr(bt.ids), ptr(bt.bag_offs), bt.B, self.cap,
+        call("wd_route_build", ptr(self.slots_small_dev if self.rep_idx else self.slots_dev), self.plan.S, self.world, ptr(bt.ids), ptr(bt.bag_offs), bt.B, self.cap,
              ptr(self.send_rows), ptr(self.pos), ptr(self.route_ws), ptr(self.peer_counts), ptr(self.overflow), st)
 
     def _exchange_rows(self):
@@ -536,7 +576,8 @@ class ShardedWideDeepEngine(WideDeepEngine):
             tw0 = self.towers[0]
             ld = tw0["layout"].ld
             xp = self._x_ptr(tw0)
-            for d, gs in (self.group_slots.items() if has_emb else ()):      # one launch per embedding dim
+            groups = (self.group_slots_big if self.rep_idx else self.group_slots) if has_emb else {}
+            for d, gs in groups.items():      # one launch per embedding dim (exchanged columns)
                 call("wd_embag_fwd_strided", ptr(self.fwd_recv), self.RS, ptr(self.xslots_dev), S, ptr(gs), gs.numel(),
                      d, ptr(self.pos), ptr(bt.bag_offs), B, xp, ld, st)
             if self.ind_xslots_dev is not None:
@@ -547,8 +588,14 @@ class ShardedWideDeepEngine(WideDeepEngine):
                      len(lp.dense_cols), B, xp, ld, st)
         if spec.has_wide:
             w_ptr = self.fwd_recv.data_ptr() + 4 * (self.dim if has_emb else 0)
-            call("wd_wide_fwd", w_ptr, self.RS, ptr(self.bias), ptr(self.xslots_dev), S, ptr(self.pos), ptr(bt.bag_offs), B,
-                 ptr(self.wide_logit), st)
+            call("wd_wide_fwd", w_ptr, self.RS, ptr(self.bias), ptr(self.xslots_small_dev if self.rep_idx else self.xslots_dev), S,
+                 ptr(self.pos), ptr(bt.bag_offs), B, ptr(self.wide_logit), st)
+        if self.rep_idx:
+            # replicated columns: pooled / summed from this rank's own copy of their tables (tables in LDS, csrc/small_tables.hip)
+            call("wd_small_tables_fwd", ptr(self.emb) if spec.has_deep else None, ptr(self.wide) if spec.has_wide else None,
+                 ptr(self.slots_dev), S, ptr(self.small_idx_dev), len(self.small_idx), self.small_rows, self.small_dim,
+                 ptr(bt.ids), ptr(bt.bag_offs), B, self._x_ptr(self.towers[0]) if spec.has_deep else None,
+                 self.towers[0]["layout"].ld if spec.has_deep else 0, ptr(self.wide_logit) if spec.has_wide else None, st)
 
     def _reduce_dense_grads(self):
         self._collective(lambda: _all_reduce_sum(self.G, self.group))
@@ -569,7 +616,7 @@ class ShardedWideDeepEngine(WideDeepEngine):
             call("wd_row_grad_presum", ptr(self._rq["slots"]), lp.S, bt.B, dx_ptr, ld, ptr(self.dlogit), self.dim,
                  ptr(xs["rq_pairs"]), ptr(xs["rq_long"]), self._rq["long_cap"], ptr(self.pos), ptr(self.bwd_send), self.RS, st)
             return
-        call("wd_grad_pack", ptr(self.slots_dev), lp.S, ptr(bt.bag_offs), ptr(self.pos), bt.B, dx_ptr, ld,
+        call("wd_grad_pack", ptr(self.slots_small_dev if self.rep_idx else self.slots_dev), lp.S, ptr(bt.bag_offs), ptr(self.pos), bt.B, dx_ptr, ld,
              ptr(self.dlogit) if spec.has_wide else None, self.dim, self.RS, ptr(self.bwd_send), st)
 
     def _send_grads(self):
@@ -633,6 +680,53 @@ class ShardedWideDeepEngine(WideDeepEngine):
     def _sparse_backward(self, bt: DeviceBatch, st):
         self._grads_to_owners(bt, st)
         self._owner_update(bt, st)
+        self._replicated_update(bt, st)
+
+    def _small_on(self, bt):
+        return bool(self.rep_idx)        # replicated columns have no owner: every batch takes the small-table path for them
+
+    def _chain_windows_ok(self):
+        return True
+
+    def _sync_replicas(self):
+        """Every rank draws its tables from its own seed stream: the replicated ones take rank 0's numbers."""
+        lp = self.plan
+        for i in self.rep_idx:
+            if lp.emb_off[i] >= 0:
+                v = self._emb_view(self.emb, i)
+                t = v.contiguous()
+                if dist.get_backend(self.group) == "gloo":
+                    c = t.cpu()
+                    dist.broadcast(c, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
+                    t = c.to(v.device)
+                else:
+                    dist.broadcast(t, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
+                v.copy_(t)
+
+    def _replicated_update(self, bt: DeviceBatch, st):
+        """Replicated columns: this rank's gradient sums + hit counts per row -> all-reduce(SUM) -> the same Adagrad / Ftrl
+        update on every rank (the copies stay identical: every rank adds the same numbers to the same state)."""
+        if not self.rep_idx:
+            return
+        lp, spec = self.plan, self.spec
+        has_emb = any(lp.emb_off[i] >= 0 for i in self.rep_idx)
+        dx_ptr, ld = None, 0
+        if has_emb:
+            tw0 = self.towers[0]
+            dx_ptr, ld = tw0["dact"].data_ptr() + 4 * tw0["layout"].seg_start[0], tw0["layout"].ld
+        n = len(self.small_idx)
+        if self.small_ws is None:
+            nws = int(call("wd_small_tables_ws_floats", n, self.small_rows, self.small_dim, self.max_batch))
+            self.small_ws = torch.zeros(max(nws, 1), dtype=torch.float32, device=self.device)
+            self.small_g = torch.zeros(n * self.small_rows * (self.small_dim + 2), dtype=torch.float32, device=self.device)
+        call("wd_small_tables_grad", ptr(self.slots_dev), lp.S, ptr(self.small_idx_dev), n, self.small_rows, self.small_dim,
+             ptr(bt.ids), ptr(bt.bag_offs), bt.B, dx_ptr, ld, ptr(self.dlogit) if spec.has_wide else None,
+             ptr(self.small_ws), self.small_ws.numel(), ptr(self.small_g), st)
+        self._collective(lambda: _all_reduce_sum(self.small_g, self.group))
+        lr, l1, l2 = (spec.lin_opt[1], spec.lin_opt[2], spec.lin_opt[3]) if spec.has_wide else (0.0, 0.0, 0.0)
+        call("wd_small_tables_apply", ptr(self.emb) if has_emb else None, ptr(self.emb_acc) if has_emb else None,
+             ptr(self.wide) if spec.has_wide else None, ptr(self.slots_dev), lp.S, ptr(self.small_idx_dev), n, self.small_rows,
+             self.small_dim, ptr(self.small_g), float(spec.dnn_opt[1]) if spec.has_deep else 0.0, float(lr), float(l1), float(l2), st)
 
     def _dense_tail(self, bt, st):
         """Products -> this rank's dense gradient -> D (all-reduce) -> Adagrad + the packed kernels of the next step."""
@@ -669,6 +763,7 @@ class ShardedWideDeepEngine(WideDeepEngine):
         self._grads_to_owners(bt, st)
         self._dense_tail(bt, st)         # D (all-reduce of the flat dense gradient) in the background of the owners' update
         self._owner_update(bt, st, do_bias=False)
+        self._replicated_update(bt, st)
         self._dense_finish(bt, st)
 
     def train_step(self, bt: DeviceBatch):
@@ -752,8 +847,11 @@ class ShardedWideDeepEngine(WideDeepEngine):
         """Load a FULL (unsharded) state dict in the reference's naming, keeping rows id % world == rank."""
         W, r = self.world, self.rank
         sub = {}
+        rep = self._replicated_names()
         for k, v in state.items():
-            if ("embedding_weights" in k or k.startswith("linear/linear_model/")) and "bias_weights" not in k:
+            if any(k == n or k.startswith(n + "/") for n in rep):
+                sub[k] = v                  # a replicated column: whole on every rank
+            elif ("embedding_weights" in k or k.startswith("linear/linear_model/")) and "bias_weights" not in k:
                 sh = v[r::W]
                 need = shard_rows(v.shape[0], W)
                 if sh.shape[0] < need:   # ranks whose last local row does not exist globally: pad (never addressed)
@@ -766,6 +864,14 @@ class ShardedWideDeepEngine(WideDeepEngine):
                 sub[k] = v
         self.import_state(sub)
 
+    def _replicated_names(self):
+        gp = self.global_plan
+        out = []
+        for i in self.rep_idx:
+            s = gp.slots[i]
+            out += ["dnn/input_from_feature_columns/input_layer/%s/embedding_weights" % s.deep_name, "linear/linear_model/%s/weights" % s.name]
+        return out
+
     def export_full_state(self):
         """Gather every rank's shard; returns the FULL state dict on every rank."""
         W = self.world
@@ -773,7 +879,9 @@ class ShardedWideDeepEngine(WideDeepEngine):
         out = {}
         gp = self.global_plan
         full_rows = {}
-        for s in gp.slots:
+        for i, s in enumerate(gp.slots):
+            if i in self.rep_idx:
+                continue                    # whole on every rank: the local copy is the variable
             full_rows["dnn/input_from_feature_columns/input_layer/%s/embedding_weights" % s.deep_name] = s.num_buckets
             full_rows["linear/linear_model/%s/weights" % s.name] = s.num_buckets
         for k in sorted(local):

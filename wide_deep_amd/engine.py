@@ -19,7 +19,7 @@ import torch
 from . import capi, hipgraph
 from .capi import call, ptr
 from .plan import (BN_EPS, FeaturePlan, ModelSpec, OPT_SLOT_ODD, adam_pow_names, bucket_geometry, ftrl_l2_shrinkage, ftrl_lr_power, opt_params,
-                   opt_slot_init, opt_slot_names, rmsprop_centered)
+                   opt_slot_init, opt_slot_names, rmsprop_centered, small_table_slots)
 
 
 class DeviceBatch:
@@ -131,20 +131,13 @@ class WideDeepEngine:
         # LDS.  Multi-hot batches take them out of the general path (wd_wide_fwd / the embedding-bag groups / the bucketed
         # update skip a slot whose descriptor carries WD_SLOT_F_SMALL) and through wd_small_tables_fwd / _bwd.  Separate tables,
         # the reference's default optimizers, one GPU.  WD_SMALL_TABLES=0: off; =all: every column that fits, crossed or not.
-        self.small_idx = []
+        # (row-sharded ranks, dist.py: these columns are REPLICATED instead of exchanged -- the set is fixed before the local
+        # model exists, `_small_forced`)
         mode = os.environ.get("WD_SMALL_TABLES", "cross")
-        if mode != "0" and type(self) is WideDeepEngine:
-            # the kernels size their LDS (and the workspace) by the JOINT maxima over the admitted columns -- rows of the
-            # longest table x (widest embedding + 2) -- so a column is admitted only while that product still fits (a 2000-row
-            # wide-only cross and a 1000-row cross of width 4 fit one by one and not together: the later one stays on the
-            # general path)
-            jr = jd = 0
-            for i, s in enumerate(plan.slots):
-                d = int(arr[i].dim)
-                if ((s.kind == "cross" or mode == "all") and arr[i].kind != capi.SLOT_INDICATOR and (d > 0 or arr[i].wide)
-                        and d <= 16 and max(jr, int(s.num_buckets)) * (max(jd, d) + 2) <= capi.SMALL_MAX_FLOATS):
-                    self.small_idx.append(i)
-                    jr, jd = max(jr, int(s.num_buckets)), max(jd, d)
+        forced = getattr(self, "_small_forced", None)
+        self.small_idx = (list(forced) if forced is not None else
+                          small_table_slots(plan.slots, spec.has_deep, spec.has_wide, capi.SMALL_MAX_FLOATS, mode)
+                          if type(self) is WideDeepEngine else [])
         self.slots_small_dev = self.small_idx_dev = self.small_ws = None
         if self.small_idx:
             for i in self.small_idx:
@@ -459,7 +452,7 @@ class WideDeepEngine:
         self.chain_rt = 32           # examples per workgroup of the one-launch tower (csrc/mlp_chain8.hip)
         # concatenating towers (python/lib/dnn.py:155-193: 'dense', 'resnet') take the same launch: the row tile in LDS mirrors the
         # activation row, whose segment order already makes every layer's input one contiguous window (plan.TowerLayout)
-        windows = (tl.mode in ("dense", "resnet") and not tl.copies and type(self) is WideDeepEngine
+        windows = (tl.mode in ("dense", "resnet") and not tl.copies and self._chain_windows_ok()
                    and os.environ.get("WD_CHAIN_WINDOWS", "1") != "0")
         if (tl.mode != "simple" and not windows) or L < 1 or L > capi.WD_CHAIN_MAX_LAYERS or tl.in_start[0] % 4 or tl.ld % 4:
             return
@@ -556,6 +549,10 @@ class WideDeepEngine:
                 emb_cols = max(emb_cols, plan.out_col[i] + int(sl.dim))
         tw["dx_cols"] = min(emb_cols, K0)
         self.chain = True
+
+    def _chain_windows_ok(self):
+        """Concatenating towers in the one launch (dist.py: the row-sharded engine takes them too)."""
+        return type(self) is WideDeepEngine
 
     def _setup_prefetch(self):
         """Prefetched input layer (one-id-per-bag batches on row records, single GPU): x and the wide weights of a batch are

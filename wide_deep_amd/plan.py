@@ -460,6 +460,26 @@ class FeaturePlan:
 # ---------------------------------------------------------------------------------------------
 # Synthetic Criteo-shaped specs (BASELINE.json configs 2-5)
 # ---------------------------------------------------------------------------------------------
+def small_table_slots(slots, has_deep, has_wide, max_floats, mode="cross"):
+    """Indices (into `slots`, a FeaturePlan's order) of the categorical columns whose whole table fits in LDS and that go through
+    csrc/small_tables.hip: crossed columns (mode 'cross'; 'all': any column) that are embedded with a width <= 16 or wide, not
+    indicator columns, admitted against the JOINT maxima the kernels size their LDS by -- rows of the longest table x (widest
+    embedding + 2) <= max_floats (a 2000-row wide-only cross and a 1000-row cross of width 4 fit one by one and not together:
+    the later one stays on the general path).  mode '0': none."""
+    out, jr, jd = [], 0, 0
+    if mode == "0":
+        return out
+    for i, s in enumerate(slots):
+        emb = s.deep == "embedding" and has_deep
+        d = int(s.dim) if emb else 0
+        wide = bool(has_wide and s.wide)
+        if ((s.kind == "cross" or mode == "all") and not (s.deep == "indicator" and has_deep) and (d > 0 or wide) and d <= 16
+                and max(jr, int(s.num_buckets)) * (max(jd, d) + 2) <= max_floats):
+            out.append(i)
+            jr, jd = max(jr, int(s.num_buckets)), max(jd, d)
+    return out
+
+
 def criteo_spec(n_dense=13, n_sparse=26, buckets=1_000_000, dim=16, hidden=(256, 128, 64), mode="simple",
                 model_type="wide_deep", batch_norm=True, crosses=(), cross_buckets=200, use_weight_column=False,
                 pos_weight=0.99, neg_weight=0.01):

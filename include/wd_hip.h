@@ -76,6 +76,10 @@ typedef struct wd_slot {
  * bytes[tok_offs[t] .. tok_offs[t+1]).  out_fp[t] = FarmHash Fingerprint64(token t). */
 int wd_fingerprint64(const uint8_t *bytes, const int32_t *tok_offs, int64_t ntok, uint64_t *out_fp,
                      wd_stream_t stream);
+/* The same with the token count on the DEVICE: tokens [0, *ntok_dev] are hashed (the last one is the batch's trailing ''), the
+ * grid covers ntok_capacity -- for a featurizer captured into a hipGraph over fixed-capacity buffers. */
+int wd_fingerprint64_dyn(const uint8_t *bytes, const int32_t *tok_offs, int64_t ntok_capacity, const int32_t *ntok_dev,
+                         uint64_t *out_fp, wd_stream_t stream);
 
 /* ids[t] = Fingerprint64(token t) % num_buckets of the token's slot.  Tokens are in bag order
  * (example-major); token_bag_offs = bag CSR over tokens (NULL: exactly one token per bag, bag t = token t);
@@ -166,10 +170,25 @@ typedef struct wd_feat_batch {
   int64_t batch;
   int32_t S;                 /* slots per example (= rows of the slot table) */
   int32_t empty_index;       /* T */
+  const int32_t *ntok_dev;   /* optional: T on the DEVICE (overrides empty_index) -- a featurizer captured into a hipGraph whose
+                              * batches differ in token count (fixed-capacity buffers, wd_fingerprint64_dyn) */
 } wd_feat_batch_t;
+/* vocabulary_list of one string feature for wd_feat_vocab_lookup_all (device pointers; nvocab 0: the feature has none) */
+typedef struct wd_feat_vocab {
+  const uint8_t *bytes;
+  const int32_t *offs;       /* [nvocab + 1] */
+  int32_t nvocab;
+  int32_t pad_;
+} wd_feat_vocab_t;
 int wd_feat_vocab_lookup(const uint8_t *bytes, const int32_t *tok_offs, int64_t tok_begin, int64_t n,
                          const uint8_t *vocab_bytes, const int32_t *vocab_offs, int32_t nvocab, int32_t *tok_val,
                          wd_stream_t stream);
+/* The same for EVERY vocabulary_list column in one launch: token t belongs to the feature f with tok_base[f] <= t < tok_base[f] +
+ * tok_n[f] (device arrays [nfeat]) and is looked up in vocab_table_dev[f].  ntok: tokens (grid size; with ntok_dev non-NULL the
+ * capacity, the count is read from the device). */
+int wd_feat_vocab_lookup_all(const uint8_t *bytes, const int32_t *tok_offs, int64_t ntok, const int32_t *ntok_dev,
+                             const int32_t *tok_base, const int32_t *tok_n, int32_t nfeat, const wd_feat_vocab_t *vocab_table_dev,
+                             int32_t *tok_val, wd_stream_t stream);
 /* lens[b * S + s] = ids column s gives example b; block_stats[2 k], [2 k + 1] = sum of the lengths of pairs [256 k, 256 k + 256)
  * and "one of them is not 1" (wd_feat_offsets_workspace_bytes(batch * S) bytes). */
 int wd_feat_lens(const wd_feat_slot_t *slots_dev, const wd_feat_batch_t *batch, int32_t *lens, int32_t *block_stats,

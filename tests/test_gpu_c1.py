@@ -233,3 +233,29 @@ def test_eval_py_and_pred_py_clis(tmp_path):
     out = subprocess.run([sys.executable, os.path.join(root, "pred.py"), "--model_dir", model_root], capture_output=True,
                          text=True, timeout=600)
     assert out.returncode != 0 and "Must specify prediction data_file by --data_dir" in out.stderr
+
+
+@pytest.mark.parametrize("bs", [64, 128])
+def test_train_loop_captured_steps_equal_eager_steps(tmp_path, monkeypatch, bs):
+    """python/train.py:65-165 at the reference's batch sizes (64 shipped, conf/train.yaml:47): from the third batch of a size on the
+    loop replays ONE hipGraph per step -- the featurizer's launches (token count and id count on the device, fixed-capacity stage)
+    + the train step -- and must train exactly like the eager launches (WD_TRAIN_GRAPH=0) on the same rows: same logits on a probe
+    batch, same parameters, the shorter last batch of the file on the eager path in both."""
+    from wide_deep_amd import build_estimator as BE, dataset as DS
+    lines = open(FIXTURE, "rb").read().splitlines()
+    path = _write(tmp_path, lines * 2 + lines[: bs // 2 + 3])        # several full batches + a ragged last one
+    states = {}
+    for tag, env in (("graph", "1"), ("eager", "0")):
+        monkeypatch.setenv("WD_TRAIN_GRAPH", env)
+        m = BE.build_custom_estimator(str(tmp_path / tag), "wide_deep", max_batch=bs)
+        m.train(input_fn=lambda: DS.input_fn(path, None, "train", bs))
+        torch.cuda.synchronize()
+        nfull = (2 * len(lines) + bs // 2 + 3) // bs
+        assert m.last_train["steps"] == nfull + 1 and m.last_train["examples"] == 2 * len(lines) + bs // 2 + 3
+        assert m.last_train["graph_batch_sizes"] == ([bs] if tag == "graph" else [])
+        states[tag] = (m.engine.export_state(), m.engine.global_step, float(m.last_train["loss"]))
+    (a, ga, la), (b, gb, lb) = states["graph"], states["eager"]
+    assert ga == gb and abs(la - lb) <= 1e-5 * max(1.0, abs(lb))
+    for k in b:
+        if b[k].dtype.is_floating_point:
+            assert torch.allclose(a[k], b[k], rtol=1e-5, atol=1e-6), "%s differs (max |d| %.3g)" % (k, float((a[k] - b[k]).abs().max()))

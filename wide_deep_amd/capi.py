@@ -158,7 +158,11 @@ class WdFeatBatch(ctypes.Structure):
     _fields_ = [("fp", ctypes.c_void_p), ("tok_val", ctypes.c_void_p), ("ex_offs", ctypes.c_void_p),
                 ("tok_base", ctypes.c_void_p), ("lmax", ctypes.c_void_p), ("ints", ctypes.c_void_p),
                 ("floats", ctypes.c_void_p), ("bounds", ctypes.c_void_p), ("batch", ctypes.c_int64), ("S", ctypes.c_int32),
-                ("empty_index", ctypes.c_int32)]
+                ("empty_index", ctypes.c_int32), ("ntok_dev", ctypes.c_void_p)]
+
+
+class WdFeatVocab(ctypes.Structure):
+    _fields_ = [("bytes", ctypes.c_void_p), ("offs", ctypes.c_void_p), ("nvocab", ctypes.c_int32), ("pad_", ctypes.c_int32)]
 
 
 P = ctypes.c_void_p
@@ -169,6 +173,8 @@ _PROTOS = {
     "wd_abi_version": [],
     "wd_build_stamp": [],
     "wd_fingerprint64": [P, P, I64, P, P],
+    "wd_fingerprint64_dyn": [P, P, I64, P, P, P],
+    "wd_feat_vocab_lookup_all": [P, P, I64, P, P, P, I32, P, P, P],
     "wd_hash_bucket": [P, P, I64, P, I64, P, I32, P, P],
     "wd_emit_hash_slot": [P, P, I64, U64, P, I32, I32, P, P],
     "wd_emit_int_slot": [P, P, I64, P, I32, I32, P, P],

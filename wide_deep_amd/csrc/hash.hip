@@ -148,8 +148,9 @@ __device__ __forceinline__ uint64_t fingerprint_cat64(uint64_t fp1, uint64_t fp2
 }
 
 __global__ void k_fingerprint64(const uint8_t *__restrict__ bytes, const int32_t *__restrict__ tok_offs, int64_t ntok,
-                                uint64_t *__restrict__ out) {
+                                const int32_t *__restrict__ ntok_dev, uint64_t *__restrict__ out) {
   int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (ntok_dev) ntok = (int64_t)*ntok_dev + 1;       // the batch's token count lives on the device: tokens [0, T] (T = the trailing '')
   if (t >= ntok) return;
   int32_t o0 = tok_offs[t], o1 = tok_offs[t + 1];
   out[t] = fingerprint64(bytes + o0, (uint32_t)(o1 - o0));
@@ -280,7 +281,7 @@ __device__ __forceinline__ uint64_t feat_key_value(const wd_feat_key_t &k, const
   if (k.kind == WD_FEAT_KEY_STRING) {
     const int32_t *eo = q.ex_offs + (int64_t)k.src * (q.batch + 1);
     const int32_t real = eo[b + 1] - eo[b];
-    return j < real ? q.fp[q.tok_base[k.src] + eo[b] + j] : q.fp[q.empty_index];
+    return j < real ? q.fp[q.tok_base[k.src] + eo[b] + j] : q.fp[q.ntok_dev ? *q.ntok_dev : q.empty_index];
   }
   if (k.kind == WD_FEAT_KEY_IDENTITY) {
     const int64_t v = q.ints[(int64_t)k.src * q.batch + b];
@@ -486,6 +487,7 @@ k_feat_emit_par(const wd_feat_slot_t *__restrict__ slots, wd_feat_batch_t q, con
         }
     }
   }
+  const int32_t empty_index = q.ntok_dev ? *q.ntok_dev : q.empty_index;     // (uniform: a scalar load)
   __syncthreads();
   if (FE_EXP & 1) return;
   // ---- prefixes: combinations of the leading keys per crossed (example, column), scanned over the pairs ----
@@ -545,7 +547,7 @@ k_feat_emit_par(const wd_feat_slot_t *__restrict__ slots, wd_feat_batch_t q, con
     for (int k = 0; k < WD_MAX_CROSS_KEYS - 1; ++k) {
       if (k + 1 < c.nkeys) {
         const int32_t real = kr[k];
-        const uint64_t v = real < 0 ? (uint64_t)(int64_t)kb[k] : q.fp[(int32_t)idx[k] < real ? kb[k] + (int32_t)idx[k] : q.empty_index];
+        const uint64_t v = real < 0 ? (uint64_t)(int64_t)kb[k] : q.fp[(int32_t)idx[k] < real ? kb[k] + (int32_t)idx[k] : empty_index];
         h = fingerprint_cat64(h, v);
       }
     }
@@ -586,7 +588,7 @@ k_feat_emit_par(const wd_feat_slot_t *__restrict__ slots, wd_feat_batch_t q, con
         const uint32_t y = j / nl, il = j - y * nl;     // combination of the leading keys, digit of the last key
         const int32_t real = kr[kl];
         imm = real < 0;
-        fi = imm ? q.empty_index : ((int32_t)il < real ? kb[kl] + (int32_t)il : q.empty_index);
+        fi = imm ? empty_index : ((int32_t)il < real ? kb[kl] + (int32_t)il : empty_index);
         const int32_t px = pbase[pi] + (int32_t)y;
         if (px < FE_PREFIX_CAP) {
           h = hp[px];
@@ -606,7 +608,7 @@ k_feat_emit_par(const wd_feat_slot_t *__restrict__ slots, wd_feat_batch_t q, con
           for (int k = 0; k < WD_MAX_CROSS_KEYS - 1; ++k) {
             if (k < kl) {
               const int32_t rk = kr[k];
-              const uint64_t v = rk < 0 ? (uint64_t)(int64_t)kb[k] : q.fp[(int32_t)idx[k] < rk ? kb[k] + (int32_t)idx[k] : q.empty_index];
+              const uint64_t v = rk < 0 ? (uint64_t)(int64_t)kb[k] : q.fp[(int32_t)idx[k] < rk ? kb[k] + (int32_t)idx[k] : empty_index];
               h = fingerprint_cat64(h, v);
             }
           }
@@ -649,6 +651,37 @@ k_feat_vocab(const uint8_t *__restrict__ bytes, const int32_t *__restrict__ tok_
   out[t0 + t] = hit;
 }
 
+// ... of every token of the batch in ONE launch: the token's feature by its range [tok_base[f], tok_base[f] + tok_n[f]) (F <= a few
+// dozen: a linear walk), the feature's vocabulary from a device table; features without a vocabulary_list column are skipped.
+// ntok_dev (optional): the token count on the device (a captured featurizer).
+__global__ void __launch_bounds__(256)
+k_feat_vocab_all(const uint8_t *__restrict__ bytes, const int32_t *__restrict__ tok_offs, int64_t ntok,
+                 const int32_t *__restrict__ ntok_dev, const int32_t *__restrict__ tok_base, const int32_t *__restrict__ tok_n,
+                 int32_t F, const wd_feat_vocab_t *__restrict__ vt, int32_t *__restrict__ out) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (ntok_dev) ntok = *ntok_dev;
+  if (t >= ntok) return;
+  int f = -1;
+  for (int g = 0; g < F; ++g) {
+    const int32_t b0 = tok_base[g];
+    if (t >= b0 && t < b0 + tok_n[g]) f = g;
+  }
+  if (f < 0 || vt[f].nvocab <= 0) return;
+  const uint8_t *__restrict__ vbytes = vt[f].bytes;
+  const int32_t *__restrict__ voffs = vt[f].offs;
+  const int32_t nv = vt[f].nvocab;
+  const int32_t o0 = tok_offs[t], len = tok_offs[t + 1] - o0;
+  int32_t hit = -1;
+  for (int32_t v = 0; v < nv && hit < 0; ++v) {
+    const int32_t w0 = voffs[v];
+    if (voffs[v + 1] - w0 != len) continue;
+    bool eq = true;
+    for (int32_t c = 0; c < len; ++c) eq = eq && bytes[o0 + c] == vbytes[w0 + c];
+    if (eq) hit = v;
+  }
+  out[t] = hit;
+}
+
 }  // namespace
 
 static bool feat_batch_ok(const wd_feat_batch_t *q) {
@@ -663,6 +696,16 @@ extern "C" int wd_feat_vocab_lookup(const uint8_t *bytes, const int32_t *tok_off
   hipLaunchKernelGGL(k_feat_vocab, dim3((unsigned)wd::ceil_div(n, 256)), dim3(256), 0, wd::as_stream(stream), bytes, tok_offs,
                      tok_begin, n, vocab_bytes, vocab_offs, nvocab, tok_val);
   return wd::check_launch("wd_feat_vocab_lookup");
+}
+
+extern "C" int wd_feat_vocab_lookup_all(const uint8_t *bytes, const int32_t *tok_offs, int64_t ntok, const int32_t *ntok_dev,
+                                        const int32_t *tok_base, const int32_t *tok_n, int32_t nfeat,
+                                        const wd_feat_vocab_t *vocab_table_dev, int32_t *tok_val, wd_stream_t stream) {
+  if (ntok <= 0 || nfeat <= 0) return WD_OK;
+  WD_REQUIRE(bytes && tok_offs && tok_base && tok_n && vocab_table_dev && tok_val, "null pointer");
+  hipLaunchKernelGGL(k_feat_vocab_all, dim3((unsigned)wd::ceil_div(ntok, 256)), dim3(256), 0, wd::as_stream(stream), bytes, tok_offs,
+                     ntok, ntok_dev, tok_base, tok_n, nfeat, vocab_table_dev, tok_val);
+  return wd::check_launch("wd_feat_vocab_lookup_all");
 }
 
 extern "C" int wd_feat_lens(const wd_feat_slot_t *slots_dev, const wd_feat_batch_t *batch, int32_t *lens, int32_t *block_stats,
@@ -720,8 +763,17 @@ extern "C" int wd_fingerprint64(const uint8_t *bytes, const int32_t *tok_offs, i
   if (ntok <= 0) return WD_OK;
   WD_REQUIRE(bytes && tok_offs && out_fp, "null pointer");
   hipLaunchKernelGGL(k_fingerprint64, dim3((unsigned)wd::ceil_div(ntok, 256)), dim3(256), 0, wd::as_stream(stream),
-                     bytes, tok_offs, ntok, out_fp);
+                     bytes, tok_offs, ntok, (const int32_t *)nullptr, out_fp);
   return wd::check_launch("wd_fingerprint64");
+}
+
+extern "C" int wd_fingerprint64_dyn(const uint8_t *bytes, const int32_t *tok_offs, int64_t ntok_capacity, const int32_t *ntok_dev,
+                                    uint64_t *out_fp, wd_stream_t stream) {
+  if (ntok_capacity <= 0) return WD_OK;
+  WD_REQUIRE(bytes && tok_offs && out_fp && ntok_dev, "null pointer");
+  hipLaunchKernelGGL(k_fingerprint64, dim3((unsigned)wd::ceil_div(ntok_capacity, 256)), dim3(256), 0, wd::as_stream(stream),
+                     bytes, tok_offs, ntok_capacity, ntok_dev, out_fp);
+  return wd::check_launch("wd_fingerprint64_dyn");
 }
 
 extern "C" int wd_hash_bucket(const uint8_t *bytes, const int32_t *tok_offs, int64_t ntok,

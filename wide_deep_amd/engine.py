@@ -107,9 +107,13 @@ class WideDeepEngine:
         # bucket geometry of the fused sparse backward (wd_sparse_bucketize): ~64 occurrences per row-range bucket,
         # one bucket per row for vocabularies too small to be cut (plan.bucket_geometry)
         exp_nnz = int(expected_nnz) if expected_nnz else self.max_batch * max(S, 1)
+        # ~64 occurrences per bucket at BASELINE batch sizes; a small batch (the reference's own 64-512: conf/train.yaml:47,
+        # BASELINE configs[0]) gets smaller buckets -- enough of them to fill the chip (k_bucket_update is one workgroup per bucket:
+        # at batch 512 of the shipped conf 423 buckets, the slowest holding six rows with > 32 occurrences each, reduced one after the
+        # other by its workgroup, took 140 us for 50 k occurrences; profiles/r6_c1_kernel_stats_b512_before.md)
+        target = float(os.environ.get("WD_BUCKET_TARGET", "0")) or min(64.0, max(8.0, exp_nnz / 2048.0))
         shifts, bases, self.n_buckets = bucket_geometry(
-            [s.num_buckets for s in plan.slots], exp_nnz / max(S, 1), int(call("wd_bucket_max")),
-            float(os.environ.get("WD_BUCKET_TARGET", "64")))
+            [s.num_buckets for s in plan.slots], exp_nnz / max(S, 1), int(call("wd_bucket_max")), target)
         self.bucket_shifts = shifts
         arr = (capi.WdSlot * max(S, 1))()
         for i, s in enumerate(plan.slots):

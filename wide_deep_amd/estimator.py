@@ -25,6 +25,57 @@ from .engine import DeviceBatch, WideDeepEngine
 from .features import Featurizer
 
 
+class _GraphStep(object):
+    """`Featurizer.run` + `engine.train_step` of ONE batch size captured into a hipGraph over fixed-capacity buffers
+    (features.FixedStage): a train step of the loop is then one staged host-to-device copy + one graph launch instead of the
+    featurizer's and the step's ~80 eager launches (python/train.py:65-165 at the reference's batch sizes -- 64 shipped,
+    conf/train.yaml:47; BASELINE configs[0] 512 -- is launch-bound on this GPU, not kernel-bound).  The id count and the token
+    count stay on the device; `check()` reads the capacity flags every few steps."""
+
+    def __init__(self, est, raws):
+        import os
+        from . import hipgraph
+        eng, fz = est._engine, est._featurizer
+        B = raws[0].B
+        tok = max(len(r.tok_offs) - 2 for r in raws)
+        nby = max(len(r.tok_bytes) for r in raws)
+        slack = float(os.environ.get("WD_TRAIN_GRAPH_SLACK", "1.5"))
+        self.eng, self.fz, self.B = eng, fz, B
+        self.pdb = fz.resident_fixed(B, int(tok * slack) + 256, int(nby * slack) + 4096, labels=raws[0].labels is not None,
+                                     weights=raws[0].weights is not None and eng.spec.use_weight_column,
+                                     nnz_hint=est._nnz_seen * 1.25 + 1024 if est._nnz_seen else None)
+        self.stage = self.pdb.stg
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            self.stage.fill(raws[-1])
+            fz.run(self.pdb)              # (first launches of the dynamic-count kernels outside the capture; changes no state)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = hipgraph.new_graph()
+        gs = eng.global_step
+        with torch.cuda.graph(self.graph, stream=side):
+            fz.run(self.pdb)
+            eng.train_step(self.pdb.batch)
+        eng.global_step = gs
+        self._bump = 3 if eng.spec.model_type == "wide_deep" else 2
+        self.stream = side
+
+    def fits(self, raw):
+        return self.stage.fits(raw)
+
+    def step(self, raw):
+        self.stage.fill(raw)
+        self.graph.replay()
+        self.eng.global_step += self._bump
+        return self.eng.loss
+
+    def check(self):
+        """the id array's capacity flag (wd_feat_offsets): a batch with more ids than the engine holds dropped some"""
+        if int(self.pdb.flags[0].item()):
+            raise ValueError("a batch produced more ids than the engine's capacity (max_nnz=%d)" % self.eng.max_nnz)
+
+
 class WideAndDeepClassifier(object):
     def __init__(self, spec, model_dir=None, runconfig=None, max_batch=None, max_nnz=None, cross_padding="tf_dense",
                  seed=None, engine=None):
@@ -37,6 +88,9 @@ class WideAndDeepClassifier(object):
         self._engine = engine
         self._featurizer = None
         self._restored_from = None
+        self._graph_steps = {}        # batch size -> _GraphStep (captured featurizer + train step)
+        self._warm = {}               # batch size -> the first RawBatches of that size (eager steps; they size the fixed stage)
+        self._nnz_seen = 0
 
     # ---- engine life cycle --------------------------------------------------------------------------
     def _ensure_engine(self, first_batch):
@@ -97,6 +151,38 @@ class WideAndDeepClassifier(object):
         flag = torch.tensor([1 if (self._rank() == 0 and time.time() - t_save >= save_secs) else 0], dtype=torch.int32, device=dev)
         td.broadcast(flag, src=0)
         return bool(int(flag.item()))
+
+    _GRAPH_AFTER = 2      # eager steps of a batch size before its step is captured (lazy allocations, capacities from real batches)
+
+    def _graph_step_for(self, raw):
+        """The captured step for this batch, or None (eager): one GPU, parsed host batches through the device featurizer, constant
+        learning rates (a captured step bakes them in), WD_TRAIN_GRAPH != 0, batches up to WD_TRAIN_GRAPH_MAX_BATCH (2048) examples --
+        the small batches the reference ships are bound by the ~80 launches of a step, a batch of 8192 by the kernels and the
+        parser, and its eager featurizer overlaps the previous step on a stream of its own (measured: 64: +39 %, 512: +22 %,
+        8192: -8 %, profiles/r6_c1_train_loop.md); a batch size is captured once it has been seen _GRAPH_AFTER times (the last,
+        shorter batch of a file stays eager unless it comes back every epoch)."""
+        import os
+        if (isinstance(raw, DeviceBatch) or self._engine is None or self._world() > 1 or self._engine.spec.lr_decay
+                or self._featurizer is None or self._featurizer.mode != "device" or os.environ.get("WD_TRAIN_GRAPH", "1") == "0"
+                or raw.B == 0 or raw.labels is None or raw.B > int(os.environ.get("WD_TRAIN_GRAPH_MAX_BATCH", "2048"))):
+            return None
+        g = self._graph_steps.get(raw.B)
+        if g is None:
+            w = self._warm.setdefault(raw.B, [])
+            if len(w) < self._GRAPH_AFTER:
+                w.append(raw)
+                return None
+            try:
+                g = self._graph_steps[raw.B] = _GraphStep(self, w + [raw])
+            except Exception as e:         # a capture the runtime refuses: stay eager for this size, say why once
+                import warnings
+                warnings.warn("train: the step of batch size %d is not captured into a hipGraph (%s: %s); eager launches"
+                              % (raw.B, type(e).__name__, e))
+                g = self._graph_steps[raw.B] = False
+            self._warm.pop(raw.B, None)
+        if not g or not g.fits(raw):
+            return None                    # (more tokens than the fixed stage holds: this batch takes the eager path)
+        return g
 
     def _device_batch(self, b):
         if isinstance(b, DeviceBatch):
@@ -228,7 +314,10 @@ class WideAndDeepClassifier(object):
         log_every = int(self.runconfig.get("log_step_count_steps") or 0)
         loss = None
         for raw in it:
-            bt = self._device_batch(raw)
+            gstep = self._graph_step_for(raw) if n else None
+            bt = None
+            if gstep is None:
+                bt = self._device_batch(raw)
             if n == 0:
                 self._restore()
                 t0 = time.time()       # examples/sec of the loop itself: checkpoint restore / save are reported apart
@@ -239,9 +328,15 @@ class WideAndDeepClassifier(object):
                 sp, gs = eng.spec, eng.global_step
                 eng.set_learning_rates(dnn=sp.decayed_lr("dnn", gs, eng.lr0["dnn"]) if sp.has_deep else None,
                                        linear=sp.decayed_lr("linear", gs, eng.lr0["linear"]) if sp.has_wide else None)
-            loss = self._engine.train_step(bt)
+            if gstep is not None:
+                loss = gstep.step(raw)          # one staged copy + one hipGraph launch: featurizer + train step
+                if n % self._CHECK_EVERY == 0:
+                    gstep.check()
+            else:
+                loss = self._engine.train_step(bt)
+                self._nnz_seen = max(self._nnz_seen, int(getattr(bt, "nnz", 0) or 0))
             n += 1
-            seen += bt.B
+            seen += raw.B if bt is None else bt.B
             if log_every and n % log_every == 0 and self._rank() == 0:
                 torch.cuda.synchronize()
                 dt = time.time() - t0
@@ -260,8 +355,12 @@ class WideAndDeepClassifier(object):
         if n:
             torch.cuda.synchronize()
             self._check_overflow()
+            for g in self._graph_steps.values():
+                if g:
+                    g.check()
             self.last_train = {"steps": n, "examples": seen, "seconds": time.time() - t0,
-                               "loss": float(loss) if loss is not None else None}
+                               "loss": float(loss) if loss is not None else None,
+                               "graph_batch_sizes": sorted(b for b, g in self._graph_steps.items() if g)}
             self.save_checkpoint()
         return self
 

@@ -96,6 +96,89 @@ class _Stage(object):
         return self.dbuf[off: off + a.nbytes].view(_NP2T[a.dtype])
 
 
+class FixedStage(object):
+    """The staged form of a parsed batch with FIXED capacities and therefore fixed device addresses: what a featurizer + train step
+    captured into ONE hipGraph (estimator.WideAndDeepClassifier.train, one graph per batch size) reads its batch from.  `fill(raw)`
+    packs a RawBatch into a pinned host copy of the layout (rotating: a copy may still be in flight) and issues ONE host-to-device
+    copy on the current stream; what varies from batch to batch besides the contents -- the token count -- travels in the buffer
+    (`hdr[0]`), the kernels read it on the device (wd_fingerprint64_dyn, wd_feat_batch_t.ntok_dev)."""
+
+    def __init__(self, fz, B, tok_cap, bytes_cap, labels=True, weights=False, n_host=3):
+        plan = fz.plan
+        F, NI, NF, nd = max(len(fz.str_feats), 1), max(len(fz.int_feats), 1), max(len(fz.float_rows), 1), len(plan.dense_cols)
+        self.fz, self.B, self.tok_cap, self.bytes_cap = fz, int(B), int(tok_cap), int(bytes_cap)
+        lay = [("bytes", np.uint8, (self.bytes_cap,)), ("toffs", np.int32, (self.tok_cap + 2,)), ("ex", np.int32, (F, B + 1)),
+               ("base", np.int32, (F,)), ("tokn", np.int32, (F,)), ("lmax", np.int32, (F,)), ("hdr", np.int32, (4,)),
+               ("ints", np.int64, (NI, max(B, 1))), ("floats", np.float32, (NF, max(B, 1)))]
+        if nd:
+            lay.append(("dense", np.float32, (B, nd)))
+        if labels:
+            lay.append(("lab", np.float32, (B,)))
+        if weights:
+            lay.append(("wts", np.float32, (B,)))
+        self.items, off = {}, 0
+        for name, dt, shape in lay:
+            off = (off + 15) // 16 * 16
+            nbytes = int(np.prod(shape)) * np.dtype(dt).itemsize
+            self.items[name] = (off, np.dtype(dt), shape, nbytes)
+            off += nbytes
+        self.size = (off + 15) // 16 * 16
+        self.dbuf = torch.zeros(self.size, dtype=torch.uint8, device=fz.dev)
+        self.base = self.dbuf.data_ptr()
+        self._host = [torch.zeros(self.size, dtype=torch.uint8).pin_memory() for _ in range(n_host)]
+        self._views = [{k: h.numpy()[o: o + nb].view(dt).reshape(shape) for k, (o, dt, shape, nb) in self.items.items()} for h in self._host]
+        self._busy = [None] * n_host
+        self._k = 0
+        self.h = {k: (k if k in self.items else None) for k in ("bytes", "toffs", "ex", "base", "tokn", "lmax", "hdr", "ints", "floats",
+                                                                 "dense", "lab", "wts")}
+
+    def fits(self, raw):
+        return (raw.B == self.B and len(raw.tok_offs) - 2 <= self.tok_cap and len(raw.tok_bytes) <= self.bytes_cap
+                and (raw.labels is not None) == ("lab" in self.items)
+                and (raw.weights is not None and self.fz.engine.spec.use_weight_column) == ("wts" in self.items))
+
+    def ptr(self, h):
+        return ctypes.c_void_p(self.base + self.items[h][0])
+
+    def tensor(self, h):
+        o, dt, shape, nb = self.items[h]
+        return self.dbuf[o: o + nb].view(_NP2T[dt])
+
+    def fill(self, raw):
+        """pack `raw` (the caller checked `fits`) and copy it to the device on the current stream"""
+        fz, plan = self.fz, self.fz.plan
+        k = self._k
+        self._k = (k + 1) % len(self._host)
+        if self._busy[k] is not None:
+            self._busy[k].synchronize()              # the copy that last read this pinned buffer
+        v = self._views[k]
+        nb, T = len(raw.tok_bytes), len(raw.tok_offs) - 2
+        v["bytes"][:nb] = raw.tok_bytes
+        v["toffs"][: T + 2] = raw.tok_offs
+        for j, f in enumerate(fz.str_feats):
+            pc = raw.cat[f]
+            v["ex"][j] = pc.ex_offs
+            v["base"][j], v["tokn"][j] = pc.base, pc.n
+            v["lmax"][j] = int(np.diff(pc.ex_offs).max()) if self.B else 0
+        v["hdr"][0] = T
+        for j, f in enumerate(fz.int_feats):
+            v["ints"][j] = raw.ints[f]
+        for j, (f, log) in enumerate(fz.float_rows):
+            x = np.asarray(raw.floats[f], dtype=np.float32)
+            v["floats"][j] = np.log(x) if log else x
+        if "dense" in v:
+            for j, d in enumerate(plan.dense_cols):
+                v["dense"][:, j] = raw.floats[d.feature]
+        if "lab" in v:
+            v["lab"][:] = raw.labels
+        if "wts" in v:
+            v["wts"][:] = raw.weights
+        self.dbuf.copy_(self._host[k], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._busy[k] = ev
+
+
 class ParsedDeviceBatch(object):
     """A parsed batch resident in HBM (the staged buffer of Featurizer._stage: token bytes + offsets, per-feature example
     ranges, integer / float feature matrices, labels) with the buffers the featurizer's launches fill: fingerprints, vocabulary
@@ -202,6 +285,12 @@ class Featurizer(object):
         self.vocab_dev = {}
         for i, (vb, vo, nv) in self.vocab_packed.items():
             self.vocab_dev[i] = (torch.from_numpy(vb).to(dev), torch.from_numpy(vo).to(dev), nv)
+        # vocabulary per STRING FEATURE for the one-launch lookup (wd_feat_vocab_lookup_all)
+        varr = (capi.WdFeatVocab * max(len(self.str_feats), 1))()
+        for i, (vb, vo, nv) in self.vocab_dev.items():
+            j = self.str_feats.index(slots[i].feature)
+            varr[j].bytes, varr[j].offs, varr[j].nvocab = vb.data_ptr(), vo.data_ptr(), int(nv)
+        self.vocab_table_dev = torch.from_numpy(np.frombuffer(bytes(varr), dtype=np.uint8).copy()).to(dev)
         self._fs = torch.cuda.Stream(device=dev)
         # the tables above were uploaded on the caller's stream: one edge, once, so that the featurizer's own stream -- which is
         # deliberately NOT ordered behind the training stream per batch -- never reads them before they have arrived
@@ -216,12 +305,14 @@ class Featurizer(object):
         h = {"bytes": stg.add(raw.tok_bytes, np.uint8), "toffs": stg.add(raw.tok_offs, np.int32)}
         ex = np.zeros((max(F, 1), B + 1), dtype=np.int32)
         base = np.zeros(max(F, 1), dtype=np.int32)
+        tokn = np.zeros(max(F, 1), dtype=np.int32)
         lmax = np.zeros(max(F, 1), dtype=np.int32)
         for j, f in enumerate(self.str_feats):
             pc = raw.cat[f]
-            ex[j], base[j] = pc.ex_offs, pc.base
+            ex[j], base[j], tokn[j] = pc.ex_offs, pc.base, pc.n
             lmax[j] = int(np.diff(pc.ex_offs).max()) if B else 0
         h["ex"], h["base"], h["lmax"] = stg.add(ex, np.int32), stg.add(base, np.int32), stg.add(lmax, np.int32)
+        h["tokn"], h["hdr"] = stg.add(tokn, np.int32), None
         ints = (np.stack([np.asarray(raw.ints[f], dtype=np.int64) for f in self.int_feats]) if self.int_feats
                 else np.zeros((1, max(B, 1)), np.int64))
         rows = []
@@ -261,6 +352,27 @@ class Featurizer(object):
         self._make_batch(pdb, nnz=cap, one_hot=False)
         return pdb
 
+    def resident_fixed(self, B, tok_cap, bytes_cap, ids_capacity=None, labels=True, weights=False, nnz_hint=None):
+        """A ParsedDeviceBatch over a FixedStage: fixed addresses, refilled batch after batch (`pdb.stg.fill(raw)`), featurized by
+        `run` with the token count read on the device -- what a captured featurizer + train step works on.  nnz_hint: the engine's
+        sizing hint for the id count (default: the capacity)."""
+        eng = self.engine
+        if self.mode != "device":
+            raise ValueError("Featurizer.resident_fixed needs mode='device'")
+        if B > eng.max_batch:
+            raise ValueError("batch (B=%d) exceeds engine capacity (max_batch=%d)" % (B, eng.max_batch))
+        cap = min(int(ids_capacity) if ids_capacity is not None else int(eng.max_nnz), int(eng.max_nnz))
+        pdb = ParsedDeviceBatch()
+        pdb.B, pdb.T, pdb.raw, pdb.dynamic = int(B), int(tok_cap), None, True
+        pdb.stg = FixedStage(self, B, tok_cap, bytes_cap, labels=labels, weights=weights)
+        pdb.h = pdb.stg.h
+        self._alloc_head(pdb)
+        pdb.q.ntok_dev = pdb.stg.ptr("hdr").value
+        pdb.cap = cap
+        pdb.ids = torch.zeros(max(cap, 1), dtype=torch.int32, device=self.dev)
+        self._make_batch(pdb, nnz=min(int(nnz_hint), cap) if nnz_hint else cap, one_hot=False)
+        return pdb
+
     def _alloc_head(self, pdb):
         stg, h, B, S, T = pdb.stg, pdb.h, pdb.B, self.plan.S, pdb.T
         i32 = dict(dtype=torch.int32, device=self.dev)
@@ -282,21 +394,24 @@ class Featurizer(object):
     def _make_batch(self, pdb, nnz, one_hot):
         stg, h, B, nd = pdb.stg, pdb.h, pdb.B, len(self.plan.dense_cols)
         dense = stg.tensor(h["dense"]).view(B, nd) if nd else None
-        labels = stg.tensor(h["lab"]) if h["lab"] is not None else None
-        weights = stg.tensor(h["wts"]) if h["wts"] is not None else None
+        labels = stg.tensor(h["lab"]) if h.get("lab") is not None else None
+        weights = stg.tensor(h["wts"]) if h.get("wts") is not None else None
         pdb.batch = DeviceBatch(B, pdb.ids, pdb.bag, dense, labels, weights, nnz=nnz, one_hot=one_hot)
         pdb.batch._keep = [pdb.fp, pdb.tok_val, pdb.lens, stg.dbuf, pdb.flags, pdb.scan_ws]
         return pdb.batch
 
     def _run_head(self, pdb, st):
         """2. fingerprints of every token (+ the trailing ''), vocabulary indices; 3a. lengths -> bag CSR"""
-        plan, stg, h, raw = self.plan, pdb.stg, pdb.h, pdb.raw
+        plan, stg, h = self.plan, pdb.stg, pdb.h
         n = pdb.B * plan.S
-        call("wd_fingerprint64", stg.ptr(h["bytes"]), stg.ptr(h["toffs"]), pdb.T + 1, ptr(pdb.fp), st)
-        for i, (vb, vo, nv) in self.vocab_dev.items():
-            pc = raw.cat[plan.slots[i].feature]
-            call("wd_feat_vocab_lookup", stg.ptr(h["bytes"]), stg.ptr(h["toffs"]), pc.base, pc.n, ptr(vb), ptr(vo), nv,
-                 ptr(pdb.tok_val), st)
+        dyn = stg.ptr(h["hdr"]) if getattr(pdb, "dynamic", False) else None      # fixed-capacity stage: the token count is on the device
+        if dyn is not None:
+            call("wd_fingerprint64_dyn", stg.ptr(h["bytes"]), stg.ptr(h["toffs"]), pdb.T + 1, dyn, ptr(pdb.fp), st)
+        else:
+            call("wd_fingerprint64", stg.ptr(h["bytes"]), stg.ptr(h["toffs"]), pdb.T + 1, ptr(pdb.fp), st)
+        if self.vocab_dev:      # every vocabulary_list column in one launch
+            call("wd_feat_vocab_lookup_all", stg.ptr(h["bytes"]), stg.ptr(h["toffs"]), pdb.T, dyn, stg.ptr(h["base"]),
+                 stg.ptr(h["tokn"]), len(self.str_feats), ptr(self.vocab_table_dev), ptr(pdb.tok_val), st)
         call("wd_feat_lens", ptr(self.feat_slots_dev), ctypes.byref(pdb.q), ptr(pdb.lens), ptr(pdb.scan_ws), st)
         call("wd_feat_offsets", ptr(pdb.lens), ptr(pdb.scan_ws), n, ptr(pdb.bag), pdb.cap, ptr(pdb.flags), st)
 

@@ -43,6 +43,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc child passes (roofline traffic = null)")
     ap.add_argument("--no-parity", action="store_true", help="skip the oracle check of batch 0 before the timed region")
+    ap.add_argument("--dump-stamps", default=None, metavar="PATH",
+                    help="write the per-launch clock stamps `roofline` is computed from (first workgroup start, last store landed)")
     ap.add_argument("--force-sharded", action="store_true",
                     help="diagnostics: run the row-sharded engine even with one rank (one-rank RCCL group)")
     ap.add_argument("--cpu-steps", type=int, default=50)
@@ -212,7 +214,18 @@ def gather_kernel_roofline(eng, batches, args, iters=200):
                      "batches take it (or k_input_layer) inside the step")}
 
 
-def gather_instep_roofline(eng, dev_batches, step_eager, steps=16, runner=None, span=None):
+def rocprof_instep_record():
+    """The tracked rocprofv3 --kernel-trace figure for the same launch in the same graphs (profiles/r6_gather_instep_rocprof.json,
+    written by scripts/gather_instep_from_trace.py from the trace of this command on the box of profiles/README.md): bench.py cannot
+    trace itself, so the line carries the committed number next to the stamps it measures live."""
+    path = os.path.join(ROOT, "profiles", "r6_gather_instep_rocprof.json")
+    try:
+        return json.load(open(path))
+    except Exception:
+        return None
+
+
+def gather_instep_roofline(eng, dev_batches, step_eager, steps=16, runner=None, span=None, dump=None):
     """The gather AS IT RUNS IN THE STEP.  One-id-per-bag batches (C2 / C3): the input layer is the first phase of
     k_tower_chain; every workgroup stores the chip-wide realtime clock (100 MHz) at its start and when its x tile is complete
     (wd_chain_opts_t.tile_stamps), and the phase's duration is  max(tile complete) - min(start)  over all workgroups of a
@@ -228,13 +241,24 @@ def gather_instep_roofline(eng, dev_batches, step_eager, steps=16, runner=None, 
         # every workgroup stores the chip-wide realtime clock (100 MHz) at its start and, once its stores have completed, at its
         # end (per activation buffer).  Measured on THE GRAPHS THAT WERE TIMED (pipeline.StepRunner, captured with the stamp
         # buffer attached): after a replay the buffer holds the stamps of the last launch into each activation buffer
-        durs = []
+        durs, rows = [], []
         for i in range(steps):
             runner.run(runner.spg)
             torch.cuda.synchronize()
             v = span.cpu()
-            durs += [float(v[p, :, 1].max() - v[p, :, 0].min()) / 100.0 for p in range(v.shape[0])]
+            for p in range(v.shape[0]):
+                t0, t1 = int(v[p, :, 0].min()), int(v[p, :, 1].max())
+                durs.append((t1 - t0) / 100.0)
+                rows.append((i, p, t0, t1, int(v[p, :, 0].max()) - t0))
         us = sum(durs) / len(durs)
+        if dump:
+            with open(dump, "w") as f:
+                f.write("# k_prefetch_onehot inside the timed graphs: chip-wide 100 MHz realtime clock, one line per launch (the last launch\n"
+                        "# into each of the %d activation buffers after a replay of %d steps)\n"
+                        "# replay  buffer  first_workgroup_start  last_store_landed  duration_us  start_skew_of_the_workgroups_us\n"
+                        % (v.shape[0], runner.spg))
+                for i, p, t0, t1, skew in rows:
+                    f.write("%4d %4d %16d %16d %8.2f %8.2f\n" % (i, p, t0, t1, (t1 - t0) / 100.0, skew / 100.0))
         kernel = "k_prefetch_onehot<%d, 1> (the input layer of batch t+1, launched beside the tower of batch t)" % (dim // 4)
         how = ("realtime-clock stamps of the launch's workgroups, first start -> last end (stores completed), in the chained "
                "%d-step hipGraphs the timed region replays, mean of %d launches (min %.2f, max %.2f us)"
@@ -281,8 +305,18 @@ def gather_instep_roofline(eng, dev_batches, step_eager, steps=16, runner=None, 
                      " + k_small_fwd (crossed columns, tables in LDS)" if eng._small_on(bt0) else ""))
         how = "HIP events around the launch%s (in the step as timed here), 100 times over the resident pool" % ("" if fused else "es")
     gbs = alg / us / 1e3
+    extra = {}
+    rp = rocprof_instep_record() if (span is not None and runner is not None and runner.multis) else None
+    if rp and rp.get("in_step_us_mean"):
+        # `frac` is the stamp figure (first workgroup's first instruction -> last workgroup's stores landed, measured live in the
+        # timed graphs); the kernel-trace duration of the same launch also holds the dispatch ramp in front of the first wavefront
+        # and the end-of-kernel release behind the last one
+        extra = {"rocprof_instep_us": rp["in_step_us_mean"],
+                 "frac_rocprof_instep": round(alg / rp["in_step_us_mean"] / 1e3 / HBM_PEAK_GBS, 4),
+                 "rocprof_source": "profiles/r6_gather_instep_rocprof.json (rocprofv3 --kernel-trace of this command, %d in-step "
+                                   "launches; another box than this run's)" % rp.get("in_step_launches", 0)}
     return {"bound": "hbm", "kernel": kernel, "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
+            "frac": round(gbs / HBM_PEAK_GBS, 4), **extra, "traffic": None,
             "traffic_source": "PMC counters are per launch, not per overlap window: the traffic of this launch, measured alone, is "
                               "in roofline_gather_kernel",
             "algorithmic_bytes_per_launch": int(alg), "avg_launch_us": round(us, 2), "measured": how,
@@ -944,7 +978,7 @@ def main():
                 synth.hash_tokens(eng, tb)
             torch.cuda.synchronize()
             if not sharded and eng.spec.has_deep and eng.group_slots:
-                out["roofline"] = gather_instep_roofline(eng, dev_batches, step_eager, runner=runner, span=span)
+                out["roofline"] = gather_instep_roofline(eng, dev_batches, step_eager, runner=runner, span=span, dump=args.dump_stamps)
             out["roofline_gather_kernel"] = gather_kernel_roofline(eng, [tb.batch for tb in dev_batches], args)
             if "roofline" not in out:
                 out["roofline"] = out["roofline_gather_kernel"]

@@ -49,6 +49,22 @@ def _spec(kind):
         s.slots.append(CatSlot(name="C00_X_C03", kind="cross", num_buckets=11, deep=None, dim=0, wide=True,
                                cross_keys=[CrossKey("C00", "string"), CrossKey("C03", "string")]))
         return s, 3
+    if kind == "adam":          # Adam on both scopes: every row of this rank's shard moves every step, beta powers on the device
+        s = criteo_spec(n_dense=3, n_sparse=4, buckets=53, dim=8, hidden=(32, 16))
+        s.slots[3].deep, s.slots[3].dim = None, 0          # a wide-only column (rows behind the embedding rows)
+        s.dnn_opt, s.lin_opt = ("Adam", 0.01, 0.9, 0.999, 1e-8), ("Adam", 0.02, 0.9, 0.99, 1e-7)
+        return s, 2
+    if kind == "rmsprop":       # centered RMSProp (three slots) on the dnn scope, SGD on the linear one, mixed embedding widths
+        s = criteo_spec(n_dense=2, n_sparse=4, buckets=61, dim=16, hidden=(24, 12), mode="resnet")
+        for sl, d in zip(s.slots, (8, 16, 4, 16)):
+            sl.dim = d
+        s.dnn_opt, s.lin_opt = ("RMSProp", 0.01, 0.9, 0.1, 1e-10, True), ("SGD", 0.05)
+        return s, 2
+    if kind == "towers":        # multi-DNN (python/lib/dnn.py:260-274): two towers share the input layer, logits summed
+        from wide_deep_amd.plan import TowerSpec
+        s = criteo_spec(n_dense=3, n_sparse=4, buckets=101, dim=16, hidden=(32, 16))
+        s.towers = [TowerSpec([32, 16], "simple"), TowerSpec([24], "dense")]
+        return s, 2
     if kind == "multihot":
         return criteo_spec(n_dense=2, n_sparse=4, buckets=101, dim=16, hidden=(16, 8), mode="resnet"), 3
     if kind == "wideonly":
@@ -194,7 +210,7 @@ def test_exchange_overflow_is_reported():
     _run(_overflow_worker, "onehot")
 
 
-@pytest.mark.parametrize("kind", ["onehot", "multihot", "crosses", "crosses4", "wideonly", "deeponly", "chain", "chain_graph", "mixed", "indicator",
+@pytest.mark.parametrize("kind", ["onehot", "multihot", "crosses", "crosses4", "adam", "adam4", "rmsprop", "towers", "wideonly", "deeponly", "chain", "chain_graph", "mixed", "indicator",
                                   "onehot4", "chain4", "mixed4", "indicator4", "chain_dedup", "chain_graph_dedup", "chain_dedup4"])
 def test_sharded_world2_equals_single_engine(kind):
     """world 2, and (kinds ending in 4) world 4: four owners per table, three peers per all-to-all"""

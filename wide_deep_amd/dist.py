@@ -269,12 +269,13 @@ class ShardedWideDeepEngine(WideDeepEngine):
         # the owner keeps its LOCAL rows as records [emb | w z n - | pad] when the model is record-shaped (engine.py): a request
         # is answered from one 128-byte line, the update touches two lines per row (WD_ROW_RECORDS=0: separate tables)
         self._records_ok = not self.mixed_dims and not self.rep_idx       # (the small-table kernels take separate tables)
+        if self.dedup and not spec_default_opts(spec):
+            self.dedup = self._cap_from_unique = False      # (the sender-side unique works on row records: default optimizers)
         self._small_forced = list(self.rep_idx)
         super().__init__(local_spec(spec, W, keep=rep_names), max_batch=max_batch, max_nnz=max(mn, self.n_req), device=device,
                          seed=seed, expected_nnz=self.n_req, table_seed=int(seed) * 1000003 + 7919 * (self.rank + 1))
-        if not self.default_opts:
-            raise NotImplementedError("sharded engine: Adagrad (dnn) + Ftrl (linear) only; the other optimizers of "
-                                      "model_util.py:84-90 run on the single-GPU engine")
+        # any optimizer python/lib/utils/model_util.py:84-90 accepts on either scope: the defaults (Adagrad / Ftrl) keep their
+        # specialised kernels, the others take the generic owner update (wd_sparse_apply_opt) on separate tables
         self._segs = None
         self._work_c = None
         self._work_d = None
@@ -353,10 +354,17 @@ class ShardedWideDeepEngine(WideDeepEngine):
         self.oslot_dev = make_slots([dict(emb_off=0, row_base=0, num_buckets=max(self.n_emb_rows, 1), dim=self.dim,
                                           out_col=0, kind=capi.SLOT_EMBEDDING if has_emb else capi.SLOT_NONE, wide=1,
                                           bucket_shift=osh[0], bucket_base=0)])
+        # the local row space as two row ranges for wd_adam_untouched: rows with an embedding (padded to self.dim) + a wide line,
+        # then the rows of the wide-only columns
+        self.aslots_dev = make_slots([dict(emb_off=0 if has_emb else -1, row_base=0, num_buckets=max(self.n_emb_rows, 1) if has_emb else 0,
+                                           dim=self.dim, out_col=0, kind=capi.SLOT_EMBEDDING if has_emb else capi.SLOT_NONE, wide=1),
+                                      dict(emb_off=-1, row_base=self.n_emb_rows if has_emb else 0,
+                                           num_buckets=max(lp.total_rows - (self.n_emb_rows if has_emb else 0), 0), dim=0, out_col=0,
+                                           kind=capi.SLOT_NONE, wide=1)])
         # bias gradient = sum_b dlogit[b] = bias gradient of the logits layer -> rides in the flat all-reduce
         self._logits_b_off = self.towers[0]["metas"][-1]["b_off"] if spec.has_deep else None
-        if spec.has_deep and len(self.towers) != 1:
-            raise NotImplementedError("sharded engine: one tower")
+        # (several towers -- python/lib/dnn.py:260-274 -- share the input layer and every tower's logits bias sees the same
+        # gradient sum_b dlogit[b]: tower 0's rides for the linear bias)
         self._gsum = torch.zeros(1, **f32)
         # feature hashing happens in the GLOBAL id space (id = Fingerprint64 % global buckets); only then is an id split
         # into (owner, local row).  Batches are therefore built / hashed against global_plan + these descriptors.
@@ -371,15 +379,21 @@ class ShardedWideDeepEngine(WideDeepEngine):
     def _pad_tables(self):
         """Mixed embedding dims: re-lay the local tables (and the Adagrad accumulator) as [n_emb_rows][Dmax]."""
         lp, D, n = self.plan, self.dim, self.n_emb_rows
-        for name, fill in (("emb", 0.0), ("emb_acc", float(self.spec.dnn_opt[2]))):
-            old = getattr(self, name)
-            new = torch.full((max(n * D, 4),), fill, dtype=torch.float32, device=self.device)
+        from .plan import opt_slot_init
+        ia, ib = opt_slot_init(self.spec.dnn_opt)
+        for name, fill in (("emb", 0.0), ("emb_a", ia), ("emb_acc", ib), ("emb_c", 0.0)):
+            old = getattr(self, name, None)
+            if old is None:
+                continue
+            new = torch.full((max(n * D, 4),), float(fill), dtype=torch.float32, device=self.device)
             v = new[: n * D].view(n, D)
             for i in range(self.n_emb_slots):
                 s, r0 = lp.slots[i], lp.row_base[i]
                 v[r0: r0 + s.num_buckets, : s.dim] = old[lp.emb_off[i]: lp.emb_off[i] + s.num_buckets * s.dim].view(
                     s.num_buckets, s.dim)
             setattr(self, name, new)
+            if name == "emb_c" and "dnn" in self.opt_c:
+                self.opt_c["dnn"].slot_c = new.data_ptr()      # (the descriptor held the flat buffer's address)
         self._padded = True
 
     def _emb_view(self, buf, i):
@@ -639,12 +653,28 @@ class ShardedWideDeepEngine(WideDeepEngine):
         """Owner: dedup by row + Adagrad / FTRL on the received (row, gradient) list; bias handled elsewhere."""
         spec = self.spec
         has_emb = self.n_emb_slots > 0
-        lr, l1, l2 = (spec.lin_opt[1], spec.lin_opt[2], spec.lin_opt[3]) if spec.has_wide else (0.0, 0.0, 0.0)
+        lr, l1, l2 = (spec.lin_opt[1], spec.lin_opt[2], spec.lin_opt[3]) if (spec.has_wide and self.default_opts) else (0.0, 0.0, 0.0)
         g_ptr = self.bwd_recv.data_ptr()
         dl_ptr = g_ptr + 4 * (self.dim if has_emb else 0)
         ob = self._obsets[self._pset]
         if not bucketized:
             self._owner_bucketize(st)
+        if not self.default_opts:
+            # the generic optimizers (SGD / Adagrad / Ftrl with any lr_power / RMSProp / Adam) on the received (row, gradient) list;
+            # Adam moves every row of a sparsely updated variable (tf 1.x _apply_sparse_shared): the rows of this shard no request
+            # named are stepped by wd_adam_untouched (the touched bitmap is over LOCAL fused rows)
+            import ctypes
+            od = ctypes.byref(self.opt_c["dnn"]) if has_emb else None
+            ol = ctypes.byref(self.opt_c["linear"]) if spec.has_wide else None
+            call("wd_sparse_apply_opt", ptr(self.emb) if has_emb else None, ptr(self.emb_a) if has_emb else None,
+                 ptr(self.emb_acc) if has_emb else None, ptr(self.wide) if spec.has_wide else None, None, ptr(self.oslot_dev), 1,
+                 ptr(self.req_offs), self.n_req, g_ptr if has_emb else None, self.RS, dl_ptr if spec.has_wide else None, self.RS,
+                 od, ol, ptr(ob["start"]), ptr(ob["pairs"]), self.n_buckets, ptr(self.touched), st)
+            if self.pow:
+                call("wd_adam_untouched", ptr(self.emb) if (has_emb and "dnn" in self.pow) else None, ptr(self.emb_a),
+                     ptr(self.emb_acc), ptr(self.wide) if "linear" in self.pow else None, ptr(self.aslots_dev), 2,
+                     max(self.plan.total_rows, 1), max(self.plan.total_rows, 1), ptr(self.touched), od, ol, st)
+            return
         if self.rec is not None:
             call("wd_sparse_apply_rec", ptr(self.rec), self.rec_stride, self.dim, ptr(self.emb_acc), None, ptr(self.oslot_dev),
                  1, ptr(self.req_offs), self.n_req, g_ptr, self.RS, dl_ptr, self.RS, float(spec.dnn_opt[1]), float(lr),
@@ -668,14 +698,23 @@ class ShardedWideDeepEngine(WideDeepEngine):
         if not spec.has_wide:
             return
         # bias_weights: dense FTRL on the GLOBAL sum of dlogit
-        lr, l1, l2 = spec.lin_opt[1], spec.lin_opt[2], spec.lin_opt[3]
+        lr, l1, l2 = (spec.lin_opt[1], spec.lin_opt[2], spec.lin_opt[3]) if self.default_opts else (0.0, 0.0, 0.0)
         if self._logits_b_off is not None:
             gsum = self.G[self._logits_b_off: self._logits_b_off + 1]     # already all-reduced with G
         else:
             torch.sum(self.dlogit[:bt.B], dim=0, keepdim=True, out=self._gsum)
             self._collective(lambda: _all_reduce_sum(self._gsum, self.group))
             gsum = self._gsum
-        call("wd_bias_ftrl", ptr(self.bias), ptr(gsum), 1, float(lr), float(l1), float(l2), st)
+        if self.default_opts:
+            call("wd_bias_ftrl", ptr(self.bias), ptr(gsum), 1, float(lr), float(l1), float(l2), st)
+        else:       # bias_weights is a dense [1] variable of the linear scope: {w, slot a, slot b, slot c} = self.bias
+            import ctypes
+            ob = capi.WdOpt()
+            ctypes.memmove(ctypes.byref(ob), ctypes.byref(self.opt_c["linear"]), ctypes.sizeof(ob))
+            ob.slot_c = self.bias.data_ptr() + 12
+            self._bias_opt = ob
+            call("wd_opt_dense", self.bias.data_ptr(), self.bias.data_ptr() + 4, self.bias.data_ptr() + 8, ptr(gsum), 1,
+                 ctypes.byref(ob), st)
 
     def _sparse_backward(self, bt: DeviceBatch, st):
         self._grads_to_owners(bt, st)
@@ -744,13 +783,23 @@ class ShardedWideDeepEngine(WideDeepEngine):
                 self._work_d.wait()
                 self._work_d = None
         self._collective(wait_d)
-        if self._fold_at_end():
+        if not self.default_opts:
+            import ctypes
+            call("wd_opt_dense", ptr(self.P), ptr(self.Pa), ptr(self.Pacc), ptr(self.G), self.P.numel(),
+                 ctypes.byref(self.opt_c["dnn_dense"]), st)
+            if self._fold_at_end():
+                self._chain_tail(capi.WD_TAIL_PACK, st)      # the MFMA-packed kernels the next tower launch reads
+                self._folded = True
+        elif self._fold_at_end():
             # Adagrad on the all-reduced gradient + the MFMA-packed kernels the next tower launch reads, one launch
             self._chain_tail(capi.WD_TAIL_UPDATE | capi.WD_TAIL_PACK, st)
             self._folded = True
         else:
             call("wd_adagrad_dense", ptr(self.P), ptr(self.Pacc), ptr(self.G), self.P.numel(), float(self.spec.dnn_opt[1]), st)
         self._bias_update(bt, st)
+        for scope, pw in self.pow.items():     # Adam: beta1^t, beta2^t -> t + 1 (the base engine ticks them in backward_and_update)
+            o = self.spec.dnn_opt if scope == "dnn" else self.spec.lin_opt
+            call("wd_adam_tick", ptr(pw), float(o[2]), float(o[3]), st)
 
     def backward_and_update(self, bt: DeviceBatch, bucketized=False, pset=0, lookahead=None):
         """With the one-launch tower dx exists when forward() returns: the gradient exchange starts first and overlaps
@@ -856,8 +905,8 @@ class ShardedWideDeepEngine(WideDeepEngine):
                 need = shard_rows(v.shape[0], W)
                 if sh.shape[0] < need:   # ranks whose last local row does not exist globally: pad (never addressed)
                     pad = torch.zeros((need - sh.shape[0],) + tuple(v.shape[1:]), dtype=v.dtype)
-                    if k.endswith("/Adagrad") or k.endswith("/Ftrl"):
-                        pad += 0.1
+                    if k.endswith("/Adagrad") or k.endswith("/Ftrl") or k.endswith("/RMSProp"):
+                        pad += 0.1          # (rows that exist on no rank's id space: never addressed; any positive accumulator)
                     sh = torch.cat([sh, pad], 0)
                 sub[k] = sh.contiguous()
             else:
@@ -886,7 +935,11 @@ class ShardedWideDeepEngine(WideDeepEngine):
             full_rows["linear/linear_model/%s/weights" % s.name] = s.num_buckets
         for k in sorted(local):
             v = local[k]
-            base = k.replace("/Adagrad", "").replace("/Ftrl_1", "").replace("/Ftrl", "")
+            base = k
+            for suf in ("/Adagrad", "/Ftrl_1", "/Ftrl", "/RMSProp_2", "/RMSProp_1", "/RMSProp", "/Adam_1", "/Adam"):
+                if base.endswith(suf):
+                    base = base[: -len(suf)]
+                    break
             if base in full_rows:
                 if dist.get_backend(self.group) != "gloo":
                     v = v.to(self.device)                       # RCCL moves device tensors only

@@ -249,9 +249,10 @@ class WideAndDeepClassifier(object):
             want = {}
             for k, shape in self._engine.state_shapes().items():
                 base = k
-                for suf in ("/Adagrad", "/Ftrl_1", "/Ftrl"):
+                for suf in ("/Adagrad", "/Ftrl_1", "/Ftrl", "/RMSProp_2", "/RMSProp_1", "/RMSProp", "/Adam_1", "/Adam"):
                     if base.endswith(suf):
                         base = base[: -len(suf)]
+                        break
                 if base in rows:
                     shape = (rows[base],) + shape[1:]
                 want[k] = shape

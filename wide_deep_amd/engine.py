@@ -1330,7 +1330,7 @@ class WideDeepEngine:
                 self._fold(False, st)
                 self._folded = True
 
-    def backward_and_update(self, bt: DeviceBatch, bucketized=False, pset=0, lookahead=None):
+    def backward_and_update(self, bt: DeviceBatch, bucketized=False, pset=0, lookahead=None, before_join=None):
         spec, st = self.spec, _stream()
         B = bt.B
         has_emb = bool(self.group_slots) if spec.has_deep else False
@@ -1357,6 +1357,12 @@ class WideDeepEngine:
                 # (32 KB of LDS) find no CU the tower's workgroup has left room on, and the row update waits for them:
                 # profiles/r5_c4_nocross_step_timeline_before.txt, scatter 8 -> 212 us, update from 218
                 self._sparse_bucketize(lookahead[0], st, lookahead[1])
+            if before_join is not None:
+                # what the caller wants launched on this stream while the row update still runs on the side stream -- the
+                # featurizer of the NEXT batch (pipeline.StepGraph: configs[3]'s update is 270 us, this stream idles for the last
+                # 100 of them, and a featurizer launched behind the join sat on the critical path: profiles/r6_c4_tokens_timeline_before.txt)
+                before_join()
+                before_join = None
             torch.cuda.current_stream().wait_stream(side)
         elif lookahead is not None:
             raise ValueError("train_step(lookahead=): needs the update on the side stream (lookahead_ok)")
@@ -1365,6 +1371,8 @@ class WideDeepEngine:
             self._sparse_backward(bt, st, bucketized=True, pset=pset)
         else:
             self._sparse_backward(bt, st)
+        if before_join is not None:
+            before_join()
         if self.dropout:
             call("wd_counter_tick", ptr(self.drop_seed), st)   # next step draws a new mask
         for scope, pw in self.pow.items():     # Adam: beta1^t, beta2^t -> t + 1 (AdamOptimizer._finish)
@@ -1379,11 +1387,12 @@ class WideDeepEngine:
         return bool(type(self) is WideDeepEngine and getattr(self, "chain", False) and self.overlap_bucket and self._has_sparse_update()
                     and not self._bucket_onehot_ok(bt) and not self._small_on(bt) and os.environ.get("WD_SPARSE_SIDE", "1") == "1")
 
-    def train_step(self, bt: DeviceBatch, pset=None, lookahead=None):
+    def train_step(self, bt: DeviceBatch, pset=None, lookahead=None, before_join=None):
         """One step of python/lib/joint.py:224-262: forward, batch-SUM loss, both optimizers.
         pset: this batch's occurrences are already bucketed, in scratch set `pset` (by the previous step's `lookahead`);
         lookahead = (next batch, scratch set): bucket that batch's occurrences behind this step's dense tail, while the row update
-        runs on the side stream -- pipeline.StepGraph, for batches `lookahead_ok`."""
+        runs on the side stream -- pipeline.StepGraph, for batches `lookahead_ok`.  before_join: launches for this stream that do not
+        depend on the step (the next batch's featurizer), issued before the step joins its row update."""
         if bt.labels is None:
             raise ValueError("train_step needs labels")
         bucketized = False
@@ -1395,7 +1404,7 @@ class WideDeepEngine:
             self._sparse_bucketize(bt, side.cuda_stream)
             bucketized = True
         self.forward(bt, need_loss=True)
-        self.backward_and_update(bt, bucketized=bucketized, pset=pset or 0, lookahead=lookahead)
+        self.backward_and_update(bt, bucketized=bucketized, pset=pset or 0, lookahead=lookahead, before_join=before_join)
         # the reference bumps global_step once per minimize() plus the explicit assign_add (quirk C.4)
         self.global_step += 3 if self.spec.model_type == "wide_deep" else 2
         return self.loss

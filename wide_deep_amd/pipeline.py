@@ -109,8 +109,19 @@ class StepGraph:
         look = (os.environ.get("WD_LOOKAHEAD", "1") != "0" and hasattr(eng, "lookahead_ok")
                 and all(eng.lookahead_ok(tb.batch) and tb.batch.labels is not None for tb in tbs))
         if not look:
-            for tb in tbs:
-                step_eager(eng, tb, ids_input)
+            # the tokens -> ids work of batch t+1 (hash buckets; crossed columns: features.Featurizer.run, ~50 us at configs[3]) goes
+            # INTO step t, behind its dense tail / small tables and in front of the join with its row update: this stream idles
+            # there, and launched behind the join the featurizer sat between two steps (0.598 -> 0.55 ms at configs[3] from tokens)
+            ahead = (not ids_input and type(eng) is WideDeepEngine and os.environ.get("WD_HASH_AHEAD", "1") != "0"
+                     and all(tb.batch.labels is not None for tb in tbs))
+            if not ahead:
+                for tb in tbs:
+                    step_eager(eng, tb, ids_input)
+                return
+            synth.hash_tokens(eng, tbs[0])
+            for t, tb in enumerate(tbs):
+                nxt = tbs[t + 1] if t + 1 < len(tbs) else None
+                eng.train_step(tb.batch, before_join=(lambda nxt=nxt: synth.hash_tokens(eng, nxt)) if nxt is not None else None)
             return
         main = torch.cuda.current_stream()
         keep = self._events = []

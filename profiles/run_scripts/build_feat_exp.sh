@@ -8,7 +8,7 @@ OUT="$HERE/../_lib"
 for e in "$@"; do
   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -DFE_EXP=$e -c "$HERE/hash.hip" -o "$HERE/_obj/hash_fe$e.o"
   objs=""
-  for f in build_stamp common embag sparse_update sparse_fused small_tables onehot_path dist_exchange mlp mlp_tn mlp_half mlp_chain mlp_chain8; do objs="$objs $HERE/_obj/$f.o"; done
+  for f in build_stamp common embag sparse_update sparse_fused small_tables onehot_path dist_exchange mlp mlp_half mlp_chain mlp_chain8; do objs="$objs $HERE/_obj/$f.o"; done
   hipcc --offload-arch=gfx950 -shared -fPIC $objs "$HERE/_obj/hash_fe$e.o" -o "$OUT/libwd_hip_fe_$e.so"
   echo "built $OUT/libwd_hip_fe_$e.so"
 done

@@ -12,7 +12,7 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "wide_deep_amd", "csrc")
-FILES = ["hash", "embag", "sparse_update", "sparse_fused", "small_tables", "onehot_path", "dist_exchange", "mlp", "mlp_tn", "mlp_half",
+FILES = ["hash", "embag", "sparse_update", "sparse_fused", "small_tables", "onehot_path", "dist_exchange", "mlp", "mlp_half",
          "mlp_chain", "mlp_chain8"]
 
 

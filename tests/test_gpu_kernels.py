@@ -202,23 +202,13 @@ def test_gemm_variants_match_torch_fp32():
             assert_close(G[K], dZ.double().sum(0), 1e-5, 2e-4, "TN ones row")
 
 
-@pytest.mark.parametrize("stream", ["1", "0"])
-def test_grouped_weight_gradient_products_streamed_and_tiled(stream):
-    """wd_gemm_tn_splitk_group in a process of its own with WD_TN_STREAM set (the library reads it once): see _tn_group_check."""
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, "-c", "import sys; sys.path.insert(0, %r); from tests.test_gpu_kernels import _tn_group_check; "
-                        "_tn_group_check(); print('TN-GROUP-OK')" % root], capture_output=True, text=True, timeout=600, cwd=root,
-                       env=dict(os.environ, WD_TN_STREAM=stream))
-    assert r.returncode == 0 and "TN-GROUP-OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+def test_grouped_weight_gradient_products():
+    _tn_group_check()
 
 
 def _tn_group_check():
-    """wd_gemm_tn_splitk_group: the register-streamed kernel (csrc/mlp_tn.hip) on operands it can read as MFMA fragments -- even row
-    strides, odd widths, ragged last tiles, batches that are not a multiple of 16 or of 2, more splits than sets -- against fp64
-    torch, with column-sum jobs in the same launch, and the LDS-tiled kernel on what the streamed one refuses (odd strides)."""
+    """wd_gemm_tn_splitk_group: even and odd row strides, odd widths, ragged last tiles, batches that are not a multiple of 16 or of
+    2, many splits -- against fp64 torch, with column-sum jobs in the same launch."""
     import ctypes
     from wide_deep_amd import capi
     from wide_deep_amd.capi import call, ptr

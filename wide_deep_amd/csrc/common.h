@@ -159,10 +159,6 @@ __device__ __forceinline__ void tail_element(const wd_tail_layer_t &L, const Tai
   tail_apply(L, c, idx, e < nW ? e : -1, gv, c.P[idx], upd ? c.Pacc[idx] : 0.f, grad, upd, pack);
 }
 
-// mlp_tn.hip: the grouped weight-gradient products as register-streamed MFMA products.  > 0: the group is not eligible (the
-// caller runs the LDS-tiled kernel of mlp.hip), 0: launched, < 0: error
-int tn_stream_launch(const wd_tn_job_t *jobs, int32_t njobs, wd_stream_t stream);
-
 }  // namespace wd
 
 #define WD_REQUIRE(cond, msg)                 \

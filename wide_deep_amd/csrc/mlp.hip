@@ -1111,10 +1111,8 @@ extern "C" int wd_gemm_tn_splitk_group(const wd_tn_job_t *jobs, int32_t njobs, w
   if (njobs <= 0) return WD_OK;
   WD_REQUIRE(jobs, "null pointer");
   WD_REQUIRE(njobs <= MAX_TN_JOBS, "njobs <= WD_TN_GROUP_MAX");
-  {   // fp32 products whose operands can be read as MFMA fragments straight from HBM: the register-streamed kernel (mlp_tn.hip)
-    const int rc = wd::tn_stream_launch(jobs, njobs, stream);
-    if (rc <= 0) return rc;
-  }
+  // (round 5's register-streamed variant of these products -- 35-38 us alone against 41-45, no faster in the step, where the
+  // row update beside it sets the pace -- was removed in round 6: profiles/r5_products_stream.md)
   GroupArgs G{};
   bool vec = true;
   int total = 0;

@@ -801,19 +801,21 @@ class ShardedWideDeepEngine(WideDeepEngine):
             o = self.spec.dnn_opt if scope == "dnn" else self.spec.lin_opt
             call("wd_adam_tick", ptr(pw), float(o[2]), float(o[3]), st)
 
-    def backward_and_update(self, bt: DeviceBatch, bucketized=False, pset=0, lookahead=None):
+    def backward_and_update(self, bt: DeviceBatch, bucketized=False, pset=0, lookahead=None, before_join=None):
         """With the one-launch tower dx exists when forward() returns: the gradient exchange starts first and overlaps
         with the dense branch (weight-gradient GEMMs, all-reduce, dense tail)."""
         spec, st = self.spec, _stream()
         if self._bucketized:
             torch.cuda.current_stream().wait_stream(self._side(0))     # the early bucketing (see _sparse_exchange)
         if not (spec.has_deep and self.chain):
-            return super().backward_and_update(bt, False)
+            return super().backward_and_update(bt, False, before_join=before_join)
         self._grads_to_owners(bt, st)
         self._dense_tail(bt, st)         # D (all-reduce of the flat dense gradient) in the background of the owners' update
         self._owner_update(bt, st, do_bias=False)
         self._replicated_update(bt, st)
         self._dense_finish(bt, st)
+        if before_join is not None:
+            before_join()
 
     def train_step(self, bt: DeviceBatch):
         self._train_fwd = True
@@ -996,6 +998,8 @@ class ShardedStepGraph:
         self._bump = (3 if eng.spec.model_type == "wide_deep" else 2) * self.n
 
     def _capture(self, tbs, ids_input, synth):
+        # (a third layout with the whole chain B -> tower -> pack -> A -> C -> owner update on the main branch was measured in round 6
+        # and removed: 0.2818 against 0.2636 ms/step, profiles/r6_sharded_layout_v3_experiment.txt)
         if os.environ.get("WD_SHARD_LAYOUT", "v2") == "v2" and os.environ.get("WD_SHARD_PIPE", "1") != "0":
             return self._capture_v2(tbs, ids_input, synth)
         eng = self.eng

@@ -491,16 +491,6 @@ class WideDeepEngine:
         for nm in ("db", "dg", "dbeta"):
             tw[nm + "_part"] = [torch.zeros(ntile * metas[l]["N"], **f32) for l in range(L)]
             tw[nm + "_sum"] = [torch.zeros(metas[l]["N"], **f32) for l in range(L)]
-        # WD_TN_STREAM=1: the register-streamed weight-gradient products (csrc/mlp_tn.hip: one workgroup = one 64 x 64 tile of one
-        # layer over one slice of the batch, its four wavefronts a quarter of the slice each) take ONE slicing for all layers:
-        # as many slices as give every CU two workgroups, at most 16 partials for the dense tail to sum, >= 64 examples each
-        if os.environ.get("WD_TN_STREAM", "0") != "0" or "WD_TN_SPLIT" in os.environ:
-            tiles = sum(math.ceil(metas[l]["K"] / 64) * math.ceil(metas[l]["N"] / 64) for l in range(L))
-            ns = max(1, min(16, (2 * 256) // max(tiles, 1), B // 64))
-            ns = int(os.environ.get("WD_TN_SPLIT", ns))
-            for l in range(L):
-                tw["nsplit"][l] = ns
-                tw["Gpart"][l] = torch.zeros(ns * (metas[l]["K"] + 1) * metas[l]["N"], **f32)
         # logits-layer gradient partials: one per row tile
         ns = ntile
         tw["nsplit"][L] = ns

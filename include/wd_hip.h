@@ -807,7 +807,9 @@ int wd_fill_f32(float *p, float v, int64_t n, wd_stream_t stream);
  * multi-valued keys (python/lib/build_estimator.py:138-155: a bag holds the product of its keys' counts), their
  * embedding_column(combiner='mean') and linear_model weight, Adagrad / Ftrl with IndexedSlices semantics (joint.py:224-262).
  * small_idx[nsmall]: slot numbers (device); max_rows / max_dim over those slots, max_rows * (max_dim + 2) <=
- * WD_SMALL_MAX_FLOATS, max_dim <= 16.  Separate tables only (emb flat, wide [rows][4] = {w, z, n, -}).
+ * WD_SMALL_MAX_FLOATS, max_dim <= 16.  rec_stride 0: separate tables (emb flat at the slot's emb_off, wide [rows][4] = {w, z, n, -});
+ * rec_stride > 0 (round 6): row records -- `emb` = the record table, row r of a slot at (row_base + r) * rec_stride, `wide` = the
+ * {w, z, n, -} part of record 0 (same stride); the Adagrad accumulator stays flat (the slot's emb_off) in both.
  *   wd_small_tables_fwd: x[b][out_col ..] = mean of the bag's rows; wide_logit[b] += sum of the bag's wide weights -- call it
  *     BEHIND wd_wide_fwd on the same stream (that launch writes bias + the other columns).
  *   wd_small_tables_bwd: per slot, count x (dx / len | dlogit) summed per row in ascending example order (integer histograms in
@@ -818,11 +820,11 @@ int wd_fill_f32(float *p, float v, int64_t n, wd_stream_t stream);
 int64_t wd_small_tables_ws_floats(int32_t nsmall, int32_t max_rows, int32_t max_dim, int64_t max_batch);
 int wd_small_tables_fwd(const float *emb, const float *wide, const wd_slot_t *slots, int32_t S, const int32_t *small_idx,
                         int32_t nsmall, int32_t max_rows, int32_t max_dim, const int32_t *ids, const int32_t *bag_offs,
-                        int64_t batch, float *x, int64_t ldx, float *wide_logit, wd_stream_t stream);
+                        int64_t batch, float *x, int64_t ldx, float *wide_logit, int32_t rec_stride, wd_stream_t stream);
 int wd_small_tables_bwd(float *emb, float *emb_accum, float *wide_wzn, const wd_slot_t *slots, int32_t S,
                         const int32_t *small_idx, int32_t nsmall, int32_t max_rows, int32_t max_dim, const int32_t *ids,
                         const int32_t *bag_offs, int64_t batch, const float *dx, int64_t ldx, const float *dlogit, float lr_emb,
-                        float lr_wide, float l1, float l2, float *ws, int64_t ws_floats, wd_stream_t stream);
+                        float lr_wide, float l1, float l2, float *ws, int64_t ws_floats, int32_t rec_stride, wd_stream_t stream);
 /* The same update in two halves, for tables REPLICATED on every rank of a row-sharded model (a 200-row crossed column is not
  * worth an all-to-all; the reference's parameter server would hold it on one task, python/lib/joint.py:140-143):
  *   wd_small_tables_grad: this rank's sums -- gsum[nsmall][max_rows][max_dim + 2] = per row g_0 .. g_{D-1}, g_wide, hit count of
@@ -833,7 +835,7 @@ int wd_small_tables_grad(const wd_slot_t *slots, int32_t S, const int32_t *small
                          const float *dlogit, float *ws, int64_t ws_floats, float *gsum, wd_stream_t stream);
 int wd_small_tables_apply(float *emb, float *emb_accum, float *wide_wzn, const wd_slot_t *slots, int32_t S,
                           const int32_t *small_idx, int32_t nsmall, int32_t max_rows, int32_t max_dim, const float *gsum,
-                          float lr_emb, float lr_wide, float l1, float l2, wd_stream_t stream);
+                          float lr_emb, float lr_wide, float l1, float l2, int32_t rec_stride, wd_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -47,7 +47,15 @@ struct SmallArgs {
   // apply
   float *emb_w, *emb_acc, *wide_w;
   float lr_emb, lr_w, l1, l2;
+  // table layout: separate tables (es == 0: row r of a slot at emb + emb_off + r * D; wide line at wide + (row_base + r) * 4) or
+  // row records (engine.py: es = ws = the record stride; row at emb + (row_base + r) * es, wide line at wide + (row_base + r) * ws,
+  // `wide` pointing at the {w, z, n, -} part of record 0); the Adagrad accumulator is flat in both
+  int64_t es, ws;
 };
+
+__device__ __forceinline__ int64_t sm_row(const SmallArgs &a, const wd_slot_t &sl, int r, int D) {
+  return a.es ? (sl.row_base + r) * a.es : sl.emb_off + (int64_t)r * D;
+}
 
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
@@ -71,10 +79,15 @@ __global__ void __launch_bounds__(256) k_small_fwd(SmallArgs a) {
     const int R = uni(sl.num_buckets), D = uni(sl.dim);
     float *T = lds, *W = lds + (int64_t)R * D;
     __syncthreads();                         // the previous slot's table is no longer read
-    if (D > 0)
-      for (int i = t; i < R * D; i += 256) T[i] = a.emb[sl.emb_off + i];
+    if (D > 0) {
+      if (a.es) {
+        for (int i = t; i < R * D; i += 256) T[i] = a.emb[sm_row(a, sl, i / D, D) + i % D];
+      } else {
+        for (int i = t; i < R * D; i += 256) T[i] = a.emb[sl.emb_off + i];
+      }
+    }
     if (sl.wide)
-      for (int i = t; i < R; i += 256) W[i] = a.wide[(sl.row_base + i) * 4];
+      for (int i = t; i < R; i += 256) W[i] = a.wide[(sl.row_base + i) * a.ws];
     __syncthreads();
     any_wide = any_wide || sl.wide;
 #pragma unroll
@@ -248,11 +261,11 @@ __global__ void __launch_bounds__(256) k_small_apply(SmallArgs a) {
     const int64_t o = sl.emb_off + (int64_t)r * D + d;
     const float acc = a.emb_acc[o] + g * g;
     a.emb_acc[o] = acc;
-    a.emb_w[o] -= a.lr_emb * g / sqrtf(acc);
+    a.emb_w[sm_row(a, sl, r, D) + d] -= a.lr_emb * g / sqrtf(acc);
   } else if (sl.wide && a.wide_w) {
-    float4 q = *reinterpret_cast<float4 *>(a.wide_w + (sl.row_base + r) * 4);
+    float4 q = *reinterpret_cast<float4 *>(a.wide_w + (sl.row_base + r) * a.ws);
     ftrl1(q.x, q.y, q.z, g, a.lr_w, a.l1, a.l2);
-    *reinterpret_cast<float4 *>(a.wide_w + (sl.row_base + r) * 4) = q;
+    *reinterpret_cast<float4 *>(a.wide_w + (sl.row_base + r) * a.ws) = q;
   }
 }
 
@@ -299,11 +312,11 @@ __global__ void __launch_bounds__(256) k_small_apply_sum(SmallArgs a, const floa
     const int64_t o = sl.emb_off + (int64_t)r * D + d;
     const float acc = a.emb_acc[o] + g * g;
     a.emb_acc[o] = acc;
-    a.emb_w[o] -= a.lr_emb * g / sqrtf(acc);
+    a.emb_w[sm_row(a, sl, r, D) + d] -= a.lr_emb * g / sqrtf(acc);
   } else if (sl.wide && a.wide_w) {
-    float4 q = *reinterpret_cast<float4 *>(a.wide_w + (sl.row_base + r) * 4);
+    float4 q = *reinterpret_cast<float4 *>(a.wide_w + (sl.row_base + r) * a.ws);
     ftrl1(q.x, q.y, q.z, g, a.lr_w, a.l1, a.l2);
-    *reinterpret_cast<float4 *>(a.wide_w + (sl.row_base + r) * 4) = q;
+    *reinterpret_cast<float4 *>(a.wide_w + (sl.row_base + r) * a.ws) = q;
   }
 }
 
@@ -331,8 +344,9 @@ static int small_check(const wd_slot_t *slots, const int32_t *small_idx, int32_t
 extern "C" int wd_small_tables_fwd(const float *emb, const float *wide, const wd_slot_t *slots, int32_t S,
                                    const int32_t *small_idx, int32_t nsmall, int32_t max_rows, int32_t max_dim,
                                    const int32_t *ids, const int32_t *bag_offs, int64_t batch, float *x, int64_t ldx,
-                                   float *wide_logit, wd_stream_t stream) {
+                                   float *wide_logit, int32_t rec_stride, wd_stream_t stream) {
   if (batch <= 0 || nsmall <= 0) return WD_OK;
+  WD_REQUIRE(rec_stride >= 0 && rec_stride % 4 == 0, "rec_stride: 0 (separate tables) or the record stride in floats");
   const int rc = small_check(slots, small_idx, nsmall, max_rows, max_dim);
   if (rc != WD_OK) return rc;
   WD_REQUIRE(ids && bag_offs, "null pointer");
@@ -340,6 +354,7 @@ extern "C" int wd_small_tables_fwd(const float *emb, const float *wide, const wd
   SmallArgs a{};
   a.slots = slots; a.small_idx = small_idx; a.nsmall = nsmall; a.S = S; a.ids = ids; a.bag_offs = bag_offs; a.batch = batch;
   a.emb = emb; a.wide = wide; a.x = x; a.ldx = ldx; a.wide_logit = wide_logit;
+  a.es = rec_stride; a.ws = rec_stride ? rec_stride : 4;
   const size_t lds = (size_t)max_rows * (max_dim + 1) * 4;
   hipLaunchKernelGGL(k_small_fwd, dim3((unsigned)wd::ceil_div(batch, (int64_t)SM_EX_PER_WG)), dim3(256), lds,
                      wd::as_stream(stream), a);
@@ -349,7 +364,7 @@ extern "C" int wd_small_tables_fwd(const float *emb, const float *wide, const wd
 static int small_bwd_args(SmallArgs &a, size_t &lds, float *emb, float *emb_accum, float *wide_wzn, const wd_slot_t *slots, int32_t S,
                           const int32_t *small_idx, int32_t nsmall, int32_t max_rows, int32_t max_dim, const int32_t *ids,
                           const int32_t *bag_offs, int64_t batch, const float *dx, int64_t ldx, const float *dlogit, float lr_emb,
-                          float lr_wide, float l1, float l2, float *ws, int64_t ws_floats) {
+                          float lr_wide, float l1, float l2, float *ws, int64_t ws_floats, int32_t rec_stride = 0) {
   const int rc = small_check(slots, small_idx, nsmall, max_rows, max_dim);
   if (rc != WD_OK) return rc;
   WD_REQUIRE(ids && bag_offs && ws, "null pointer");
@@ -364,6 +379,7 @@ static int small_bwd_args(SmallArgs &a, size_t &lds, float *emb, float *emb_accu
   WD_REQUIRE((int64_t)nsmall * a.nslice * max_rows * (max_dim + 2) <= ws_floats, "workspace too small (wd_small_tables_ws_floats)");
   a.emb_w = emb; a.emb_acc = emb_accum; a.wide_w = wide_wzn;
   a.lr_emb = lr_emb; a.lr_w = lr_wide; a.l1 = l1; a.l2 = l2;
+  a.es = rec_stride; a.ws = rec_stride ? rec_stride : 4;
   lds = (size_t)max_rows * (max_dim + 2) * 4 + (size_t)2 * max_rows * 4 + (size_t)2 * SM_SLICE * 4 +
         (size_t)SM_SLICE * (SM_MAX_DIM + 1) * 4;
   // a wide-only table of ~4 k rows asks for 32 KB of partials + 32 KB of histograms + staging: beyond the 64 KB a launch gets
@@ -382,12 +398,13 @@ extern "C" int wd_small_tables_bwd(float *emb, float *emb_accum, float *wide_wzn
                                    const int32_t *small_idx, int32_t nsmall, int32_t max_rows, int32_t max_dim,
                                    const int32_t *ids, const int32_t *bag_offs, int64_t batch, const float *dx, int64_t ldx,
                                    const float *dlogit, float lr_emb, float lr_wide, float l1, float l2, float *ws,
-                                   int64_t ws_floats, wd_stream_t stream) {
+                                   int64_t ws_floats, int32_t rec_stride, wd_stream_t stream) {
   if (batch <= 0 || nsmall <= 0) return WD_OK;
+  WD_REQUIRE(rec_stride >= 0 && rec_stride % 4 == 0, "rec_stride: 0 (separate tables) or the record stride in floats");
   SmallArgs a;
   size_t lds;
   const int rc = small_bwd_args(a, lds, emb, emb_accum, wide_wzn, slots, S, small_idx, nsmall, max_rows, max_dim, ids, bag_offs, batch,
-                                dx, ldx, dlogit, lr_emb, lr_wide, l1, l2, ws, ws_floats);
+                                dx, ldx, dlogit, lr_emb, lr_wide, l1, l2, ws, ws_floats, rec_stride);
   if (rc != WD_OK) return rc;
   hipStream_t st = wd::as_stream(stream);
   hipLaunchKernelGGL(k_small_bwd, dim3((unsigned)a.nslice, (unsigned)nsmall), dim3(256), lds, st, a);
@@ -421,7 +438,7 @@ extern "C" int wd_small_tables_grad(const wd_slot_t *slots, int32_t S, const int
 
 extern "C" int wd_small_tables_apply(float *emb, float *emb_accum, float *wide_wzn, const wd_slot_t *slots, int32_t S,
                                      const int32_t *small_idx, int32_t nsmall, int32_t max_rows, int32_t max_dim, const float *gsum,
-                                     float lr_emb, float lr_wide, float l1, float l2, wd_stream_t stream) {
+                                     float lr_emb, float lr_wide, float l1, float l2, int32_t rec_stride, wd_stream_t stream) {
   if (nsmall <= 0) return WD_OK;
   const int rc = small_check(slots, small_idx, nsmall, max_rows, max_dim);
   if (rc != WD_OK) return rc;
@@ -431,6 +448,7 @@ extern "C" int wd_small_tables_apply(float *emb, float *emb_accum, float *wide_w
   a.part_rows = max_rows; a.part_w = max_dim + 2;
   a.emb_w = emb; a.emb_acc = emb_accum; a.wide_w = wide_wzn;
   a.lr_emb = lr_emb; a.lr_w = lr_wide; a.l1 = l1; a.l2 = l2;
+  a.es = rec_stride; a.ws = rec_stride ? rec_stride : 4;
   hipLaunchKernelGGL(k_small_apply_sum, dim3((unsigned)wd::ceil_div((int64_t)max_rows * (max_dim + 1), (int64_t)256), (unsigned)nsmall),
                      dim3(256), 0, wd::as_stream(stream), a, gsum);
   return wd::check_launch("wd_small_tables_apply");

@@ -609,7 +609,7 @@ class ShardedWideDeepEngine(WideDeepEngine):
             call("wd_small_tables_fwd", ptr(self.emb) if spec.has_deep else None, ptr(self.wide) if spec.has_wide else None,
                  ptr(self.slots_dev), S, ptr(self.small_idx_dev), len(self.small_idx), self.small_rows, self.small_dim,
                  ptr(bt.ids), ptr(bt.bag_offs), B, self._x_ptr(self.towers[0]) if spec.has_deep else None,
-                 self.towers[0]["layout"].ld if spec.has_deep else 0, ptr(self.wide_logit) if spec.has_wide else None, st)
+                 self.towers[0]["layout"].ld if spec.has_deep else 0, ptr(self.wide_logit) if spec.has_wide else None, 0, st)
 
     def _reduce_dense_grads(self):
         self._collective(lambda: _all_reduce_sum(self.G, self.group))
@@ -765,7 +765,7 @@ class ShardedWideDeepEngine(WideDeepEngine):
         lr, l1, l2 = (spec.lin_opt[1], spec.lin_opt[2], spec.lin_opt[3]) if spec.has_wide else (0.0, 0.0, 0.0)
         call("wd_small_tables_apply", ptr(self.emb) if has_emb else None, ptr(self.emb_acc) if has_emb else None,
              ptr(self.wide) if spec.has_wide else None, ptr(self.slots_dev), lp.S, ptr(self.small_idx_dev), n, self.small_rows,
-             self.small_dim, ptr(self.small_g), float(spec.dnn_opt[1]) if spec.has_deep else 0.0, float(lr), float(l1), float(l2), st)
+             self.small_dim, ptr(self.small_g), float(spec.dnn_opt[1]) if spec.has_deep else 0.0, float(lr), float(l1), float(l2), 0, st)
 
     def _dense_tail(self, bt, st):
         """Products -> this rank's dense gradient -> D (all-reduce) -> Adagrad + the packed kernels of the next step."""

@@ -82,12 +82,24 @@ class WideDeepEngine:
         # ONE 32 / 64 / 128-byte record, so that the forward finds the wide weight in the line it fetched for the row and the
         # update touches two random lines per row (record + accumulator) instead of three (profiles/r2z_layouts.txt).
         # row_records=None: on when eligible (WD_ROW_RECORDS=0 turns it off); True: required; False: separate tables.
-        dims = sorted(plan.emb_groups) if spec.has_deep else []
+        # Round 6: the small tables of csrc/small_tables.hip (crossed columns) may be narrower than the record -- they sit in records
+        # of the big columns' width ([emb d <= D | pad | w z n - | pad]; the small-table kernels take the record stride), so a model
+        # like BASELINE configs[3] (26 columns of width 16 + two crossed columns of width 4) is record-shaped too: its multi-hot
+        # gather and its row update touch one line less per row (profiles/r2z_layouts.txt: 3 tables -> 2, -17 % on the update).
+        forced = getattr(self, "_small_forced", None)
+        small0 = (list(forced) if forced is not None else
+                  small_table_slots(plan.slots, spec.has_deep, spec.has_wide, capi.SMALL_MAX_FLOATS, os.environ.get("WD_SMALL_TABLES", "cross"))
+                  if type(self) is WideDeepEngine else [])
+        big = [i for i in range(plan.S) if i not in small0]
+        dims = sorted({int(plan.slots[i].dim) for i in big if plan.slots[i].deep == "embedding"}) if spec.has_deep else []
         # (the row-sharded engine lays its LOCAL rows out the same way: dist.py sets _records_ok before it gets here)
         eligible = (spec.has_deep and spec.has_wide and self.default_opts
                     and getattr(self, "_records_ok", type(self) is WideDeepEngine)
-                    and len(dims) == 1 and dims[0] in (4, 8, 16) and plan.n_emb == plan.S and plan.S > 0
-                    and all(sl.wide for sl in plan.slots))
+                    and len(dims) == 1 and dims[0] in (4, 8, 16) and plan.S > 0 and len(big) > 0
+                    and all(plan.slots[i].deep == "embedding" and plan.slots[i].wide for i in big)
+                    and all(plan.slots[i].wide and (plan.slots[i].deep in ("embedding", None))
+                            and (plan.slots[i].deep is None or int(plan.slots[i].dim) <= dims[0]) for i in small0)
+                    and (not small0 or os.environ.get("WD_SMALL_RECORDS", "1") != "0"))
         if row_records and not eligible:
             raise ValueError("row_records=True: the model is not record-shaped (one embedding width in {4, 8, 16} on every "
                              "categorical column, all of them wide columns too, Adagrad + Ftrl)")
@@ -137,11 +149,7 @@ class WideDeepEngine:
         # the reference's default optimizers, one GPU.  WD_SMALL_TABLES=0: off; =all: every column that fits, crossed or not.
         # (row-sharded ranks, dist.py: these columns are REPLICATED instead of exchanged -- the set is fixed before the local
         # model exists, `_small_forced`)
-        mode = os.environ.get("WD_SMALL_TABLES", "cross")
-        forced = getattr(self, "_small_forced", None)
-        self.small_idx = (list(forced) if forced is not None else
-                          small_table_slots(plan.slots, spec.has_deep, spec.has_wide, capi.SMALL_MAX_FLOATS, mode)
-                          if type(self) is WideDeepEngine else [])
+        self.small_idx = small0
         self.slots_small_dev = self.small_idx_dev = self.small_ws = None
         if self.small_idx:
             for i in self.small_idx:
@@ -778,12 +786,14 @@ class WideDeepEngine:
             call("wd_small_tables_fwd", ptr(self.emb) if spec.has_deep else None, ptr(self.wide) if spec.has_wide else None,
                  ptr(self.slots_dev), S, ptr(self.small_idx_dev), len(self.small_idx), self.small_rows, self.small_dim,
                  ptr(bt.ids), ptr(bt.bag_offs), B, self._x_ptr(self.towers[0]) if spec.has_deep else None,
-                 self.towers[0]["layout"].ld if spec.has_deep else 0, ptr(self.wide_logit) if spec.has_wide else None, st)
+                 self.towers[0]["layout"].ld if spec.has_deep else 0, ptr(self.wide_logit) if spec.has_wide else None,
+                 self.rec_stride, st)
 
     def _small_on(self, bt):
-        """This batch's small-table columns go through csrc/small_tables.hip: multi-hot batches on separate tables with the
-        reference's default optimizers (one-id-per-bag batches keep the one-launch bucketing, whose bags cannot be long)."""
-        return bool(self.small_idx) and not bt.one_hot and self.rec is None and self.default_opts
+        """This batch's small-table columns go through csrc/small_tables.hip: multi-hot batches with the reference's default
+        optimizers, on separate tables or on row records (one-id-per-bag batches keep the one-launch bucketing, whose bags cannot
+        be long)."""
+        return bool(self.small_idx) and not bt.one_hot and self.default_opts
 
     def embag_fwd(self, dim, gs, bt, xp, ld, st, sub=False):
         """Embedding-bag gather of one dim group into x (the kernel bench.py reports the HBM roofline of).  sub: `gs` is the
@@ -1155,7 +1165,7 @@ class WideDeepEngine:
              ptr(self.wide) if spec.has_wide else None, ptr(self.slots_dev), plan.S, ptr(self.small_idx_dev),
              len(self.small_idx), self.small_rows, self.small_dim, ptr(bt.ids), ptr(bt.bag_offs), bt.B, dx_ptr, ld,
              ptr(self.dlogit), float(spec.dnn_opt[1]) if spec.has_deep else 0.0, float(lr), float(l1), float(l2),
-             ptr(self.small_ws), self.small_ws.numel(), st)
+             ptr(self.small_ws), self.small_ws.numel(), self.rec_stride, st)
 
     def _sparse_backward(self, bt: DeviceBatch, st, bucketized=False, pset=0, patch=None, small=True):
         """Scatter-add of the row gradients + fused Adagrad (embedding rows) / FTRL (wide rows, bias).  small=False: the caller
@@ -1166,6 +1176,8 @@ class WideDeepEngine:
             return
         if not bucketized:
             self._sparse_bucketize(bt, st, pset)
+        if small:
+            self._small_backward(bt, st)      # (nothing unless this batch's small tables go through csrc/small_tables.hip)
         bsx = self._bucket_sets[pset]
         dx_ptr, ld = None, 0
         if has_emb:
@@ -1205,8 +1217,6 @@ class WideDeepEngine:
             return
         if self.default_opts:
             lr, l1, l2 = (spec.lin_opt[1], spec.lin_opt[2], spec.lin_opt[3]) if spec.has_wide else (0.0, 0.0, 0.0)
-            if small:
-                self._small_backward(bt, st)
             call("wd_sparse_apply", ptr(self.emb) if has_emb else None, ptr(self.emb_acc) if has_emb else None,
                  ptr(self.wide), ptr(self.bias), ptr(self.slots_dev), plan.S, ptr(bt.bag_offs), bt.B, dx_ptr, ld,
                  ptr(self.dlogit), 1, float(spec.dnn_opt[1]) if spec.has_deep else 0.0, float(lr), float(l1), float(l2),

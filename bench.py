@@ -757,9 +757,12 @@ def main():
                                     slack=args.slack if args.slack else (1.1 if args.dist == "uniform" else 1.2 if dedup_expected else 2.5))
     elif featurized:
         eng = WideDeepEngine(spec, max_batch=B, max_nnz=int(1.02 * max(hb["nnz"] for _, hb in parsed)) + 1024, seed=0,
-                             tower_dtype=tower_dtype)
+                             tower_dtype=tower_dtype, expected_nnz=B * 28 * mean_len)
     else:
-        eng = WideDeepEngine(spec, max_batch=B, max_nnz=B * 26 * (2 * mean_len + 2), seed=0, tower_dtype=tower_dtype)
+        # (multi-hot: the bucket geometry is sized from the occurrences a batch really holds -- ~130 per bucket, what the bucket
+        # sort's 256-pair workgroups take -- not from one id per bag)
+        eng = WideDeepEngine(spec, max_batch=B, max_nnz=B * 26 * (2 * mean_len + 2), seed=0, tower_dtype=tower_dtype,
+                             expected_nnz=B * 26 * mean_len if mean_len > 1 else None)
     plan = getattr(eng, "hash_plan", eng.plan)    # sharded: batches live in the GLOBAL id space
 
     # resident batch pool (raw tokens in HBM); distinct seeds per rank

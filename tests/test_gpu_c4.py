@@ -197,3 +197,45 @@ def test_small_tables_are_admitted_against_their_joint_maxima(monkeypatch):
     for k in a:
         if a[k].dtype.is_floating_point:
             assert_close(a[k], g[k], 5e-4, 1e-5, "state %s vs the general path" % k)
+
+
+@pytest.mark.parametrize("buckets", [7, 3000])
+def test_flat_ragged_update_equals_the_bucket_update_and_the_oracle(monkeypatch, buckets):
+    """Multi-hot batches on row records (round 6): wd_sparse_bucketize -> wd_bucket_sort_ragged -> wd_row_update_ragged against the
+    same steps with the sort inside the update's workgroups (WD_FLAT_RAGGED=0: wd_sparse_apply_rec) and against the oracle.
+    3000-row vocabularies: short segments -- the two updates add every row's occurrences in the same order: bit-identical tables.
+    7 rows: ids repeat INSIDE a bag (equal (row, bag) pairs in the sort) and every row is a long segment (hundreds of occurrences,
+    reduced by a whole workgroup in a fixed tree whose shape differs between the two kernels: equal to 1e-5 relative)."""
+    from tests.helpers import assert_close, oracle_batch, oracle_from_engine
+    from wide_deep_amd import synth
+    from wide_deep_amd.engine import WideDeepEngine
+    from wide_deep_amd.plan import criteo_spec
+    B = 301
+    spec = criteo_spec(n_dense=3, n_sparse=5, buckets=buckets, dim=8, hidden=(32, 16), mode="resnet", use_weight_column=True)
+    monkeypatch.setenv("WD_FLAT_RAGGED", "0")
+    ref = WideDeepEngine(spec, max_batch=B, seed=9)
+    monkeypatch.setenv("WD_FLAT_RAGGED", "1")
+    eng = WideDeepEngine(spec, max_batch=B, seed=9)
+    assert eng.rec is not None and ref.rec is not None
+    ora = oracle_from_engine(eng)
+    for step in range(3):
+        hb = synth.make_raw_batch(eng.plan, B, seed=300 + step, mean_len=5, pos_rate=0.3)
+        w = np.where(hb["labels"] > 0, 0.99, 0.01).astype(np.float32)
+        bt, bt2 = synth.to_device_ids(eng.plan, hb, weights=w), synth.to_device_ids(eng.plan, hb, weights=w)
+        assert not bt.one_hot and eng._flat_ragged_ok(bt) and not ref._flat_ragged_ok(bt2)
+        if buckets == 7:      # ids repeated inside a bag exist
+            ids, offs = bt.ids.cpu().numpy(), bt.bag_offs.cpu().numpy()
+            assert any(len(set(ids[offs[g]: offs[g + 1]])) < offs[g + 1] - offs[g] for g in range(len(offs) - 1))
+        loss, loss2 = float(eng.train_step(bt)), float(ref.train_step(bt2))
+        torch.cuda.synchronize()
+        assert eng._bucket_sets[0]["ragged"] and not ref._bucket_sets[0]["ragged"]
+        oloss, ologits = ora.train_step(oracle_batch(eng.plan, bt.ids.cpu().numpy(), bt.bag_offs.cpu().numpy(), B, hb["dense"],
+                                                     hb["labels"], w))
+        assert_close(eng.logit[:B], ologits, 2e-4, 2e-5, "logits vs oracle, step %d" % step)
+        if buckets == 3000:
+            assert loss == loss2 and torch.equal(eng.rec, ref.rec) and torch.equal(eng.emb_acc, ref.emb_acc), \
+                "flat ragged update differs from wd_sparse_apply_rec at step %d" % step
+            assert torch.equal(eng.bias, ref.bias) and torch.equal(eng.P, ref.P)
+        else:
+            assert_close(eng.rec, ref.rec, 1e-5, 1e-6, "records vs wd_sparse_apply_rec, step %d" % step)
+            assert_close(eng.emb_acc, ref.emb_acc, 1e-5, 1e-6, "accumulators vs wd_sparse_apply_rec, step %d" % step)

@@ -306,7 +306,8 @@ __device__ __forceinline__ void bitonic_sort_nt(PtrT p, int m) {     // all comp
 
 // rank[q] of the lane's q-th element (index t + NT q) among arr[0 .. m): number of smaller elements (all distinct).  NQ = elements
 // per lane that exist -- a compile-time bound, so that a 300-pair bucket in a 1024-pair workgroup pays for two, not four.
-template <typename T, int NQ, int NT>
+// TIES (ragged bags, round 6: an id may repeat INSIDE a bag -- two equal (row, bag) pairs): equal elements rank by their index.
+template <typename T, int NQ, int NT, bool TIES>
 __device__ __forceinline__ void rank_loop(const T *arr, int m, int t, int *r) {
   T x[NQ];
 #pragma unroll
@@ -317,22 +318,28 @@ __device__ __forceinline__ void rank_loop(const T *arr, int m, int t, int *r) {
   for (int j = 0; j < m; ++j) {
     const T y = arr[j];
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) r[q] += y < x[q] ? 1 : 0;
+    for (int q = 0; q < NQ; ++q) r[q] += (y < x[q] || (TIES && y == x[q] && j < t + NT * q)) ? 1 : 0;
+  }
+}
+
+template <typename T, int MAXQ, int NT, bool TIES>
+__device__ __forceinline__ void rank_dispatch_t(const T *arr, int m, int nq, int t, int *r) {
+#pragma unroll
+  for (int q = 0; q < MAXQ; ++q) r[q] = 0;
+  if (MAXQ >= 4 && nq > 2) {
+    if (nq == 3) rank_loop<T, (MAXQ >= 3 ? 3 : 1), NT, TIES>(arr, m, t, r);
+    else rank_loop<T, (MAXQ >= 4 ? 4 : 1), NT, TIES>(arr, m, t, r);
+  } else if (MAXQ >= 2 && nq == 2) {
+    rank_loop<T, (MAXQ >= 2 ? 2 : 1), NT, TIES>(arr, m, t, r);
+  } else {
+    rank_loop<T, 1, NT, TIES>(arr, m, t, r);
   }
 }
 
 template <typename T, int MAXQ, int NT>
-__device__ __forceinline__ void rank_dispatch(const T *arr, int m, int nq, int t, int *r) {
-#pragma unroll
-  for (int q = 0; q < MAXQ; ++q) r[q] = 0;
-  if (MAXQ >= 4 && nq > 2) {
-    if (nq == 3) rank_loop<T, (MAXQ >= 3 ? 3 : 1), NT>(arr, m, t, r);
-    else rank_loop<T, (MAXQ >= 4 ? 4 : 1), NT>(arr, m, t, r);
-  } else if (MAXQ >= 2 && nq == 2) {
-    rank_loop<T, (MAXQ >= 2 ? 2 : 1), NT>(arr, m, t, r);
-  } else {
-    rank_loop<T, 1, NT>(arr, m, t, r);
-  }
+__device__ __forceinline__ void rank_dispatch(const T *arr, int m, int nq, int t, int *r, bool ties) {
+  if (ties) rank_dispatch_t<T, MAXQ, NT, true>(arr, m, nq, t, r);
+  else rank_dispatch_t<T, MAXQ, NT, false>(arr, m, nq, t, r);
 }
 
 struct SortArgs {
@@ -346,6 +353,7 @@ struct SortArgs {
   int32_t long_cap, bag_bits, nb, S;
   int64_t batch;
   int32_t prio;              // wavefront priority of the two launches (WD_SORT_PRIO; they run beside the tower)
+  int32_t ties;              // ragged bags: equal pairs exist (an id repeated inside a bag) -- rank them by index, no bitmap path
 };
 
 // One bucket, CAP pairs rank-sorted in LDS (2 x CAP x 8 bytes).  false: the bucket is larger (SMALL launch: the caller lists it).
@@ -401,7 +409,7 @@ __device__ __forceinline__ bool sort_bucket(const SortArgs &g, int bkt, uint64_t
     uint64_t o_pair[(512 + NT - 1) / NT];      // dominant-row path: the pairs of OTHER rows this lane places, and where
     int o_rank[(512 + NT - 1) / NT];
     int n_other = 0;
-    if (!SMALL && SORT_CAP >= 1024 && NT >= 256 && g.batch <= 16384) {
+    if (!SMALL && SORT_CAP >= 1024 && NT >= 256 && g.batch <= 16384 && !g.ties) {
       // ---- a bucket dominated by ONE row K (a Zipf head row: ~780 of ~900 pairs): O(m) instead of O(m^2).  The pairs of a row
       // are distinct EXAMPLES (one id per bag), so their order by bag is a rank in a bitmap over the examples:
       // rank = (pairs of smaller rows) + popcount(bits below example b); the few other pairs rank among themselves.
@@ -489,9 +497,9 @@ __device__ __forceinline__ bool sort_bucket(const SortArgs &g, int bkt, uint64_t
         ck[i] = ((key_of(p) - kmin) << bag_bits) | (uint32_t)p;
       }
       __syncthreads();
-      rank_dispatch<uint32_t, SORT_CAP / NT, NT>(ck, m, nq, t, r);
+      rank_dispatch<uint32_t, SORT_CAP / NT, NT>(ck, m, nq, t, r, g.ties != 0);
     } else {
-      rank_dispatch<uint64_t, SORT_CAP / NT, NT>(lds_in, m, nq, t, r);
+      rank_dispatch<uint64_t, SORT_CAP / NT, NT>(lds_in, m, nq, t, r, g.ties != 0);
     }
     __syncthreads();
 #pragma unroll
@@ -606,6 +614,10 @@ struct RowUpd {
   float *emit_out;
   const int32_t *emit_pos;
   int32_t emit_rs;
+  // ragged bags (round 6, wd_row_update_ragged): an occurrence carries dx / len(bag) (combiner='mean'), the number of pairs is a
+  // device value (what wd_sparse_bucketize scattered: ids < 0 and the small-table columns are not in the list)
+  const int32_t *bag_offs;
+  const int32_t *nnz_dev;
 };
 
 __device__ __forceinline__ void ftrl_row(float &w, float &z, float &n, float g, float lr, float l1, float l2) {
@@ -635,6 +647,7 @@ k_row_update(RowUpd u) {
   __shared__ float4 red[256];
   __shared__ float redw[256];
   __shared__ int32_t seg_ex[256];
+  __shared__ float seg_scale[256];
   __shared__ float new_row[20];           // long segments: the row's new value (16 floats at most) + its wide weight
   const int t = threadIdx.x;
   const int S = u.S, D = u.dim, LG = D >> 2;
@@ -701,7 +714,16 @@ k_row_update(RowUpd u) {
       float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
       for (int64_t j0 = i; j0 < e; j0 += 256) {
         const int n = e - j0 < 256 ? (int)(e - j0) : 256;
-        if (t < n) seg_ex[t] = (int32_t)(uint32_t)u.pairs[j0 + t] / S;
+        if (t < n) {
+          const int32_t bag = (int32_t)(uint32_t)u.pairs[j0 + t];
+          seg_ex[t] = bag / S;
+          float sc = 1.0f;
+          if (u.bag_offs) {
+            const int32_t len = u.bag_offs[bag + 1] - u.bag_offs[bag];
+            sc = len > 1 ? 1.0f / (float)len : 1.0f;
+          }
+          seg_scale[t] = sc;
+        }
         __syncthreads();
         if (c < LG) {
           float4 d[4];
@@ -715,7 +737,7 @@ k_row_update(RowUpd u) {
           for (int k = 0; k < 4; ++k) {
             const int idx = gidx + 64 * k;
             if (idx < n) {
-              const float scale = 1.0f;
+              const float scale = seg_scale[idx];
               g.x += d[k].x * scale; g.y += d[k].y * scale; g.z += d[k].z * scale; g.w += d[k].w * scale;
             }
           }
@@ -785,21 +807,26 @@ k_row_update(RowUpd u) {
   const int64_t i = (((int64_t)blockIdx.x - LONG_WORKERS - 1) * 256 + t) >> 2;
   uint64_t pr = 0, prv = ~0ull, nxt = ~0ull, far = ~0ull;
   int2 pj = make_int2(-1, 0);
-  if (i < u.nnz) {
+  int64_t nnz = u.nnz;
+  if (u.nnz_dev) {          // ragged: the grid covers the capacity, the list holds *nnz_dev pairs
+    const int64_t nd = *u.nnz_dev;
+    nnz = nd < nnz ? nd : nnz;
+  }
+  if (i < nnz) {
     pr = u.pairs[i];
     if (i > 0) prv = u.pairs[i - 1];
-    if (i + 1 < u.nnz) nxt = u.pairs[i + 1];
-    if (i + ROW_LONG_SEG < u.nnz) far = u.pairs[i + ROW_LONG_SEG];
+    if (i + 1 < nnz) nxt = u.pairs[i + 1];
+    if (i + ROW_LONG_SEG < nnz) far = u.pairs[i + ROW_LONG_SEG];
     if (u.patch) pj = u.patch[i];
   }
   __syncthreads();          // slot tables
-  if (i >= u.nnz) return;
+  if (i >= nnz) return;
   const uint32_t key = key_of(pr);
   if (key_of(prv) == key) return;            // not the first occurrence of its row
   if (key_of(far) == key) return;            // more than ROW_LONG_SEG occurrences: listed by k_bucket_sort, reduced above
   int64_t e = i + 1;
   if (key_of(nxt) == key) {                  // (sorted: the row's pairs end inside (i + 1, i + ROW_LONG_SEG])
-    int64_t lo = i + 2, hi = i + ROW_LONG_SEG < u.nnz ? i + ROW_LONG_SEG : u.nnz;
+    int64_t lo = i + 2, hi = i + ROW_LONG_SEG < nnz ? i + ROW_LONG_SEG : nnz;
     while (lo < hi) {
       const int64_t mid = (lo + hi) >> 1;
       if (key_of(u.pairs[mid]) == key) lo = mid + 1; else hi = mid;
@@ -824,9 +851,13 @@ k_row_update(RowUpd u) {
   if (gl == 0 && !emit) r = *reinterpret_cast<float4 *>(u.rec + (int64_t)key * RS + D);
   float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
   float gw = 0.f;
-  const float scale = 1.0f;                  // one id per bag: the mean of one
   if (e - i == 1) {
     const int64_t b = bag0 / S;
+    float scale = 1.0f;                      // one id per bag: the mean of one; ragged: dx / len(bag)
+    if (u.bag_offs) {
+      const int32_t len = u.bag_offs[bag0 + 1] - u.bag_offs[bag0];
+      scale = len > 1 ? 1.0f / (float)len : 1.0f;
+    }
     if (lane_emb) {
       const float4 d = *reinterpret_cast<const float4 *>(u.dx + b * u.ldx + out_col + 4 * gl);
       g.x += d.x * scale; g.y += d.y * scale; g.z += d.z * scale; g.w += d.w * scale;
@@ -852,20 +883,25 @@ k_row_update(RowUpd u) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) bag[k] = (int32_t)__shfl((int)mybag[c], l0 + k, 64);
       float4 d[4];
-      float v[4];
+      float v[4], scale[4];
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         d[k] = make_float4(0.f, 0.f, 0.f, 0.f);
         v[k] = 0.f;
+        scale[k] = 1.0f;
         if (4 * c + k < n) {
           if (lane_emb) d[k] = *reinterpret_cast<const float4 *>(u.dx + (int64_t)(bag[k] / S) * u.ldx + out_col + 4 * gl);
           if (gl == 0) v[k] = u.dlogit[bag[k] / S];
+          if (u.bag_offs) {
+            const int32_t len = u.bag_offs[bag[k] + 1] - u.bag_offs[bag[k]];
+            scale[k] = len > 1 ? 1.0f / (float)len : 1.0f;
+          }
         }
       }
 #pragma unroll
       for (int k = 0; k < 4; ++k)
         if (4 * c + k < n) {
-          g.x += d[k].x * scale; g.y += d[k].y * scale; g.z += d[k].z * scale; g.w += d[k].w * scale;
+          g.x += d[k].x * scale[k]; g.y += d[k].y * scale[k]; g.z += d[k].z * scale[k]; g.w += d[k].w * scale[k];
           gw += v[k];
         }
     }
@@ -987,6 +1023,52 @@ extern "C" int wd_bucket_sort(const int32_t *bucket_start, uint64_t *pairs, int3
   hipLaunchKernelGGL(k_bucket_sort_small, dim3((unsigned)nbuckets), dim3(256), 0, st, g);
   hipLaunchKernelGGL(k_bucket_sort_big, dim3(BIG_WORKERS), dim3(512), 0, st, g);
   return wd::check_launch("wd_bucket_sort");
+}
+
+// ragged bags (multi-hot batches on row records, round 6): the buckets of wd_sparse_bucketize sorted in place (equal pairs -- an id
+// repeated inside a bag -- allowed), long rows listed; no patch lists (no prefetched input layer on this path)
+extern "C" int wd_bucket_sort_ragged(const int32_t *bucket_start, uint64_t *pairs, int32_t nbuckets, int32_t *long_list,
+                                     int32_t long_capacity, int32_t *big_list, int64_t batch, int32_t S, int64_t nnz_capacity,
+                                     wd_stream_t stream) {
+  WD_REQUIRE(bucket_start && pairs && long_list && big_list && nbuckets > 0 && nbuckets <= MAX_NB, "null pointer / bad bucket geometry");
+  WD_REQUIRE(long_capacity > 0 && batch > 0 && S > 0 && nnz_capacity > 0, "long_capacity, batch, S, nnz_capacity");
+  SortArgs g{};
+  g.S = S; g.batch = batch;
+  g.start = bucket_start; g.pairs = pairs; g.long_list = long_list; g.big_list = big_list; g.long_cap = long_capacity; g.nb = nbuckets;
+  static const int sort_prio = getenv("WD_SORT_PRIO") ? atoi(getenv("WD_SORT_PRIO")) : 1;
+  g.prio = sort_prio;
+  g.ties = 1;
+  g.bag_bits = 1;
+  while (g.bag_bits < 32 && ((int64_t)1 << g.bag_bits) < batch * S) ++g.bag_bits;
+  hipStream_t st = wd::as_stream(stream);
+  if (hipMemsetAsync(long_list, 0, 8, st) != hipSuccess) {      // the two counters wd_bucket_onehot zeroes on the one-id-per-bag path
+    wd::set_error("wd_bucket_sort_ragged: hipMemsetAsync failed");
+    return WD_ERR_LAUNCH;
+  }
+  hipLaunchKernelGGL(k_bucket_sort_small, dim3((unsigned)nbuckets), dim3(256), 0, st, g);
+  hipLaunchKernelGGL(k_bucket_sort_big, dim3(BIG_WORKERS), dim3(512), 0, st, g);
+  return wd::check_launch("wd_bucket_sort_ragged");
+}
+
+extern "C" int wd_row_update_ragged(float *rec, int32_t rec_stride, int32_t dim, float *emb_accum, float *bias_wzn,
+                                    const wd_slot_t *slots, int32_t S, int64_t batch, const int32_t *bag_offs, const float *dx,
+                                    int64_t ldx, const float *dlogit, float lr_emb, float lr_wide, float l1, float l2,
+                                    const uint64_t *pairs, int64_t nnz_capacity, const int32_t *nnz_dev, const int32_t *long_list,
+                                    int32_t long_capacity, wd_stream_t stream) {
+  if (batch <= 0) return WD_OK;
+  WD_REQUIRE(rec && emb_accum && slots && dx && dlogit && pairs && long_list && bag_offs && nnz_dev, "null pointer");
+  WD_REQUIRE(S > 0 && S <= 128 && (dim == 4 || dim == 8 || dim == 16) && rec_stride % 4 == 0 && rec_stride >= dim + 4,
+             "record = [dim | w z n -], dim in {4, 8, 16}, S <= 128");
+  WD_REQUIRE(nnz_capacity > 0 && nnz_capacity < ((int64_t)1 << 31), "nnz_capacity");
+  RowUpd u{};
+  u.rec = rec; u.accum = emb_accum; u.bias = bias_wzn; u.slots = slots; u.dx = dx; u.dlogit = dlogit; u.pairs = pairs;
+  u.long_list = long_list; u.long_cap = long_capacity; u.ldx = ldx; u.nnz = nnz_capacity; u.batch = batch; u.rec_stride = rec_stride;
+  u.dim = dim; u.S = S; u.lr_emb = lr_emb; u.lr_w = lr_wide; u.l1 = l1; u.l2 = l2;
+  u.bag_offs = bag_offs; u.nnz_dev = nnz_dev;
+  u.flat_blocks = (int32_t)wd::ceil_div(u.nnz * 4, 256);
+  u.wt = wd::wt_mask() & WD_WT_ROW_UPDATE ? 1 : 0;
+  hipLaunchKernelGGL(k_row_update, dim3((unsigned)(u.flat_blocks + LONG_WORKERS + 1)), dim3(256), 0, wd::as_stream(stream), u);
+  return wd::check_launch("wd_row_update_ragged");
 }
 
 extern "C" int wd_row_update(float *rec, int32_t rec_stride, int32_t dim, float *emb_accum, float *bias_wzn,

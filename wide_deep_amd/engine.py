@@ -107,6 +107,7 @@ class WideDeepEngine:
             row_records = os.environ.get("WD_ROW_RECORDS", "1") != "0"
         self.rec_stride = {4: 8, 8: 16, 16: 32}[dims[0]] if (row_records and eligible) else 0
         self.rec = None
+        self.flat_ragged = os.environ.get("WD_FLAT_RAGGED", "1") != "0"       # multi-hot batches on records: sort ahead, flat update
         self.act_id = capi.ACT_IDS["relu" if self.crelu else spec.activation]
         self.global_step = 0
         self._primed = None             # pipeline.StepGraph: (batch, bucket set, activation buffer, global step) whose input work is in place
@@ -1129,15 +1130,31 @@ class WideDeepEngine:
             call("wd_bucket_onehot", ptr(self.slots_dev), plan.S, ptr(bt.ids_cols if cols else bt.ids), 1 if cols else 0, bt.B,
                  ptr(bs["start"]), ptr(bs["pairs"]), self.n_buckets, self.max_slot_buckets,
                  None if flat else ptr(bs["ticket"]), ptr(bs["long_list"]) if flat else None, st)
-            bs["unsorted"], bs["sorted"] = True, flat
+            bs["unsorted"], bs["sorted"], bs["ragged"] = True, flat, False
             if flat:
                 bp = self._bucket_sets[prev] if prev is not None else None
                 call("wd_bucket_sort", ptr(bs["start"]), ptr(bs["pairs"]), self.n_buckets, ptr(bs["long_list"]),
                      (bs["long_list"].numel() - 2) // 2, ptr(bs["big_list"]), bt.B, plan.S, ptr(bp["start"]) if bp else None, ptr(bp["pairs"]) if bp else None, ptr(bp["patch"]) if bp else None, st)
             return
-        bs["unsorted"] = bs["sorted"] = False
+        bs["unsorted"] = bs["sorted"] = bs["ragged"] = False
         call("wd_sparse_bucketize", ptr(self.slots_small_dev if self._small_on(bt) else self.slots_dev), plan.S, ptr(bt.ids), ptr(bt.bag_offs), bt.B, bt.nnz,
              ptr(bs["cnt"]), ptr(bs["start"]), ptr(bs["rank"]), ptr(bs["pairs"]), self.n_buckets, st)
+        if self._flat_ragged_ok(bt):
+            # ragged bags on row records: every bucket sorted here, with the bucketing (beside the input layer / the tower), and the
+            # update itself a flat launch over the sorted pairs (wd_row_update_ragged) -- the C2 step's split of the work
+            call("wd_bucket_sort_ragged", ptr(bs["start"]), ptr(bs["pairs"]), self.n_buckets, ptr(bs["long_list"]),
+                 (bs["long_list"].numel() - 2) // 2, ptr(bs["big_list"]), bt.B, plan.S, self.max_nnz, st)
+            bs["sorted"] = bs["ragged"] = True
+
+    def _flat_ragged_ok(self, bt):
+        """Multi-hot batches on row records with one big embedding width (the small tables go their own way): bucketing + sort
+        ahead, flat update (WD_FLAT_RAGGED=0: the sort stays inside wd_sparse_apply_rec's update workgroups)."""
+        return (self.rec is not None and type(self) is WideDeepEngine and self.default_opts and self.plan.S <= 128
+                and self.emb.shape[1] in (4, 8, 16) and self.flat_ragged
+                and all(int(self.plan.slots[i].dim) == self.emb.shape[1] for i in range(self.plan.S)
+                        if i not in (self.small_idx if self._small_on(bt) else ()) and self.plan.slots[i].deep == "embedding")
+                and all(self.plan.slots[i].deep == "embedding" for i in range(self.plan.S)
+                        if i not in (self.small_idx if self._small_on(bt) else ())))
 
     def _bucket_onehot_ok(self, bt):
         return (bt.one_hot and self.rec is not None and type(self) is WideDeepEngine and bt.nnz == bt.B * self.plan.S
@@ -1184,6 +1201,12 @@ class WideDeepEngine:
             tw0 = self.towers[0]
             tl0 = tw0["layout"]
             dx_ptr, ld = tw0["dact"].data_ptr() + 4 * tl0.seg_start[0], tl0.ld
+        if self.rec is not None and bsx["sorted"] and bsx.get("ragged"):
+            call("wd_row_update_ragged", ptr(self.rec), self.rec_stride, self.emb.shape[1], ptr(self.emb_acc), ptr(self.bias),
+                 ptr(self.slots_dev), plan.S, bt.B, ptr(bt.bag_offs), dx_ptr, ld, ptr(self.dlogit), float(spec.dnn_opt[1]),
+                 float(spec.lin_opt[1]), float(spec.lin_opt[2]), float(spec.lin_opt[3]), ptr(bsx["pairs"]), self.max_nnz,
+                 bsx["start"].data_ptr() + 4 * self.n_buckets, ptr(bsx["long_list"]), (bsx["long_list"].numel() - 2) // 2, st)
+            return
         if self.rec is not None and bsx["sorted"]:
             nx, pa = None, None
             if patch is not None:
@@ -1384,8 +1407,12 @@ class WideDeepEngine:
         the side stream)."""
         # (not with small tables: their update already runs there, and the bucketing on top of it costs the row update more than
         # it saves -- configs[3] with its crosses 0.524 -> 0.541 ms/step, without them 0.505 -> 0.495)
+        # (round 6: not on row records with the flat ragged update either -- the bucketing + sort of a batch then run on the side
+        # stream behind the previous update, beside this batch's input layer and tower: configs[3] without its crosses 0.4954 ->
+        # 0.4585 ms/step, profiles/r6_c4_flat_ragged_ab.txt)
         return bool(type(self) is WideDeepEngine and getattr(self, "chain", False) and self.overlap_bucket and self._has_sparse_update()
-                    and not self._bucket_onehot_ok(bt) and not self._small_on(bt) and os.environ.get("WD_SPARSE_SIDE", "1") == "1")
+                    and not self._bucket_onehot_ok(bt) and not self._small_on(bt) and not self._flat_ragged_ok(bt)
+                    and os.environ.get("WD_SPARSE_SIDE", "1") == "1")
 
     def train_step(self, bt: DeviceBatch, pset=None, lookahead=None, before_join=None):
         """One step of python/lib/joint.py:224-262: forward, batch-SUM loss, both optimizers.

@@ -842,7 +842,7 @@ int wd_small_tables_bwd(float *emb, float *emb_accum, float *wide_wzn, const wd_
 /* The same update in two halves, for tables REPLICATED on every rank of a row-sharded model (a 200-row crossed column is not
  * worth an all-to-all; the reference's parameter server would hold it on one task, python/lib/joint.py:140-143):
  *   wd_small_tables_grad: this rank's sums -- gsum[nsmall][max_rows][max_dim + 2] = per row g_0 .. g_{D-1}, g_wide, hit count of
- *     ITS OWN width D (the slice partials added in slice order; batch == 0: zeros); dx / dlogit NULL: that half is not computed;
+ *     ITS OWN width D (the slice partials added in a fixed tree; batch == 0: zeros); dx / dlogit NULL: that half is not computed;
  *   the ranks all-reduce(SUM) gsum; wd_small_tables_apply: Adagrad / Ftrl from the sums on the rows some rank's batch holds. */
 int wd_small_tables_grad(const wd_slot_t *slots, int32_t S, const int32_t *small_idx, int32_t nsmall, int32_t max_rows,
                          int32_t max_dim, const int32_t *ids, const int32_t *bag_offs, int64_t batch, const float *dx, int64_t ldx,

@@ -17,7 +17,7 @@
 //                  count x (dx / len | dlogit) to its partial sums in LDS -- a fixed order of float adds, no sort, no float atomic;
 //                  one barrier per bag (histograms double-buffered); the slice's bag bounds and gradients are staged in one
 //                  round of loads, the ids of four bags ride in a register ring.  Partials + hit counts go to HBM per slice.
-//   k_small_apply  per slot: partials summed in slice order, Adagrad on the embedding rows / Ftrl on {w, z, n} of the rows
+//   k_small_apply  per slot: partials summed in a fixed tree over the slices, Adagrad on the embedding rows / Ftrl on {w, z, n} of the rows
 //                  the batch touched.
 #include "common.h"
 
@@ -231,31 +231,48 @@ __device__ __forceinline__ void ftrl1(float &w, float &z, float &n, float g, flo
   n = n_new;
 }
 
-// one thread per (row, element): element d < D = embedding column d (Adagrad), d == D = the wide weight (Ftrl)
-__global__ void __launch_bounds__(256) k_small_apply(SmallArgs a) {
-  const int k = blockIdx.y;
-  const int s = uni(a.small_idx[k]);
-  const wd_slot_t sl = a.slots[s];
-  const int R = sl.num_buckets, D = sl.dim;
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= R * (D + 1)) return;
-  const int r = i / (D + 1), d = i - r * (D + 1);
+// SM_AP lanes per (row, element): element d < D = embedding column d (Adagrad), d == D = the wide weight (Ftrl).  Lane l adds the
+// partials of slices l * per .. (l + 1) * per - 1 in slice order, the SM_AP lane sums meet in a fixed shuffle tree -- one round of
+// loads per lane instead of a chain of nslice / 32 rounds in ONE thread per element (round 5: 8 workgroups on the whole chip, 15 us
+// alone and 50-70 us beside the row update's traffic, on the critical stream of a configs[3] step)
+constexpr int SM_AP = 32;
+
+__device__ __forceinline__ void small_slice_sum(const SmallArgs &a, int k, int r, int d, int D, int lane, float &g, float &hits) {
   const float *p = a.part + (int64_t)k * a.nslice * a.part_rows * a.part_w + (int64_t)r * a.part_w;
   const int64_t st = (int64_t)a.part_rows * a.part_w;
-  float g = 0.f, hits = 0.f;
-  constexpr int RND = 32;                            // slices per round of loads, added in slice order (128 slices: 4 round trips)
-  for (int c0 = 0; c0 < a.nslice; c0 += RND) {
+  const int per = (a.nslice + SM_AP - 1) / SM_AP;
+  g = 0.f; hits = 0.f;
+  constexpr int RND = 8;
+  for (int c0 = lane * per; c0 < (lane + 1) * per; c0 += RND) {
     float v[RND], h[RND];
 #pragma unroll
     for (int u = 0; u < RND; ++u) {
-      const bool live = c0 + u < a.nslice;
+      const bool live = c0 + u < (lane + 1) * per && c0 + u < a.nslice;
       v[u] = live ? p[(c0 + u) * st + d] : 0.f;
       h[u] = live ? p[(c0 + u) * st + D + 1] : 0.f;
     }
 #pragma unroll
     for (int u = 0; u < RND; ++u) { g += v[u]; hits += h[u]; }
   }
-  if (hits == 0.f) return;                          // the batch does not hold this row: it does not move
+#pragma unroll
+  for (int m = SM_AP / 2; m >= 1; m >>= 1) {
+    g += __shfl_xor(g, m, SM_AP);
+    hits += __shfl_xor(hits, m, SM_AP);
+  }
+}
+
+__global__ void __launch_bounds__(256) k_small_apply(SmallArgs a) {
+  const int k = blockIdx.y;
+  const int s = uni(a.small_idx[k]);
+  const wd_slot_t sl = a.slots[s];
+  const int R = sl.num_buckets, D = sl.dim;
+  const int gid = blockIdx.x * 256 + threadIdx.x;
+  const int i = gid / SM_AP, lane = gid % SM_AP;
+  if (i >= R * (D + 1)) return;          // (whole lane groups leave together: SM_AP divides the workgroup)
+  const int r = i / (D + 1), d = i - r * (D + 1);
+  float g, hits;
+  small_slice_sum(a, k, r, d, D, lane, g, hits);
+  if (lane != 0 || hits == 0.f) return;             // the batch does not hold this row: it does not move
   if (d < D) {
     if (!a.emb_w || sl.out_col < 0) return;
     const int64_t o = sl.emb_off + (int64_t)r * D + d;
@@ -271,29 +288,19 @@ __global__ void __launch_bounds__(256) k_small_apply(SmallArgs a) {
 
 // ---- the same update in two halves, for tables that are REPLICATED on every rank of a row-sharded model (dist.py: a 200-row
 // crossed column is not worth an all-to-all): k_small_reduce leaves this rank's gradient sums + hit counts per row
-// ([nsmall][part_rows][part_w], partials added in slice order), the ranks all-reduce that buffer, k_small_apply_sum applies it.
+// ([nsmall][part_rows][part_w], partials added in the same fixed tree), the ranks all-reduce that buffer, k_small_apply_sum applies it.
 __global__ void __launch_bounds__(256) k_small_reduce(SmallArgs a, float *__restrict__ gsum) {
   const int k = blockIdx.y;
   const int s = uni(a.small_idx[k]);
   const wd_slot_t sl = a.slots[s];
   const int R = sl.num_buckets, D = sl.dim, PW = D + 2;
-  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int gid = blockIdx.x * 256 + threadIdx.x;
+  const int i = gid / SM_AP, lane = gid % SM_AP;
   if (i >= a.part_rows * a.part_w) return;
   const int r = i / a.part_w, d = i - r * a.part_w;
-  float g = 0.f;
-  if (r < R && d < PW) {
-    const float *p = a.part + (int64_t)k * a.nslice * a.part_rows * a.part_w + (int64_t)r * a.part_w + d;
-    const int64_t st = (int64_t)a.part_rows * a.part_w;
-    constexpr int RND = 32;
-    for (int c0 = 0; c0 < a.nslice; c0 += RND) {
-      float v[RND];
-#pragma unroll
-      for (int u = 0; u < RND; ++u) v[u] = c0 + u < a.nslice ? p[(c0 + u) * st] : 0.f;
-#pragma unroll
-      for (int u = 0; u < RND; ++u) g += v[u];
-    }
-  }
-  gsum[(int64_t)k * a.part_rows * a.part_w + i] = g;       // (rows / columns a narrower table does not have: zeros)
+  float g = 0.f, hits = 0.f;
+  if (r < R && d < PW) small_slice_sum(a, k, r, d, D, lane, g, hits);      // (d == D + 1: the hit count itself)
+  if (lane == 0) gsum[(int64_t)k * a.part_rows * a.part_w + i] = g;       // (rows / columns a narrower table does not have: zeros)
 }
 
 __global__ void __launch_bounds__(256) k_small_apply_sum(SmallArgs a, const float *__restrict__ gsum) {
@@ -408,7 +415,7 @@ extern "C" int wd_small_tables_bwd(float *emb, float *emb_accum, float *wide_wzn
   if (rc != WD_OK) return rc;
   hipStream_t st = wd::as_stream(stream);
   hipLaunchKernelGGL(k_small_bwd, dim3((unsigned)a.nslice, (unsigned)nsmall), dim3(256), lds, st, a);
-  hipLaunchKernelGGL(k_small_apply, dim3((unsigned)wd::ceil_div((int64_t)max_rows * (max_dim + 1), (int64_t)256), (unsigned)nsmall),
+  hipLaunchKernelGGL(k_small_apply, dim3((unsigned)wd::ceil_div((int64_t)max_rows * (max_dim + 1) * SM_AP, (int64_t)256), (unsigned)nsmall),
                      dim3(256), 0, st, a);
   return wd::check_launch("wd_small_tables_bwd");
 }
@@ -427,11 +434,14 @@ extern "C" int wd_small_tables_grad(const wd_slot_t *slots, int32_t S, const int
   a.emb_w = a.emb_acc = a.wide_w = nullptr;
   hipStream_t st = wd::as_stream(stream);
   if (batch <= 0) {        // a rank without examples still takes part in the all-reduce: zeros
-    hipMemsetAsync(gsum, 0, sizeof(float) * (size_t)nsmall * max_rows * (max_dim + 2), st);
+    if (hipMemsetAsync(gsum, 0, sizeof(float) * (size_t)nsmall * max_rows * (max_dim + 2), st) != hipSuccess) {
+      wd::set_error("wd_small_tables_grad: hipMemsetAsync failed");
+      return WD_ERR_LAUNCH;
+    }
     return wd::check_launch("wd_small_tables_grad");
   }
   hipLaunchKernelGGL(k_small_bwd, dim3((unsigned)a.nslice, (unsigned)nsmall), dim3(256), lds, st, a);
-  hipLaunchKernelGGL(k_small_reduce, dim3((unsigned)wd::ceil_div((int64_t)max_rows * (max_dim + 2), (int64_t)256), (unsigned)nsmall),
+  hipLaunchKernelGGL(k_small_reduce, dim3((unsigned)wd::ceil_div((int64_t)max_rows * (max_dim + 2) * SM_AP, (int64_t)256), (unsigned)nsmall),
                      dim3(256), 0, st, a, gsum);
   return wd::check_launch("wd_small_tables_grad");
 }

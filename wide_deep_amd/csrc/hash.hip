@@ -403,9 +403,10 @@ k_feat_offsets(const int32_t *__restrict__ lens, const int32_t *__restrict__ blo
 #ifndef FE_EXP
 #define FE_EXP 0                     // ablation builds (profiles/run_scripts/build_feat_exp.sh): 1 stop behind the tables, 2 stop behind the
 #endif                               // prefixes, 4 ids without the hashing (position in the bag stored)
-constexpr int FE_EX = 4;             // examples per workgroup (fewer when the model has more than FE_MAX_PAIRS / 4 columns)
+constexpr int FE_EX = 2;             // examples per workgroup (fewer when the model has more than FE_MAX_PAIRS / 2 columns): 2 and 4 take the
+                                     // same time alone (33.1 / 33.3 us), 2 needs half the LDS -- the launch then fits beside the one-launch tower
 constexpr int FE_MAX_PAIRS = 1024;   // (example, column) pairs of a workgroup's LDS tables
-constexpr int FE_PREFIX_CAP = 1024;  // chained hashes of the LEADING keys' combinations kept per workgroup (8 KB)
+constexpr int FE_PREFIX_CAP = 512;   // chained hashes of the LEADING keys' combinations kept per workgroup (4 KB; configs[3]: ~60 per workgroup)
 
 struct FeCol {                        // per column, in LDS
   int32_t kind, nkeys;

@@ -1415,12 +1415,13 @@ class WideDeepEngine:
                     and not self._bucket_onehot_ok(bt) and not self._small_on(bt) and not self._flat_ragged_ok(bt)
                     and os.environ.get("WD_SPARSE_SIDE", "1") == "1")
 
-    def train_step(self, bt: DeviceBatch, pset=None, lookahead=None, before_join=None):
+    def train_step(self, bt: DeviceBatch, pset=None, lookahead=None, before_join=None, beside_tower=None):
         """One step of python/lib/joint.py:224-262: forward, batch-SUM loss, both optimizers.
         pset: this batch's occurrences are already bucketed, in scratch set `pset` (by the previous step's `lookahead`);
         lookahead = (next batch, scratch set): bucket that batch's occurrences behind this step's dense tail, while the row update
-        runs on the side stream -- pipeline.StepGraph, for batches `lookahead_ok`.  before_join: launches for this stream that do not
-        depend on the step (the next batch's featurizer), issued before the step joins its row update."""
+        runs on the side stream -- pipeline.StepGraph, for batches `lookahead_ok`.  before_join / beside_tower: launches that do not
+        depend on the step (the next batch's featurizer) -- issued on this stream before the step joins its row update, or on the side
+        stream behind this batch's bucketing (where there is none: before the join)."""
         if bt.labels is None:
             raise ValueError("train_step needs labels")
         bucketized = False
@@ -1431,6 +1432,14 @@ class WideDeepEngine:
             side.wait_stream(main)                       # the ids were produced on the main stream
             self._sparse_bucketize(bt, side.cuda_stream)
             bucketized = True
+            if beside_tower is not None:
+                # launches that depend on nothing of this step, for the side stream behind the bucketing: they meet the input layer
+                # and the tower (MFMA-bound, the memory system idle) instead of the row update -- the next batch's featurizer
+                with torch.cuda.stream(side):
+                    beside_tower()
+                beside_tower = None
+        if beside_tower is not None:
+            before_join = beside_tower if before_join is None else (lambda a=before_join, b=beside_tower: (a(), b()))
         self.forward(bt, need_loss=True)
         self.backward_and_update(bt, bucketized=bucketized, pset=pset or 0, lookahead=lookahead, before_join=before_join)
         # the reference bumps global_step once per minimize() plus the explicit assign_add (quirk C.4)

@@ -110,8 +110,8 @@ class StepGraph:
                 and all(eng.lookahead_ok(tb.batch) and tb.batch.labels is not None for tb in tbs))
         if not look:
             # the tokens -> ids work of batch t+1 (hash buckets; crossed columns: features.Featurizer.run, ~50 us at configs[3]) goes
-            # INTO step t, behind its dense tail / small tables and in front of the join with its row update: this stream idles
-            # there, and launched behind the join the featurizer sat between two steps (0.598 -> 0.55 ms at configs[3] from tokens)
+            # INTO step t: launched behind the step's join with its row update the featurizer sat between two steps, behind the
+            # update on the same hardware queue (0.598 -> 0.562 ms at configs[3] from tokens when it moved in front of the join)
             ahead = (not ids_input and type(eng) is WideDeepEngine and os.environ.get("WD_HASH_AHEAD", "1") != "0"
                      and all(tb.batch.labels is not None for tb in tbs))
             if not ahead:
@@ -119,9 +119,17 @@ class StepGraph:
                     step_eager(eng, tb, ids_input)
                 return
             synth.hash_tokens(eng, tbs[0])
+            # on the side stream behind this batch's bucketing, i.e. beside the input layer and the tower (default; the featurizer's
+            # launches fit beside the tower's row tile since round 6: 0.510 -> 0.500-0.505 ms/step at configs[3]), or on this stream
+            # in front of the join with the row update (WD_HASH_WHERE=join)
+            where = os.environ.get("WD_HASH_WHERE", "tower")
             for t, tb in enumerate(tbs):
                 nxt = tbs[t + 1] if t + 1 < len(tbs) else None
-                eng.train_step(tb.batch, before_join=(lambda nxt=nxt: synth.hash_tokens(eng, nxt)) if nxt is not None else None)
+                fn = (lambda nxt=nxt: synth.hash_tokens(eng, nxt)) if nxt is not None else None
+                if where == "tower":
+                    eng.train_step(tb.batch, beside_tower=fn)
+                else:
+                    eng.train_step(tb.batch, before_join=fn)
             return
         main = torch.cuda.current_stream()
         keep = self._events = []

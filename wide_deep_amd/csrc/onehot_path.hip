@@ -596,6 +596,117 @@ __global__ void __launch_bounds__(512) k_bucket_sort_big(SortArgs g) {
 }
 
 
+// ---- ragged bags: one WAVEFRONT per bucket, the pairs sorted in REGISTERS (bitonic network over 64 lanes x NQ registers, partners
+// reached by shuffles) -- no LDS at all, so the launch runs beside the window tower, whose row tile leaves 13 KB of a CU's LDS
+// (k_bucket_sort_small there: three workgroups per CU, 160 us instead of 40; profiles/r6_c4_flat_ragged_ab.txt).  Equal pairs (an id
+// repeated inside a bag) are bitwise identical: their order is free.  Buckets of more than 256 pairs go to k_bucket_sort_big.
+__device__ __forceinline__ uint64_t shfl_xor64(uint64_t v, int m) {
+  const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, m, 64), hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), m, 64);
+  return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint64_t shfl64(uint64_t v, int src) {
+  const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)v, src, 64), hi = (uint32_t)__shfl((int)(uint32_t)(v >> 32), src, 64);
+  return ((uint64_t)hi << 32) | lo;
+}
+
+// position p = lane + 64 q (striped: coalesced loads / stores); ascending over p
+template <int NQ>
+__device__ __forceinline__ void wave_bitonic(uint64_t (&x)[4], int lane) {
+  constexpr int N = 64 * NQ;
+#pragma unroll
+  for (int k = 2; k <= N; k <<= 1) {
+#pragma unroll
+    for (int j = k >> 1; j >= 1; j >>= 1) {
+      if (j >= 64) {            // partner in another register of the same lane
+        const int dq = j >> 6;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+          if ((q & dq) == 0) {
+            const int p = lane + 64 * q;
+            const bool asc = (p & k) == 0;
+            const uint64_t a = x[q], b = x[q | dq];
+            const bool sw = asc ? a > b : a < b;
+            x[q] = sw ? b : a;
+            x[q | dq] = sw ? a : b;
+          }
+        }
+      } else {                  // partner in another lane, same register
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+          const int p = lane + 64 * q;
+          const bool asc = (p & k) == 0;
+          const bool low = (lane & j) == 0;            // this lane holds the lower position of the pair
+          const uint64_t a = x[q], b = shfl_xor64(a, j);
+          const bool keep_min = asc == low;
+          x[q] = keep_min ? (a < b ? a : b) : (a > b ? a : b);
+        }
+      }
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) k_bucket_sort_wave(SortArgs g) {
+  if (g.prio) __builtin_amdgcn_s_setprio(3);
+  const int lane = threadIdx.x & 63;
+  const int bkt = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (bkt >= g.nb) return;
+  const int32_t s0 = g.start[bkt];
+  const int m = g.start[bkt + 1] - s0;
+  if (m <= 0) return;
+  if (m > 256) {
+    if (lane == 0) g.big_list[atomicAdd(&g.long_list[1], 1)] = bkt;
+    return;
+  }
+  uint64_t x[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) x[q] = lane + 64 * q < m ? g.pairs[s0 + lane + 64 * q] : ~0ull;
+  if (m <= 64) wave_bitonic<1>(x, lane);
+  else if (m <= 128) wave_bitonic<2>(x, lane);
+  else wave_bitonic<4>(x, lane);
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+    if (lane + 64 * q < m) g.pairs[s0 + lane + 64 * q] = x[q];
+  // rows with more than ROW_LONG_SEG occurrences: (position, length) -> long_list.  Position p's predecessor is (lane - 1, q) or
+  // (63, q - 1); the pair ROW_LONG_SEG = 32 positions ahead is (lane + 32, q) or (lane - 32, q + 1).
+  bool any = false;
+  uint32_t keyq[4];
+  bool headlong[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    keyq[q] = key_of(x[q]);
+    const uint32_t up = (uint32_t)__shfl_up((int)keyq[q], 1, 64);
+    const uint32_t wrap = q > 0 ? (uint32_t)__shfl((int)keyq[q > 0 ? q - 1 : 0], 63, 64) : 0u;
+    const uint32_t prev = lane > 0 ? up : wrap;
+    const uint32_t f0 = (uint32_t)__shfl((int)keyq[q], (lane + 32) & 63, 64);
+    const uint32_t f1 = q < 3 ? (uint32_t)__shfl((int)key_of(x[q < 3 ? q + 1 : 3]), (lane + 32) & 63, 64) : 0u;
+    const int p = lane + 64 * q;
+    const uint32_t far = lane < 32 ? f0 : f1;
+    const bool head = p < m && (p == 0 || prev != keyq[q]);
+    headlong[q] = head && p + ROW_LONG_SEG < m && (lane < 32 || q < 3) && far == keyq[q];
+    any = any || headlong[q];
+  }
+  if (!__ballot(any)) return;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    unsigned long long todo = __ballot(headlong[q]);
+    while (todo) {              // a wavefront-uniform loop over the long rows' heads: count the row's pairs among all positions
+      const int src = __ffsll((long long)todo) - 1;
+      todo &= todo - 1;
+      const uint32_t K = (uint32_t)__shfl((int)keyq[q], src, 64);
+      int cnt = 0;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) cnt += __popcll(__ballot(lane + 64 * r < m && keyq[r] == K));
+      if (lane == src) {
+        const int32_t e = atomicAdd(&g.long_list[0], 1);
+        if (e < g.long_cap) {
+          g.long_list[2 + 2 * e] = s0 + lane + 64 * q;
+          g.long_list[3 + 2 * e] = cnt;
+        }
+      }
+    }
+  }
+}
+
 struct RowUpd {
   float *rec, *accum, *bias;
   const wd_slot_t *slots;
@@ -1045,7 +1156,9 @@ extern "C" int wd_bucket_sort_ragged(const int32_t *bucket_start, uint64_t *pair
     wd::set_error("wd_bucket_sort_ragged: hipMemsetAsync failed");
     return WD_ERR_LAUNCH;
   }
-  hipLaunchKernelGGL(k_bucket_sort_small, dim3((unsigned)nbuckets), dim3(256), 0, st, g);
+  static const int wave_sort = getenv("WD_SORT_WAVE") ? atoi(getenv("WD_SORT_WAVE")) : 1;
+  if (wave_sort) hipLaunchKernelGGL(k_bucket_sort_wave, dim3((unsigned)wd::ceil_div(nbuckets, 4)), dim3(256), 0, st, g);
+  else hipLaunchKernelGGL(k_bucket_sort_small, dim3((unsigned)nbuckets), dim3(256), 0, st, g);
   hipLaunchKernelGGL(k_bucket_sort_big, dim3(BIG_WORKERS), dim3(512), 0, st, g);
   return wd::check_launch("wd_bucket_sort_ragged");
 }

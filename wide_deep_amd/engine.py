@@ -1115,7 +1115,7 @@ class WideDeepEngine:
     def _reduce_dense_grads(self):
         """Hook for data-parallel ranks (dist.py: all_reduce(SUM) of the flat gradient buffer)."""
 
-    def _sparse_bucketize(self, bt: DeviceBatch, st, pset=0, prev=None):
+    def _sparse_bucketize(self, bt: DeviceBatch, st, pset=0, prev=None, between=None):
         """Phase 1 of the sparse backward (ids only): occurrences -> row-range buckets (scratch set `pset`).  Flat row update:
         + the sort of every bucket; prev = scratch set of the batch stepped BEFORE this one (pipelined graph): its patch list
         (rows this batch reads too) is filled as well."""
@@ -1139,6 +1139,12 @@ class WideDeepEngine:
         bs["unsorted"] = bs["sorted"] = bs["ragged"] = False
         call("wd_sparse_bucketize", ptr(self.slots_small_dev if self._small_on(bt) else self.slots_dev), plan.S, ptr(bt.ids), ptr(bt.bag_offs), bt.B, bt.nnz,
              ptr(bs["cnt"]), ptr(bs["start"]), ptr(bs["rank"]), ptr(bs["pairs"]), self.n_buckets, st)
+        if between is not None:
+            # (train_step(beside_tower=): the next batch's featurizer goes BETWEEN the bucketing and the sort -- the sort's second
+            # launch, for buckets of more than 256 pairs, carries 16 KB of LDS and does not start before the window tower has left
+            # its CUs; behind it the featurizer would run after the tower and delay the row update by its own 60-100 us)
+            between()
+            between = None
         if self._flat_ragged_ok(bt):
             # ragged bags on row records: every bucket sorted here, with the bucketing (beside the input layer / the tower), and the
             # update itself a flat launch over the sorted pairs (wd_row_update_ragged) -- the C2 step's split of the work
@@ -1147,15 +1153,14 @@ class WideDeepEngine:
             bs["sorted"] = bs["ragged"] = True
 
     def _flat_ragged_ok(self, bt):
-        """Multi-hot batches on row records, every column embedded with the record's width: bucketing + sort ahead, flat update
-        (WD_FLAT_RAGGED=0: the sort stays inside wd_sparse_apply_rec's update workgroups).  Not with small tables: there the main
-        stream (products, dense tail, the small tables' update, the next featurizer) is the critical chain whichever update runs,
-        and the bucket sort beside the window tower -- 13 KB of LDS left per CU -- takes 160 us instead of 40, which delays the
-        update behind it (configs[3]: 0.538 against 0.534 ms/step; without the crosses 0.4585 against 0.4697:
-        profiles/r6_c4_flat_ragged_ab.txt)."""
+        """Multi-hot batches on row records, every column that is not a small table embedded with the record's width: bucketing +
+        sort ahead (the sort one wavefront per bucket in registers: no LDS, it runs beside the window tower), flat update
+        (WD_FLAT_RAGGED=0: the sort stays inside wd_sparse_apply_rec's update workgroups)."""
+        skip = self.small_idx if self._small_on(bt) else ()
         return (self.rec is not None and type(self) is WideDeepEngine and self.default_opts and self.plan.S <= 128
-                and self.emb.shape[1] in (4, 8, 16) and self.flat_ragged and not self._small_on(bt)
-                and all(sl.deep == "embedding" and int(sl.dim) == self.emb.shape[1] for sl in self.plan.slots))
+                and self.emb.shape[1] in (4, 8, 16) and self.flat_ragged
+                and all(sl.deep == "embedding" and int(sl.dim) == self.emb.shape[1]
+                        for i, sl in enumerate(self.plan.slots) if i not in skip))
 
     def _bucket_onehot_ok(self, bt):
         return (bt.one_hot and self.rec is not None and type(self) is WideDeepEngine and bt.nnz == bt.B * self.plan.S
@@ -1430,16 +1435,17 @@ class WideDeepEngine:
         elif self.overlap_bucket and self._overlap_ok() and self._has_sparse_update():
             main, side = torch.cuda.current_stream(), self._side(0)
             side.wait_stream(main)                       # the ids were produced on the main stream
-            self._sparse_bucketize(bt, side.cuda_stream)
-            bucketized = True
-            if beside_tower is not None:
+            if beside_tower is not None and not self._bucket_onehot_ok(bt):
                 # launches that depend on nothing of this step, for the side stream behind the bucketing: they meet the input layer
                 # and the tower (MFMA-bound, the memory system idle) instead of the row update -- the next batch's featurizer
                 with torch.cuda.stream(side):
-                    beside_tower()
+                    self._sparse_bucketize(bt, side.cuda_stream, between=beside_tower)
                 beside_tower = None
+            else:
+                self._sparse_bucketize(bt, side.cuda_stream)
+            bucketized = True
         if beside_tower is not None:
-            before_join = beside_tower if before_join is None else (lambda a=before_join, b=beside_tower: (a(), b()))
+            before_join = beside_tower if before_join is None else (lambda a=before_join, b=beside_tower: (b(), a()))
         self.forward(bt, need_loss=True)
         self.backward_and_update(bt, bucketized=bucketized, pset=pset or 0, lookahead=lookahead, before_join=before_join)
         # the reference bumps global_step once per minimize() plus the explicit assign_add (quirk C.4)

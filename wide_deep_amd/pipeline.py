@@ -119,17 +119,39 @@ class StepGraph:
                     step_eager(eng, tb, ids_input)
                 return
             synth.hash_tokens(eng, tbs[0])
-            # on the side stream behind this batch's bucketing, i.e. beside the input layer and the tower (default; the featurizer's
-            # launches fit beside the tower's row tile since round 6: 0.510 -> 0.500-0.505 ms/step at configs[3]), or on this stream
-            # in front of the join with the row update (WD_HASH_WHERE=join)
-            where = os.environ.get("WD_HASH_WHERE", "tower")
+            # Where: the HEAD of the next batch's featurizer (fingerprints, bag lengths, bag CSR; a plain token batch: its whole hash)
+            # on the side stream between this batch's bucketing and its sort -- beside the input layer and the tower, whose CUs'
+            # memory side idles; the EMIT (one lane per id: 64-bit integer VALU, 33 us alone and 120 beside the tower's MFMA stream,
+            # where it also ran past the tower's end and held up the row update behind it) on this stream in front of the join with
+            # the row update, behind the small tables' update.  WD_HASH_WHERE=join: all of it there (0.510 against 0.498-0.505 ms/step
+            # at configs[3]); =tower: all of it on the side stream.
+            where = os.environ.get("WD_HASH_WHERE", "split")
+            keep = self._events = []
             for t, tb in enumerate(tbs):
                 nxt = tbs[t + 1] if t + 1 < len(tbs) else None
-                fn = (lambda nxt=nxt: synth.hash_tokens(eng, nxt)) if nxt is not None else None
-                if where == "tower":
-                    eng.train_step(tb.batch, beside_tower=fn)
+                if nxt is None:
+                    eng.train_step(tb.batch)
+                elif where == "join":
+                    eng.train_step(tb.batch, before_join=lambda nxt=nxt: synth.hash_tokens(eng, nxt))
+                elif where == "tower":
+                    eng.train_step(tb.batch, beside_tower=lambda nxt=nxt: synth.hash_tokens(eng, nxt))
                 else:
-                    eng.train_step(tb.batch, before_join=fn)
+                    box = {}
+
+                    def head(nxt=nxt, box=box):
+                        synth.hash_tokens(eng, nxt, phase="head")
+                        box["ev"] = torch.cuda.Event()
+                        box["ev"].record(torch.cuda.current_stream())
+                        keep.append(box["ev"])
+
+                    def emit(nxt=nxt, box=box):
+                        if "ev" in box:
+                            torch.cuda.current_stream().wait_event(box["ev"])
+                        else:       # (the engine had no side work for this batch: the head has not run yet)
+                            synth.hash_tokens(eng, nxt, phase="head")
+                        synth.hash_tokens(eng, nxt, phase="emit")
+
+                    eng.train_step(tb.batch, beside_tower=head, before_join=emit)
             return
         main = torch.cuda.current_stream()
         keep = self._events = []

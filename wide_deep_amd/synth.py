@@ -124,12 +124,23 @@ class ParsedTokenBatch:
         self.batch = featurizer.finalize(self.pdb)
 
 
-def hash_tokens(engine, tb):
-    """tokens -> ids on the device (wd_hash_bucket): a4 of SURVEY section 8."""
+def hash_tokens(engine, tb, phase="all"):
+    """tokens -> ids on the device (wd_hash_bucket): a4 of SURVEY section 8.  phase: "all", or -- a pipelined capture that wants the two
+    halves of a parsed batch's featurizer on two streams -- "head" (fingerprints, bag lengths, bag CSR: memory-light, fits beside the
+    tower) then "emit" (the ids: 64-bit integer VALU, slow beside the tower); a plain TokenBatch is hashed whole by "head"."""
     if isinstance(tb, FeaturizedBatch):
         return tb.batch
     if isinstance(tb, ParsedTokenBatch):     # a4 + a5: hash buckets and crossed columns of a parsed batch (features.Featurizer.run)
-        return tb.fz.run(tb.pdb)
+        if phase == "all":
+            return tb.fz.run(tb.pdb)
+        st = torch.cuda.current_stream().cuda_stream
+        if phase == "head":
+            tb.fz._run_head(tb.pdb, st)
+        else:
+            tb.fz._run_emit(tb.pdb, st)
+        return tb.batch
+    if phase == "emit":
+        return tb.batch
     plan = getattr(engine, "hash_plan", engine.plan)            # sharded engines hash in the global id space
     slots_dev = getattr(engine, "hash_slots_dev", engine.slots_dev)
     st = torch.cuda.current_stream().cuda_stream

@@ -211,6 +211,15 @@ int wd_feat_emit(const wd_feat_slot_t *slots_dev, const wd_feat_batch_t *batch, 
 int wd_embag_fwd(const float *emb, const wd_slot_t *slots, int32_t S, const int32_t *group_slots, int32_t ngroup,
                  int32_t dim, const int32_t *ids, const int32_t *bag_offs, int64_t batch, float *x, int64_t ldx,
                  wd_stream_t stream);
+/* Round 6, row records and ragged bags: wd_embag_fwd_strided on the record table that also leaves the wide sum of every bag
+ * (python/lib/linear.py:29-36) -- wide_vals[b * S + s] = sum over the bag of rec[row][dim], the word behind the row in the line the gather
+ * fetched anyway; wd_wide_sum: wide_logit[b] = bias + the sums of b's bags (columns that are not wide or carry WD_SLOT_F_SMALL skipped).
+ * Replaces wd_wide_fwd's second pass over the same lines. */
+int wd_embag_fwd_wide(const float *rec, int64_t rec_stride, const wd_slot_t *rec_slots, int32_t S, const int32_t *group_slots,
+                      int32_t ngroup, int32_t dim, const int32_t *ids, const int32_t *bag_offs, int64_t batch, float *x, int64_t ldx,
+                      float *wide_vals, wd_stream_t stream);
+int wd_wide_sum(const float *wide_vals, const float *bias, const wd_slot_t *slots, int32_t S, int64_t batch, float *out,
+                wd_stream_t stream);
 /* Same with an explicit row stride (floats, multiple of 4, >= dim): row i of a slot starts at emb_off + i*row_stride.
  * Used to pool rows that arrived through the all-to-all exchange (rows are then `row_stride` apart); ids < 0 are
  * skipped (they still count in the mean's denominator, like an all-zero row). */

@@ -191,6 +191,8 @@ _PROTOS = {
     "wd_dense_fwd": [P, I64, P, I32, I64, P, I64, P],
     "wd_wide_fwd": [P, I32, P, P, I32, P, P, I64, P, P],
     "wd_small_tables_ws_floats": [I32, I32, I32, I64],
+    "wd_embag_fwd_wide": [P, I64, P, I32, P, I32, I32, P, P, I64, P, I64, P, P],
+    "wd_wide_sum": [P, P, P, I32, I64, P, P],
     "wd_small_tables_fwd": [P, P, P, I32, P, I32, I32, I32, P, P, I64, P, I64, P, I32, P],
     "wd_small_tables_bwd": [P, P, P, P, I32, P, I32, I32, I32, P, P, I64, P, I64, P, F32, F32, F32, F32, P, I64, I32, P],
     "wd_small_tables_grad": [P, I32, P, I32, I32, I32, P, P, I64, P, I64, P, P, I64, P, P],

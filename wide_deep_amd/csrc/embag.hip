@@ -15,11 +15,15 @@
 
 namespace {
 
-template <int LANES>  // LANES = D/4 lanes cooperate on one bag
+// WIDE (round 6, row records): the bag's wide sum rides along -- lane 0 adds the {w, ..} word behind every row it fetches (same
+// 128-byte line) and leaves wide_vals[bag]; wd_wide_sum adds a row's bags up.  The separate wide pass re-read every line: 30 us of
+// the 120 us input layer of a configs[3] step.
+template <int LANES, bool WIDE = false>  // LANES = D/4 lanes cooperate on one bag
 __global__ void __launch_bounds__(256)
 k_embag_fwd(const float *__restrict__ emb, const wd_slot_t *__restrict__ slots, int32_t S,
             const int32_t *__restrict__ group_slots, int32_t ngroup, const int32_t *__restrict__ ids,
-            const int32_t *__restrict__ bag_offs, int64_t nwork, float *__restrict__ x, int64_t ldx, int64_t RS4) {
+            const int32_t *__restrict__ bag_offs, int64_t nwork, float *__restrict__ x, int64_t ldx, int64_t RS4,
+            float *__restrict__ wide_vals = nullptr) {
   WD_SIDE_PRIO();
   // RS4: row stride in float4 units (LANES for a dense table; larger for rows received through the exchange)
   constexpr int D = LANES * 4;
@@ -38,6 +42,8 @@ k_embag_fwd(const float *__restrict__ emb, const wd_slot_t *__restrict__ slots, 
   typedef float f4 __attribute__((ext_vector_type(4)));
   const f4 *__restrict__ tv = reinterpret_cast<const f4 *>(tab);
   f4 acc = (f4)(0.f);
+  float wacc = 0.f;
+  const float *__restrict__ wp = emb + emb_off + D;      // WIDE: the {w, z, n, -} words sit behind the D floats of a row
   int32_t j = j0;
   for (; j + 4 <= j1; j += 4) {
     int32_t i0 = ids[j], i1 = ids[j + 1], i2 = ids[j + 2], i3 = ids[j + 3];
@@ -45,12 +51,19 @@ k_embag_fwd(const float *__restrict__ emb, const wd_slot_t *__restrict__ slots, 
     f4 r1 = i1 >= 0 ? tv[(int64_t)i1 * RS4 + lane] : (f4)(0.f);
     f4 r2 = i2 >= 0 ? tv[(int64_t)i2 * RS4 + lane] : (f4)(0.f);
     f4 r3 = i3 >= 0 ? tv[(int64_t)i3 * RS4 + lane] : (f4)(0.f);
+    if (WIDE && lane == 0) {
+      const float w0 = i0 >= 0 ? wp[(int64_t)i0 * RS4 * 4] : 0.f, w1 = i1 >= 0 ? wp[(int64_t)i1 * RS4 * 4] : 0.f;
+      const float w2 = i2 >= 0 ? wp[(int64_t)i2 * RS4 * 4] : 0.f, w3 = i3 >= 0 ? wp[(int64_t)i3 * RS4 * 4] : 0.f;
+      wacc += w0; wacc += w1; wacc += w2; wacc += w3;
+    }
     acc += r0; acc += r1; acc += r2; acc += r3;
   }
   for (; j < j1; ++j) {
     const int32_t i0 = ids[j];
     acc += i0 >= 0 ? tv[(int64_t)i0 * RS4 + lane] : (f4)(0.f);
+    if (WIDE && lane == 0 && i0 >= 0) wacc += wp[(int64_t)i0 * RS4 * 4];
   }
+  if (WIDE && lane == 0) wide_vals[bag] = wacc;
   const int32_t n = j1 - j0;
   if (n > 1) {  // combiner='mean': sum / count (duplicates counted), SURVEY App. A.6
     const float c = (float)n;
@@ -334,6 +347,29 @@ __device__ __forceinline__ void wide_body(const float *__restrict__ wide, const 
   if (b < batch && lane == 0) out[b] = acc + bias[0];
 }
 
+// out[b] = bias + the wide sums of example b's bags (wide_vals[b * S + s], left by k_embag_fwd<.., true>): 16 lanes per example,
+// lane l takes the slots l, l + 16, ..; small-table columns (wd_small_tables_fwd adds their share) and non-wide columns skipped
+__global__ void __launch_bounds__(256)
+k_wide_sum(const float *__restrict__ wide_vals, const float *__restrict__ bias, const wd_slot_t *__restrict__ slots, int32_t S,
+           int64_t batch, float *__restrict__ out) {
+  WD_SIDE_PRIO();
+  const int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t b = tid >> 4;
+  const int lane = (int)(tid & 15);
+  float acc = 0.f;
+  if (b < batch)
+    for (int32_t s = lane; s < S; s += 16) {
+      const wd_slot_t sl = slots[s];
+      if (!sl.wide || (sl.flags & WD_SLOT_F_SMALL)) continue;
+      acc += wide_vals[b * S + s];
+    }
+  acc += __shfl_xor(acc, 8, 16);
+  acc += __shfl_xor(acc, 4, 16);
+  acc += __shfl_xor(acc, 2, 16);
+  acc += __shfl_xor(acc, 1, 16);
+  if (b < batch && lane == 0) out[b] = acc + bias[0];
+}
+
 __global__ void __launch_bounds__(256)
 k_wide_fwd(const float *__restrict__ wide, const float *__restrict__ bias, const wd_slot_t *__restrict__ slots,
            int32_t S, const int32_t *__restrict__ ids, const int32_t *__restrict__ bag_offs, int64_t batch,
@@ -438,7 +474,8 @@ extern "C" int wd_bce_loss_sum(const float *logit, const float *labels, const fl
 
 static int embag_fwd_impl(const float *emb, int64_t row_stride, const wd_slot_t *slots, int32_t S,
                           const int32_t *group_slots, int32_t ngroup, int32_t dim, const int32_t *ids,
-                          const int32_t *bag_offs, int64_t batch, float *x, int64_t ldx, wd_stream_t stream) {
+                          const int32_t *bag_offs, int64_t batch, float *x, int64_t ldx, wd_stream_t stream,
+                          float *wide_vals = nullptr) {
   if (batch <= 0 || ngroup <= 0) return WD_OK;
   WD_REQUIRE(emb && slots && group_slots && ids && bag_offs && x, "null pointer");
   WD_REQUIRE(dim > 0, "dim must be > 0");
@@ -449,7 +486,17 @@ static int embag_fwd_impl(const float *emb, int64_t row_stride, const wd_slot_t 
   hipStream_t st = wd::as_stream(stream);
 #define WD_LAUNCH_EMBAG(L)                                                                                         \
   hipLaunchKernelGGL(k_embag_fwd<L>, dim3((unsigned)wd::ceil_div(nwork * L, 256)), dim3(256), 0, st, emb, slots, S, \
-                     group_slots, ngroup, ids, bag_offs, nwork, x, ldx, RS4)
+                     group_slots, ngroup, ids, bag_offs, nwork, x, ldx, RS4, (float *)nullptr)
+#define WD_LAUNCH_EMBAG_W(L)                                                                                            \
+  hipLaunchKernelGGL((k_embag_fwd<L, true>), dim3((unsigned)wd::ceil_div(nwork * L, 256)), dim3(256), 0, st, emb, slots, \
+                     S, group_slots, ngroup, ids, bag_offs, nwork, x, ldx, RS4, wide_vals)
+  if (wide_vals) {
+    WD_REQUIRE((dim == 4 || dim == 8 || dim == 16) && row_stride >= dim + 4, "wide_vals: row records [dim | w z n -], dim in {4, 8, 16}");
+    if (dim == 4) WD_LAUNCH_EMBAG_W(1);
+    else if (dim == 8) WD_LAUNCH_EMBAG_W(2);
+    else WD_LAUNCH_EMBAG_W(4);
+    return wd::check_launch("wd_embag_fwd_wide");
+  }
   switch (dim) {
     case 4: WD_LAUNCH_EMBAG(1); break;
     case 8: WD_LAUNCH_EMBAG(2); break;
@@ -462,6 +509,7 @@ static int embag_fwd_impl(const float *emb, int64_t row_stride, const wd_slot_t 
                          slots, S, group_slots, ngroup, dim, ids, bag_offs, nwork, x, ldx);
   }
 #undef WD_LAUNCH_EMBAG
+#undef WD_LAUNCH_EMBAG_W
   return wd::check_launch("wd_embag_fwd");
 }
 
@@ -495,6 +543,23 @@ extern "C" int wd_dense_fwd(const float *dense, int64_t ld_dense, const wd_dense
   hipLaunchKernelGGL(k_dense_fwd, dim3((unsigned)wd::ceil_div(batch * ncols, 256)), dim3(256), 0,
                      wd::as_stream(stream), dense, ld_dense, cols, ncols, batch, x, ldx);
   return wd::check_launch("wd_dense_fwd");
+}
+
+extern "C" int wd_embag_fwd_wide(const float *rec, int64_t rec_stride, const wd_slot_t *rec_slots, int32_t S,
+                                 const int32_t *group_slots, int32_t ngroup, int32_t dim, const int32_t *ids,
+                                 const int32_t *bag_offs, int64_t batch, float *x, int64_t ldx, float *wide_vals,
+                                 wd_stream_t stream) {
+  WD_REQUIRE(wide_vals, "null pointer");
+  return embag_fwd_impl(rec, rec_stride, rec_slots, S, group_slots, ngroup, dim, ids, bag_offs, batch, x, ldx, stream, wide_vals);
+}
+
+extern "C" int wd_wide_sum(const float *wide_vals, const float *bias, const wd_slot_t *slots, int32_t S, int64_t batch, float *out,
+                           wd_stream_t stream) {
+  if (batch <= 0) return WD_OK;
+  WD_REQUIRE(wide_vals && bias && slots && out && S > 0, "null pointer");
+  hipLaunchKernelGGL(k_wide_sum, dim3((unsigned)wd::ceil_div(batch * 16, 256)), dim3(256), 0, wd::as_stream(stream), wide_vals, bias,
+                     slots, S, batch, out);
+  return wd::check_launch("wd_wide_sum");
 }
 
 extern "C" int wd_wide_fwd(const float *wide, int32_t wide_stride, const float *bias, const wd_slot_t *slots, int32_t S,

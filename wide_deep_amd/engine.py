@@ -768,19 +768,34 @@ class WideDeepEngine:
             return
         small = self._small_on(bt)
         slots_dev = self.slots_small_dev if small else self.slots_dev
+        # row records, ragged bags, ONE embedding group over every column that is not a small table: the gather leaves each bag's
+        # wide sum too (the weight sits in the line it fetched), a short launch adds them up per example -- instead of wd_wide_fwd's
+        # second pass over the same 1.06 M lines (configs[3]: 30 of the input layer's 120 us)
+        groups = self.group_slots_big if small else self.group_slots
+        fuse_wide = (self.rec is not None and spec.has_deep and spec.has_wide and len(groups) == 1
+                     and next(iter(groups)) == self.emb.shape[1] and os.environ.get("WD_EMBAG_WIDE", "1") != "0"
+                     and all(sl.wide for i, sl in enumerate(plan.slots) if i not in (self.small_idx if small else ())))
         if spec.has_deep:
             tw0 = self.towers[0]
             ld = tw0["layout"].ld
             xp = self._x_ptr(tw0)
-            for dim, gs in (self.group_slots_big if small else self.group_slots).items():
-                self.embag_fwd(dim, gs, bt, xp, ld, st, sub=small)
+            for dim, gs in groups.items():
+                if fuse_wide:
+                    if getattr(self, "_wv_ragged", None) is None:
+                        self._wv_ragged = torch.zeros(self.max_batch * max(S, 1), dtype=torch.float32, device=self.device)
+                    call("wd_embag_fwd_wide", ptr(self.rec), self.rec_stride, ptr(self.rslots_dev), S, ptr(gs), gs.numel(), dim,
+                         ptr(bt.ids), ptr(bt.bag_offs), B, xp, ld, ptr(self._wv_ragged), st)
+                else:
+                    self.embag_fwd(dim, gs, bt, xp, ld, st, sub=small)
             if self.ind_slots_dev is not None:
                 call("wd_indicator_fwd", ptr(self.slots_dev), S, ptr(self.ind_slots_dev), self.ind_slots_dev.numel(),
                      ptr(bt.ids), ptr(bt.bag_offs), B, xp, ld, st)
             if self.dense_cols_dev is not None:
                 call("wd_dense_fwd", ptr(bt.dense), bt.dense.stride(0), ptr(self.dense_cols_dev),
                      len(plan.dense_cols), B, xp, ld, st)
-        if spec.has_wide:
+        if spec.has_wide and fuse_wide:
+            call("wd_wide_sum", ptr(self._wv_ragged), ptr(self.bias), ptr(slots_dev), S, B, ptr(self.wide_logit), st)
+        elif spec.has_wide:
             call("wd_wide_fwd", ptr(self.wide), self.rec_stride or 4, ptr(self.bias), ptr(slots_dev), S, ptr(bt.ids),
                  ptr(bt.bag_offs), B, ptr(self.wide_logit), st)
         if small:

@@ -389,14 +389,16 @@ int wd_row_update(float *rec, int32_t rec_stride, int32_t dim, float *emb_accum,
  * listed (the two counters long_list[0], [1] are zeroed here); the update walks them as a flat launch over nnz_capacity positions
  * of which *nnz_dev (device; pass bucket_start + nbuckets) exist, every occurrence carrying dx / len(bag) (combiner='mean',
  * python/lib/dnn.py:83-90) -- wd_sparse_apply_rec's arithmetic, summation order included, without its sort inside the update
- * (configs[3]: 259 -> ~150 us in the step, the sort beside the tower). */
+ * (configs[3]: 259 -> ~150 us in the step, the sort beside the tower).  ld_dlogit: dlogit of example b at dlogit[b * ld_dlogit]
+ * (1; the sharded owner's received gradient records [dim | dlogit | ..]: their stride, with bias_wzn NULL). */
 int wd_bucket_sort_ragged(const int32_t *bucket_start, uint64_t *pairs, int32_t nbuckets, int32_t *long_list,
                           int32_t long_capacity, int32_t *big_list, int64_t batch, int32_t S, int64_t nnz_capacity,
                           wd_stream_t stream);
 int wd_row_update_ragged(float *rec, int32_t rec_stride, int32_t dim, float *emb_accum, float *bias_wzn, const wd_slot_t *slots,
                          int32_t S, int64_t batch, const int32_t *bag_offs, const float *dx, int64_t ldx, const float *dlogit,
-                         float lr_emb, float lr_wide, float l1, float l2, const uint64_t *pairs, int64_t nnz_capacity,
-                         const int32_t *nnz_dev, const int32_t *long_list, int32_t long_capacity, wd_stream_t stream);
+                         int64_t ld_dlogit, float lr_emb, float lr_wide, float l1, float l2, const uint64_t *pairs,
+                         int64_t nnz_capacity, const int32_t *nnz_dev, const int32_t *long_list, int32_t long_capacity,
+                         wd_stream_t stream);
 /* The input layer of a one-id-per-bag batch on the row-record tables, as its own launch (python/lib/dnn.py:83-91,
  * python/lib/linear.py:29-36): x[b*ldx + out_col_s + 0..dim) = rec[row(b,s)][0..dim), wide_vals[b*S + s] = rec[row(b,s)][dim]
  * (the wide weight, NOT summed: wd_tower_chain adds them up with the bias, wd_chain_opts_t.wide_vals), numeric columns as

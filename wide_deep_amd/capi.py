@@ -215,7 +215,7 @@ _PROTOS = {
     "wd_bucket_sort": [P, P, I32, P, I32, P, I64, I32, P, P, P, P],
     "wd_row_update": [P, I32, I32, P, P, P, I32, I64, P, I64, P, F32, F32, F32, F32, P, P, I32, P, P, P],
     "wd_bucket_sort_ragged": [P, P, I32, P, I32, P, I64, I32, I64, P],
-    "wd_row_update_ragged": [P, I32, I32, P, P, P, I32, I64, P, P, I64, P, F32, F32, F32, F32, P, I64, P, P, I32, P],
+    "wd_row_update_ragged": [P, I32, I32, P, P, P, I32, I64, P, P, I64, P, I64, F32, F32, F32, F32, P, I64, P, P, I32, P],
     "wd_hash_bucket_cols": [P, P, I64, P, I32, P, P, P],
     "wd_prefetch_onehot_blocks": [I64, I32, I32, I32],
     "wd_prefetch_onehot": [P, I32, I32, P, I32, P, I64, P, I64, P, P, I64, P, I32, P, P],

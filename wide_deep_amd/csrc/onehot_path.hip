@@ -729,6 +729,7 @@ struct RowUpd {
   // device value (what wd_sparse_bucketize scattered: ids < 0 and the small-table columns are not in the list)
   const int32_t *bag_offs;
   const int32_t *nnz_dev;
+  int64_t ld_dl;              // dlogit of example b at dlogit[b * ld_dl] (1; the sharded owner's gradient records: their stride)
 };
 
 __device__ __forceinline__ void ftrl_row(float &w, float &z, float &n, float g, float lr, float l1, float l2) {
@@ -888,7 +889,7 @@ k_row_update(RowUpd u) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           const int64_t jj = j + 256 * k;
-          v[k] = jj < e ? u.dlogit[(int32_t)(uint32_t)u.pairs[jj] / S] : 0.f;
+          v[k] = jj < e ? u.dlogit[(int64_t)((int32_t)(uint32_t)u.pairs[jj] / S) * u.ld_dl] : 0.f;
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) gw += v[k];
@@ -973,7 +974,7 @@ k_row_update(RowUpd u) {
       const float4 d = *reinterpret_cast<const float4 *>(u.dx + b * u.ldx + out_col + 4 * gl);
       g.x += d.x * scale; g.y += d.y * scale; g.z += d.z * scale; g.w += d.w * scale;
     }
-    if (gl == 0) gw += u.dlogit[b];
+    if (gl == 0) gw += u.dlogit[b * u.ld_dl];
   } else {
     // 2 .. 32 occurrences: their bag indices in ONE round of loads (lane gl of the group takes pairs i + gl, + 4, ...; a bag
     // travels to the other lanes by shuffle), then four gradient rows per round -- 1 + ceil(n / 4) dependent round trips
@@ -1002,7 +1003,7 @@ k_row_update(RowUpd u) {
         scale[k] = 1.0f;
         if (4 * c + k < n) {
           if (lane_emb) d[k] = *reinterpret_cast<const float4 *>(u.dx + (int64_t)(bag[k] / S) * u.ldx + out_col + 4 * gl);
-          if (gl == 0) v[k] = u.dlogit[bag[k] / S];
+          if (gl == 0) v[k] = u.dlogit[(int64_t)(bag[k] / S) * u.ld_dl];
           if (u.bag_offs) {
             const int32_t len = u.bag_offs[bag[k] + 1] - u.bag_offs[bag[k]];
             scale[k] = len > 1 ? 1.0f / (float)len : 1.0f;
@@ -1058,6 +1059,7 @@ extern "C" int wd_row_grad_presum(const wd_slot_t *slots, int32_t S, int64_t bat
              "record = [dim | dlogit ..], dim in {4, 8, 16}, row_stride % 4 == 0, S <= 128");
   WD_REQUIRE(ldx % 4 == 0, "ldx % 4 == 0");
   RowUpd u{};
+  u.ld_dl = 1;
   u.slots = slots; u.dx = dx; u.dlogit = dlogit; u.pairs = pairs; u.long_list = long_list; u.long_cap = long_capacity;
   u.ldx = ldx; u.nnz = batch * S; u.batch = batch; u.rec_stride = row_stride; u.dim = dim; u.S = S;
   u.emit_out = out; u.emit_pos = pos; u.emit_rs = row_stride;
@@ -1165,19 +1167,21 @@ extern "C" int wd_bucket_sort_ragged(const int32_t *bucket_start, uint64_t *pair
 
 extern "C" int wd_row_update_ragged(float *rec, int32_t rec_stride, int32_t dim, float *emb_accum, float *bias_wzn,
                                     const wd_slot_t *slots, int32_t S, int64_t batch, const int32_t *bag_offs, const float *dx,
-                                    int64_t ldx, const float *dlogit, float lr_emb, float lr_wide, float l1, float l2,
-                                    const uint64_t *pairs, int64_t nnz_capacity, const int32_t *nnz_dev, const int32_t *long_list,
-                                    int32_t long_capacity, wd_stream_t stream) {
+                                    int64_t ldx, const float *dlogit, int64_t ld_dlogit, float lr_emb, float lr_wide, float l1,
+                                    float l2, const uint64_t *pairs, int64_t nnz_capacity, const int32_t *nnz_dev,
+                                    const int32_t *long_list, int32_t long_capacity, wd_stream_t stream) {
   if (batch <= 0) return WD_OK;
   WD_REQUIRE(rec && emb_accum && slots && dx && dlogit && pairs && long_list && bag_offs && nnz_dev, "null pointer");
+  WD_REQUIRE(ld_dlogit >= 1 && (ld_dlogit == 1 || !bias_wzn), "ld_dlogit >= 1; the bias update reads a contiguous dlogit");
   WD_REQUIRE(S > 0 && S <= 128 && (dim == 4 || dim == 8 || dim == 16) && rec_stride % 4 == 0 && rec_stride >= dim + 4,
              "record = [dim | w z n -], dim in {4, 8, 16}, S <= 128");
   WD_REQUIRE(nnz_capacity > 0 && nnz_capacity < ((int64_t)1 << 31), "nnz_capacity");
   RowUpd u{};
+  u.ld_dl = 1;
   u.rec = rec; u.accum = emb_accum; u.bias = bias_wzn; u.slots = slots; u.dx = dx; u.dlogit = dlogit; u.pairs = pairs;
   u.long_list = long_list; u.long_cap = long_capacity; u.ldx = ldx; u.nnz = nnz_capacity; u.batch = batch; u.rec_stride = rec_stride;
   u.dim = dim; u.S = S; u.lr_emb = lr_emb; u.lr_w = lr_wide; u.l1 = l1; u.l2 = l2;
-  u.bag_offs = bag_offs; u.nnz_dev = nnz_dev;
+  u.bag_offs = bag_offs; u.nnz_dev = nnz_dev; u.ld_dl = ld_dlogit;
   u.flat_blocks = (int32_t)wd::ceil_div(u.nnz * 4, 256);
   u.wt = wd::wt_mask() & WD_WT_ROW_UPDATE ? 1 : 0;
   hipLaunchKernelGGL(k_row_update, dim3((unsigned)(u.flat_blocks + LONG_WORKERS + 1)), dim3(256), 0, wd::as_stream(stream), u);
@@ -1196,6 +1200,7 @@ extern "C" int wd_row_update(float *rec, int32_t rec_stride, int32_t dim, float 
   WD_REQUIRE(!patch || (next && next->pairs && next->x && next->wide_vals && next->ldx > 0),
              "patch needs the next batch's sorted pairs, x tile and wide-weight list");
   RowUpd u{};
+  u.ld_dl = 1;
   u.rec = rec; u.accum = emb_accum; u.bias = bias_wzn; u.slots = slots; u.dx = dx; u.dlogit = dlogit; u.pairs = pairs;
   u.long_list = long_list; u.long_cap = long_capacity; u.patch = reinterpret_cast<const int2 *>(patch); u.ldx = ldx; u.nnz = batch * S; u.batch = batch; u.rec_stride = rec_stride;
   u.dim = dim; u.S = S; u.lr_emb = lr_emb; u.lr_w = lr_wide; u.l1 = l1; u.l2 = l2;

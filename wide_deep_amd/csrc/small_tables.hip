@@ -43,6 +43,7 @@ struct SmallArgs {
   const float *dx, *dlogit;
   float *part;                // [nsmall][nslice][part_rows][D_max + 2]  (g_0 .. g_{D-1}, g_wide, count)
   int32_t nslice, part_rows, part_w;
+  int32_t cnt_ints;           // LDS words of the backward's [bag][row] count matrix
   int64_t bags_per_slice;
   // apply
   float *emb_w, *emb_acc, *wide_w;
@@ -65,92 +66,128 @@ __device__ __forceinline__ float wave_sum(float v) {     // fixed-shape tree ove
   return v;
 }
 
+// LDS row of the forward: LGP float4 lanes per id (1, 2 or 4 for D <= 4, 8, 16), the row padded by one float4 so that rows of
+// neighbouring ids start 4 * (LGP + 1) banks apart (rounds 5-6: rows of D floats read one float per lane -- for D = 16 every lane of a
+// wavefront on one of TWO banks, a 32-way conflict on each of the 16 reads of an id: 46 us for the 1.2 M ids of a configs[3] batch)
+// (one float4 per id -- D <= 4 -- needs no padding: random ids spread over the eight groups of four banks)
+__host__ __device__ __forceinline__ int sm_lgs(int D) { return D <= 4 ? 0 : (D <= 8 ? 1 : 2); }        // log2(lanes per id)
+__host__ __device__ __forceinline__ int sm_fwd_stride(int D) { return D <= 0 ? 0 : (D <= 4 ? 4 : (4 << sm_lgs(D)) + 4); }
+
 __global__ void __launch_bounds__(256) k_small_fwd(SmallArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];     // table [R][D] then wide weights [R]
+  extern __shared__ __attribute__((aligned(16))) float lds[];     // table [R][DS] then wide weights [R]
+  constexpr int EPW = SM_EX_PER_WG / 4;      // examples per wavefront
+  constexpr int NI = 8;                      // ids per lane in flight
   const int t = threadIdx.x, lane = t & 63, wave = uni(t >> 6);
-  const int64_t b0 = (int64_t)blockIdx.x * SM_EX_PER_WG + wave * (SM_EX_PER_WG / 4);
-  float wsum[SM_EX_PER_WG / 4];
+  const int64_t b0 = (int64_t)blockIdx.x * SM_EX_PER_WG + wave * EPW;
+  float wsum[EPW];
 #pragma unroll
-  for (int e = 0; e < SM_EX_PER_WG / 4; ++e) wsum[e] = 0.f;
+  for (int e = 0; e < EPW; ++e) wsum[e] = 0.f;
   bool any_wide = false;
   for (int k = 0; k < a.nsmall; ++k) {
     const int s = uni(a.small_idx[k]);
     const wd_slot_t sl = a.slots[s];
     const int R = uni(sl.num_buckets), D = uni(sl.dim);
-    float *T = lds, *W = lds + (int64_t)R * D;
+    const int LGS = sm_lgs(D), LGP = 1 << LGS, DS = sm_fwd_stride(D), IPI = 64 >> LGS;      // ids per wavefront and round
+    const int i = lane >> LGS, q = lane & (LGP - 1);
+    float *T = lds, *W = lds + (int64_t)R * DS;
+    // this wavefront's bags of the column: bounds, then the first NI ids of every lane -- in flight while the table lands
+    int32_t j0[EPW], j1[EPW], idv[EPW][NI];
+#pragma unroll
+    for (int e = 0; e < EPW; ++e) {
+      j0[e] = 0; j1[e] = 0;
+      if (b0 + e < a.batch) {
+        j0[e] = uni(a.bag_offs[(b0 + e) * a.S + s]);
+        j1[e] = uni(a.bag_offs[(b0 + e) * a.S + s + 1]);
+      }
+#pragma unroll
+      for (int u = 0; u < NI; ++u) {
+        const int32_t j = j0[e] + i + u * IPI;
+        idv[e][u] = j < j1[e] ? a.ids[j] : -1;
+      }
+    }
     __syncthreads();                         // the previous slot's table is no longer read
     if (D > 0) {
-      if (a.es) {
-        for (int i = t; i < R * D; i += 256) T[i] = a.emb[sm_row(a, sl, i / D, D) + i % D];
-      } else {
-        for (int i = t; i < R * D; i += 256) T[i] = a.emb[sl.emb_off + i];
+      const int DPS = LGS + 2, DP = 1 << DPS;
+      for (int x = t; x < R * DP; x += 256) {
+        const int r = x >> DPS, d = x & (DP - 1);
+        T[r * DS + d] = d < D ? a.emb[sm_row(a, sl, r, D) + d] : 0.f;
       }
     }
     if (sl.wide)
-      for (int i = t; i < R; i += 256) W[i] = a.wide[(sl.row_base + i) * a.ws];
+      for (int x = t; x < R; x += 256) W[x] = a.wide[(sl.row_base + x) * a.ws];
     __syncthreads();
     any_wide = any_wide || sl.wide;
 #pragma unroll
-    for (int e = 0; e < SM_EX_PER_WG / 4; ++e) {
+    for (int e = 0; e < EPW; ++e) {
       const int64_t b = b0 + e;
       if (b >= a.batch) break;
-      const int64_t bag = b * a.S + s;
-      const int32_t j0 = a.bag_offs[bag], j1 = a.bag_offs[bag + 1];
-      float acc[SM_MAX_DIM];
-#pragma unroll
-      for (int d = 0; d < SM_MAX_DIM; ++d) acc[d] = 0.f;
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
       float ws = 0.f;
       // combiner='mean' divides by the bag's length, as wd_embag_fwd and k_small_bwd do (a negative id -- none reaches a bag
       // of the featurizer -- contributes a zero row but still counts)
-      const float cnt = (float)(j1 - j0);
-      for (int32_t j = j0 + lane; j < j1; j += 64) {
-        const int32_t id = a.ids[j];
-        if (id < 0) continue;
-        if (sl.wide) ws += W[id];
-#pragma unroll
-        for (int d = 0; d < SM_MAX_DIM; ++d)
-          if (d < D) acc[d] += T[id * D + d];
-      }
-      if (sl.wide) wsum[e] += wave_sum(ws);
-      if (D > 0 && sl.out_col >= 0) {
-#pragma unroll
-        for (int d = 0; d < SM_MAX_DIM; ++d) {
-          if (d < D) {
-            float v = wave_sum(acc[d]);
-            if (cnt > 1.f) v = v / cnt;              // combiner='mean' (an empty bag stays the zero vector)
-            if (lane == 0) a.x[b * a.ldx + sl.out_col + d] = v;
-          }
+      const float cnt = (float)(j1[e] - j0[e]);
+      auto one = [&](int32_t id) {
+        if (id < 0) return;
+        if (sl.wide && q == 0) ws += W[id];
+        if (D > 0) {
+          const float4 v = *reinterpret_cast<const float4 *>(T + id * DS + 4 * q);
+          acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
         }
+      };
+#pragma unroll
+      for (int u = 0; u < NI; ++u) one(idv[e][u]);
+      for (int32_t j = j0[e] + i + NI * IPI; j < j1[e]; j += IPI) one(a.ids[j]);
+      for (int m = LGP; m < 64; m <<= 1) {         // fixed tree over the lanes of one quarter
+        acc.x += __shfl_xor(acc.x, m, 64); acc.y += __shfl_xor(acc.y, m, 64);
+        acc.z += __shfl_xor(acc.z, m, 64); acc.w += __shfl_xor(acc.w, m, 64);
+        ws += __shfl_xor(ws, m, 64);
+      }
+      if (sl.wide) wsum[e] += ws;
+      if (D > 0 && sl.out_col >= 0 && lane < LGP) {
+        if (cnt > 1.f) { acc.x /= cnt; acc.y /= cnt; acc.z /= cnt; acc.w /= cnt; }     // (an empty bag stays the zero vector)
+        float *xp = a.x + b * a.ldx + sl.out_col + 4 * q;
+        const float v[4] = {acc.x, acc.y, acc.z, acc.w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          if (4 * q + c < D) xp[c] = v[c];
       }
     }
   }
   if (any_wide && a.wide_logit && lane == 0) {
 #pragma unroll
-    for (int e = 0; e < SM_EX_PER_WG / 4; ++e)
+    for (int e = 0; e < EPW; ++e)
       if (b0 + e < a.batch) a.wide_logit[b0 + e] += wsum[e];      // behind wd_wide_fwd (bias + the other columns) in stream order
   }
 }
 
+// Backward partials of one (slice of the batch, slot).  Round 5 walked the slice's bags one after the other -- count a bag into an
+// LDS histogram, barrier, every row's owner adds count x gradient: 64 barriers in a row on 256 workgroups, 55 us at configs[3] for
+// 10 MB of ids.  Now the bags of a pass (as many as fit: 64 at 200 rows) are counted TOGETHER into a [bag][row] matrix of integer
+// LDS atomics (exact, order-free; four wavefronts, a bag each, the ids of eight bags in flight), one barrier, and the owner thread
+// of a row walks the pass's bags in ascending order adding count x (dx / len | dlogit) -- the same adds in the same order as
+// before (bit-identical partials), on staged products, without a barrier between them.
+constexpr int SM_GS = 20;                    // staged gradient of a bag: [dx * (1 / len)  (16) | dlogit | - - -]
+constexpr int SM_CNT_INTS = 12800;           // count matrix of a pass, at most (64 bags x 200 rows)
+
 __global__ void __launch_bounds__(256) k_small_bwd(SmallArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int t = threadIdx.x;
+  const int t = threadIdx.x, lane = t & 63, wave = uni(t >> 6);
   const int k = blockIdx.y, c = blockIdx.x;
   const int s = uni(a.small_idx[k]);
   const wd_slot_t sl = a.slots[s];
   const int R = uni(sl.num_buckets), D = uni(sl.dim);
   const int PW = D + 2;                                   // partial record: g_0 .. g_{D-1}, g_wide, count
   float *part = lds;                                      // [R][PW]
-  int32_t *cnt = reinterpret_cast<int32_t *>(lds + (int64_t)R * PW);   // [2][R]
-  for (int i = t; i < R * PW; i += 256) part[i] = 0.f;
-  for (int i = t; i < 2 * R; i += 256) cnt[i] = 0;
-  __syncthreads();
+  int32_t *cnt = reinterpret_cast<int32_t *>(lds + (int64_t)a.part_rows * a.part_w);      // [PB][R]
+  int32_t *lo = cnt + a.cnt_ints, *hi = lo + SM_SLICE;       // [SM_SLICE] each: ids [lo, hi) of the slice's q-th bag
+  float *gs = reinterpret_cast<float *>(hi + SM_SLICE);      // [SM_SLICE][SM_GS]
   const int64_t e0 = (int64_t)c * a.bags_per_slice;
   const int64_t e1 = e0 + a.bags_per_slice < a.batch ? e0 + a.bags_per_slice : a.batch;
   const int nbag = (int)(e1 - e0);
-  // the slice's bag bounds and gradients in ONE round of loads (a bag's own chain offsets -> ids -> count would be two round
-  // trips per bag, 64 times in a row: 84 us for a launch that moves 10 MB)
-  int32_t *lo = cnt + 2 * R, *hi = lo + SM_SLICE;            // [SM_SLICE] each: ids [lo, hi) of the slice's q-th bag
-  float *gs = reinterpret_cast<float *>(hi + SM_SLICE);      // [SM_SLICE][SM_MAX_DIM + 1]: its dx and dlogit
+  int PB = a.cnt_ints / R;                                   // bags per pass (cnt_ints >= the longest table: at least one)
+  PB = PB < (int)a.bags_per_slice ? PB : (int)a.bags_per_slice;
+  for (int i = t; i < R * PW; i += 256) part[i] = 0.f;
+  // the slice's bag bounds and gradients in ONE round of loads
   for (int i = t; i < nbag; i += 256) {
     lo[i] = a.bag_offs[(e0 + i) * a.S + s];
     hi[i] = a.bag_offs[(e0 + i) * a.S + s + 1];
@@ -158,60 +195,76 @@ __global__ void __launch_bounds__(256) k_small_bwd(SmallArgs a) {
   for (int i = t; i < nbag * (D + 1); i += 256) {
     const int q = i / (D + 1), d = i - q * (D + 1);
     float v;
-    if (d < D) v = (a.dx && sl.out_col >= 0) ? a.dx[(e0 + q) * a.ldx + sl.out_col + d] : 0.f;
-    else v = (sl.wide && a.dlogit) ? a.dlogit[e0 + q] : 0.f;
-    gs[q * (SM_MAX_DIM + 1) + d] = v;
+    if (d < D) {
+      v = (a.dx && sl.out_col >= 0) ? a.dx[(e0 + q) * a.ldx + sl.out_col + d] : 0.f;
+      const int32_t len = a.bag_offs[(e0 + q) * a.S + s + 1] - a.bag_offs[(e0 + q) * a.S + s];
+      const float scale = len > 1 ? 1.0f / (float)len : 1.0f;      // mean combiner: every occurrence carries dx / len
+      gs[q * SM_GS + d] = v * scale;
+    } else {
+      gs[q * SM_GS + SM_MAX_DIM] = (sl.wide && a.dlogit) ? a.dlogit[e0 + q] : 0.f;
+    }
   }
-  __syncthreads();
-  // ids: a ring of four bags in flight (two ids per lane each; what a bag holds beyond 512 ids is loaded when it is counted)
-  int32_t idr[4][2];
-  auto lens_of = [&](int q, int32_t &j0, int32_t &j1) {
-    j0 = 0; j1 = 0;
-    if (q < nbag) { j0 = lo[q]; j1 = hi[q]; }
-  };
-  auto load_ids = [&](int q, int32_t (&r)[2]) {
-    int32_t j0, j1;
-    lens_of(q, j0, j1);
-    r[0] = j0 + t < j1 ? a.ids[j0 + t] : -1;
-    r[1] = j0 + t + 256 < j1 ? a.ids[j0 + t + 256] : -1;
-  };
-#pragma unroll
-  for (int q = 0; q < 4; ++q) load_ids(q, idr[q]);
-  int p = 0;
-  auto one_bag = [&](int q, int32_t (&r)[2]) {
-    if (q >= nbag) return;
-    int32_t j0, j1;
-    lens_of(q, j0, j1);
-    const int32_t len = j1 - j0;
-    int32_t *cp = cnt + p * R;
-    if (r[0] >= 0) atomicAdd(&cp[r[0]], 1);
-    if (r[1] >= 0) atomicAdd(&cp[r[1]], 1);
-    for (int32_t j = j0 + 512 + t; j < j1; j += 256) {
-      const int32_t id = a.ids[j];
-      if (id >= 0) atomicAdd(&cp[id], 1);
-    }
-    load_ids(q + 4, r);                                   // this slot of the ring: the bag four ahead
+  for (int q0 = 0; q0 < nbag; q0 += PB) {
+    const int nb = nbag - q0 < PB ? nbag - q0 : PB;
+    __syncthreads();                                      // staging done / the previous pass's counts are consumed
+    for (int i = t; i < nb * R; i += 256) cnt[i] = 0;
     __syncthreads();
-    const float scale = len > 1 ? 1.0f / (float)len : 1.0f;      // mean combiner: every occurrence carries dx / len
-    const float *gp = gs + q * (SM_MAX_DIM + 1);
-    for (int rr = t; rr < R; rr += 256) {
-      const int32_t n = cp[rr];
-      if (n == 0) continue;
-      cp[rr] = 0;                                 // this histogram is counted into again two bags from now
-      const float fn = (float)n;
-      float *pr = part + (int64_t)rr * PW;
-      for (int d = 0; d < D; ++d) pr[d] += fn * (gp[d] * scale);
-      pr[D] += fn * gp[D];
-      pr[D + 1] += fn;
+    // count: wavefront w takes bags w, w + 4, ...; the ids of eight of them (128 per bag) in flight at a time
+    for (int qb = wave; qb < nb; qb += 32) {
+      int32_t idr[8][2];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int q = qb + 4 * u;
+        idr[u][0] = -1; idr[u][1] = -1;
+        if (q < nb) {
+          const int32_t j0 = lo[q0 + q], j1 = hi[q0 + q];
+          if (j0 + lane < j1) idr[u][0] = a.ids[j0 + lane];
+          if (j0 + lane + 64 < j1) idr[u][1] = a.ids[j0 + lane + 64];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int q = qb + 4 * u;
+        if (q >= nb) break;
+        int32_t *cp = cnt + q * R;
+        if (idr[u][0] >= 0) atomicAdd(&cp[idr[u][0]], 1);
+        if (idr[u][1] >= 0) atomicAdd(&cp[idr[u][1]], 1);
+        const int32_t j1 = hi[q0 + q];
+        for (int32_t j = lo[q0 + q] + 128 + lane; j < j1; j += 64) {
+          const int32_t id = a.ids[j];
+          if (id >= 0) atomicAdd(&cp[id], 1);
+        }
+      }
     }
-    p ^= 1;
-    // (no second barrier: the next bag counts into the OTHER histogram; a thread can be at most one barrier ahead of another)
-  };
-  for (int q0 = 0; q0 < nbag; q0 += 4) {
-    one_bag(q0 + 0, idr[0]);
-    one_bag(q0 + 1, idr[1]);
-    one_bag(q0 + 2, idr[2]);
-    one_bag(q0 + 3, idr[3]);
+    __syncthreads();
+    for (int rr = t; rr < R; rr += 256) {
+      float *pr = part + (int64_t)rr * PW;
+      float acc[SM_MAX_DIM + 2];
+#pragma unroll
+      for (int d = 0; d < SM_MAX_DIM; ++d) acc[d] = d < D ? pr[d] : 0.f;
+      acc[SM_MAX_DIM] = pr[D];
+      acc[SM_MAX_DIM + 1] = pr[D + 1];
+      for (int q = 0; q < nb; ++q) {
+        const int32_t n = cnt[q * R + rr];
+        if (n == 0) continue;
+        const float fn = (float)n;
+        const float *gp = gs + (q0 + q) * SM_GS;
+#pragma unroll
+        for (int d4 = 0; d4 < SM_MAX_DIM / 4; ++d4) {
+          if (4 * d4 < D) {
+            const float4 g = *reinterpret_cast<const float4 *>(gp + 4 * d4);
+            acc[4 * d4 + 0] += fn * g.x; acc[4 * d4 + 1] += fn * g.y; acc[4 * d4 + 2] += fn * g.z; acc[4 * d4 + 3] += fn * g.w;
+          }
+        }
+        acc[SM_MAX_DIM] += fn * gp[SM_MAX_DIM];
+        acc[SM_MAX_DIM + 1] += fn;
+      }
+#pragma unroll
+      for (int d = 0; d < SM_MAX_DIM; ++d)
+        if (d < D) pr[d] = acc[d];
+      pr[D] = acc[SM_MAX_DIM];
+      pr[D + 1] = acc[SM_MAX_DIM + 1];
+    }
   }
   __syncthreads();
   float *out = a.part + ((int64_t)k * a.nslice + c) * a.part_rows * a.part_w;
@@ -362,7 +415,7 @@ extern "C" int wd_small_tables_fwd(const float *emb, const float *wide, const wd
   a.slots = slots; a.small_idx = small_idx; a.nsmall = nsmall; a.S = S; a.ids = ids; a.bag_offs = bag_offs; a.batch = batch;
   a.emb = emb; a.wide = wide; a.x = x; a.ldx = ldx; a.wide_logit = wide_logit;
   a.es = rec_stride; a.ws = rec_stride ? rec_stride : 4;
-  const size_t lds = (size_t)max_rows * (max_dim + 1) * 4;
+  const size_t lds = (size_t)max_rows * (sm_fwd_stride(max_dim) + 1) * 4;      // (< 64 KB for every shape small_check admits)
   hipLaunchKernelGGL(k_small_fwd, dim3((unsigned)wd::ceil_div(batch, (int64_t)SM_EX_PER_WG)), dim3(256), lds,
                      wd::as_stream(stream), a);
   return wd::check_launch("wd_small_tables_fwd");
@@ -387,10 +440,13 @@ static int small_bwd_args(SmallArgs &a, size_t &lds, float *emb, float *emb_accu
   a.emb_w = emb; a.emb_acc = emb_accum; a.wide_w = wide_wzn;
   a.lr_emb = lr_emb; a.lr_w = lr_wide; a.l1 = l1; a.l2 = l2;
   a.es = rec_stride; a.ws = rec_stride ? rec_stride : 4;
-  lds = (size_t)max_rows * (max_dim + 2) * 4 + (size_t)2 * max_rows * 4 + (size_t)2 * SM_SLICE * 4 +
-        (size_t)SM_SLICE * (SM_MAX_DIM + 1) * 4;
-  // a wide-only table of ~4 k rows asks for 32 KB of partials + 32 KB of histograms + staging: beyond the 64 KB a launch gets
-  // without the attribute (WD_SMALL_MAX_FLOATS bounds it at 32 KB + 64 KB + 4.9 KB)
+  {
+    const int64_t want = a.bags_per_slice * max_rows;      // every bag of a slice in one pass, if that fits
+    a.cnt_ints = (int32_t)(want < SM_CNT_INTS ? want : (max_rows > SM_CNT_INTS ? max_rows : SM_CNT_INTS));
+  }
+  lds = (size_t)max_rows * (max_dim + 2) * 4 + (size_t)a.cnt_ints * 4 + (size_t)2 * SM_SLICE * 4 + (size_t)SM_SLICE * SM_GS * 4;
+  // configs[3] (200 rows x 16 + 2, 64 bags per pass) asks for 14 + 50 + 5.5 KB, a wide-only table of ~4 k rows for 32 + 50 + 5.5:
+  // beyond the 64 KB a launch gets without the attribute (WD_SMALL_MAX_FLOATS bounds it at 32 + 50 + 5.5 KB)
   static size_t lds_allowed = 64 * 1024;
   if (lds > lds_allowed) {
     const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_small_bwd), hipFuncAttributeMaxDynamicSharedMemorySize,

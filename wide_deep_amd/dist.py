@@ -350,7 +350,13 @@ class ShardedWideDeepEngine(WideDeepEngine):
         self._obsets = [dict(cnt=torch.zeros((2 * int(call("wd_bucket_chunks")) + 1) * self.n_buckets, **i32),
                              start=torch.zeros(2 * self.n_buckets + 2, **i32),   # starts [nb+1] + launch order [nb]
                              rank=torch.zeros(self.n_req, **i32),
+                             long_list=torch.zeros(2 * (self.n_req // 32 + 2) + 2, **i32), big_list=torch.zeros(self.n_buckets, **i32),
                              pairs=torch.zeros(self.n_req, dtype=torch.int64, device=dev)) for _ in range(2)]
+        # default optimizers on row records, every local row embedded: the owner's update is the single engine's flat one -- the
+        # buckets of the received list sorted ahead (one wavefront per bucket, beside the gradient exchange), wd_row_update_ragged
+        # over the sorted pairs (WD_OWNER_FLAT=0: wd_sparse_apply_rec sorts inside its update workgroups)
+        self.owner_flat = (self.rec is not None and self.default_opts and self.dim in (4, 8, 16) and has_emb
+                           and self.n_emb_rows == lp.total_rows and os.environ.get("WD_OWNER_FLAT", "1") != "0")
         self.oslot_dev = make_slots([dict(emb_off=0, row_base=0, num_buckets=max(self.n_emb_rows, 1), dim=self.dim,
                                           out_col=0, kind=capi.SLOT_EMBEDDING if has_emb else capi.SLOT_NONE, wide=1,
                                           bucket_shift=osh[0], bucket_base=0)])
@@ -521,6 +527,9 @@ class ShardedWideDeepEngine(WideDeepEngine):
         ob = self._obsets[self._pset]
         call("wd_sparse_bucketize", ptr(self.oslot_dev), 1, ptr(self.recv_rows), ptr(self.req_offs), self.n_req,
              self.n_req, ptr(ob["cnt"]), ptr(ob["start"]), ptr(ob["rank"]), ptr(ob["pairs"]), self.n_buckets, st)
+        if self.owner_flat:
+            call("wd_bucket_sort_ragged", ptr(ob["start"]), ptr(ob["pairs"]), self.n_buckets, ptr(ob["long_list"]),
+                 (ob["long_list"].numel() - 2) // 2, ptr(ob["big_list"]), self.n_req, 1, self.n_req, st)
 
     def _owner_gather(self, st):
         """B: owners read the requested rows (+ wide weight) and send them back."""
@@ -674,6 +683,12 @@ class ShardedWideDeepEngine(WideDeepEngine):
                 call("wd_adam_untouched", ptr(self.emb) if (has_emb and "dnn" in self.pow) else None, ptr(self.emb_a),
                      ptr(self.emb_acc), ptr(self.wide) if "linear" in self.pow else None, ptr(self.aslots_dev), 2,
                      max(self.plan.total_rows, 1), max(self.plan.total_rows, 1), ptr(self.touched), od, ol, st)
+            return
+        if self.owner_flat:
+            call("wd_row_update_ragged", ptr(self.rec), self.rec_stride, self.dim, ptr(self.emb_acc), None, ptr(self.oslot_dev), 1,
+                 self.n_req, ptr(self.req_offs), g_ptr, self.RS, dl_ptr, self.RS, float(spec.dnn_opt[1]), float(lr), float(l1),
+                 float(l2), ptr(ob["pairs"]), self.n_req, ob["start"].data_ptr() + 4 * self.n_buckets, ptr(ob["long_list"]),
+                 (ob["long_list"].numel() - 2) // 2, st)
             return
         if self.rec is not None:
             call("wd_sparse_apply_rec", ptr(self.rec), self.rec_stride, self.dim, ptr(self.emb_acc), None, ptr(self.oslot_dev),

@@ -1224,7 +1224,7 @@ class WideDeepEngine:
             dx_ptr, ld = tw0["dact"].data_ptr() + 4 * tl0.seg_start[0], tl0.ld
         if self.rec is not None and bsx["sorted"] and bsx.get("ragged"):
             call("wd_row_update_ragged", ptr(self.rec), self.rec_stride, self.emb.shape[1], ptr(self.emb_acc), ptr(self.bias),
-                 ptr(self.slots_dev), plan.S, bt.B, ptr(bt.bag_offs), dx_ptr, ld, ptr(self.dlogit), float(spec.dnn_opt[1]),
+                 ptr(self.slots_dev), plan.S, bt.B, ptr(bt.bag_offs), dx_ptr, ld, ptr(self.dlogit), 1, float(spec.dnn_opt[1]),
                  float(spec.lin_opt[1]), float(spec.lin_opt[2]), float(spec.lin_opt[3]), ptr(bsx["pairs"]), self.max_nnz,
                  bsx["start"].data_ptr() + 4 * self.n_buckets, ptr(bsx["long_list"]), (bsx["long_list"].numel() - 2) // 2, st)
             return

@@ -31,6 +31,8 @@ torch.cuda.synchronize(); t_step = time.time() - t0
 print(json.dumps({"config": "C1 repo-default conf, real rows, batch %d" % bs, "rows": n,
                   "train_examples_per_sec": round(n / t_all, 1),
                   "train_loop_examples_per_sec": round(m.last_train["examples"] / m.last_train["seconds"], 1),
+                  "train_loop_steps": m.last_train["steps"], "train_loop_seconds": round(m.last_train["seconds"], 4),
+                  "train_loop_host_seconds": m.last_train.get("host_seconds"),
                   "checkpoint_restore_save_sec": round(t_all - m.last_train["seconds"], 3),
                   "host_parse_rows_per_sec": round(n / t_parse, 1),
                   "gpu_featurize_rows_per_sec": round(n / t_feat, 1),

@@ -107,7 +107,7 @@ def test_c4_shape_through_conf_path_matches_oracle(tmp_path, monkeypatch, paddin
     assert k == len(lines)
 
 
-@pytest.mark.parametrize("dims", [(16, 4), (8, 8)])
+@pytest.mark.parametrize("dims", [(16, 4), (8, 8), (16, 10), (4, 6), (8, 1)])
 def test_small_table_path_trains_like_the_general_path_and_the_oracle(monkeypatch, dims):
     """Crossed columns (200 / 37 buckets over 2 and 3 multi-hot slots, one of them wide-only) through csrc/small_tables.hip
     (tables in LDS, bags counted, no sort) against the SAME model on the general bucketed path (WD_SMALL_TABLES=0) and against
@@ -133,7 +133,8 @@ def test_small_table_path_trains_like_the_general_path_and_the_oracle(monkeypatc
     monkeypatch.setenv("WD_SMALL_TABLES", "cross")
     eng = WideDeepEngine(spec, max_batch=256, max_nnz=nnz, seed=4)
     # (round 6: the small tables sit in row records of the big columns' width; the general path of `gen` keeps separate tables)
-    assert not gen.small_idx and len(eng.small_idx) == 3 and eng.rec is not None and gen.rec is None
+    # (a cross wider than the big columns does not fit their record: separate tables, dims (4, 6))
+    assert not gen.small_idx and len(eng.small_idx) == 3 and (eng.rec is not None) == (dims[1] <= dims[0]) and gen.rec is None
     ora = oracle_from_engine(eng)
     fz, fzg = Featurizer(eng, cross_padding="ragged"), Featurizer(gen, cross_padding="ragged")
     for step, (raw, hb) in enumerate(parsed):

@@ -23,5 +23,5 @@ hipcc --offload-arch=gfx950 -shared -fPIC "$HERE"/_obj/build_stamp.o "$HERE"/_ob
       "$HERE"/_obj/sparse_update.o "$HERE"/_obj/sparse_fused.o "$HERE"/_obj/small_tables.o "$HERE"/_obj/onehot_path.o "$HERE"/_obj/dist_exchange.o "$HERE"/_obj/mlp.o "$HERE"/_obj/mlp_half.o "$HERE"/_obj/mlp_chain.o "$HERE"/_obj/mlp_chain8.o -o "$OUT/libwd_hip.so"
 echo "built $OUT/libwd_hip.so"
 # host-side TSV ingest (plain C, no GPU code)
-gcc -O2 -fPIC -shared -std=c99 -Wall "$HERE/tsv_ingest.c" -o "$OUT/libwd_ingest.so"
+gcc -O3 -fPIC -shared -std=c99 -Wall "$HERE/tsv_ingest.c" -o "$OUT/libwd_ingest.so"
 echo "built $OUT/libwd_ingest.so"

@@ -38,19 +38,77 @@ static inline int is_na(const uint8_t *p, int64_t n) { return n == 0 || (n == 1 
 /* field boundaries of one line [s, e): fills off[0..nfields] (off[i]..off[i+1]-1 is field i incl. its tab); returns
  * the number of fields found (capped at maxf + 1) */
 static int split_fields(const uint8_t *buf, int64_t s, int64_t e, int64_t *off, int maxf) {
+  /* one pass over the bytes of the line (fields are a few bytes each: a memchr call per field cost more than the scan) */
   int nf = 0;
-  int64_t pos = s;
   off[0] = s;
-  while (pos <= e) {
-    const uint8_t *tab = pos < e ? (const uint8_t *)memchr(buf + pos, '\t', (size_t)(e - pos)) : NULL;
-    int64_t end = tab ? (int64_t)(tab - buf) : e;
-    ++nf;
-    if (nf <= maxf) off[nf] = end + 1;
-    if (!tab) break;
-    pos = end + 1;
-    if (nf > maxf) break;
+  for (int64_t pos = s; pos < e; ++pos) {
+    if (buf[pos] == '\t') {
+      ++nf;
+      if (nf > maxf) return nf;
+      off[nf] = pos + 1;
+    }
   }
+  ++nf;
+  if (nf <= maxf) off[nf] = e + 1;
   return nf;
+}
+
+/* Decimal fields without a library call where that is exact: [sign] digits [. digits] [e [sign] digits] with at most 19
+ * significant digits, mantissa <= 2^53 and |decimal exponent| <= 22 is ONE correctly rounded double operation on two exactly
+ * representable doubles (Clinger's fast path) -- the value strtod returns.  Anything else (longer mantissas, inf / nan / hex,
+ * blanks, stray characters) returns 0 and the caller takes strtod / strtol as before. */
+static const double wd_p10[23] = {1e0,  1e1,  1e2,  1e3,  1e4,  1e5,  1e6,  1e7,  1e8,  1e9,  1e10, 1e11,
+                                  1e12, 1e13, 1e14, 1e15, 1e16, 1e17, 1e18, 1e19, 1e20, 1e21, 1e22};
+
+static int fast_double(const uint8_t *p, int64_t n, double *out) {
+  int64_t i = 0;
+  int neg = 0;
+  if (n <= 0) return 0;
+  if (p[0] == '-' || p[0] == '+') { neg = p[0] == '-'; i = 1; }
+  uint64_t m = 0;
+  int nd = 0, any = 0, e10 = 0;
+  for (; i < n && p[i] >= '0' && p[i] <= '9'; ++i) {
+    any = 1;
+    if (m || p[i] != '0') { if (++nd > 19) return 0; m = m * 10 + (uint64_t)(p[i] - '0'); }
+  }
+  if (i < n && p[i] == '.') {
+    for (++i; i < n && p[i] >= '0' && p[i] <= '9'; ++i) {
+      any = 1;
+      if (m || p[i] != '0') { if (++nd > 19) return 0; m = m * 10 + (uint64_t)(p[i] - '0'); }
+      --e10;
+    }
+  }
+  if (!any) return 0;
+  if (i < n && (p[i] == 'e' || p[i] == 'E')) {
+    int eneg = 0, ev = 0, ed = 0;
+    ++i;
+    if (i < n && (p[i] == '-' || p[i] == '+')) { eneg = p[i] == '-'; ++i; }
+    for (; i < n && p[i] >= '0' && p[i] <= '9'; ++i) { if (++ed > 4) return 0; ev = ev * 10 + (p[i] - '0'); }
+    if (!ed) return 0;
+    e10 += eneg ? -ev : ev;
+  }
+  if (i != n) return 0;
+  if (m == 0) { *out = neg ? -0.0 : 0.0; return 1; }
+  if (m > ((uint64_t)1 << 53) || e10 < -22 || e10 > 22) return 0;
+  double d = (double)m;
+  d = e10 < 0 ? d / wd_p10[-e10] : d * wd_p10[e10];
+  *out = neg ? -d : d;
+  return 1;
+}
+
+static int fast_long(const uint8_t *p, int64_t n, long *out) {
+  int64_t i = 0;
+  int neg = 0;
+  if (n <= 0 || n > 18) return 0;
+  if (p[0] == '-' || p[0] == '+') { neg = p[0] == '-'; i = 1; }
+  if (i == n) return 0;
+  long v = 0;
+  for (; i < n; ++i) {
+    if (p[i] < '0' || p[i] > '9') return 0;
+    v = v * 10 + (p[i] - '0');
+  }
+  *out = neg ? -v : v;
+  return 1;
 }
 
 static inline int64_t line_end(const uint8_t *buf, int64_t s, int64_t e) {
@@ -144,7 +202,10 @@ int wd_tsv_fill(const uint8_t *buf, const int64_t *starts, const int64_t *ends, 
       const uint8_t *p = buf + off[int_cols[f]];
       const int64_t n = off[int_cols[f] + 1] - 1 - off[int_cols[f]];
       int32_t v = 0;
-      if (!is_na(p, n)) {
+      long fl;
+      if (!is_na(p, n) && fast_long(p, n, &fl)) {
+        v = (int32_t)fl;
+      } else if (!is_na(p, n)) {
         char tmp[32];
         if (n >= (int64_t)sizeof(tmp)) { if (err_line) *err_line = i; return WD_TSV_INT; }
         memcpy(tmp, p, (size_t)n);
@@ -161,7 +222,10 @@ int wd_tsv_fill(const uint8_t *buf, const int64_t *starts, const int64_t *ends, 
       const uint8_t *p = buf + off[flt_cols[f]];
       const int64_t n = off[flt_cols[f] + 1] - 1 - off[flt_cols[f]];
       float v = 0.0f;
-      if (!is_na(p, n)) {
+      double fd;
+      if (!is_na(p, n) && fast_double(p, n, &fd)) {
+        v = (float)fd;
+      } else if (!is_na(p, n)) {
         char tmp[64];
         if (n >= (int64_t)sizeof(tmp)) { if (err_line) *err_line = i; return WD_TSV_FLOAT; }
         memcpy(tmp, p, (size_t)n);
@@ -177,7 +241,10 @@ int wd_tsv_fill(const uint8_t *buf, const int64_t *starts, const int64_t *ends, 
       const uint8_t *p = buf + off[label_col];
       const int64_t n = off[label_col + 1] - 1 - off[label_col];
       float y = 0.0f;
-      if (!is_na(p, n)) {
+      long fl;
+      if (!is_na(p, n) && fast_long(p, n, &fl)) {
+        y = fl == 1 ? 1.0f : 0.0f;
+      } else if (!is_na(p, n)) {
         char tmp[32];
         if (n >= (int64_t)sizeof(tmp)) { if (err_line) *err_line = i; return WD_TSV_INT; }
         memcpy(tmp, p, (size_t)n);
@@ -190,7 +257,6 @@ int wd_tsv_fill(const uint8_t *buf, const int64_t *starts, const int64_t *ends, 
       labels[i] = y;
     }
   }
-  for (int f = 0; f < n_str; ++f) (void)0;
   return WD_TSV_OK;
 }
 

@@ -89,6 +89,10 @@ class RawBatch(object):
     def __init__(self, B, cat, ints, floats, labels, weights, tok_bytes=None, tok_offs=None):
         self.B, self.cat, self.ints, self.floats, self.labels, self.weights = B, cat, ints, floats, labels, weights
         self.tok_bytes, self.tok_offs = tok_bytes, tok_offs
+        # the C parser's own arrays, feature-major (features.FixedStage.fill packs a batch from them in a dozen array copies
+        # instead of a handful per feature): {"str": (names, ex_offs [n][B + 1], tok_base [n], ntok [n]), "int": (names, [n][B]),
+        # "flt": (names, [n][B])}, or None (the pure-Python parser)
+        self.packed = None
 
     def lmax(self, feature):
         """Width of the padded [B, Lmax] tensor padded_batch would build for a string feature."""
@@ -145,6 +149,9 @@ class CsvDataset(object):
                 (self._int_feats if c["transform"] == "identity" else self._str_feats).append((f, i))
             else:
                 self._flt_feats.append((f, i))
+        self._str_names = tuple(f for f, _ in self._str_feats)
+        self._int_names = tuple(f for f, _ in self._int_feats)
+        self._flt_names = tuple(f for f, _ in self._flt_feats)
 
     # ---- raw bytes + line index ----------------------------------------------------------------------
     def _load(self):
@@ -209,9 +216,11 @@ class CsvDataset(object):
         tok_offs[T] = NB
         tok_offs[T + 1] = NB
         cat = {f: PackedTokens(tok_bytes, tok_offs, tok_base[j], ntok[j], ex_offs[j]) for j, (f, _) in enumerate(self._str_feats)}
-        return self._finish(B, cat, {f: ints[j] for j, (f, _) in enumerate(self._int_feats)},
-                            {f: flts[j] for j, (f, _) in enumerate(self._flt_feats)}, None if is_pred else labels,
-                            tok_bytes, tok_offs)
+        raw = self._finish(B, cat, {f: ints[j] for j, (f, _) in enumerate(self._int_feats)},
+                           {f: flts[j] for j, (f, _) in enumerate(self._flt_feats)}, None if is_pred else labels,
+                           tok_bytes, tok_offs)
+        raw.packed = {"str": (self._str_names, ex_offs, tok_base, ntok), "int": (self._int_names, ints), "flt": (self._flt_names, flts)}
+        return raw
 
     # ---- parsing: pure Python (cross-check path) -------------------------------------------------------
     def _batch_py(self, buf, starts, ends, is_pred):

@@ -311,6 +311,20 @@ class WideAndDeepClassifier(object):
     def train(self, input_fn, hooks=None, steps=None, max_steps=None, saving_listeners=None):
         it = iter(input_fn())
         n, t_save, t0, seen = 0, time.time(), time.time(), 0
+        # WD_TRAIN_TIMES=1: where the host thread of the loop spends its time (last_train["host_seconds"]: waiting for the parser,
+        # staging a batch, launching its step) -- diagnostics of scripts/bench_c1.py
+        prof = {"parse_wait": 0.0, "stage": 0.0, "launch": 0.0} if os.environ.get("WD_TRAIN_TIMES") == "1" else None
+        if prof is not None:
+            def timed_iter(src):
+                while True:
+                    t = time.perf_counter()
+                    try:
+                        x = next(src)
+                    except StopIteration:
+                        return
+                    prof["parse_wait"] += time.perf_counter() - t
+                    yield x
+            it = timed_iter(it)
         save_secs = self.runconfig.get("save_checkpoints_secs")
         log_every = int(self.runconfig.get("log_step_count_steps") or 0)
         loss = None
@@ -329,7 +343,16 @@ class WideAndDeepClassifier(object):
                 sp, gs = eng.spec, eng.global_step
                 eng.set_learning_rates(dnn=sp.decayed_lr("dnn", gs, eng.lr0["dnn"]) if sp.has_deep else None,
                                        linear=sp.decayed_lr("linear", gs, eng.lr0["linear"]) if sp.has_wide else None)
-            if gstep is not None:
+            if gstep is not None and prof is not None:
+                t1 = time.perf_counter()
+                gstep.stage.fill(raw)
+                t2 = time.perf_counter()
+                gstep.graph.replay()
+                self._engine.global_step += gstep._bump
+                loss = self._engine.loss
+                prof["stage"] += t2 - t1
+                prof["launch"] += time.perf_counter() - t2
+            elif gstep is not None:
                 loss = gstep.step(raw)          # one staged copy + one hipGraph launch: featurizer + train step
                 if n % self._CHECK_EVERY == 0:
                     gstep.check()
@@ -362,6 +385,8 @@ class WideAndDeepClassifier(object):
             self.last_train = {"steps": n, "examples": seen, "seconds": time.time() - t0,
                                "loss": float(loss) if loss is not None else None,
                                "graph_batch_sizes": sorted(b for b, g in self._graph_steps.items() if g)}
+            if prof is not None:
+                self.last_train["host_seconds"] = {k: round(v, 4) for k, v in prof.items()}
             self.save_checkpoint()
         return self
 

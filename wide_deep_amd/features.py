@@ -155,6 +155,13 @@ class FixedStage(object):
         nb, T = len(raw.tok_bytes), len(raw.tok_offs) - 2
         v["bytes"][:nb] = raw.tok_bytes
         v["toffs"][: T + 2] = raw.tok_offs
+        if getattr(raw, "packed", None) is not None:
+            self._fill_packed(raw, v, T)
+            self.dbuf.copy_(self._host[k], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            self._busy[k] = ev
+            return
         for j, f in enumerate(fz.str_feats):
             pc = raw.cat[f]
             v["ex"][j] = pc.ex_offs
@@ -177,6 +184,47 @@ class FixedStage(object):
         ev = torch.cuda.Event()
         ev.record()
         self._busy[k] = ev
+
+
+    def _fill_packed(self, raw, v, T):
+        """`fill` from the C parser's feature-major arrays (dataset.RawBatch.packed): a dozen array copies per batch where the
+        per-feature loop makes ~6 small numpy calls per feature -- 0.54 ms of host time per step on the shipped conf (33 string + 6
+        numeric features) at ANY batch size, which bound `python train.py`'s loop at batch 64-512 (profiles/r6_c1_train_loop.md)."""
+        fz, plan = self.fz, self.fz.plan
+        pk = raw.packed
+        key = (pk["str"][0], pk["int"][0], pk["flt"][0])
+        m = getattr(self, "_pmap", None)
+        if m is None or m[0] != key:
+            sn, inn, fn = {f: j for j, f in enumerate(key[0])}, {f: j for j, f in enumerate(key[1])}, {f: j for j, f in enumerate(key[2])}
+            m = self._pmap = (key,
+                              np.asarray([sn[f] for f in fz.str_feats], dtype=np.int64),
+                              np.asarray([inn[f] for f in fz.int_feats], dtype=np.int64),
+                              np.asarray([fn[f] for f, _ in fz.float_rows], dtype=np.int64),
+                              np.asarray([j for j, (_, log) in enumerate(fz.float_rows) if log], dtype=np.int64),
+                              np.asarray([fn[d.feature] for d in plan.dense_cols], dtype=np.int64))
+        _, si, ii, fi, logrows, di = m
+        _, ex, tok_base, ntok = pk["str"]
+        F = len(si)
+        if F:
+            e = v["ex"][:F]
+            np.take(ex, si, axis=0, out=e)
+            v["base"][:F] = tok_base[si]
+            v["tokn"][:F] = ntok[si]
+            v["lmax"][:F] = (e[:, 1:] - e[:, :-1]).max(axis=1) if self.B else 0
+        v["hdr"][0] = T
+        if len(ii):
+            v["ints"][: len(ii)] = pk["int"][1][ii]
+        if len(fi):
+            x = pk["flt"][1][fi]
+            if len(logrows):
+                x[logrows] = np.log(x[logrows])
+            v["floats"][: len(fi)] = x
+        if "dense" in v:
+            v["dense"][:] = pk["flt"][1][di].T
+        if "lab" in v:
+            v["lab"][:] = raw.labels
+        if "wts" in v:
+            v["wts"][:] = raw.weights
 
 
 class ParsedDeviceBatch(object):

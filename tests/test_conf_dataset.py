@@ -224,6 +224,44 @@ def test_c_ingest_matches_python_parser_and_reports_errors(tmp_path, monkeypatch
         list(DS.CsvDataset(str(bad)).input_fn("eval", 8))
 
 
+def test_c_ingest_decimal_fields_equal_python_float_for_every_spelling(tmp_path, monkeypatch):
+    """Decimal fields of the C parser take a fast path (digits -> one exactly rounded double operation) where that is exact and
+    strtod otherwise: the float / integer columns of rows with awkward spellings -- long mantissas, exponents past the fast
+    path, signs, bare dots, signed zeros, values that overflow float32 -- must equal np.float32(float(s)) / int(s), as before."""
+    assert DS.ingest_lib() is not None
+    schema = Config().read_schema()
+    pos = {v: k - 1 for k, v in schema.items()}
+    conf = Config().read_feature_conf()
+    flt = [f for f in (schema[k] for k in sorted(schema)) if f in conf and conf[f]["type"] != "category"]
+    ints = [f for f in (schema[k] for k in sorted(schema)) if f in conf and conf[f]["type"] == "category" and conf[f]["transform"] == "identity"]
+    assert flt and ints
+    base = open(FIXTURE, "rb").read().splitlines()[0].split(b"\t")
+    spell = [b"0", b"-0", b"-0.0", b"+3", b"3.", b".5", b"-.25", b"1e-3", b"1E3", b"1.5e+2", b"12345.678901", b"0.1", b"0.30000000000000004",
+             b"123456789012345678", b"1234567890123456789012", b"9007199254740993", b"1e22", b"1e23", b"1e-22", b"1e-23", b"4.9e-324",
+             b"1e38", b"3.5e38", b"1e400", b"-1e400", b"00012.50", b"2.2250738585072014e-308", b"0.000000000000000000000000000001",
+             b"16777217", b"1.17549435e-38", b"7e-46", b"6.02214076e23", b"-", b""]
+    lines = []
+    for k, sp in enumerate(spell):
+        parts = list(base)
+        for j, f in enumerate(flt):
+            parts[pos[f]] = spell[(k + j) % len(spell)]
+        for j, f in enumerate(ints):
+            parts[pos[f]] = [b"7", b"-3", b"+12", b"0", b"-", b"007", b"2147483647"][(k + j) % 7]
+        lines.append(b"\t".join(parts))
+    path = tmp_path / "dec.tsv"
+    path.write_bytes(b"\n".join(lines) + b"\n")
+    got_c = list(DS.CsvDataset(str(path)).input_fn("eval", 16))
+    monkeypatch.setattr(DS, "_ingest", False)
+    got_py = list(DS.CsvDataset(str(path)).input_fn("eval", 16))
+    monkeypatch.setattr(DS, "_ingest", None)
+    assert sum(b.B for b in got_c) == len(lines)
+    for c, p in zip(got_c, got_py):
+        for f in p.floats:
+            assert np.array_equal(c.floats[f].view(np.uint32), p.floats[f].view(np.uint32)), (f, c.floats[f], p.floats[f])     # bits: -0.0, inf
+        for f in p.ints:
+            assert np.array_equal(c.ints[f], p.ints[f]), f
+
+
 def test_buffer_shuffle_semantics():
     a = DS._buffer_shuffle(1000, 10000, seed=123)
     assert sorted(a.tolist()) == list(range(1000))                       # fits the buffer: a permutation

@@ -12,6 +12,8 @@ rep = int(os.environ.get("C1_REPEAT", "20"))
 bs = int(os.environ.get("C1_BATCH", "512"))
 lines = open(os.path.join(ROOT, "tests", "golden", "c1_rows.tsv"), "rb").read().splitlines()
 tmp = tempfile.mkdtemp()
+import atexit, shutil
+atexit.register(shutil.rmtree, tmp, True)      # (the model directory holds a 1.3 GB checkpoint per run)
 path = os.path.join(tmp, "train.tsv")
 with open(path, "wb") as f:
     for _ in range(rep):

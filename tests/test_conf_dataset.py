@@ -262,6 +262,31 @@ def test_c_ingest_decimal_fields_equal_python_float_for_every_spelling(tmp_path,
             assert np.array_equal(c.ints[f], p.ints[f]), f
 
 
+def test_raw_batch_packed_arrays_are_the_per_feature_views(tmp_path):
+    """dataset.RawBatch.packed (what features.FixedStage.fill packs a staged batch from, feature-major) holds the same numbers as the
+    per-feature dictionaries every other consumer reads; the pure-Python parser leaves it None."""
+    assert DS.ingest_lib() is not None
+    lines = _with_na_rows(open(FIXTURE, "rb").read().splitlines(), Config().read_schema())
+    path = tmp_path / "rows.tsv"
+    path.write_bytes(b"\n".join(lines) + b"\n")
+    n = 0
+    for raw in DS.CsvDataset(str(path)).input_fn("train", 96):
+        pk = raw.packed
+        assert pk is not None
+        names, ex, base, ntok = pk["str"]
+        assert set(names) == set(raw.cat) and ex.shape == (len(names), raw.B + 1)
+        for j, f in enumerate(names):
+            pc = raw.cat[f]
+            assert np.array_equal(ex[j], pc.ex_offs) and int(base[j]) == pc.base and int(ntok[j]) == pc.n, f
+        for key, d in (("int", raw.ints), ("flt", raw.floats)):
+            names, arr = pk[key]
+            assert set(names) == set(d)
+            for j, f in enumerate(names):
+                assert np.array_equal(arr[j], d[f]), f
+        n += raw.B
+    assert n == len(lines)
+
+
 def test_buffer_shuffle_semantics():
     a = DS._buffer_shuffle(1000, 10000, seed=123)
     assert sorted(a.tolist()) == list(range(1000))                       # fits the buffer: a permutation

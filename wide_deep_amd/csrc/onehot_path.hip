@@ -937,13 +937,24 @@ k_row_update(RowUpd u) {
   if (key_of(prv) == key) return;            // not the first occurrence of its row
   if (key_of(far) == key) return;            // more than ROW_LONG_SEG occurrences: listed by k_bucket_sort, reduced above
   int64_t e = i + 1;
-  if (key_of(nxt) == key) {                  // (sorted: the row's pairs end inside (i + 1, i + ROW_LONG_SEG])
-    int64_t lo = i + 2, hi = i + ROW_LONG_SEG < nnz ? i + ROW_LONG_SEG : nnz;
-    while (lo < hi) {
-      const int64_t mid = (lo + hi) >> 1;
-      if (key_of(u.pairs[mid]) == key) lo = mid + 1; else hi = mid;
+  uint32_t mybag[ROW_LONG_SEG / 4];
+  if (key_of(nxt) == key) {
+    // sorted: the row's pairs end inside (i + 1, i + ROW_LONG_SEG].  The group's four lanes load the ROW_LONG_SEG pairs from i on
+    // in ONE round (lane gl: i + gl, + 4, ...) and count the ones that carry the key -- a prefix; the bag indices the gradient
+    // rounds below need arrive with them.  (Rounds 3-5: a binary search, five dependent round trips per row with more than one
+    // occurrence before its first gradient row was requested: with skewed ids a third of the rows.)
+    int cnt = 0;
+#pragma unroll
+    for (int k = 0; k < ROW_LONG_SEG / 4; ++k) {
+      const int64_t idx = i + gl + 4 * k;
+      const uint64_t p = idx < nnz ? u.pairs[idx] : ~0ull;
+      const bool mine = key_of(p) == key;
+      mybag[k] = mine ? (uint32_t)p : 0u;
+      cnt += mine ? 1 : 0;
     }
-    e = lo;
+    cnt += __shfl_xor(cnt, 1, 64);
+    cnt += __shfl_xor(cnt, 2, 64);
+    e = i + cnt;
   }
   const int32_t bag0 = (int32_t)(uint32_t)pr;
   const int32_t sidx = bag0 % S;
@@ -976,18 +987,12 @@ k_row_update(RowUpd u) {
     }
     if (gl == 0) gw += u.dlogit[b * u.ld_dl];
   } else {
-    // 2 .. 32 occurrences: their bag indices in ONE round of loads (lane gl of the group takes pairs i + gl, + 4, ...; a bag
-    // travels to the other lanes by shuffle), then four gradient rows per round -- 1 + ceil(n / 4) dependent round trips
-    // instead of two per occurrence for the remainder of a count that is not a multiple of four; the adds keep ascending bag
-    // order (bit-identical sums)
+    // 2 .. 32 occurrences: their bag indices arrived with the count above (lane gl of the group holds pairs i + gl, + 4, ...; a bag
+    // travels to the other lanes by shuffle), then four gradient rows per round -- 1 + ceil(n / 4) dependent round trips (eight
+    // per round cost the launch its occupancy: slower with uniform and with skewed ids); the adds keep ascending bag order
+    // (bit-identical sums)
     const int n = (int)(e - i);
     const int l0 = (t & 63) & ~3;
-    uint32_t mybag[ROW_LONG_SEG / 4];
-#pragma unroll
-    for (int k = 0; k < ROW_LONG_SEG / 4; ++k) {
-      const int64_t idx = i + gl + 4 * k;
-      mybag[k] = idx < e ? (uint32_t)u.pairs[idx] : 0u;
-    }
 #pragma unroll
     for (int c = 0; c < ROW_LONG_SEG / 4; ++c) {
       if (4 * c >= n) break;

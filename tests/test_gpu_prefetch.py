@@ -210,3 +210,73 @@ def test_chained_graphs_are_bit_identical(kw, B, dist):
     torch.cuda.synchronize()
     _state_equal(a, b, "chain entered in the middle / after an eager step")
     assert a.global_step == b.global_step
+
+
+@pytest.mark.parametrize("ragged", [False, True])
+def test_row_update_counts_a_rows_occurrences_at_every_boundary(ragged):
+    """k_row_update finds how often a row occurs from ONE round of loads behind its first sorted position (the four lanes load the
+    next 32 pairs and count the key's prefix): rows with exactly 1, 2, 3, 4, 5, 31, 32 (the last one the flat part takes), 33 and 70
+    (the long-row list) occurrences, the rows with the largest keys included -- their pairs end the sorted list, so the count must stop
+    at the list's end -- against the oracle: one-id bags through the pipelined graph (wd_row_update + patch of the next batch) and
+    ragged bags through eager steps (wd_row_update_ragged)."""
+    from tests.helpers import assert_close, oracle_batch, oracle_from_engine
+    from wide_deep_amd import synth
+    from wide_deep_amd.pipeline import StepGraph, step_eager
+    from wide_deep_amd.plan import criteo_spec
+    B, S, NB = 256, 6, 400
+    spec = criteo_spec(n_dense=16, n_sparse=S, buckets=NB, dim=8, hidden=(64, 32))
+    eng = _engine(spec, B)
+    assert eng.rec is not None and eng.prefetch
+    counts = [1, 2, 3, 4, 5, 31, 32, 33, 70]
+
+    def host_batch(seed):
+        rng = np.random.default_rng(seed)
+        lens = np.ones((B, S), dtype=np.int64)
+        if ragged:
+            lens[rng.random((B, S)) < 0.3] = 2
+        nnz = int(lens.sum())
+        slot_of = np.repeat(np.tile(np.arange(S), B), lens.reshape(-1))
+        raw = np.empty(nnz, dtype=np.int64)
+        for s in range(S):
+            pos = np.flatnonzero(slot_of == s)
+            rng.shuffle(pos)
+            # the LAST rows of the slot (for the last slot: the largest keys of the whole sorted list) take the boundary counts,
+            # the other occurrences fall on distinct low rows
+            k = 0
+            for j, c in enumerate(counts):
+                raw[pos[k: k + c]] = NB - 1 - j
+                k += c
+            rest = pos[k:]
+            raw[rest] = np.arange(len(rest)) % (NB - len(counts))
+        return {"B": B, "lens": lens, "raw": raw, "dense": rng.standard_normal((B, 16)).astype(np.float32),
+                "labels": (rng.random(B) < 0.4).astype(np.float32)}
+
+    hbs = [host_batch(7 + i) for i in range(3)]
+    tbs = [synth.FeaturizedBatch(synth.to_device_ids(eng.plan, hb), hb) for hb in hbs]
+    assert all(tb.batch.one_hot == (not ragged) for tb in tbs)
+    ora = oracle_from_engine(eng)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        step_eager(eng, tbs[0], ids_input=True)
+        if ragged:
+            for tb in tbs[1:]:
+                step_eager(eng, tb, ids_input=True)
+    torch.cuda.synchronize()
+    if ragged:
+        bs = eng._bucket_sets[0]
+        assert bs["sorted"] and bs.get("ragged")                       # the flat ragged update ran
+    else:
+        g = StepGraph(eng, tbs[1:3], ids_input=True, stream=side)       # gather a step ahead, flat update + patch
+        assert g.pipelined and any(b["sorted"] for b in eng._bucket_sets)
+        g.replay()
+        torch.cuda.synchronize()
+    for hb, tb in zip(hbs, tbs):
+        ora.train_step(oracle_batch(eng.plan, tb.batch.ids.cpu().numpy().astype(np.int64), synth.offsets_from_lens(hb["lens"]), B,
+                                    hb["dense"], hb["labels"]))
+    st, so = eng.export_state(), ora.state
+    n = 0
+    for k in st:
+        if st[k].dtype.is_floating_point and k in so:
+            assert_close(st[k], so[k], 5e-4, 2e-5, k)
+            n += 1
+    assert n >= 2 * S
